@@ -1,0 +1,377 @@
+/* oracle/pgp_oracle.c -- CPU restatement of the reference's scoring path.  TEST INFRASTRUCTURE
+ * ONLY (see pgp_oracle.h for the parity status and the import rule).
+ *
+ * Every float operation below is written as a separately-rounded C expression in the exact
+ * order Eigen 3.3.90 evaluates the corresponding reference expression on x86-64/SSE2 (pinned
+ * empirically against oracle/_ref, see tests/test_oracle_vs_ref.py).  Build with
+ * -ffp-contract=off (oracle/Makefile) so no FMA is formed.
+ */
+#include "pgp_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define KD_MAX_DEPTH 32       /* kdtree.h:60 */
+#define KD_POINT_PER_CELL 64  /* kdtree.h:63 */
+
+/* ---- elementary expressions ------------------------------------------------------------- */
+
+void orc_transform_point(const float T[16], const float q[3], float out[3]) {
+  for (int r = 0; r < 3; ++r) {
+    float a = T[0 + r] * q[0];
+    float b = T[4 + r] * q[1];
+    float c = T[8 + r] * q[2];
+    float s = a + b;
+    s = s + c;
+    out[r] = s + T[12 + r];
+  }
+}
+
+void orc_rotate_normal(const float T[16], const float n[3], float out[3]) {
+  for (int r = 0; r < 3; ++r) {
+    float a = T[0 + r] * n[0];
+    float b = T[4 + r] * n[1];
+    float c = T[8 + r] * n[2];
+    float bc = b + c;
+    out[r] = a + bc;
+  }
+}
+
+float orc_sqdist(const float a[3], const float b[3]) {
+  float dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+  float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+  float t = yy + zz;
+  return xx + t;
+}
+
+float orc_dot(const float a[3], const float b[3]) {
+  float x = a[0] * b[0], y = a[1] * b[1], z = a[2] * b[2];
+  float t = y + z;
+  return x + t;
+}
+
+int orc_normal_gate(float dot, float gate_deg) {
+  /* base.cc:1756: float angle_n = std::acos(<float>)*180/M_PI;  -> acosf, float*int->float,
+   * then / (double)M_PI in double, narrowed to float on assignment. */
+  float ac = acosf(dot);
+  float ac180 = ac * 180.0f;
+  float angle_n = (float)((double)ac180 / M_PI);
+  /* base.cc:1757: std::min(angle_n, fabs(180-angle_n)) -- all float (SURVEY hazard 5).
+   * std::min(a,b) = (b < a) ? b : a, so a NaN angle_n stays NaN. */
+  float other = fabsf(180.0f - angle_n);
+  float m = (other < angle_n) ? other : angle_n;
+  return m < gate_deg; /* NaN -> false (hazard 4) */
+}
+
+/* ---- kd-tree (kdtree.h) ------------------------------------------------------------------ */
+
+typedef struct {
+  int leaf;
+  /* internal */
+  float splitValue;
+  int firstChildId;
+  int dim;
+  /* leaf */
+  int start;
+  int size;
+} kd_node;
+
+struct orc_kdtree {
+  float* pts; /* reordered copy, n x 3 (mPoints) */
+  int* idx;   /* original ids (mIndices) */
+  int n;
+  kd_node* nodes;
+  int n_nodes, cap_nodes;
+};
+
+static int kd_push_node(orc_kdtree* t) {
+  if (t->n_nodes == t->cap_nodes) {
+    t->cap_nodes = t->cap_nodes ? 2 * t->cap_nodes : 64;
+    t->nodes = (kd_node*)realloc(t->nodes, sizeof(kd_node) * (size_t)t->cap_nodes);
+  }
+  kd_node* nd = &t->nodes[t->n_nodes];
+  memset(nd, 0, sizeof(*nd));
+  return t->n_nodes++;
+}
+
+static void kd_swap(orc_kdtree* t, int a, int b) {
+  float tmp[3];
+  memcpy(tmp, t->pts + 3 * a, sizeof tmp);
+  memcpy(t->pts + 3 * a, t->pts + 3 * b, sizeof tmp);
+  memcpy(t->pts + 3 * b, tmp, sizeof tmp);
+  int ti = t->idx[a];
+  t->idx[a] = t->idx[b];
+  t->idx[b] = ti;
+}
+
+/* kdtree.h:522-538 */
+static int kd_split(orc_kdtree* t, int start, int end, int dim, float splitValue) {
+  int l = start, r = end - 1;
+  for (; l < r; ++l, --r) {
+    while (l < end && t->pts[3 * l + dim] < splitValue) l++;
+    while (r >= start && t->pts[3 * r + dim] >= splitValue) r--;
+    if (l > r) break;
+    kd_swap(t, l, r);
+  }
+  if (l >= end) return l; /* the reference would read one past the range here (UB) */
+  return (t->pts[3 * l + dim] < splitValue) ? l + 1 : l;
+}
+
+/* kdtree.h:560-641 */
+static void kd_create(orc_kdtree* t, int nodeId, int start, int end, int level) {
+  float mn[3] = {FLT_MAX / 2, FLT_MAX / 2, FLT_MAX / 2};      /* bbox.h:63-64 */
+  float mx[3] = {-FLT_MAX / 2, -FLT_MAX / 2, -FLT_MAX / 2};
+  for (int i = start; i < end; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float v = t->pts[3 * i + k];
+      if (v < mn[k]) mn[k] = v; /* bbox.h:73-75: select(q < min, q, min) */
+      if (v > mx[k]) mx[k] = v;
+    }
+  float diag[3];
+  for (int k = 0; k < 3; ++k) diag[k] = 0.5f * (mx[k] - mn[k]);
+  int dim = 0; /* Eigen maxCoeff(&dim): first strict maximum */
+  for (int k = 1; k < 3; ++k)
+    if (diag[k] > diag[dim]) dim = k;
+  float splitValue = mn[dim] + ((mx[dim] - mn[dim]) / 2.0f); /* bbox.h:88-89 center() */
+
+  t->nodes[nodeId].dim = dim;
+  t->nodes[nodeId].splitValue = splitValue;
+  int midId = kd_split(t, start, end, dim, splitValue);
+
+  int first = kd_push_node(t);
+  kd_push_node(t);
+  t->nodes[nodeId].firstChildId = first;
+
+  if ((unsigned)(midId - start) <= KD_POINT_PER_CELL || level >= KD_MAX_DEPTH) {
+    t->nodes[first].leaf = 1;
+    t->nodes[first].start = start;
+    t->nodes[first].size = midId - start; /* reference narrows to unsigned short (kdtree.h:155) */
+  } else {
+    t->nodes[first].leaf = 0;
+    kd_create(t, first, start, midId, level + 1);
+  }
+  if ((unsigned)(end - midId) <= KD_POINT_PER_CELL || level >= KD_MAX_DEPTH) {
+    t->nodes[first + 1].leaf = 1;
+    t->nodes[first + 1].start = midId;
+    t->nodes[first + 1].size = end - midId;
+  } else {
+    t->nodes[first + 1].leaf = 0;
+    kd_create(t, first + 1, midId, end, level + 1);
+  }
+}
+
+orc_kdtree* orc_kd_build(const float* xyz, int n) {
+  orc_kdtree* t = (orc_kdtree*)calloc(1, sizeof(*t));
+  t->n = n;
+  t->pts = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+  t->idx = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  memcpy(t->pts, xyz, sizeof(float) * 3 * (size_t)n);
+  for (int i = 0; i < n; ++i) t->idx[i] = i;
+  int root = kd_push_node(t); /* kdtree.h:362-363: one node, leaf = 0 */
+  t->nodes[root].leaf = 0;
+  kd_create(t, 0, 0, n, 1); /* kdtree.h:367 */
+  return t;
+}
+
+void orc_kd_free(orc_kdtree* t) {
+  if (!t) return;
+  free(t->pts);
+  free(t->idx);
+  free(t->nodes);
+  free(t);
+}
+
+int orc_kd_num_nodes(const orc_kdtree* t) { return t->n_nodes; }
+
+/* kdtree.h:394-459 */
+int orc_kd_query(const orc_kdtree* t, const float q[3], float sqdist) {
+  struct { int nodeId; float sq; } stack[64];
+  int cl_id = -1;
+  float cl_dist = sqdist;
+  stack[0].nodeId = 0;
+  stack[0].sq = 0.f;
+  unsigned count = 1;
+  while (count) {
+    int top = (int)count - 1;
+    const kd_node* node = &t->nodes[stack[top].nodeId];
+    if (stack[top].sq < cl_dist) {
+      if (node->leaf) {
+        --count;
+        const int end = node->start + node->size;
+        for (int i = node->start; i < end; ++i) {
+          const float d = orc_sqdist(q, t->pts + 3 * i);
+          if (d <= cl_dist) { /* inclusive; a later equal distance replaces the earlier */
+            cl_dist = d;
+            cl_id = t->idx[i];
+          }
+        }
+      } else {
+        const float new_off = q[node->dim] - node->splitValue;
+        if (new_off < 0.) {
+          stack[count].nodeId = node->firstChildId;
+          stack[top].nodeId = node->firstChildId + 1;
+        } else {
+          stack[count].nodeId = node->firstChildId + 1;
+          stack[top].nodeId = node->firstChildId;
+        }
+        stack[count].sq = stack[top].sq;
+        stack[top].sq = new_off * new_off;
+        ++count;
+      }
+    } else {
+      --count;
+    }
+  }
+  return cl_id;
+}
+
+int orc_brute_query(const float* xyz, int n, const float q[3], float sqdist) {
+  int best = -1;
+  float bd = sqdist;
+  for (int i = 0; i < n; ++i) {
+    float d = orc_sqdist(q, xyz + 3 * i);
+    if (best < 0 ? d <= bd : d < bd) {
+      bd = d;
+      best = i;
+    }
+  }
+  return best;
+}
+
+/* ---- Verify / WeightedVerify ------------------------------------------------------------- */
+
+static int nn_query(const orc_kdtree* kd, const float* P_xyz, int nP, const float q[3], float sq) {
+  return kd ? orc_kd_query(kd, q, sq) : orc_brute_query(P_xyz, nP, q, sq);
+}
+
+float orc_verify(const orc_kdtree* kd, const float* P_xyz, int nP, const float* Q_xyz, int nQ,
+                 const float T[16], float delta, float best_lcp, int early_out,
+                 int* good_out, int* hit_ids) {
+  const float epsilon = delta;
+  int good_points = 0;
+  const size_t number_of_points = (size_t)nQ;
+  const int terminate_value = (int)(best_lcp * number_of_points); /* float * size_t -> float -> int */
+  const float sq_eps = epsilon * epsilon;
+  for (int i = 0; i < nQ; ++i) {
+    float x[3];
+    orc_transform_point(T, Q_xyz + 3 * i, x);
+    int resId = nn_query(kd, P_xyz, nP, x, sq_eps);
+    if (hit_ids) hit_ids[i] = resId;
+    if (resId != -1) good_points++;
+    /* base.cc:1725: size_t arithmetic, compared with an int promoted to size_t */
+    if (early_out && (number_of_points - (size_t)i + (size_t)good_points) < (size_t)terminate_value) break;
+  }
+  if (good_out) *good_out = good_points;
+  return (float)good_points / (float)number_of_points;
+}
+
+float orc_weighted_verify(const orc_kdtree* kd, const float* P_xyz, const float* P_nrm,
+                          const float* P_w, int nP, const float* Q_xyz, const float* Q_nrm, int nQ,
+                          const float T[16], float delta, float gate_deg,
+                          int* registered, int* n_registered) {
+  const float sq_eps = delta * delta;
+  float weighted_match = 0;
+  int nreg = 0;
+  for (int i = 0; i < nQ; ++i) {
+    float x[3];
+    orc_transform_point(T, Q_xyz + 3 * i, x);
+    int resId = nn_query(kd, P_xyz, nP, x, sq_eps);
+    if (resId != -1) {
+      float n_q[3];
+      orc_rotate_normal(T, Q_nrm + 3 * i, n_q);
+      float d = orc_dot(P_nrm + 3 * resId, n_q);
+      if (orc_normal_gate(d, gate_deg)) {
+        weighted_match += P_w ? P_w[resId] : 1.0f;
+        if (registered) registered[nreg] = resId;
+        nreg++;
+      }
+    }
+  }
+  if (n_registered) *n_registered = nreg;
+  return weighted_match / (float)(size_t)nQ;
+}
+
+void orc_score_batch(const orc_kdtree* kd, const float* P_xyz, const float* P_nrm, const float* P_w,
+                     int nP, const float* Q_xyz, const float* Q_nrm, int nQ,
+                     const float* T, int n_h, float delta, int mode, float gate_deg,
+                     int early_out, int threads,
+                     float* scores, int* best_index, int* selected, int* n_selected) {
+  if (mode == 0 && early_out) {
+    /* order-dependent: strictly serial, as base.cc:1888-1901 */
+    float best = 0.f;
+    int bi = -1, ns = 0;
+    for (int h = 0; h < n_h; ++h) {
+      float lcp = orc_verify(kd, P_xyz, nP, Q_xyz, nQ, T + 16 * (size_t)h, delta, best, 1, NULL, NULL);
+      scores[h] = lcp;
+      if (lcp > best) {
+        best = lcp;
+        bi = h;
+        if (selected) selected[ns] = h;
+        ns++;
+      }
+    }
+    if (best_index) *best_index = bi;
+    if (n_selected) *n_selected = ns;
+    return;
+  }
+  if (threads < 1) threads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads)
+#endif
+  for (int h = 0; h < n_h; ++h) {
+    const float* Th = T + 16 * (size_t)h;
+    if (mode == 0)
+      scores[h] = orc_verify(kd, P_xyz, nP, Q_xyz, nQ, Th, delta, 0.f, 0, NULL, NULL);
+    else
+      scores[h] = orc_weighted_verify(kd, P_xyz, P_nrm, P_w, nP, Q_xyz, Q_nrm, nQ, Th, delta,
+                                      gate_deg, NULL, NULL);
+  }
+  float best = 0.f; /* base.cc:308 best_LCP_ = 0.0 */
+  int bi = -1, ns = 0;
+  for (int h = 0; h < n_h; ++h) {
+    if (scores[h] > best) {
+      best = scores[h];
+      bi = h;
+      if (selected) selected[ns] = h;
+      ns++;
+    }
+  }
+  if (best_index) *best_index = bi;
+  if (n_selected) *n_selected = ns;
+}
+
+/* ---- init(): centring (base.cc:242-268) -------------------------------------------------- */
+
+void orc_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int nQv,
+                float centroid_P[3], float centroid_Q[3]) {
+  float cP[3] = {0, 0, 0}, cQ[3] = {0, 0, 0};
+  for (int i = 0; i < nP; ++i)
+    for (int k = 0; k < 3; ++k) cP[k] += P_xyz[3 * i + k];
+  for (int k = 0; k < 3; ++k) cP[k] /= (float)nP;
+  for (int i = 0; i < nQs; ++i)
+    for (int k = 0; k < 3; ++k) cQ[k] += Qs_xyz[3 * i + k];
+  for (int k = 0; k < 3; ++k) cQ[k] /= (float)nQs;
+  for (int i = 0; i < nP; ++i)
+    for (int k = 0; k < 3; ++k) P_xyz[3 * i + k] -= cP[k];
+  for (int i = 0; i < nQs; ++i)
+    for (int k = 0; k < 3; ++k) Qs_xyz[3 * i + k] -= cQ[k];
+  for (int i = 0; i < nQv; ++i)
+    for (int k = 0; k < 3; ++k) Qv_xyz[3 * i + k] -= cQ[k];
+  for (int k = 0; k < 3; ++k) {
+    centroid_P[k] = cP[k];
+    centroid_Q[k] = cQ[k];
+  }
+}
+
+int orc_max_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

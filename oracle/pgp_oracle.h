@@ -1,0 +1,91 @@
+/* oracle/pgp_oracle.h -- CPU restatement of the reference's pose-hypothesis scoring path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load this library; the product (physimglobalpose_amd/, include/pgp.h) never does.
+ *
+ * Parity status: PARTIALLY PINNED.
+ *   - nearest-neighbour query + kd-tree build: pinned bit-for-bit (returned index, including
+ *     ties) against the reference's own kdtree.h compiled here (oracle/_ref, `make ref`);
+ *   - Verify / WeightedVerify / rigid fit: the reference translation unit (match4pcsBase.cc)
+ *     needs OpenCV + boost, absent from this image => unbuildable without stand-ins.  Their loop
+ *     bodies are restated in oracle/ref_harness.cc on the reference's vendored Eigen (so the
+ *     float evaluation order is Eigen's) and THIS file is pinned bit-for-bit against that.
+ *   - The reference ships no golden vectors for the path.
+ *
+ * Citations: S4 = /root/reference/src/3rdparty/super4pcs/src/super4pcs, base.cc =
+ * S4/algorithms/match4pcsBase.cc.
+ *
+ * Conventions: clouds are n x 3 row-major float; a transform is the reference's
+ * Eigen::Matrix<float,4,4> memory image = 16 floats COLUMN-major (element (r,c) at [4*c+r]),
+ * i.e. exactly one entry of `allTransforms` (base.cc:1468).
+ */
+#ifndef PGP_ORACLE_H
+#define PGP_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_kdtree orc_kdtree;
+
+/* S4/accelerators/kdtree.h:355-370 (finalize), :522-538 (split), :560-641 (createTree);
+ * 64 points per leaf, max depth 32 (kdtree.h:60-63). */
+orc_kdtree* orc_kd_build(const float* xyz, int n);
+void orc_kd_free(orc_kdtree* t);
+int orc_kd_num_nodes(const orc_kdtree* t);
+/* S4/accelerators/kdtree.h:394-459 (doQueryRestrictedClosestIndex): index of the closest point
+ * with d2 <= sqdist (inclusive), -1 if none. Re-entrant (stack is local, unlike kdtree.h:311). */
+int orc_kd_query(const orc_kdtree* t, const float q[3], float sqdist);
+/* Semantic definition of the same query by exhaustive scan; ties -> lowest index. */
+int orc_brute_query(const float* xyz, int n, const float q[3], float sqdist);
+
+/* (mat * q.homogeneous()).head<3>() with Eigen's evaluation order (base.cc:1718,1750):
+ * out_r = ((m_r0*q0 + m_r1*q1) + m_r2*q2) + m_r3, every operation rounded to float. */
+void orc_transform_point(const float T[16], const float q[3], float out[3]);
+/* mat.block<3,3>(0,0) * n (base.cc:1755): out_r = m_r0*n0 + (m_r1*n1 + m_r2*n2). */
+void orc_rotate_normal(const float T[16], const float n[3], float out[3]);
+/* (a-b).squaredNorm() (kdtree.h:423): dx*dx + (dy*dy + dz*dz). */
+float orc_sqdist(const float a[3], const float b[3]);
+/* a.dot(b) (base.cc:1756): a0*b0 + (a1*b1 + a2*b2). */
+float orc_dot(const float a[3], const float b[3]);
+/* The normal gate of base.cc:1756-1758 as a predicate on the dot product:
+ * a = (float)((double)(acosf(d)*180.f)/M_PI); a = fminf(a, fabsf(180.f-a)); return a < gate. */
+int orc_normal_gate(float dot, float gate_deg);
+
+/* base.cc:1699-1731 (Verify).  use_nn: 0 = kd-tree (kd != NULL), 1 = brute force over P_xyz.
+ * early_out != 0 keeps the reference's termination test against best_lcp (base.cc:1708,1725).
+ * hit_ids (nullable, nQ ints) receives the NN index per model point (-1 = no inlier; entries
+ * after an early-out are left untouched).  Returns good/nQ as float; *good_out = count. */
+float orc_verify(const orc_kdtree* kd, const float* P_xyz, int nP, const float* Q_xyz, int nQ,
+                 const float T[16], float delta, float best_lcp, int early_out,
+                 int* good_out, int* hit_ids);
+
+/* base.cc:1733-1766 (WeightedVerify).  registered (nullable, capacity nQ) receives the P ids
+ * in model-point order, *n_registered their number.  gate_deg = 30 in the reference. */
+float orc_weighted_verify(const orc_kdtree* kd, const float* P_xyz, const float* P_nrm,
+                          const float* P_w, int nP, const float* Q_xyz, const float* Q_nrm, int nQ,
+                          const float T[16], float delta, float gate_deg,
+                          int* registered, int* n_registered);
+
+/* base.cc:1885-1901 (verification loop of Perform_N_steps) over n_h transforms, no early-out
+ * for mode 1 (weighted, the live operMode=1) and -- unless early_out is set -- none for mode 0
+ * either (equal work per hypothesis).  scores[n_h]; *best_index = the index that
+ * last satisfied `lcp > best` (strict), -1 if none; selected/n_selected (nullable) = the
+ * running-best subsequence of base.cc:1903-1908.  threads > 1 splits hypotheses over OpenMP
+ * threads (only legal without early-out; the bookkeeping is then replayed serially). */
+void orc_score_batch(const orc_kdtree* kd, const float* P_xyz, const float* P_nrm, const float* P_w,
+                     int nP, const float* Q_xyz, const float* Q_nrm, int nQ,
+                     const float* T, int n_h, float delta, int mode, float gate_deg,
+                     int early_out, int threads,
+                     float* scores, int* best_index, int* selected, int* n_selected);
+
+/* base.cc:242-268 (init): centre P on centroid(P); Q_search and Q_val on centroid(Q_search). */
+void orc_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int nQv,
+                float centroid_P[3], float centroid_Q[3]);
+
+int orc_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

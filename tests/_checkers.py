@@ -1,0 +1,205 @@
+"""ctypes bindings to the CHECKERS: oracle/liboracle.so (our C restatement) and, when built,
+oracle/_ref/libpgp_ref.so (harness over the reference's own kd-tree + Eigen).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libpgp_ref.so")
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+_d = C.POINTER(C.c_double)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(_f)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(_i)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+
+
+def build_oracle():
+    """Compile the C restatement if missing or stale (gcc, < 1 s)."""
+    src = os.path.join(ORACLE_DIR, "pgp_oracle.c")
+    if (not os.path.exists(ORACLE_SO)) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return ORACLE_SO
+
+
+_oracle = None
+
+
+def oracle_lib():
+    global _oracle
+    if _oracle is None:
+        L = C.CDLL(build_oracle())
+        L.orc_kd_build.restype = C.c_void_p
+        L.orc_kd_build.argtypes = [_f, C.c_int]
+        L.orc_kd_free.argtypes = [C.c_void_p]
+        L.orc_kd_num_nodes.argtypes = [C.c_void_p]
+        L.orc_kd_query.argtypes = [C.c_void_p, _f, C.c_float]
+        L.orc_brute_query.argtypes = [_f, C.c_int, _f, C.c_float]
+        L.orc_transform_point.argtypes = [_f, _f, _f]
+        L.orc_rotate_normal.argtypes = [_f, _f, _f]
+        L.orc_sqdist.restype = C.c_float
+        L.orc_sqdist.argtypes = [_f, _f]
+        L.orc_dot.restype = C.c_float
+        L.orc_dot.argtypes = [_f, _f]
+        L.orc_normal_gate.argtypes = [C.c_float, C.c_float]
+        L.orc_verify.restype = C.c_float
+        L.orc_verify.argtypes = [C.c_void_p, _f, C.c_int, _f, C.c_int, _f, C.c_float, C.c_float,
+                                 C.c_int, _i, _i]
+        L.orc_weighted_verify.restype = C.c_float
+        L.orc_weighted_verify.argtypes = [C.c_void_p, _f, _f, _f, C.c_int, _f, _f, C.c_int, _f,
+                                          C.c_float, C.c_float, _i, _i]
+        L.orc_score_batch.argtypes = [C.c_void_p, _f, _f, _f, C.c_int, _f, _f, C.c_int, _f, C.c_int,
+                                      C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, _f, _i, _i, _i]
+        L.orc_center.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]
+        _oracle = L
+    return _oracle
+
+
+class Oracle:
+    """The C restatement bound to one (P, Q_val) pair.  use_kd=False -> brute-force NN."""
+
+    def __init__(self, P_xyz, P_nrm, P_w, Q_xyz, Q_nrm, use_kd=True):
+        self.L = oracle_lib()
+        self.P = _f32(P_xyz)
+        self.Pn = _f32(P_nrm)
+        self.Pw = _f32(P_w)
+        self.Q = _f32(Q_xyz)
+        self.Qn = _f32(Q_nrm)
+        self.nP, self.nQ = self.P.shape[0], self.Q.shape[0]
+        self.kd = self.L.orc_kd_build(_fp(self.P), self.nP) if use_kd else None
+
+    def __del__(self):
+        if getattr(self, "kd", None):
+            self.L.orc_kd_free(self.kd)
+            self.kd = None
+
+    def kd_query(self, q, sqdist):
+        q = _f32(q)
+        return self.L.orc_kd_query(self.kd, _fp(q), C.c_float(sqdist))
+
+    def brute_query(self, q, sqdist):
+        q = _f32(q)
+        return self.L.orc_brute_query(_fp(self.P), self.nP, _fp(q), C.c_float(sqdist))
+
+    def verify(self, T16, delta, best_lcp=0.0, early_out=False):
+        T16 = _f32(T16)
+        good = C.c_int(0)
+        hits = np.full(self.nQ, -2, dtype=np.int32)
+        s = self.L.orc_verify(self.kd, _fp(self.P), self.nP, _fp(self.Q), self.nQ, _fp(T16),
+                              C.c_float(delta), C.c_float(best_lcp), int(early_out),
+                              C.byref(good), _ip(hits))
+        return float(np.float32(s)), good.value, hits
+
+    def weighted_verify(self, T16, delta, gate_deg=30.0):
+        T16 = _f32(T16)
+        reg = np.zeros(max(self.nQ, 1), dtype=np.int32)
+        n = C.c_int(0)
+        s = self.L.orc_weighted_verify(self.kd, _fp(self.P), _fp(self.Pn), _fp(self.Pw), self.nP,
+                                       _fp(self.Q), _fp(self.Qn), self.nQ, _fp(T16),
+                                       C.c_float(delta), C.c_float(gate_deg), _ip(reg), C.byref(n))
+        return float(np.float32(s)), reg[: n.value].copy()
+
+    def score_batch(self, T, delta, mode=0, gate_deg=30.0, early_out=False, threads=1):
+        T = _f32(T).reshape(-1, 16)
+        n_h = T.shape[0]
+        scores = np.zeros(n_h, dtype=np.float32)
+        best = C.c_int(-1)
+        sel = np.zeros(max(n_h, 1), dtype=np.int32)
+        nsel = C.c_int(0)
+        self.L.orc_score_batch(self.kd, _fp(self.P), _fp(self.Pn), _fp(self.Pw), self.nP,
+                               _fp(self.Q), _fp(self.Qn), self.nQ, _fp(T), n_h, C.c_float(delta),
+                               int(mode), C.c_float(gate_deg), int(early_out), int(threads),
+                               _fp(scores), C.byref(best), _ip(sel), C.byref(nsel))
+        return scores, best.value, sel[: nsel.value].copy()
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+_ref = None
+
+
+def ref_lib():
+    global _ref
+    if _ref is None:
+        L = C.CDLL(REF_SO)
+        L.ref_create.restype = C.c_void_p
+        L.ref_create.argtypes = [_f, _f, _f, C.c_int, _f, _f, C.c_int]
+        L.ref_destroy.argtypes = [C.c_void_p]
+        L.ref_get_normals.argtypes = [C.c_void_p, C.c_int, _f]
+        L.ref_center.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]
+        L.ref_kd_query.argtypes = [C.c_void_p, _f, C.c_float]
+        L.ref_verify.restype = C.c_float
+        L.ref_verify.argtypes = [C.c_void_p, _f, C.c_float, C.c_float, C.c_int, _i, _i]
+        L.ref_weighted_verify.restype = C.c_float
+        L.ref_weighted_verify.argtypes = [C.c_void_p, _f, C.c_float, _i, _i]
+        L.ref_transform_point.argtypes = [_f, _f, _f]
+        L.ref_rotate_normal.argtypes = [_f, _f, _f]
+        L.ref_sqdist.restype = C.c_float
+        L.ref_sqdist.argtypes = [_f, _f]
+        L.ref_dot.restype = C.c_float
+        L.ref_dot.argtypes = [_f, _f]
+        L.ref_rigid_from_pair.argtypes = [_f, _f, _f, _f, _f, _d, _f]
+        _ref = L
+    return _ref
+
+
+class Ref:
+    """The reference's own kd-tree (+ Eigen-order loop bodies) bound to one (P, Q_val) pair.
+    Only usable in the build container (needs oracle/_ref built from /root/reference)."""
+
+    def __init__(self, P_xyz, P_nrm, P_w, Q_xyz, Q_nrm):
+        self.L = ref_lib()
+        self.P, self.Q = _f32(P_xyz), _f32(Q_xyz)
+        self.nP, self.nQ = self.P.shape[0], self.Q.shape[0]
+        Pn, Qn, Pw = _f32(P_nrm), _f32(Q_nrm), _f32(P_w)
+        self.h = self.L.ref_create(_fp(self.P), _fp(Pn), _fp(Pw), self.nP, _fp(self.Q), _fp(Qn), self.nQ)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_destroy(self.h)
+            self.h = None
+
+    def normals(self, which):
+        n = self.nQ if which else self.nP
+        out = np.zeros((n, 3), dtype=np.float32)
+        self.L.ref_get_normals(self.h, which, _fp(out))
+        return out
+
+    def kd_query(self, q, sqdist):
+        q = _f32(q)
+        return self.L.ref_kd_query(self.h, _fp(q), C.c_float(sqdist))
+
+    def verify(self, T16, delta, best_lcp=0.0, early_out=False):
+        T16 = _f32(T16)
+        good = C.c_int(0)
+        hits = np.full(self.nQ, -2, dtype=np.int32)
+        s = self.L.ref_verify(self.h, _fp(T16), C.c_float(delta), C.c_float(best_lcp),
+                              int(early_out), C.byref(good), _ip(hits))
+        return float(np.float32(s)), good.value, hits
+
+    def weighted_verify(self, T16, delta):
+        T16 = _f32(T16)
+        reg = np.zeros(max(self.nQ, 1), dtype=np.int32)
+        n = C.c_int(0)
+        s = self.L.ref_weighted_verify(self.h, _fp(T16), C.c_float(delta), _ip(reg), C.byref(n))
+        return float(np.float32(s)), reg[: n.value].copy()
