@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- pose hypotheses/sec LCP-scored (BASELINE.json metric) on MI355X.
+
+A "step" = one pass of the hot path over one batch: every rank LCP-scores its shard of
+hypotheses (C2: 4096 per GPU, 5 000-pt model vs 50 000-pt scene, plain LCP = the reference's
+Verify without early-out) with the clouds, the index and the transforms already resident in HBM,
+then (N > 1) the per-hypothesis scores are combined with one RCCL all-reduce and the arg-max is
+taken.  value = hypotheses all ranks scored / max-over-ranks wall time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode plain|weighted]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the round prompt): metric/value/unit/... plus
+"roofline" (dominant kernel, algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak) and
+"cpu_baseline" (the CPU oracle timed on this box's host cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+N_SCENE, N_MODEL, N_HYP = 50000, 5000, 4096   # BASELINE.json configs[1] (C2)
+
+
+def algorithmic_bytes_per_hypothesis(n_scene, n_model, mode):
+    """plain 12|Q|+12|P|+52, weighted 24|Q|+28|P|+52."""
+    if mode == "plain":
+        return 12 * n_model + 12 * n_scene + 52
+    return 24 * n_model + 28 * n_scene + 52
+
+
+def cpu_baseline(w, mode, budget_s=12.0):
+    """Time the CPU oracle (kd-tree restatement of the reference path) on this box's cores."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _checkers import Oracle, oracle_lib
+    cores = int(oracle_lib().orc_max_threads())
+    orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+    m = 0 if mode == "plain" else 1
+    # calibrate on 256 hypotheses, then size the sample for ~budget_s of wall time
+    t0 = time.perf_counter()
+    orc.score_batch(w.T[:256], w.delta, mode=m, gate_deg=w.gate_deg, threads=cores)
+    rate = 256 / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(max(rate * budget_s, 256), 64 * len(w.T)))
+    reps = -(-n // len(w.T))
+    T = np.concatenate([w.T] * reps)[:n]
+    t0 = time.perf_counter()
+    orc.score_batch(T, w.delta, mode=m, gate_deg=w.gate_deg, threads=cores)
+    dt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    n1 = max(64, min(512, int(rate / max(cores, 1) * 3)))
+    orc.score_batch(w.T[:n1], w.delta, mode=m, gate_deg=w.gate_deg, threads=1)
+    dt1 = time.perf_counter() - t0
+    return {
+        "value": n / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
+        "sample": f"{n} hypotheses of the same C2 batch (cycled), kd-tree oracle "
+                  f"(oracle/pgp_oracle.c, OpenMP x{cores}), {dt:.1f} s",
+        "one_thread_value": n1 / dt1,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["plain", "weighted"], default="plain")
+    ap.add_argument("--hyp", type=int, default=N_HYP, help="hypotheses per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
+
+    mode = PGP_MODE_PLAIN if args.mode == "plain" else PGP_MODE_WEIGHTED
+    n_h = args.hyp
+    # every rank builds the same scene/model (replicated) and takes its own slice of
+    # a world*n_h hypothesis batch (weak scaling: per-GPU work fixed)
+    w = synth.make_workload(N_SCENE, N_MODEL, n_h * world, config_id=2)
+    sc = LcpScorer(local_rank)
+    t0 = time.perf_counter()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    sc.reserve(n_h)
+    T_all = torch.from_numpy(w.T).to(dev)
+    d_T = T_all[rank * n_h:(rank + 1) * n_h].contiguous()
+    d_scores_all = torch.zeros(world * n_h, dtype=torch.float32, device=dev)
+    d_scores = d_scores_all[rank * n_h:(rank + 1) * n_h]
+    d_counts = torch.zeros(n_h, dtype=torch.int32, device=dev)
+    d_best = torch.zeros(2, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        if world > 1:
+            d_scores_all.zero_()
+        sc.score_device(d_T, d_scores, d_counts, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
+        if world > 1:
+            # every rank filled only its slice of a zeroed vector: sum == gather (north_star:
+            # "RCCL all-reduce over xGMI of the per-hypothesis LCP scores"), then local arg-max
+            dist.all_reduce(d_scores_all, op=dist.ReduceOp.SUM)
+            torch.argmax(d_scores_all)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    sc.set_kernel_timing(True)
+    sc.kernel_timing(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches, kern_ms = sc.kernel_timing(reset=True)
+    sc.set_kernel_timing(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # sanity inside the bench: the device result of the last step matches a host-pointer call
+    best = d_best.cpu().numpy()
+    s_host, _, bi_host, _ = sc.score(w.T[rank * n_h:(rank + 1) * n_h], mode, w.gate_deg)
+    assert np.array_equal(s_host, d_scores.cpu().numpy()) and bi_host == int(best[0])
+
+    if rank == 0:
+        total_h = n_h * world * args.steps
+        value = total_h / dt
+        B_h = algorithmic_bytes_per_hypothesis(N_SCENE, N_MODEL, args.mode)
+        kern_avg_ms = kern_ms / max(launches, 1)
+        achieved = B_h * n_h / (kern_avg_ms * 1e-3) / 1e9 if launches else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"score_hypotheses_{args.mode}_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "pose hypotheses/sec LCP-scored (50k-pt scene x 5k-pt model)",
+            "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2 (BASELINE.json configs[1]): 1 object, 5000-pt model vs "
+                                   "50000-pt synthetic scene, 4096 hypotheses per GPU per step, "
+                                   f"{args.mode} LCP, delta 5 mm",
+                       "n_scene": N_SCENE, "n_model": N_MODEL, "hypotheses_per_gpu": n_h,
+                       "mode": args.mode, "sharding": f"hypotheses x{world}, clouds replicated"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": f"score_hypotheses<{args.mode}>", "launches": launches,
+                         "avg_kernel_ms": kern_avg_ms, "algorithmic_bytes_per_hypothesis": B_h},
+            "index": sc.index_info(), "cold_setup_ms": cold_ms,
+            "best_index": int(best[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(w, args.mode)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+/* include/pgp.h -- C ABI of the MI355X-native pose-hypothesis scoring path (libpgp.so).
+ *
+ * This is the drop-in boundary for the hot path of cmitash/PhysimGlobalPose: everything the
+ * reference computes between "a list of candidate transforms exists" and "every candidate has an
+ * LCP score and the best one is known" (S4/algorithms/match4pcsBase.cc:1885-1901, with
+ * S4 = src/3rdparty/super4pcs/src/super4pcs), plus the steps either side of it as they are
+ * added (rigid fit from congruent pairs, ICP refinement).  Plain pointers and sizes only.
+ *
+ * Frames and layouts are the reference's own, so its containers can be passed without copies:
+ *   - a cloud is n x 3 row-major float (pos() of each Point3D, S4/shared4pcs.h:61-111);
+ *   - a transform is the memory image of Eigen::Matrix<float,4,4>: 16 floats, COLUMN-major
+ *     (element (r,c) at [4*c + r]); `allTransforms.data()` (base.cc:1468) is such an array;
+ *   - scoring happens in the CENTRED frames of Match4PCSBase::init (base.cc:242-268): the scene
+ *     cloud minus centroid_P, the validation model minus centroid_Q.  pgp_center() does that.
+ *
+ * Every function returns 0 on success or a negative PGP_E* code; pgp_last_error() then holds a
+ * message for the calling thread.  A context is bound to one HIP device; calls on one context
+ * must not overlap (the reference is single-threaded: main.cpp:212), distinct contexts are
+ * independent.  There is NO CPU fallback: without a usable HIP device pgp_create() fails.
+ */
+#ifndef PGP_H
+#define PGP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pgp_ctx pgp_ctx;
+
+enum {
+  PGP_OK = 0,
+  PGP_EINVAL = -1,   /* bad argument (null pointer, negative size, NaN delta ...) */
+  PGP_ENODEV = -2,   /* no usable HIP device / runtime error at create */
+  PGP_EHIP = -3,     /* a HIP call failed */
+  PGP_ESTATE = -4,   /* scene / model / index not set for this call */
+  PGP_ENOMEM = -5
+};
+
+/* Scoring mode: which reference verifier is reproduced. */
+enum {
+  PGP_MODE_PLAIN = 0,    /* Match4PCSBase::Verify, base.cc:1699-1731, WITHOUT the early-out
+                            (every hypothesis gets its true inlier count) */
+  PGP_MODE_WEIGHTED = 1  /* Match4PCSBase::WeightedVerify, base.cc:1733-1766 (live operMode=1) */
+};
+
+int pgp_version(void);
+const char* pgp_last_error(void);
+
+/* Replaces the construction of the per-call MatchSuper4PCS object (S4/super4pcs_test.cc:102).
+ * device_id < 0 selects the current HIP device. */
+int pgp_create(pgp_ctx** out, int device_id);
+int pgp_destroy(pgp_ctx* ctx);
+
+/* Replaces Match4PCSBase::init's centring loop (base.cc:242-268): in place, float arithmetic in
+ * the reference's order.  P is centred on centroid(P); Qs (search model) and Qv (validation
+ * model) on centroid(Qs).  Pure host helper (O(n)); any of the clouds may be empty. */
+int pgp_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int nQv,
+               float centroid_P[3], float centroid_Q[3]);
+
+/* Replaces `sampled_P_3D_ = P` + initKdTree() + orig_probabilities_ (base.cc:235,270,1046-1056,
+ * 327-340): uploads the (centred) scene cloud and builds the device spatial index for inlier
+ * radius `delta` (options_.delta, S4/super4pcs_test.cc:20).  nrm and weight may be NULL
+ * (weights default to 1; PGP_MODE_WEIGHTED then needs normals and fails without them).
+ * Host pointers, synchronous. */
+int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float* weight, int n,
+                  float delta);
+
+/* Replaces `validation_Q_3D = Q_validation` (base.cc:237).  Host pointers, synchronous. */
+int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n);
+
+/* Replaces the verification loop of Perform_N_steps (base.cc:1885-1901) for n_h transforms.
+ *   scores[n_h]     : lcp per hypothesis (inliers / nQ, or weighted sum / nQ), as allPose[i].second
+ *   counts[n_h]     : (nullable) integer inlier count per hypothesis (for weighted mode: the
+ *                     number of registered points)
+ *   best_index      : (nullable) what best_lcp_index ends as: the lowest index attaining the
+ *                     maximum score if that maximum is > 0, else -1 (base.cc:1891,309)
+ *   best_score      : (nullable) best_LCP_
+ * gate_deg is the normal-agreement gate of base.cc:1758 (30 in the reference; ignored in plain
+ * mode).  Host pointers, synchronous. */
+int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_deg,
+                  float* scores, int* counts, int* best_index, float* best_score);
+
+/* Same computation with DEVICE pointers, enqueued on `stream` (a hipStream_t; NULL = default
+ * stream) and not synchronised: for callers that keep the hypothesis batch resident (bench.py,
+ * multi-GPU sharding).  d_best (nullable) receives 2 ints: {best_index, float bits of best
+ * score}.  No allocation happens inside when n_h <= the capacity reserved by
+ * pgp_reserve(); otherwise PGP_ESTATE. */
+int pgp_reserve(pgp_ctx* ctx, int max_hypotheses);
+int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
+                         float* d_scores, int* d_counts, int* d_best, void* stream);
+
+/* Replaces `registered_indices = temp_registered_indices` (base.cc:1897): the scene-point ids
+ * matched under ONE transform, in model-point order.  ids has capacity nQ; *n receives the
+ * count.  In plain mode every inlier's nearest scene point is reported. */
+int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int* ids, int* n);
+
+/* Running-best subsequence of base.cc:1891-1908 over a score vector (host helper): writes the
+ * indices i with scores[i] > max(scores[0..i-1], 0) to selected (capacity n_h). */
+int pgp_running_best(const float* scores, int n_h, int* selected, int* n_selected);
+
+/* Introspection for DESIGN.md / bench.py: sizes of the device index of the current scene. */
+typedef struct {
+  int n_scene, n_model;
+  int grid_nx, grid_ny, grid_nz;
+  float cell_size, delta;
+  long long n_cells, n_candidates;      /* entries in the dilated per-cell candidate lists */
+  long long bytes_index;                /* bitmap + cell offsets + candidate lists */
+  float build_ms;                       /* device time of the last index build */
+} pgp_index_info;
+int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info);
+
+/* Per-kernel timing for bench.py's roofline line: when enabled, every pgp_score_lcp[_device]
+ * call brackets its dominant kernel (score_hypotheses) with a pair of HIP events on the SAME
+ * stream it is launched on.  pgp_get_kernel_timing synchronises those events and returns the
+ * number of bracketed launches and the sum of their durations since the last reset. */
+int pgp_set_kernel_timing(pgp_ctx* ctx, int enable);
+int pgp_get_kernel_timing(pgp_ctx* ctx, int* launches, float* total_ms, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGP_H */

@@ -1,0 +1,74 @@
+"""ctypes binding of libpgp.so (include/pgp.h).  Fails loudly when the HIP library is missing:
+there is no Python, torch or CPU fallback for any entry point."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpgp.so")
+
+PGP_MODE_PLAIN = 0
+PGP_MODE_WEIGHTED = 1
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("n_scene", C.c_int), ("n_model", C.c_int),
+                ("grid_nx", C.c_int), ("grid_ny", C.c_int), ("grid_nz", C.c_int),
+                ("cell_size", C.c_float), ("delta", C.c_float),
+                ("n_cells", C.c_longlong), ("n_candidates", C.c_longlong),
+                ("bytes_index", C.c_longlong), ("build_ms", C.c_float)]
+
+
+# every symbol include/pgp.h declares: (restype, argtypes)
+SIGNATURES = {
+    "pgp_version": (C.c_int, []),
+    "pgp_last_error": (C.c_char_p, []),
+    "pgp_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
+    "pgp_destroy": (C.c_int, [C.c_void_p]),
+    "pgp_center": (C.c_int, [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]),
+    "pgp_set_scene": (C.c_int, [C.c_void_p, _f, _f, _f, C.c_int, C.c_float]),
+    "pgp_set_model": (C.c_int, [C.c_void_p, _f, _f, C.c_int]),
+    "pgp_score_lcp": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_int, C.c_float, _f, _i, _i, _f]),
+    "pgp_reserve": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgp_score_lcp_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgp_registered": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _i, _i]),
+    "pgp_running_best": (C.c_int, [_f, C.c_int, _i, _i]),
+    "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),
+    "pgp_get_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libpgp.so and bind every declared symbol; raises if the library or a symbol is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: build it with `make -C physimglobalpose_amd/csrc` "
+            "(or __graft_entry__.build()); there is no fallback path")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class PgpError(RuntimeError):
+    pass
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().pgp_last_error()
+        raise PgpError(f"libpgp error {rc}: {msg.decode() if msg else '?'}")

@@ -1,0 +1,292 @@
+// csrc/grid_index.hip -- device spatial index over the scene cloud.
+//
+// Replaces Match4PCSBase::initKdTree (S4/algorithms/match4pcsBase.cc:1046-1056) and the kd-tree
+// it builds (S4/accelerators/kdtree.h:355-370,560-641).  The reference answers "nearest scene
+// point within delta of x" by a stack-driven kd-tree walk (kdtree.h:394-459); a data-dependent
+// tree walk per lane is the wrong shape for 64-wide wavefronts, so the device index is a uniform
+// grid with DILATED per-cell candidate lists:
+//
+//   cell(x)      = floor((x - origin) * inv_h), h >= delta
+//   cand(c)      = every scene point within `reach` = delta + margin of the box of cell c
+//   bitmap       = 1 bit per cell: cand(c) non-empty           (L2-resident: 0.9 MB at C2)
+//   cell_start   = CSR offsets into one float4 array {x,y,z,bits(id)} of all candidate lists
+//
+// A query is then: one bitmap word, (if set) two offsets, one contiguous float4 run -- no
+// neighbour-cell gather, no tree.  Exactness: the scoring kernel applies the reference's float
+// test d2 <= delta^2 (kdtree.h:423-424) to every candidate; the dilation margin (see
+// choose_grid) covers the float rounding of cell(x), so cand(cell(x)) is a superset of the
+// scene points that pass the test for x.  The result equals an exhaustive scan.
+//
+// HBM layout: 27 copies of each point on average (h = delta) = 21.6 MB at |P| = 50 k; the index
+// trades capacity (288 GB) for one-run locality.
+
+#include "pgp_internal.h"
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+namespace pgp {
+
+namespace {
+
+constexpr int kMaxDim = 1024;                  // cells per axis
+constexpr long long kMaxCells = 1LL << 28;     // 268 M cells (1 GiB of offsets) hard cap
+
+__device__ __forceinline__ float box_dist2(float px, float lo, float h) {
+  // squared distance from coordinate px to the interval [lo, lo+h]
+  float a = lo - px;
+  float b = px - (lo + h);
+  float d = fmaxf(fmaxf(a, b), 0.f);
+  return d * d;
+}
+
+// One thread per scene point: visit the (2r+1)^3 cells around its own cell; for each whose box
+// is within `reach`, either count it (FILL=false) or append the point to the cell's list.
+template <bool FILL>
+__global__ __launch_bounds__(256) void scatter_points(GridDesc g, int r, const float4* __restrict__ P,
+                                                      int nP, uint32_t* __restrict__ cell_ctr,
+                                                      const uint32_t* __restrict__ cell_start,
+                                                      float4* __restrict__ cand) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nP) return;
+  float4 p = P[i];
+  float fx = (p.x - g.ox) * g.inv_h, fy = (p.y - g.oy) * g.inv_h, fz = (p.z - g.oz) * g.inv_h;
+  if (!(fx >= 0.f && fx < (float)g.nx && fy >= 0.f && fy < (float)g.ny && fz >= 0.f && fz < (float)g.nz))
+    return;  // NaN / inf points can never be inliers (d2 <= eps is false for NaN)
+  int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+  float reach2 = g.reach * g.reach;
+  for (int dz = -r; dz <= r; ++dz) {
+    int z = cz + dz;
+    if (z < 0 || z >= g.nz) continue;
+    float ez = box_dist2(p.z, g.oz + (float)z * g.h, g.h);
+    for (int dy = -r; dy <= r; ++dy) {
+      int y = cy + dy;
+      if (y < 0 || y >= g.ny) continue;
+      float ey = box_dist2(p.y, g.oy + (float)y * g.h, g.h);
+      for (int dx = -r; dx <= r; ++dx) {
+        int x = cx + dx;
+        if (x < 0 || x >= g.nx) continue;
+        float ex = box_dist2(p.x, g.ox + (float)x * g.h, g.h);
+        if (ex + ey + ez > reach2) continue;
+        size_t c = ((size_t)z * g.ny + y) * g.nx + x;
+        uint32_t slot = atomicAdd(&cell_ctr[c], 1u);
+        if (FILL) cand[cell_start[c] + slot] = p;
+      }
+    }
+  }
+}
+
+// ---- exclusive scan over uint32 (3 passes) ----
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__global__ __launch_bounds__(kScanThreads) void scan_tiles(const uint32_t* __restrict__ in,
+                                                           uint32_t* __restrict__ out, size_t n,
+                                                           uint32_t* __restrict__ tile_sums) {
+  __shared__ uint32_t s_wave[kScanThreads / 64];
+  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t v[kScanItems];
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? in[base + k] : 0u;
+    sum += v[k];
+  }
+  // inclusive scan of `sum` across the wave, then across the 4 waves
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t incl = sum;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t t = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+  uint32_t excl = wave_off + incl - sum;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n) out[base + k] = excl;
+    excl += v[k];
+  }
+  if (threadIdx.x == kScanThreads - 1) tile_sums[blockIdx.x] = wave_off + incl;
+}
+
+__global__ __launch_bounds__(1024) void scan_tile_sums(uint32_t* __restrict__ tile_sums, int n_tiles) {
+  // single block: sequential over chunks of 1024, carry in a shared word
+  __shared__ uint32_t s_wave[16];
+  __shared__ uint32_t s_carry;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int base = 0; base < n_tiles; base += 1024) {
+    int i = base + threadIdx.x;
+    uint32_t v = (i < n_tiles) ? tile_sums[i] : 0u;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += s_wave[w];
+    uint32_t carry = s_carry;
+    if (i < n_tiles) tile_sums[i] = carry + wave_off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kScanThreads) void scan_add_offsets(uint32_t* __restrict__ out, size_t n,
+                                                                 const uint32_t* __restrict__ tile_sums) {
+  size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
+  uint32_t off = tile_sums[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n) out[base + k] += off;
+}
+
+__global__ __launch_bounds__(256) void make_bitmap(GridDesc g, const uint32_t* __restrict__ cell_start,
+                                                   uint32_t* __restrict__ bitmap, size_t n_words) {
+  size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  size_t row = w / g.nxw;  // = z*ny + y
+  int xw = (int)(w - row * g.nxw);
+  uint32_t bits = 0;
+  size_t c0 = row * g.nx + (size_t)xw * 32;
+  int lim = min(32, g.nx - xw * 32);
+  for (int b = 0; b < lim; ++b)
+    if (cell_start[c0 + b + 1] > cell_start[c0 + b]) bits |= (1u << b);
+  bitmap[w] = bits;
+}
+
+// Choose cell size, origin and dims for a bounding box and a radius.
+int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, int* r_out) {
+  float ext[3], maxext = 0.f, maxabs = 0.f;
+  for (int k = 0; k < 3; ++k) {
+    ext[k] = mx[k] - mn[k];
+    maxext = fmaxf(maxext, ext[k]);
+    maxabs = fmaxf(maxabs, fmaxf(fabsf(mn[k]), fabsf(mx[k])));
+  }
+  // h slightly above delta so that reach = delta + margin <= h and the dilation is one ring
+  // (r = 1, 27 cells); h grows further only to keep the grid within kMaxDim / kMaxCells
+  // (h >= delta stays exact: r is always computed from reach / h).
+  float h = delta * 1.02f;
+  for (int iter = 0; iter < 200; ++iter) {
+    // margin: rounding of cell(x) is <= ~4 ulp of (x-origin)*inv_h (value up to kMaxDim) plus
+    // the ulp of the coordinates themselves; 0.4 % of a cell + 64 ulp(extent) covers it.
+    float margin = 0.004f * h + 1e-6f * (float)kMaxDim * h + 64.f * FLT_EPSILON * (maxabs + maxext);
+    float reach = delta * (1.f + 4.f * FLT_EPSILON) + margin;
+    int r = (int)ceilf(reach / h);
+    if (r < 1) r = 1;
+    // origin one dilation ring (+1 cell) outside the box so that every position within reach of
+    // a point has a valid cell; a position outside the grid is farther than delta from all of P.
+    float pad = (float)(r + 1) * h;
+    g->h = h;
+    g->inv_h = 1.0f / h;
+    g->reach = reach;
+    g->ox = mn[0] - pad;
+    g->oy = mn[1] - pad;
+    g->oz = mn[2] - pad;
+    double nx = floor((double)(mx[0] - g->ox) / h) + r + 2;
+    double ny = floor((double)(mx[1] - g->oy) / h) + r + 2;
+    double nz = floor((double)(mx[2] - g->oz) / h) + r + 2;
+    if (nx <= kMaxDim && ny <= kMaxDim && nz <= kMaxDim && nx * ny * nz <= (double)kMaxCells) {
+      g->nx = (int)nx;
+      g->ny = (int)ny;
+      g->nz = (int)nz;
+      g->nxw = (g->nx + 31) / 32;
+      *r_out = r;
+      return PGP_OK;
+    }
+    h *= 1.25f;
+  }
+  set_error("scene extent %.3g m cannot be gridded for delta %.3g", maxext, delta);
+  return PGP_EINVAL;
+}
+
+}  // namespace
+
+int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
+  const int nP = ctx->nP;
+  hipStream_t st = ctx->stream;
+  ctx->has_index = false;
+
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  int finite = 0;
+  for (int i = 0; i < nP; ++i) {
+    const float* p = h_xyz + 3 * (size_t)i;
+    if (!(std::isfinite(p[0]) && std::isfinite(p[1]) && std::isfinite(p[2]))) continue;
+    ++finite;
+    for (int k = 0; k < 3; ++k) {
+      mn[k] = fminf(mn[k], p[k]);
+      mx[k] = fmaxf(mx[k], p[k]);
+    }
+  }
+  if (finite == 0) {
+    for (int k = 0; k < 3; ++k) mn[k] = mx[k] = 0.f;
+  }
+  GridDesc g{};
+  int r = 1;
+  int rc = choose_grid(mn, mx, delta, &g, &r);
+  if (rc != PGP_OK) return rc;
+  const size_t n_cells = (size_t)g.nx * g.ny * g.nz;
+  const size_t n_scan = n_cells + 1;
+  const int n_tiles = (int)((n_scan + kScanTile - 1) / kScanTile);
+  const size_t n_words = (size_t)g.nz * g.ny * g.nxw;
+
+  if ((rc = ctx->d_cell_start.ensure(n_scan * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cell_tmp.ensure(n_scan * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure((size_t)n_tiles * 4 + 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_bitmap.ensure(n_words * 4)) != PGP_OK) return rc;
+
+  hipEvent_t e0, e1;
+  PGP_HIP(hipEventCreate(&e0));
+  PGP_HIP(hipEventCreate(&e1));
+  PGP_HIP(hipEventRecord(e0, st));
+
+  uint32_t* ctr = ctx->d_cell_tmp.as<uint32_t>();
+  uint32_t* start = ctx->d_cell_start.as<uint32_t>();
+  PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
+  const int pb = (nP + 255) / 256;
+  if (nP > 0)
+    hipLaunchKernelGGL(scatter_points<false>, dim3(pb), dim3(256), 0, st, g, r,
+                       ctx->d_P.as<float4>(), nP, ctr, (const uint32_t*)nullptr, (float4*)nullptr);
+  hipLaunchKernelGGL(scan_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, ctr, start, n_scan,
+                     ctx->d_scan_tmp.as<uint32_t>());
+  hipLaunchKernelGGL(scan_tile_sums, dim3(1), dim3(1024), 0, st, ctx->d_scan_tmp.as<uint32_t>(), n_tiles);
+  hipLaunchKernelGGL(scan_add_offsets, dim3(n_tiles), dim3(kScanThreads), 0, st, start, n_scan,
+                     ctx->d_scan_tmp.as<uint32_t>());
+  PGP_HIP(hipGetLastError());
+  uint32_t total = 0;
+  PGP_HIP(hipMemcpyAsync(&total, start + n_cells, 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  if ((rc = ctx->d_cand.ensure(((size_t)total + 1) * sizeof(float4))) != PGP_OK) return rc;
+  PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
+  if (nP > 0)
+    hipLaunchKernelGGL(scatter_points<true>, dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(),
+                       nP, ctr, start, ctx->d_cand.as<float4>());
+  hipLaunchKernelGGL(make_bitmap, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g, start,
+                     ctx->d_bitmap.as<uint32_t>(), n_words);
+  PGP_HIP(hipGetLastError());
+  PGP_HIP(hipEventRecord(e1, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  PGP_HIP(hipEventElapsedTime(&ctx->build_ms, e0, e1));
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+
+  ctx->grid = g;
+  ctx->n_cells = (long long)n_cells;
+  ctx->n_cand = (long long)total;
+  ctx->delta = delta;
+  ctx->has_index = true;
+  return PGP_OK;
+}
+
+}  // namespace pgp

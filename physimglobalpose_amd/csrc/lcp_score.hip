@@ -1,0 +1,451 @@
+// csrc/lcp_score.hip -- batched LCP scoring of pose hypotheses on gfx950.
+//
+// Replaces, for a whole batch of transforms at once:
+//   Match4PCSBase::Verify          S4/algorithms/match4pcsBase.cc:1699-1731  (PGP_MODE_PLAIN)
+//   Match4PCSBase::WeightedVerify  S4/algorithms/match4pcsBase.cc:1733-1766  (PGP_MODE_WEIGHTED)
+//   the verification loop + best bookkeeping of Perform_N_steps  :1885-1901
+//   KdTree::doQueryRestrictedClosestIndex  S4/accelerators/kdtree.h:394-459  (via grid_index.hip)
+//
+// Mapping to the machine
+//   lane            = one validation-model point (kept in VGPRs for the whole block: it is
+//                     re-used by every hypothesis of the block's chunk, so it never needs LDS)
+//   workgroup       = 256 model points (4 wave64) x a chunk of `hpb` hypotheses
+//   hypothesis      = wave-uniform: its 4x4 is read with scalar loads (one 64 B line) and lives
+//                     in SGPRs; the transform is 9 mul + 9 add per lane, no contraction
+//   inlier count    = __ballot + popcount per wave, 4 wave totals combined in LDS in fixed order,
+//                     one (tile, hypothesis) partial per block, summed by finalize_scores in tile
+//                     order => no atomics on the data path, bit-reproducible run to run
+//   block -> (chunk, tile) is XCD-aware: blocks that share blockIdx%8 (one XCD, one L2) work on
+//                     the same hypothesis chunks, so the cells those poses touch stay in that L2.
+//
+// Float parity: every arithmetic expression that decides an inlier is evaluated in the order
+// Eigen evaluates it in the reference (pinned in oracle/, tests/test_oracle_vs_ref.py), each
+// operation rounded separately (__fmul_rn/__fadd_rn; the file is also built -ffp-contract=off):
+//   x'_r = ((m_r0*q0 + m_r1*q1) + m_r2*q2) + m_r3          (mat * q.homogeneous()).head<3>()
+//   d2   = dx*dx + (dy*dy + dz*dz),  inlier iff d2 <= delta*delta    kdtree.h:423-424
+//   n'_r = m_r0*n0 + (m_r1*n1 + m_r2*n2)                    mat.block<3,3>(0,0) * normal
+//   dot  = a0*b0 + (a1*b1 + a2*b2)
+// The acos/fold/<30 gate of base.cc:1756-1758 is monotone in the dot product, so it is applied
+// as two thresholds found by bisection over the host libm's acosf (gate_thresholds): no device
+// transcendental can disagree with the host at the gate boundary.
+
+#include "pgp_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace pgp {
+
+namespace {
+
+constexpr int kTile = 256;    // model points per workgroup
+constexpr int kMaxHpb = 64;   // hypotheses per workgroup (LDS partial slots)
+
+struct Xf {  // one hypothesis, wave-uniform (SGPRs)
+  float m00, m10, m20, m01, m11, m21, m02, m12, m22, m03, m13, m23;
+};
+
+__device__ __forceinline__ Xf load_xf(const float* __restrict__ T, int h) {
+  const float4* c = reinterpret_cast<const float4*>(T + 16 * (size_t)h);  // column-major 4x4
+  float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+  Xf x;
+  x.m00 = c0.x; x.m10 = c0.y; x.m20 = c0.z;
+  x.m01 = c1.x; x.m11 = c1.y; x.m21 = c1.z;
+  x.m02 = c2.x; x.m12 = c2.y; x.m22 = c2.z;
+  x.m03 = c3.x; x.m13 = c3.y; x.m23 = c3.z;
+  return x;
+}
+
+__device__ __forceinline__ float xf_row(float a, float b, float c, float t, float q0, float q1, float q2) {
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, q0), __fmul_rn(b, q1)), __fmul_rn(c, q2)), t);
+}
+
+__device__ __forceinline__ float rot_row(float a, float b, float c, float n0, float n1, float n2) {
+  return __fadd_rn(__fmul_rn(a, n0), __fadd_rn(__fmul_rn(b, n1), __fmul_rn(c, n2)));
+}
+
+__device__ __forceinline__ float sqdist(float x, float y, float z, float4 p) {
+  float dx = __fsub_rn(x, p.x), dy = __fsub_rn(y, p.y), dz = __fsub_rn(z, p.z);
+  return __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
+}
+
+// Cell lookup: returns the candidate run [s, e) for position (x,y,z); empty if outside the grid
+// or the bitmap says the cell has no candidates.
+__device__ __forceinline__ void cell_run(const GridDesc& g, const uint32_t* __restrict__ bitmap,
+                                         const uint32_t* __restrict__ cell_start, float x, float y,
+                                         float z, uint32_t* s, uint32_t* e) {
+  float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
+  *s = 0;
+  *e = 0;
+  if (fx >= 0.f && fx < (float)g.nx && fy >= 0.f && fy < (float)g.ny && fz >= 0.f && fz < (float)g.nz) {
+    int cx = (int)fx, cy = (int)fy, cz = (int)fz;
+    size_t row = (size_t)cz * g.ny + cy;
+    uint32_t word = bitmap[row * g.nxw + (cx >> 5)];
+    if ((word >> (cx & 31)) & 1u) {
+      size_t c = row * g.nx + cx;
+      *s = cell_start[c];
+      *e = cell_start[c + 1];
+    }
+  }
+}
+
+// Nearest candidate with d2 <= sq_eps; ties -> lowest scene index (the reference's tie rule
+// depends on kd-tree leaf order, kdtree.h:424; ties are measure-zero on real data).
+__device__ __forceinline__ int nearest_in_run(const float4* __restrict__ cand, uint32_t s, uint32_t e,
+                                              float x, float y, float z, float sq_eps) {
+  float best = sq_eps;
+  int bid = -1;
+  for (uint32_t j = s; j < e; ++j) {
+    float4 p = cand[j];
+    float d2 = sqdist(x, y, z, p);
+    int id = __float_as_int(p.w);
+    if (d2 < best || (d2 == best && (bid < 0 || id < bid))) {
+      best = d2;
+      bid = id;
+    }
+  }
+  return bid;
+}
+
+__device__ __forceinline__ bool any_in_run(const float4* __restrict__ cand, uint32_t s, uint32_t e,
+                                           float x, float y, float z, float sq_eps) {
+  for (uint32_t j = s; j < e; ++j) {
+    float d2 = sqdist(x, y, z, cand[j]);
+    if (d2 <= sq_eps) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ bool gate_ok(float dot, float lo, float hi) {
+  // aligned branch: lo <= dot <= 1 ; anti-parallel branch (the fold of base.cc:1757): -1 <= dot <= hi
+  // dot outside [-1,1] -> acos = NaN -> rejected (SURVEY hazard 4)
+  return (dot >= lo && dot <= 1.0f) || (dot <= hi && dot >= -1.0f);
+}
+
+struct ScoreArgs {
+  GridDesc g;
+  const uint32_t* bitmap;
+  const uint32_t* cell_start;
+  const float4* cand;
+  const float4* Pnw;
+  const float4* Q;
+  const float4* Qn;
+  int nQ;
+  const float* T;
+  int n_h, hpb, n_tiles, n_chunks;
+  float sq_eps, gate_lo, gate_hi;
+  int* partial_cnt;     // [n_tiles][n_h]
+  float* partial_sum;   // [n_tiles][n_h] (weighted only)
+};
+
+template <int MODE>
+__global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
+  __shared__ int s_cnt[kTile / 64][kMaxHpb];
+  __shared__ float s_sum[kTile / 64][kMaxHpb];
+
+  // XCD-aware decode: consecutive blocks are dealt round-robin over the 8 XCDs, so blocks that
+  // agree in blockIdx%8 share an L2; give each XCD its own hypothesis chunks.
+  const int L = blockIdx.x;
+  const int xcd = L & 7, seq = L >> 3;
+  const int chunk = (seq / a.n_tiles) * 8 + xcd;
+  const int tile = seq % a.n_tiles;
+  if (chunk >= a.n_chunks) return;  // whole block exits together (padding blocks)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = tile * kTile + threadIdx.x;
+  const bool live = qi < a.nQ;
+  float4 q = live ? a.Q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == PGP_MODE_WEIGHTED && live) qn = a.Qn[qi];
+
+  const int h0 = chunk * a.hpb;
+  const int h1 = min(h0 + a.hpb, a.n_h);
+  for (int h = h0; h < h1; ++h) {
+    const Xf m = load_xf(a.T, h);
+    float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
+    float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
+    float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
+    uint32_t s = 0, e = 0;
+    if (live) cell_run(a.g, a.bitmap, a.cell_start, x, y, z, &s, &e);
+    bool hit = false;
+    float wsum = 0.f;
+    if (MODE == PGP_MODE_PLAIN) {
+      hit = any_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+    } else {
+      int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+      if (id >= 0) {
+        float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
+        float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
+        float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
+        float4 pn = a.Pnw[id];
+        float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+        if (gate_ok(dot, a.gate_lo, a.gate_hi)) {
+          hit = true;
+          wsum = pn.w;
+        }
+      }
+    }
+    unsigned long long mask = __ballot(hit);
+    if (MODE == PGP_MODE_WEIGHTED) {
+      // fixed butterfly: same association every run
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
+    }
+    if (lane == 0) {
+      s_cnt[wave][h - h0] = __popcll(mask);
+      if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][h - h0] = wsum;
+    }
+  }
+  __syncthreads();
+  const int hh = threadIdx.x;
+  if (hh < h1 - h0) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < kTile / 64; ++w) c += s_cnt[w][hh];
+    a.partial_cnt[(size_t)tile * a.n_h + h0 + hh] = c;
+    if (MODE == PGP_MODE_WEIGHTED) {
+      float f = 0.f;
+#pragma unroll
+      for (int w = 0; w < kTile / 64; ++w) f += s_sum[w][hh];
+      a.partial_sum[(size_t)tile * a.n_h + h0 + hh] = f;
+    }
+  }
+}
+
+// Sum the per-tile partials in tile order, form the score exactly as the reference does
+// (Scalar(good_points)/Scalar(number_of_points), base.cc:1730 / weighted_match/Scalar(n), :1765)
+// and fold the batch arg-max: key = score bits << 32 | ~index, so the maximum key is the highest
+// score at its LOWEST index = what `lcp > best_LCP_` (strict, base.cc:1891) ends on.
+__global__ __launch_bounds__(256) void finalize_scores(const int* __restrict__ partial_cnt,
+                                                       const float* __restrict__ partial_sum,
+                                                       int n_tiles, int n_h, int nQ, int mode,
+                                                       float* __restrict__ scores,
+                                                       int* __restrict__ counts,
+                                                       unsigned long long* __restrict__ best_key) {
+  int h = blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned long long key = 0;
+  if (h < n_h) {
+    int c = 0;
+    float f = 0.f;
+    for (int t = 0; t < n_tiles; ++t) {
+      c += partial_cnt[(size_t)t * n_h + h];
+      if (mode == PGP_MODE_WEIGHTED) f += partial_sum[(size_t)t * n_h + h];
+    }
+    float score = (mode == PGP_MODE_PLAIN) ? __fdiv_rn((float)c, (float)nQ) : __fdiv_rn(f, (float)nQ);
+    scores[h] = score;
+    if (counts) counts[h] = c;
+    if (score > 0.f)  // NaN and <= 0 never become best (best_LCP_ starts at 0, strict >)
+      key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    unsigned long long o = __shfl_xor(key, off, 64);
+    key = o > key ? o : key;
+  }
+  if ((threadIdx.x & 63) == 0 && key) atomicMax(best_key, key);
+}
+
+__global__ void publish_best(const unsigned long long* __restrict__ best_key, int* __restrict__ best) {
+  unsigned long long k = *best_key;
+  if (k == 0) {
+    best[0] = -1;
+    best[1] = 0;  // best_LCP_ = 0.0f
+  } else {
+    best[0] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
+    best[1] = (int)(unsigned)(k >> 32);
+  }
+}
+
+// One transform, per-model-point result in ORIGINAL model order (the Q arrays are Morton-sorted;
+// q.w carries the original index): hit id after the gate, or -1.
+template <int MODE>
+__global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __restrict__ hits) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nQ) return;
+  const Xf m = load_xf(a.T, 0);
+  float4 q = a.Q[i];
+  float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
+  float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
+  float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
+  uint32_t s, e;
+  cell_run(a.g, a.bitmap, a.cell_start, x, y, z, &s, &e);
+  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+  if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
+    float4 qn = a.Qn[i];
+    float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
+    float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
+    float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
+    float4 pn = a.Pnw[id];
+    float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+    if (!gate_ok(dot, a.gate_lo, a.gate_hi)) id = -1;
+  }
+  hits[__float_as_int(q.w)] = id;
+}
+
+// base.cc:1756-1758 evaluated on the host, exactly as the reference evaluates it.
+bool gate_pred(float dot, float gate_deg) {
+  float ac = std::acos(dot);
+  float ac180 = ac * 180;
+  float angle_n = (float)((double)ac180 / M_PI);
+  angle_n = std::min(angle_n, std::fabs(180 - angle_n));
+  return angle_n < gate_deg;
+}
+
+// float <-> monotone integer key
+int32_t f2key(float f) {
+  int32_t i;
+  std::memcpy(&i, &f, 4);
+  return i >= 0 ? i : (int32_t)(0x80000000u - (uint32_t)i);
+}
+float key2f(int32_t k) {
+  int32_t i = k >= 0 ? k : (int32_t)(0x80000000u - (uint32_t)k);
+  float f;
+  std::memcpy(&f, &i, 4);
+  return f;
+}
+
+int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, ScoreArgs* a) {
+  if (!ctx->has_index) {
+    set_error("no scene index: call pgp_set_scene first");
+    return PGP_ESTATE;
+  }
+  if (ctx->nQ <= 0 && n_h > 0 && !ctx->d_Q.p) {
+    set_error("no model: call pgp_set_model first");
+    return PGP_ESTATE;
+  }
+  if (mode != PGP_MODE_PLAIN && mode != PGP_MODE_WEIGHTED) {
+    set_error("unknown mode %d", mode);
+    return PGP_EINVAL;
+  }
+  if (mode == PGP_MODE_WEIGHTED && !(ctx->has_scene_normals && ctx->has_model_normals)) {
+    set_error("weighted mode needs scene and model normals");
+    return PGP_ESTATE;
+  }
+  if (mode == PGP_MODE_WEIGHTED && ctx->gate_deg_cached != gate_deg) {
+    gate_thresholds(gate_deg, &ctx->gate_lo, &ctx->gate_hi);
+    ctx->gate_deg_cached = gate_deg;
+  }
+  a->g = ctx->grid;
+  a->bitmap = ctx->d_bitmap.as<uint32_t>();
+  a->cell_start = ctx->d_cell_start.as<uint32_t>();
+  a->cand = ctx->d_cand.as<float4>();
+  a->Pnw = ctx->d_Pnw.as<float4>();
+  a->Q = ctx->d_Q.as<float4>();
+  a->Qn = ctx->d_Qn.as<float4>();
+  a->nQ = ctx->nQ;
+  a->T = d_T;
+  a->n_h = n_h;
+  a->n_tiles = tiles_for(ctx->nQ);
+  // delta*delta in float, as `sq_eps = epsilon*epsilon` (base.cc:1711)
+  a->sq_eps = ctx->delta * ctx->delta;
+  a->gate_lo = ctx->gate_lo;
+  a->gate_hi = ctx->gate_hi;
+  return PGP_OK;
+}
+
+}  // namespace
+
+int tiles_for(int nQ) { return nQ > 0 ? (nQ + kTile - 1) / kTile : 1; }
+
+void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max) {
+  // pred(d) is true on [-1, hi] U [lo, 1] (acosf is monotone): bisect both edges over the
+  // ordered float keys.  Degenerate gates collapse naturally (gate >= 90: everything in
+  // [-1,1] passes; gate <= 0: nothing does).
+  *c_aligned_min = 2.f;   // nothing passes
+  *c_anti_max = -2.f;
+  if (!(gate_deg == gate_deg)) return;
+  if (gate_pred(1.0f, gate_deg)) {
+    int32_t lo = f2key(0.0f), hi = f2key(1.0f);  // pred(hi) true; find first true in [0,1]
+    if (gate_pred(0.0f, gate_deg)) {
+      *c_aligned_min = 0.0f;
+    } else {
+      while (hi - lo > 1) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (gate_pred(key2f(mid), gate_deg)) hi = mid; else lo = mid;
+      }
+      *c_aligned_min = key2f(hi);
+    }
+  }
+  if (gate_pred(-1.0f, gate_deg)) {
+    int32_t lo = f2key(-1.0f), hi = f2key(-0.0f);  // pred(lo) true; find last true in [-1,-0]
+    if (gate_pred(-0.0f, gate_deg)) {
+      *c_anti_max = 0.0f;
+    } else {
+      while (hi - lo > 1) {
+        int32_t mid = lo + (hi - lo) / 2;
+        if (gate_pred(key2f(mid), gate_deg)) lo = mid; else hi = mid;
+      }
+      *c_anti_max = key2f(lo);
+    }
+  }
+}
+
+int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
+                 float* d_scores, int* d_counts, int* d_best, hipStream_t stream) {
+  ScoreArgs a{};
+  int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
+  if (rc != PGP_OK) return rc;
+  if (n_h > ctx->cap_h) {
+    set_error("n_h %d exceeds reserved capacity %d (pgp_reserve)", n_h, ctx->cap_h);
+    return PGP_ESTATE;
+  }
+  unsigned long long* key = ctx->d_best.as<unsigned long long>();
+  int* best_local = reinterpret_cast<int*>(key + 1);
+  PGP_HIP(hipMemsetAsync(key, 0, 8, stream));
+  if (n_h > 0) {
+    // aim for ~16 workgroups per CU; at least 4 hypotheses per block to amortise the model load
+    long long work = (long long)n_h * a.n_tiles;
+    int hpb = (int)(work / 4096);
+    if (hpb < 4) hpb = 4;
+    if (hpb > kMaxHpb) hpb = kMaxHpb;
+    a.hpb = hpb;
+    a.n_chunks = (n_h + hpb - 1) / hpb;
+    a.partial_cnt = ctx->d_partial.as<int>();
+    a.partial_sum = reinterpret_cast<float*>(a.partial_cnt + (size_t)a.n_tiles * ctx->cap_h);
+    int chunks_pad = (a.n_chunks + 7) / 8 * 8;
+    dim3 grid((unsigned)(chunks_pad * a.n_tiles));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->timing) {
+      if (ctx->ev_used + 2 > ctx->ev.size()) {
+        for (int k = 0; k < 2; ++k) {
+          hipEvent_t e;
+          PGP_HIP(hipEventCreate(&e));
+          ctx->ev.push_back(e);
+        }
+      }
+      ev0 = ctx->ev[ctx->ev_used];
+      ev1 = ctx->ev[ctx->ev_used + 1];
+      ctx->ev_used += 2;
+      PGP_HIP(hipEventRecord(ev0, stream));
+    }
+    if (mode == PGP_MODE_PLAIN)
+      hipLaunchKernelGGL(score_hypotheses<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, a);
+    else
+      hipLaunchKernelGGL(score_hypotheses<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, a);
+    if (ev1) PGP_HIP(hipEventRecord(ev1, stream));
+    hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream,
+                       (const int*)a.partial_cnt, (const float*)a.partial_sum, a.n_tiles, n_h, a.nQ,
+                       mode, d_scores, d_counts, key);
+  }
+  hipLaunchKernelGGL(publish_best, dim3(1), dim3(1), 0, stream, (const unsigned long long*)key,
+                     d_best ? d_best : best_local);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
+                      hipStream_t stream) {
+  ScoreArgs a{};
+  int rc = fill_args(ctx, d_T16, 1, mode, gate_deg, &a);
+  if (rc != PGP_OK) return rc;
+  if (ctx->nQ == 0) return PGP_OK;
+  dim3 grid((ctx->nQ + 255) / 256);
+  if (mode == PGP_MODE_PLAIN)
+    hipLaunchKernelGGL(registered_points<PGP_MODE_PLAIN>, grid, dim3(256), 0, stream, a, d_hits);
+  else
+    hipLaunchKernelGGL(registered_points<PGP_MODE_WEIGHTED>, grid, dim3(256), 0, stream, a, d_hits);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+}  // namespace pgp

@@ -1,0 +1,424 @@
+// csrc/pgp_api.hip -- the C ABI of include/pgp.h: context, uploads, host-pointer entry points.
+// No CPU fallback anywhere: every scoring entry point ends in a HIP kernel launch or an error.
+
+#include "pgp_internal.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+namespace pgp {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+int DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap && p) return PGP_OK;
+  if (bytes == 0) bytes = 16;
+  if (p) {
+    hipError_t e = hipFree(p);
+    (void)e;
+    p = nullptr;
+    cap = 0;
+  }
+  // grow geometrically so repeated calls with slowly growing sizes do not reallocate each time
+  size_t want = bytes + bytes / 4;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    p = nullptr;
+    set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    return e == hipErrorOutOfMemory ? PGP_ENOMEM : PGP_EHIP;
+  }
+  cap = want;
+  return PGP_OK;
+}
+
+void DevBuf::release() {
+  if (p) {
+    hipError_t e = hipFree(p);
+    (void)e;
+  }
+  p = nullptr;
+  cap = 0;
+}
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) {
+      hipError_t e = hipSetDevice(prev);
+      (void)e;
+    }
+  }
+};
+
+inline uint32_t spread10(uint32_t v) {
+  v &= 1023u;
+  v = (v | (v << 16)) & 0x030000FFu;
+  v = (v | (v << 8)) & 0x0300F00Fu;
+  v = (v | (v << 4)) & 0x030C30C3u;
+  v = (v | (v << 2)) & 0x09249249u;
+  return v;
+}
+
+}  // namespace
+}  // namespace pgp
+
+using namespace pgp;
+
+extern "C" {
+
+int pgp_version(void) { return 100; }
+
+const char* pgp_last_error(void) { return g_err; }
+
+int pgp_create(pgp_ctx** out, int device_id) {
+  if (!out) {
+    set_error("pgp_create: out is NULL");
+    return PGP_EINVAL;
+  }
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    set_error("no HIP device available (%s); libpgp has no CPU fallback",
+              e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    return PGP_ENODEV;
+  }
+  if (device_id < 0) {
+    if (hipGetDevice(&device_id) != hipSuccess) device_id = 0;
+  }
+  if (device_id >= n) {
+    set_error("device %d out of range (%d devices)", device_id, n);
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(device_id);
+  if (!guard.ok) {
+    set_error("hipSetDevice(%d) failed", device_id);
+    return PGP_ENODEV;
+  }
+  pgp_ctx* ctx = new pgp_ctx();
+  ctx->device = device_id;
+  e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
+    delete ctx;
+    return PGP_ENODEV;
+  }
+  int rc = ctx->d_best.ensure(32);
+  if (rc != PGP_OK) {
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return PGP_OK;
+}
+
+int pgp_destroy(pgp_ctx* ctx) {
+  if (!ctx) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  if (ctx->stream) {
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)e;
+  }
+  DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
+                    &ctx->d_bitmap, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
+                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits};
+  for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : ctx->ev) {
+    hipError_t r = hipEventDestroy(e);
+    (void)r;
+  }
+  if (ctx->stream) {
+    hipError_t e = hipStreamDestroy(ctx->stream);
+    (void)e;
+  }
+  delete ctx;
+  return PGP_OK;
+}
+
+int pgp_center(float* P, int nP, float* Qs, int nQs, float* Qv, int nQv, float centroid_P[3],
+               float centroid_Q[3]) {
+  if (nP < 0 || nQs < 0 || nQv < 0 || (nP && !P) || (nQs && !Qs) || (nQv && !Qv) || !centroid_P ||
+      !centroid_Q) {
+    set_error("pgp_center: bad argument");
+    return PGP_EINVAL;
+  }
+  // base.cc:242-249: centroid += pos (index order, float), then /= Scalar(n)
+  float cP[3] = {0.f, 0.f, 0.f}, cQ[3] = {0.f, 0.f, 0.f};
+  for (int i = 0; i < nP; ++i)
+    for (int k = 0; k < 3; ++k) cP[k] += P[3 * (size_t)i + k];
+  for (int k = 0; k < 3; ++k) cP[k] /= (float)nP;
+  for (int i = 0; i < nQs; ++i)
+    for (int k = 0; k < 3; ++k) cQ[k] += Qs[3 * (size_t)i + k];
+  for (int k = 0; k < 3; ++k) cQ[k] /= (float)nQs;
+  // base.cc:256-264
+  for (int i = 0; i < nP; ++i)
+    for (int k = 0; k < 3; ++k) P[3 * (size_t)i + k] -= cP[k];
+  for (int i = 0; i < nQs; ++i)
+    for (int k = 0; k < 3; ++k) Qs[3 * (size_t)i + k] -= cQ[k];
+  for (int i = 0; i < nQv; ++i)
+    for (int k = 0; k < 3; ++k) Qv[3 * (size_t)i + k] -= cQ[k];
+  for (int k = 0; k < 3; ++k) {
+    centroid_P[k] = cP[k];
+    centroid_Q[k] = cQ[k];
+  }
+  return PGP_OK;
+}
+
+int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float* weight, int n,
+                  float delta) {
+  if (!ctx || n < 0 || (n > 0 && !xyz) || !(delta > 0.f) || !std::isfinite(delta)) {
+    set_error("pgp_set_scene: bad argument (n=%d, delta=%g)", n, (double)delta);
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  ctx->has_index = false;
+  ctx->nP = n;
+  ctx->has_scene_normals = nrm != nullptr;
+  std::vector<float4> hp((size_t)std::max(n, 1)), hn((size_t)std::max(n, 1));
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * (size_t)i;
+    hp[i] = make_float4(p[0], p[1], p[2], __builtin_bit_cast(float, i));
+    float w = weight ? weight[i] : 1.0f;
+    if (nrm)
+      hn[i] = make_float4(nrm[3 * (size_t)i], nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2], w);
+    else
+      hn[i] = make_float4(0.f, 0.f, 0.f, w);
+  }
+  int rc;
+  if ((rc = ctx->d_P.ensure(hp.size() * sizeof(float4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_Pnw.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_P.p, hp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipMemcpyAsync(ctx->d_Pnw.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  return build_index(ctx, xyz, delta);
+}
+
+int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
+  if (!ctx || n < 0 || (n > 0 && !xyz)) {
+    set_error("pgp_set_model: bad argument (n=%d)", n);
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  ctx->nQ = n;
+  ctx->has_model_normals = nrm != nullptr;
+  // Morton order: neighbouring lanes hold neighbouring model points, so under any rigid
+  // transform a wave's 64 queries fall into neighbouring cells (coalesced bitmap / offset /
+  // candidate reads, similar run lengths => little divergence).  Scores are sums over the
+  // model, so the order is free; q.w keeps the original index for pgp_registered.
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float v = xyz[3 * (size_t)i + k];
+      if (std::isfinite(v)) {
+        mn[k] = std::min(mn[k], v);
+        mx[k] = std::max(mx[k], v);
+      }
+    }
+  float scale[3];
+  for (int k = 0; k < 3; ++k) scale[k] = (mx[k] > mn[k]) ? 1023.0f / (mx[k] - mn[k]) : 0.f;
+  std::vector<uint32_t> code((size_t)std::max(n, 1));
+  for (int i = 0; i < n; ++i) {
+    uint32_t c[3];
+    for (int k = 0; k < 3; ++k) {
+      float v = (xyz[3 * (size_t)i + k] - mn[k]) * scale[k];
+      c[k] = std::isfinite(v) ? (uint32_t)std::min(1023.f, std::max(0.f, v)) : 0u;
+    }
+    code[i] = spread10(c[0]) | (spread10(c[1]) << 1) | (spread10(c[2]) << 2);
+  }
+  std::vector<int> order((size_t)n);
+  std::iota(order.begin(), order.end(), 0);
+  std::sort(order.begin(), order.end(), [&](int a, int b) { return code[a] != code[b] ? code[a] < code[b] : a < b; });
+  std::vector<float4> hq((size_t)std::max(n, 1)), hn((size_t)std::max(n, 1));
+  for (int s = 0; s < n; ++s) {
+    int i = order[s];
+    hq[s] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+                        __builtin_bit_cast(float, i));
+    hn[s] = nrm ? make_float4(nrm[3 * (size_t)i], nrm[3 * (size_t)i + 1], nrm[3 * (size_t)i + 2], 0.f)
+                : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  int rc;
+  if ((rc = ctx->d_Q.ensure(hq.size() * sizeof(float4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_Qn.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_hits.ensure(hq.size() * sizeof(int))) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_Q.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipMemcpyAsync(ctx->d_Qn.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  // the per-tile partial buffer depends on the model size
+  if (ctx->cap_h > 0) {
+    int cap = ctx->cap_h;
+    ctx->cap_h = 0;
+    return pgp_reserve(ctx, cap);
+  }
+  return PGP_OK;
+}
+
+int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
+  if (!ctx || max_hypotheses < 0) {
+    set_error("pgp_reserve: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  if (max_hypotheses <= ctx->cap_h) return PGP_OK;
+  int rc;
+  size_t cap = (size_t)max_hypotheses;
+  size_t tiles = (size_t)tiles_for(ctx->nQ);
+  if ((rc = ctx->d_T.ensure(cap * 16 * sizeof(float))) != PGP_OK) return rc;
+  if ((rc = ctx->d_partial.ensure(tiles * cap * (sizeof(int) + sizeof(float)))) != PGP_OK) return rc;
+  if ((rc = ctx->d_scores.ensure(cap * sizeof(float))) != PGP_OK) return rc;
+  if ((rc = ctx->d_counts.ensure(cap * sizeof(int))) != PGP_OK) return rc;
+  ctx->cap_h = max_hypotheses;
+  return PGP_OK;
+}
+
+int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
+                         float* d_scores, int* d_counts, int* d_best, void* stream) {
+  if (!ctx || n_h < 0 || (n_h > 0 && (!d_T || !d_scores))) {
+    set_error("pgp_score_lcp_device: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_score(ctx, d_T, n_h, mode, gate_deg, d_scores, d_counts, d_best,
+                      static_cast<hipStream_t>(stream));
+}
+
+int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_deg, float* scores,
+                  int* counts, int* best_index, float* best_score) {
+  if (!ctx || n_h < 0 || (n_h > 0 && (!T || !scores))) {
+    set_error("pgp_score_lcp: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  int rc = pgp_reserve(ctx, n_h);
+  if (rc != PGP_OK) return rc;
+  hipStream_t st = ctx->stream;
+  if (n_h > 0)
+    PGP_HIP(hipMemcpyAsync(ctx->d_T.p, T, (size_t)n_h * 16 * sizeof(float), hipMemcpyHostToDevice, st));
+  int* d_best = reinterpret_cast<int*>(ctx->d_best.as<unsigned long long>() + 1);
+  rc = launch_score(ctx, ctx->d_T.as<float>(), n_h, mode, gate_deg, ctx->d_scores.as<float>(),
+                    ctx->d_counts.as<int>(), d_best, st);
+  if (rc != PGP_OK) return rc;
+  int best[2] = {-1, 0};
+  if (n_h > 0) {
+    PGP_HIP(hipMemcpyAsync(scores, ctx->d_scores.p, (size_t)n_h * sizeof(float), hipMemcpyDeviceToHost, st));
+    if (counts)
+      PGP_HIP(hipMemcpyAsync(counts, ctx->d_counts.p, (size_t)n_h * sizeof(int), hipMemcpyDeviceToHost, st));
+  }
+  PGP_HIP(hipMemcpyAsync(best, d_best, sizeof best, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  if (best_index) *best_index = best[0];
+  if (best_score) std::memcpy(best_score, &best[1], 4);
+  return PGP_OK;
+}
+
+int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int* ids, int* n) {
+  if (!ctx || !T16 || !n || (ctx->nQ > 0 && !ids)) {
+    set_error("pgp_registered: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  int rc = pgp_reserve(ctx, 1);
+  if (rc != PGP_OK) return rc;
+  hipStream_t st = ctx->stream;
+  PGP_HIP(hipMemcpyAsync(ctx->d_T.p, T16, 16 * sizeof(float), hipMemcpyHostToDevice, st));
+  rc = launch_registered(ctx, ctx->d_T.as<float>(), mode, gate_deg, ctx->d_hits.as<int>(), st);
+  if (rc != PGP_OK) return rc;
+  std::vector<int> hits((size_t)std::max(ctx->nQ, 1));
+  if (ctx->nQ > 0)
+    PGP_HIP(hipMemcpyAsync(hits.data(), ctx->d_hits.p, (size_t)ctx->nQ * sizeof(int), hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  int k = 0;
+  for (int i = 0; i < ctx->nQ; ++i)
+    if (hits[i] >= 0) ids[k++] = hits[i];  // model-point order, as push_back in base.cc:1760
+  *n = k;
+  return PGP_OK;
+}
+
+int pgp_running_best(const float* scores, int n_h, int* selected, int* n_selected) {
+  if (n_h < 0 || (n_h > 0 && (!scores || !selected)) || !n_selected) {
+    set_error("pgp_running_best: bad argument");
+    return PGP_EINVAL;
+  }
+  float best = 0.f;  // best_LCP_ = 0.0 (base.cc:308)
+  int k = 0;
+  for (int i = 0; i < n_h; ++i)
+    if (scores[i] > best) {
+      best = scores[i];
+      selected[k++] = i;
+    }
+  *n_selected = k;
+  return PGP_OK;
+}
+
+int pgp_set_kernel_timing(pgp_ctx* ctx, int enable) {
+  if (!ctx) {
+    set_error("pgp_set_kernel_timing: ctx is NULL");
+    return PGP_EINVAL;
+  }
+  ctx->timing = enable != 0;
+  return PGP_OK;
+}
+
+int pgp_get_kernel_timing(pgp_ctx* ctx, int* launches, float* total_ms, int reset) {
+  if (!ctx || !launches || !total_ms) {
+    set_error("pgp_get_kernel_timing: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  float sum = 0.f;
+  for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
+    PGP_HIP(hipEventSynchronize(ctx->ev[k + 1]));
+    float ms = 0.f;
+    PGP_HIP(hipEventElapsedTime(&ms, ctx->ev[k], ctx->ev[k + 1]));
+    sum += ms;
+  }
+  *launches = (int)(ctx->ev_used / 2);
+  *total_ms = sum;
+  if (reset) ctx->ev_used = 0;
+  return PGP_OK;
+}
+
+int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info) {
+  if (!ctx || !info) {
+    set_error("pgp_get_index_info: bad argument");
+    return PGP_EINVAL;
+  }
+  std::memset(info, 0, sizeof *info);
+  info->n_scene = ctx->nP;
+  info->n_model = ctx->nQ;
+  if (ctx->has_index) {
+    info->grid_nx = ctx->grid.nx;
+    info->grid_ny = ctx->grid.ny;
+    info->grid_nz = ctx->grid.nz;
+    info->cell_size = ctx->grid.h;
+    info->delta = ctx->delta;
+    info->n_cells = ctx->n_cells;
+    info->n_candidates = ctx->n_cand;
+    info->bytes_index = (long long)((size_t)ctx->grid.nz * ctx->grid.ny * ctx->grid.nxw * 4 +
+                                    ((size_t)ctx->n_cells + 1) * 4 + (size_t)ctx->n_cand * 16);
+    info->build_ms = ctx->build_ms;
+  }
+  return PGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,104 @@
+// csrc/pgp_internal.h -- shared declarations of libpgp.so (host side + kernel launchers).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/pgp.h"
+
+namespace pgp {
+
+void set_error(const char* fmt, ...);
+
+#define PGP_HIP(call)                                                                   \
+  do {                                                                                  \
+    hipError_t _e = (call);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      pgp::set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return PGP_EHIP;                                                                  \
+    }                                                                                   \
+  } while (0)
+
+// Uniform grid over the (centred) scene cloud.  cell(x) = floor((x - origin) * inv_h).
+struct GridDesc {
+  float ox, oy, oz;   // origin (min corner of cell (0,0,0))
+  float h, inv_h;     // cell edge (>= delta) and its float reciprocal
+  int nx, ny, nz;     // cells per axis
+  int nxw;            // 32-bit bitmap words per x-row = ceil(nx/32)
+  float reach;        // delta + margin: a point is a candidate of every cell within `reach`
+};
+
+// A growable device buffer (never shrinks; freed with the context).
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes);  // returns PGP_OK / PGP_EHIP
+  void release();
+  template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace pgp
+
+struct pgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;  // internal stream for the synchronous host-pointer API
+
+  // scene
+  int nP = 0;
+  bool has_scene_normals = false;
+  float delta = 0.f;
+  pgp::DevBuf d_P;       // float4 {x,y,z,bits(i)}             [nP]
+  pgp::DevBuf d_Pnw;     // float4 {nx,ny,nz,w}                [nP]
+  // index
+  bool has_index = false;
+  pgp::GridDesc grid{};
+  long long n_cells = 0, n_cand = 0;
+  pgp::DevBuf d_cell_start;  // uint32 [n_cells+1]
+  pgp::DevBuf d_cell_tmp;    // uint32 [n_cells+1]  (counts, then fill cursors)
+  pgp::DevBuf d_scan_tmp;    // uint32 block sums
+  pgp::DevBuf d_bitmap;      // uint32 [nz*ny*nxw]
+  pgp::DevBuf d_cand;        // float4 {x,y,z,bits(i)} [n_cand]
+  float build_ms = 0.f;
+
+  // model
+  int nQ = 0;
+  bool has_model_normals = false;
+  pgp::DevBuf d_Q;       // float4 {x,y,z,bits(orig i)} in Morton order [nQ]
+  pgp::DevBuf d_Qn;      // float4 {nx,ny,nz,0}          in Morton order [nQ]
+
+  // scoring workspace
+  int cap_h = 0;
+  pgp::DevBuf d_T;        // staged transforms (host API)            [cap_h*16] float
+  pgp::DevBuf d_partial;  // per (tile, hypothesis) partials          [n_tiles*cap_h] int2/float
+  pgp::DevBuf d_scores;   // [cap_h] float
+  pgp::DevBuf d_counts;   // [cap_h] int
+  pgp::DevBuf d_best;     // 2 x uint64 packed argmax + {index, score bits}
+  pgp::DevBuf d_hits;     // [nQ] int (pgp_registered)
+
+  // optional per-kernel timing (pgp_set_kernel_timing)
+  bool timing = false;
+  std::vector<hipEvent_t> ev;   // pairs: [2k] start, [2k+1] stop
+  size_t ev_used = 0;           // events recorded since the last reset
+
+  // normal gate (base.cc:1756-1758) as thresholds on the dot product, see gate_thresholds()
+  float gate_deg_cached = -1.f;
+  float gate_lo = 2.f, gate_hi = -2.f;
+};
+
+namespace pgp {
+
+// grid_index.hip
+int build_index(pgp_ctx* ctx, const float* h_xyz, float delta);
+
+// lcp_score.hip
+int tiles_for(int nQ);
+int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
+                 float* d_scores, int* d_counts, int* d_best, hipStream_t stream);
+int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
+                      hipStream_t stream);
+void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
+
+}  // namespace pgp

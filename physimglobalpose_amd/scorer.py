@@ -1,0 +1,171 @@
+"""Host-side mirror of the reference's scoring surface, over the C ABI (include/pgp.h).
+
+Names follow the reference (S4/algorithms/match4pcsBase.{h,cc}): a `LcpScorer` plays the part of
+the per-call `MatchSuper4PCS` object between `init()` and the end of `Perform_N_steps()`:
+
+    init(P, Q_validation)            -> LcpScorer.init(...)            base.cc:216-345
+    Verify(mat)                      -> LcpScorer.Verify(mat)          base.cc:1699-1731
+    WeightedVerify(mat, registered)  -> LcpScorer.WeightedVerify(mat)  base.cc:1733-1766
+    verification loop                -> LcpScorer.score(transforms)    base.cc:1885-1901
+
+All computation happens in libpgp.so's HIP kernels; this file only marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import numpy as np
+
+from . import _lib
+from ._lib import PGP_MODE_PLAIN, PGP_MODE_WEIGHTED
+
+_f = C.POINTER(C.c_float)
+_i = C.POINTER(C.c_int)
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(_f)
+
+
+def _f32(a, cols=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+class LcpScorer:
+    """One (scene, model) pair on one GPU."""
+
+    def __init__(self, device: int = -1):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.pgp_create(C.byref(h), int(device)))
+        self._h = h
+        self.nQ = 0
+        self.nP = 0
+        self.delta = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pgp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- init() -----------------------------------------------------------------------------
+    @staticmethod
+    def center(P_xyz, Qs_xyz, Qv_xyz):
+        """base.cc:242-268: returns centred copies and the two centroids."""
+        lib = _lib.load()
+        P, Qs, Qv = (np.array(_f32(x, 3), copy=True) for x in (P_xyz, Qs_xyz, Qv_xyz))
+        cP, cQ = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        _lib.check(lib.pgp_center(_fp(P), len(P), _fp(Qs), len(Qs), _fp(Qv), len(Qv), _fp(cP), _fp(cQ)))
+        return P, Qs, Qv, cP, cQ
+
+    def set_scene(self, xyz, nrm=None, weight=None, delta=0.005):
+        xyz, nrm, weight = _f32(xyz, 3), _f32(nrm, 3), _f32(weight)
+        if nrm is not None and len(nrm) != len(xyz):
+            raise ValueError("normals / points size mismatch")
+        if weight is not None and len(weight) != len(xyz):
+            raise ValueError("weights / points size mismatch")
+        _lib.check(self._lib.pgp_set_scene(self._h, _fp(xyz), _fp(nrm), _fp(weight), len(xyz),
+                                           C.c_float(delta)))
+        self.nP, self.delta = len(xyz), float(delta)
+
+    def set_model(self, xyz, nrm=None):
+        xyz, nrm = _f32(xyz, 3), _f32(nrm, 3)
+        if nrm is not None and len(nrm) != len(xyz):
+            raise ValueError("normals / points size mismatch")
+        _lib.check(self._lib.pgp_set_model(self._h, _fp(xyz), _fp(nrm), len(xyz)))
+        self.nQ = len(xyz)
+
+    def init(self, P_xyz, P_nrm, P_w, Q_xyz, Q_nrm, delta=0.005):
+        self.set_scene(P_xyz, P_nrm, P_w, delta)
+        self.set_model(Q_xyz, Q_nrm)
+
+    # ---- verification loop -----------------------------------------------------------------------
+    def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
+        """T: (n_h,16) column-major float transforms.  Returns (scores, counts, best_index, best_score)."""
+        T = _f32(T, 16)
+        n_h = len(T)
+        scores = np.zeros(n_h, np.float32)
+        counts = np.zeros(n_h, np.int32)
+        bi = C.c_int(-1)
+        bs = C.c_float(0)
+        _lib.check(self._lib.pgp_score_lcp(self._h, _fp(T), n_h, int(mode), C.c_float(gate_deg),
+                                           _fp(scores), counts.ctypes.data_as(_i), C.byref(bi), C.byref(bs)))
+        return scores, counts, bi.value, float(np.float32(bs.value))
+
+    def Verify(self, mat16):
+        s, c, _, _ = self.score(np.asarray(mat16, np.float32).reshape(1, 16), PGP_MODE_PLAIN)
+        return float(s[0]), int(c[0])
+
+    def WeightedVerify(self, mat16, gate_deg=30.0):
+        mat16 = _f32(mat16).reshape(16)
+        s, _, _, _ = self.score(mat16.reshape(1, 16), PGP_MODE_WEIGHTED, gate_deg)
+        return float(s[0]), self.registered(mat16, PGP_MODE_WEIGHTED, gate_deg)
+
+    def registered(self, mat16, mode=PGP_MODE_WEIGHTED, gate_deg=30.0):
+        mat16 = _f32(mat16).reshape(16)
+        ids = np.zeros(max(self.nQ, 1), np.int32)
+        n = C.c_int(0)
+        _lib.check(self._lib.pgp_registered(self._h, _fp(mat16), int(mode), C.c_float(gate_deg),
+                                            ids.ctypes.data_as(_i), C.byref(n)))
+        return ids[: n.value].copy()
+
+    @staticmethod
+    def running_best(scores):
+        scores = _f32(scores)
+        sel = np.zeros(max(len(scores), 1), np.int32)
+        n = C.c_int(0)
+        _lib.check(_lib.load().pgp_running_best(_fp(scores), len(scores), sel.ctypes.data_as(_i), C.byref(n)))
+        return sel[: n.value].copy()
+
+    # ---- device-resident path (torch tensors only carry memory + stream) --------------------------
+    def reserve(self, max_hypotheses):
+        _lib.check(self._lib.pgp_reserve(self._h, int(max_hypotheses)))
+
+    def score_device(self, d_T, d_scores, d_counts=None, d_best=None, mode=PGP_MODE_PLAIN,
+                     gate_deg=30.0, stream=None):
+        """d_T: cuda float32 tensor (n_h,16); d_scores: cuda float32 (n_h,); d_counts int32 (n_h,)
+        or None; d_best int32 (2,) or None.  Enqueued on `stream` (torch stream or raw handle;
+        default: torch's current stream).  Does not synchronise."""
+        import torch
+        assert d_T.is_cuda and d_T.dtype == torch.float32 and d_T.is_contiguous()
+        assert d_scores.is_cuda and d_scores.dtype == torch.float32 and d_scores.is_contiguous()
+        n_h = int(d_T.shape[0])
+        assert d_scores.numel() >= n_h
+        if d_counts is not None:
+            assert d_counts.is_cuda and d_counts.dtype == torch.int32 and d_counts.numel() >= n_h
+        if d_best is not None:
+            assert d_best.is_cuda and d_best.dtype == torch.int32 and d_best.numel() >= 2
+        if stream is None:
+            stream = torch.cuda.current_stream(d_T.device).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        _lib.check(self._lib.pgp_score_lcp_device(
+            self._h, C.c_void_p(d_T.data_ptr()), n_h, int(mode), C.c_float(gate_deg),
+            C.c_void_p(d_scores.data_ptr()),
+            C.c_void_p(d_counts.data_ptr()) if d_counts is not None else None,
+            C.c_void_p(d_best.data_ptr()) if d_best is not None else None,
+            C.c_void_p(stream)))
+
+    def set_kernel_timing(self, enable=True):
+        _lib.check(self._lib.pgp_set_kernel_timing(self._h, int(bool(enable))))
+
+    def kernel_timing(self, reset=True):
+        """(launches, total_ms) of the dominant kernel since the last reset (HIP events)."""
+        n, ms = C.c_int(0), C.c_float(0)
+        _lib.check(self._lib.pgp_get_kernel_timing(self._h, C.byref(n), C.byref(ms), int(reset)))
+        return n.value, float(ms.value)
+
+    def index_info(self):
+        info = _lib.IndexInfo()
+        _lib.check(self._lib.pgp_get_index_info(self._h, C.byref(info)))
+        return {k: getattr(info, k) for k, _ in info._fields_}

@@ -1,0 +1,66 @@
+"""Parity of the HIP scoring path (through the C ABI) against the CPU oracle.
+
+Bar: inlier counts, plain scores, best index and registered ids are BIT-EXACT; the weighted score
+(a float sum whose association differs from the reference's sequential loop) is within 2e-6
+absolute -- the north_star tolerance is 1e-4.
+"""
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
+from _checkers import Oracle
+
+pytestmark = pytest.mark.gpu
+
+W_TOL = 2e-6
+
+
+def _check(w, scorer=None, threads=8, check_registered=4):
+    sc = scorer or LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+    # plain
+    s, c, bi, bs = sc.score(w.T, PGP_MODE_PLAIN)
+    so, bio, selo = orc.score_batch(w.T, w.delta, mode=0, threads=threads)
+    assert np.array_equal(s, so), f"plain scores differ at {np.flatnonzero(s != so)[:10]}"
+    assert bi == bio
+    if bio >= 0:
+        assert bs == so[bio]
+    assert np.array_equal(LcpScorer.running_best(s), selo)
+    if w.n_h:
+        assert np.array_equal(c, np.round(so.astype(np.float64) * len(w.Q_xyz)).astype(np.int32))
+    # weighted
+    s, c, bi, bs = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
+    so, bio, _ = orc.score_batch(w.T, w.delta, mode=1, gate_deg=w.gate_deg, threads=threads)
+    assert np.allclose(s, so, rtol=0, atol=W_TOL), np.abs(s - so).max()
+    if bio >= 0:
+        assert abs(bs - so[bio]) <= W_TOL
+        assert so[bi] >= so[bio] - W_TOL
+    for h in list(range(min(check_registered, w.n_h))) + ([bio] if bio >= 0 else []):
+        ws, reg = orc.weighted_verify(w.T[h], w.delta, w.gate_deg)
+        assert np.array_equal(sc.registered(w.T[h], PGP_MODE_WEIGHTED, w.gate_deg), reg)
+        assert c[h] == len(reg)
+        _, _, hits = orc.verify(w.T[h], w.delta)
+        assert np.array_equal(sc.registered(w.T[h], PGP_MODE_PLAIN), hits[hits >= 0])
+    return sc
+
+
+@pytest.mark.parametrize("nP,nQ,nH,cfg", [
+    (2000, 300, 64, 11),
+    (5000, 1000, 256, 12),
+    (712, 1000, 500, 13),     # reference-like sizes
+    (50000, 5000, 96, 14),    # C2 clouds, few hypotheses (oracle stays in seconds)
+    (3000, 257, 33, 15),      # ragged: model not a multiple of the 256-point tile
+])
+def test_parity_seeded(nP, nQ, nH, cfg):
+    _check(synth.make_workload(nP, nQ, nH, config_id=cfg))
+
+
+def test_ground_truth_pose_wins():
+    w = synth.make_workload(20000, 2000, 128, config_id=16)
+    w.T = np.concatenate([w.T, w.T_gt[None]])
+    sc = LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    s, c, bi, bs = sc.score(w.T, PGP_MODE_PLAIN)
+    assert s[-1] > 0.3
+    assert s[bi] >= s[-1]
