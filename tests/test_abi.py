@@ -1,0 +1,84 @@
+"""The C-ABI library loads on a CPU-only box and exports every symbol include/pgp.h declares;
+host-only helpers behave like the reference; scoring without a GPU fails loudly (no fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import _lib
+from _checkers import oracle_lib, _fp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pgp.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pgp_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 14
+    lib = _lib.load()
+    raw = C.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), f"{n} declared in include/pgp.h but not exported by libpgp.so"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature in _lib.py"
+    assert set(_lib.SIGNATURES) <= set(names)
+    assert lib.pgp_version() >= 100
+
+
+def test_no_torch_types_in_abi():
+    src = open(os.path.join(ROOT, "include", "pgp.h")).read()
+    assert "torch" not in src and "at::" not in src and "std::" not in src
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="GPU present")
+def test_create_fails_loudly_without_gpu():
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.pgp_create(C.byref(h), -1)
+    assert rc == -2 and not h.value
+    assert b"no CPU fallback" in lib.pgp_last_error()
+    from physimglobalpose_amd import LcpScorer
+    with pytest.raises(_lib.PgpError):
+        LcpScorer()
+
+
+def test_center_matches_oracle_bits():
+    rng = np.random.default_rng(5)
+    P = (rng.uniform(-1, 1, (1234, 3)) + 0.7).astype(np.float32)
+    Qs = rng.uniform(-0.1, 0.1, (77, 3)).astype(np.float32)
+    Qv = rng.uniform(-0.1, 0.1, (500, 3)).astype(np.float32)
+    from physimglobalpose_amd import LcpScorer
+    a = LcpScorer.center(P, Qs, Qv)
+    b = [P.copy(), Qs.copy(), Qv.copy(), np.zeros(3, np.float32), np.zeros(3, np.float32)]
+    oracle_lib().orc_center(_fp(b[0]), len(P), _fp(b[1]), len(Qs), _fp(b[2]), len(Qv), _fp(b[3]), _fp(b[4]))
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+
+
+def test_running_best_rule():
+    from physimglobalpose_amd import LcpScorer
+    s = np.array([0.0, 0.2, 0.2, 0.1, 0.3, 0.3, 0.25, 0.31], np.float32)
+    assert LcpScorer.running_best(s).tolist() == [1, 4, 7]
+    assert LcpScorer.running_best(np.zeros(4, np.float32)).tolist() == []
+    assert LcpScorer.running_best(np.zeros(0, np.float32)).tolist() == []
+
+
+def test_bad_arguments_are_rejected():
+    lib = _lib.load()
+    assert lib.pgp_create(None, 0) == -1
+    assert lib.pgp_running_best(None, 3, None, None) == -1
+    assert lib.pgp_set_scene(None, None, None, None, 0, C.c_float(0.005)) == -1

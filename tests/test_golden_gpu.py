@@ -1,0 +1,44 @@
+"""HIP path (through the C ABI) against the committed golden vectors from the reference-backed
+harness.  Bit-exact for counts / plain scores / NN ids / registered ids / best index; weighted
+score within 2e-6 (different float association of the sum; north_star tolerance 1e-4)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
+               if not p.endswith("rigid_fit.npz"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_hip_matches_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    delta = float(g["delta"])
+    sc = LcpScorer()
+    sc.init(g["P"], g["Pn"], g["Pw"], g["Q"], g["Qn"], delta)
+    s, c, bi, bs = sc.score(g["T"], PGP_MODE_PLAIN)
+    assert np.array_equal(c, g["counts"])
+    assert np.array_equal(s, g["scores"])
+    assert bi == int(g["best_plain"]) and np.float32(bs) == g["scores"][bi]
+    assert np.array_equal(LcpScorer.running_best(s), g["sel_plain"])
+    ties = name == "duplicates"   # exact distance ties: NN id follows our lowest-index rule
+    for h, T in enumerate(g["T"]):
+        hits = g["hits"][h]
+        got = sc.registered(T, PGP_MODE_PLAIN)
+        assert len(got) == g["counts"][h]
+        if not ties:
+            assert np.array_equal(got, hits[hits >= 0])
+    if ties:
+        return
+    s, c, bi, bs = sc.score(g["T"], PGP_MODE_WEIGHTED, 30.0)
+    assert np.allclose(s, g["wscores"], rtol=0, atol=2e-6)
+    assert np.array_equal(c, np.diff(g["reg_off"]).astype(np.int32))
+    assert abs(bs - g["wscores"][int(g["best_weighted"])]) <= 2e-6
+    for h, T in enumerate(g["T"]):
+        reg = g["reg_flat"][g["reg_off"][h]:g["reg_off"][h + 1]]
+        assert np.array_equal(sc.registered(T, PGP_MODE_WEIGHTED, 30.0), reg)

@@ -1,0 +1,84 @@
+"""world_size-2 (and 3) gloo runs of the multi-GPU sharding path on CPU: the sharded batch must
+give the same score vector and the same best index as the unsharded one (the oracle stands in
+for the per-rank device scorer -- checker use only)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from physimglobalpose_amd import synth
+from physimglobalpose_amd.sharding import ShardedScorer, best_of, shard_bounds
+
+
+def test_shard_bounds_cover_and_balance():
+    for n in (0, 1, 7, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_best_of_rule():
+    assert best_of(torch.tensor([0.0, 0.0])) == (-1, 0.0)
+    assert best_of(torch.tensor([])) == (-1, 0.0)
+    bi, bs = best_of(torch.tensor([0.1, 0.5, 0.5, 0.2]))
+    assert bi == 1 and abs(bs - 0.5) < 1e-7
+    assert best_of(torch.tensor([float("nan"), 0.25]))[0] == 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_h, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), here]
+    from _checkers import Oracle
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        w = synth.make_workload(1500, 200, n_h, config_id=31)
+        orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+
+        def local(Ts):
+            s, _, _ = orc.score_batch(Ts.numpy(), w.delta, mode=0)
+            return torch.from_numpy(s)
+
+        sh = ShardedScorer(local)
+        scores, bi, bs = sh.score(torch.from_numpy(w.T))
+        q.put((rank, scores.numpy(), bi, bs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_h", [(2, 37), (3, 64)])
+def test_sharded_equals_unsharded(world, n_h):
+    from _checkers import Oracle
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_h, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    w = synth.make_workload(1500, 200, n_h, config_id=31)
+    orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+    s_ref, bi_ref, _ = orc.score_batch(w.T, w.delta, mode=0)
+    for rank, s, bi, bs in results:
+        assert np.array_equal(s, s_ref), f"rank {rank}"
+        assert bi == bi_ref and np.float32(bs) == s_ref[bi_ref]
