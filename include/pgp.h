@@ -104,7 +104,8 @@ typedef struct {
   int grid_nx, grid_ny, grid_nz;
   float cell_size, delta;
   long long n_cells, n_candidates;      /* entries in the dilated per-cell candidate lists */
-  long long bytes_index;                /* bitmap + cell offsets + candidate lists */
+  long long n_occupied;                 /* cells with a non-empty candidate list */
+  long long bytes_index;                /* query-time index: words + occupied offsets + lists */
   float build_ms;                       /* device time of the last index build */
 } pgp_index_info;
 int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info);

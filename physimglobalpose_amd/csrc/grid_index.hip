@@ -8,11 +8,12 @@
 //
 //   cell(x)      = floor((x - origin) * inv_h), h >= delta
 //   cand(c)      = every scene point within `reach` = delta + margin of the box of cell c
-//   bitmap       = 1 bit per cell: cand(c) non-empty           (L2-resident: 0.9 MB at C2)
-//   cell_start   = CSR offsets into one float4 array {x,y,z,bits(id)} of all candidate lists
+//   words        = per 32 cells along x: {occupancy bits, rank base}   (1.6 MB at C2, L2-resident)
+//   occ_start    = CSR offsets, one per OCCUPIED cell (rank = base + popcount of lower bits),
+//                  into one float4 array {x,y,z,bits(id)} of all candidate lists (1.1 MB at C2)
 //
-// A query is then: one bitmap word, (if set) two offsets, one contiguous float4 run -- no
-// neighbour-cell gather, no tree.  Exactness: the scoring kernel applies the reference's float
+// A query is then: one 8-byte word, (if the bit is set) one 8-byte offset pair, one contiguous
+// float4 run -- no neighbour-cell gather, no tree; ~78 % of C2 queries end at the word.  Exactness: the scoring kernel applies the reference's float
 // test d2 <= delta^2 (kdtree.h:423-424) to every candidate; the dilation margin (see
 // choose_grid) covers the float rounding of cell(x), so cand(cell(x)) is a superset of the
 // scene points that pass the test for x.  The result equals an exhaustive scan.
@@ -82,9 +83,9 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
-__global__ __launch_bounds__(kScanThreads) void scan_tiles(const uint32_t* __restrict__ in,
-                                                           uint32_t* __restrict__ out, size_t n,
-                                                           uint32_t* __restrict__ tile_sums) {
+// `in` and `out` may alias (every thread reads its items before it writes them)
+__global__ __launch_bounds__(kScanThreads) void scan_tiles(const uint32_t* in, uint32_t* out, size_t n,
+                                                           uint32_t* tile_sums) {
   __shared__ uint32_t s_wave[kScanThreads / 64];
   size_t base = (size_t)blockIdx.x * kScanTile + (size_t)threadIdx.x * kScanItems;
   uint32_t v[kScanItems];
@@ -152,10 +153,16 @@ __global__ __launch_bounds__(kScanThreads) void scan_add_offsets(uint32_t* __res
     if (base + k < n) out[base + k] += off;
 }
 
-__global__ __launch_bounds__(256) void make_bitmap(GridDesc g, const uint32_t* __restrict__ cell_start,
-                                                   uint32_t* __restrict__ bitmap, size_t n_words) {
+// occupancy bits + popcount per 32-cell word
+__global__ __launch_bounds__(256) void make_words(GridDesc g, const uint32_t* __restrict__ cell_start,
+                                                  uint2* __restrict__ words,
+                                                  uint32_t* __restrict__ word_cnt, size_t n_words) {
   size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (w >= n_words) return;
+  if (w > n_words) return;
+  if (w == n_words) {  // scan sentinel
+    word_cnt[w] = 0;
+    return;
+  }
   size_t row = w / g.nxw;  // = z*ny + y
   int xw = (int)(w - row * g.nxw);
   uint32_t bits = 0;
@@ -163,7 +170,31 @@ __global__ __launch_bounds__(256) void make_bitmap(GridDesc g, const uint32_t* _
   int lim = min(32, g.nx - xw * 32);
   for (int b = 0; b < lim; ++b)
     if (cell_start[c0 + b + 1] > cell_start[c0 + b]) bits |= (1u << b);
-  bitmap[w] = bits;
+  words[w].x = bits;
+  word_cnt[w] = __popc(bits);
+}
+
+// rank base per word + compact offsets of the occupied cells
+__global__ __launch_bounds__(256) void fill_occupied(GridDesc g, const uint32_t* __restrict__ cell_start,
+                                                     const uint32_t* __restrict__ word_base,
+                                                     uint2* __restrict__ words,
+                                                     uint32_t* __restrict__ occ_start, size_t n_words,
+                                                     size_t n_cells) {
+  size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  uint32_t base = word_base[w];
+  uint32_t bits = words[w].x;
+  words[w].y = base;
+  size_t row = w / g.nxw;
+  int xw = (int)(w - row * g.nxw);
+  size_t c0 = row * g.nx + (size_t)xw * 32;
+  uint32_t k = base;
+  while (bits) {
+    int b = __ffs(bits) - 1;
+    bits &= bits - 1;
+    occ_start[k++] = cell_start[c0 + b];
+  }
+  if (w == n_words - 1) occ_start[word_base[n_words]] = cell_start[n_cells];  // end sentinel
 }
 
 // Choose cell size, origin and dims for a bounding box and a radius.
@@ -213,6 +244,16 @@ int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, 
 
 }  // namespace
 
+// exclusive scan of n uint32 (in -> out, may alias), tile sums in `tmp`
+static int exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, hipStream_t st) {
+  const int n_tiles = (int)((n + kScanTile - 1) / kScanTile);
+  hipLaunchKernelGGL(scan_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, in, out, n, tmp);
+  hipLaunchKernelGGL(scan_tile_sums, dim3(1), dim3(1024), 0, st, tmp, n_tiles);
+  hipLaunchKernelGGL(scan_add_offsets, dim3(n_tiles), dim3(kScanThreads), 0, st, out, n, (const uint32_t*)tmp);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
 int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   const int nP = ctx->nP;
   hipStream_t st = ctx->stream;
@@ -244,7 +285,7 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   if ((rc = ctx->d_cell_start.ensure(n_scan * 4)) != PGP_OK) return rc;
   if ((rc = ctx->d_cell_tmp.ensure(n_scan * 4)) != PGP_OK) return rc;
   if ((rc = ctx->d_scan_tmp.ensure((size_t)n_tiles * 4 + 4)) != PGP_OK) return rc;
-  if ((rc = ctx->d_bitmap.ensure(n_words * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_bitmap.ensure(n_words * 8)) != PGP_OK) return rc;
 
   hipEvent_t e0, e1;
   PGP_HIP(hipEventCreate(&e0));
@@ -258,12 +299,7 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   if (nP > 0)
     hipLaunchKernelGGL(scatter_points<false>, dim3(pb), dim3(256), 0, st, g, r,
                        ctx->d_P.as<float4>(), nP, ctr, (const uint32_t*)nullptr, (float4*)nullptr);
-  hipLaunchKernelGGL(scan_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, ctr, start, n_scan,
-                     ctx->d_scan_tmp.as<uint32_t>());
-  hipLaunchKernelGGL(scan_tile_sums, dim3(1), dim3(1024), 0, st, ctx->d_scan_tmp.as<uint32_t>(), n_tiles);
-  hipLaunchKernelGGL(scan_add_offsets, dim3(n_tiles), dim3(kScanThreads), 0, st, start, n_scan,
-                     ctx->d_scan_tmp.as<uint32_t>());
-  PGP_HIP(hipGetLastError());
+  if ((rc = exclusive_scan(ctr, start, n_scan, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
   uint32_t total = 0;
   PGP_HIP(hipMemcpyAsync(&total, start + n_cells, 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
@@ -272,11 +308,22 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   if (nP > 0)
     hipLaunchKernelGGL(scatter_points<true>, dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(),
                        nP, ctr, start, ctx->d_cand.as<float4>());
-  hipLaunchKernelGGL(make_bitmap, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g, start,
-                     ctx->d_bitmap.as<uint32_t>(), n_words);
+  // two-level compaction: words {bits, rank base} + offsets of occupied cells only
+  uint2* words = ctx->d_bitmap.as<uint2>();
+  hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
+                     (const uint32_t*)start, words, ctr, n_words);
+  if ((rc = exclusive_scan(ctr, ctr, n_words + 1, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
+  uint32_t n_occ = 0;
+  PGP_HIP(hipMemcpyAsync(&n_occ, ctr + n_words, 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  if ((rc = ctx->d_occ_start.ensure(((size_t)n_occ + 2) * 4)) != PGP_OK) return rc;
+  hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
+                     (const uint32_t*)start, (const uint32_t*)ctr, words,
+                     ctx->d_occ_start.as<uint32_t>(), n_words, n_cells);
   PGP_HIP(hipGetLastError());
   PGP_HIP(hipEventRecord(e1, st));
   PGP_HIP(hipStreamSynchronize(st));
+  ctx->n_occ = (long long)n_occ;
   PGP_HIP(hipEventElapsedTime(&ctx->build_ms, e0, e1));
   hipEventDestroy(e0);
   hipEventDestroy(e1);

@@ -69,51 +69,80 @@ __device__ __forceinline__ float sqdist(float x, float y, float z, float4 p) {
   return __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
 }
 
-// Cell lookup: returns the candidate run [s, e) for position (x,y,z); empty if outside the grid
-// or the bitmap says the cell has no candidates.
-__device__ __forceinline__ void cell_run(const GridDesc& g, const uint32_t* __restrict__ bitmap,
-                                         const uint32_t* __restrict__ cell_start, float x, float y,
-                                         float z, uint32_t* s, uint32_t* e) {
+// Level 1 of the lookup: the {occupancy bits, rank base} word of the cell holding (x,y,z), and
+// the bit position inside it; bit = -1 when the position is outside the grid (or NaN).
+__device__ __forceinline__ size_t word_index(const GridDesc& g, float x, float y, float z, int* bit) {
   float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
-  *s = 0;
-  *e = 0;
+  *bit = -1;
   if (fx >= 0.f && fx < (float)g.nx && fy >= 0.f && fy < (float)g.ny && fz >= 0.f && fz < (float)g.nz) {
     int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-    size_t row = (size_t)cz * g.ny + cy;
-    uint32_t word = bitmap[row * g.nxw + (cx >> 5)];
-    if ((word >> (cx & 31)) & 1u) {
-      size_t c = row * g.nx + cx;
-      *s = cell_start[c];
-      *e = cell_start[c + 1];
-    }
+    *bit = cx & 31;
+    return ((size_t)cz * g.ny + cy) * g.nxw + (cx >> 5);
   }
+  return 0;
+}
+
+// Level 2: candidate run [s, e) of an occupied cell; empty when the bit is clear.
+__device__ __forceinline__ void run_of(const uint32_t* __restrict__ occ_start, uint2 wd, int bit,
+                                       uint32_t* s, uint32_t* e) {
+  *s = 0;
+  *e = 0;
+  if (bit >= 0 && ((wd.x >> bit) & 1u)) {
+    uint32_t k = wd.y + __popc(wd.x & ((1u << bit) - 1u));
+    *s = occ_start[k];
+    *e = occ_start[k + 1];
+  }
+}
+
+__device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
+                                         const uint32_t* __restrict__ occ_start, float x, float y,
+                                         float z, uint32_t* s, uint32_t* e) {
+  int bit;
+  size_t wi = word_index(g, x, y, z, &bit);
+  uint2 wd = make_uint2(0u, 0u);
+  if (bit >= 0) wd = words[wi];
+  run_of(occ_start, wd, bit, s, e);
 }
 
 // Nearest candidate with d2 <= sq_eps; ties -> lowest scene index (the reference's tie rule
 // depends on kd-tree leaf order, kdtree.h:424; ties are measure-zero on real data).
+__device__ __forceinline__ void nn_update(float4 p, float x, float y, float z, float* best, int* bid) {
+  float d2 = sqdist(x, y, z, p);
+  int id = __float_as_int(p.w);
+  if (d2 < *best || (d2 == *best && (*bid < 0 || id < *bid))) {
+    *best = d2;
+    *bid = id;
+  }
+}
+
+// Four candidates per trip: the loads are independent, so one memory round trip serves four
+// tests (the run is contiguous; indices past the end are clamped to the last element, which is
+// harmless for "exists" and for arg-min with the lowest-index tie rule).
 __device__ __forceinline__ int nearest_in_run(const float4* __restrict__ cand, uint32_t s, uint32_t e,
                                               float x, float y, float z, float sq_eps) {
   float best = sq_eps;
   int bid = -1;
-  for (uint32_t j = s; j < e; ++j) {
-    float4 p = cand[j];
-    float d2 = sqdist(x, y, z, p);
-    int id = __float_as_int(p.w);
-    if (d2 < best || (d2 == best && (bid < 0 || id < bid))) {
-      best = d2;
-      bid = id;
-    }
+  for (uint32_t j = s; j < e; j += 4) {
+    uint32_t last = e - 1;
+    float4 p0 = cand[j], p1 = cand[min(j + 1, last)], p2 = cand[min(j + 2, last)], p3 = cand[min(j + 3, last)];
+    nn_update(p0, x, y, z, &best, &bid);
+    nn_update(p1, x, y, z, &best, &bid);
+    nn_update(p2, x, y, z, &best, &bid);
+    nn_update(p3, x, y, z, &best, &bid);
   }
   return bid;
 }
 
 __device__ __forceinline__ bool any_in_run(const float4* __restrict__ cand, uint32_t s, uint32_t e,
                                            float x, float y, float z, float sq_eps) {
-  for (uint32_t j = s; j < e; ++j) {
-    float d2 = sqdist(x, y, z, cand[j]);
-    if (d2 <= sq_eps) return true;
+  bool hit = false;
+  for (uint32_t j = s; j < e && !hit; j += 4) {
+    uint32_t last = e - 1;
+    float4 p0 = cand[j], p1 = cand[min(j + 1, last)], p2 = cand[min(j + 2, last)], p3 = cand[min(j + 3, last)];
+    float d0 = sqdist(x, y, z, p0), d1 = sqdist(x, y, z, p1), d2 = sqdist(x, y, z, p2), d3 = sqdist(x, y, z, p3);
+    hit = (d0 <= sq_eps) | (d1 <= sq_eps) | (d2 <= sq_eps) | (d3 <= sq_eps);
   }
-  return false;
+  return hit;
 }
 
 __device__ __forceinline__ bool gate_ok(float dot, float lo, float hi) {
@@ -124,8 +153,8 @@ __device__ __forceinline__ bool gate_ok(float dot, float lo, float hi) {
 
 struct ScoreArgs {
   GridDesc g;
-  const uint32_t* bitmap;
-  const uint32_t* cell_start;
+  const uint2* words;
+  const uint32_t* occ_start;
   const float4* cand;
   const float4* Pnw;
   const float4* Q;
@@ -138,7 +167,11 @@ struct ScoreArgs {
   float* partial_sum;   // [n_tiles][n_h] (weighted only)
 };
 
-template <int MODE>
+// U hypotheses are in flight per lane: their word loads, then their offset loads, then their
+// candidate trips are issued back to back, so a wave keeps U independent dependency chains in
+// the memory system instead of one (the kernel is latency-bound: 79 % of wave cycles were
+// s_waitcnt at U = 1, profiles/r01_a_*).
+template <int MODE, int U>
 __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
   __shared__ int s_cnt[kTile / 64][kMaxHpb];
   __shared__ float s_sum[kTile / 64][kMaxHpb];
@@ -160,40 +193,60 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
 
   const int h0 = chunk * a.hpb;
   const int h1 = min(h0 + a.hpb, a.n_h);
-  for (int h = h0; h < h1; ++h) {
-    const Xf m = load_xf(a.T, h);
-    float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
-    float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
-    float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
-    uint32_t s = 0, e = 0;
-    if (live) cell_run(a.g, a.bitmap, a.cell_start, x, y, z, &s, &e);
-    bool hit = false;
-    float wsum = 0.f;
-    if (MODE == PGP_MODE_PLAIN) {
-      hit = any_in_run(a.cand, s, e, x, y, z, a.sq_eps);
-    } else {
-      int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
-      if (id >= 0) {
-        float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
-        float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
-        float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
-        float4 pn = a.Pnw[id];
-        float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
-        if (gate_ok(dot, a.gate_lo, a.gate_hi)) {
-          hit = true;
-          wsum = pn.w;
+  for (int hb = h0; hb < h1; hb += U) {
+    Xf m[U];
+    float x[U], y[U], z[U];
+    int bit[U];
+    size_t wi[U];
+    uint2 wd[U];
+    uint32_t s[U], e[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int h = min(hb + u, h1 - 1);  // tail: recompute the last one, result discarded
+      m[u] = load_xf(a.T, h);
+      x[u] = xf_row(m[u].m00, m[u].m01, m[u].m02, m[u].m03, q.x, q.y, q.z);
+      y[u] = xf_row(m[u].m10, m[u].m11, m[u].m12, m[u].m13, q.x, q.y, q.z);
+      z[u] = xf_row(m[u].m20, m[u].m21, m[u].m22, m[u].m23, q.x, q.y, q.z);
+      wi[u] = word_index(a.g, x[u], y[u], z[u], &bit[u]);
+      if (!live) bit[u] = -1;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      wd[u] = make_uint2(0u, 0u);
+      if (bit[u] >= 0) wd[u] = a.words[wi[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) run_of(a.occ_start, wd[u], bit[u], &s[u], &e[u]);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      bool hit = false;
+      float wsum = 0.f;
+      if (MODE == PGP_MODE_PLAIN) {
+        hit = any_in_run(a.cand, s[u], e[u], x[u], y[u], z[u], a.sq_eps);
+      } else {
+        int id = nearest_in_run(a.cand, s[u], e[u], x[u], y[u], z[u], a.sq_eps);
+        if (id >= 0) {
+          float nx = rot_row(m[u].m00, m[u].m01, m[u].m02, qn.x, qn.y, qn.z);
+          float ny = rot_row(m[u].m10, m[u].m11, m[u].m12, qn.x, qn.y, qn.z);
+          float nz = rot_row(m[u].m20, m[u].m21, m[u].m22, qn.x, qn.y, qn.z);
+          float4 pn = a.Pnw[id];
+          float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+          if (gate_ok(dot, a.gate_lo, a.gate_hi)) {
+            hit = true;
+            wsum = pn.w;
+          }
         }
       }
-    }
-    unsigned long long mask = __ballot(hit);
-    if (MODE == PGP_MODE_WEIGHTED) {
-      // fixed butterfly: same association every run
+      unsigned long long mask = __ballot(hit);
+      if (MODE == PGP_MODE_WEIGHTED) {
+        // fixed butterfly: same association every run
 #pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
-    }
-    if (lane == 0) {
-      s_cnt[wave][h - h0] = __popcll(mask);
-      if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][h - h0] = wsum;
+        for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
+      }
+      if (lane == 0 && hb + u < h1) {
+        s_cnt[wave][hb + u - h0] = __popcll(mask);
+        if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][hb + u - h0] = wsum;
+      }
     }
   }
   __syncthreads();
@@ -268,7 +321,7 @@ __global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __res
   float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
   float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
   uint32_t s, e;
-  cell_run(a.g, a.bitmap, a.cell_start, x, y, z, &s, &e);
+  cell_run(a.g, a.words, a.occ_start, x, y, z, &s, &e);
   int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
   if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
     float4 qn = a.Qn[i];
@@ -304,6 +357,28 @@ float key2f(int32_t k) {
   return f;
 }
 
+void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a) {
+#define PGP_LAUNCH(M, UU) hipLaunchKernelGGL((score_hypotheses<M, UU>), grid, dim3(kTile), 0, stream, a)
+  if (mode == PGP_MODE_PLAIN) {
+    switch (unroll) {
+      case 1: PGP_LAUNCH(PGP_MODE_PLAIN, 1); break;
+      case 2: PGP_LAUNCH(PGP_MODE_PLAIN, 2); break;
+      case 8: PGP_LAUNCH(PGP_MODE_PLAIN, 8); break;
+      case 4: PGP_LAUNCH(PGP_MODE_PLAIN, 4); break;
+      default: PGP_LAUNCH(PGP_MODE_PLAIN, 2); break;
+    }
+  } else {
+    switch (unroll) {
+      case 1: PGP_LAUNCH(PGP_MODE_WEIGHTED, 1); break;
+      case 2: PGP_LAUNCH(PGP_MODE_WEIGHTED, 2); break;
+      case 8: PGP_LAUNCH(PGP_MODE_WEIGHTED, 8); break;
+      case 4: PGP_LAUNCH(PGP_MODE_WEIGHTED, 4); break;
+      default: PGP_LAUNCH(PGP_MODE_WEIGHTED, 2); break;
+    }
+  }
+#undef PGP_LAUNCH
+}
+
 int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, ScoreArgs* a) {
   if (!ctx->has_index) {
     set_error("no scene index: call pgp_set_scene first");
@@ -326,8 +401,8 @@ int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
     ctx->gate_deg_cached = gate_deg;
   }
   a->g = ctx->grid;
-  a->bitmap = ctx->d_bitmap.as<uint32_t>();
-  a->cell_start = ctx->d_cell_start.as<uint32_t>();
+  a->words = ctx->d_bitmap.as<uint2>();
+  a->occ_start = ctx->d_occ_start.as<uint32_t>();
   a->cand = ctx->d_cand.as<float4>();
   a->Pnw = ctx->d_Pnw.as<float4>();
   a->Q = ctx->d_Q.as<float4>();
@@ -393,9 +468,10 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
   int* best_local = reinterpret_cast<int*>(key + 1);
   PGP_HIP(hipMemsetAsync(key, 0, 8, stream));
   if (n_h > 0) {
-    // aim for ~16 workgroups per CU; at least 4 hypotheses per block to amortise the model load
+    // ~40 workgroups per CU (measured best at C2: hpb 8 -> 125 us vs 136 us at hpb 20); at least
+    // 4 hypotheses per block to amortise the model-point load
     long long work = (long long)n_h * a.n_tiles;
-    int hpb = (int)(work / 4096);
+    int hpb = ctx->hpb_override > 0 ? ctx->hpb_override : (int)(work / 10240);
     if (hpb < 4) hpb = 4;
     if (hpb > kMaxHpb) hpb = kMaxHpb;
     a.hpb = hpb;
@@ -418,10 +494,7 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
       ctx->ev_used += 2;
       PGP_HIP(hipEventRecord(ev0, stream));
     }
-    if (mode == PGP_MODE_PLAIN)
-      hipLaunchKernelGGL(score_hypotheses<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, a);
-    else
-      hipLaunchKernelGGL(score_hypotheses<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, a);
+    launch_variant(mode, ctx->unroll, grid, stream, a);
     if (ev1) PGP_HIP(hipEventRecord(ev1, stream));
     hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream,
                        (const int*)a.partial_cnt, (const float*)a.partial_sum, a.n_tiles, n_h, a.nQ,

@@ -7,6 +7,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -117,6 +118,8 @@ int pgp_create(pgp_ctx** out, int device_id) {
   }
   pgp_ctx* ctx = new pgp_ctx();
   ctx->device = device_id;
+  if (const char* v = getenv("PGP_UNROLL")) ctx->unroll = atoi(v);
+  if (const char* v = getenv("PGP_HPB")) ctx->hpb_override = atoi(v);
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -141,7 +144,7 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
-                    &ctx->d_bitmap, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
+                    &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
@@ -414,8 +417,9 @@ int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info) {
     info->delta = ctx->delta;
     info->n_cells = ctx->n_cells;
     info->n_candidates = ctx->n_cand;
-    info->bytes_index = (long long)((size_t)ctx->grid.nz * ctx->grid.ny * ctx->grid.nxw * 4 +
-                                    ((size_t)ctx->n_cells + 1) * 4 + (size_t)ctx->n_cand * 16);
+    info->n_occupied = ctx->n_occ;
+    info->bytes_index = (long long)((size_t)ctx->grid.nz * ctx->grid.ny * ctx->grid.nxw * 8 +
+                                    ((size_t)ctx->n_occ + 1) * 4 + (size_t)ctx->n_cand * 16);
     info->build_ms = ctx->build_ms;
   }
   return PGP_OK;

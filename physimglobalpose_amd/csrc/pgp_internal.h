@@ -56,10 +56,12 @@ struct pgp_ctx {
   bool has_index = false;
   pgp::GridDesc grid{};
   long long n_cells = 0, n_cand = 0;
-  pgp::DevBuf d_cell_start;  // uint32 [n_cells+1]
+  pgp::DevBuf d_cell_start;  // uint32 [n_cells+1]  (build-time scratch: full-grid CSR)
   pgp::DevBuf d_cell_tmp;    // uint32 [n_cells+1]  (counts, then fill cursors)
   pgp::DevBuf d_scan_tmp;    // uint32 block sums
-  pgp::DevBuf d_bitmap;      // uint32 [nz*ny*nxw]
+  pgp::DevBuf d_bitmap;      // uint2 {occupancy bits, rank base} [nz*ny*nxw]
+  pgp::DevBuf d_occ_start;   // uint32 [n_occ+1]   CSR offsets of the occupied cells only
+  long long n_occ = 0;
   pgp::DevBuf d_cand;        // float4 {x,y,z,bits(i)} [n_cand]
   float build_ms = 0.f;
 
@@ -77,6 +79,10 @@ struct pgp_ctx {
   pgp::DevBuf d_counts;   // [cap_h] int
   pgp::DevBuf d_best;     // 2 x uint64 packed argmax + {index, score bits}
   pgp::DevBuf d_hits;     // [nQ] int (pgp_registered)
+
+  // tuning knobs (env PGP_UNROLL / PGP_HPB at pgp_create; defaults chosen by measurement)
+  int unroll = 2;
+  int hpb_override = 0;
 
   // optional per-kernel timing (pgp_set_kernel_timing)
   bool timing = false;
