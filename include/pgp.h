@@ -110,6 +110,28 @@ typedef struct {
 } pgp_index_info;
 int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info);
 
+/* Replaces `sampled_Q_3D_ = Q` (base.cc:236): the sparse search model whose points the
+ * congruent quads index.  Host pointer, synchronous. */
+int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n);
+
+/* Replaces ComputeRigidTransformFromCongruentPair + ComputeRigidTransformation
+ * (base.cc:1411-1488, 1504-1614) for n congruent pairs.  base_ids[n][4] index the scene cloud
+ * (base_3D_ ids), quad_ids[n][4] the search model; only the first three of each are used, as in
+ * the reference.  Outputs (host, caller-owned, any of pose/rms nullable):
+ *   T[n][16]     centred transform, column-major float = what allTransforms receives (:1468)
+ *   pose[n][16]  de-centred transform as double, column-major = allPose[i].first (:1484)
+ *   status[n]    1 pushed | 0 rejected (non-orthogonal / rms) | 2 degenerate input | -1 bad index
+ *   rms[n]
+ * Entries with status != 1 hold NaN transforms (they score 0); the reference simply does not
+ * push them -- compact by status to reproduce its lists. */
+int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_ids, int n,
+                             const float centroid_P[3], const float centroid_Q[3], float* T,
+                             double* pose, int* status, float* rms);
+/* Same with device pointers on `stream` (ids as int4 arrays; d_pose / d_rms nullable). */
+int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n,
+                                    const float centroid_P[3], const float centroid_Q[3], float* d_T,
+                                    double* d_pose, int* d_status, float* d_rms, void* stream);
+
 /* Per-kernel timing for bench.py's roofline line: when enabled, every pgp_score_lcp[_device]
  * call brackets its dominant kernel (score_hypotheses) with a pair of HIP events on the SAME
  * stream it is launched on.  pgp_get_kernel_timing synchronises those events and returns the

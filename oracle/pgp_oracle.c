@@ -368,6 +368,132 @@ void orc_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int
   }
 }
 
+/* ---- rigid fit from a congruent pair (base.cc:1411-1488, 1504-1614) ---------------------- */
+
+static float sqnorm3(const float v[3]) { /* Eigen squaredNorm: x*x + (y*y + z*z) */
+  float x = v[0] * v[0], y = v[1] * v[1], z = v[2] * v[2];
+  float t = y + z;
+  return x + t;
+}
+static float dot3(const float a[3], const float b[3]) {
+  float x = a[0] * b[0], y = a[1] * b[1], z = a[2] * b[2];
+  float t = y + z;
+  return x + t;
+}
+static void normalize3(float v[3]) { /* Eigen normalize(): z = squaredNorm; if z > 0: v /= sqrt(z) */
+  float z = sqnorm3(v);
+  if (z > 0.f) {
+    float n = sqrtf(z);
+    v[0] = v[0] / n;
+    v[1] = v[1] / n;
+    v[2] = v[2] / n;
+  }
+}
+static void cross3(const float a[3], const float b[3], float o[3]) {
+  float t0 = a[1] * b[2], t1 = a[2] * b[1];
+  float t2 = a[2] * b[0], t3 = a[0] * b[2];
+  float t4 = a[0] * b[1], t5 = a[1] * b[0];
+  o[0] = t0 - t1;
+  o[1] = t2 - t3;
+  o[2] = t4 - t5;
+}
+/* Gram-Schmidt frame of base.cc:1532-1546; returns 0 on the degenerate exits */
+static int frame3(const float a0[3], const float a1[3], const float a2[3], float v1[3], float v2[3],
+                  float v3[3]) {
+  float d[3], proj;
+  for (int k = 0; k < 3; ++k) v1[k] = a1[k] - a0[k];
+  if (sqnorm3(v1) == 0) return 0;
+  normalize3(v1);
+  for (int k = 0; k < 3; ++k) d[k] = a2[k] - a0[k];
+  proj = dot3(d, v1);
+  for (int k = 0; k < 3; ++k) {
+    float t = proj * v1[k];
+    v2[k] = d[k] - t;
+  }
+  if (sqnorm3(v2) == 0) return 0;
+  normalize3(v2);
+  cross3(v1, v2, v3);
+  return 1;
+}
+
+int orc_rigid_from_pair(const float* p, const float* q, const float centroid_P[3],
+                        const float centroid_Q[3], float* T_centred, double* pose, float* rms_out) {
+  const float kLargeNumber = 1e9f, kSmallNumber = 1e-6f;
+  float c1[3], c2[3];
+  for (int k = 0; k < 3; ++k) { /* (b1 + b2 + b3) / 3 */
+    float s1 = p[k] + p[3 + k];
+    s1 = s1 + p[6 + k];
+    c1[k] = s1 / 3.0f;
+    float s2 = q[k] + q[3 + k];
+    s2 = s2 + q[6 + k];
+    c2[k] = s2 / 3.0f;
+  }
+  if (rms_out) *rms_out = kLargeNumber;
+  float p1[3], p2[3], p3[3], q1[3], q2[3], q3[3];
+  if (!frame3(p, p + 3, p + 6, p1, p2, p3)) return 2;
+  if (!frame3(q, q + 3, q + 6, q1, q2, q3)) return 2;
+  /* rotation = rotate_p^T * rotate_q : R(i,j) = p1_i q1_j + (p2_i q2_j + p3_i q3_j) */
+  float R[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float a = p1[i] * q1[j], b = p2[i] * q2[j], c = p3[i] * q3[j];
+      float bc = b + c;
+      R[i][j] = a + bc;
+    }
+  for (int i = 0; i < 3; ++i) { /* diag(R*R) - 1 > 1e-6 -> reject */
+    float a = R[i][0] * R[0][i], b = R[i][1] * R[1][i], c = R[i][2] * R[2][i];
+    float bc = b + c;
+    float d = a + bc;
+    if (d - 1.0f > kSmallNumber) return 0;
+  }
+  float rms = 0.f;
+  for (int i = 0; i < 3; ++i) {
+    float first[3], tr[3], e[3];
+    for (int k = 0; k < 3; ++k) first[k] = 1.0f * q[3 * i + k] - c2[k];
+    for (int r = 0; r < 3; ++r) {
+      float a = R[r][0] * first[0], b = R[r][1] * first[1], c = R[r][2] * first[2];
+      float bc = b + c;
+      tr[r] = a + bc;
+    }
+    for (int k = 0; k < 3; ++k) {
+      float t = tr[k] - p[3 * i + k];
+      e[k] = t + c1[k];
+    }
+    rms += sqrtf(sqnorm3(e));
+  }
+  rms /= 4.0f;
+  if (rms_out) *rms_out = rms;
+  /* etrans = translate(c1) * rotate(R) * translate(-c2): t_r = c1_r + (R_r0*(-c2_0) + (R_r1*(-c2_1) + R_r2*(-c2_2))) */
+  float t[3];
+  for (int r = 0; r < 3; ++r) {
+    float a = R[r][0] * (-c2[0]), b = R[r][1] * (-c2[1]), c = R[r][2] * (-c2[2]);
+    float bc = b + c;
+    float s = a + bc;
+    t[r] = c1[r] + s;
+  }
+  if (!(rms >= 0.f)) return 0; /* base.cc:1467 `ok && rms >= 0` (false for NaN) */
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) T_centred[4 * c + r] = (r == c) ? 1.f : 0.f;
+  for (int r = 0; r < 3; ++r) {
+    for (int c = 0; c < 3; ++c) T_centred[4 * c + r] = R[r][c];
+    T_centred[12 + r] = t[r];
+  }
+  /* de-centring (base.cc:1474-1482): col(3) = (c1 + cP) - L*(c2 + cQ) */
+  float u[3], tw[3];
+  for (int k = 0; k < 3; ++k) u[k] = c2[k] + centroid_Q[k];
+  for (int r = 0; r < 3; ++r) {
+    float a = R[r][0] * u[0], b = R[r][1] * u[1], c = R[r][2] * u[2];
+    float bc = b + c;
+    float s = a + bc;
+    float l = c1[r] + centroid_P[r];
+    tw[r] = l - s;
+  }
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) pose[4 * c + r] = (double)T_centred[4 * c + r];
+  for (int r = 0; r < 3; ++r) pose[12 + r] = (double)tw[r];
+  return 1;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

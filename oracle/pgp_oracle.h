@@ -83,6 +83,17 @@ void orc_score_batch(const orc_kdtree* kd, const float* P_xyz, const float* P_nr
 void orc_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int nQv,
                 float centroid_P[3], float centroid_Q[3]);
 
+/* base.cc:1411-1488 (ComputeRigidTransformFromCongruentPair) + base.cc:1504-1614
+ * (ComputeRigidTransformation, computeScale = false, max_angle < 0 as shipped) for ONE pair:
+ * p[4][3] base points (centred P frame), q[4][3] congruent quad points (centred Q frame).
+ * Returns 1 = transform pushed (T_centred: 16 floats col-major; pose: 16 doubles col-major),
+ * 0 = rejected (non-orthogonal), 2 = degenerate input (the reference's `return kLargeNumber`).
+ * The centred transform is bit-exact Eigen order; the de-centred translation uses the linear
+ * part itself where the reference multiplies the polar factors rot*scale of an SVD
+ * (computeRotationScaling, base.cc:1480-1481): equal up to float rounding (~1e-7). */
+int orc_rigid_from_pair(const float* p, const float* q, const float centroid_P[3],
+                        const float centroid_Q[3], float* T_centred, double* pose, float* rms_out);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

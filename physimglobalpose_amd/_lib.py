@@ -38,6 +38,12 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_registered": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _i, _i]),
     "pgp_running_best": (C.c_int, [_f, C.c_int, _i, _i]),
+    "pgp_set_search_model": (C.c_int, [C.c_void_p, _f, C.c_int]),
+    "pgp_rigid_from_congruent": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, _f,
+                                           C.POINTER(C.c_double), _i, _f]),
+    "pgp_rigid_from_congruent_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _f, _f,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                  C.c_void_p]),
     "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),
     "pgp_get_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),

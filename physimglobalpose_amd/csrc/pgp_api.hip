@@ -145,7 +145,8 @@ int pgp_destroy(pgp_ctx* ctx) {
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
-                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits};
+                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
+                    &ctx->d_rig};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
@@ -370,6 +371,69 @@ int pgp_running_best(const float* scores, int n_h, int* selected, int* n_selecte
       selected[k++] = i;
     }
   *n_selected = k;
+  return PGP_OK;
+}
+
+int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
+  if (!ctx || n < 0 || (n > 0 && !xyz)) {
+    set_error("pgp_set_search_model: bad argument (n=%d)", n);
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  std::vector<float4> hq((size_t)std::max(n, 1));
+  for (int i = 0; i < n; ++i)
+    hq[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],
+                        __builtin_bit_cast(float, i));
+  int rc = ctx->d_Qs.ensure(hq.size() * sizeof(float4));
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_Qs.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->nQs = n;
+  return PGP_OK;
+}
+
+int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n,
+                                    const float centroid_P[3], const float centroid_Q[3], float* d_T,
+                                    double* d_pose, int* d_status, float* d_rms, void* stream) {
+  if (!ctx || n < 0 || !centroid_P || !centroid_Q || (n > 0 && (!d_base_ids || !d_quad_ids || !d_T || !d_status))) {
+    set_error("pgp_rigid_from_congruent_device: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_rigid(ctx, d_base_ids, d_quad_ids, n, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms,
+                      static_cast<hipStream_t>(stream));
+}
+
+int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_ids, int n,
+                             const float centroid_P[3], const float centroid_Q[3], float* T,
+                             double* pose, int* status, float* rms) {
+  if (!ctx || n < 0 || !centroid_P || !centroid_Q || (n > 0 && (!base_ids || !quad_ids || !T || !status))) {
+    set_error("pgp_rigid_from_congruent: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)n;
+  int rc;
+  if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  // layout of the staged outputs: pose (double, first for alignment) | T | rms | status
+  if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
+  int* d_b = ctx->d_ids.as<int>();
+  int* d_q = d_b + 4 * N;
+  double* d_pose = ctx->d_rig.as<double>();
+  float* d_T = reinterpret_cast<float*>(d_pose + 16 * N);
+  float* d_rms = d_T + 16 * N;
+  int* d_status = reinterpret_cast<int*>(d_rms + N);
+  PGP_HIP(hipMemcpyAsync(d_b, base_ids, N * 16, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_q, quad_ids, N * 16, hipMemcpyHostToDevice, st));
+  rc = launch_rigid(ctx, d_b, d_q, n, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms, st);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(T, d_T, N * 64, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemcpyAsync(status, d_status, N * 4, hipMemcpyDeviceToHost, st));
+  if (pose) PGP_HIP(hipMemcpyAsync(pose, d_pose, N * 128, hipMemcpyDeviceToHost, st));
+  if (rms) PGP_HIP(hipMemcpyAsync(rms, d_rms, N * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
   return PGP_OK;
 }
 

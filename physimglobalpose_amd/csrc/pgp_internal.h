@@ -71,6 +71,12 @@ struct pgp_ctx {
   pgp::DevBuf d_Q;       // float4 {x,y,z,bits(orig i)} in Morton order [nQ]
   pgp::DevBuf d_Qn;      // float4 {nx,ny,nz,0}          in Morton order [nQ]
 
+  // search model (congruent-set side, sampled_Q_3D_)
+  int nQs = 0;
+  pgp::DevBuf d_Qs;      // float4 {x,y,z,bits(i)} original order [nQs]
+  pgp::DevBuf d_ids;     // staged int4 base / quad ids (host API)
+  pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
+
   // scoring workspace
   int cap_h = 0;
   pgp::DevBuf d_T;        // staged transforms (host API)            [cap_h*16] float
@@ -106,5 +112,10 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream);
 void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
+
+// rigid_fit.hip
+int launch_rigid(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n, const float cP[3],
+                 const float cQ[3], float* d_T, double* d_pose, int* d_status, float* d_rms,
+                 hipStream_t stream);
 
 }  // namespace pgp

@@ -89,6 +89,29 @@ class LcpScorer:
         self.set_scene(P_xyz, P_nrm, P_w, delta)
         self.set_model(Q_xyz, Q_nrm)
 
+    # ---- rigid fit from congruent pairs (base.cc:1411-1488) ----------------------------------------
+    def set_search_model(self, xyz):
+        xyz = _f32(xyz, 3)
+        _lib.check(self._lib.pgp_set_search_model(self._h, _fp(xyz), len(xyz)))
+        self.nQs = len(xyz)
+
+    def rigid_from_congruent(self, base_ids, quad_ids, centroid_P, centroid_Q):
+        """base_ids, quad_ids: (n,4) int.  Returns (T (n,16) f32, pose (n,16) f64, status (n,), rms (n,))
+        for every pair; keep status == 1 to get the reference's allTransforms / allPose lists."""
+        b = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        q = np.ascontiguousarray(quad_ids, np.int32).reshape(-1, 4)
+        assert len(b) == len(q)
+        n = len(b)
+        cP, cQ = _f32(centroid_P).reshape(3), _f32(centroid_Q).reshape(3)
+        T = np.zeros((n, 16), np.float32)
+        pose = np.zeros((n, 16), np.float64)
+        status = np.zeros(n, np.int32)
+        rms = np.zeros(n, np.float32)
+        _lib.check(self._lib.pgp_rigid_from_congruent(
+            self._h, b.ctypes.data_as(_i), q.ctypes.data_as(_i), n, _fp(cP), _fp(cQ), _fp(T),
+            pose.ctypes.data_as(C.POINTER(C.c_double)), status.ctypes.data_as(_i), _fp(rms)))
+        return T, pose, status, rms
+
     # ---- verification loop -----------------------------------------------------------------------
     def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         """T: (n_h,16) column-major float transforms.  Returns (scores, counts, best_index, best_score)."""

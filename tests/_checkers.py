@@ -69,6 +69,7 @@ def oracle_lib():
         L.orc_score_batch.argtypes = [C.c_void_p, _f, _f, _f, C.c_int, _f, _f, C.c_int, _f, C.c_int,
                                       C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, _f, _i, _i, _i]
         L.orc_center.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]
+        L.orc_rigid_from_pair.argtypes = [_f, _f, _f, _f, _f, _d, _f]
         _oracle = L
     return _oracle
 
@@ -129,6 +130,28 @@ class Oracle:
                                int(mode), C.c_float(gate_deg), int(early_out), int(threads),
                                _fp(scores), C.byref(best), _ip(sel), C.byref(nsel))
         return scores, best.value, sel[: nsel.value].copy()
+
+
+def oracle_rigid_from_pairs(P_xyz, Qs_xyz, base_ids, quad_ids, cP, cQ):
+    """orc_rigid_from_pair over a batch: returns (T, pose, status, rms) like the C ABI."""
+    L = oracle_lib()
+    P, Qs = _f32(P_xyz), _f32(Qs_xyz)
+    cP, cQ = _f32(cP), _f32(cQ)
+    n = len(base_ids)
+    T = np.full((n, 16), np.nan, np.float32)
+    pose = np.full((n, 16), np.nan, np.float64)
+    status = np.zeros(n, np.int32)
+    rms = np.zeros(n, np.float32)
+    for i in range(n):
+        p = np.ascontiguousarray(P[np.asarray(base_ids[i])])
+        q = np.ascontiguousarray(Qs[np.asarray(quad_ids[i])])
+        t16, p16, r = np.zeros(16, np.float32), np.zeros(16, np.float64), C.c_float(0)
+        status[i] = L.orc_rigid_from_pair(_fp(p), _fp(q), _fp(cP), _fp(cQ), _fp(t16),
+                                          p16.ctypes.data_as(_d), C.byref(r))
+        rms[i] = r.value
+        if status[i] == 1:
+            T[i], pose[i] = t16, p16
+    return T, pose, status, rms
 
 
 def have_ref():

@@ -80,3 +80,18 @@ def test_normal_gate_fixture_has_nan_rejections():
     assert g["counts"][0] == len(g["Q"])
     n_reg = g["reg_off"][1] - g["reg_off"][0]
     assert 0 < n_reg < len(g["Q"])
+
+
+def test_rigid_fit_oracle_matches_golden():
+    """ComputeRigidTransformFromCongruentPair restatement vs the Eigen-backed harness: status,
+    centred 4x4 and rms bit-exact; de-centred pose to 1e-6 (SVD polar factors in the reference)."""
+    from _checkers import oracle_rigid_from_pairs
+    g = np.load(os.path.join(GOLD, "rigid_fit.npz"))
+    n = len(g["p"])
+    ids = np.arange(4 * n).reshape(n, 4)
+    T, pose, status, rms = oracle_rigid_from_pairs(g["p"].reshape(-1, 3), g["q"].reshape(-1, 3), ids, ids,
+                                                   g["centroid_P"], g["centroid_Q"])
+    assert np.array_equal(status, g["status"])
+    ok = status == 1
+    assert np.array_equal(T[ok], g["T"][ok]) and np.array_equal(rms[ok], g["rms"][ok])
+    assert np.abs(pose[ok] - g["pose"][ok]).max() < 1e-6
