@@ -132,6 +132,32 @@ int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const i
                                     const float centroid_P[3], const float centroid_Q[3], float* d_T,
                                     double* d_pose, int* d_status, float* d_rms, void* stream);
 
+/* ICP refinement.  Replaces the inner loop behind pcl::recognition::TrimmedICP::align
+ * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and
+ * pcl::IterativeClosestPoint::align (utilities.cpp:697-703; PPE/data_layer/SceneCfg.cpp:101,135-141)
+ * for a batch of n initial guesses at once.  PCL is not vendored in the reference, so the
+ * arithmetic is this library's own statement of the algorithm: nearest neighbour by
+ * exhaustive search, keep the |trim*n_src| closest pairs (or those within max_corr_dist), Horn's
+ * closed-form rigid update, repeat while mean-squared-distance / previous < energy_ratio. */
+typedef struct {
+  int max_iterations;    /* <= 0: 100 (utilities.cpp:698); TrimmedICP itself is unbounded */
+  float trim_fraction;   /* (0,1]: k = (int)|trim * n_src| (UCTState.cpp:176,194); 1 = use all */
+  float max_corr_dist;   /* > 0: drop pairs farther than this instead of trimming (State.cpp:139) */
+  float energy_ratio;    /* setNewToOldEnergyRatio: 1.0 at the call sites (UCTState.cpp:139) */
+} pgp_icp_params;
+
+/* src: points that are moved (the scene segment in the reference), tgt: the cloud searched for
+ * neighbours (the model).  T[n][16]: column-major float, source frame -> target frame; initial
+ * guesses in, refined transforms out (UCTState.cpp:184-203 inverts the pose before and after).
+ * energy[n] (nullable): final mean squared distance of the selected pairs; iters[n] (nullable).
+ * Host pointers, synchronous. */
+int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt,
+                   float* T, int n, const pgp_icp_params* params, float* energy, int* iters);
+/* Device pointers: d_src / d_tgt are float4 arrays {x,y,z,-}; asynchronous on `stream`. */
+int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
+                          float* d_T, int n, const pgp_icp_params* params, float* d_energy,
+                          int* d_iters, void* stream);
+
 /* Per-kernel timing for bench.py's roofline line: when enabled, every pgp_score_lcp[_device]
  * call brackets its dominant kernel (score_hypotheses) with a pair of HIP events on the SAME
  * stream it is launched on.  pgp_get_kernel_timing synchronises those events and returns the

@@ -494,6 +494,151 @@ int orc_rigid_from_pair(const float* p, const float* q, const float centroid_P[3
   return 1;
 }
 
+/* ---- trimmed ICP (own definition; PCL absent) --------------------------------------------- */
+
+typedef struct { float d2; int i; } icp_pair;
+
+static int icp_cmp(const void* a, const void* b) {
+  const icp_pair* x = (const icp_pair*)a;
+  const icp_pair* y = (const icp_pair*)b;
+  if (x->d2 < y->d2) return -1;
+  if (x->d2 > y->d2) return 1;
+  return (x->i > y->i) - (x->i < y->i); /* ties: lowest source index first */
+}
+
+static void jacobi_eig4(double A[4][4], double q[4]) {
+  double V[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 4; ++p)
+      for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int r = p + 1; r < 4; ++r) {
+        double apr = A[p][r];
+        if (apr == 0.0) continue;
+        double theta = (A[r][r] - A[p][p]) / (2.0 * apr);
+        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) {
+          double akp = A[k][p], akr = A[k][r];
+          A[k][p] = c * akp - s * akr;
+          A[k][r] = s * akp + c * akr;
+        }
+        for (int k = 0; k < 4; ++k) {
+          double apk = A[p][k], ark = A[r][k];
+          A[p][k] = c * apk - s * ark;
+          A[r][k] = s * apk + c * ark;
+        }
+        for (int k = 0; k < 4; ++k) {
+          double vkp = V[k][p], vkr = V[k][r];
+          V[k][p] = c * vkp - s * vkr;
+          V[k][r] = s * vkp + c * vkr;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (A[k][k] > A[best][best]) best = k;
+  for (int k = 0; k < 4; ++k) q[k] = V[k][best];
+}
+
+int orc_icp(const float* src, int n_src, const float* tgt, int n_tgt, float* T, int max_iterations,
+            float trim_fraction, float max_corr_dist, float energy_ratio, float* energy_out) {
+  if (max_iterations <= 0) max_iterations = 100;
+  if (!(trim_fraction > 0.f) || trim_fraction > 1.f) trim_fraction = 1.f;
+  int k = (int)fabsf(trim_fraction * (float)n_src);
+  if (k < 1) k = 1;
+  if (k > n_src) k = n_src;
+  const float cap2 = max_corr_dist > 0.f ? max_corr_dist * max_corr_dist : -1.f;
+  const double ratio = energy_ratio > 0.f ? (double)energy_ratio : 1.0;
+  icp_pair* pr = (icp_pair*)malloc(sizeof(icp_pair) * (size_t)(n_src > 0 ? n_src : 1));
+  int* nn = (int*)malloc(sizeof(int) * (size_t)(n_src > 0 ? n_src : 1));
+  double E_old = (double)FLT_MAX, E = 0.0;
+  int it = 0;
+  for (;;) {
+    for (int i = 0; i < n_src; ++i) {
+      float x[3];
+      orc_transform_point(T, src + 3 * i, x);
+      float best = FLT_MAX;
+      int bj = -1;
+      for (int j = 0; j < n_tgt; ++j) {
+        float d = orc_sqdist(x, tgt + 3 * j);
+        if (d < best) {
+          best = d;
+          bj = j;
+        }
+      }
+      pr[i].d2 = best;
+      pr[i].i = i;
+      nn[i] = bj;
+    }
+    int n_sel;
+    if (cap2 >= 0.f) {
+      n_sel = 0;
+      for (int i = 0; i < n_src; ++i)
+        if (pr[i].d2 <= cap2) pr[n_sel++] = pr[i];
+    } else {
+      if (k < n_src) qsort(pr, (size_t)n_src, sizeof(icp_pair), icp_cmp);
+      n_sel = k;
+    }
+    double red[16] = {0};
+    double e = 0.0;
+    for (int s = 0; s < n_sel; ++s) {
+      int i = pr[s].i, j = nn[i];
+      if (j < 0) continue;
+      const float* a = src + 3 * i;
+      const float* m = tgt + 3 * j;
+      red[0] += 1.0;
+      for (int c = 0; c < 3; ++c) {
+        red[1 + c] += a[c];
+        red[4 + c] += m[c];
+        for (int d = 0; d < 3; ++d) red[7 + 3 * c + d] += (double)a[c] * m[d];
+      }
+      e += (double)pr[s].d2;
+    }
+    E = red[0] >= 1.0 ? e / red[0] : 0.0;
+    if (red[0] >= 1.0) {
+      double n = red[0], sb[3], mb[3], S[3][3];
+      for (int c = 0; c < 3; ++c) {
+        sb[c] = red[1 + c] / n;
+        mb[c] = red[4 + c] / n;
+      }
+      for (int c = 0; c < 3; ++c)
+        for (int d = 0; d < 3; ++d) S[c][d] = red[7 + 3 * c + d] - n * sb[c] * mb[d];
+      double N[4][4] = {
+          {S[0][0] + S[1][1] + S[2][2], S[1][2] - S[2][1], S[2][0] - S[0][2], S[0][1] - S[1][0]},
+          {S[1][2] - S[2][1], S[0][0] - S[1][1] - S[2][2], S[0][1] + S[1][0], S[2][0] + S[0][2]},
+          {S[2][0] - S[0][2], S[0][1] + S[1][0], -S[0][0] + S[1][1] - S[2][2], S[1][2] + S[2][1]},
+          {S[0][1] - S[1][0], S[2][0] + S[0][2], S[1][2] + S[2][1], -S[0][0] - S[1][1] + S[2][2]}};
+      double q[4];
+      jacobi_eig4(N, q);
+      double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+      if (nq > 0.0) {
+        double w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
+        double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                          {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                          {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+        for (int r = 0; r < 3; ++r) {
+          double t = mb[r] - (R[r][0] * sb[0] + R[r][1] * sb[1] + R[r][2] * sb[2]);
+          for (int c = 0; c < 3; ++c) T[4 * c + r] = (float)R[r][c];
+          T[12 + r] = (float)t;
+        }
+        T[3] = T[7] = T[11] = 0.f;
+        T[15] = 1.f;
+      }
+    }
+    ++it;
+    int go = (it < max_iterations) && (E / E_old < ratio);
+    E_old = E;
+    if (!go) break;
+  }
+  if (energy_out) *energy_out = (float)E;
+  free(pr);
+  free(nn);
+  return it;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -94,6 +94,17 @@ void orc_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int
 int orc_rigid_from_pair(const float* p, const float* q, const float centroid_P[3],
                         const float centroid_Q[3], float* T_centred, double* pose, float* rms_out);
 
+/* Trimmed point-to-point ICP, the library's own statement of the algorithm behind
+ * pcl::recognition::TrimmedICP::align / pcl::IterativeClosestPoint::align (call sites:
+ * PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-703).
+ * PARITY UNPINNED against PCL (not vendored, version unpinned: SURVEY 8c); this restatement pins
+ * the HIP kernel.  Definition: see physimglobalpose_amd/csrc/icp.hip header.  T (16 floats,
+ * col-major, source->target) is refined in place; returns the iteration count; *energy = final
+ * mean squared distance of the selected pairs. */
+int orc_icp(const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt, float* T,
+            int max_iterations, float trim_fraction, float max_corr_dist, float energy_ratio,
+            float* energy);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -23,6 +23,11 @@ class IndexInfo(C.Structure):
                 ("n_occupied", C.c_longlong), ("bytes_index", C.c_longlong), ("build_ms", C.c_float)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("trim_fraction", C.c_float),
+                ("max_corr_dist", C.c_float), ("energy_ratio", C.c_float)]
+
+
 # every symbol include/pgp.h declares: (restype, argtypes)
 SIGNATURES = {
     "pgp_version": (C.c_int, []),
@@ -44,6 +49,10 @@ SIGNATURES = {
     "pgp_rigid_from_congruent_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _f, _f,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p]),
+    "pgp_icp_refine": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _f, C.c_int,
+                                 C.POINTER(IcpParams), _f, _i]),
+    "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_int, C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),
     "pgp_get_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),

@@ -1,0 +1,381 @@
+// csrc/icp.hip -- batched (trimmed) point-to-point ICP refinement on gfx950.
+//
+// Replaces the ICP inner loop the reference reaches through PCL / libpointmatcher:
+//   pcl::recognition::TrimmedICP::align    PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194
+//                                          PPE/misc/utilities.cpp:666-676
+//   pcl::IterativeClosestPoint::align      PPE/misc/utilities.cpp:697-703, PPE/data_layer/SceneCfg.cpp:101,135-141
+// PCL and libpointmatcher are not vendored in the reference (version unpinned, sources
+// absent), so there is no reference arithmetic to reproduce: this file implements the published
+// algorithm with the parameters the call sites set, and oracle/pgp_oracle.c restates the same
+// definition on the CPU ("parity unpinned" against PCL; pinned against our own oracle):
+//
+//   G <- initial guess (source frame -> target frame);  E_old <- +inf
+//   do   x_i = G s_i ; (j_i, d2_i) = nearest target point of x_i (exhaustive, ties: lowest j)
+//        S   = the k = |trim * n| source points with smallest d2 (ties: lowest i), or all with
+//              d2 <= max_corr^2 when a correspondence cap is set
+//        E   = mean_{i in S} d2_i   (|S| = k is constant when trimming: same test as PCL's sum)
+//        G   <- argmin_G sum_{i in S} |G s_i - m_{j_i}|^2      (Horn 1987, closed form)
+//   while (E / E_old < ratio, E_old <- E, iterations < max)     [ratio = 1: UCTState.cpp:139]
+//
+// Mapping to the machine: ONE WORKGROUP (1024 threads, 16 wave64) PER POSE, persistent over all
+// iterations -- poses are independent, so there is no inter-workgroup traffic at all.
+//   * NN search is a tiled exhaustive scan: a tile of 4096 target points is staged in LDS (64 KB)
+//     with coalesced 16-B loads, every lane keeps R = 4 transformed source points in VGPRs and
+//     reads each target point once as an LDS broadcast (ds_read_b128, same address in all lanes:
+//     conflict-free) => 256 distance tests per LDS read per wave; VALU-bound by design.
+//   * trimming is an exact radix select on the float bits of d2 (4 passes x 256-bin LDS
+//     histogram), deterministic tie handling by an ordered block scan;
+//   * the 3x3 cross-covariance and centroids are accumulated in f64 per thread and reduced
+//     across the block in a fixed tree (bit-reproducible), then one lane solves Horn's 4x4
+//     symmetric eigenproblem with cyclic Jacobi sweeps.
+// Algorithmic bytes per pose-iteration: 12|src| + 12|tgt| + 48 + 64.
+
+#include "pgp_internal.h"
+
+#include <cfloat>
+
+namespace pgp {
+
+namespace {
+
+constexpr int kIcpThreads = 1024;
+constexpr int kIcpR = 4;                 // source points per lane per sweep
+constexpr int kTgtTile = 4096;           // target points per LDS tile (64 KB)
+constexpr int kRed = 16;                 // doubles reduced per thread
+
+struct IcpArgs {
+  const float4* src;   // [n_src] {x,y,z,-}
+  const float4* tgt;   // [n_tgt]
+  int n_src, n_tgt;
+  float* T;            // [n][16] in/out, column-major
+  int n;
+  int max_iter, k_trim;
+  float max_corr2;     // < 0: unlimited
+  float ratio;
+  float* ws_d2;        // [n][n_src]
+  int* ws_j;           // [n][n_src]
+  float* energy;       // [n] (nullable)
+  int* iters;          // [n] (nullable)
+};
+
+__device__ __forceinline__ float row_xf(float a, float b, float c, float t, float x, float y, float z) {
+  return __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)), __fmul_rn(c, z)), t);
+}
+
+// cyclic Jacobi on a symmetric 4x4 (double); returns the eigenvector of the largest eigenvalue.
+// A and V live in LDS: the rotation planes are indexed at run time, and run-time indexed
+// private arrays would be placed in scratch memory (cdna_hip_programming.md rule 20).
+__device__ void largest_eigvec4(double (*A)[4], double (*V)[4], double q[4]) {
+  for (int p = 0; p < 4; ++p)
+    for (int r = 0; r < 4; ++r) V[p][r] = p == r ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 16; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < 4; ++p)
+      for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
+    if (off < 1e-300) break;
+    for (int p = 0; p < 3; ++p)
+      for (int r = p + 1; r < 4; ++r) {
+        double apr = A[p][r];
+        if (apr == 0.0) continue;
+        double theta = (A[r][r] - A[p][p]) / (2.0 * apr);
+        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+        for (int k = 0; k < 4; ++k) {  // A <- A J
+          double akp = A[k][p], akr = A[k][r];
+          A[k][p] = c * akp - s * akr;
+          A[k][r] = s * akp + c * akr;
+        }
+        for (int k = 0; k < 4; ++k) {  // A <- J^T A
+          double apk = A[p][k], ark = A[r][k];
+          A[p][k] = c * apk - s * ark;
+          A[r][k] = s * apk + c * ark;
+        }
+        for (int k = 0; k < 4; ++k) {
+          double vkp = V[k][p], vkr = V[k][r];
+          V[k][p] = c * vkp - s * vkr;
+          V[k][r] = s * vkp + c * vkr;
+        }
+      }
+  }
+  int best = 0;
+  for (int k = 1; k < 4; ++k)
+    if (A[k][k] > A[best][best]) best = k;
+  for (int k = 0; k < 4; ++k) q[k] = V[k][best];
+}
+
+// Horn's closed form from the f64 sums over the selected pairs:
+// red = {n, sx,sy,sz, mx,my,mz, Sxx,Sxy,Sxz, Syx,Syy,Syz, Szx,Szy,Szz}  (S_ab = sum s_a m_b)
+__device__ void solve_rigid(const double* red, float* G, double (*N)[4], double (*V)[4]) {
+  double n = red[0];
+  if (!(n >= 1.0)) return;  // nothing selected: keep G
+  double sb[3] = {red[1] / n, red[2] / n, red[3] / n}, mb[3] = {red[4] / n, red[5] / n, red[6] / n};
+  const double Sxx = red[7] - n * sb[0] * mb[0], Sxy = red[8] - n * sb[0] * mb[1], Sxz = red[9] - n * sb[0] * mb[2];
+  const double Syx = red[10] - n * sb[1] * mb[0], Syy = red[11] - n * sb[1] * mb[1], Syz = red[12] - n * sb[1] * mb[2];
+  const double Szx = red[13] - n * sb[2] * mb[0], Szy = red[14] - n * sb[2] * mb[1], Szz = red[15] - n * sb[2] * mb[2];
+  N[0][0] = Sxx + Syy + Szz; N[0][1] = Syz - Szy;       N[0][2] = Szx - Sxz;        N[0][3] = Sxy - Syx;
+  N[1][0] = Syz - Szy;       N[1][1] = Sxx - Syy - Szz; N[1][2] = Sxy + Syx;        N[1][3] = Szx + Sxz;
+  N[2][0] = Szx - Sxz;       N[2][1] = Sxy + Syx;       N[2][2] = -Sxx + Syy - Szz; N[2][3] = Syz + Szy;
+  N[3][0] = Sxy - Syx;       N[3][1] = Szx + Sxz;       N[3][2] = Syz + Szy;        N[3][3] = -Sxx - Syy + Szz;
+  double q[4];
+  largest_eigvec4(N, V, q);
+  double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (!(nq > 0.0)) return;
+  double w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
+  double R[3][3] = {{1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)},
+                    {2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)},
+                    {2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)}};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    double t = mb[r] - (R[r][0] * sb[0] + R[r][1] * sb[1] + R[r][2] * sb[2]);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) G[4 * c + r] = (float)R[r][c];
+    G[12 + r] = (float)t;
+  }
+  G[3] = G[7] = G[11] = 0.f;
+  G[15] = 1.f;
+}
+
+__global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float4* s_tgt = reinterpret_cast<float4*>(smem);                         // kTgtTile float4
+  double* s_red = reinterpret_cast<double*>(smem);                         // aliases the tile
+  __shared__ float s_G[16];
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_scan[kIcpThreads / 64];
+  __shared__ unsigned s_prefix, s_kleft, s_carry;
+  __shared__ double s_energy, s_energy_old;
+  __shared__ int s_continue;
+  __shared__ double s_N[4][4], s_V[4][4], s_sum[kRed + 1];
+
+  const int pose = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Tg = a.T + 16 * (size_t)pose;
+  float* d2w = a.ws_d2 + (size_t)pose * a.n_src;
+  int* jw = a.ws_j + (size_t)pose * a.n_src;
+  if (tid < 16) s_G[tid] = Tg[tid];
+  if (tid == 0) {
+    s_energy_old = (double)FLT_MAX;   // PCL: energy starts at numeric_limits<float>::max()
+    s_energy = 0.0;
+  }
+  __syncthreads();
+
+  int it = 0;
+  for (;;) {
+    // ---- 1. correspondences: exhaustive NN of G*s_i in the target, tiled through LDS --------
+    const float g00 = s_G[0], g10 = s_G[1], g20 = s_G[2], g01 = s_G[4], g11 = s_G[5], g21 = s_G[6],
+                g02 = s_G[8], g12 = s_G[9], g22 = s_G[10], g03 = s_G[12], g13 = s_G[13], g23 = s_G[14];
+    for (int base = 0; base < a.n_src; base += kIcpThreads * kIcpR) {
+      float x[kIcpR], y[kIcpR], z[kIcpR], best[kIcpR];
+      int bj[kIcpR];
+#pragma unroll
+      for (int r = 0; r < kIcpR; ++r) {
+        int i = base + r * kIcpThreads + tid;
+        float4 s = i < a.n_src ? a.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[r] = row_xf(g00, g01, g02, g03, s.x, s.y, s.z);
+        y[r] = row_xf(g10, g11, g12, g13, s.x, s.y, s.z);
+        z[r] = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+        best[r] = FLT_MAX;
+        bj[r] = -1;
+      }
+      for (int t0 = 0; t0 < a.n_tgt; t0 += kTgtTile) {
+        const int tn = min(kTgtTile, a.n_tgt - t0);
+        __syncthreads();  // previous tile fully consumed
+        for (int j = tid; j < tn; j += kIcpThreads) s_tgt[j] = a.tgt[t0 + j];
+        __syncthreads();
+        for (int j = 0; j < tn; ++j) {
+          const float4 m = s_tgt[j];  // broadcast read
+#pragma unroll
+          for (int r = 0; r < kIcpR; ++r) {
+            float dx = __fsub_rn(x[r], m.x), dy = __fsub_rn(y[r], m.y), dz = __fsub_rn(z[r], m.z);
+            float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
+            if (d2 < best[r]) {  // strict: the lowest j wins ties
+              best[r] = d2;
+              bj[r] = t0 + j;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kIcpR; ++r) {
+        int i = base + r * kIcpThreads + tid;
+        if (i < a.n_src) {
+          d2w[i] = best[r];
+          jw[i] = bj[r];
+        }
+      }
+    }
+    __syncthreads();  // d2w/jw visible to the block (same workgroup: global writes + barrier)
+
+    // ---- 2. selection threshold: k-th smallest d2 by radix select on the float bits ---------
+    unsigned thr_key = 0xFFFFFFFFu, ties_to_take = 0xFFFFFFFFu;  // default: take everything
+    if (a.max_corr2 < 0.f && a.k_trim < a.n_src) {
+      if (tid == 0) {
+        s_prefix = 0;
+        s_kleft = (unsigned)a.k_trim;  // rank (1-based) of the element we look for
+      }
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < a.n_src; i += kIcpThreads) {
+          unsigned key = __float_as_uint(d2w[i]);
+          if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned kleft = s_kleft, acc = 0;
+          int b = 0;
+          for (; b < 256; ++b) {
+            if (acc + s_hist[b] >= kleft) break;
+            acc += s_hist[b];
+          }
+          if (b > 255) b = 255;
+          s_kleft = kleft - acc;
+          s_prefix = prefix | ((unsigned)b << shift);
+        }
+        __syncthreads();
+      }
+      thr_key = s_prefix;        // the k-th smallest key
+      ties_to_take = s_kleft;    // how many elements equal to it belong to the k smallest
+    }
+
+    // ---- 3. f64 sums over the selected pairs (ordered tie handling), fixed-tree reduction ----
+    double acc[kRed];
+#pragma unroll
+    for (int k = 0; k < kRed; ++k) acc[k] = 0.0;
+    double e_acc = 0.0;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int base = 0; base < a.n_src; base += kIcpThreads) {
+      const int i = base + tid;
+      unsigned key = 0xFFFFFFFFu;
+      float d2 = 0.f;
+      if (i < a.n_src) {
+        d2 = d2w[i];
+        key = __float_as_uint(d2);
+      }
+      bool sel;
+      if (a.max_corr2 >= 0.f) {
+        sel = i < a.n_src && d2 <= a.max_corr2;
+      } else if (thr_key == 0xFFFFFFFFu) {
+        sel = i < a.n_src;
+      } else {
+        // ties at the threshold are taken in index order: ordered exclusive scan of the flags
+        bool tie = i < a.n_src && key == thr_key;
+        unsigned long long bm = __ballot(tie);
+        unsigned before = __popcll(bm & ((1ull << lane) - 1ull));
+        if (lane == 0) s_scan[wave] = __popcll(bm);
+        __syncthreads();
+        unsigned woff = s_carry;
+        for (int w = 0; w < wave; ++w) woff += s_scan[w];
+        sel = i < a.n_src && (key < thr_key || (tie && woff + before < ties_to_take));
+        __syncthreads();
+        if (tid == 0) {
+          unsigned tot = 0;
+          for (int w = 0; w < kIcpThreads / 64; ++w) tot += s_scan[w];
+          s_carry += tot;
+        }
+        __syncthreads();
+      }
+      const int jm = i < a.n_src ? jw[i] : -1;
+      if (sel && jm >= 0) {  // jm < 0: a non-finite transformed point has no neighbour
+        float4 s = a.src[i];
+        float4 m = a.tgt[jm];
+        acc[0] += 1.0;
+        acc[1] += s.x; acc[2] += s.y; acc[3] += s.z;
+        acc[4] += m.x; acc[5] += m.y; acc[6] += m.z;
+        acc[7] += (double)s.x * m.x; acc[8] += (double)s.x * m.y; acc[9] += (double)s.x * m.z;
+        acc[10] += (double)s.y * m.x; acc[11] += (double)s.y * m.y; acc[12] += (double)s.y * m.z;
+        acc[13] += (double)s.z * m.x; acc[14] += (double)s.z * m.y; acc[15] += (double)s.z * m.z;
+        e_acc += (double)d2;
+      }
+    }
+    // wave butterfly, then the 16 wave results through LDS (aliases the target tile: all reads of
+    // the tile finished before the barrier after step 1)
+#pragma unroll
+    for (int k = 0; k < kRed; ++k)
+      for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+    for (int off = 32; off >= 1; off >>= 1) e_acc += __shfl_xor(e_acc, off, 64);
+    __syncthreads();
+    if (lane == 0) {
+      for (int k = 0; k < kRed; ++k) s_red[wave * (kRed + 1) + k] = acc[k];
+      s_red[wave * (kRed + 1) + kRed] = e_acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 0; k <= kRed; ++k) {
+        double v = 0.0;
+        for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRed + 1) + k];
+        s_sum[k] = v;
+      }
+      const double* red = s_sum;
+      // progress is judged on the mean squared distance of the selected pairs; with a fixed
+      // trim count this is PCL's energy test (E/E_old), and it stays meaningful when a
+      // correspondence cap lets |S| change between iterations
+      const double E = red[0] >= 1.0 ? red[kRed] / red[0] : 0.0;
+      // ---- 4. closed-form update, then the progress test (PCL order: update first) ----------
+      solve_rigid(red, s_G, s_N, s_V);
+      const double E_old = s_energy_old;
+      s_energy = E;
+      s_energy_old = E;
+      s_continue = (it + 1 < a.max_iter) && (E / E_old < (double)a.ratio) ? 1 : 0;
+    }
+    __syncthreads();
+    ++it;
+    if (!s_continue) break;
+  }
+  if (tid < 16) Tg[tid] = s_G[tid];
+  if (tid == 0) {
+    if (a.energy) a.energy[pose] = (float)s_energy;
+    if (a.iters) a.iters[pose] = it;
+  }
+}
+
+}  // namespace
+
+int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,
+               int n, const pgp_icp_params* prm, float* d_energy, int* d_iters, hipStream_t stream) {
+  if (n <= 0) return PGP_OK;
+  if (n_src <= 0 || n_tgt <= 0) {
+    set_error("icp: empty source or target cloud");
+    return PGP_EINVAL;
+  }
+  IcpArgs a{};
+  a.src = d_src;
+  a.tgt = d_tgt;
+  a.n_src = n_src;
+  a.n_tgt = n_tgt;
+  a.T = d_T;
+  a.n = n;
+  a.max_iter = prm->max_iterations > 0 ? prm->max_iterations : 100;
+  float tf = prm->trim_fraction;
+  if (!(tf > 0.f) || tf > 1.f) tf = 1.f;
+  // float numPoints = trim * size; align(..., abs(numPoints), ...) -> int (UCTState.cpp:176,194)
+  int k = (int)fabsf(tf * (float)n_src);
+  if (k < 1) k = 1;
+  if (k > n_src) k = n_src;
+  a.k_trim = k;
+  a.max_corr2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : -1.f;
+  a.ratio = prm->energy_ratio > 0.f ? prm->energy_ratio : 1.f;
+  int rc;
+  size_t need = (size_t)n * n_src;
+  if ((rc = ctx->d_icp_ws.ensure(need * 8)) != PGP_OK) return rc;
+  a.ws_d2 = ctx->d_icp_ws.as<float>();
+  a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
+  a.energy = d_energy;
+  a.iters = d_iters;
+  const size_t lds = (size_t)kTgtTile * sizeof(float4);
+  static bool attr_set = false;
+  if (!attr_set) {
+    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(icp_refine, dim3(n), dim3(kIcpThreads), lds, stream, a);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+}  // namespace pgp

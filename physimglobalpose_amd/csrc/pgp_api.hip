@@ -146,7 +146,7 @@ int pgp_destroy(pgp_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
-                    &ctx->d_rig};
+                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
@@ -433,6 +433,55 @@ int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_
   PGP_HIP(hipMemcpyAsync(status, d_status, N * 4, hipMemcpyDeviceToHost, st));
   if (pose) PGP_HIP(hipMemcpyAsync(pose, d_pose, N * 128, hipMemcpyDeviceToHost, st));
   if (rms) PGP_HIP(hipMemcpyAsync(rms, d_rms, N * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  return PGP_OK;
+}
+
+int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
+                          float* d_T, int n, const pgp_icp_params* params, float* d_energy,
+                          int* d_iters, void* stream) {
+  if (!ctx || !params || n < 0 || n_src < 0 || n_tgt < 0 || (n > 0 && (!d_src4 || !d_tgt4 || !d_T))) {
+    set_error("pgp_icp_refine_device: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src,
+                    reinterpret_cast<const float4*>(d_tgt4), n_tgt, d_T, n, params, d_energy, d_iters,
+                    static_cast<hipStream_t>(stream));
+}
+
+int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt,
+                   float* T, int n, const pgp_icp_params* params, float* energy, int* iters) {
+  if (!ctx || !params || n < 0 || n_src < 0 || n_tgt < 0 ||
+      (n > 0 && (!T || (n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz)))) {
+    set_error("pgp_icp_refine: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  auto pack = [](const float* xyz, int m) {
+    std::vector<float4> v((size_t)std::max(m, 1));
+    for (int i = 0; i < m; ++i) v[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+    return v;
+  };
+  std::vector<float4> hs = pack(src_xyz, n_src), ht = pack(tgt_xyz, n_tgt);
+  int rc;
+  if ((rc = ctx->d_icp_src.ensure(hs.size() * 16)) != PGP_OK) return rc;
+  if ((rc = ctx->d_icp_tgt.ensure(ht.size() * 16)) != PGP_OK) return rc;
+  if ((rc = ctx->d_icp_T.ensure((size_t)n * 64)) != PGP_OK) return rc;
+  if ((rc = ctx->d_icp_out.ensure((size_t)n * 8)) != PGP_OK) return rc;
+  float* d_energy = ctx->d_icp_out.as<float>();
+  int* d_iters = reinterpret_cast<int*>(d_energy + n);
+  PGP_HIP(hipMemcpyAsync(ctx->d_icp_src.p, hs.data(), (size_t)n_src * 16, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(ctx->d_icp_T.p, T, (size_t)n * 64, hipMemcpyHostToDevice, st));
+  rc = launch_icp(ctx, ctx->d_icp_src.as<float4>(), n_src, ctx->d_icp_tgt.as<float4>(), n_tgt,
+                  ctx->d_icp_T.as<float>(), n, params, d_energy, d_iters, st);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(T, ctx->d_icp_T.p, (size_t)n * 64, hipMemcpyDeviceToHost, st));
+  if (energy) PGP_HIP(hipMemcpyAsync(energy, d_energy, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  if (iters) PGP_HIP(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
   return PGP_OK;
 }

@@ -77,6 +77,9 @@ struct pgp_ctx {
   pgp::DevBuf d_ids;     // staged int4 base / quad ids (host API)
   pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
 
+  // ICP (host API staging + per-pose correspondence workspace)
+  pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_T, d_icp_out, d_icp_ws;
+
   // scoring workspace
   int cap_h = 0;
   pgp::DevBuf d_T;        // staged transforms (host API)            [cap_h*16] float
@@ -112,6 +115,10 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream);
 void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
+
+// icp.hip
+int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,
+               int n, const pgp_icp_params* prm, float* d_energy, int* d_iters, hipStream_t stream);
 
 // rigid_fit.hip
 int launch_rigid(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n, const float cP[3],

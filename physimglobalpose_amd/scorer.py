@@ -112,6 +112,20 @@ class LcpScorer:
             pose.ctypes.data_as(C.POINTER(C.c_double)), status.ctypes.data_as(_i), _fp(rms)))
         return T, pose, status, rms
 
+    # ---- ICP refinement (UCTState::performTrICP / utilities::performICP inner loop) --------------
+    def icp_refine(self, src_xyz, tgt_xyz, T, trim=1.0, max_iterations=100, max_corr_dist=0.0,
+                   energy_ratio=1.0):
+        """T: (n,16) column-major guesses (source -> target frame).  Returns (T_refined, energy, iters)."""
+        src, tgt = _f32(src_xyz, 3), _f32(tgt_xyz, 3)
+        T = np.array(_f32(T, 16), copy=True)
+        n = len(T)
+        prm = _lib.IcpParams(int(max_iterations), float(trim), float(max_corr_dist), float(energy_ratio))
+        energy = np.zeros(n, np.float32)
+        iters = np.zeros(n, np.int32)
+        _lib.check(self._lib.pgp_icp_refine(self._h, _fp(src), len(src), _fp(tgt), len(tgt), _fp(T), n,
+                                            C.byref(prm), _fp(energy), iters.ctypes.data_as(_i)))
+        return T, energy, iters
+
     # ---- verification loop -----------------------------------------------------------------------
     def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         """T: (n_h,16) column-major float transforms.  Returns (scores, counts, best_index, best_score)."""

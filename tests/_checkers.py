@@ -70,6 +70,7 @@ def oracle_lib():
                                       C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, _f, _i, _i, _i]
         L.orc_center.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]
         L.orc_rigid_from_pair.argtypes = [_f, _f, _f, _f, _f, _d, _f]
+        L.orc_icp.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, C.c_float, C.c_float, C.c_float, _f]
         _oracle = L
     return _oracle
 
@@ -152,6 +153,21 @@ def oracle_rigid_from_pairs(P_xyz, Qs_xyz, base_ids, quad_ids, cP, cQ):
         if status[i] == 1:
             T[i], pose[i] = t16, p16
     return T, pose, status, rms
+
+
+def oracle_icp(src, tgt, T, trim=1.0, max_iterations=100, max_corr_dist=0.0, energy_ratio=1.0):
+    """orc_icp over a batch of guesses: returns (T_refined, energy, iters)."""
+    L = oracle_lib()
+    src, tgt = _f32(src), _f32(tgt)
+    T = np.array(_f32(T).reshape(-1, 16), copy=True)
+    energy = np.zeros(len(T), np.float32)
+    iters = np.zeros(len(T), np.int32)
+    for h in range(len(T)):
+        e = C.c_float(0)
+        iters[h] = L.orc_icp(_fp(src), len(src), _fp(tgt), len(tgt), _fp(T[h]), int(max_iterations),
+                             C.c_float(trim), C.c_float(max_corr_dist), C.c_float(energy_ratio), C.byref(e))
+        energy[h] = e.value
+    return T, energy, iters
 
 
 def have_ref():
