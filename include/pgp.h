@@ -132,6 +132,23 @@ int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const i
                                     const float centroid_P[3], const float centroid_Q[3], float* d_T,
                                     double* d_pose, int* d_status, float* d_rms, void* stream);
 
+/* Replaces MatchSuper4PCS::ExtractPairs (S4/algorithms/super4pcs.cc:193-236; operMode 0) over the
+ * search model set by pgp_set_search_model: every ordered pair (a,b), a != b, with
+ * | |q_a - q_b| - pair_distance | <= eps (no normal / colour / angle gates, as the fork sets
+ * them), written as (j,i),(i,j) for i > j in (i,j) order.  pairs: cap x 2 ints; *n_pairs = the
+ * full count (may exceed cap).  Same SET as the reference's octree functor. */
+int pgp_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* pairs, int cap, int* n_pairs);
+
+/* Replaces MatchSuper4PCS::FindCongruentQuadrilaterals (super4pcs.cc:78-187) for one base:
+ * base[4][3] = positions of base_3D_ (row-major), invariants of the base, threshold =
+ * distance_factor * delta (base.cc:1989-1990), P_pairs / Q_pairs = the two pair lists (flat
+ * (first,second) ids into the search model: pairs1 / pairs6 of base.cc:1970-1981).  quads:
+ * cap x 4 ints in the reference's order (its std::set of (P-pair id, Q-pair id));
+ * *n_quads = the full count. */
+int pgp_find_congruent(pgp_ctx* ctx, const float* base, float invariant1, float invariant2, float threshold,
+                       const int* P_pairs, int nP, const int* Q_pairs, int nQ, int* quads, int cap,
+                       int* n_quads);
+
 /* ICP refinement.  Replaces the inner loop behind pcl::recognition::TrimmedICP::align
  * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and
  * pcl::IterativeClosestPoint::align (utilities.cpp:697-703; PPE/data_layer/SceneCfg.cpp:101,135-141)

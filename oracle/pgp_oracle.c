@@ -494,6 +494,276 @@ int orc_rigid_from_pair(const float* p, const float* q, const float centroid_P[3
   return 1;
 }
 
+/* ---- congruent-set extraction ---------------------------------------------------------------- */
+
+struct orc_cs {
+  int n;
+  float* world; /* n x 3, sampled_Q_3D_ positions */
+  float* unit;  /* n x 3, pcfunctor_.points (unit cube) */
+  float gcenter[3];
+  float ratio;
+};
+
+orc_cs* orc_cs_create(const float* Q, int n) {
+  orc_cs* s = (orc_cs*)calloc(1, sizeof(*s));
+  s->n = n;
+  s->world = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+  s->unit = (float*)malloc(sizeof(float) * 3 * (size_t)(n > 0 ? n : 1));
+  memcpy(s->world, Q, sizeof(float) * 3 * (size_t)n);
+  float mn[3] = {FLT_MAX / 2, FLT_MAX / 2, FLT_MAX / 2}, mx[3] = {-FLT_MAX / 2, -FLT_MAX / 2, -FLT_MAX / 2};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float v = Q[3 * i + k];
+      if (v < mn[k]) mn[k] = v;
+      if (v > mx[k]) mx[k] = v;
+    }
+  float ext[3];
+  for (int k = 0; k < 3; ++k) {
+    ext[k] = mx[k] - mn[k];
+    s->gcenter[k] = mn[k] + (ext[k] / 2.0f); /* bbox.center() */
+  }
+  /* pairCreationFunctor.h:122-124: std::max(depth+0.001, max(width+0.001, height+0.001)) in double */
+  double r = (double)ext[2] + 0.001, w = (double)ext[1] + 0.001, h = (double)ext[0] + 0.001;
+  double m = w > h ? w : h;
+  m = r > m ? r : m;
+  s->ratio = (float)m;
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) { /* worldToUnit: (p - gcenter) / ratio + half */
+      float d = Q[3 * i + k] - s->gcenter[k];
+      float u = d / s->ratio;
+      s->unit[3 * i + k] = u + 0.5f;
+    }
+  return s;
+}
+
+void orc_cs_free(orc_cs* s) {
+  if (!s) return;
+  free(s->world);
+  free(s->unit);
+  free(s);
+}
+
+int orc_cs_extract_pairs(const orc_cs* s, float pair_distance, float eps, int* out, int cap) {
+  int n = 0;
+  const double pd = (double)pair_distance, pe = (double)eps; /* functor members are double */
+  for (int i = 0; i < s->n; ++i)
+    for (int j = 0; j < i; ++j) {
+      float d[3];
+      for (int k = 0; k < 3; ++k) d[k] = s->world[3 * i + k] - s->world[3 * j + k];
+      const float distance = sqrtf(sqnorm3(d));
+      if (fabs((double)distance - pd) > pe) continue;
+      if (n < cap) { out[2 * n] = j; out[2 * n + 1] = i; }
+      ++n;
+      if (n < cap) { out[2 * n] = i; out[2 * n + 1] = j; }
+      ++n;
+    }
+  return n;
+}
+
+static void vnormalized(const float v[3], float o[3]) { /* Eigen normalized(): z > 0 ? v / sqrt(z) : v */
+  float z = sqnorm3(v);
+  if (z > 0.f) {
+    float nrm = sqrtf(z);
+    o[0] = v[0] / nrm; o[1] = v[1] / nrm; o[2] = v[2] / nrm;
+  } else {
+    o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+  }
+}
+
+/* IndexedNormalSet::indexNormal: int((n/2 + 1/2) / _nepsilon) per dim, 7 bins, _nepsilon = 1/7 + 1e-5 */
+static int normal_bin(const float n[3]) {
+  const float nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);
+  int idx[3];
+  for (int k = 0; k < 3; ++k) {
+    float h = n[k] / 2.0f;
+    float c = h + 0.5f;
+    c = c / nepsilon;
+    idx[k] = (int)c;
+    if (idx[k] < 0 || idx[k] > 6) return -1; /* the reference does not validate (UB) */
+  }
+  return idx[2] * 49 + idx[1] * 7 + idx[0];
+}
+
+static long long pos_cell(const float p[3], float epsilon, int eg) {
+  long long idx[3];
+  for (int k = 0; k < 3; ++k) {
+    float c = p[k] / epsilon;
+    idx[k] = (long long)(int)c;
+    if (idx[k] < 0 || idx[k] >= eg) return -1; /* outside the unit cube: never for inv in [0,1] */
+  }
+  return (idx[2] * eg + idx[1]) * eg + idx[0];
+}
+
+typedef struct { long long cell; int bin; int id; } cs_entry;
+static int cs_entry_cmp(const void* a, const void* b) {
+  const cs_entry* x = (const cs_entry*)a;
+  const cs_entry* y = (const cs_entry*)b;
+  if (x->cell != y->cell) return x->cell < y->cell ? -1 : 1;
+  return (x->id > y->id) - (x->id < y->id);
+}
+typedef struct { int id, i; } cs_match;
+static int cs_match_cmp(const void* a, const void* b) {
+  const cs_match* x = (const cs_match*)a;
+  const cs_match* y = (const cs_match*)b;
+  if (x->id != y->id) return x->id < y->id ? -1 : 1;
+  return (x->i > y->i) - (x->i < y->i);
+}
+
+int orc_cs_find_congruent(const orc_cs* s, const float* base, float inv1, float inv2, float threshold,
+                          const int* Pp, int nP, const int* Qp, int nQ, int* quads, int cap) {
+  /* alpha = (b1-b0).normalized().dot((b3-b2).normalized())  (super4pcs.cc:107-109) */
+  float d01[3], d23[3], u01[3], u23[3];
+  for (int k = 0; k < 3; ++k) {
+    d01[k] = base[3 + k] - base[k];
+    d23[k] = base[9 + k] - base[6 + k];
+  }
+  vnormalized(d01, u01);
+  vnormalized(d23, u23);
+  const float cosAlpha = dot3(u01, u23);
+  /* IndexedNormalSet ctor (normalset.h:114-122) */
+  const float eps = threshold / s->ratio; /* getNormalizedEpsilon */
+  const int gridDepth = (int)(-log2f(eps));
+  const int eg = (int)pow(2, gridDepth);
+  const float epsilon = 1.f / (float)eg;
+
+  cs_entry* ent = (cs_entry*)malloc(sizeof(cs_entry) * (size_t)(nP > 0 ? nP : 1));
+  int ne = 0;
+  for (int i = 0; i < nP; ++i) {
+    const float* p1 = s->unit + 3 * Pp[2 * i];
+    const float* p2 = s->unit + 3 * Pp[2 * i + 1];
+    float d[3], nrm[3], pos[3];
+    for (int k = 0; k < 3; ++k) d[k] = p2[k] - p1[k];
+    vnormalized(d, nrm);
+    for (int k = 0; k < 3; ++k) {
+      float t = inv1 * d[k];
+      pos[k] = p1[k] + t;
+    }
+    long long c = pos_cell(pos, epsilon, eg);
+    int b = normal_bin(nrm);
+    if (c < 0 || b < 0) continue;
+    ent[ne].cell = c;
+    ent[ne].bin = b;
+    ent[ne].id = i;
+    ++ne;
+  }
+  qsort(ent, (size_t)ne, sizeof(cs_entry), cs_entry_cmp);
+
+  /* cone "rendering" constants (normalset.hpp:176-182); NaN alpha -> no samples (the reference
+   * converts NaN to unsigned there, which is undefined) */
+  const float alpha = acosf(cosAlpha);
+  const float perimeter = (float)((double)2.0f * M_PI * (double)atanf(alpha));
+  const float nbf = 2 * ceilf(perimeter * 7.0f / 2.0f);
+  const unsigned nbSample = (nbf == nbf && nbf > 0.f && nbf < 1e6f) ? (unsigned)nbf : 0u;
+  const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nbSample);
+  const float sinAlpha = sinf(alpha);
+
+  size_t mcap = 1024, nm = 0;
+  cs_match* mt = (cs_match*)malloc(sizeof(cs_match) * mcap);
+  for (int i = 0; i < nQ; ++i) {
+    const int a = Qp[2 * i], b = Qp[2 * i + 1];
+    const float* p1 = s->unit + 3 * a;
+    const float* p2 = s->unit + 3 * b;
+    float d[3], query[3], queryn[3], queryQ[3];
+    for (int k = 0; k < 3; ++k) {
+      d[k] = p2[k] - p1[k];
+      float t = inv2 * d[k];
+      query[k] = p1[k] + t;
+      float dw = s->world[3 * b + k] - s->world[3 * a + k];
+      float tw = inv2 * dw;
+      queryQ[k] = s->world[3 * a + k] + tw;
+    }
+    vnormalized(d, queryn);
+    long long c = pos_cell(query, epsilon, eg);
+    if (c < 0) continue;
+    /* range of entries in the same cell */
+    int lo = 0, hi = ne;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (ent[mid].cell < c) lo = mid + 1; else hi = mid; }
+    int first = lo;
+    hi = ne;
+    while (lo < hi) { int mid = (lo + hi) / 2; if (ent[mid].cell <= c) lo = mid + 1; else hi = mid; }
+    int last = lo;
+    if (first == last) continue; /* angularGrid(p) == NULL */
+    /* q.setFromTwoVectors((0,0,1), queryn)  (Eigen Quaternion.h:577-610) */
+    float v1[3];
+    vnormalized(queryn, v1);
+    float cq = v1[2]; /* v1.dot((0,0,1)) = x*0 + (y*0 + z*1) */
+    {
+      float x = v1[0] * 0.f, y = v1[1] * 0.f, z = v1[2] * 1.f;
+      float t = y + z;
+      cq = x + t;
+    }
+    float qv[3], qw;
+    if (cq < -1.0f + 1e-5f) {
+      /* nearly opposite: the reference solves a 2x3 SVD for the axis; any unit axis orthogonal to
+       * z gives a valid half-turn -- we take x (documented divergence, |dir + z| < 0.26 deg) */
+      float cc = cq > -1.0f ? cq : -1.0f;
+      float w2 = (1.0f + cc) * 0.5f;
+      qw = sqrtf(w2);
+      float sv = sqrtf(1.0f - w2);
+      qv[0] = sv; qv[1] = 0.f; qv[2] = 0.f;
+    } else {
+      /* axis = (0,0,1) x v1 = (0*v1z - 1*v1y, 1*v1x - 0*v1z, 0*v1y - 0*v1x) */
+      float axis[3];
+      axis[0] = 0.f * v1[2] - 1.f * v1[1];
+      axis[1] = 1.f * v1[0] - 0.f * v1[2];
+      axis[2] = 0.f * v1[1] - 0.f * v1[0];
+      float sq = sqrtf((1.0f + cq) * 2.0f);
+      float invs = 1.0f / sq;
+      qv[0] = axis[0] * invs; qv[1] = axis[1] * invs; qv[2] = axis[2] * invs;
+      qw = sq * 0.5f;
+    }
+    unsigned char colored[343];
+    memset(colored, 0, sizeof colored);
+    for (unsigned a2 = 0; a2 != nbSample; ++a2) {
+      float theta = (float)a2 * angleStep;
+      float v[3] = {sinAlpha * cosf(theta), sinAlpha * sinf(theta), cosAlpha};
+      /* q * v = v + w*uv + vec x uv, uv = 2 (vec x v)  (Quaternion.h:470-480) */
+      float uv[3], c2[3], r[3], dir[3];
+      cross3(qv, v, uv);
+      for (int k = 0; k < 3; ++k) uv[k] = uv[k] + uv[k];
+      cross3(qv, uv, c2);
+      for (int k = 0; k < 3; ++k) {
+        float t = qw * uv[k];
+        float t2 = v[k] + t;
+        r[k] = t2 + c2[k];
+      }
+      vnormalized(r, dir);
+      int id = normal_bin(dir);
+      if (id >= 0) colored[id] = 1;
+    }
+    for (int e = first; e < last; ++e) {
+      if (!colored[ent[e].bin]) continue;
+      const int id = ent[e].id;
+      const float* pp1 = s->world + 3 * Pp[2 * id];
+      const float* pp2 = s->world + 3 * Pp[2 * id + 1];
+      float diff[3];
+      for (int k = 0; k < 3; ++k) {
+        float dd = pp2[k] - pp1[k];
+        float t = dd * inv1;
+        float ip = pp1[k] + t;
+        diff[k] = queryQ[k] - ip;
+      }
+      if (sqnorm3(diff) <= threshold) { /* squared distance vs delta, sic (super4pcs.cc:170) */
+        if (nm == mcap) { mcap *= 2; mt = (cs_match*)realloc(mt, sizeof(cs_match) * mcap); }
+        mt[nm].id = id;
+        mt[nm].i = i;
+        ++nm;
+      }
+    }
+  }
+  qsort(mt, nm, sizeof(cs_match), cs_match_cmp);
+  for (size_t k = 0; k < nm; ++k)
+    if ((int)k < cap) {
+      quads[4 * k] = Pp[2 * mt[k].id];
+      quads[4 * k + 1] = Pp[2 * mt[k].id + 1];
+      quads[4 * k + 2] = Qp[2 * mt[k].i];
+      quads[4 * k + 3] = Qp[2 * mt[k].i + 1];
+    }
+  free(ent);
+  free(mt);
+  return (int)nm;
+}
+
 /* ---- trimmed ICP (own definition; PCL absent) --------------------------------------------- */
 
 typedef struct { float d2; int i; } icp_pair;

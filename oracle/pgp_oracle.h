@@ -94,6 +94,28 @@ void orc_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int
 int orc_rigid_from_pair(const float* p, const float* q, const float centroid_P[3],
                         const float centroid_Q[3], float* T_centred, double* pose, float* rms_out);
 
+/* ---- congruent-set extraction (S4/algorithms/super4pcs.cc, S4/pairCreationFunctor.h,
+ * S4/accelerators/normalset.{h,hpp}) -------------------------------------------------------- */
+typedef struct orc_cs orc_cs;
+/* PairCreationFunctor::synch3DContent (pairCreationFunctor.h:102-138): unit-cube image of the
+ * (centred) search model Q. */
+orc_cs* orc_cs_create(const float* Qs_xyz, int n);
+void orc_cs_free(orc_cs* s);
+/* MatchSuper4PCS::ExtractPairs (super4pcs.cc:193-236) + PairCreationFunctor::process
+ * (pairCreationFunctor.h:167-253) with the options the fork sets (no normal / colour /
+ * translation / angle gates): every i > j with |(float)|q_i - q_j| - d| <= eps (evaluated in
+ * double as in the reference), emitted as (j,i) then (i,j), in (i,j) lexicographic order.  The
+ * reference finds them through an octree rasterisation whose emission order differs; parity is
+ * at the SET level.  Returns the pair count (may exceed cap; only cap pairs are written). */
+int orc_cs_extract_pairs(const orc_cs* s, float pair_distance, float eps, int* pairs_out, int cap);
+/* MatchSuper4PCS::FindCongruentQuadrilaterals (super4pcs.cc:78-187) incl. IndexedNormalSet
+ * <Point,3,7,float> (normalset.hpp:114-131 add, :166-214 cone query): base[4][3] = base_3D_
+ * positions, P_pairs / Q_pairs flat (first,second) ids into the search model.  Quads are written
+ * in the reference's order (sorted by (P-pair id, Q-pair id)); returns their number. */
+int orc_cs_find_congruent(const orc_cs* s, const float* base, float invariant1, float invariant2,
+                          float threshold, const int* P_pairs, int nP, const int* Q_pairs, int nQ,
+                          int* quads_out, int cap);
+
 /* Trimmed point-to-point ICP, the library's own statement of the algorithm behind
  * pcl::recognition::TrimmedICP::align / pcl::IterativeClosestPoint::align (call sites:
  * PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-703).

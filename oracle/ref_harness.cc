@@ -30,6 +30,8 @@
 #include "Eigen/Dense"
 #include "shared4pcs.h"
 #include "accelerators/kdtree.h"
+#include "pairCreationFunctor.h"          // PairCreationFunctor + IntersectionFunctor (header-only)
+#include "accelerators/normalset.h"       // IndexedNormalSet (header-only)
 
 namespace {
 
@@ -171,9 +173,135 @@ int ComputeRigidTransformation(const std::array<std::pair<Point3D, Point3D>, 4>&
   return 1;
 }
 
+// ---- congruent-set extraction on the reference's own header-only accelerators -------------
+// MatchSuper4PCS itself lives in super4pcs.cc, which includes match4pcsBase.h -> OpenCV:
+// unbuildable here.  Its two methods are restated below around the REAL PairCreationFunctor,
+// IntersectionFunctor and IndexedNormalSet<Point,3,7,float> classes.
+struct RefCS {
+  std::vector<Point3D> sampled_Q_3D_;            // must precede pcfunctor_ (it keeps a reference)
+  match_4pcs::Match4PCSOptions options_;
+  PairCreationFunctor<Scalar> pcfunctor_;
+  std::vector<Point3D> base_3D_;
+  RefCS(const std::vector<Point3D>& Q, double delta)
+      : sampled_Q_3D_(Q), options_(make_options(delta)), pcfunctor_(options_, sampled_Q_3D_), base_3D_(4) {
+    pcfunctor_.synch3DContent();                 // MatchSuper4PCS::Initialize, super4pcs.cc:242-246
+  }
+  static match_4pcs::Match4PCSOptions make_options(double delta) {
+    match_4pcs::Match4PCSOptions o;              // S4/super4pcs_test.cc:91-99: delta, the rest off
+    o.delta = delta;
+    return o;
+  }
+};
+
+// super4pcs.cc:193-236 (MatchSuper4PCS::ExtractPairs)
+void ExtractPairs(RefCS& s, Scalar pair_distance, Scalar pair_normals_angle, Scalar pair_distance_epsilon,
+                  int base_point1, int base_point2, std::vector<std::pair<int, int> >* pairs) {
+  using namespace Super4PCS::Accelerators::PairExtraction;
+  s.pcfunctor_.pairs = pairs;
+  pairs->clear();
+  pairs->reserve(2 * s.pcfunctor_.points.size());
+  s.pcfunctor_.pair_distance = pair_distance;
+  s.pcfunctor_.pair_distance_epsilon = pair_distance_epsilon;
+  s.pcfunctor_.pair_normals_angle = pair_normals_angle;
+  s.pcfunctor_.norm_threshold = 0.5 * s.options_.max_normal_difference * M_PI / 180.0;
+  s.pcfunctor_.setRadius(pair_distance);
+  s.pcfunctor_.setBase(base_point1, base_point2, s.base_3D_);
+  s.pcfunctor_.ppf_ = std::vector<int>(4, 0);
+  IntersectionFunctor<PairCreationFunctor<Scalar>::Primitive, PairCreationFunctor<Scalar>::Point, 3, Scalar>
+      interFunctor;
+  Scalar eps = s.pcfunctor_.getNormalizedEpsilon(pair_distance_epsilon);
+  interFunctor.process(s.pcfunctor_.primitives, s.pcfunctor_.points, eps, 50, s.pcfunctor_);
+}
+
+// super4pcs.cc:78-187 (MatchSuper4PCS::FindCongruentQuadrilaterals)
+bool FindCongruentQuadrilaterals(RefCS& s, Scalar invariant1, Scalar invariant2, Scalar distance_threshold2,
+                                 const std::vector<std::pair<int, int> >& P_pairs,
+                                 const std::vector<std::pair<int, int> >& Q_pairs,
+                                 std::vector<match_4pcs::Quadrilateral>* quadrilaterals) {
+  typedef PairCreationFunctor<Scalar>::Point Point;
+  typedef Super4PCS::IndexedNormalSet<Point, 3, 7, Scalar> IndexedNormalSet3D;
+  quadrilaterals->clear();
+  const Scalar alpha = (s.base_3D_[1].pos() - s.base_3D_[0].pos()).normalized().dot(
+      (s.base_3D_[3].pos() - s.base_3D_[2].pos()).normalized());
+  const Scalar eps = s.pcfunctor_.getNormalizedEpsilon(distance_threshold2);
+  IndexedNormalSet3D nset(eps);
+  for (size_t i = 0; i < P_pairs.size(); ++i) {
+    const Point& p1 = s.pcfunctor_.points[P_pairs[i].first];
+    const Point& p2 = s.pcfunctor_.points[P_pairs[i].second];
+    const Point n = (p2 - p1).normalized();
+    nset.addElement((p1 + Point::Scalar(invariant1) * (p2 - p1)).eval(), n, i);
+  }
+  std::set<std::pair<unsigned int, unsigned int> > comb;
+  std::vector<unsigned int> nei;
+  for (unsigned int i = 0; i < Q_pairs.size(); ++i) {
+    const Point& p1 = s.pcfunctor_.points[Q_pairs[i].first];
+    const Point& p2 = s.pcfunctor_.points[Q_pairs[i].second];
+    const VectorType& pq1 = s.sampled_Q_3D_[Q_pairs[i].first].pos();
+    const VectorType& pq2 = s.sampled_Q_3D_[Q_pairs[i].second].pos();
+    nei.clear();
+    const Point query = p1 + invariant2 * (p2 - p1);
+    const VectorType queryQ = pq1 + invariant2 * (pq2 - pq1);
+    const Point queryn = (p2 - p1).normalized();
+    nset.getNeighbors(query, queryn, alpha, nei);
+    VectorType invPoint;
+    for (unsigned int k = 0; k != nei.size(); k++) {
+      const int id = nei[k];
+      const VectorType& pp1 = s.sampled_Q_3D_[P_pairs[id].first].pos();
+      const VectorType& pp2 = s.sampled_Q_3D_[P_pairs[id].second].pos();
+      invPoint = pp1 + (pp2 - pp1) * invariant1;
+      if ((queryQ - invPoint).squaredNorm() <= distance_threshold2) comb.emplace(id, i);
+    }
+  }
+  for (std::set<std::pair<unsigned int, unsigned int> >::const_iterator it = comb.begin(); it != comb.end(); ++it)
+    quadrilaterals->emplace_back(P_pairs[it->first].first, P_pairs[it->first].second,
+                                 Q_pairs[it->second].first, Q_pairs[it->second].second);
+  return quadrilaterals->size() != 0;
+}
+
 }  // namespace
 
 extern "C" {
+
+// Q_xyz: centred search model (sampled_Q_3D_), n x 3.
+void* ref_cs_create(const float* Q_xyz, int nQ, double delta) {
+  std::vector<Point3D> Q(nQ);
+  for (int i = 0; i < nQ; ++i) Q[i].pos() = VectorType(Q_xyz[3 * i], Q_xyz[3 * i + 1], Q_xyz[3 * i + 2]);
+  return new RefCS(Q, delta);
+}
+void ref_cs_destroy(void* h) { delete static_cast<RefCS*>(h); }
+
+// base: 4 x 3 positions of base_3D_ (scene frame).  Returns the number of pairs; pairs_out
+// (capacity cap pairs, 2 ints each) receives them in emission order.
+int ref_cs_extract_pairs(void* h, const float* base, int base_point1, int base_point2, float pair_distance,
+                         float eps, int* pairs_out, int cap) {
+  RefCS* s = static_cast<RefCS*>(h);
+  for (int i = 0; i < 4; ++i) s->base_3D_[i].pos() = VectorType(base[3 * i], base[3 * i + 1], base[3 * i + 2]);
+  std::vector<std::pair<int, int> > pairs;
+  ExtractPairs(*s, pair_distance, 0.f, eps, base_point1, base_point2, &pairs);
+  int n = (int)pairs.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    pairs_out[2 * i] = pairs[i].first;
+    pairs_out[2 * i + 1] = pairs[i].second;
+  }
+  return n;
+}
+
+// P_pairs / Q_pairs: flat (first, second) index pairs into the search model.  Returns the number
+// of quadrilaterals; quads_out (capacity cap, 4 ints each) in the reference's (id, i) set order.
+int ref_cs_find_congruent(void* h, const float* base, float invariant1, float invariant2, float threshold,
+                          const int* P_pairs, int nP, const int* Q_pairs, int nQ, int* quads_out, int cap) {
+  RefCS* s = static_cast<RefCS*>(h);
+  for (int i = 0; i < 4; ++i) s->base_3D_[i].pos() = VectorType(base[3 * i], base[3 * i + 1], base[3 * i + 2]);
+  std::vector<std::pair<int, int> > Pp(nP), Qp(nQ);
+  for (int i = 0; i < nP; ++i) Pp[i] = std::make_pair(P_pairs[2 * i], P_pairs[2 * i + 1]);
+  for (int i = 0; i < nQ; ++i) Qp[i] = std::make_pair(Q_pairs[2 * i], Q_pairs[2 * i + 1]);
+  std::vector<match_4pcs::Quadrilateral> quads;
+  FindCongruentQuadrilaterals(*s, invariant1, invariant2, threshold, Pp, Qp, &quads);
+  int n = (int)quads.size();
+  for (int i = 0; i < n && i < cap; ++i)
+    for (int k = 0; k < 4; ++k) quads_out[4 * i + k] = quads[i][k];
+  return n;
+}
 
 // xyz/nrm: n x 3 row-major float; w: n float (nullable -> 1.0). Normals go through
 // Point3D::set_normal (shared4pcs.h:85-87) exactly as the reference's PLY reader does.

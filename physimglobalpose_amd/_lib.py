@@ -49,6 +49,9 @@ SIGNATURES = {
     "pgp_rigid_from_congruent_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _f, _f,
                                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                                   C.c_void_p]),
+    "pgp_extract_pairs": (C.c_int, [C.c_void_p, C.c_float, C.c_float, _i, C.c_int, _i]),
+    "pgp_find_congruent": (C.c_int, [C.c_void_p, _f, C.c_float, C.c_float, C.c_float, _i, C.c_int,
+                                     _i, C.c_int, _i, C.c_int, _i]),
     "pgp_icp_refine": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _f, C.c_int,
                                  C.POINTER(IcpParams), _f, _i]),
     "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -1,0 +1,466 @@
+// csrc/congruent.hip -- congruent-set extraction on gfx950.
+//
+// Replaces, for one base at a time (the host keeps the base sampling RNG):
+//   MatchSuper4PCS::ExtractPairs               S4/algorithms/super4pcs.cc:193-236
+//     + PairCreationFunctor::process           S4/pairCreationFunctor.h:167-253
+//     + IntersectionFunctor (octree raster)    S4/accelerators/pairExtraction/intersectionFunctor.h:105-234
+//   MatchSuper4PCS::FindCongruentQuadrilaterals  S4/algorithms/super4pcs.cc:78-187
+//     + IndexedNormalSet<Point,3,7,float>      S4/accelerators/normalset.{h,hpp}
+//
+// ExtractPairs: the reference rasterises a sphere of radius d around every point through an
+// octree to find all i > j with | |q_i - q_j| - d | <= eps.  On the GPU the search model (<= a few
+// thousand points) is scanned exhaustively: one wave per row i, lanes stride j < i, ballot +
+// popcount give each hit its output slot, so the list comes out in (i, j) lexicographic order,
+// (j,i) then (i,j) per hit -- the same SET as the reference's functor (tests/golden/congruent_*).
+//
+// FindCongruentQuadrilaterals: the reference hashes the invariant point e1 = p1 + inv1 (p2-p1) of
+// every P-pair into an eps-grid cell x 7^3 direction bin, then for every Q-pair looks at the ONE
+// cell of its own invariant point e2, "renders" a cone of half-angle alpha around the pair
+// direction into the 343 direction bins, and accepts the P-pairs of the coloured bins whose
+// world-space invariant points are within sqrt(delta) (sic: squared distance vs delta,
+// super4pcs.cc:170).  Here: P-pairs are bucketed by a hash of their cell (count / scan / fill),
+// one lane per Q-pair recomputes the cone mask (11 x 32 bits in VGPRs) and walks its bucket;
+// hits are (P-pair id, Q-pair id) keys, sorted with a device radix sort = the reference's
+// std::set order, so `congruent_quads[k]` means the same quad in both implementations.
+//
+// Float parity: all index arithmetic (unit-cube coordinates, cell and bin indices, quaternion
+// rotation of the cone samples, normalisation) is evaluated in the reference's order with
+// separately rounded operations and correctly rounded sqrt/divide.  The transcendental part of
+// the cone (acos, atan, sin, cos of per-BASE constants) is evaluated once per call on the host
+// with the host libm -- exactly what the reference does -- and passed in as a <= 56-entry table.
+
+#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
+
+#include "pgp_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <cfloat>
+#include <cmath>
+#include <vector>
+
+namespace pgp {
+
+namespace {
+
+__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+// correctly rounded float sqrt (see rigid_fit.hip: __fsqrt_rn is 1 ulp off on ~15 % of inputs)
+__device__ __forceinline__ float sqrt_rn(float z) { return (float)__dsqrt_rn((double)z); }
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ float sqnorm(V3 v) { return add(mul(v.x, v.x), add(mul(v.y, v.y), mul(v.z, v.z))); }
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return {sub(a.x, b.x), sub(a.y, b.y), sub(a.z, b.z)}; }
+__device__ __forceinline__ V3 normalized(V3 v) {  // Eigen normalized(): z > 0 ? v / sqrt(z) : v
+  float z = sqnorm(v);
+  if (z > 0.f) {
+    float n = sqrt_rn(z);
+    return {fdiv(v.x, n), fdiv(v.y, n), fdiv(v.z, n)};
+  }
+  return v;
+}
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return {sub(mul(a.y, b.z), mul(a.z, b.y)), sub(mul(a.z, b.x), mul(a.x, b.z)), sub(mul(a.x, b.y), mul(a.y, b.x))};
+}
+__device__ __forceinline__ V3 ld3(const float4* __restrict__ a, int i) {
+  float4 v = a[i];
+  return {v.x, v.y, v.z};
+}
+// p1 + inv * (p2 - p1)
+__device__ __forceinline__ V3 lerp_pt(V3 p1, V3 p2, float inv) {
+  V3 d = vsub(p2, p1);
+  return {add(p1.x, mul(inv, d.x)), add(p1.y, mul(inv, d.y)), add(p1.z, mul(inv, d.z))};
+}
+
+// IndexedNormalSet::indexNormal (normalset.h:100-104, utils.h:141-148): 7 bins per axis
+__device__ __forceinline__ int normal_bin(V3 n, float nepsilon) {
+  int ix = (int)fdiv(add(fdiv(n.x, 2.0f), 0.5f), nepsilon);
+  int iy = (int)fdiv(add(fdiv(n.y, 2.0f), 0.5f), nepsilon);
+  int iz = (int)fdiv(add(fdiv(n.z, 2.0f), 0.5f), nepsilon);
+  if ((unsigned)ix > 6u || (unsigned)iy > 6u || (unsigned)iz > 6u) return -1;
+  return iz * 49 + iy * 7 + ix;
+}
+
+// IndexedNormalSet::indexPos: int(p / epsilon) per axis in an eg^3 grid; -1 outside
+__device__ __forceinline__ long long pos_cell(V3 p, float epsilon, int eg) {
+  float cx = fdiv(p.x, epsilon), cy = fdiv(p.y, epsilon), cz = fdiv(p.z, epsilon);
+  if (!(cx > -1.0f && cx < (float)eg && cy > -1.0f && cy < (float)eg && cz > -1.0f && cz < (float)eg)) return -1;
+  int ix = (int)cx, iy = (int)cy, iz = (int)cz;  // truncation toward zero, as int(coord)
+  if (ix < 0 || iy < 0 || iz < 0) return -1;
+  return ((long long)iz * eg + iy) * eg + ix;
+}
+
+__device__ __forceinline__ unsigned bucket_of(long long cell, unsigned mask) {
+  unsigned long long h = (unsigned long long)cell * 0x9E3779B97F4A7C15ull;
+  return (unsigned)(h >> 40) & mask;
+}
+
+// ---------------- ExtractPairs ----------------
+template <bool FILL>
+__global__ __launch_bounds__(256) void pair_rows(const float4* __restrict__ Qw, int n, double pair_distance,
+                                                 double eps, uint32_t* __restrict__ row_cnt,
+                                                 const uint32_t* __restrict__ row_start,
+                                                 int2* __restrict__ out, uint32_t cap) {
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (i >= n) return;
+  const V3 qi = ld3(Qw, i);
+  uint32_t running = 0;
+  const uint32_t base = FILL ? row_start[i] : 0u;
+  for (int j0 = 0; j0 < i; j0 += 64) {
+    const int j = j0 + lane;
+    bool hit = false;
+    if (j < i) {
+      V3 d = vsub(qi, ld3(Qw, j));
+      float dist = sqrt_rn(sqnorm(d));  // (q.pos() - p.pos()).norm()
+      hit = !(fabs((double)dist - pair_distance) > eps);
+    }
+    unsigned long long m = __ballot(hit);
+    if (FILL && hit) {
+      uint32_t slot = base + running + __popcll(m & ((1ull << lane) - 1ull));
+      if (2ull * slot + 1 < cap) {
+        out[2 * slot] = make_int2(j, i);      // pairs->emplace_back(j, i)
+        out[2 * slot + 1] = make_int2(i, j);  // pairs->emplace_back(i, j)
+      }
+    }
+    running += __popcll(m);
+  }
+  if (!FILL && lane == 0) row_cnt[i] = running;
+}
+
+// ---------------- FindCongruentQuadrilaterals ----------------
+struct ConeTable {
+  int nb;          // nbSample
+  float v[56][3];  // (sinAlpha cos(theta_a), sinAlpha sin(theta_a), cosAlpha)
+};
+
+struct CsArgs {
+  const float4* Qw;  // world (centred) search model
+  const float4* Qu;  // unit-cube image
+  int nQs;
+  const int2* Pp;
+  int nP;
+  const int2* Qp;
+  int nQ;
+  float inv1, inv2, threshold, epsilon, nepsilon;
+  int eg;
+  unsigned bmask;
+  uint32_t* bucket_cnt;          // [nb+1]
+  const uint32_t* bucket_start;  // [nb+1]
+  int4* entries;                 // {cell_lo, cell_hi, bin, id}
+  uint32_t* q_cnt;               // [nQ+1]
+  const uint32_t* q_start;
+  unsigned long long* keys;
+  uint32_t cap;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void p_entries(CsArgs a) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nP) return;
+  int2 pr = a.Pp[i];
+  if ((unsigned)pr.x >= (unsigned)a.nQs || (unsigned)pr.y >= (unsigned)a.nQs) return;
+  V3 p1 = ld3(a.Qu, pr.x), p2 = ld3(a.Qu, pr.y);
+  V3 n = normalized(vsub(p2, p1));
+  long long c = pos_cell(lerp_pt(p1, p2, a.inv1), a.epsilon, a.eg);
+  int b = normal_bin(n, a.nepsilon);
+  if (c < 0 || b < 0) return;  // addElement returns false
+  unsigned bk = bucket_of(c, a.bmask);
+  uint32_t slot = atomicAdd(&a.bucket_cnt[bk], 1u);
+  if (FILL) a.entries[a.bucket_start[bk] + slot] = make_int4((int)(c & 0xFFFFFFFFll), (int)(c >> 32), b, i);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(128) void q_match(CsArgs a, ConeTable cone) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nQ) return;
+  int2 qr = a.Qp[i];
+  uint32_t found = 0;
+  const uint32_t out0 = FILL ? a.q_start[i] : 0u;
+  if ((unsigned)qr.x < (unsigned)a.nQs && (unsigned)qr.y < (unsigned)a.nQs) {
+    V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
+    long long c = pos_cell(lerp_pt(p1, p2, a.inv2), a.epsilon, a.eg);
+    if (c >= 0) {
+      unsigned bk = bucket_of(c, a.bmask);
+      uint32_t s = a.bucket_start[bk], e = a.bucket_start[bk + 1];
+      // is there anything of this cell in the bucket?  (angularGrid(p) == NULL otherwise)
+      bool any = false;
+      for (uint32_t k = s; k < e && !any; ++k) {
+        int4 en = a.entries[k];
+        any = en.x == (int)(c & 0xFFFFFFFFll) && en.y == (int)(c >> 32);
+      }
+      if (any) {
+        // q.setFromTwoVectors((0,0,1), queryn)   (Eigen Quaternion.h:577-610)
+        V3 queryn = normalized(vsub(p2, p1));
+        V3 v1 = normalized(queryn);
+        float cq = add(mul(v1.x, 0.f), add(mul(v1.y, 0.f), mul(v1.z, 1.f)));
+        V3 qv;
+        float qw;
+        if (cq < add(-1.0f, 1e-5f)) {
+          // nearly opposite to +z: the reference takes the axis from a 2x3 SVD; any unit axis
+          // orthogonal to z is a valid half-turn, we take x (documented divergence)
+          float cc = cq > -1.0f ? cq : -1.0f;
+          float w2 = mul(add(1.0f, cc), 0.5f);
+          qw = sqrt_rn(w2);
+          qv = {sqrt_rn(sub(1.0f, w2)), 0.f, 0.f};
+        } else {
+          V3 axis = {sub(mul(0.f, v1.z), mul(1.f, v1.y)), sub(mul(1.f, v1.x), mul(0.f, v1.z)),
+                     sub(mul(0.f, v1.y), mul(0.f, v1.x))};
+          float sq = sqrt_rn(mul(add(1.0f, cq), 2.0f));
+          float invs = fdiv(1.0f, sq);
+          qv = {mul(axis.x, invs), mul(axis.y, invs), mul(axis.z, invs)};
+          qw = mul(sq, 0.5f);
+        }
+        // cone "rendering" into the 343 direction bins (normalset.hpp:186-196)
+        uint32_t colored[11];
+#pragma unroll
+        for (int w = 0; w < 11; ++w) colored[w] = 0u;
+        for (int s2 = 0; s2 < cone.nb; ++s2) {
+          V3 v = {cone.v[s2][0], cone.v[s2][1], cone.v[s2][2]};
+          V3 uv = cross(qv, v);  // q * v = v + w*uv + vec x uv, uv = 2 (vec x v)
+          uv = {add(uv.x, uv.x), add(uv.y, uv.y), add(uv.z, uv.z)};
+          V3 c2 = cross(qv, uv);
+          V3 r = {add(add(v.x, mul(qw, uv.x)), c2.x), add(add(v.y, mul(qw, uv.y)), c2.y),
+                  add(add(v.z, mul(qw, uv.z)), c2.z)};
+          int id = normal_bin(normalized(r), a.nepsilon);
+          if (id >= 0) {
+#pragma unroll
+            for (int w = 0; w < 11; ++w)
+              if (w == (id >> 5)) colored[w] |= 1u << (id & 31);
+          }
+        }
+        // world-space invariant point of the query pair
+        V3 queryQ = lerp_pt(ld3(a.Qw, qr.x), ld3(a.Qw, qr.y), a.inv2);
+        for (uint32_t k = s; k < e; ++k) {
+          int4 en = a.entries[k];
+          if (en.x != (int)(c & 0xFFFFFFFFll) || en.y != (int)(c >> 32)) continue;
+          uint32_t word = 0;
+#pragma unroll
+          for (int w = 0; w < 11; ++w)
+            if (w == (en.z >> 5)) word = colored[w];
+          if (!((word >> (en.z & 31)) & 1u)) continue;
+          int2 pp = a.Pp[en.w];
+          V3 w1 = ld3(a.Qw, pp.x), w2 = ld3(a.Qw, pp.y);
+          V3 dd = vsub(w2, w1);  // invPoint = pp1 + (pp2 - pp1) * invariant1
+          V3 ip = {add(w1.x, mul(dd.x, a.inv1)), add(w1.y, mul(dd.y, a.inv1)), add(w1.z, mul(dd.z, a.inv1))};
+          if (sqnorm(vsub(queryQ, ip)) <= a.threshold) {  // squared distance vs delta, sic
+            if (FILL && out0 + found < a.cap)
+              a.keys[out0 + found] = ((unsigned long long)(unsigned)en.w << 32) | (unsigned)i;
+            ++found;
+          }
+        }
+      }
+    }
+  }
+  if (!FILL) a.q_cnt[i] = found;
+}
+
+__global__ __launch_bounds__(256) void emit_quads(const unsigned long long* __restrict__ keys, uint32_t n,
+                                                  const int2* __restrict__ Pp, const int2* __restrict__ Qp,
+                                                  int4* __restrict__ quads) {
+  uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  unsigned long long key = keys[k];
+  int2 p = Pp[(uint32_t)(key >> 32)], q = Qp[(uint32_t)(key & 0xFFFFFFFFull)];
+  quads[k] = make_int4(p.x, p.y, q.x, q.y);
+}
+
+}  // namespace
+
+// PairCreationFunctor::synch3DContent (pairCreationFunctor.h:102-138): centre + ratio of the
+// unit-cube normalisation, and the normalised points.  Host, O(n), float/double as the reference.
+void unit_cube_image(const float* xyz, int n, float gcenter[3], float* ratio, std::vector<float4>* unit) {
+  float mn[3] = {FLT_MAX / 2, FLT_MAX / 2, FLT_MAX / 2}, mx[3] = {-FLT_MAX / 2, -FLT_MAX / 2, -FLT_MAX / 2};
+  for (int i = 0; i < n; ++i)
+    for (int k = 0; k < 3; ++k) {
+      float v = xyz[3 * (size_t)i + k];
+      if (v < mn[k]) mn[k] = v;
+      if (v > mx[k]) mx[k] = v;
+    }
+  float ext[3];
+  for (int k = 0; k < 3; ++k) {
+    ext[k] = mx[k] - mn[k];
+    gcenter[k] = mn[k] + (ext[k] / 2.0f);
+  }
+  double r = (double)ext[2] + 0.001, w = (double)ext[1] + 0.001, h = (double)ext[0] + 0.001;
+  double m = w > h ? w : h;
+  m = r > m ? r : m;
+  *ratio = (float)m;
+  unit->resize((size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; ++i) {
+    float u[3];
+    for (int k = 0; k < 3; ++k) {
+      float d = xyz[3 * (size_t)i + k] - gcenter[k];
+      u[k] = d / *ratio + 0.5f;  // worldToUnit: (p - gcenter) / ratio + half
+    }
+    (*unit)[i] = make_float4(u[0], u[1], u[2], 0.f);
+  }
+}
+
+int launch_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* d_pairs, int cap,
+                         int* n_pairs_host, hipStream_t st) {
+  const int n = ctx->nQs;
+  *n_pairs_host = 0;
+  if (n <= 0 || !ctx->d_Qs.p) {
+    set_error("no search model: call pgp_set_search_model first");
+    return PGP_ESTATE;
+  }
+  int rc;
+  if ((rc = ctx->d_cs_cnt.ensure(((size_t)n + 1) * 8 + 64)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure(((size_t)n / 2048 + 2) * 4)) != PGP_OK) return rc;
+  uint32_t* cnt = ctx->d_cs_cnt.as<uint32_t>();
+  uint32_t* start = cnt + (n + 1);
+  PGP_HIP(hipMemsetAsync(cnt, 0, ((size_t)n + 1) * 4, st));
+  dim3 grid((n + 3) / 4);
+  hipLaunchKernelGGL(pair_rows<false>, grid, dim3(256), 0, st, ctx->d_Qs.as<float4>(), n,
+                     (double)pair_distance, (double)eps, cnt, (const uint32_t*)nullptr, (int2*)nullptr, 0u);
+  if ((rc = device_exclusive_scan(cnt, start, (size_t)n + 1, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
+  uint32_t total = 0;
+  PGP_HIP(hipMemcpyAsync(&total, start + n, 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *n_pairs_host = (int)(2u * total);
+  if (total > 0 && cap > 0)
+    hipLaunchKernelGGL(pair_rows<true>, grid, dim3(256), 0, st, ctx->d_Qs.as<float4>(), n,
+                       (double)pair_distance, (double)eps, cnt, (const uint32_t*)start,
+                       reinterpret_cast<int2*>(d_pairs), (uint32_t)cap);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float inv2, float threshold,
+                          const int* d_Pp, int nP, const int* d_Qp, int nQ, int* d_quads, int cap,
+                          int* n_quads_host, hipStream_t st) {
+  *n_quads_host = 0;
+  if (ctx->nQs <= 0 || !ctx->d_Qs.p) {
+    set_error("no search model: call pgp_set_search_model first");
+    return PGP_ESTATE;
+  }
+  if (nP <= 0 || nQ <= 0) return PGP_OK;
+  // ---- per-base constants, host libm exactly as the reference evaluates them -------------
+  auto normalized_h = [](const float v[3], float o[3]) {
+    float x = v[0] * v[0], y = v[1] * v[1], z = v[2] * v[2];
+    float t = y + z;
+    float s = x + t;
+    if (s > 0.f) {
+      float n = std::sqrt(s);
+      o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+    } else {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+  };
+  float d01[3], d23[3], u01[3], u23[3];
+  for (int k = 0; k < 3; ++k) {
+    d01[k] = base[3 + k] - base[k];
+    d23[k] = base[9 + k] - base[6 + k];
+  }
+  normalized_h(d01, u01);
+  normalized_h(d23, u23);
+  float cosAlpha;
+  {
+    float x = u01[0] * u23[0], y = u01[1] * u23[1], z = u01[2] * u23[2];
+    float t = y + z;
+    cosAlpha = x + t;  // super4pcs.cc:107-109
+  }
+  CsArgs a{};
+  const float eps = threshold / ctx->cs_ratio;          // getNormalizedEpsilon
+  const int gridDepth = (int)(-std::log2(eps));          // normalset.h:116
+  if (!(eps > 0.f) || gridDepth < 0 || gridDepth > 20) {
+    set_error("find_congruent: threshold %g gives an unusable grid depth %d", (double)threshold, gridDepth);
+    return PGP_EINVAL;
+  }
+  a.eg = (int)std::pow(2, gridDepth);
+  a.epsilon = 1.f / (float)a.eg;
+  a.nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:88
+  ConeTable cone{};
+  {
+    const float alpha = std::acos(cosAlpha);
+    const float perimeter = (float)((double)2.0f * M_PI * (double)std::atan(alpha));
+    const float nbf = 2 * std::ceil(perimeter * 7.0f / 2.0f);
+    const unsigned nb = (nbf == nbf && nbf > 0.f && nbf <= 56.f) ? (unsigned)nbf : 0u;  // NaN: UB in the reference
+    const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
+    const float sinAlpha = std::sin(alpha);
+    cone.nb = (int)nb;
+    for (unsigned s = 0; s < nb; ++s) {
+      float theta = (float)s * angleStep;
+      cone.v[s][0] = sinAlpha * std::cos(theta);
+      cone.v[s][1] = sinAlpha * std::sin(theta);
+      cone.v[s][2] = cosAlpha;
+    }
+  }
+  // ---- buffers -------------------------------------------------------------------------------
+  unsigned nbk = 1024;
+  while (nbk < 2u * (unsigned)nP && nbk < (1u << 24)) nbk <<= 1;
+  a.bmask = nbk - 1;
+  int rc;
+  const size_t n_cnt = (size_t)nbk + 1 + (size_t)nQ + 1;
+  if ((rc = ctx->d_cs_cnt.ensure(n_cnt * 8 + 64)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cs_entries.ensure((size_t)nP * 16 + 16)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure((n_cnt / 2048 + 2) * 4)) != PGP_OK) return rc;
+  uint32_t* bcnt = ctx->d_cs_cnt.as<uint32_t>();
+  uint32_t* bstart = bcnt + (nbk + 1);
+  uint32_t* qcnt = bstart + (nbk + 1);
+  uint32_t* qstart = qcnt + (nQ + 1);
+  a.Qw = ctx->d_Qs.as<float4>();
+  a.Qu = ctx->d_Qs_unit.as<float4>();
+  a.nQs = ctx->nQs;
+  a.Pp = reinterpret_cast<const int2*>(d_Pp);
+  a.nP = nP;
+  a.Qp = reinterpret_cast<const int2*>(d_Qp);
+  a.nQ = nQ;
+  a.inv1 = inv1;
+  a.inv2 = inv2;
+  a.threshold = threshold;
+  a.bucket_cnt = bcnt;
+  a.bucket_start = bstart;
+  a.entries = ctx->d_cs_entries.as<int4>();
+  a.q_cnt = qcnt;
+  a.q_start = qstart;
+  a.cap = (uint32_t)(cap > 0 ? cap : 0);
+  uint32_t* scan_tmp = ctx->d_scan_tmp.as<uint32_t>();
+  const dim3 gp((nP + 255) / 256), gq((nQ + 127) / 128);
+  PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
+  hipLaunchKernelGGL(p_entries<false>, gp, dim3(256), 0, st, a);
+  if ((rc = device_exclusive_scan(bcnt, bstart, (size_t)nbk + 1, scan_tmp, st)) != PGP_OK) return rc;
+  PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
+  hipLaunchKernelGGL(p_entries<true>, gp, dim3(256), 0, st, a);
+  PGP_HIP(hipMemsetAsync(qcnt + nQ, 0, 4, st));
+  hipLaunchKernelGGL(q_match<false>, gq, dim3(128), 0, st, a, cone);
+  if ((rc = device_exclusive_scan(qcnt, qstart, (size_t)nQ + 1, scan_tmp, st)) != PGP_OK) return rc;
+  uint32_t total = 0;
+  PGP_HIP(hipMemcpyAsync(&total, qstart + nQ, 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *n_quads_host = (int)total;
+  if (total == 0 || cap <= 0) return PGP_OK;
+  // all matches are materialised and sorted, then the first `cap` are emitted: truncation keeps
+  // the reference's (id, i) order
+  size_t sort_bytes = 0;
+  hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
+                                           (unsigned long long*)nullptr, (size_t)total, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  if ((rc = ctx->d_cs_keys.ensure((size_t)total * 16 + sort_bytes + 256)) != PGP_OK) return rc;
+  unsigned long long* keys_in = ctx->d_cs_keys.as<unsigned long long>();
+  unsigned long long* keys_out = keys_in + total;
+  void* sort_tmp = keys_out + total;
+  a.keys = keys_in;
+  a.cap = total;
+  hipLaunchKernelGGL(q_match<true>, gq, dim3(128), 0, st, a, cone);
+  he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)total, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  const uint32_t n_emit = total < (uint32_t)cap ? total : (uint32_t)cap;
+  hipLaunchKernelGGL(emit_quads, dim3((n_emit + 255) / 256), dim3(256), 0, st,
+                     (const unsigned long long*)keys_out, n_emit, a.Pp, a.Qp, reinterpret_cast<int4*>(d_quads));
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+}  // namespace pgp

@@ -244,8 +244,8 @@ int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, 
 
 }  // namespace
 
-// exclusive scan of n uint32 (in -> out, may alias), tile sums in `tmp`
-static int exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, hipStream_t st) {
+// exclusive scan of n uint32 (in -> out, may alias), tile sums in `tmp` (>= n/2048 + 2 words)
+int device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, hipStream_t st) {
   const int n_tiles = (int)((n + kScanTile - 1) / kScanTile);
   hipLaunchKernelGGL(scan_tiles, dim3(n_tiles), dim3(kScanThreads), 0, st, in, out, n, tmp);
   hipLaunchKernelGGL(scan_tile_sums, dim3(1), dim3(1024), 0, st, tmp, n_tiles);
@@ -299,7 +299,7 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   if (nP > 0)
     hipLaunchKernelGGL(scatter_points<false>, dim3(pb), dim3(256), 0, st, g, r,
                        ctx->d_P.as<float4>(), nP, ctr, (const uint32_t*)nullptr, (float4*)nullptr);
-  if ((rc = exclusive_scan(ctr, start, n_scan, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
+  if ((rc = device_exclusive_scan(ctr, start, n_scan, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
   uint32_t total = 0;
   PGP_HIP(hipMemcpyAsync(&total, start + n_cells, 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
@@ -312,7 +312,7 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   uint2* words = ctx->d_bitmap.as<uint2>();
   hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
                      (const uint32_t*)start, words, ctr, n_words);
-  if ((rc = exclusive_scan(ctr, ctr, n_words + 1, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
+  if ((rc = device_exclusive_scan(ctr, ctr, n_words + 1, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
   uint32_t n_occ = 0;
   PGP_HIP(hipMemcpyAsync(&n_occ, ctr + n_words, 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));

@@ -146,7 +146,8 @@ int pgp_destroy(pgp_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
-                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws};
+                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
+                    &ctx->d_cs_pairs, &ctx->d_cs_out};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
@@ -386,6 +387,11 @@ int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
                         __builtin_bit_cast(float, i));
   int rc = ctx->d_Qs.ensure(hq.size() * sizeof(float4));
   if (rc != PGP_OK) return rc;
+  // unit-cube image for the congruent-set accelerators (pairCreationFunctor.h:102-138)
+  std::vector<float4> hu;
+  unit_cube_image(xyz, n, ctx->cs_gcenter, &ctx->cs_ratio, &hu);
+  if ((rc = ctx->d_Qs_unit.ensure(hu.size() * sizeof(float4))) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_Qs_unit.p, hu.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipMemcpyAsync(ctx->d_Qs.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipStreamSynchronize(ctx->stream));
   ctx->nQs = n;
@@ -434,6 +440,57 @@ int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_
   if (pose) PGP_HIP(hipMemcpyAsync(pose, d_pose, N * 128, hipMemcpyDeviceToHost, st));
   if (rms) PGP_HIP(hipMemcpyAsync(rms, d_rms, N * 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  return PGP_OK;
+}
+
+int pgp_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* pairs, int cap, int* n_pairs) {
+  if (!ctx || !n_pairs || cap < 0 || (cap > 0 && !pairs) || !(eps >= 0.f)) {
+    set_error("pgp_extract_pairs: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  int rc = ctx->d_cs_out.ensure((size_t)std::max(cap, 1) * 8);
+  if (rc != PGP_OK) return rc;
+  int total = 0;
+  rc = launch_extract_pairs(ctx, pair_distance, eps, ctx->d_cs_out.as<int>(), cap, &total, st);
+  if (rc != PGP_OK) return rc;
+  int n_copy = std::min(total, cap);
+  if (n_copy > 0)
+    PGP_HIP(hipMemcpyAsync(pairs, ctx->d_cs_out.p, (size_t)n_copy * 8, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *n_pairs = total;
+  return PGP_OK;
+}
+
+int pgp_find_congruent(pgp_ctx* ctx, const float* base, float invariant1, float invariant2, float threshold,
+                       const int* P_pairs, int nP, const int* Q_pairs, int nQ, int* quads, int cap,
+                       int* n_quads) {
+  if (!ctx || !base || !n_quads || nP < 0 || nQ < 0 || cap < 0 || (nP > 0 && !P_pairs) ||
+      (nQ > 0 && !Q_pairs) || (cap > 0 && !quads)) {
+    set_error("pgp_find_congruent: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_quads = 0;
+  if (nP == 0 || nQ == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = ctx->d_cs_pairs.ensure(((size_t)nP + nQ) * 8)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cs_out.ensure((size_t)std::max(cap, 1) * 16)) != PGP_OK) return rc;
+  int* d_Pp = ctx->d_cs_pairs.as<int>();
+  int* d_Qp = d_Pp + 2 * (size_t)nP;
+  PGP_HIP(hipMemcpyAsync(d_Pp, P_pairs, (size_t)nP * 8, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_Qp, Q_pairs, (size_t)nQ * 8, hipMemcpyHostToDevice, st));
+  int total = 0;
+  rc = launch_find_congruent(ctx, base, invariant1, invariant2, threshold, d_Pp, nP, d_Qp, nQ,
+                             ctx->d_cs_out.as<int>(), cap, &total, st);
+  if (rc != PGP_OK) return rc;
+  int n_copy = std::min(total, cap);
+  if (n_copy > 0)
+    PGP_HIP(hipMemcpyAsync(quads, ctx->d_cs_out.p, (size_t)n_copy * 16, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *n_quads = total;
   return PGP_OK;
 }
 

@@ -74,6 +74,11 @@ struct pgp_ctx {
   // search model (congruent-set side, sampled_Q_3D_)
   int nQs = 0;
   pgp::DevBuf d_Qs;      // float4 {x,y,z,bits(i)} original order [nQs]
+  pgp::DevBuf d_Qs_unit; // float4 unit-cube image (PairCreationFunctor::points) [nQs]
+  float cs_gcenter[3] = {0.f, 0.f, 0.f};
+  float cs_ratio = 1.f;
+  pgp::DevBuf d_cs_cnt, d_cs_entries, d_cs_keys;   // congruent-set workspaces
+  pgp::DevBuf d_cs_pairs, d_cs_out;                // host-API staging
   pgp::DevBuf d_ids;     // staged int4 base / quad ids (host API)
   pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
 
@@ -107,6 +112,15 @@ namespace pgp {
 
 // grid_index.hip
 int build_index(pgp_ctx* ctx, const float* h_xyz, float delta);
+int device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, hipStream_t st);
+
+// congruent.hip
+void unit_cube_image(const float* xyz, int n, float gcenter[3], float* ratio, std::vector<float4>* unit);
+int launch_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* d_pairs, int cap,
+                         int* n_pairs_host, hipStream_t st);
+int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float inv2, float threshold,
+                          const int* d_Pp, int nP, const int* d_Qp, int nQ, int* d_quads, int cap,
+                          int* n_quads_host, hipStream_t st);
 
 // lcp_score.hip
 int tiles_for(int nQ);

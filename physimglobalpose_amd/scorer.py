@@ -112,6 +112,34 @@ class LcpScorer:
             pose.ctypes.data_as(C.POINTER(C.c_double)), status.ctypes.data_as(_i), _fp(rms)))
         return T, pose, status, rms
 
+    # ---- congruent-set extraction (super4pcs.cc:78-236) ---------------------------------------------
+    def extract_pairs(self, pair_distance, eps, cap=None):
+        """(n,2) int32 ordered pairs of search-model ids at distance pair_distance +- eps."""
+        n = C.c_int(0)
+        if cap is None:
+            _lib.check(self._lib.pgp_extract_pairs(self._h, C.c_float(pair_distance), C.c_float(eps), None, 0,
+                                                   C.byref(n)))
+            cap = n.value
+        out = np.zeros((max(cap, 1), 2), np.int32)
+        _lib.check(self._lib.pgp_extract_pairs(self._h, C.c_float(pair_distance), C.c_float(eps),
+                                               out.ctypes.data_as(_i), int(cap), C.byref(n)))
+        return out[: min(n.value, cap)].copy()
+
+    def find_congruent(self, base, invariant1, invariant2, threshold, P_pairs, Q_pairs, cap=None):
+        """(n,4) int32 congruent quadrilaterals in the reference's order."""
+        base = _f32(base).reshape(12)
+        Pp = np.ascontiguousarray(P_pairs, np.int32).reshape(-1, 2)
+        Qp = np.ascontiguousarray(Q_pairs, np.int32).reshape(-1, 2)
+        n = C.c_int(0)
+        args = (self._h, _fp(base), C.c_float(invariant1), C.c_float(invariant2), C.c_float(threshold),
+                Pp.ctypes.data_as(_i), len(Pp), Qp.ctypes.data_as(_i), len(Qp))
+        if cap is None:
+            _lib.check(self._lib.pgp_find_congruent(*args, None, 0, C.byref(n)))
+            cap = n.value
+        out = np.zeros((max(cap, 1), 4), np.int32)
+        _lib.check(self._lib.pgp_find_congruent(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
+        return out[: min(n.value, cap)].copy()
+
     # ---- ICP refinement (UCTState::performTrICP / utilities::performICP inner loop) --------------
     def icp_refine(self, src_xyz, tgt_xyz, T, trim=1.0, max_iterations=100, max_corr_dist=0.0,
                    energy_ratio=1.0):

@@ -70,6 +70,12 @@ def oracle_lib():
                                       C.c_float, C.c_int, C.c_float, C.c_int, C.c_int, _f, _i, _i, _i]
         L.orc_center.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]
         L.orc_rigid_from_pair.argtypes = [_f, _f, _f, _f, _f, _d, _f]
+        L.orc_cs_create.restype = C.c_void_p
+        L.orc_cs_create.argtypes = [_f, C.c_int]
+        L.orc_cs_free.argtypes = [C.c_void_p]
+        L.orc_cs_extract_pairs.argtypes = [C.c_void_p, C.c_float, C.c_float, _i, C.c_int]
+        L.orc_cs_find_congruent.argtypes = [C.c_void_p, _f, C.c_float, C.c_float, C.c_float, _i, C.c_int,
+                                            _i, C.c_int, _i, C.c_int]
         L.orc_icp.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, C.c_float, C.c_float, C.c_float, _f]
         _oracle = L
     return _oracle
@@ -155,6 +161,48 @@ def oracle_rigid_from_pairs(P_xyz, Qs_xyz, base_ids, quad_ids, cP, cQ):
     return T, pose, status, rms
 
 
+class CongruentChecker:
+    """Congruent-set extraction over one search model: kind='oracle' (C restatement) or 'ref'
+    (the reference's own PairCreationFunctor / IntersectionFunctor / IndexedNormalSet)."""
+
+    def __init__(self, Qs_xyz, kind="oracle", delta=0.005):
+        self.kind = kind
+        self.Qs = _f32(Qs_xyz)
+        if kind == "oracle":
+            self.L = oracle_lib()
+            self.h = self.L.orc_cs_create(_fp(self.Qs), len(self.Qs))
+        else:
+            self.L = ref_lib()
+            self.h = self.L.ref_cs_create(_fp(self.Qs), len(self.Qs), C.c_double(delta))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            (self.L.orc_cs_free if self.kind == "oracle" else self.L.ref_cs_destroy)(self.h)
+            self.h = None
+
+    def extract_pairs(self, pair_distance, eps, base=None, cap=1 << 22):
+        out = np.zeros((cap, 2), np.int32)
+        if self.kind == "oracle":
+            n = self.L.orc_cs_extract_pairs(self.h, C.c_float(pair_distance), C.c_float(eps), _ip(out), cap)
+        else:
+            b = _f32(base if base is not None else np.zeros((4, 3))).reshape(12)
+            n = self.L.ref_cs_extract_pairs(self.h, _fp(b), 0, 1, C.c_float(pair_distance), C.c_float(eps),
+                                            _ip(out), cap)
+        assert n <= cap
+        return out[:n].copy()
+
+    def find_congruent(self, base, inv1, inv2, threshold, P_pairs, Q_pairs, cap=1 << 22):
+        b = _f32(base).reshape(12)
+        Pp = np.ascontiguousarray(P_pairs, np.int32).reshape(-1, 2)
+        Qp = np.ascontiguousarray(Q_pairs, np.int32).reshape(-1, 2)
+        out = np.zeros((cap, 4), np.int32)
+        fn = self.L.orc_cs_find_congruent if self.kind == "oracle" else self.L.ref_cs_find_congruent
+        n = fn(self.h, _fp(b), C.c_float(inv1), C.c_float(inv2), C.c_float(threshold), _ip(Pp), len(Pp),
+               _ip(Qp), len(Qp), _ip(out), cap)
+        assert n <= cap
+        return out[:n].copy()
+
+
 def oracle_icp(src, tgt, T, trim=1.0, max_iterations=100, max_corr_dist=0.0, energy_ratio=1.0):
     """orc_icp over a batch of guesses: returns (T_refined, energy, iters)."""
     L = oracle_lib()
@@ -198,6 +246,12 @@ def ref_lib():
         L.ref_dot.restype = C.c_float
         L.ref_dot.argtypes = [_f, _f]
         L.ref_rigid_from_pair.argtypes = [_f, _f, _f, _f, _f, _d, _f]
+        L.ref_cs_create.restype = C.c_void_p
+        L.ref_cs_create.argtypes = [_f, C.c_int, C.c_double]
+        L.ref_cs_destroy.argtypes = [C.c_void_p]
+        L.ref_cs_extract_pairs.argtypes = [C.c_void_p, _f, C.c_int, C.c_int, C.c_float, C.c_float, _i, C.c_int]
+        L.ref_cs_find_congruent.argtypes = [C.c_void_p, _f, C.c_float, C.c_float, C.c_float, _i, C.c_int,
+                                            _i, C.c_int, _i, C.c_int]
         _ref = L
     return _ref
 

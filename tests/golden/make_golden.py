@@ -175,7 +175,44 @@ def main():
     path = os.path.join(HERE, "rigid_fit.npz")
     np.savez_compressed(path, p=ps, q=qs, centroid_P=cP, centroid_Q=cQ, status=status, T=Tc, pose=pose, rms=rms)
     print("rigid_fit:", np.bincount(status, minlength=3), f"{os.path.getsize(path)/1024:.0f} KiB")
+    congruent_cases()
+
+
+def congruent_cases():
+    """(8) congruent-set extraction on the reference's own PairCreationFunctor / IntersectionFunctor /
+    IndexedNormalSet: pair lists (as sets) and congruent quads (in the reference's order)."""
+    from _checkers import CongruentChecker
+    for k, (n_search, seed) in enumerate([(150, 71), (300, 72), (400, 73)]):
+        w = synth.make_workload(6000, 1200, 4, config_id=seed, n_search=n_search)
+        ref = CongruentChecker(w.Qs_xyz, "ref")
+        rng = np.random.default_rng(seed)
+        T = w.T_gt.reshape(4, 4).T
+        bases, invs, P1, P6, QD, off = [], [], [], [], [], [0]
+        for _ in range(4):
+            ids = rng.choice(len(w.Qs_xyz), 4, replace=False)
+            base = (w.Qs_xyz[ids] @ T[:3, :3].T + T[:3, 3] + 0.0005 * rng.standard_normal((4, 3))).astype(np.float32)
+            d1 = np.float32(np.linalg.norm(base[0] - base[1]))
+            d6 = np.float32(np.linalg.norm(base[2] - base[3]))
+            p1 = ref.extract_pairs(d1, w.delta, base)
+            p6 = ref.extract_pairs(d6, w.delta, base)
+            inv1, inv2 = np.float32(rng.uniform(0.15, 0.85)), np.float32(rng.uniform(0.15, 0.85))
+            quads = ref.find_congruent(base, inv1, inv2, w.delta, p1, p6)
+            bases.append(base)
+            invs.append((inv1, inv2, d1, d6))
+            P1.append(p1)
+            P6.append(p6)
+            QD.append(quads)
+        path = os.path.join(HERE, f"congruent_{k}.npz")
+        np.savez_compressed(path, Qs=w.Qs_xyz, delta=np.float32(w.delta), bases=np.array(bases),
+                            invs=np.array(invs, np.float32),
+                            **{f"p1_{i}": P1[i] for i in range(4)}, **{f"p6_{i}": P6[i] for i in range(4)},
+                            **{f"quads_{i}": QD[i] for i in range(4)})
+        print(f"congruent_{k}: |Qs|={n_search} pairs", [len(x) for x in P1], [len(x) for x in P6],
+              "quads", [len(x) for x in QD], f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "congruent":
+        congruent_cases()
+        sys.exit(0)
     main()
