@@ -28,10 +28,13 @@ for f in glob.glob(out + "/pmc*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
+import re
 for k, d in agg.items():
-    short = k.split("(")[0].split("::")[-1]
-    if "score_hypotheses" in k or "icp" in k or "finalize" in k:
-        res[short + ("<1>" if "<1>" in k else "<0>" if "<0>" in k else "")] = {c: sum(v) / len(v) for c, v in d.items()} | {"n": max(len(v) for v in d.values())}
+    name = k.replace("(anonymous namespace)::", "")
+    m = re.search(r"(\w+(?:<[^>]*>)?)\(", name)
+    short = m.group(1) if m else name
+    if any(t in short for t in ("score_hypotheses", "icp_refine", "finalize_scores", "q_match", "pair_rows")):
+        res[short] = {c: sum(v) / len(v) for c, v in d.items()} | {"n": max(len(v) for v in d.values())}
 json.dump(res, open(out + "/pmc_summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
