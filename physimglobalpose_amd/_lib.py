@@ -73,6 +73,13 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: build it with `make -C physimglobalpose_amd/csrc` "
             "(or __graft_entry__.build()); there is no fallback path")
+    # PyTorch-ROCm wheels bundle their own libamdhip64; if libpgp.so pulls in the system HIP
+    # runtime first, a later `import torch` finds two runtimes in the process and reports
+    # "No HIP GPUs are available".  Loading torch first makes both share one runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing

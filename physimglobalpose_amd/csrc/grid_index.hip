@@ -9,8 +9,8 @@
 //   cell(x)      = floor((x - origin) * inv_h), h >= delta
 //   cand(c)      = every scene point within `reach` = delta + margin of the box of cell c
 //   words        = per 32 cells along x: {occupancy bits, rank base}   (1.6 MB at C2, L2-resident)
-//   occ_start    = CSR offsets, one per OCCUPIED cell (rank = base + popcount of lower bits),
-//                  into one float4 array {x,y,z,bits(id)} of all candidate lists (1.1 MB at C2)
+//   occ_run      = {start, count} per OCCUPIED cell (rank = base + popcount of lower bits) into
+//                  one float4 array {x,y,z,bits(id)} of all candidate lists (2.3 MB at C2)
 //
 // A query is then: one 8-byte word, (if the bit is set) one 8-byte offset pair, one contiguous
 // float4 run -- no neighbour-cell gather, no tree; ~78 % of C2 queries end at the word.  Exactness: the scoring kernel applies the reference's float
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void make_words(GridDesc g, const uint32_t* __
 __global__ __launch_bounds__(256) void fill_occupied(GridDesc g, const uint32_t* __restrict__ cell_start,
                                                      const uint32_t* __restrict__ word_base,
                                                      uint2* __restrict__ words,
-                                                     uint32_t* __restrict__ occ_start, size_t n_words,
+                                                     uint2* __restrict__ occ_run, size_t n_words,
                                                      size_t n_cells) {
   size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_words) return;
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256) void fill_occupied(GridDesc g, const uint32_t*
   while (bits) {
     int b = __ffs(bits) - 1;
     bits &= bits - 1;
-    occ_start[k++] = cell_start[c0 + b];
+    uint32_t st = cell_start[c0 + b];
+    occ_run[k++] = make_uint2(st, cell_start[c0 + b + 1] - st);  // {start, count}
   }
-  if (w == n_words - 1) occ_start[word_base[n_words]] = cell_start[n_cells];  // end sentinel
 }
 
 // Choose cell size, origin and dims for a bounding box and a radius.
@@ -316,10 +316,10 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   uint32_t n_occ = 0;
   PGP_HIP(hipMemcpyAsync(&n_occ, ctr + n_words, 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
-  if ((rc = ctx->d_occ_start.ensure(((size_t)n_occ + 2) * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_occ_start.ensure(((size_t)n_occ + 2) * 8)) != PGP_OK) return rc;
   hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
                      (const uint32_t*)start, (const uint32_t*)ctr, words,
-                     ctx->d_occ_start.as<uint32_t>(), n_words, n_cells);
+                     ctx->d_occ_start.as<uint2>(), n_words, n_cells);
   PGP_HIP(hipGetLastError());
   PGP_HIP(hipEventRecord(e1, st));
   PGP_HIP(hipStreamSynchronize(st));

@@ -83,25 +83,30 @@ __device__ __forceinline__ size_t word_index(const GridDesc& g, float x, float y
 }
 
 // Level 2: candidate run [s, e) of an occupied cell; empty when the bit is clear.
-__device__ __forceinline__ void run_of(const uint32_t* __restrict__ occ_start, uint2 wd, int bit,
+__device__ __forceinline__ void run_of(const uint2* __restrict__ occ_run, uint2 wd, int bit,
                                        uint32_t* s, uint32_t* e) {
   *s = 0;
   *e = 0;
   if (bit >= 0 && ((wd.x >> bit) & 1u)) {
     uint32_t k = wd.y + __popc(wd.x & ((1u << bit) - 1u));
-    *s = occ_start[k];
-    *e = occ_start[k + 1];
+    unsigned long long rv = reinterpret_cast<const unsigned long long*>(occ_run)[k];  // {start, count}
+    *s = (unsigned)(rv & 0xFFFFFFFFull);
+    *e = *s + (unsigned)(rv >> 32);
   }
 }
 
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
-                                         const uint32_t* __restrict__ occ_start, float x, float y,
+                                         const uint2* __restrict__ occ_run, float x, float y,
                                          float z, uint32_t* s, uint32_t* e) {
   int bit;
   size_t wi = word_index(g, x, y, z, &bit);
   uint2 wd = make_uint2(0u, 0u);
-  if (bit >= 0) wd = words[wi];
-  run_of(occ_start, wd, bit, s, e);
+  if (bit >= 0) {
+    // one 8-byte load (as a 64-bit scalar, or hipcc fetches .x, tests the bit, then fetches .y)
+    unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
+    wd = make_uint2((unsigned)(wv & 0xFFFFFFFFull), (unsigned)(wv >> 32));
+  }
+  run_of(occ_run, wd, bit, s, e);
 }
 
 // Nearest candidate with d2 <= sq_eps; ties -> lowest scene index (the reference's tie rule
@@ -154,7 +159,7 @@ __device__ __forceinline__ bool gate_ok(float dot, float lo, float hi) {
 struct ScoreArgs {
   GridDesc g;
   const uint2* words;
-  const uint32_t* occ_start;
+  const uint2* occ_run;
   const float4* cand;
   const float4* Pnw;
   const float4* Q;
@@ -213,10 +218,13 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       wd[u] = make_uint2(0u, 0u);
-      if (bit[u] >= 0) wd[u] = a.words[wi[u]];
+      if (bit[u] >= 0) {
+        unsigned long long wv = reinterpret_cast<const unsigned long long*>(a.words)[wi[u]];
+        wd[u] = make_uint2((unsigned)(wv & 0xFFFFFFFFull), (unsigned)(wv >> 32));
+      }
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) run_of(a.occ_start, wd[u], bit[u], &s[u], &e[u]);
+    for (int u = 0; u < U; ++u) run_of(a.occ_run, wd[u], bit[u], &s[u], &e[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool hit = false;
@@ -247,6 +255,166 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
         s_cnt[wave][hb + u - h0] = __popcll(mask);
         if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][hb + u - h0] = wsum;
       }
+    }
+  }
+  __syncthreads();
+  const int hh = threadIdx.x;
+  if (hh < h1 - h0) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < kTile / 64; ++w) c += s_cnt[w][hh];
+    a.partial_cnt[(size_t)tile * a.n_h + h0 + hh] = c;
+    if (MODE == PGP_MODE_WEIGHTED) {
+      float f = 0.f;
+#pragma unroll
+      for (int w = 0; w < kTile / 64; ++w) f += s_sum[w][hh];
+      a.partial_sum[(size_t)tile * a.n_h + h0 + hh] = f;
+    }
+  }
+}
+
+// ---- wave-flattened candidate phase --------------------------------------------------------------
+// What binds the per-lane kernel above (profiles/r01_c_*): the vector L1 is busy for the whole
+// kernel (TCP_GATE_EN ~ kernel duration) at ~25 busy cycles per vector-memory WAVE-INSTRUCTION,
+// almost independent of how many lanes or lines the instruction touches; only ~22 % of the lanes
+// own a candidate run (mean 9.4 entries, p90 23), so the per-lane walk spends 5-6 load
+// instructions per hypothesis on ~132 candidates.  Two experiments that kept the per-lane walk
+// (software pipelining across hypotheses; 16-lane groups per run) issued MORE such instructions
+// and were slower (157 and 203 us vs 125 us).  Here the runs of a wave are flattened: the lanes
+// that own a run are compacted into an LDS table, every candidate slot w of the concatenated runs
+// gets its owner from an LDS owner map, and lane (w mod 64) tests candidate w -- so a load
+// instruction serves 64 useful candidates and a wave-iteration needs ceil(W/64) ~ 2.1 of them.
+// Per-owner results are combined with LDS atomics (or / 64-bit min) and read back by the owner.
+// Arithmetic per (query, candidate) pair is unchanged; results are identical.
+constexpr int kFlatCap = 1024;  // candidate slots per wave-iteration served by the flat path
+
+// The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
+// hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
+// with FOUR vector loads per hypothesis instead of scalar loads.
+template <int MODE>
+__global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, const float* __restrict__ Tm,
+                                                               const uint2* __restrict__ words,
+                                                               const uint2* __restrict__ occ_run,
+                                                               const float4* __restrict__ cand,
+                                                               const float4* __restrict__ Pnw) {
+  __shared__ int s_cnt[kTile / 64][kMaxHpb];
+  __shared__ float s_sum[kTile / 64][kMaxHpb];
+  __shared__ float4 s_ent[kTile / 64][64];                 // {x', y', z', bits(run start - prefix)}
+  __shared__ unsigned long long s_res[kTile / 64][64];     // plain: 0/1 ; weighted: min key
+  __shared__ unsigned char s_own[kTile / 64][kFlatCap];    // slot -> compact owner index
+
+  const int L = blockIdx.x;
+  const int xcd = L & 7, seq = L >> 3;
+  const int chunk = (seq / a.n_tiles) * 8 + xcd;
+  const int tile = seq % a.n_tiles;
+  if (chunk >= a.n_chunks) return;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
+  const int qi = tile * kTile + threadIdx.x;
+  const bool live = qi < a.nQ;
+  float4 q = live ? a.Q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == PGP_MODE_WEIGHTED && live) qn = a.Qn[qi];
+  float4* ent = s_ent[wave];
+  unsigned long long* res = s_res[wave];
+  unsigned char* own = s_own[wave];
+
+  const int h0 = chunk * a.hpb;
+  const int h1 = min(h0 + a.hpb, a.n_h);
+  for (int h = h0; h < h1; ++h) {
+    const Xf m = load_xf(Tm, h);
+    const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
+    const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
+    const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
+    uint32_t s = 0, e = 0;
+    if (live) cell_run(a.g, words, occ_run, x, y, z, &s, &e);
+    const uint32_t len = e - s;
+    // exclusive prefix of the run lengths over the wave
+    uint32_t incl = len;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t t = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += t;
+    }
+    const uint32_t pre = incl - len;
+    const uint32_t W = __shfl(incl, 63, 64);
+    bool hit = false;
+    int nn_id = -1;
+    if (W == 0) {
+      // nothing to test in this wave-iteration (35 % of them at C2)
+    } else if (W <= (uint32_t)kFlatCap) {
+      const bool act = len > 0;
+      const unsigned long long am = __ballot(act);
+      const int r = __popcll(am & lt_mask);
+      if (act) {
+        // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
+        ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
+        res[r] = MODE == PGP_MODE_PLAIN ? 0ull : ~0ull;
+        for (uint32_t k = 0; k < len; ++k) own[pre + k] = (unsigned char)r;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // four chunks of 64 slots per batch: owner lookups, then ALL candidate loads, then tests
+      for (uint32_t w0 = 0; w0 < W; w0 += 256) {
+        int o[4];
+        float4 en[4], p[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t w = w0 + 64 * c + lane;
+          o[c] = w < W ? (int)own[w] : -1;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) en[c] = ent[o[c] >= 0 ? o[c] : 0];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const uint32_t w = w0 + 64 * c + lane;
+          // a finished lane re-reads the wave's first candidate (always valid: W > 0)
+          p[c] = cand[o[c] >= 0 ? __float_as_uint(en[c].w) + w : __float_as_uint(ent[0].w)];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float d2 = sqdist(en[c].x, en[c].y, en[c].z, p[c]);
+          if (o[c] >= 0 && d2 <= a.sq_eps) {
+            if (MODE == PGP_MODE_PLAIN) {
+              res[o[c]] = 1ull;  // benign race: every writer stores the same value
+            } else {
+              atomicMin(&res[o[c]],
+                        ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (act) {
+        const unsigned long long rv = res[r];
+        if (MODE == PGP_MODE_PLAIN) hit = rv != 0ull;
+        else nn_id = rv == ~0ull ? -1 : (int)(unsigned)(rv & 0xFFFFFFFFull);
+      }
+    } else {
+      // oversized wave-iteration (very dense scene): per-lane walk
+      if (MODE == PGP_MODE_PLAIN) hit = any_in_run(cand, s, e, x, y, z, a.sq_eps);
+      else nn_id = nearest_in_run(cand, s, e, x, y, z, a.sq_eps);
+    }
+    float wsum = 0.f;
+    if (MODE == PGP_MODE_WEIGHTED && nn_id >= 0) {
+      const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
+      const float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
+      const float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
+      const float4 pn = Pnw[nn_id];
+      const float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+      if (gate_ok(dot, a.gate_lo, a.gate_hi)) {
+        hit = true;
+        wsum = pn.w;
+      }
+    }
+    const unsigned long long mask = __ballot(hit);
+    if (MODE == PGP_MODE_WEIGHTED) {
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
+    }
+    if (lane == 0) {
+      s_cnt[wave][h - h0] = __popcll(mask);
+      if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][h - h0] = wsum;
     }
   }
   __syncthreads();
@@ -321,7 +489,7 @@ __global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __res
   float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
   float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
   uint32_t s, e;
-  cell_run(a.g, a.words, a.occ_start, x, y, z, &s, &e);
+  cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e);
   int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
   if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
     float4 qn = a.Qn[i];
@@ -358,6 +526,18 @@ float key2f(int32_t k) {
 }
 
 void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a) {
+  // defaults by measurement at C2 (tools/tune.py): plain 120.7 us flat vs 124.2 us per-lane U=2;
+  // weighted 184 us flat (64-bit LDS atomic min per hit) vs 166 us per-lane U=2
+  if (unroll == 0 && mode == PGP_MODE_WEIGHTED) unroll = 2;
+  if (unroll <= 0) {  // wave-flattened candidate phase
+    if (mode == PGP_MODE_PLAIN)
+      hipLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, a, a.T, a.words,
+                         a.occ_run, a.cand, a.Pnw);
+    else
+      hipLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, a, a.T,
+                         a.words, a.occ_run, a.cand, a.Pnw);
+    return;
+  }
 #define PGP_LAUNCH(M, UU) hipLaunchKernelGGL((score_hypotheses<M, UU>), grid, dim3(kTile), 0, stream, a)
   if (mode == PGP_MODE_PLAIN) {
     switch (unroll) {
@@ -402,7 +582,7 @@ int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
   }
   a->g = ctx->grid;
   a->words = ctx->d_bitmap.as<uint2>();
-  a->occ_start = ctx->d_occ_start.as<uint32_t>();
+  a->occ_run = ctx->d_occ_start.as<uint2>();
   a->cand = ctx->d_cand.as<float4>();
   a->Pnw = ctx->d_Pnw.as<float4>();
   a->Q = ctx->d_Q.as<float4>();

@@ -60,7 +60,7 @@ struct pgp_ctx {
   pgp::DevBuf d_cell_tmp;    // uint32 [n_cells+1]  (counts, then fill cursors)
   pgp::DevBuf d_scan_tmp;    // uint32 block sums
   pgp::DevBuf d_bitmap;      // uint2 {occupancy bits, rank base} [nz*ny*nxw]
-  pgp::DevBuf d_occ_start;   // uint32 [n_occ+1]   CSR offsets of the occupied cells only
+  pgp::DevBuf d_occ_start;   // uint2 {start, count} per occupied cell [n_occ]
   long long n_occ = 0;
   pgp::DevBuf d_cand;        // float4 {x,y,z,bits(i)} [n_cand]
   float build_ms = 0.f;
@@ -95,7 +95,7 @@ struct pgp_ctx {
   pgp::DevBuf d_hits;     // [nQ] int (pgp_registered)
 
   // tuning knobs (env PGP_UNROLL / PGP_HPB at pgp_create; defaults chosen by measurement)
-  int unroll = 2;
+  int unroll = 0;      // 0: wave-flattened candidate phase; 1/2/4/8: per-lane walk, U hypotheses in flight
   int hpb_override = 0;
 
   // optional per-kernel timing (pgp_set_kernel_timing)
