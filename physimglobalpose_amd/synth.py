@@ -32,6 +32,8 @@ class Workload:
     centroid_Q: np.ndarray
     delta: float = DELTA
     gate_deg: float = GATE_DEG
+    Qs_nrm: np.ndarray = None       # (nQs,3) f32 normals of the search model
+    T_gt_world: np.ndarray = None   # (4,4) f64 ground-truth pose, model frame -> camera frame
 
     @property
     def n_h(self) -> int:
@@ -257,7 +259,8 @@ def make_workload(n_scene=50000, n_model=5000, n_hyp=4096, config_id=2, n_search
         P_w=np.ascontiguousarray(w.astype(np.float32)),
         Q_xyz=np.ascontiguousarray(Qvc), Q_nrm=np.ascontiguousarray(Qn.astype(np.float32)),
         Qs_xyz=np.ascontiguousarray(Qsc), T=np.ascontiguousarray(Tc.astype(np.float32)),
-        T_gt=centred(T_gt), centroid_P=cP, centroid_Q=cQ)
+        T_gt=centred(T_gt), centroid_P=cP, centroid_Q=cQ,
+        Qs_nrm=np.ascontiguousarray(Qn[sel].astype(np.float32)), T_gt_world=T_gt)
 
 
 def colmajor16(T4x4) -> np.ndarray:

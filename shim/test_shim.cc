@@ -1,0 +1,61 @@
+// shim/test_shim.cc -- stands in for the node side of the boundary
+// (PPE/hypothesis_generation/ObjectPoseCandidateSet.cpp:53-68 + PPE/data_layer/Objects.cpp:31-49):
+// loads PPFMap.txt the way Objects::readPPFMap does, calls getProbableTransformsSuper4PCS exactly
+// as CongruentSetMatching::generate does, and prints the outputs for tests/test_shim_gpu.py.
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+
+void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std::string input3,
+                                    std::pair<Eigen::Isometry3d, float>& bestHypothesis,
+                                    std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
+                                    std::string probImagePath,
+                                    std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
+                                    int max_count_ppf, Eigen::Matrix3f camIntrinsic, std::string objName,
+                                    std::string scenePath, std::vector<int>& registered_points);
+
+int main(int argc, char** argv) {
+  if (argc < 10) {
+    std::fprintf(stderr, "usage: test_shim segment.ply model_val.ply model_search.ply prob.png PPFMap.txt fx fy cx cy\n");
+    return 2;
+  }
+  std::map<std::vector<int>, std::vector<std::pair<int, int> > > PPFMap;
+  {
+    std::ifstream f(argv[5]);
+    std::vector<int> key(4);
+    int count;
+    while (f >> key[0] >> key[1] >> key[2] >> key[3] >> count) {
+      std::vector<std::pair<int, int> > pairs;
+      for (int i = 0; i < count; ++i) {
+        int a, b;
+        f >> a >> b;
+        pairs.push_back(std::make_pair(a, b));
+      }
+      PPFMap.insert(std::make_pair(key, pairs));
+    }
+  }
+  Eigen::Matrix3f K = Eigen::Matrix3f::Identity();
+  K(0, 0) = std::atof(argv[6]); K(1, 1) = std::atof(argv[7]); K(0, 2) = std::atof(argv[8]); K(1, 2) = std::atof(argv[9]);
+  std::pair<Eigen::Isometry3d, float> best;
+  best.first.matrix().setIdentity();
+  best.second = 0;
+  std::vector<std::pair<Eigen::Isometry3d, float> > hyps;
+  std::vector<int> registered;
+  getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMap, 0, K, "synthetic_object",
+                                 "./", registered);
+  std::printf("PPFMAP %zu\n", PPFMap.size());
+  std::printf("BEST_SCORE %.9g\n", best.second);
+  std::printf("BEST_POSE");
+  for (int r = 0; r < 4; ++r)
+    for (int c = 0; c < 4; ++c) std::printf(" %.17g", best.first.matrix()(r, c));
+  std::printf("\nHYPOTHESES %zu", hyps.size());
+  for (size_t i = 0; i < hyps.size(); ++i) std::printf(" %.9g", hyps[i].second);
+  std::printf("\nREGISTERED %zu\n", registered.size());
+  return 0;
+}
