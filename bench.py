@@ -69,6 +69,58 @@ def cpu_baseline(w, mode, budget_s=12.0):
     }
 
 
+def other_rows(sc, w, torch):
+    """Secondary measurements for the other rows of SURVEY section 8 (not the headline metric):
+    weighted LCP, batched ICP, congruent-set extraction, rigid fits.  Device time via host wall
+    clock around synchronous C-ABI calls, inputs staged per call (PCIe inclusive)."""
+    from physimglobalpose_amd import PGP_MODE_WEIGHTED, synth
+    out = {}
+    rng = np.random.default_rng(0)
+
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, r
+
+    # ICP: 64 poses, 2500-pt segment vs 5000-pt model, 10 iterations each (trim 0.9)
+    seg = w.Q_xyz[rng.choice(len(w.Q_xyz), 2500, replace=False)]
+    R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8)
+    S = (seg @ R.T + np.array([0.1, 0.0, 0.7])).astype(np.float32)
+    Tinv = np.linalg.inv(synth._se3(R, np.array([0.1, 0.0, 0.7])))
+    G = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(5)), 0.005 * rng.standard_normal(3)))
+                  for _ in range(64)])
+    dt, (_, _, its) = timed(lambda: sc.icp_refine(S, w.Q_xyz, G, trim=0.9, max_iterations=10), reps=3)
+    n_it = int(its.sum())
+    out["icp"] = {"poses": 64, "n_src": 2500, "n_tgt": len(w.Q_xyz), "iterations_total": n_it,
+                  "pose_iterations_per_s": n_it / dt, "ms_per_call": dt * 1e3,
+                  "algorithmic_GBps": n_it * (12 * 2500 + 12 * len(w.Q_xyz) + 112) / dt / 1e9}
+    # congruent sets on a 1000-pt search model
+    w2 = synth.make_workload(4000, 2000, 4, config_id=3, n_search=1000)
+    sc.set_search_model(w2.Qs_xyz)
+    T = w2.T_gt.reshape(4, 4).T
+    ids = rng.choice(1000, 4, replace=False)
+    base = (w2.Qs_xyz[ids] @ T[:3, :3].T + T[:3, 3]).astype(np.float32)
+    d1 = float(np.linalg.norm(base[0] - base[1]))
+    d6 = float(np.linalg.norm(base[2] - base[3]))
+    dt1, p1 = timed(lambda: sc.extract_pairs(d1, w.delta, cap=1 << 20))
+    p6 = sc.extract_pairs(d6, w.delta, cap=1 << 20)
+    dt2, q = timed(lambda: sc.find_congruent(base, 0.4, 0.6, w.delta, p1, p6, cap=1 << 20))
+    out["congruent"] = {"n_search": 1000, "pairs": int(len(p1)), "pairs_per_s": len(p1) / dt1,
+                        "pair_tests_per_s": 1000 * 999 / 2 / dt1, "quads": int(len(q)),
+                        "pair_pairs_per_s": float(len(p1)) * len(p6) / dt2, "ms_extract": dt1 * 1e3, "ms_find": dt2 * 1e3}
+    # rigid fits: 10 000 (base, quad) pairs
+    sc.set_search_model(w.Qs_xyz)
+    b = rng.integers(0, len(w.P_xyz), (10000, 4)).astype(np.int32)
+    qd = rng.integers(0, len(w.Qs_xyz), (10000, 4)).astype(np.int32)
+    dt3, _ = timed(lambda: sc.rigid_from_congruent(b, qd, w.centroid_P, w.centroid_Q))
+    out["rigid_fit"] = {"pairs": 10000, "fits_per_s": 10000 / dt3, "ms_per_call": dt3 * 1e3}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,6 +237,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.mode)
+            try:
+                out["other_rows"] = other_rows(sc, w, torch)
+            except Exception as e:  # secondary numbers must never take the headline line down
+                out["other_rows"] = {"error": repr(e)}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
