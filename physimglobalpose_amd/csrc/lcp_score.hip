@@ -437,12 +437,15 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
 // (Scalar(good_points)/Scalar(number_of_points), base.cc:1730 / weighted_match/Scalar(n), :1765)
 // and fold the batch arg-max: key = score bits << 32 | ~index, so the maximum key is the highest
 // score at its LOWEST index = what `lcp > best_LCP_` (strict, base.cc:1891) ends on.
+// The last block to finish (ticket) publishes {best index, best score bits} and re-arms the key
+// and the ticket for the next call, so a scoring call is two launches: score + finalize.
 __global__ __launch_bounds__(256) void finalize_scores(const int* __restrict__ partial_cnt,
                                                        const float* __restrict__ partial_sum,
                                                        int n_tiles, int n_h, int nQ, int mode,
                                                        float* __restrict__ scores,
                                                        int* __restrict__ counts,
-                                                       unsigned long long* __restrict__ best_key) {
+                                                       unsigned long long* best_key,
+                                                       unsigned int* ticket, int* __restrict__ best) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long key = 0;
   if (h < n_h) {
@@ -463,18 +466,32 @@ __global__ __launch_bounds__(256) void finalize_scores(const int* __restrict__ p
     unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  if ((threadIdx.x & 63) == 0 && key) atomicMax(best_key, key);
+  __shared__ unsigned long long s_key[4];
+  if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long k = s_key[0];
+    for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k;
+    if (k) atomicMax(best_key, k);   // device-scope atomics: performed at L2, visible to every XCD
+    __threadfence();
+    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+      __threadfence();
+      const unsigned long long kk = atomicExch(best_key, 0ull);  // read the result and re-arm
+      atomicExch(ticket, 0u);
+      if (kk == 0) {
+        best[0] = -1;
+        best[1] = 0;  // best_LCP_ = 0.0f
+      } else {
+        best[0] = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+        best[1] = (int)(unsigned)(kk >> 32);
+      }
+    }
+  }
 }
 
-__global__ void publish_best(const unsigned long long* __restrict__ best_key, int* __restrict__ best) {
-  unsigned long long k = *best_key;
-  if (k == 0) {
-    best[0] = -1;
-    best[1] = 0;  // best_LCP_ = 0.0f
-  } else {
-    best[0] = (int)(0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull));
-    best[1] = (int)(unsigned)(k >> 32);
-  }
+__global__ void publish_none(int* __restrict__ best) {  // empty hypothesis list (base.cc:1791-1794)
+  best[0] = -1;
+  best[1] = 0;
 }
 
 // One transform, per-model-point result in ORIGINAL model order (the Q arrays are Morton-sorted;
@@ -644,9 +661,9 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     set_error("n_h %d exceeds reserved capacity %d (pgp_reserve)", n_h, ctx->cap_h);
     return PGP_ESTATE;
   }
-  unsigned long long* key = ctx->d_best.as<unsigned long long>();
-  int* best_local = reinterpret_cast<int*>(key + 1);
-  PGP_HIP(hipMemsetAsync(key, 0, 8, stream));
+  unsigned long long* key = ctx->d_best.as<unsigned long long>();   // zeroed at create, re-armed
+  int* best_local = reinterpret_cast<int*>(key + 1);                 // by every finalize launch
+  unsigned int* ticket = reinterpret_cast<unsigned int*>(key + 2);
   if (n_h > 0) {
     // ~40 workgroups per CU (measured best at C2: hpb 8 -> 125 us vs 136 us at hpb 20); at least
     // 4 hypotheses per block to amortise the model-point load
@@ -678,10 +695,10 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     if (ev1) PGP_HIP(hipEventRecord(ev1, stream));
     hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream,
                        (const int*)a.partial_cnt, (const float*)a.partial_sum, a.n_tiles, n_h, a.nQ,
-                       mode, d_scores, d_counts, key);
+                       mode, d_scores, d_counts, key, ticket, d_best ? d_best : best_local);
+  } else {
+    hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best ? d_best : best_local);
   }
-  hipLaunchKernelGGL(publish_best, dim3(1), dim3(1), 0, stream, (const unsigned long long*)key,
-                     d_best ? d_best : best_local);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

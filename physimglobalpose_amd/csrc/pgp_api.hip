@@ -127,6 +127,7 @@ int pgp_create(pgp_ctx** out, int device_id) {
     return PGP_ENODEV;
   }
   int rc = ctx->d_best.ensure(32);
+  if (rc == PGP_OK && hipMemset(ctx->d_best.p, 0, 32) != hipSuccess) rc = PGP_EHIP;  // key + ticket armed
   if (rc != PGP_OK) {
     hipStreamDestroy(ctx->stream);
     delete ctx;
