@@ -330,12 +330,15 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
     uint32_t s = 0, e = 0;
     if (live) cell_run(a.g, words, occ_run, x, y, z, &s, &e);
     const uint32_t len = e - s;
-    // exclusive prefix of the run lengths over the wave
+    // exclusive prefix of the run lengths over the wave (skipped when no lane owns a run:
+    // 35 % of the wave-iterations at C2)
     uint32_t incl = len;
+    if (__ballot(len > 0)) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t t = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += t;
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+      }
     }
     const uint32_t pre = incl - len;
     const uint32_t W = __shfl(incl, 63, 64);
