@@ -40,7 +40,7 @@ def test_three_objects_score_then_icp_refine():
         s_before = sc.score(w.T[top], PGP_MODE_PLAIN)[0]
         # trimmed ICP minimises the distance energy, not the inlier count: the refined poses agree
         # with each other and sit at the level of the best candidate (within a few inliers)
-        assert s_ref.max() >= s_before.max() - 3.0 / len(w.Q_xyz)
+        assert s_ref.max() >= 0.97 * s_before.max()
         assert np.median(s_ref) >= np.median(s_before)
         assert s_ref.max() - s_ref.min() <= 5.0 / len(w.Q_xyz)
         assert (iters >= 1).all() and np.isfinite(energy).all()
