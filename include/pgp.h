@@ -57,6 +57,15 @@ int pgp_destroy(pgp_ctx* ctx);
 int pgp_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int nQv,
                float centroid_P[3], float centroid_Q[3]);
 
+/* Replaces the "priority based sampling" loop of Match4PCSBase::init (base.cc:317-340): the
+ * per-scene-point weight orig_probabilities_[i] = probImg(row, col) with probImg = u16 / 10000
+ * and (col,row) = int(K * (p_i + centroid_P)) / z, float arithmetic in the reference's order.
+ * P_xyz is the CENTRED cloud; K is the 3x3 intrinsic matrix, row-major; img is the decoded
+ * 16-bit probability image (rows x cols, row-major).  Pixels outside the image give weight 0
+ * (the reference reads out of bounds there).  Pure host helper. */
+int pgp_weights_from_image(const float* P_xyz, int n, const float centroid_P[3], const float K[9],
+                           const unsigned short* img, int rows, int cols, float* weights);
+
 /* Replaces `sampled_P_3D_ = P` + initKdTree() + orig_probabilities_ (base.cc:235,270,1046-1056,
  * 327-340): uploads the (centred) scene cloud and builds the device spatial index for inlier
  * radius `delta` (options_.delta, S4/super4pcs_test.cc:20).  nrm and weight may be NULL

@@ -351,6 +351,33 @@ void ref_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int
   for (int k = 0; k < 3; ++k) { centroid_P[k] = cP(k); centroid_Q[k] = cQ(k); }
 }
 
+// base.cc:327-340 (priority based sampling): weight of every centred scene point from the decoded
+// probability image.  cv::Mat / cv::imread are the only OpenCV pieces of the original loop; the
+// arithmetic is Eigen's and is restated with the same types.  K is row-major 3x3.
+void ref_weights_from_image(const float* P_xyz, int n, const float* centroid_P, const float* K,
+                            const unsigned short* img, int rows, int cols, float* out) {
+  Eigen::Matrix3f camIntrinsic;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) camIntrinsic(r, c) = K[3 * r + c];
+  VectorType centroid_P_(centroid_P[0], centroid_P[1], centroid_P[2]);
+  for (int i = 0; i < n; ++i) {
+    Point3D b_ii(P_xyz[3 * i], P_xyz[3 * i + 1], P_xyz[3 * i + 2]);
+    b_ii.pos() += centroid_P_;
+    double x1 = b_ii.x();
+    double y1 = b_ii.y();
+    double z1 = b_ii.z();
+    Eigen::Vector3f point2D = camIntrinsic * Eigen::Vector3f(x1, y1, z1);
+    int col = point2D[0] / point2D[2];
+    int row = point2D[1] / point2D[2];
+    float prob = 0.f;
+    if (row >= 0 && row < rows && col >= 0 && col < cols) {
+      unsigned short probShort = img[(size_t)row * cols + col];
+      prob = (float)probShort / 10000;
+    }
+    out[i] = prob;
+  }
+}
+
 // The reference's kd-tree query itself (kdtree.h:394-459).
 int ref_kd_query(void* h, const float* xyz, float sqdist) {
   RefScene* s = static_cast<RefScene*>(h);

@@ -191,6 +191,35 @@ int pgp_center(float* P, int nP, float* Qs, int nQs, float* Qv, int nQv, float c
   return PGP_OK;
 }
 
+int pgp_weights_from_image(const float* P, int n, const float cP[3], const float K[9],
+                           const unsigned short* img, int rows, int cols, float* weights) {
+  if (n < 0 || rows < 0 || cols < 0 || (n > 0 && (!P || !weights)) || !cP || !K || (rows * cols > 0 && !img)) {
+    set_error("pgp_weights_from_image: bad argument");
+    return PGP_EINVAL;
+  }
+  for (int i = 0; i < n; ++i) {
+    // b_ii.pos() += centroid_P_ (float), then double x1,y1,z1 -> Eigen::Vector3f(x1,y1,z1) (back to float)
+    const float x = P[3 * (size_t)i] + cP[0], y = P[3 * (size_t)i + 1] + cP[1], z = P[3 * (size_t)i + 2] + cP[2];
+    // camIntrinsic * v: Eigen evaluates a 3x3 * 3x1 float product as k0*x + (k1*y + k2*z) per row
+    float u[3];
+    for (int r = 0; r < 3; ++r) {
+      float a = K[3 * r] * x, b = K[3 * r + 1] * y, c = K[3 * r + 2] * z;
+      float bc = b + c;
+      u[r] = a + bc;
+    }
+    const float fc = u[0] / u[2], fr = u[1] / u[2];
+    // int col = point2D[0]/point2D[2]: truncation toward zero; guard what the reference leaves undefined
+    const bool ok = fc == fc && fr == fr && fc > -1.f && fr > -1.f && fc < (float)cols && fr < (float)rows;
+    float w = 0.f;
+    if (ok) {
+      const int col = (int)fc, row = (int)fr;
+      if (col >= 0 && row >= 0 && col < cols && row < rows) w = (float)img[(size_t)row * cols + col] / 10000;
+    }
+    weights[i] = w;
+  }
+  return PGP_OK;
+}
+
 int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float* weight, int n,
                   float delta) {
   if (!ctx || n < 0 || (n > 0 && !xyz) || !(delta > 0.f) || !std::isfinite(delta)) {

@@ -68,6 +68,18 @@ class LcpScorer:
         _lib.check(lib.pgp_center(_fp(P), len(P), _fp(Qs), len(Qs), _fp(Qv), len(Qv), _fp(cP), _fp(cQ)))
         return P, Qs, Qv, cP, cQ
 
+    @staticmethod
+    def weights_from_image(P_centred, centroid_P, K, img_u16):
+        """base.cc:317-340: per-point weight = probability image (u16 / 10000) at the projection."""
+        P = _f32(P_centred, 3)
+        cP, K = _f32(centroid_P).reshape(3), _f32(K).reshape(9)
+        img = np.ascontiguousarray(img_u16, np.uint16)
+        out = np.zeros(len(P), np.float32)
+        _lib.check(_lib.load().pgp_weights_from_image(
+            _fp(P), len(P), _fp(cP), _fp(K), img.ctypes.data_as(C.POINTER(C.c_ushort)),
+            img.shape[0], img.shape[1], _fp(out)))
+        return out
+
     def set_scene(self, xyz, nrm=None, weight=None, delta=0.005):
         xyz, nrm, weight = _f32(xyz, 3), _f32(nrm, 3), _f32(weight)
         if nrm is not None and len(nrm) != len(xyz):

@@ -469,14 +469,12 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
     int rows = 0, cols = 0;
     bool have = read_png_gray(probImagePath, px, rows, cols);
     if (!have) std::cerr << "[libsuper4pcs shim] no probability image at " << probImagePath << ": weights = 1" << std::endl;
-    m.prob.resize(seg.n);
-    for (int i = 0; i < seg.n; ++i) {
-      if (!have) { m.prob[i] = 1.f; continue; }
-      double x1 = m.P[i](0) + cP[0], y1 = m.P[i](1) + cP[1], z1 = m.P[i](2) + cP[2];
-      Eigen::Vector3f p2 = camIntrinsic * Eigen::Vector3f(x1, y1, z1);
-      int col = p2[0] / p2[2], row = p2[1] / p2[2];
-      // the reference does not bounds-check (SURVEY 7 "unchecked prob-image indexing")
-      m.prob[i] = (row >= 0 && row < rows && col >= 0 && col < cols) ? (float)px[(size_t)row * cols + col] / 10000 : 0.f;
+    m.prob.assign(seg.n, 1.f);
+    if (have) {
+      float K[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
+      pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, px.data(), rows, cols, m.prob.data());
     }
   }
 

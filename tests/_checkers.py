@@ -246,6 +246,7 @@ def ref_lib():
         L.ref_dot.restype = C.c_float
         L.ref_dot.argtypes = [_f, _f]
         L.ref_rigid_from_pair.argtypes = [_f, _f, _f, _f, _f, _d, _f]
+        L.ref_weights_from_image.argtypes = [_f, C.c_int, _f, _f, C.POINTER(C.c_ushort), C.c_int, C.c_int, _f]
         L.ref_cs_create.restype = C.c_void_p
         L.ref_cs_create.argtypes = [_f, C.c_int, C.c_double]
         L.ref_cs_destroy.argtypes = [C.c_void_p]

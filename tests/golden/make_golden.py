@@ -176,6 +176,25 @@ def main():
     np.savez_compressed(path, p=ps, q=qs, centroid_P=cP, centroid_Q=cQ, status=status, T=Tc, pose=pose, rms=rms)
     print("rigid_fit:", np.bincount(status, minlength=3), f"{os.path.getsize(path)/1024:.0f} KiB")
     congruent_cases()
+    weights_case()
+
+
+def weights_case():
+    """(9) per-point weights from the probability image (base.cc:317-340) via the Eigen harness."""
+    import ctypes as C
+    L = ref_lib()
+    w = synth.make_workload(3000, 300, 2, config_id=120)
+    K = np.array([[615.3, 0, 320.7], [0, 612.9, 241.2], [0, 0, 1]], np.float32)
+    rng = np.random.default_rng(9)   # 20 x 20-pixel blocks: compresses to a few KB
+    img = np.kron(rng.integers(0, 10001, (24, 32)), np.ones((20, 20), np.int64)).astype(np.uint16)
+    img[100:200, 200:400] = 10000
+    img[300:, :50] = 0
+    out = np.zeros(len(w.P_xyz), np.float32)
+    L.ref_weights_from_image(_fp(w.P_xyz), len(w.P_xyz), _fp(w.centroid_P), _fp(K.ravel().copy()),
+                             img.ctypes.data_as(C.POINTER(C.c_ushort)), 480, 640, _fp(out))
+    path = os.path.join(HERE, "weights.npz")
+    np.savez_compressed(path, P=w.P_xyz, centroid_P=w.centroid_P, K=K, img=img, weights=out)
+    print("weights:", (out > 0).mean(), f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def congruent_cases():
@@ -214,5 +233,8 @@ def congruent_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "congruent":
         congruent_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "weights":
+        weights_case()
         sys.exit(0)
     main()

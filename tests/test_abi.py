@@ -70,6 +70,18 @@ def test_center_matches_oracle_bits():
         assert np.array_equal(x, y)
 
 
+def test_weights_from_image_matches_golden():
+    """base.cc:317-340 (probability image -> per-point weights): bit-exact vs the Eigen harness."""
+    from physimglobalpose_amd import LcpScorer
+    g = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
+    got = LcpScorer.weights_from_image(g["P"], g["centroid_P"], g["K"], g["img"])
+    assert np.array_equal(got, g["weights"]) and 0.2 < (got > 0).mean() <= 1.0
+    # points that project outside the image get weight 0 instead of an out-of-bounds read
+    far = g["P"].copy()
+    far[:, 0] += 50.0
+    assert not LcpScorer.weights_from_image(far, g["centroid_P"], g["K"], g["img"]).any()
+
+
 def test_running_best_rule():
     from physimglobalpose_amd import LcpScorer
     s = np.array([0.0, 0.2, 0.2, 0.1, 0.3, 0.3, 0.25, 0.31], np.float32)
