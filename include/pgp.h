@@ -179,7 +179,10 @@ typedef struct {
  * Host pointers, synchronous. */
 int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt,
                    float* T, int n, const pgp_icp_params* params, float* energy, int* iters);
-/* Device pointers: d_src / d_tgt are float4 arrays {x,y,z,-}; asynchronous on `stream`. */
+/* Device pointers: d_src / d_tgt are float4 arrays {x,y,z,-}; enqueued on `stream`.  The
+ * iterations are driven from the host (many workgroups per pose) and the call synchronises the
+ * stream every four iterations to test for convergence; PGP_ICP_SPLIT=0 selects the single-launch
+ * persistent kernel instead (never synchronises, same results, slower). */
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
                           float* d_T, int n, const pgp_icp_params* params, float* d_energy,
                           int* d_iters, void* stream);

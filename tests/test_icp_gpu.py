@@ -77,3 +77,18 @@ def test_bad_arguments():
     T, e, it = sc.icp_refine(np.zeros((5, 3), np.float32), np.zeros((5, 3), np.float32),
                              np.zeros((0, 16), np.float32))
     assert len(T) == 0
+
+
+@pytest.mark.parametrize("trim,cap", [(0.9, 0.0), (1.0, 0.015)])
+def test_split_path_is_bit_identical_to_persistent_path(trim, cap, monkeypatch):
+    """Few poses: correspondences searched by many workgroups per pose (icp_nn_split + 64-bit
+    atomic-min keys); many poses: one persistent workgroup per pose.  Same result, bit for bit."""
+    S, M, G, _ = _problem(5, 3000, 1700, 6)
+    sc = LcpScorer()
+    monkeypatch.setenv("PGP_ICP_SPLIT", "0")
+    T0, e0, it0 = sc.icp_refine(S, M, G, trim=trim, max_iterations=40, max_corr_dist=cap)
+    monkeypatch.setenv("PGP_ICP_SPLIT", "1")
+    T1, e1, it1 = sc.icp_refine(S, M, G, trim=trim, max_iterations=40, max_corr_dist=cap)
+    assert np.array_equal(it0, it1) and np.array_equal(T0, T1) and np.array_equal(e0, e1)
+    To, eo, ito = oracle_icp(S, M, G, trim=trim, max_iterations=40, max_corr_dist=cap)
+    assert np.array_equal(it1, ito) and np.abs(T1 - To).max() < 2e-6
