@@ -302,6 +302,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
   __shared__ float4 s_ent[kTile / 64][64];                 // {x', y', z', bits(run start - prefix)}
   __shared__ unsigned long long s_res[kTile / 64][64];     // plain: 0/1 ; weighted: min key
   __shared__ unsigned char s_own[kTile / 64][kFlatCap];    // slot -> compact owner index
+  __shared__ uint32_t s_wcount[kTile / 64];                // slots handed out in this wave-iteration
 
   const int L = blockIdx.x;
   const int xcd = L & 7, seq = L >> 3;
@@ -319,6 +320,8 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
   float4* ent = s_ent[wave];
   unsigned long long* res = s_res[wave];
   unsigned char* own = s_own[wave];
+  uint32_t* wcount = &s_wcount[wave];
+  if (lane == 0) *wcount = 0;
 
   const int h0 = chunk * a.hpb;
   const int h1 = min(h0 + a.hpb, a.n_h);
@@ -330,18 +333,17 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
     uint32_t s = 0, e = 0;
     if (live) cell_run(a.g, words, occ_run, x, y, z, &s, &e);
     const uint32_t len = e - s;
-    // exclusive prefix of the run lengths over the wave (skipped when no lane owns a run:
-    // 35 % of the wave-iterations at C2)
-    uint32_t incl = len;
+    // slot allocation in the concatenated run of the wave: one returning LDS atomic add per
+    // owning lane (any order will do: the owner map below resolves slots to owners), skipped
+    // when no lane owns a run (35 % of the wave-iterations at C2)
+    uint32_t pre = 0, W = 0;
     if (__ballot(len > 0)) {
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-      }
+      if (len > 0) pre = atomicAdd(wcount, len);
+      __builtin_amdgcn_wave_barrier();
+      W = *wcount;
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) *wcount = 0;
     }
-    const uint32_t pre = incl - len;
-    const uint32_t W = __shfl(incl, 63, 64);
     bool hit = false;
     int nn_id = -1;
     if (W == 0) {
