@@ -21,6 +21,21 @@ def shard_bounds(n_total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def flat_slices(counts, rank: int, world: int):
+    """Several objects, each with its own hypothesis list (BASELINE.json configs[3]: 6 objects,
+    64 k hypotheses over 8 GPUs): flatten (object, hypothesis) into one index space, give rank
+    `rank` its contiguous share, and return it as [(object, lo, hi), ...] pieces."""
+    counts = [int(c) for c in counts]
+    lo, hi = shard_bounds(sum(counts), rank, world)
+    out, base = [], 0
+    for obj, c in enumerate(counts):
+        a, b = max(lo, base), min(hi, base + c)
+        if b > a:
+            out.append((obj, a - base, b - base))
+        base += c
+    return out
+
+
 def best_of(scores: torch.Tensor):
     """(best_index, best_score) with the reference's strict-> / first-maximum rule."""
     if scores.numel() == 0:
@@ -62,3 +77,29 @@ class ShardedScorer:
         combine_scores(out, self.group)
         bi, bs = best_of(out)
         return out, bi, bs
+
+
+class MultiObjectShardedScorer:
+    """`score_local[obj](T_slice) -> scores` per object; every object's clouds are replicated on
+    every rank.  One all-reduce for the concatenated score vector of all objects, then a local
+    arg-max per object."""
+
+    def __init__(self, score_local, rank=None, world=None, group=None):
+        self.score_local = list(score_local)
+        self.group = group
+        init = dist.is_available() and dist.is_initialized()
+        self.rank = rank if rank is not None else (dist.get_rank(group) if init else 0)
+        self.world = world if world is not None else (dist.get_world_size(group) if init else 1)
+
+    def score(self, T_per_object):
+        counts = [int(T.shape[0]) for T in T_per_object]
+        offs = [0]
+        for c in counts:
+            offs.append(offs[-1] + c)
+        dev = T_per_object[0].device if counts else torch.device("cpu")
+        flat = torch.zeros(offs[-1], dtype=torch.float32, device=dev)
+        for obj, lo, hi in flat_slices(counts, self.rank, self.world):
+            flat[offs[obj] + lo:offs[obj] + hi] = self.score_local[obj](T_per_object[obj][lo:hi])
+        combine_scores(flat, self.group)
+        per_obj = [flat[offs[o]:offs[o + 1]] for o in range(len(counts))]
+        return per_obj, [best_of(s) for s in per_obj]

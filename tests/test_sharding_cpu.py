@@ -11,7 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from physimglobalpose_amd import synth
-from physimglobalpose_amd.sharding import ShardedScorer, best_of, shard_bounds
+from physimglobalpose_amd.sharding import (MultiObjectShardedScorer, ShardedScorer, best_of, flat_slices,
+                                           shard_bounds)
 
 
 def test_shard_bounds_cover_and_balance():
@@ -30,6 +31,21 @@ def test_best_of_rule():
     bi, bs = best_of(torch.tensor([0.1, 0.5, 0.5, 0.2]))
     assert bi == 1 and abs(bs - 0.5) < 1e-7
     assert best_of(torch.tensor([float("nan"), 0.25]))[0] == 1
+
+
+def test_flat_slices_partition_every_object_exactly_once():
+    for counts in ([5], [3, 0, 9], [16384] * 3, [10923] * 6, [1, 1, 1, 1, 1, 1]):
+        for world in (1, 2, 3, 8):
+            seen = [np.zeros(c, int) for c in counts]
+            sizes = []
+            for r in range(world):
+                n = 0
+                for obj, lo, hi in flat_slices(counts, r, world):
+                    seen[obj][lo:hi] += 1
+                    n += hi - lo
+                sizes.append(n)
+            assert all((s == 1).all() for s in seen)
+            assert max(sizes) - min(sizes) <= 1
 
 
 def _free_port():
@@ -58,7 +74,10 @@ def _worker(rank, world, port, n_h, q):
 
         sh = ShardedScorer(local)
         scores, bi, bs = sh.score(torch.from_numpy(w.T))
-        q.put((rank, scores.numpy(), bi, bs))
+        # several objects at once (configs[3] pattern): here the same scorer under 3 list lengths
+        Ts = [torch.from_numpy(w.T[:n]) for n in (n_h, n_h // 3, 5)]
+        per_obj, bests = MultiObjectShardedScorer([local] * 3).score(Ts)
+        q.put((rank, scores.numpy(), bi, bs, [p.numpy() for p in per_obj], bests))
     finally:
         dist.destroy_process_group()
 
@@ -79,6 +98,10 @@ def test_sharded_equals_unsharded(world, n_h):
     w = synth.make_workload(1500, 200, n_h, config_id=31)
     orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
     s_ref, bi_ref, _ = orc.score_batch(w.T, w.delta, mode=0)
-    for rank, s, bi, bs in results:
+    for rank, s, bi, bs, per_obj, bests in results:
         assert np.array_equal(s, s_ref), f"rank {rank}"
         assert bi == bi_ref and np.float32(bs) == s_ref[bi_ref]
+        for n, p, (obi, obs) in zip((n_h, n_h // 3, 5), per_obj, bests):
+            assert np.array_equal(p, s_ref[:n])
+            exp = int(np.argmax(s_ref[:n])) if s_ref[:n].max() > 0 else -1
+            assert obi == exp
