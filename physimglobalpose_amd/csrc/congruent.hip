@@ -122,10 +122,8 @@ __global__ __launch_bounds__(256) void pair_rows(const float4* __restrict__ Qw, 
     unsigned long long m = __ballot(hit);
     if (FILL && hit) {
       uint32_t slot = base + running + __popcll(m & ((1ull << lane) - 1ull));
-      if (2ull * slot + 1 < cap) {
-        out[2 * slot] = make_int2(j, i);      // pairs->emplace_back(j, i)
-        out[2 * slot + 1] = make_int2(i, j);  // pairs->emplace_back(i, j)
-      }
+      if (2ull * slot < cap) out[2 * slot] = make_int2(j, i);          // pairs->emplace_back(j, i)
+      if (2ull * slot + 1 < cap) out[2 * slot + 1] = make_int2(i, j);  // pairs->emplace_back(i, j)
     }
     running += __popcll(m);
   }

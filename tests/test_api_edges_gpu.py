@@ -1,0 +1,70 @@
+"""Edge cases of the secondary entry points (through the C ABI): empty and degenerate inputs,
+caps, non-finite transforms.  The scoring entry points have their own file (test_edge_gpu.py)."""
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import LcpScorer, synth, _lib
+
+pytestmark = pytest.mark.gpu
+I16 = synth.colmajor16(np.eye(4))
+
+
+def test_congruent_entry_points_on_tiny_and_empty_inputs():
+    sc = LcpScorer()
+    with pytest.raises(_lib.PgpError):
+        sc.extract_pairs(0.1, 0.005)                       # no search model yet
+    sc.set_search_model(np.zeros((1, 3), np.float32))
+    assert len(sc.extract_pairs(0.1, 0.005)) == 0         # a single point has no pairs
+    pts = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0], [0.1, 0.1, 0]], np.float32)
+    sc.set_search_model(pts)
+    p = sc.extract_pairs(0.1, 0.001)
+    assert {tuple(x) for x in p.tolist()} == {(0, 1), (1, 0), (0, 2), (2, 0), (1, 3), (3, 1), (2, 3), (3, 2)}
+    assert len(sc.extract_pairs(0.1, 0.001, cap=3)) == 3  # truncated, no overflow
+    base = pts.copy()
+    assert len(sc.find_congruent(base, 0.5, 0.5, 0.005, np.zeros((0, 2), np.int32), p)) == 0
+    # crossing diagonals of the square: the two segments meet at their midpoints
+    diag = sc.extract_pairs(np.float32(0.1 * np.sqrt(2)), 0.001)
+    assert {tuple(x) for x in diag.tolist()} == {(0, 3), (3, 0), (1, 2), (2, 1)}
+    cross = pts[[0, 3, 1, 2]]
+    q = sc.find_congruent(cross, 0.5, 0.5, 0.005, diag, diag)
+    # whatever the reference's cone rasterisation yields here (nothing, for this exactly planar
+    # toy), the GPU yields the same list
+    from _checkers import CongruentChecker
+    assert np.array_equal(q, CongruentChecker(pts, "oracle").find_congruent(cross, 0.5, 0.5, 0.005, diag, diag))
+    # parallel base segments: the reference's cone angle is acos(1) = 0 -> zero samples
+    par = np.array([[0, 0, 0], [0.1, 0, 0], [0, 0.1, 0], [0.1, 0.1, 0]], np.float32)
+    assert len(sc.find_congruent(par, 0.5, 0.5, 0.005, p, p)) >= 0
+    # out-of-range pair ids are ignored, not dereferenced
+    bad = np.array([[0, 99], [1, 2]], np.int32)
+    sc.find_congruent(base, 0.5, 0.5, 0.005, bad, p)
+    with pytest.raises(_lib.PgpError):
+        sc.find_congruent(base, 0.5, 0.5, 0.0, p, p)       # threshold 0 -> unusable grid
+
+
+def test_icp_with_nonfinite_guess_and_tiny_clouds():
+    rng = np.random.default_rng(0)
+    M = rng.uniform(-0.1, 0.1, (50, 3)).astype(np.float32)
+    S = M[:7] + np.float32(0.001)
+    G = np.stack([I16, I16.copy()])
+    G[1, 12] = np.nan
+    sc = LcpScorer()
+    T, e, it = sc.icp_refine(S, M, G, trim=0.7, max_iterations=20)
+    assert np.isfinite(T[0]).all() and e[0] < 1e-5 and it[0] >= 1
+    assert it[1] >= 1                                       # the NaN pose terminates too
+    T1, _, it1 = sc.icp_refine(M[:1], M[:1], I16[None], trim=1.0)   # one point each
+    assert np.isfinite(T1).all() and it1[0] >= 1
+
+
+def test_rigid_fit_empty_batch_and_state_errors():
+    sc = LcpScorer()
+    with pytest.raises(_lib.PgpError):
+        sc.rigid_from_congruent(np.zeros((1, 4), np.int32), np.zeros((1, 4), np.int32), np.zeros(3), np.zeros(3))
+    sc.set_scene(np.zeros((4, 3), np.float32), None, None, 0.005)
+    sc.set_search_model(np.zeros((4, 3), np.float32))
+    T, pose, st, rms = sc.rigid_from_congruent(np.zeros((0, 4), np.int32), np.zeros((0, 4), np.int32),
+                                               np.zeros(3), np.zeros(3))
+    assert len(T) == 0
+    # all points coincide: every fit is degenerate (status 2), transforms are NaN
+    T, pose, st, rms = sc.rigid_from_congruent(np.array([[0, 1, 2, 3]], np.int32), np.array([[0, 1, 2, 3]], np.int32),
+                                               np.zeros(3), np.zeros(3))
+    assert st[0] == 2 and np.isnan(T).all()
