@@ -177,6 +177,7 @@ def main():
     print("rigid_fit:", np.bincount(status, minlength=3), f"{os.path.getsize(path)/1024:.0f} KiB")
     congruent_cases()
     weights_case()
+    test_scene_case()
 
 
 def weights_case():
@@ -195,6 +196,43 @@ def weights_case():
     path = os.path.join(HERE, "weights.npz")
     np.savez_compressed(path, P=w.P_xyz, centroid_P=w.centroid_P, K=K, img=img, weights=out)
     print("weights:", (out > 0).mean(), f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+def test_scene_case():
+    """(10) BASELINE.json configs[0]: the reference's own test-scene/ (one RGB-D frame, class mask,
+    intrinsics).  Decodes the depth PNG as PPE/misc/utilities.cpp:47-61 does (16-bit rotate right by
+    3, / 10000), back-projects every mask class to a camera-frame cloud, thins it with a 1 cm voxel
+    grid (PPE/segmentation/Segmentation.cpp:234-237) and estimates normals (PCA over 12 neighbours,
+    flipped to the viewpoint as ObjectPoseCandidateSet.cpp:39-51).  Only these derived clouds are
+    stored -- no reference file is copied."""
+    from PIL import Image
+    d = "/root/reference/test-scene/"
+    raw = np.array(Image.open(d + "frame-000000.depth.png")).astype(np.uint16)
+    depth = (((raw.astype(np.uint32) << 13) | (raw >> 3)) & 0xFFFF).astype(np.float32) / np.float32(10000)
+    mask = np.array(Image.open(d + "frame-000000.mask.png"))
+    if mask.ndim == 3:
+        mask = mask[..., 0]
+    K = np.array([[6.13998108e+02, 0, 3.22453583e+02], [0, 6.13998169e+02, 2.39678940e+02], [0, 0, 1]])
+    out = {"K": K.astype(np.float32)}
+    for cls in [c for c in np.unique(mask) if c != 0]:
+        v, u = np.nonzero((mask == cls) & (depth > 0.2) & (depth < 2.0))
+        z = depth[v, u].astype(np.float64)
+        pts = np.stack([(u - K[0, 2]) * z / K[0, 0], (v - K[1, 2]) * z / K[1, 1], z], 1)
+        key = np.floor(pts / 0.01).astype(np.int64)
+        _, first = np.unique(key, axis=0, return_index=True)
+        pts = pts[np.sort(first)]
+        nrm = np.zeros_like(pts)
+        for i in range(len(pts)):
+            nb = pts[np.argsort(((pts - pts[i]) ** 2).sum(1))[:12]]
+            w_, vec = np.linalg.eigh(np.cov((nb - nb.mean(0)).T))
+            n = vec[:, 0]
+            nrm[i] = -n if n @ pts[i] > 0 else n
+        out[f"seg_{cls}"] = pts.astype(np.float32)
+        out[f"nrm_{cls}"] = nrm.astype(np.float32)
+        print(f"test-scene class {cls}: {len(pts)} points, z {pts[:,2].min():.3f}..{pts[:,2].max():.3f}")
+    path = os.path.join(HERE, "test_scene_segments.npz")
+    np.savez_compressed(path, **out)
+    print("test_scene_segments:", f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def congruent_cases():
@@ -233,6 +271,9 @@ def congruent_cases():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "congruent":
         congruent_cases()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "test_scene":
+        test_scene_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "weights":
         weights_case()
