@@ -25,6 +25,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 namespace pgp {
@@ -209,6 +210,10 @@ int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, 
   // (r = 1, 27 cells); h grows further only to keep the grid within kMaxDim / kMaxCells
   // (h >= delta stays exact: r is always computed from reach / h).
   float h = delta * 1.02f;
+  if (const char* v = getenv("PGP_CELL_RATIO")) {  // experiment knob: cell edge / delta
+    float ratio = (float)atof(v);
+    if (ratio > 0.05f && ratio < 64.f) h = delta * ratio;
+  }
   for (int iter = 0; iter < 200; ++iter) {
     // margin: rounding of cell(x) is <= ~4 ulp of (x-origin)*inv_h (value up to kMaxDim) plus
     // the ulp of the coordinates themselves; 0.4 % of a cell + 64 ulp(extent) covers it.

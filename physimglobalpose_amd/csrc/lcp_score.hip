@@ -69,44 +69,27 @@ __device__ __forceinline__ float sqdist(float x, float y, float z, float4 p) {
   return __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
 }
 
-// Level 1 of the lookup: the {occupancy bits, rank base} word of the cell holding (x,y,z), and
-// the bit position inside it; bit = -1 when the position is outside the grid (or NaN).
-__device__ __forceinline__ size_t word_index(const GridDesc& g, float x, float y, float z, int* bit) {
-  float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
-  *bit = -1;
-  if (fx >= 0.f && fx < (float)g.nx && fy >= 0.f && fy < (float)g.ny && fz >= 0.f && fz < (float)g.nz) {
-    int cx = (int)fx, cy = (int)fy, cz = (int)fz;
-    *bit = cx & 31;
-    return ((size_t)cz * g.ny + cy) * g.nxw + (cx >> 5);
-  }
-  return 0;
-}
-
-// Level 2: candidate run [s, e) of an occupied cell; empty when the bit is clear.
-__device__ __forceinline__ void run_of(const uint2* __restrict__ occ_run, uint2 wd, int bit,
-                                       uint32_t* s, uint32_t* e) {
-  *s = 0;
-  *e = 0;
-  if (bit >= 0 && ((wd.x >> bit) & 1u)) {
-    uint32_t k = wd.y + __popc(wd.x & ((1u << bit) - 1u));
-    unsigned long long rv = reinterpret_cast<const unsigned long long*>(occ_run)[k];  // {start, count}
-    *s = (unsigned)(rv & 0xFFFFFFFFull);
-    *e = *s + (unsigned)(rv >> 32);
-  }
-}
-
+// Cell lookup: candidate run [s, e) for position (x,y,z); empty outside the grid / in empty cells.
+// Branch-free on purpose: the kernel is instruction-issue bound and every `if` costs an exec-mask
+// save / branch / restore triple; both loads are issued unconditionally from always-valid addresses
+// (entry 0 when the position is outside the grid or the cell is empty) and the result is selected.
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
                                          const uint2* __restrict__ occ_run, float x, float y,
-                                         float z, uint32_t* s, uint32_t* e) {
-  int bit;
-  size_t wi = word_index(g, x, y, z, &bit);
-  uint2 wd = make_uint2(0u, 0u);
-  if (bit >= 0) {
-    // one 8-byte load (as a 64-bit scalar, or hipcc fetches .x, tests the bit, then fetches .y)
-    unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
-    wd = make_uint2((unsigned)(wv & 0xFFFFFFFFull), (unsigned)(wv >> 32));
-  }
-  run_of(occ_run, wd, bit, s, e);
+                                         float z, uint32_t* s, uint32_t* e, bool live = true) {
+  const float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
+  const bool valid = live & (fx >= 0.f) & (fx < (float)g.nx) & (fy >= 0.f) & (fy < (float)g.ny) & (fz >= 0.f) &
+                     (fz < (float)g.nz);  // NaN fails every comparison
+  const int cx = valid ? (int)fx : 0, cy = valid ? (int)fy : 0, cz = valid ? (int)fz : 0;
+  const size_t wi = ((size_t)cz * g.ny + cy) * g.nxw + (cx >> 5);
+  const unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
+  const unsigned lo = (unsigned)(wv & 0xFFFFFFFFull), base = (unsigned)(wv >> 32);
+  const int bit = cx & 31;
+  const bool occ = valid & (((lo >> bit) & 1u) != 0u);
+  const uint32_t k = occ ? base + __popc(lo & ((1u << bit) - 1u)) : 0u;
+  const unsigned long long rv = reinterpret_cast<const unsigned long long*>(occ_run)[k];  // {start, count}
+  const uint32_t st = (unsigned)(rv & 0xFFFFFFFFull), cnt = (unsigned)(rv >> 32);
+  *s = occ ? st : 0u;
+  *e = occ ? st + cnt : 0u;
 }
 
 // Nearest candidate with d2 <= sq_eps; ties -> lowest scene index (the reference's tie rule
@@ -201,9 +184,6 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
   for (int hb = h0; hb < h1; hb += U) {
     Xf m[U];
     float x[U], y[U], z[U];
-    int bit[U];
-    size_t wi[U];
-    uint2 wd[U];
     uint32_t s[U], e[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -212,19 +192,8 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
       x[u] = xf_row(m[u].m00, m[u].m01, m[u].m02, m[u].m03, q.x, q.y, q.z);
       y[u] = xf_row(m[u].m10, m[u].m11, m[u].m12, m[u].m13, q.x, q.y, q.z);
       z[u] = xf_row(m[u].m20, m[u].m21, m[u].m22, m[u].m23, q.x, q.y, q.z);
-      wi[u] = word_index(a.g, x[u], y[u], z[u], &bit[u]);
-      if (!live) bit[u] = -1;
+      cell_run(a.g, a.words, a.occ_run, x[u], y[u], z[u], &s[u], &e[u], live);
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      wd[u] = make_uint2(0u, 0u);
-      if (bit[u] >= 0) {
-        unsigned long long wv = reinterpret_cast<const unsigned long long*>(a.words)[wi[u]];
-        wd[u] = make_uint2((unsigned)(wv & 0xFFFFFFFFull), (unsigned)(wv >> 32));
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) run_of(a.occ_run, wd[u], bit[u], &s[u], &e[u]);
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       bool hit = false;
@@ -330,8 +299,8 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
     const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
     const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
     const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
-    uint32_t s = 0, e = 0;
-    if (live) cell_run(a.g, words, occ_run, x, y, z, &s, &e);
+    uint32_t s, e;
+    cell_run(a.g, words, occ_run, x, y, z, &s, &e, live);
     const uint32_t len = e - s;
     // slot allocation in the concatenated run of the wave: one returning LDS atomic add per
     // owning lane (any order will do: the owner map below resolves slots to owners), skipped
@@ -511,7 +480,7 @@ __global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __res
   float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
   float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
   uint32_t s, e;
-  cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e);
+  cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
   int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
   if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
     float4 qn = a.Qn[i];
