@@ -257,6 +257,39 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
 // Arithmetic per (query, candidate) pair is unchanged; results are identical.
 constexpr int kFlatCap = 1024;  // candidate slots per wave-iteration served by the flat path
 
+// NC chunks of 64 candidate slots of the wave's concatenated runs (see score_hypotheses_flat)
+template <int MODE, int NC>
+__device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __restrict__ cand,
+                                           const float4* ent, unsigned long long* res,
+                                           const unsigned char* own, uint32_t W, uint32_t w0, int lane) {
+  int o[NC];
+  float4 en[NC], p[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const uint32_t w = w0 + 64 * c + lane;
+    o[c] = w < W ? (int)own[w] : -1;
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) en[c] = ent[o[c] >= 0 ? o[c] : 0];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const uint32_t w = w0 + 64 * c + lane;
+    // a finished lane re-reads the wave's first candidate (always valid: W > 0)
+    p[c] = cand[o[c] >= 0 ? __float_as_uint(en[c].w) + w : __float_as_uint(ent[0].w)];
+  }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const float d2 = sqdist(en[c].x, en[c].y, en[c].z, p[c]);
+    if (o[c] >= 0 && d2 <= a.sq_eps) {
+      if (MODE == PGP_MODE_PLAIN) {
+        res[o[c]] = 1ull;  // benign race: every writer stores the same value
+      } else {
+        atomicMin(&res[o[c]], ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
+      }
+    }
+  }
+}
+
 // The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
 // with FOUR vector loads per hypothesis instead of scalar loads.
@@ -329,33 +362,20 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
       }
       __builtin_amdgcn_wave_barrier();
       // four chunks of 64 slots per batch: owner lookups, then ALL candidate loads, then tests
-      for (uint32_t w0 = 0; w0 < W; w0 += 256) {
-        int o[4];
-        float4 en[4], p[4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t w = w0 + 64 * c + lane;
-          o[c] = w < W ? (int)own[w] : -1;
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) en[c] = ent[o[c] >= 0 ? o[c] : 0];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const uint32_t w = w0 + 64 * c + lane;
-          // a finished lane re-reads the wave's first candidate (always valid: W > 0)
-          p[c] = cand[o[c] >= 0 ? __float_as_uint(en[c].w) + w : __float_as_uint(ent[0].w)];
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float d2 = sqdist(en[c].x, en[c].y, en[c].z, p[c]);
-          if (o[c] >= 0 && d2 <= a.sq_eps) {
-            if (MODE == PGP_MODE_PLAIN) {
-              res[o[c]] = 1ull;  // benign race: every writer stores the same value
-            } else {
-              atomicMin(&res[o[c]],
-                        ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
-            }
-          }
+      // batches of NC chunks of 64 slots: owner lookups, then ALL candidate loads, then tests.
+      // Half of the non-empty wave-iterations need a single chunk (median W = 6 at C2), so the
+      // batch width follows what is left instead of always issuing four chunks.
+      for (uint32_t w0 = 0; w0 < W;) {
+        const uint32_t left = W - w0;
+        if (left > 128) {
+          flat_batch<MODE, 4>(a, cand, ent, res, own, W, w0, lane);
+          w0 += 256;
+        } else if (left > 64) {
+          flat_batch<MODE, 2>(a, cand, ent, res, own, W, w0, lane);
+          w0 += 128;
+        } else {
+          flat_batch<MODE, 1>(a, cand, ent, res, own, W, w0, lane);
+          w0 += 64;
         }
       }
       __builtin_amdgcn_wave_barrier();
@@ -517,9 +537,8 @@ float key2f(int32_t k) {
 }
 
 void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a) {
-  // defaults by measurement at C2 (tools/tune.py): plain 120.7 us flat vs 124.2 us per-lane U=2;
-  // weighted 184 us flat (64-bit LDS atomic min per hit) vs 166 us per-lane U=2
-  if (unroll == 0 && mode == PGP_MODE_WEIGHTED) unroll = 2;
+  // default by measurement at C2 (tools/tune.py): wave-flattened 112 us plain / 157 us weighted vs
+  // per-lane walk (U = 2) 125 / 170 us
   if (unroll <= 0) {  // wave-flattened candidate phase
     if (mode == PGP_MODE_PLAIN)
       hipLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, a, a.T, a.words,
