@@ -187,6 +187,14 @@ int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const fl
                           float* d_T, int n, const pgp_icp_params* params, float* d_energy,
                           int* d_iters, void* stream);
 
+/* Replaces UCTState::computeCost (PPE/hypothesis_verification/mcts/UCTState.cpp:93-116) for n
+ * rendered depth images against one observed image (all rows x cols float, row-major, metres):
+ * render_score[i] = obScore + renScore - intScore with the pixel tests of the reference and
+ * threshold = explanationThreshold (0.01 there, UCTState.cpp:8).  counts (nullable) receives the
+ * three integer tallies per image.  Host pointers, synchronous. */
+int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, int n, int rows, int cols,
+                   float threshold, float* render_score, int* counts);
+
 /* Per-kernel timing for bench.py's roofline line: when enabled, every pgp_score_lcp[_device]
  * call brackets its dominant kernel (score_hypotheses) with a pair of HIP events on the SAME
  * stream it is launched on.  pgp_get_kernel_timing synchronises those events and returns the

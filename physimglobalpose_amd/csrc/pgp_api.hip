@@ -148,7 +148,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
@@ -570,6 +570,43 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
   if (energy) PGP_HIP(hipMemcpyAsync(energy, d_energy, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   if (iters) PGP_HIP(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  return PGP_OK;
+}
+
+int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, int n, int rows, int cols,
+                   float threshold, float* render_score, int* counts) {
+  if (!ctx || n < 0 || rows < 0 || cols < 0 || (n > 0 && (!observed || !rendered || !render_score))) {
+    set_error("pgp_depth_cost: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t npix = (size_t)rows * cols;
+  const size_t img_bytes = (npix * 4 + 15) & ~(size_t)15;
+  int rc = ctx->d_depth.ensure(img_bytes * ((size_t)n + 1) + (size_t)n * 12 + 64);
+  if (rc != PGP_OK) return rc;
+  float* d_obs = ctx->d_depth.as<float>();
+  float* d_ren = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(d_obs) + img_bytes);
+  int* d_counts = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(d_ren) + (size_t)n * npix * 4 + 16);
+  d_counts = reinterpret_cast<int*>(((uintptr_t)d_counts + 15) & ~(uintptr_t)15);
+  if (npix > 0) {
+    PGP_HIP(hipMemcpyAsync(d_obs, observed, npix * 4, hipMemcpyHostToDevice, st));
+    PGP_HIP(hipMemcpyAsync(d_ren, rendered, (size_t)n * npix * 4, hipMemcpyHostToDevice, st));
+  }
+  rc = launch_depth_cost(ctx, d_obs, d_ren, n, (int)npix, threshold, d_counts, st);
+  if (rc != PGP_OK) return rc;
+  std::vector<int> hc((size_t)n * 3);
+  PGP_HIP(hipMemcpyAsync(hc.data(), d_counts, hc.size() * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < n; ++i) {
+    render_score[i] = (float)hc[3 * i] + (float)hc[3 * i + 1] - (float)hc[3 * i + 2];  // UCTState.cpp:115
+    if (counts) {
+      counts[3 * i] = hc[3 * i];
+      counts[3 * i + 1] = hc[3 * i + 1];
+      counts[3 * i + 2] = hc[3 * i + 2];
+    }
+  }
   return PGP_OK;
 }
 

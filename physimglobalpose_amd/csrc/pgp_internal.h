@@ -82,6 +82,8 @@ struct pgp_ctx {
   pgp::DevBuf d_ids;     // staged int4 base / quad ids (host API)
   pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
 
+  pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
+
   // ICP (host API staging + per-pose correspondence workspace)
   pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_T, d_icp_out, d_icp_ws;
 
@@ -133,6 +135,10 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
 // icp.hip
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,
                int n, const pgp_icp_params* prm, float* d_energy, int* d_iters, hipStream_t stream);
+
+// depth_cost.hip
+int launch_depth_cost(pgp_ctx* ctx, const float* d_obs, const float* d_ren, int n, int n_pix, float thr,
+                      int* d_counts, hipStream_t stream);
 
 // rigid_fit.hip
 int launch_rigid(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n, const float cP[3],

@@ -152,6 +152,18 @@ class LcpScorer:
         _lib.check(self._lib.pgp_find_congruent(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
         return out[: min(n.value, cap)].copy()
 
+    # ---- MCTS leaf cost (UCTState::computeCost) ---------------------------------------------------------
+    def depth_cost(self, observed, rendered, threshold=0.01):
+        """observed (rows,cols) f32, rendered (n,rows,cols) f32 -> (render_score (n,), counts (n,3))."""
+        obs = np.ascontiguousarray(observed, np.float32)
+        ren = np.ascontiguousarray(rendered, np.float32).reshape(-1, *obs.shape)
+        n = len(ren)
+        score = np.zeros(n, np.float32)
+        counts = np.zeros((n, 3), np.int32)
+        _lib.check(self._lib.pgp_depth_cost(self._h, _fp(obs), _fp(ren), n, obs.shape[0], obs.shape[1],
+                                            C.c_float(threshold), _fp(score), counts.ctypes.data_as(_i)))
+        return score, counts
+
     # ---- ICP refinement (UCTState::performTrICP / utilities::performICP inner loop) --------------
     def icp_refine(self, src_xyz, tgt_xyz, T, trim=1.0, max_iterations=100, max_corr_dist=0.0,
                    energy_ratio=1.0):
