@@ -1,0 +1,90 @@
+"""Randomised parity sweep of the scoring path (both candidate-phase forms, both modes) against the
+oracle, including the regimes the seeded workloads do not reach: very dense scenes (runs far longer
+than 64 candidates, wave totals above the flat path's capacity -> per-lane fallback), clustered
+duplicates, tiny and huge radii, models smaller than a wave."""
+import os
+
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
+from _checkers import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_problem(rng):
+    kind = rng.integers(0, 4)
+    nP = int(rng.integers(1, 6000))
+    nQ = int(rng.integers(1, 900))
+    delta = float(10 ** rng.uniform(-3, -1.5))
+    if kind == 0:      # dense blob: hundreds of scene points inside one delta-ball
+        P = rng.normal(0, 0.8 * delta, (nP, 3))
+        Q = rng.normal(0, 1.5 * delta, (nQ, 3))
+    elif kind == 1:    # clusters with exact duplicates
+        c = rng.uniform(-0.2, 0.2, (max(nP // 50, 1), 3))
+        P = c[rng.integers(0, len(c), nP)] + rng.choice([0.0, 1.0], (nP, 1)) * rng.normal(0, delta, (nP, 3))
+        Q = c[rng.integers(0, len(c), nQ)] + rng.normal(0, delta, (nQ, 3))
+    elif kind == 2:    # surface-like: a noisy plane patch, model = a piece of it
+        P = np.c_[rng.uniform(-0.3, 0.3, (nP, 2)), rng.normal(0, 0.3 * delta, nP)]
+        Q = P[rng.integers(0, nP, nQ)] + rng.normal(0, 0.5 * delta, (nQ, 3))
+    else:              # sparse uniform
+        P = rng.uniform(-0.5, 0.5, (nP, 3))
+        Q = rng.uniform(-0.1, 0.1, (nQ, 3))
+    P, Q = P.astype(np.float32), Q.astype(np.float32)
+    Pn = synth._unit(rng.standard_normal(P.shape)).astype(np.float32)
+    Qn = synth._unit(rng.standard_normal(Q.shape)).astype(np.float32)
+    w = rng.uniform(0, 1, nP).astype(np.float32)
+    T = [synth.colmajor16(np.eye(4))]
+    for _ in range(int(rng.integers(1, 40))):
+        T.append(synth.colmajor16(synth._se3(synth._random_rot(rng, rng.uniform(0, 0.3)),
+                                             rng.normal(0, 2 * delta, 3))))
+    return P, Pn, w, Q, Qn, np.stack(T), delta, int(kind)
+
+
+@pytest.mark.parametrize("variant", ["0", "2"])
+def test_random_sweep(variant, monkeypatch):
+    monkeypatch.setenv("PGP_UNROLL", variant)       # 0: wave-flattened, 2: per-lane walk
+    rng = np.random.default_rng(20261003)
+    kinds = set()
+    for it in range(36):
+        P, Pn, w, Q, Qn, T, delta, kind = _random_problem(rng)
+        kinds.add(kind)
+        sc = LcpScorer()
+        sc.init(P, Pn, w, Q, Qn, delta)
+        orc = Oracle(P, Pn, w, Q, Qn)
+        s, c, bi, bs = sc.score(T, PGP_MODE_PLAIN)
+        so, bio, _ = orc.score_batch(T, delta, mode=0, threads=4)
+        assert np.array_equal(s, so) and bi == bio, (it, kind, len(P), len(Q), delta)
+        s, c, bi, bs = sc.score(T, PGP_MODE_WEIGHTED, 30.0)
+        if kind == 1:
+            continue    # exact duplicates: NN identity follows the documented tie rule, not the kd order
+        so, bio, _ = orc.score_batch(T, delta, mode=1, threads=4)
+        assert np.allclose(s, so, rtol=0, atol=3e-6), (it, kind, np.abs(s - so).max())
+    assert kinds == {0, 1, 2, 3}
+
+
+def test_wave_total_above_flat_capacity():
+    """Every lane of a wave owns a run of ~100 candidates: the wave total (~6400 slots) exceeds the
+    flat path's 1024-slot table, so the per-lane fallback inside the flat kernel must take over."""
+    rng = np.random.default_rng(1)
+    delta = 0.01
+    P = rng.normal(0, 0.004, (3000, 3)).astype(np.float32)
+    Q = rng.normal(0, 0.004, (256, 3)).astype(np.float32)
+    Pn = synth._unit(rng.standard_normal(P.shape)).astype(np.float32)
+    Qn = synth._unit(rng.standard_normal(Q.shape)).astype(np.float32)
+    w = rng.uniform(0, 1, len(P)).astype(np.float32)
+    T = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng, 0.2), rng.normal(0, 0.004, 3))) for _ in range(12)])
+    sc = LcpScorer()
+    sc.init(P, Pn, w, Q, Qn, delta)
+    assert sc.index_info()["n_candidates"] > 20 * len(P)
+    orc = Oracle(P, Pn, w, Q, Qn)
+    s, c, bi, _ = sc.score(T, PGP_MODE_PLAIN)
+    so, bio, _ = orc.score_batch(T, delta, mode=0)
+    assert np.array_equal(s, so) and bi == bio
+    s, c, bi, _ = sc.score(T, PGP_MODE_WEIGHTED)
+    so, bio, _ = orc.score_batch(T, delta, mode=1)
+    assert np.allclose(s, so, rtol=0, atol=3e-6)
+    for h in range(3):
+        _, reg = orc.weighted_verify(T[h], delta)
+        assert np.array_equal(sc.registered(T[h], PGP_MODE_WEIGHTED), reg)
