@@ -187,6 +187,18 @@ int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const fl
                           float* d_T, int n, const pgp_icp_params* params, float* d_energy,
                           int* d_iters, void* stream);
 
+/* Segment pre-processing in front of the path (PPE/hypothesis_generation/ObjectPoseCandidateSet.cpp:
+ * 28-51): pcl::RadiusOutlierRemoval(radius 0.03, min neighbours 10) followed by
+ * flipNormalTowardsViewpoint((0,0,0)) + re-normalisation.  PCL is not vendored, so the
+ * filter follows PCL 1.7 / FLANN as published: k = number of points with squared distance
+ * STRICTLY below radius^2 (the point itself included), keep iff k > min_neighbors.
+ * xyz / nrm: n x 3 (nrm nullable); keep[n] receives 0/1; nrm_out (nullable, n x 3) the flipped,
+ * re-normalised normals of ALL points (callers compact by keep).  *n_kept = number kept (the
+ * node bails out when <= 30 remain, :34-37).  Builds a temporary index in the context: call it
+ * before pgp_set_scene.  Host pointers, synchronous. */
+int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, int n, float radius,
+                              int min_neighbors, unsigned char* keep, float* nrm_out, int* n_kept);
+
 /* Replaces UCTState::computeCost (PPE/hypothesis_verification/mcts/UCTState.cpp:93-116) for n
  * rendered depth images against one observed image (all rows x cols float, row-major, metres):
  * render_score[i] = obScore + renScore - intScore with the pixel tests of the reference and

@@ -57,6 +57,8 @@ SIGNATURES = {
                                  C.POINTER(IcpParams), _f, _i]),
     "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_int, C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgp_radius_outlier_filter": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, C.c_int,
+                                            C.POINTER(C.c_ubyte), _f, _i]),
     "pgp_depth_cost": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_int, C.c_int, C.c_float, _f, _i]),
     "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),

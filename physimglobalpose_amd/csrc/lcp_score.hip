@@ -696,6 +696,46 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
   return PGP_OK;
 }
 
+// Neighbour count of every scene point inside the scene's own index (segment pre-processing,
+// pgp_radius_outlier_filter): strict d2 < r2 as FLANN's radius search, the point itself included,
+// squared distance accumulated in x, y, z order as FLANN's L2_Simple does.
+__global__ __launch_bounds__(256) void count_neighbours(GridDesc g, const uint2* __restrict__ words,
+                                                        const uint2* __restrict__ occ_run,
+                                                        const float4* __restrict__ cand,
+                                                        const float4* __restrict__ P, int nP, float r2,
+                                                        int* __restrict__ counts) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nP) return;
+  const float4 p = P[i];
+  uint32_t s, e;
+  cell_run(g, words, occ_run, p.x, p.y, p.z, &s, &e, true);
+  int k = 0;
+  for (uint32_t j = s; j < e; ++j) {
+    const float4 c = cand[j];
+    const float dx = __fsub_rn(p.x, c.x), dy = __fsub_rn(p.y, c.y), dz = __fsub_rn(p.z, c.z);
+    const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+    k += d2 < r2;
+  }
+  counts[i] = k;
+}
+
+int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream_t stream) {
+  if (!ctx->has_index) {
+    set_error("no scene index: call pgp_set_scene first");
+    return PGP_ESTATE;
+  }
+  if (radius > ctx->delta) {
+    set_error("radius %g exceeds the index radius %g", (double)radius, (double)ctx->delta);
+    return PGP_EINVAL;
+  }
+  if (ctx->nP == 0) return PGP_OK;
+  hipLaunchKernelGGL(count_neighbours, dim3((ctx->nP + 255) / 256), dim3(256), 0, stream, ctx->grid,
+                     ctx->d_bitmap.as<uint2>(), ctx->d_occ_start.as<uint2>(), ctx->d_cand.as<float4>(),
+                     ctx->d_P.as<float4>(), ctx->nP, radius * radius, d_counts);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream) {
   ScoreArgs a{};

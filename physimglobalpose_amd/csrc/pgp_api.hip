@@ -573,6 +573,45 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
   return PGP_OK;
 }
 
+int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, int n, float radius,
+                              int min_neighbors, unsigned char* keep, float* nrm_out, int* n_kept) {
+  if (!ctx || n < 0 || (n > 0 && (!xyz || !keep)) || !(radius > 0.f) || !n_kept) {
+    set_error("pgp_radius_outlier_filter: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_kept = 0;
+  if (n == 0) return PGP_OK;
+  // the scene index with delta = radius answers "points within radius" for the cloud itself
+  int rc = pgp_set_scene(ctx, xyz, nullptr, nullptr, n, radius);
+  if (rc != PGP_OK) return rc;
+  DeviceGuard guard(ctx->device);
+  if ((rc = ctx->d_counts.ensure((size_t)n * sizeof(int))) != PGP_OK) return rc;
+  rc = launch_count_neighbours(ctx, radius, ctx->d_counts.as<int>(), ctx->stream);
+  if (rc != PGP_OK) return rc;
+  std::vector<int> k((size_t)n);
+  PGP_HIP(hipMemcpyAsync(k.data(), ctx->d_counts.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    keep[i] = k[i] > min_neighbors ? 1 : 0;  // PCL 1.7: `k <= min_pts_radius_` -> outlier
+    kept += keep[i];
+    if (nrm && nrm_out) {
+      // pcl::flipNormalTowardsViewpoint(p, 0,0,0, n): flip when (vp - p).n < 0, then / magnitude
+      const float* p = xyz + 3 * (size_t)i;
+      float nx = nrm[3 * (size_t)i], ny = nrm[3 * (size_t)i + 1], nz = nrm[3 * (size_t)i + 2];
+      const float vx = 0.f - p[0], vy = 0.f - p[1], vz = 0.f - p[2];
+      const float cos_theta = vx * nx + vy * ny + vz * nz;
+      if (cos_theta < 0.f) { nx = -nx; ny = -ny; nz = -nz; }
+      const float mag = std::sqrt(nx * nx + ny * ny + nz * nz);
+      nrm_out[3 * (size_t)i] = nx / mag;
+      nrm_out[3 * (size_t)i + 1] = ny / mag;
+      nrm_out[3 * (size_t)i + 2] = nz / mag;
+    }
+  }
+  *n_kept = kept;
+  return PGP_OK;
+}
+
 int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, int n, int rows, int cols,
                    float threshold, float* render_score, int* counts) {
   if (!ctx || n < 0 || rows < 0 || cols < 0 || (n > 0 && (!observed || !rendered || !render_score))) {

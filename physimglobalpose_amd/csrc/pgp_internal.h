@@ -131,6 +131,7 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream);
 void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
+int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream_t stream);
 
 // icp.hip
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,

@@ -152,6 +152,20 @@ class LcpScorer:
         _lib.check(self._lib.pgp_find_congruent(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
         return out[: min(n.value, cap)].copy()
 
+    # ---- segment pre-processing (ObjectPoseCandidateSet.cpp:28-51) -----------------------------------
+    def radius_outlier_filter(self, xyz, nrm=None, radius=0.03, min_neighbors=10):
+        """Returns (keep mask (n,) bool, flipped + re-normalised normals (n,3) or None)."""
+        xyz, nrm = _f32(xyz, 3), _f32(nrm, 3)
+        n = len(xyz)
+        keep = np.zeros(max(n, 1), np.uint8)
+        nout = np.zeros((max(n, 1), 3), np.float32) if nrm is not None else None
+        kept = C.c_int(0)
+        _lib.check(self._lib.pgp_radius_outlier_filter(
+            self._h, _fp(xyz), _fp(nrm), n, C.c_float(radius), int(min_neighbors),
+            keep.ctypes.data_as(C.POINTER(C.c_ubyte)), _fp(nout), C.byref(kept)))
+        assert kept.value == int(keep[:n].sum())
+        return keep[:n].astype(bool), (nout[:n] if nout is not None else None)
+
     # ---- MCTS leaf cost (UCTState::computeCost) ---------------------------------------------------------
     def depth_cost(self, observed, rendered, threshold=0.01):
         """observed (rows,cols) f32, rendered (n,rows,cols) f32 -> (render_score (n,), counts (n,3))."""
