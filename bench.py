@@ -140,11 +140,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU; PGP_DIST_BACKEND=gloo + fewer GPUs than ranks is a functional smoke mode
+    # (ranks share a device, the collective goes through the host) used to exercise the N > 1
+    # code path on a 1-GPU box -- never a performance configuration
+    backend = os.environ.get("PGP_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
 
@@ -153,7 +161,7 @@ def main():
     # every rank builds the same scene/model (replicated) and takes its own slice of
     # a world*n_h hypothesis batch (weak scaling: per-GPU work fixed)
     w = synth.make_workload(N_SCENE, N_MODEL, n_h * world, config_id=2)
-    sc = LcpScorer(local_rank)
+    sc = LcpScorer(dev_index)
     t0 = time.perf_counter()
     sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
     cold_ms = (time.perf_counter() - t0) * 1e3

@@ -1,0 +1,55 @@
+"""bench.py contract: one JSON line with the required keys, at N = 1 and -- functionally, two ranks
+sharing the one GPU through gloo (PGP_DIST_BACKEND=gloo) -- at N = 2, so the multi-rank code path
+(sharding, all-reduce of the score vector, arg-max, max-over-ranks timing) is executed on the
+GPU box and not only on CPU stand-ins."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+            "scaling", "vs_baseline", "dtype", "data", "config", "roofline"]
+
+
+def _check(line, n):
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    assert d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 2
+    assert d["unit"] == "hypotheses/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert d["value"] > 1e6 and r["launches"] == 6
+    return d
+
+
+def test_single_gpu_line():
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = _check(lines[0], 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+
+
+def test_two_ranks_on_one_gpu_functional():
+    env = dict(os.environ, PGP_DIST_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", "bench.py", "--gpus", "2",
+                          "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
+                         timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                      # rank 0 only
+    d = _check(lines[0], 2)
+    assert "cpu_baseline" not in d              # N = 1 only
