@@ -549,23 +549,9 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
     return;
   }
 #define PGP_LAUNCH(M, UU) hipLaunchKernelGGL((score_hypotheses<M, UU>), grid, dim3(kTile), 0, stream, a)
-  if (mode == PGP_MODE_PLAIN) {
-    switch (unroll) {
-      case 1: PGP_LAUNCH(PGP_MODE_PLAIN, 1); break;
-      case 2: PGP_LAUNCH(PGP_MODE_PLAIN, 2); break;
-      case 8: PGP_LAUNCH(PGP_MODE_PLAIN, 8); break;
-      case 4: PGP_LAUNCH(PGP_MODE_PLAIN, 4); break;
-      default: PGP_LAUNCH(PGP_MODE_PLAIN, 2); break;
-    }
-  } else {
-    switch (unroll) {
-      case 1: PGP_LAUNCH(PGP_MODE_WEIGHTED, 1); break;
-      case 2: PGP_LAUNCH(PGP_MODE_WEIGHTED, 2); break;
-      case 8: PGP_LAUNCH(PGP_MODE_WEIGHTED, 8); break;
-      case 4: PGP_LAUNCH(PGP_MODE_WEIGHTED, 4); break;
-      default: PGP_LAUNCH(PGP_MODE_WEIGHTED, 2); break;
-    }
-  }
+  // per-lane walk, two hypotheses unrolled (U = 1, 4, 8 measured within 2 % or slower)
+  if (mode == PGP_MODE_PLAIN) PGP_LAUNCH(PGP_MODE_PLAIN, 2);
+  else PGP_LAUNCH(PGP_MODE_WEIGHTED, 2);
 #undef PGP_LAUNCH
 }
 

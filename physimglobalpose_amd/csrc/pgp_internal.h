@@ -97,7 +97,7 @@ struct pgp_ctx {
   pgp::DevBuf d_hits;     // [nQ] int (pgp_registered)
 
   // tuning knobs (env PGP_UNROLL / PGP_HPB at pgp_create; defaults chosen by measurement)
-  int unroll = 0;      // 0: wave-flattened candidate phase; 1/2/4/8: per-lane walk, U hypotheses in flight
+  int unroll = 0;      // <= 0: wave-flattened candidate phase (default); > 0: per-lane walk
   int hpb_override = 0;
 
   // optional per-kernel timing (pgp_set_kernel_timing)

@@ -13,7 +13,7 @@ from physimglobalpose_amd import LcpScorer, synth, PGP_MODE_PLAIN, PGP_MODE_WEIG
 
 
 def main():
-    unrolls = [int(x) for x in os.environ.get("TUNE_UNROLL", "1,2,4,8").split(",")]
+    unrolls = [int(x) for x in os.environ.get("TUNE_UNROLL", "0,2").split(",")]
     hpbs = [int(x) for x in os.environ.get("TUNE_HPB", "0").split(",")]
     modes = os.environ.get("TUNE_MODES", "plain,weighted").split(",")
     rounds = int(os.environ.get("TUNE_ROUNDS", "7"))
