@@ -207,6 +207,32 @@ int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, 
 int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, int n, int rows, int cols,
                    float threshold, float* render_score, int* counts);
 
+/* Replaces HypothesisSelection::greedyClustering (PPE/hypothesis_verification/HypothesisSelection.cpp:
+ * 66-115) and its pose distance utilities::getPoseError (PPE/misc/utilities.cpp:514-548) for one
+ * object's scored hypothesis list.  T: n_h x 16 col-major float (the Matrix4f images convertToMatrix
+ * yields, utilities.cpp:276-280), scores: n_h (allPose[i].second), best_score = bestHypothesis.second,
+ * sym_deg = the object's symInfo (per axis 0 / 90 / 180 / 360, PPE/data_layer/Objects.hpp:22).
+ * params NULL = the reference's constants {0.5, 10, 0.02} (:70,:99).  Hypotheses with
+ * score > accept_fraction * best_score are visited in descending score order (equal scores in
+ * index order; the reference's std::sort leaves ties unspecified) and kept unless an earlier kept
+ * one is within both thresholds.  rep_index (cap entries) receives the kept hypothesis ids in
+ * that order = clusteredHypothesisSet; *n_rep their number (may exceed cap: the list is then
+ * truncated); assignment (nullable, n_h) the id of the representative that absorbed each
+ * hypothesis (itself for a representative, -1 when pruned).  The `+=` at :102 acts on a copy in
+ * the reference, so cluster scores are the representatives' own scores[rep_index[k]].
+ * Host pointers, synchronous. */
+typedef struct pgp_cluster_params {
+  float accept_fraction; /* 0.5  */
+  float rot_thresh_deg;  /* 10   */
+  float trans_thresh;    /* 0.02 */
+} pgp_cluster_params;
+int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h, float best_score,
+                      const float sym_deg[3], const pgp_cluster_params* params, int* rep_index, int cap,
+                      int* n_rep, int* assignment);
+/* The pose distance alone, for n pairs (test[i], gt[i]) of 4x4 col-major transforms. */
+int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, const float sym_deg[3],
+                   float* rot_err_deg, float* trans_err);
+
 /* Per-kernel timing for bench.py's roofline line: when enabled, every pgp_score_lcp[_device]
  * call brackets its dominant kernel (score_hypotheses) with a pair of HIP events on the SAME
  * stream it is launched on.  pgp_get_kernel_timing synchronises those events and returns the

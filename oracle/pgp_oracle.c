@@ -909,6 +909,125 @@ int orc_icp(const float* src, int n_src, const float* tgt, int n_tgt, float* T, 
   return it;
 }
 
+/* ---- hypothesis clustering -------------------------------------------------------------- */
+
+/* Eigen 3.3.90 LU/InverseImpl.h (compute_inverse<.,.,3>): cofactor expansion along column 0. */
+static float cof3(const float m[3][3], int i, int j) {
+  int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m[i1][j1] * m[i2][j2] - m[i1][j2] * m[i2][j1];
+}
+
+void orc_pose_error(const float test[16], const float gt[16], const float sym[3], float* rot_err,
+                    float* trans_err) {
+  float a[3][3], g[3][3], inv[3][3], d[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      a[i][j] = test[i + 4 * j];
+      g[i][j] = gt[i + 4 * j];
+    }
+  /* utilities.cpp:523 testRot.inverse() */
+  float c0 = cof3(a, 0, 0), c1 = cof3(a, 1, 0), c2 = cof3(a, 2, 0);
+  float det = c0 * a[0][0] + (c1 * a[1][0] + c2 * a[2][0]);
+  float invdet = 1.0f / det;
+  inv[0][0] = c0 * invdet; inv[0][1] = c1 * invdet; inv[0][2] = c2 * invdet;
+  for (int j = 0; j < 3; ++j) {
+    inv[1][j] = cof3(a, j, 1) * invdet;
+    inv[2][j] = cof3(a, j, 2) * invdet;
+  }
+  /* :524 rotdiff = testRot * gtRot (size-3 redux: x0 + (x1 + x2)) */
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      d[i][j] = inv[i][0] * g[0][j] + (inv[i][1] * g[1][j] + inv[i][2] * g[2][j]);
+  /* :525 Quaternionf(rotdiff): Eigen Geometry/Quaternion.h quaternionbase_assign_impl<.,3,3> */
+  float q[4]; /* x y z w */
+  float t = d[0][0] + (d[1][1] + d[2][2]);
+  if (t > 0.0f) {
+    t = sqrtf(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (d[2][1] - d[1][2]) * t;
+    q[1] = (d[0][2] - d[2][0]) * t;
+    q[2] = (d[1][0] - d[0][1]) * t;
+  } else {
+    int i = 0;
+    if (d[1][1] > d[0][0]) i = 1;
+    if (d[2][2] > d[i][i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrtf(d[i][i] - d[j][j] - d[k][k] + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (d[k][j] - d[j][k]) * t;
+    q[j] = (d[j][i] + d[i][j]) * t;
+    q[k] = (d[k][i] + d[i][k]) * t;
+  }
+  /* :335-356 toEulerianAngle: float products / sums, then double */
+  float x = q[0], y = q[1], z = q[2], w = q[3], e[3];
+  double sinr = +2.0 * (double)(w * x + y * z);
+  double cosr = +1.0 - 2.0 * (double)(x * x + y * y);
+  e[0] = (float)atan2(sinr, cosr);
+  double sinp = +2.0 * (double)(w * y - z * x);
+  if (fabs(sinp) >= 1)
+    e[1] = (float)copysign(M_PI / 2, sinp);
+  else
+    e[1] = (float)asin(sinp);
+  double siny = +2.0 * (double)(w * z + x * y);
+  double cosy = +1.0 - 2.0 * (double)(y * y + z * z);
+  e[2] = (float)atan2(siny, cosy);
+  /* :528-542 */
+  for (int dim = 0; dim < 3; ++dim) {
+    float v = e[dim] * 180.0f / (float)M_PI;
+    v = fabsf(v);
+    if (sym[dim] == 90) {
+      v = fabsf(v - 90);
+      v = fminf(v, 90 - v);
+    } else if (sym[dim] == 180) {
+      v = fminf(v, 180 - v);
+    } else if (sym[dim] == 360) {
+      v = 0;
+    }
+    e[dim] = v;
+  }
+  *rot_err = (e[0] + e[1] + e[2]) / 3;
+  /* :545-547 pow(float, int) promotes to double */
+  double dx = (double)(gt[12] - test[12]), dy = (double)(gt[13] - test[13]), dz = (double)(gt[14] - test[14]);
+  *trans_err = (float)sqrt(dx * dx + dy * dy + dz * dz);
+}
+
+int orc_greedy_cluster(const float* T, const float* scores, int n, float best_score, float accept_fraction,
+                       const float sym[3], float rot_thresh, float trans_thresh, int* rep_out, int* assign) {
+  int* order = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int m = 0, n_rep = 0;
+  float bar = accept_fraction * best_score;
+  for (int i = 0; i < n; ++i) {
+    if (assign) assign[i] = -1;
+    if (scores[i] > bar) order[m++] = i;
+  }
+  /* stable insertion sort by score descending (test sizes are small) */
+  for (int i = 1; i < m; ++i) {
+    int v = order[i], j = i - 1;
+    while (j >= 0 && scores[order[j]] < scores[v]) {
+      order[j + 1] = order[j];
+      --j;
+    }
+    order[j + 1] = v;
+  }
+  for (int c = 0; c < m; ++c) {
+    int cand = order[c], hit = -1;
+    for (int r = 0; r < n_rep && hit < 0; ++r) {
+      float re, te;
+      orc_pose_error(T + 16 * (size_t)cand, T + 16 * (size_t)rep_out[r], sym, &re, &te);
+      if (re < rot_thresh && te < trans_thresh) hit = rep_out[r];
+    }
+    if (hit < 0) {
+      rep_out[n_rep++] = cand;
+      hit = cand;
+    }
+    if (assign) assign[cand] = hit;
+  }
+  free(order);
+  return n_rep;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

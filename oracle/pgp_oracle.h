@@ -127,6 +127,23 @@ int orc_icp(const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt, fl
             int max_iterations, float trim_fraction, float max_corr_dist, float energy_ratio,
             float* energy);
 
+/* Pose distance of utilities::getPoseError (PPE/misc/utilities.cpp:514-548): test / gt are 4x4
+ * col-major float images (what convertToMatrix :276-280 produces), sym = the object's symInfo in
+ * degrees per axis (0 = none, 90 / 180 / 360).  *rot_err = mean |Euler angle| of test^-1 * gt in
+ * degrees after the symmetry folds, *trans_err = translation distance. */
+void orc_pose_error(const float test[16], const float gt[16], const float sym[3], float* rot_err,
+                    float* trans_err);
+
+/* HypothesisSelection::greedyClustering (PPE/hypothesis_verification/HypothesisSelection.cpp:66-115):
+ * keep scores > accept_fraction * best_score, order by score descending (STABLE here: equal scores
+ * stay in index order; the reference's std::sort leaves that order unspecified), then greedily keep
+ * a candidate unless getPoseError(candidate, kept) < (rot_thresh, trans_thresh) for an earlier
+ * kept one.  rep_out receives the kept hypothesis ids in output order; assign (nullable, n)
+ * receives for every hypothesis the id of the representative that absorbed it (itself for a
+ * representative, -1 if pruned).  Returns the number of representatives. */
+int orc_greedy_cluster(const float* T, const float* scores, int n, float best_score, float accept_fraction,
+                       const float sym[3], float rot_thresh, float trans_thresh, int* rep_out, int* assign);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

@@ -403,6 +403,25 @@ float ref_weighted_verify(void* h, const float* T, float delta, int* registered,
   return r;
 }
 
+// The verification loop of Perform_N_steps (base.cc:1885-1901) over n transforms on ONE instance
+// (the reference is single-threaded; bench.py runs one instance per host thread for its all-core
+// CPU figure).  best_LCP_ stays 0 so that no early-out shortens a hypothesis.  mode 0 = Verify,
+// 1 = WeightedVerify.
+void ref_score_batch(void* h, const float* T, int n, float delta, int mode, float* scores) {
+  RefScene* s = static_cast<RefScene*>(h);
+  std::vector<int> reg;
+  for (int i = 0; i < n; ++i) {
+    MatrixType m = Eigen::Map<const MatrixType>(T + 16 * (size_t)i);
+    s->best_LCP_ = 0;
+    if (mode == 0) {
+      scores[i] = Verify(*s, m, delta, 0, nullptr, nullptr);
+    } else {
+      reg.clear();
+      scores[i] = WeightedVerify(*s, m, delta, reg);
+    }
+  }
+}
+
 // The transformed query point exactly as Verify() forms it (for pinning the arithmetic order).
 void ref_transform_point(const float* T, const float* q, float* out) {
   MatrixType m = Eigen::Map<const MatrixType>(T);
@@ -460,6 +479,90 @@ int ref_rigid_from_pair(const float* p, const float* q, const float* centroid_P,
   }
   { Eigen::Map<Eigen::Matrix<double, 4, 4> > out(pose); out = transformation.cast<double>(); }
   return 1;
+}
+
+// ---- hypothesis clustering -----------------------------------------------------
+// utilities.cpp pulls in OpenCV/PCL/ROS through common_io.h and is unbuildable here; the two
+// functions below restate its Eigen-only arithmetic with the same types and expression shapes.
+
+// misc/utilities.cpp:335-356 (toEulerianAngle) -- double arithmetic on float quaternion fields.
+static void ref_to_euler(Eigen::Quaternionf& q, Eigen::Vector3f& eulAngles) {
+  double sinr = +2.0 * (q.w() * q.x() + q.y() * q.z());
+  double cosr = +1.0 - 2.0 * (q.x() * q.x() + q.y() * q.y());
+  eulAngles[0] = atan2(sinr, cosr);
+  double sinp = +2.0 * (q.w() * q.y() - q.z() * q.x());
+  if (fabs(sinp) >= 1)
+    eulAngles[1] = copysign(M_PI / 2, sinp);
+  else
+    eulAngles[1] = asin(sinp);
+  double siny = +2.0 * (q.w() * q.z() + q.x() * q.y());
+  double cosy = +1.0 - 2.0 * (q.y() * q.y() + q.z() * q.z());
+  eulAngles[2] = atan2(siny, cosy);
+}
+
+// misc/utilities.cpp:514-548 (getPoseError).  `abs(float)` at :534 resolves to the float overload
+// (<cmath> + the C++ <stdlib.h> wrapper pulled in by the OpenCV/PCL headers), restated as std::abs.
+void ref_pose_error(const float* test16, const float* gt16, const float* sym, float* rot_err, float* trans_err) {
+  Eigen::Map<const Eigen::Matrix4f> testPose(test16), gtPose(gt16);
+  Eigen::Vector3f symInfo(sym[0], sym[1], sym[2]);
+  Eigen::Matrix3f testRot, gtRot, rotdiff;
+  for (int ii = 0; ii < 3; ii++)
+    for (int jj = 0; jj < 3; jj++) {
+      testRot(ii, jj) = testPose(ii, jj);
+      gtRot(ii, jj) = gtPose(ii, jj);
+    }
+  testRot = testRot.inverse().eval();
+  rotdiff = testRot * gtRot;
+  Eigen::Quaternionf rotdiffQ(rotdiff);
+  Eigen::Vector3f rotErrXYZ;
+  ref_to_euler(rotdiffQ, rotErrXYZ);
+  rotErrXYZ = rotErrXYZ * 180.0 / M_PI;
+  for (int dim = 0; dim < 3; dim++) {
+    rotErrXYZ(dim) = fabs(rotErrXYZ(dim));
+    if (symInfo(dim) == 90) {
+      rotErrXYZ(dim) = std::abs(rotErrXYZ(dim) - 90);
+      rotErrXYZ(dim) = std::min(rotErrXYZ(dim), 90 - rotErrXYZ(dim));
+    } else if (symInfo(dim) == 180) {
+      rotErrXYZ(dim) = std::min(rotErrXYZ(dim), 180 - rotErrXYZ(dim));
+    } else if (symInfo(dim) == 360) {
+      rotErrXYZ(dim) = 0;
+    }
+  }
+  *rot_err = (rotErrXYZ(0) + rotErrXYZ(1) + rotErrXYZ(2)) / 3;
+  *trans_err = sqrt(pow(gtPose(0, 3) - testPose(0, 3), 2) + pow(gtPose(1, 3) - testPose(1, 3), 2) +
+                    pow(gtPose(2, 3) - testPose(2, 3), 2));
+}
+
+// hypothesis_verification/HypothesisSelection.cpp:66-115 (greedyClustering, the live "Hough"
+// variant).  Poses are given as the Matrix4f images convertToMatrix (:95-96) produces.  The
+// `cluster_it.second += ...` at :102 acts on a by-value copy and is a no-op, so cluster scores
+// are the representatives' own.  std::sort with the reference's comparator (not stable: the
+// order among equal scores is whatever this libstdc++ yields).  Returns representative ids
+// (indices into the input list) in output order.
+int ref_greedy_cluster(const float* T, const float* scores, int n, float best_score, const float* sym,
+                       int* rep_out) {
+  typedef std::pair<int, float> Hyp;
+  std::vector<Hyp> pruned, clustered;
+  float acceptable_fraction = 0.5;
+  for (int i = 0; i < n; ++i)
+    if (scores[i] > acceptable_fraction * best_score) pruned.push_back(Hyp(i, scores[i]));
+  auto sortPoses = [](const Hyp& a, const Hyp& b) { return (a.second > b.second); };
+  std::sort(pruned.begin(), pruned.end(), sortPoses);
+  for (auto candidate_it : pruned) {
+    bool inValid = false;
+    for (auto cluster_it : clustered) {
+      float meanrotErr, transErr;
+      ref_pose_error(T + 16 * candidate_it.first, T + 16 * cluster_it.first, sym, &meanrotErr, &transErr);
+      if (meanrotErr < 10 && transErr < 0.02) {
+        inValid = true;
+        break;
+      }
+    }
+    if (inValid == false) clustered.push_back(candidate_it);
+  }
+  std::sort(clustered.begin(), clustered.end(), sortPoses);
+  for (size_t i = 0; i < clustered.size(); ++i) rep_out[i] = clustered[i].first;
+  return (int)clustered.size();
 }
 
 }  // extern "C"

@@ -28,6 +28,10 @@ class IcpParams(C.Structure):
                 ("max_corr_dist", C.c_float), ("energy_ratio", C.c_float)]
 
 
+class ClusterParams(C.Structure):
+    _fields_ = [("accept_fraction", C.c_float), ("rot_thresh_deg", C.c_float), ("trans_thresh", C.c_float)]
+
+
 # every symbol include/pgp.h declares: (restype, argtypes)
 SIGNATURES = {
     "pgp_version": (C.c_int, []),
@@ -60,6 +64,9 @@ SIGNATURES = {
     "pgp_radius_outlier_filter": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, C.c_int,
                                             C.POINTER(C.c_ubyte), _f, _i]),
     "pgp_depth_cost": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_int, C.c_int, C.c_float, _f, _i]),
+    "pgp_cluster_poses": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, _f, C.POINTER(ClusterParams), _i,
+                                    C.c_int, _i, _i]),
+    "pgp_pose_error": (C.c_int, [C.c_void_p, _f, _f, C.c_int, _f, _f, _f]),
     "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),
     "pgp_get_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),

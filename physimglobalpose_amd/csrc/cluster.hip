@@ -1,0 +1,389 @@
+// csrc/cluster.hip -- greedy pose clustering of a scored hypothesis list.
+//
+// Replaces HypothesisSelection::greedyClustering (PPE/hypothesis_verification/HypothesisSelection.cpp:
+// 66-115) with its pose distance utilities::getPoseError (PPE/misc/utilities.cpp:514-548):
+//   1. prune   : keep scores > accept_fraction * best_score                        (:70-77)
+//   2. order   : score descending (:83); equal scores stay in index order here -- the reference's
+//                std::sort leaves that order unspecified
+//   3. greedy  : a candidate is kept unless an EARLIER kept one is within (rot_thresh, trans_thresh)
+//                of it, getPoseError(candidate, kept)                                (:88-109)
+// (the `cluster_it.second += ...` at :102 updates a by-value copy, so scores are not merged).
+//
+// GPU form: the greedy pass is a non-maximum suppression.  All m(m-1)/2 pair tests are independent
+// and go first (one wave = one candidate x 64 earlier poses, ballot -> one 64-bit word of a
+// lower-triangular bit matrix); the sequential part then only ANDs words: per tile of 64
+// candidates, hits against representatives of earlier tiles are found in parallel, and the
+// 64-step dependency chain inside the tile runs on one diagonal word per candidate in registers.
+//
+// Arithmetic follows the reference's Eigen expressions (3x3 cofactor inverse, size-3 redux order
+// x0 + (x1 + x2), Shoemake quaternion extraction, Euler angles in double); float division and
+// sqrt are the correctly rounded forms.  atan2 / asin are the device's double-precision routines:
+// a pair whose error lies within an ulp-of-double of a threshold could decide differently from
+// glibc -- the tests measure the margin of every fixture (oracle/pgp_oracle.c:orc_pose_error).
+
+#include <cstring>
+
+#include "pgp_internal.h"
+
+#include <rocprim/rocprim.hpp>
+
+namespace pgp {
+
+namespace {
+
+__device__ __forceinline__ float mul(float a, float b) { return __fmul_rn(a, b); }
+__device__ __forceinline__ float add(float a, float b) { return __fadd_rn(a, b); }
+__device__ __forceinline__ float sub(float a, float b) { return __fsub_rn(a, b); }
+__device__ __forceinline__ float fdiv(float a, float b) { return __fdiv_rn(a, b); }
+__device__ __forceinline__ float sqrt_rn(float z) { return (float)__dsqrt_rn((double)z); }
+
+constexpr int kPoseStride = 12;  // per sorted pose: 9 floats of a 3x3 (row-major) + translation
+
+// float -> uint32 whose unsigned order is the float order (NaN never reaches here)
+__device__ __forceinline__ uint32_t orderable(float f) {
+  const uint32_t b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+__global__ __launch_bounds__(256) void cluster_keys(const float* __restrict__ scores, int n, float bar,
+                                                    unsigned long long* __restrict__ keys,
+                                                    int* __restrict__ m_out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  bool pass = false;
+  if (i < n) {
+    const float s = scores[i];
+    pass = s > bar;  // HypothesisSelection.cpp:75
+    // ascending sort of (~score, index) = score descending, index ascending; pruned go last
+    const uint32_t hi = pass ? ~orderable(s) : 0xFFFFFFFFu;
+    keys[i] = ((unsigned long long)hi << 32) | (uint32_t)i;
+  }
+  const unsigned long long b = __ballot(pass);
+  if ((threadIdx.x & 63) == 0 && b) atomicAdd(m_out, __popcll(b));
+}
+
+__device__ __forceinline__ float cof3(const float* a, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return sub(mul(a[3 * i1 + j1], a[3 * i2 + j2]), mul(a[3 * i1 + j2], a[3 * i2 + j1]));
+}
+
+// utilities.cpp:523 testRot.inverse(): Eigen compute_inverse<.,.,3> (row-major a, inv)
+__device__ __forceinline__ void inverse3(const float* a, float* inv) {
+  const float c0 = cof3(a, 0, 0), c1 = cof3(a, 1, 0), c2 = cof3(a, 2, 0);
+  const float det = add(mul(c0, a[0]), add(mul(c1, a[3]), mul(c2, a[6])));
+  const float invdet = fdiv(1.0f, det);
+  inv[0] = mul(c0, invdet);
+  inv[1] = mul(c1, invdet);
+  inv[2] = mul(c2, invdet);
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    inv[3 + j] = mul(cof3(a, j, 1), invdet);
+    inv[6 + j] = mul(cof3(a, j, 2), invdet);
+  }
+}
+
+// Sorted pose tables.  inv_c: AoS, the candidate role (wave-uniform reads): inverse rotation + t.
+// rot_r: SoA [12][m], the "cluster" role (lane-indexed reads): rotation + t.
+__global__ __launch_bounds__(256) void cluster_gather(const unsigned long long* __restrict__ keys_sorted,
+                                                      const float* __restrict__ T, int m,
+                                                      float* __restrict__ inv_c, float* __restrict__ rot_r,
+                                                      int* __restrict__ idx_sorted) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= m) return;
+  const int id = (int)(uint32_t)keys_sorted[c];
+  idx_sorted[c] = id;
+  const float* t = T + 16 * (size_t)id;  // column-major 4x4
+  float a[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) a[3 * i + j] = t[i + 4 * j];
+  float inv[9];
+  inverse3(a, inv);
+  float* o = inv_c + (size_t)kPoseStride * c;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) o[k] = inv[k];
+  o[9] = t[12];
+  o[10] = t[13];
+  o[11] = t[14];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) rot_r[(size_t)k * m + c] = a[k];
+  rot_r[(size_t)9 * m + c] = t[12];
+  rot_r[(size_t)10 * m + c] = t[13];
+  rot_r[(size_t)11 * m + c] = t[14];
+}
+
+struct Sym {
+  float x, y, z;
+};
+
+__device__ __forceinline__ float fold(float e, float sym) {
+  // utilities.cpp:528-542
+  float v = fdiv(mul(e, 180.0f), 3.14159274101257324f);
+  v = fabsf(v);
+  if (sym == 90.f) {
+    v = fabsf(sub(v, 90.f));
+    v = fminf(v, sub(90.f, v));
+  } else if (sym == 180.f) {
+    v = fminf(v, sub(180.f, v));
+  } else if (sym == 360.f) {
+    v = 0.f;
+  }
+  return v;
+}
+
+// getPoseError(test = candidate (inverse rotation iv, translation tc), gt = g / tg)
+__device__ __forceinline__ void pose_error(const float* iv, const float* tc, const float* g, const float* tg,
+                                           Sym sym, float* rot_err, float* trans_err) {
+  float d[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)  // :524, size-3 redux
+      d[3 * i + j] = add(mul(iv[3 * i], g[j]), add(mul(iv[3 * i + 1], g[3 + j]), mul(iv[3 * i + 2], g[6 + j])));
+  // :525 Eigen quaternionbase_assign_impl<.,3,3>
+  float x, y, z, w;
+  float t = add(d[0], add(d[4], d[8]));
+  if (t > 0.f) {
+    t = sqrt_rn(add(t, 1.0f));
+    w = mul(0.5f, t);
+    t = fdiv(0.5f, t);
+    x = mul(sub(d[7], d[5]), t);
+    y = mul(sub(d[2], d[6]), t);
+    z = mul(sub(d[3], d[1]), t);
+  } else {
+    // i = arg max of the diagonal (first maximum), j = (i+1)%3, k = (j+1)%3; spelled out per case
+    // so that no array is indexed at run time (scratch)
+    int i = 0;
+    if (d[4] > d[0]) i = 1;
+    if (d[8] > (i ? d[4] : d[0])) i = 2;
+#define PGP_QCASE(I, J, K, QI, QJ, QK)                                              \
+  {                                                                                 \
+    t = sqrt_rn(add(sub(sub(d[4 * I], d[4 * J]), d[4 * K]), 1.0f));                 \
+    QI = mul(0.5f, t);                                                              \
+    t = fdiv(0.5f, t);                                                              \
+    w = mul(sub(d[3 * K + J], d[3 * J + K]), t);                                    \
+    QJ = mul(add(d[3 * J + I], d[3 * I + J]), t);                                   \
+    QK = mul(add(d[3 * K + I], d[3 * I + K]), t);                                   \
+  }
+    if (i == 0) PGP_QCASE(0, 1, 2, x, y, z)
+    else if (i == 1) PGP_QCASE(1, 2, 0, y, z, x)
+    else PGP_QCASE(2, 0, 1, z, x, y)
+#undef PGP_QCASE
+  }
+  // :335-356 toEulerianAngle: float products and sums, the rest in double
+  const double sinr = 2.0 * (double)add(mul(w, x), mul(y, z));
+  const double cosr = 1.0 - 2.0 * (double)add(mul(x, x), mul(y, y));
+  const float e0 = (float)atan2(sinr, cosr);
+  const double sinp = 2.0 * (double)sub(mul(w, y), mul(z, x));
+  const float e1 = fabs(sinp) >= 1 ? (float)copysign(1.57079632679489661923, sinp) : (float)asin(sinp);
+  const double siny = 2.0 * (double)add(mul(w, z), mul(x, y));
+  const double cosy = 1.0 - 2.0 * (double)add(mul(y, y), mul(z, z));
+  const float e2 = (float)atan2(siny, cosy);
+  *rot_err = fdiv(add(add(fold(e0, sym.x), fold(e1, sym.y)), fold(e2, sym.z)), 3.0f);
+  // :545-547 pow(float, int) promotes to double
+  const double dx = (double)sub(tg[0], tc[0]), dy = (double)sub(tg[1], tc[1]), dz = (double)sub(tg[2], tc[2]);
+  *trans_err = (float)__dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+}
+
+__global__ __launch_bounds__(256) void pose_error_pairs(const float* __restrict__ test, const float* __restrict__ gt,
+                                                        int n, Sym sym, float* __restrict__ rot_err,
+                                                        float* __restrict__ trans_err) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float* a16 = test + 16 * (size_t)p;
+  const float* g16 = gt + 16 * (size_t)p;
+  float a[9], g[9], iv[9];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      a[3 * i + j] = a16[i + 4 * j];
+      g[3 * i + j] = g16[i + 4 * j];
+    }
+  inverse3(a, iv);
+  const float tc[3] = {a16[12], a16[13], a16[14]}, tg[3] = {g16[12], g16[13], g16[14]};
+  float re, te;
+  pose_error(iv, tc, g, tg, sym, &re, &te);
+  rot_err[p] = re;
+  trans_err[p] = te;
+}
+
+// bits[c * W + w] bit b = candidate c is within the thresholds of sorted pose r = 64 w + b, r < c.
+// One block per candidate; its 4 waves stride over the words of the row.
+__global__ __launch_bounds__(256) void cluster_pair_bits(const float* __restrict__ inv_c,
+                                                         const float* __restrict__ rot_r, int m, int W, Sym sym,
+                                                         float rot_thresh, float trans_thresh,
+                                                         unsigned long long* __restrict__ bits) {
+  const int c = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* cp = inv_c + (size_t)kPoseStride * c;
+  float iv[9], tc[3];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) iv[k] = cp[k];
+  tc[0] = cp[9];
+  tc[1] = cp[10];
+  tc[2] = cp[11];
+  const int nw = (c + 63) >> 6;  // words holding some r < c
+  for (int w = wave; w < nw; w += 4) {
+    const int r = 64 * w + lane;
+    bool hit = false;
+    if (r < c) {
+      float g[9], tg[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) g[k] = rot_r[(size_t)k * m + r];
+      tg[0] = rot_r[(size_t)9 * m + r];
+      tg[1] = rot_r[(size_t)10 * m + r];
+      tg[2] = rot_r[(size_t)11 * m + r];
+      float re, te;
+      pose_error(iv, tc, g, tg, sym, &re, &te);
+      hit = re < rot_thresh && te < trans_thresh;  // HypothesisSelection.cpp:99
+    }
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) bits[(size_t)c * W + w] = b;
+  }
+  // the diagonal word of a candidate with c % 64 == 0 holds no r < c: define it
+  if ((c & 63) == 0 && threadIdx.x == 0) bits[(size_t)c * W + (c >> 6)] = 0ull;
+}
+
+// The sequential pass.  One block (4 waves).  keep[] (LDS) = representatives so far, by sorted
+// position.  Per tile of 64 candidates: (1) each wave takes 16 of them and looks for a hit among
+// the representatives of EARLIER tiles (lanes stride over the row's words, first hit = lowest
+// position); (2) wave 0 walks the 64 candidates in order using only the tile's diagonal words.
+__global__ __launch_bounds__(256) void cluster_greedy(const unsigned long long* __restrict__ bits, int m, int W,
+                                                      const int* __restrict__ idx_sorted, int* __restrict__ rep_out,
+                                                      int* __restrict__ assign, int* __restrict__ n_rep_out) {
+  extern __shared__ unsigned long long keep[];  // W words
+  __shared__ int pre[64];                       // first earlier-tile representative hit, or -1
+  __shared__ int n_rep_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = threadIdx.x; w < W; w += blockDim.x) keep[w] = 0ull;
+  if (threadIdx.x == 0) n_rep_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < m; c0 += 64) {
+    const int wt = c0 >> 6;  // the tile's diagonal word; earlier tiles own words < wt
+    for (int j = wave; j < 64; j += 4) {
+      const int c = c0 + j;
+      int first = -1;
+      if (c < m) {
+        for (int wb = 0; wb < wt && first < 0; wb += 64) {
+          const int w = wb + lane;
+          const unsigned long long x = w < wt ? (bits[(size_t)c * W + w] & keep[w]) : 0ull;
+          const unsigned long long any = __ballot(x != 0ull);
+          if (any) {
+            const int src = __ffsll((long long)any) - 1;
+            const int pos = 64 * w + (__ffsll((long long)x) - 1);
+            first = __shfl(pos, src, 64);
+          }
+        }
+      }
+      if (lane == 0) pre[j] = first;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int c = c0 + lane;
+      const unsigned long long diag = c < m ? bits[(size_t)c * W + wt] : 0ull;
+      const int my_pre = c < m ? pre[lane] : 0;
+      unsigned long long kw = 0ull;
+      int my_assign = my_pre;
+      int n_rep = n_rep_s;
+      const int jn = m - c0 < 64 ? m - c0 : 64;
+      for (int j = 0; j < jn; ++j) {
+        const unsigned long long dj = __shfl(diag, j, 64) & kw;
+        const int pj = __shfl(my_pre, j, 64);
+        int a;
+        if (pj >= 0) {
+          a = pj;
+        } else if (dj) {
+          a = c0 + (__ffsll((long long)dj) - 1);
+        } else {
+          a = c0 + j;
+          kw |= 1ull << j;
+          if (lane == 0) rep_out[n_rep] = idx_sorted[c0 + j];
+          ++n_rep;
+        }
+        if (lane == j) my_assign = a;
+      }
+      if (c < m) assign[idx_sorted[c]] = idx_sorted[my_assign];
+      if (lane == 0) {
+        keep[wt] = kw;
+        n_rep_s = n_rep;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_rep_out = n_rep_s;
+}
+
+}  // namespace
+
+int launch_pose_error(pgp_ctx* ctx, const float* d_test, const float* d_gt, int n, const float sym[3],
+                      float* d_rot, float* d_trans, hipStream_t st) {
+  (void)ctx;
+  if (n <= 0) return PGP_OK;
+  const Sym s = {sym[0], sym[1], sym[2]};
+  hipLaunchKernelGGL(pose_error_pairs, dim3((n + 255) / 256), dim3(256), 0, st, d_test, d_gt, n, s, d_rot, d_trans);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+// d_T [n][16], d_scores [n] -> d_rep [n] (first *n_rep entries valid), d_assign [n], d_counts {m, n_rep}
+int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n, float best_score,
+                   const float sym[3], const pgp_cluster_params* prm, int* d_rep, int* d_assign,
+                   int* h_m, int* h_n_rep, hipStream_t st) {
+  *h_m = 0;
+  *h_n_rep = 0;
+  if (n <= 0) return PGP_OK;
+  const float bar = prm->accept_fraction * best_score;  // float product as at HypothesisSelection.cpp:75
+  size_t sort_bytes = 0;
+  hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
+                                           (unsigned long long*)nullptr, (size_t)n, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  int rc = ctx->d_cl_keys.ensure((size_t)n * 16 + sort_bytes + 512);
+  if (rc != PGP_OK) return rc;
+  unsigned long long* keys_in = ctx->d_cl_keys.as<unsigned long long>();
+  unsigned long long* keys_out = keys_in + n;
+  int* d_cnt = reinterpret_cast<int*>(keys_out + n);  // {m, n_rep}
+  void* sort_tmp = reinterpret_cast<unsigned char*>(d_cnt) + 256;
+  PGP_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), st));
+  PGP_HIP(hipMemsetAsync(d_assign, 0xFF, (size_t)n * sizeof(int), st));
+  hipLaunchKernelGGL(cluster_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_scores, n, bar, keys_in, d_cnt);
+  he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)n, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  int m = 0;
+  PGP_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *h_m = m;
+  if (m == 0) return PGP_OK;
+  const int W = (m + 63) / 64;
+  if ((size_t)W * 8 > 60 * 1024) {  // keep[] lives in LDS
+    set_error("pgp_cluster_poses: %d hypotheses pass the score bar; at most %d are supported", m, 60 * 1024 / 8 * 64);
+    return PGP_EINVAL;
+  }
+  const size_t pose_bytes = ((size_t)m * kPoseStride * 4 + 255) & ~(size_t)255;
+  const size_t idx_bytes = ((size_t)m * 4 + 255) & ~(size_t)255;
+  if ((rc = ctx->d_cl_ws.ensure(2 * pose_bytes + idx_bytes + (size_t)m * W * 8)) != PGP_OK) return rc;
+  unsigned char* base = ctx->d_cl_ws.as<unsigned char>();
+  float* inv_c = reinterpret_cast<float*>(base);
+  float* rot_r = reinterpret_cast<float*>(base + pose_bytes);
+  int* idx_sorted = reinterpret_cast<int*>(base + 2 * pose_bytes);
+  unsigned long long* bits = reinterpret_cast<unsigned long long*>(base + 2 * pose_bytes + idx_bytes);
+  hipLaunchKernelGGL(cluster_gather, dim3((m + 255) / 256), dim3(256), 0, st, keys_out, d_T, m, inv_c, rot_r,
+                     idx_sorted);
+  const Sym s = {sym[0], sym[1], sym[2]};
+  hipLaunchKernelGGL(cluster_pair_bits, dim3(m), dim3(256), 0, st, inv_c, rot_r, m, W, s, prm->rot_thresh_deg,
+                     prm->trans_thresh, bits);
+  hipLaunchKernelGGL(cluster_greedy, dim3(1), dim3(256), (size_t)W * 8, st, bits, m, W, idx_sorted, d_rep,
+                     d_assign, d_cnt + 1);
+  PGP_HIP(hipGetLastError());
+  PGP_HIP(hipMemcpyAsync(h_n_rep, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  return PGP_OK;
+}
+
+}  // namespace pgp

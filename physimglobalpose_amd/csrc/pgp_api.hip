@@ -148,7 +148,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
@@ -646,6 +646,67 @@ int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, i
       counts[3 * i + 2] = hc[3 * i + 2];
     }
   }
+  return PGP_OK;
+}
+
+int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h, float best_score,
+                      const float sym_deg[3], const pgp_cluster_params* params, int* rep_index, int cap,
+                      int* n_rep, int* assignment) {
+  if (!ctx || n_h < 0 || cap < 0 || !n_rep || !sym_deg || (n_h > 0 && (!T || !scores)) || (cap > 0 && !rep_index)) {
+    set_error("pgp_cluster_poses: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_rep = 0;
+  if (n_h == 0) return PGP_OK;
+  const pgp_cluster_params dflt = {0.5f, 10.f, 0.02f};  // HypothesisSelection.cpp:70,99
+  if (!params) params = &dflt;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t nT = (size_t)n_h * 64, nS = ((size_t)n_h * 4 + 63) & ~(size_t)63;
+  int rc = ctx->d_cl_io.ensure(nT + 3 * nS);
+  if (rc != PGP_OK) return rc;
+  unsigned char* base = ctx->d_cl_io.as<unsigned char>();
+  float* d_T = reinterpret_cast<float*>(base);
+  float* d_s = reinterpret_cast<float*>(base + nT);
+  int* d_rep = reinterpret_cast<int*>(base + nT + nS);
+  int* d_assign = reinterpret_cast<int*>(base + nT + 2 * nS);
+  PGP_HIP(hipMemcpyAsync(d_T, T, nT, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_s, scores, (size_t)n_h * 4, hipMemcpyHostToDevice, st));
+  int m = 0, nr = 0;
+  rc = launch_cluster(ctx, d_T, d_s, n_h, best_score, sym_deg, params, d_rep, d_assign, &m, &nr, st);
+  if (rc != PGP_OK) return rc;
+  *n_rep = nr;
+  const int n_copy = nr < cap ? nr : cap;
+  if (n_copy > 0) PGP_HIP(hipMemcpyAsync(rep_index, d_rep, (size_t)n_copy * 4, hipMemcpyDeviceToHost, st));
+  if (assignment) PGP_HIP(hipMemcpyAsync(assignment, d_assign, (size_t)n_h * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  return PGP_OK;
+}
+
+int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, const float sym_deg[3],
+                   float* rot_err_deg, float* trans_err) {
+  if (!ctx || n < 0 || !sym_deg || (n > 0 && (!test || !gt || !rot_err_deg || !trans_err))) {
+    set_error("pgp_pose_error: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t nT = (size_t)n * 64, nS = ((size_t)n * 4 + 63) & ~(size_t)63;
+  int rc = ctx->d_cl_io.ensure(2 * nT + 2 * nS);
+  if (rc != PGP_OK) return rc;
+  unsigned char* base = ctx->d_cl_io.as<unsigned char>();
+  float* d_a = reinterpret_cast<float*>(base);
+  float* d_g = reinterpret_cast<float*>(base + nT);
+  float* d_r = reinterpret_cast<float*>(base + 2 * nT);
+  float* d_t = reinterpret_cast<float*>(base + 2 * nT + nS);
+  PGP_HIP(hipMemcpyAsync(d_a, test, nT, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_g, gt, nT, hipMemcpyHostToDevice, st));
+  rc = launch_pose_error(ctx, d_a, d_g, n, sym_deg, d_r, d_t, st);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(rot_err_deg, d_r, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemcpyAsync(trans_err, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
   return PGP_OK;
 }
 

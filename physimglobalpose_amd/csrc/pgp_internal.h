@@ -83,6 +83,7 @@ struct pgp_ctx {
   pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
 
   pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
+  pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
 
   // ICP (host API staging + per-pose correspondence workspace)
   pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_T, d_icp_out, d_icp_ws;
@@ -140,6 +141,14 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
 // depth_cost.hip
 int launch_depth_cost(pgp_ctx* ctx, const float* d_obs, const float* d_ren, int n, int n_pix, float thr,
                       int* d_counts, hipStream_t stream);
+
+// cluster.hip
+int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n, float best_score,
+                   const float sym[3], const pgp_cluster_params* prm, int* d_rep, int* d_assign,
+                   int* h_m, int* h_n_rep, hipStream_t st);
+
+int launch_pose_error(pgp_ctx* ctx, const float* d_test, const float* d_gt, int n, const float sym[3],
+                      float* d_rot, float* d_trans, hipStream_t st);
 
 // rigid_fit.hip
 int launch_rigid(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n, const float cP[3],

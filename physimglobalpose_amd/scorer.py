@@ -178,6 +178,34 @@ class LcpScorer:
                                             C.c_float(threshold), _fp(score), counts.ctypes.data_as(_i)))
         return score, counts
 
+    # ---- hypothesis clustering (HypothesisSelection::greedyClustering) ---------------------------
+    def cluster_poses(self, T, scores, best_score=None, sym_deg=(0, 0, 0), accept_fraction=0.5,
+                      rot_thresh_deg=10.0, trans_thresh=0.02):
+        """T (n,16) col-major, scores (n,) -> (representative ids in clusteredHypothesisSet order,
+        assignment (n,): id of the absorbing representative, -1 when pruned)."""
+        T, scores = _f32(T, 16), np.ascontiguousarray(scores, np.float32)
+        n = len(T)
+        if best_score is None:
+            best_score = float(scores.max()) if n else 0.0
+        sym = np.ascontiguousarray(sym_deg, np.float32)
+        prm = _lib.ClusterParams(float(accept_fraction), float(rot_thresh_deg), float(trans_thresh))
+        rep = np.zeros(max(n, 1), np.int32)
+        assign = np.zeros(max(n, 1), np.int32)
+        n_rep = C.c_int(0)
+        _lib.check(self._lib.pgp_cluster_poses(self._h, _fp(T), _fp(scores), n, C.c_float(best_score), _fp(sym),
+                                               C.byref(prm), rep.ctypes.data_as(_i), n, C.byref(n_rep),
+                                               assign.ctypes.data_as(_i)))
+        return rep[: n_rep.value].copy(), assign[:n].copy()
+
+    def pose_error(self, test, gt, sym_deg=(0, 0, 0)):
+        """utilities::getPoseError for n pairs -> (mean rotation error in degrees, translation error)."""
+        test, gt = _f32(test, 16), _f32(gt, 16)
+        n = len(test)
+        sym = np.ascontiguousarray(sym_deg, np.float32)
+        rot, trans = np.zeros(n, np.float32), np.zeros(n, np.float32)
+        _lib.check(self._lib.pgp_pose_error(self._h, _fp(test), _fp(gt), n, _fp(sym), _fp(rot), _fp(trans)))
+        return rot, trans
+
     # ---- ICP refinement (UCTState::performTrICP / utilities::performICP inner loop) --------------
     def icp_refine(self, src_xyz, tgt_xyz, T, trim=1.0, max_iterations=100, max_corr_dist=0.0,
                    energy_ratio=1.0):

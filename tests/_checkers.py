@@ -77,6 +77,8 @@ def oracle_lib():
         L.orc_cs_find_congruent.argtypes = [C.c_void_p, _f, C.c_float, C.c_float, C.c_float, _i, C.c_int,
                                             _i, C.c_int, _i, C.c_int]
         L.orc_icp.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, C.c_float, C.c_float, C.c_float, _f]
+        L.orc_pose_error.argtypes = [_f, _f, _f, _f, _f]
+        L.orc_greedy_cluster.argtypes = [_f, _f, C.c_int, C.c_float, C.c_float, _f, C.c_float, C.c_float, _i, _i]
         _oracle = L
     return _oracle
 
@@ -218,6 +220,47 @@ def oracle_icp(src, tgt, T, trim=1.0, max_iterations=100, max_corr_dist=0.0, ene
     return T, energy, iters
 
 
+def _pose_error(fn, test, gt, sym):
+    test, gt = _f32(test).reshape(-1, 16), _f32(gt).reshape(-1, 16)
+    sym = _f32(sym)
+    rot, trans = np.zeros(len(test), np.float32), np.zeros(len(test), np.float32)
+    r, t = C.c_float(0), C.c_float(0)
+    for i in range(len(test)):
+        fn(_fp(test[i]), _fp(gt[i]), _fp(sym), C.byref(r), C.byref(t))
+        rot[i], trans[i] = r.value, t.value
+    return rot, trans
+
+
+def oracle_pose_error(test, gt, sym=(0, 0, 0)):
+    """orc_pose_error over n pairs of 16-float col-major transforms -> (rot_err_deg, trans_err)."""
+    return _pose_error(oracle_lib().orc_pose_error, test, gt, sym)
+
+
+def ref_pose_error(test, gt, sym=(0, 0, 0)):
+    return _pose_error(ref_lib().ref_pose_error, test, gt, sym)
+
+
+def oracle_greedy_cluster(T, scores, best_score, sym=(0, 0, 0), accept_fraction=0.5, rot_thresh=10.0,
+                          trans_thresh=0.02):
+    """orc_greedy_cluster -> (representative ids in output order, assignment per hypothesis)."""
+    T, scores, sym = _f32(T).reshape(-1, 16), _f32(scores), _f32(sym)
+    n = len(T)
+    rep = np.zeros(max(n, 1), np.int32)
+    assign = np.zeros(max(n, 1), np.int32)
+    k = oracle_lib().orc_greedy_cluster(_fp(T), _fp(scores), n, C.c_float(best_score), C.c_float(accept_fraction),
+                                        _fp(sym), C.c_float(rot_thresh), C.c_float(trans_thresh), _ip(rep),
+                                        _ip(assign))
+    return rep[:k].copy(), assign[:n].copy()
+
+
+def ref_greedy_cluster(T, scores, best_score, sym=(0, 0, 0)):
+    """The harness restatement of greedyClustering with the reference's std::sort (0.5 / 10 / 0.02)."""
+    T, scores, sym = _f32(T).reshape(-1, 16), _f32(scores), _f32(sym)
+    rep = np.zeros(max(len(T), 1), np.int32)
+    k = ref_lib().ref_greedy_cluster(_fp(T), _fp(scores), len(T), C.c_float(best_score), _fp(sym), _ip(rep))
+    return rep[:k].copy()
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 
@@ -253,6 +296,8 @@ def ref_lib():
         L.ref_cs_extract_pairs.argtypes = [C.c_void_p, _f, C.c_int, C.c_int, C.c_float, C.c_float, _i, C.c_int]
         L.ref_cs_find_congruent.argtypes = [C.c_void_p, _f, C.c_float, C.c_float, C.c_float, _i, C.c_int,
                                             _i, C.c_int, _i, C.c_int]
+        L.ref_pose_error.argtypes = [_f, _f, _f, _f, _f]
+        L.ref_greedy_cluster.argtypes = [_f, _f, C.c_int, C.c_float, _f, _i]
         _ref = L
     return _ref
 

@@ -176,6 +176,7 @@ def main():
     np.savez_compressed(path, p=ps, q=qs, centroid_P=cP, centroid_Q=cQ, status=status, T=Tc, pose=pose, rms=rms)
     print("rigid_fit:", np.bincount(status, minlength=3), f"{os.path.getsize(path)/1024:.0f} KiB")
     congruent_cases()
+    cluster_cases()
     weights_case()
     test_scene_case()
 
@@ -268,7 +269,50 @@ def congruent_cases():
               "quads", [len(x) for x in QD], f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def cluster_pose_set(rng, n, n_modes=12):
+    """Scored pose list with structure: tight groups around a few modes + scattered poses."""
+    from scipy.spatial.transform import Rotation as Rot
+    modes = [(Rot.random(random_state=int(rng.integers(1 << 30))), rng.uniform(-0.2, 0.2, 3)) for _ in range(n_modes)]
+    T = np.zeros((n, 16), np.float32)
+    for i in range(n):
+        if rng.random() < 0.75:
+            R0, t0 = modes[int(rng.integers(n_modes))]
+            R = Rot.from_rotvec(rng.normal(0, np.radians(rng.choice([2.0, 6.0, 15.0])), 3)) * R0
+            t = t0 + rng.normal(0, rng.choice([0.003, 0.012]), 3)
+        else:
+            R, t = Rot.random(random_state=int(rng.integers(1 << 30))), rng.uniform(-0.3, 0.3, 3)
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = R.as_matrix(), t
+        T[i] = M.astype(np.float32).ravel(order="F")
+    scores = rng.permutation(n).astype(np.float32) / np.float32(n) * np.float32(0.9) + np.float32(0.01)  # distinct
+    return T, scores
+
+
+def cluster_cases():
+    """(11) pose distance + greedy clustering through the Eigen harness (utilities.cpp:514-548,
+    HypothesisSelection.cpp:66-115); scores are distinct so std::sort's tie order cannot matter."""
+    from _checkers import ref_pose_error, ref_greedy_cluster
+    rng = np.random.default_rng(20261011)
+    out = {}
+    for k, (n, sym) in enumerate([(500, (0, 0, 0)), (700, (90, 180, 360)), (400, (180, 0, 90))]):
+        T, scores = cluster_pose_set(rng, n)
+        best = float(scores.max())
+        rep = ref_greedy_cluster(T, scores, best, sym)
+        ia, ib = rng.integers(0, n, 4000), rng.integers(0, n, 4000)
+        rot, trans = ref_pose_error(T[ia], T[ib], sym)
+        out.update({f"T_{k}": T, f"scores_{k}": scores, f"sym_{k}": np.array(sym, np.float32),
+                    f"rep_{k}": rep, f"pair_a_{k}": ia.astype(np.int32), f"pair_b_{k}": ib.astype(np.int32),
+                    f"rot_{k}": rot, f"trans_{k}": trans})
+        print(f"cluster_{k}: n={n} sym={sym} kept={int((scores > 0.5 * best).sum())} clusters={len(rep)}")
+    path = os.path.join(HERE, "cluster.npz")
+    np.savez_compressed(path, **out)
+    print("cluster:", f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "cluster":
+        cluster_cases()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "congruent":
         congruent_cases()
         sys.exit(0)
