@@ -191,8 +191,14 @@ def main():
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # PGP_BENCH_FORCE_DIST=1: take the collective path even with one rank (exercises RCCL init,
+    # the asynchronous all-reduce and the stream-level wait on a 1-GPU box)
+    multi = world > 1 or os.environ.get("PGP_BENCH_FORCE_DIST") == "1"
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -212,41 +218,65 @@ def main():
     sc.reserve(n_h)
     T_all = torch.from_numpy(w.T).to(dev)
     d_T = T_all[rank * n_h:(rank + 1) * n_h].contiguous()
-    d_scores_all = torch.zeros(world * n_h, dtype=torch.float32, device=dev)
+    # two score vectors: the all-reduce of step k (RCCL's own stream) overlaps the scoring kernel
+    # of step k+1 (this stream); a buffer is reused only after its collective and arg-max are done
+    n_buf = 2 if multi else 1
+    bufs = [torch.zeros(world * n_h, dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    works = [None] * n_buf
+    d_scores_all = bufs[0]
     d_scores = d_scores_all[rank * n_h:(rank + 1) * n_h]
     d_counts = torch.zeros(n_h, dtype=torch.int32, device=dev)
     d_best = torch.zeros(2, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
+    state = {"k": 0, "argmax": None}
+
+    def finish(b):
+        """Complete the exchange that was started on buffer b: every rank then holds all scores
+        (north_star: "RCCL all-reduce over xGMI of the per-hypothesis LCP scores") and takes the
+        arg-max locally."""
+        if works[b] is not None:
+            works[b].wait()          # stream-level wait under nccl; host wait under gloo
+            works[b] = None
+            state["argmax"] = torch.argmax(bufs[b])
 
     def step():
-        if world > 1:
-            d_scores_all.zero_()
-        sc.score_device(d_T, d_scores, d_counts, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
-        if world > 1:
-            # every rank filled only its slice of a zeroed vector: sum == gather (north_star:
-            # "RCCL all-reduce over xGMI of the per-hypothesis LCP scores"), then local arg-max
-            dist.all_reduce(d_scores_all, op=dist.ReduceOp.SUM)
-            torch.argmax(d_scores_all)
+        if not multi:
+            sc.score_device(d_T, d_scores, d_counts, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
+            return
+        b = state["k"] % n_buf
+        state["k"] += 1
+        finish(b)
+        buf = bufs[b]
+        buf.zero_()                  # every rank fills only its slice of a zeroed vector: sum == gather
+        sc.score_device(d_T, buf[rank * n_h:(rank + 1) * n_h], d_counts, d_best, mode=mode,
+                        gate_deg=w.gate_deg, stream=stream)
+        works[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    def drain():
+        for b in range(n_buf):
+            finish((state["k"] + b) % n_buf)
 
     for _ in range(args.warmup):
         step()
+    drain()
     torch.cuda.synchronize()
     sc.set_kernel_timing(True)
     sc.kernel_timing(reset=True)
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    drain()                          # every step's exchange and arg-max complete inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     launches, kern_ms = sc.kernel_timing(reset=True)
     sc.set_kernel_timing(False)
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -254,7 +284,13 @@ def main():
     # sanity inside the bench: the device result of the last step matches a host-pointer call
     best = d_best.cpu().numpy()
     s_host, _, bi_host, _ = sc.score(w.T[rank * n_h:(rank + 1) * n_h], mode, w.gate_deg)
-    assert np.array_equal(s_host, d_scores.cpu().numpy()) and bi_host == int(best[0])
+    last = bufs[(state["k"] - 1) % n_buf] if multi else d_scores_all
+    assert np.array_equal(s_host, last[rank * n_h:(rank + 1) * n_h].cpu().numpy()) and bi_host == int(best[0])
+    if multi:
+        # the combined vector of the last step: every slice present, arg-max = the global best
+        s_all = last.cpu().numpy()
+        assert (s_all.reshape(world, n_h).max(axis=1) > 0).all()
+        assert int(state["argmax"]) == int(np.argmax(s_all))
 
     if rank == 0:
         total_h = n_h * world * args.steps
@@ -294,7 +330,7 @@ def main():
             except Exception as e:  # secondary numbers must never take the headline line down
                 out["other_rows"] = {"error": repr(e)}
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

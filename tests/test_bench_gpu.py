@@ -39,7 +39,9 @@ def test_single_gpu_line():
     assert len(lines) == 1
     d = _check(lines[0], 1)
     cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
+    if cb["kind"] == "reference":               # the prebuilt oracle/_ref travelled along
+        assert cb["agrees_with_port"] and cb["port"]["kind"] == "port" and cb["port"]["value"] > 0
 
 
 def test_two_ranks_on_one_gpu_functional():
@@ -53,3 +55,15 @@ def test_two_ranks_on_one_gpu_functional():
     assert len(lines) == 1                      # rank 0 only
     d = _check(lines[0], 2)
     assert "cpu_baseline" not in d              # N = 1 only
+
+
+def test_one_rank_through_rccl():
+    """PGP_BENCH_FORCE_DIST=1: a one-rank process group on the real RCCL backend -- init with
+    device_id, asynchronous all-reduce on RCCL's stream, stream-level wait, drain, barrier."""
+    env = dict(os.environ, PGP_BENCH_FORCE_DIST="1", MASTER_PORT="29547")
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    _check(lines[0], 1)

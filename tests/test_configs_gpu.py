@@ -44,3 +44,54 @@ def test_three_objects_score_then_icp_refine():
         assert np.median(s_ref) >= np.median(s_before)
         assert s_ref.max() - s_ref.min() <= 5.0 / len(w.Q_xyz)
         assert (iters >= 1).all() and np.isfinite(energy).all()
+
+
+def test_six_objects_64k_hypotheses_sharded_like_8_ranks():
+    """BASELINE.json configs[3] at full hypothesis count on ONE GPU: 6 objects, 65 536 hypotheses in
+    total, partitioned exactly as 8 ranks would (flat_slices), each emulated rank filling only its
+    slice of the zeroed score vector through LcpScorer.score_device; the sum over ranks is what the
+    all-reduce(SUM) produces and must equal the unsharded scores bit for bit.  Oracle on a sample."""
+    import torch
+    from physimglobalpose_amd.sharding import MultiObjectShardedScorer, best_of, flat_slices
+    counts = [16384, 12288, 12288, 8192, 8192, 8192]
+    assert sum(counts) == 65536
+    objs = [synth.make_workload(20000, 3000, n, config_id=300 + k) for k, n in enumerate(counts)]
+    scorers, Ts = [], []
+    for w in objs:
+        sc = LcpScorer(0)
+        sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+        sc.reserve(max(counts))
+        scorers.append(sc)
+        Ts.append(torch.from_numpy(w.T).cuda())
+
+    def local(sc):
+        def f(T):
+            s = torch.zeros(len(T), device="cuda")
+            c = torch.zeros(len(T), dtype=torch.int32, device="cuda")
+            b = torch.zeros(2, dtype=torch.int32, device="cuda")
+            sc.score_device(T.contiguous(), s, c, b, mode=PGP_MODE_WEIGHTED)
+            torch.cuda.synchronize()
+            return s
+        return f
+
+    fns = [local(sc) for sc in scorers]
+    whole, bests = MultiObjectShardedScorer(fns, rank=0, world=1).score(Ts)
+    acc = [torch.zeros_like(s) for s in whole]
+    covered = 0
+    for r in range(8):
+        pieces = flat_slices(counts, r, 8)
+        covered += sum(hi - lo for _, lo, hi in pieces)
+        part, _ = MultiObjectShardedScorer(fns, rank=r, world=8).score(Ts)   # no process group: no exchange
+        for a, p in zip(acc, part):
+            a += p
+    assert covered == 65536
+    for o, (a, s) in enumerate(zip(acc, whole)):
+        assert torch.equal(a, s), f"object {o}"
+        assert best_of(a) == bests[o]
+    for w, s, (bi, bs) in zip(objs, whole, bests):
+        s = s.cpu().numpy()
+        idx = np.unique(np.concatenate([np.arange(0, len(s), 1021), [bi]]))
+        orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+        so, _, _ = orc.score_batch(w.T[idx], w.delta, mode=1, gate_deg=w.gate_deg, threads=8)
+        assert np.allclose(s[idx], so, rtol=0, atol=2e-6)
+        assert bi == int(np.argmax(s)) and np.float32(bs) == s.max()
