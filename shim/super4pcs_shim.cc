@@ -48,6 +48,7 @@
 #include <Eigen/Geometry>
 
 #include "../include/pgp.h"
+#include "super4pcs_shim.h"
 
 namespace {
 
@@ -418,6 +419,21 @@ void set_identity(std::pair<Eigen::Isometry3d, float>& h) {
 
 }  // namespace
 
+bool super4pcs_shim_read_ply(const std::string& path, std::vector<float>& xyz, std::vector<float>& normals) {
+  Cloud c;
+  if (!read_ply(path, c)) return false;
+  xyz.swap(c.xyz);
+  normals.swap(c.nrm);
+  return true;
+}
+
+bool super4pcs_shim_read_png16(const std::string& path, std::vector<unsigned short>& pixels, int& rows, int& cols) {
+  std::vector<uint16_t> px;
+  if (!read_png_gray(path, px, rows, cols)) return false;
+  pixels.assign(px.begin(), px.end());
+  return true;
+}
+
 void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std::string input3,
                                     std::pair<Eigen::Isometry3d, float>& bestHypothesis,
                                     std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
@@ -426,18 +442,45 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
                                     int max_count_ppf, Eigen::Matrix3f camIntrinsic, std::string objName,
                                     std::string scenePath, std::vector<int>& registered_points) {
   (void)max_count_ppf; (void)objName; (void)scenePath;
-  const float delta = 0.005f;              // super4pcs_test.cc:20
-  const int max_number_of_bases = 100;     // base.cc:290
-  const int max_sampled_csets = 100;       // base.cc:1858
-  pgp_ctx* ctx = nullptr;
   set_identity(bestHypothesis);
-
   // ---- file hand-off (super4pcs_test.cc:58-80): set1 = segment, set2 = validation model, set3 = search model
   Cloud seg, qval, qsearch;
   if (!read_ply(input1, seg) || !read_ply(input2, qval) || !read_ply(input3, qsearch)) {
     std::cerr << "[libsuper4pcs shim] cannot read the input PLY files" << std::endl;
     return;
   }
+  std::vector<uint16_t> px;
+  int rows = 0, cols = 0;
+  const bool have = read_png_gray(probImagePath, px, rows, cols);
+  if (!have) std::cerr << "[libsuper4pcs shim] no probability image at " << probImagePath << ": weights = 1" << std::endl;
+  const Super4PCSCloudView vs = {seg.xyz.data(), seg.nrm.data(), seg.n};
+  const Super4PCSCloudView vq = {qval.xyz.data(), qval.nrm.data(), qval.n};
+  const Super4PCSCloudView vqs = {qsearch.xyz.data(), qsearch.nrm.data(), qsearch.n};
+  getProbableTransformsSuper4PCS(vs, vq, vqs, have ? px.data() : nullptr, rows, cols, bestHypothesis, hypothesisSet,
+                                 PPFMap, camIntrinsic, registered_points);
+}
+
+void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
+                                    const Super4PCSCloudView& model_search, const unsigned short* prob_image,
+                                    int rows, int cols,
+                                    std::pair<Eigen::Isometry3d, float>& bestHypothesis,
+                                    std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
+                                    std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
+                                    Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points) {
+  const float delta = 0.005f;              // super4pcs_test.cc:20
+  const int max_number_of_bases = 100;     // base.cc:290
+  const int max_sampled_csets = 100;       // base.cc:1858
+  pgp_ctx* ctx = nullptr;
+  set_identity(bestHypothesis);
+  auto own = [](const Super4PCSCloudView& v) {   // the call centres and re-normalises: work on copies
+    Cloud c;
+    c.n = v.n > 0 && v.xyz ? v.n : 0;
+    c.xyz.assign(v.xyz, v.xyz + 3 * (size_t)c.n);
+    if (v.normals) c.nrm.assign(v.normals, v.normals + 3 * (size_t)c.n);
+    else c.nrm.assign(3 * (size_t)c.n, 0.f);
+    return c;
+  };
+  Cloud seg = own(segment), qval = own(model_validation), qsearch = own(model_search);
   if (seg.n == 0 || qval.n == 0 || qsearch.n == 0) return;
   auto unit = [](std::vector<float>& n) {  // Point3D::set_normal (shared4pcs.h:85-87)
     for (size_t i = 0; i + 2 < n.size(); i += 3) {
@@ -464,18 +507,12 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
     m.Pn[i] = Vec3(seg.nrm[3 * i], seg.nrm[3 * i + 1], seg.nrm[3 * i + 2]);
   }
   // ---- per-point weights from the probability image (base.cc:317-340)
-  {
-    std::vector<uint16_t> px;
-    int rows = 0, cols = 0;
-    bool have = read_png_gray(probImagePath, px, rows, cols);
-    if (!have) std::cerr << "[libsuper4pcs shim] no probability image at " << probImagePath << ": weights = 1" << std::endl;
-    m.prob.assign(seg.n, 1.f);
-    if (have) {
-      float K[9];
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
-      pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, px.data(), rows, cols, m.prob.data());
-    }
+  m.prob.assign(seg.n, 1.f);
+  if (prob_image && rows > 0 && cols > 0) {
+    float K[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
+    pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, m.prob.data());
   }
 
   // ---- device state: scene index, validation model, search model

@@ -3,6 +3,7 @@
 // loads PPFMap.txt the way Objects::readPPFMap does, calls getProbableTransformsSuper4PCS exactly
 // as CongruentSetMatching::generate does, and prints the outputs for tests/test_shim_gpu.py.
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -11,6 +12,8 @@
 
 #include <Eigen/Core>
 #include <Eigen/Geometry>
+
+#include "super4pcs_shim.h"  // the in-memory overload + readers (SHIM_TEST_INMEMORY=1 uses them)
 
 void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std::string input3,
                                     std::pair<Eigen::Isometry3d, float>& bestHypothesis,
@@ -47,8 +50,21 @@ int main(int argc, char** argv) {
   best.second = 0;
   std::vector<std::pair<Eigen::Isometry3d, float> > hyps;
   std::vector<int> registered;
-  getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMap, 0, K, "synthetic_object",
-                                 "./", registered);
+  if (std::getenv("SHIM_TEST_INMEMORY")) {
+    std::vector<float> sx, sn, vx, vn, qx, qn;
+    std::vector<unsigned short> px;
+    int rows = 0, cols = 0;
+    if (!super4pcs_shim_read_ply(argv[1], sx, sn) || !super4pcs_shim_read_ply(argv[2], vx, vn) ||
+        !super4pcs_shim_read_ply(argv[3], qx, qn)) return 3;
+    const bool have = super4pcs_shim_read_png16(argv[4], px, rows, cols);
+    const Super4PCSCloudView s = {sx.data(), sn.data(), (int)(sx.size() / 3)};
+    const Super4PCSCloudView v = {vx.data(), vn.data(), (int)(vx.size() / 3)};
+    const Super4PCSCloudView q = {qx.data(), qn.data(), (int)(qx.size() / 3)};
+    getProbableTransformsSuper4PCS(s, v, q, have ? px.data() : nullptr, rows, cols, best, hyps, PPFMap, K, registered);
+  } else {
+    getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMap, 0, K, "synthetic_object",
+                                   "./", registered);
+  }
   std::printf("PPFMAP %zu\n", PPFMap.size());
   std::printf("BEST_SCORE %.9g\n", best.second);
   std::printf("BEST_POSE");

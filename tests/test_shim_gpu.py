@@ -100,6 +100,11 @@ def test_drop_in_symbol_recovers_the_pose(tmp_path, binary):
     out = subprocess.run([BIN, seg, val, search, png, ppf, str(fx), str(fy), str(cx), str(cy)], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
+    # the in-memory overload (no PLY/PNG round trip) gives the same answer for the same seed
+    out_mem = subprocess.run([BIN, seg, val, search, png, ppf, str(fx), str(fy), str(cx), str(cy)],
+                             env=dict(env, SHIM_TEST_INMEMORY="1"), capture_output=True, text=True, timeout=600)
+    assert out_mem.returncode == 0, out_mem.stderr[-2000:]
+    assert out_mem.stdout == out.stdout
     lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l[0].isupper()}
     assert int(lines["PPFMAP"][0]) == len(table)
     score = float(lines["BEST_SCORE"][0])
