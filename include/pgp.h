@@ -233,10 +233,13 @@ int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h
 int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, const float sym_deg[3],
                    float* rot_err_deg, float* trans_err);
 
-/* Per-kernel timing for bench.py's roofline line: when enabled, every pgp_score_lcp[_device]
- * call brackets its dominant kernel (score_hypotheses) with a pair of HIP events on the SAME
- * stream it is launched on.  pgp_get_kernel_timing synchronises those events and returns the
- * number of bracketed launches and the sum of their durations since the last reset. */
+/* Per-kernel timing for bench.py's roofline line.  enable = N >= 1: every Nth pgp_score_lcp[_device]
+ * call (the 1st, N+1st, ...) attaches a start and a stop HIP event to its dominant kernel's dispatch
+ * (score_hypotheses), on the SAME stream it is launched on; 0 switches it off.  Timing a launch costs
+ * the stream about 8 us (the runtime serialises around a timed dispatch), which is why a throughput
+ * measurement samples (N = 8 in bench.py) instead of timing every step.  pgp_get_kernel_timing
+ * synchronises those events and returns the number of timed launches and the sum of their
+ * durations since the last reset. */
 int pgp_set_kernel_timing(pgp_ctx* ctx, int enable);
 int pgp_get_kernel_timing(pgp_ctx* ctx, int* launches, float* total_ms, int reset);
 

@@ -31,6 +31,8 @@
 
 #include "pgp_internal.h"
 
+#include <hip/hip_ext.h>
+
 #include <cmath>
 #include <cstring>
 
@@ -536,19 +538,25 @@ float key2f(int32_t k) {
   return f;
 }
 
-void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a) {
+// ev0 / ev1 (both or neither): start / stop events attached to the dispatch itself
+// (hipExtLaunchKernelGGL) -- the kernel's own begin / end timestamps, without the two barrier
+// packets that hipEventRecord before and after the launch put on the stream (those cost the
+// C2 step 8 us, 7 % of its throughput, when per-kernel timing was on).
+void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a, hipEvent_t ev0,
+                    hipEvent_t ev1) {
   // default by measurement at C2 (tools/tune.py): wave-flattened 112 us plain / 157 us weighted vs
   // per-lane walk (U = 2) 125 / 170 us
   if (unroll <= 0) {  // wave-flattened candidate phase
     if (mode == PGP_MODE_PLAIN)
-      hipLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, a, a.T, a.words,
-                         a.occ_run, a.cand, a.Pnw);
+      hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T,
+                            a.words, a.occ_run, a.cand, a.Pnw);
     else
-      hipLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, a, a.T,
-                         a.words, a.occ_run, a.cand, a.Pnw);
+      hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
+                            a.T, a.words, a.occ_run, a.cand, a.Pnw);
     return;
   }
-#define PGP_LAUNCH(M, UU) hipLaunchKernelGGL((score_hypotheses<M, UU>), grid, dim3(kTile), 0, stream, a)
+#define PGP_LAUNCH(M, UU) \
+  hipExtLaunchKernelGGL((score_hypotheses<M, UU>), grid, dim3(kTile), 0, stream, ev0, ev1, 0, a)
   // per-lane walk, two hypotheses unrolled (U = 1, 4, 8 measured within 2 % or slower)
   if (mode == PGP_MODE_PLAIN) PGP_LAUNCH(PGP_MODE_PLAIN, 2);
   else PGP_LAUNCH(PGP_MODE_WEIGHTED, 2);
@@ -657,7 +665,7 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     int chunks_pad = (a.n_chunks + 7) / 8 * 8;
     dim3 grid((unsigned)(chunks_pad * a.n_tiles));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->timing) {
+    if (ctx->timing > 0 && (ctx->timing_seq++ % (unsigned)ctx->timing) == 0) {
       if (ctx->ev_used + 2 > ctx->ev.size()) {
         for (int k = 0; k < 2; ++k) {
           hipEvent_t e;
@@ -668,10 +676,8 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
       ev0 = ctx->ev[ctx->ev_used];
       ev1 = ctx->ev[ctx->ev_used + 1];
       ctx->ev_used += 2;
-      PGP_HIP(hipEventRecord(ev0, stream));
     }
-    launch_variant(mode, ctx->unroll, grid, stream, a);
-    if (ev1) PGP_HIP(hipEventRecord(ev1, stream));
+    launch_variant(mode, ctx->unroll, grid, stream, a, ev0, ev1);
     hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream,
                        (const int*)a.partial_cnt, (const float*)a.partial_sum, a.n_tiles, n_h, a.nQ,
                        mode, d_scores, d_counts, key, ticket, d_best ? d_best : best_local);

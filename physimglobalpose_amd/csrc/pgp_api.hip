@@ -715,7 +715,8 @@ int pgp_set_kernel_timing(pgp_ctx* ctx, int enable) {
     set_error("pgp_set_kernel_timing: ctx is NULL");
     return PGP_EINVAL;
   }
-  ctx->timing = enable != 0;
+  ctx->timing = enable > 0 ? enable : 0;
+  ctx->timing_seq = 0;
   return PGP_OK;
 }
 

@@ -102,7 +102,8 @@ struct pgp_ctx {
   int hpb_override = 0;
 
   // optional per-kernel timing (pgp_set_kernel_timing)
-  bool timing = false;
+  int timing = 0;               // 0 off, N >= 1: every Nth scoring launch carries start/stop events
+  unsigned timing_seq = 0;
   std::vector<hipEvent_t> ev;   // pairs: [2k] start, [2k+1] stop
   size_t ev_used = 0;           // events recorded since the last reset
 

@@ -288,7 +288,8 @@ class LcpScorer:
             C.c_void_p(stream)))
 
     def set_kernel_timing(self, enable=True):
-        _lib.check(self._lib.pgp_set_kernel_timing(self._h, int(bool(enable))))
+        """True / 1: time every scoring launch; N > 1: every Nth; False / 0: off."""
+        _lib.check(self._lib.pgp_set_kernel_timing(self._h, int(enable)))
 
     def kernel_timing(self, reset=True):
         """(launches, total_ms) of the dominant kernel since the last reset (HIP events)."""

@@ -194,3 +194,23 @@ def test_device_pointer_entry_matches_host_entry():
     with pytest.raises(_lib.PgpError):
         big = torch.zeros(301, 16, device="cuda")
         sc.score_device(big, torch.zeros(301, device="cuda"))   # beyond pgp_reserve: no hidden alloc
+
+
+def test_large_and_odd_batch_sizes():
+    """20 000 hypotheses (79 finalize workgroups folding one device-scope arg-max) down to 1, at
+    sizes on both sides of the workgroup multiples: scores, counts and best against the oracle."""
+    w = synth.make_workload(3000, 400, 20000, config_id=47)
+    sc = LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+    so, bio, _ = orc.score_batch(w.T, w.delta, mode=0, threads=8)
+    for n in (20000, 16385, 16384, 1025, 1024, 1):
+        s, c, bi, bs = sc.score(w.T[:n])
+        assert np.array_equal(s, so[:n])
+        exp = int(np.argmax(so[:n])) if so[:n].max() > 0 else -1
+        assert bi == exp and (bi < 0 or np.float32(bs) == so[bi])
+    swo, bwo, _ = orc.score_batch(w.T, w.delta, mode=1, gate_deg=w.gate_deg, threads=8)
+    for n in (20000, 16384):
+        sw, _, bi, _ = sc.score(w.T[:n], PGP_MODE_WEIGHTED, w.gate_deg)
+        assert np.allclose(sw, swo[:n], rtol=0, atol=2e-6)
+        assert bi == (int(np.argmax(sw)) if sw.max() > 0 else -1)
