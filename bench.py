@@ -92,9 +92,14 @@ def cpu_baseline(w, mode, budget_s=8.0):
     s_ref = run(refs[0], w.T[:256])
     r1 = 256 / (time.perf_counter() - t0)
     s_port, _, _ = orc.score_batch(w.T[:256], w.delta, mode=m, gate_deg=w.gate_deg, threads=cores)
-    per = int(min(max(r1 * budget_s, 64), 16 * len(w.T)))
-    Ts = np.ascontiguousarray(np.concatenate([w.T] * (-(-per // len(w.T))))[:per])
     with ThreadPoolExecutor(cores) as ex:
+        # calibrate the ALL-THREAD rate first (the box's logical cores are shared: 128 threads run
+        # far below 128 x the one-thread rate), then size the sample for ~budget_s of wall time
+        t0 = time.perf_counter()
+        list(ex.map(lambda r: run(r, w.T[:32]), refs))
+        agg = 32 * cores / (time.perf_counter() - t0)
+        per = int(min(max(agg * budget_s / cores, 32), 16 * len(w.T)))
+        Ts = np.ascontiguousarray(np.concatenate([w.T] * (-(-per // len(w.T))))[:per])
         t0 = time.perf_counter()
         list(ex.map(lambda r: run(r, Ts), refs))
         dtr = time.perf_counter() - t0

@@ -71,10 +71,31 @@ __device__ __forceinline__ float sqdist(float x, float y, float z, float4 p) {
   return __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
 }
 
+// Sum over the 64 lanes in a FIXED association, on the DPP cross-lane path (no LDS traffic, unlike
+// __shfl_xor = ds_bpermute): four row-local steps (quad swaps, half-row and row mirrors -- after
+// them every lane of a 16-lane row holds the row total), then the four row totals (r0+r1)+(r2+r3).
+template <int CTRL>
+__device__ __forceinline__ float dpp_step(float v) {
+  const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+  return __fadd_rn(v, __int_as_float(moved));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = dpp_step<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_step<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_step<0x141>(v);  // row_half_mirror
+  v = dpp_step<0x140>(v);  // row_mirror
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+  const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+  const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return __fadd_rn(__fadd_rn(r0, r1), __fadd_rn(r2, r3));
+}
+
 // Cell lookup: candidate run [s, e) for position (x,y,z); empty outside the grid / in empty cells.
 // Branch-free on purpose: the kernel is instruction-issue bound and every `if` costs an exec-mask
 // save / branch / restore triple; both loads are issued unconditionally from always-valid addresses
 // (entry 0 when the position is outside the grid or the cell is empty) and the result is selected.
+template <bool WAVE_SKIP = false>
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
                                          const uint2* __restrict__ occ_run, float x, float y,
                                          float z, uint32_t* s, uint32_t* e, bool live = true) {
@@ -82,11 +103,20 @@ __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restr
   const bool valid = live & (fx >= 0.f) & (fx < (float)g.nx) & (fy >= 0.f) & (fy < (float)g.ny) & (fz >= 0.f) &
                      (fz < (float)g.nz);  // NaN fails every comparison
   const int cx = valid ? (int)fx : 0, cy = valid ? (int)fy : 0, cz = valid ? (int)fz : 0;
-  const size_t wi = ((size_t)cz * g.ny + cy) * g.nxw + (cx >> 5);
+  // 24-bit multiplies (full rate; 32- and 64-bit integer multiplies issue at a quarter of it):
+  // every axis has <= 1024 cells (grid_index.hip kMaxDim), so cz * ny + cy < 2^20, nxw <= 32
+  // (the masks change no value; they let the compiler prove that the operands fit in 24 bits)
+  const uint32_t row = ((uint32_t)cz & 1023u) * ((uint32_t)g.ny & 2047u) + ((uint32_t)cy & 1023u);
+  const uint32_t wi = (row & 0xFFFFFu) * ((uint32_t)g.nxw & 63u) + ((uint32_t)cx >> 5);
   const unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
   const unsigned lo = (unsigned)(wv & 0xFFFFFFFFull), base = (unsigned)(wv >> 32);
   const int bit = cx & 31;
   const bool occ = valid & (((lo >> bit) & 1u) != 0u);
+  if (WAVE_SKIP && __ballot(occ) == 0ull) {  // wave-uniform: no lane has a candidate run
+    *s = 0u;
+    *e = 0u;
+    return;
+  }
   const uint32_t k = occ ? base + __popc(lo & ((1u << bit) - 1u)) : 0u;
   const unsigned long long rv = reinterpret_cast<const unsigned long long*>(occ_run)[k];  // {start, count}
   const uint32_t st = (unsigned)(rv & 0xFFFFFFFFull), cnt = (unsigned)(rv >> 32);
@@ -217,11 +247,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
         }
       }
       unsigned long long mask = __ballot(hit);
-      if (MODE == PGP_MODE_WEIGHTED) {
-        // fixed butterfly: same association every run
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
-      }
+      if (MODE == PGP_MODE_WEIGHTED && mask) wsum = wave_sum(wsum);  // fixed association, same every run
       if (lane == 0 && hb + u < h1) {
         s_cnt[wave][hb + u - h0] = __popcll(mask);
         if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][hb + u - h0] = wsum;
@@ -264,25 +290,24 @@ template <int MODE, int NC>
 __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __restrict__ cand,
                                            const float4* ent, unsigned long long* res,
                                            const unsigned char* own, uint32_t W, uint32_t w0, int lane) {
+  // a lane past the last slot repeats the LAST slot's test (valid owner, valid candidate) and is
+  // masked out of the result: no exec-mask branches in the batch
+  uint32_t we[NC];
   int o[NC];
   float4 en[NC], p[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    const uint32_t w = w0 + 64 * c + lane;
-    o[c] = w < W ? (int)own[w] : -1;
+    we[c] = min(w0 + 64 * c + lane, W - 1u);
+    o[c] = (int)own[we[c]];
   }
 #pragma unroll
-  for (int c = 0; c < NC; ++c) en[c] = ent[o[c] >= 0 ? o[c] : 0];
+  for (int c = 0; c < NC; ++c) en[c] = ent[o[c]];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const uint32_t w = w0 + 64 * c + lane;
-    // a finished lane re-reads the wave's first candidate (always valid: W > 0)
-    p[c] = cand[o[c] >= 0 ? __float_as_uint(en[c].w) + w : __float_as_uint(ent[0].w)];
-  }
+  for (int c = 0; c < NC; ++c) p[c] = cand[__float_as_uint(en[c].w) + we[c]];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float d2 = sqdist(en[c].x, en[c].y, en[c].z, p[c]);
-    if (o[c] >= 0 && d2 <= a.sq_eps) {
+    if (w0 + 64 * c + lane < W && d2 <= a.sq_eps) {
       if (MODE == PGP_MODE_PLAIN) {
         res[o[c]] = 1ull;  // benign race: every writer stores the same value
       } else {
@@ -335,7 +360,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
     const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
     const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
     uint32_t s, e;
-    cell_run(a.g, words, occ_run, x, y, z, &s, &e, live);
+    cell_run<true>(a.g, words, occ_run, x, y, z, &s, &e, live);
     const uint32_t len = e - s;
     // slot allocation in the concatenated run of the wave: one returning LDS atomic add per
     // owning lane (any order will do: the owner map below resolves slots to owners), skipped
@@ -344,7 +369,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
     if (__ballot(len > 0)) {
       if (len > 0) pre = atomicAdd(wcount, len);
       __builtin_amdgcn_wave_barrier();
-      W = *wcount;
+      W = __builtin_amdgcn_readfirstlane(*wcount);  // wave-uniform: keep it (and the batch loop) scalar
       __builtin_amdgcn_wave_barrier();
       if (lane == 0) *wcount = 0;
     }
@@ -369,7 +394,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
       // batch width follows what is left instead of always issuing four chunks.
       for (uint32_t w0 = 0; w0 < W;) {
         const uint32_t left = W - w0;
-        if (left > 128) {
+        if (MODE == PGP_MODE_PLAIN && left > 128) {
           flat_batch<MODE, 4>(a, cand, ent, res, own, W, w0, lane);
           w0 += 256;
         } else if (left > 64) {
@@ -404,10 +429,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
       }
     }
     const unsigned long long mask = __ballot(hit);
-    if (MODE == PGP_MODE_WEIGHTED) {
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) wsum += __shfl_xor(wsum, off, 64);
-    }
+    if (MODE == PGP_MODE_WEIGHTED && mask) wsum = wave_sum(wsum);  // no hit in the wave: the sum is 0
     if (lane == 0) {
       s_cnt[wave][h - h0] = __popcll(mask);
       if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][h - h0] = wsum;
