@@ -95,14 +95,21 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Branch-free on purpose: the kernel is instruction-issue bound and every `if` costs an exec-mask
 // save / branch / restore triple; both loads are issued unconditionally from always-valid addresses
 // (entry 0 when the position is outside the grid or the cell is empty) and the result is selected.
+// Returns the run as (start, count).
+// Validity is tested on the truncated integers with one unsigned compare per axis.  Truncation maps
+// (-1, 0) to cell 0 and the conversion maps NaN to 0 as well (v_cvt_i32_f32 saturates, NaN -> 0):
+// both end in the outermost cell layer, which holds no candidates by construction (choose_grid pads
+// the box by r + 1 cells and the dilation reaches r), so such a position finds nothing -- the same
+// answer as "outside the grid".
 template <bool WAVE_SKIP = false>
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
                                          const uint2* __restrict__ occ_run, float x, float y,
-                                         float z, uint32_t* s, uint32_t* e, bool live = true) {
+                                         float z, uint32_t* s, uint32_t* n, bool live = true) {
   const float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
-  const bool valid = live & (fx >= 0.f) & (fx < (float)g.nx) & (fy >= 0.f) & (fy < (float)g.ny) & (fz >= 0.f) &
-                     (fz < (float)g.nz);  // NaN fails every comparison
-  const int cx = valid ? (int)fx : 0, cy = valid ? (int)fy : 0, cz = valid ? (int)fz : 0;
+  const int ix = __float2int_rz(fx), iy = __float2int_rz(fy), iz = __float2int_rz(fz);
+  const bool valid = live & ((uint32_t)ix < (uint32_t)g.nx) & ((uint32_t)iy < (uint32_t)g.ny) &
+                     ((uint32_t)iz < (uint32_t)g.nz);
+  const int cx = valid ? ix : 0, cy = valid ? iy : 0, cz = valid ? iz : 0;
   // 24-bit multiplies (full rate; 32- and 64-bit integer multiplies issue at a quarter of it):
   // every axis has <= 1024 cells (grid_index.hip kMaxDim), so cz * ny + cy < 2^20, nxw <= 32
   // (the masks change no value; they let the compiler prove that the operands fit in 24 bits)
@@ -114,14 +121,14 @@ __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restr
   const bool occ = valid & (((lo >> bit) & 1u) != 0u);
   if (WAVE_SKIP && __ballot(occ) == 0ull) {  // wave-uniform: no lane has a candidate run
     *s = 0u;
-    *e = 0u;
+    *n = 0u;
     return;
   }
   const uint32_t k = occ ? base + __popc(lo & ((1u << bit) - 1u)) : 0u;
   const unsigned long long rv = reinterpret_cast<const unsigned long long*>(occ_run)[k];  // {start, count}
   const uint32_t st = (unsigned)(rv & 0xFFFFFFFFull), cnt = (unsigned)(rv >> 32);
   *s = occ ? st : 0u;
-  *e = occ ? st + cnt : 0u;
+  *n = occ ? cnt : 0u;
 }
 
 // Nearest candidate with d2 <= sq_eps; ties -> lowest scene index (the reference's tie rule
@@ -225,6 +232,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
       y[u] = xf_row(m[u].m10, m[u].m11, m[u].m12, m[u].m13, q.x, q.y, q.z);
       z[u] = xf_row(m[u].m20, m[u].m21, m[u].m22, m[u].m23, q.x, q.y, q.z);
       cell_run(a.g, a.words, a.occ_run, x[u], y[u], z[u], &s[u], &e[u], live);
+      e[u] += s[u];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -285,20 +293,45 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
 // Arithmetic per (query, candidate) pair is unchanged; results are identical.
 constexpr int kFlatCap = 1024;  // candidate slots per wave-iteration served by the flat path
 
-// NC chunks of 64 candidate slots of the wave's concatenated runs (see score_hypotheses_flat)
+// Inclusive prefix sum over the 64 lanes on the DPP path: a shift-and-add scan inside each 16-lane
+// row (zeros are shifted in at the row start), then the row totals are carried across rows
+// (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_scan_step(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, true);
+}
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  v = dpp_scan_step<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_scan_step<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_scan_step<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_scan_step<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_scan_step<0x142, 0xA>(v);  // row_bcast:15 -> rows 1, 3
+  v = dpp_scan_step<0x143, 0xC>(v);  // row_bcast:31 -> rows 2, 3
+  return v;
+}
+
+// NC chunks of 64 candidate slots of the wave's concatenated runs (see score_hypotheses_flat).
+// Slot w belongs to the owner with the greatest run start <= w.  Run starts are marked as bits
+// (marks[w >> 6] bit w & 63) and owners are numbered in start order, so the owner of slot w is
+//   (#owners starting before the chunk) + popcount(marks word of the chunk & bits <= lane) - 1:
+// one uniform LDS read, a ballot and four VALU per chunk -- no per-slot owner table to fill.
 template <int MODE, int NC>
 __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __restrict__ cand,
                                            const float4* ent, unsigned long long* res,
-                                           const unsigned char* own, uint32_t W, uint32_t w0, int lane) {
-  // a lane past the last slot repeats the LAST slot's test (valid owner, valid candidate) and is
-  // masked out of the result: no exec-mask branches in the batch
+                                           const unsigned long long* marks, uint32_t start_key, uint32_t W,
+                                           uint32_t w0, int lane, uint32_t le_lo, uint32_t le_hi) {
+  // a lane past the last slot resolves to the LAST owner and repeats its last candidate (valid
+  // owner, valid candidate); it is masked out of the result: no exec-mask branches in the batch
   uint32_t we[NC];
   int o[NC];
   float4 en[NC], p[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    we[c] = min(w0 + 64 * c + lane, W - 1u);
-    o[c] = (int)own[we[c]];
+    const uint32_t wb = w0 + 64 * c;                       // wave-uniform
+    const unsigned long long word = marks[wb >> 6];        // same address in every lane: one broadcast read
+    const int before = __popcll(__ballot(start_key < wb)); // owners whose run starts before this chunk
+    o[c] = before - 1 + __popc((uint32_t)word & le_lo) + __popc((uint32_t)(word >> 32) & le_hi);
+    we[c] = min(wb + lane, W - 1u);
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) en[c] = ent[o[c]];
@@ -321,7 +354,7 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
 // with FOUR vector loads per hypothesis instead of scalar loads.
 template <int MODE>
-__global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, const float* __restrict__ Tm,
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat(ScoreArgs a, const float* __restrict__ Tm,
                                                                const uint2* __restrict__ words,
                                                                const uint2* __restrict__ occ_run,
                                                                const float4* __restrict__ cand,
@@ -330,8 +363,9 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
   __shared__ float s_sum[kTile / 64][kMaxHpb];
   __shared__ float4 s_ent[kTile / 64][64];                 // {x', y', z', bits(run start - prefix)}
   __shared__ unsigned long long s_res[kTile / 64][64];     // plain: 0/1 ; weighted: min key
-  __shared__ unsigned char s_own[kTile / 64][kFlatCap];    // slot -> compact owner index
-  __shared__ uint32_t s_wcount[kTile / 64];                // slots handed out in this wave-iteration
+  // run-start bits of the wave's concatenated runs; 4 spare words: the last batch may look one
+  // to three chunks past the end (they stay zero)
+  __shared__ unsigned long long s_marks[kTile / 64][kFlatCap / 64 + 4];
 
   const int L = blockIdx.x;
   const int xcd = L & 7, seq = L >> 3;
@@ -348,64 +382,65 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
   if (MODE == PGP_MODE_WEIGHTED && live) qn = a.Qn[qi];
   float4* ent = s_ent[wave];
   unsigned long long* res = s_res[wave];
-  unsigned char* own = s_own[wave];
-  uint32_t* wcount = &s_wcount[wave];
-  if (lane == 0) *wcount = 0;
+  unsigned long long* marks = s_marks[wave];
+  if (lane < kFlatCap / 64 + 4) marks[lane] = 0ull;
+  const unsigned long long le_mask = lt_mask | (1ull << lane);
+  const uint32_t le_lo = (uint32_t)le_mask, le_hi = (uint32_t)(le_mask >> 32);
 
   const int h0 = chunk * a.hpb;
   const int h1 = min(h0 + a.hpb, a.n_h);
+  int my_cnt = 0;
+  float my_sum = 0.f;
   for (int h = h0; h < h1; ++h) {
     const Xf m = load_xf(Tm, h);
     const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
     const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
     const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
-    uint32_t s, e;
-    cell_run<true>(a.g, words, occ_run, x, y, z, &s, &e, live);
-    const uint32_t len = e - s;
-    // slot allocation in the concatenated run of the wave: one returning LDS atomic add per
-    // owning lane (any order will do: the owner map below resolves slots to owners), skipped
-    // when no lane owns a run (35 % of the wave-iterations at C2)
+    uint32_t s, len;
+    cell_run<true>(a.g, words, occ_run, x, y, z, &s, &len, live);
+    // slot allocation in the concatenated run of the wave, in LANE order: an inclusive DPP scan of
+    // the run lengths (no LDS); the total lands in an SGPR, so everything below branches scalar.
+    // Skipped when no lane owns a run (35 % of the wave-iterations at C2).
+    const unsigned long long am = __ballot(len > 0);
     uint32_t pre = 0, W = 0;
-    if (__ballot(len > 0)) {
-      if (len > 0) pre = atomicAdd(wcount, len);
-      __builtin_amdgcn_wave_barrier();
-      W = __builtin_amdgcn_readfirstlane(*wcount);  // wave-uniform: keep it (and the batch loop) scalar
-      __builtin_amdgcn_wave_barrier();
-      if (lane == 0) *wcount = 0;
+    if (am) {
+      const uint32_t incl = wave_inclusive_scan(len);
+      W = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+      pre = incl - len;
     }
     bool hit = false;
     int nn_id = -1;
     if (W == 0) {
-      // nothing to test in this wave-iteration (35 % of them at C2)
+      // nothing to test in this wave-iteration
     } else if (W <= (uint32_t)kFlatCap) {
       const bool act = len > 0;
-      const unsigned long long am = __ballot(act);
-      const int r = __popcll(am & lt_mask);
+      const int r = __popcll(am & lt_mask);  // owners are numbered in lane order = start order
       if (act) {
         // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
         ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
         res[r] = MODE == PGP_MODE_PLAIN ? 0ull : ~0ull;
-        for (uint32_t k = 0; k < len; ++k) own[pre + k] = (unsigned char)r;
+        atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
       }
       __builtin_amdgcn_wave_barrier();
-      // four chunks of 64 slots per batch: owner lookups, then ALL candidate loads, then tests
-      // batches of NC chunks of 64 slots: owner lookups, then ALL candidate loads, then tests.
+      const uint32_t start_key = act ? pre : 0xFFFFFFFFu;
+      // batches of NC chunks of 64 slots: owner resolution, then ALL candidate loads, then tests.
       // Half of the non-empty wave-iterations need a single chunk (median W = 6 at C2), so the
       // batch width follows what is left instead of always issuing four chunks.
       for (uint32_t w0 = 0; w0 < W;) {
         const uint32_t left = W - w0;
         if (MODE == PGP_MODE_PLAIN && left > 128) {
-          flat_batch<MODE, 4>(a, cand, ent, res, own, W, w0, lane);
+          flat_batch<MODE, 4>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 256;
         } else if (left > 64) {
-          flat_batch<MODE, 2>(a, cand, ent, res, own, W, w0, lane);
+          flat_batch<MODE, 2>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 128;
         } else {
-          flat_batch<MODE, 1>(a, cand, ent, res, own, W, w0, lane);
+          flat_batch<MODE, 1>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 64;
         }
       }
       __builtin_amdgcn_wave_barrier();
+      if ((uint32_t)lane < ((W + 63u) >> 6)) marks[lane] = 0ull;  // clear the bits for the next iteration
       if (act) {
         const unsigned long long rv = res[r];
         if (MODE == PGP_MODE_PLAIN) hit = rv != 0ull;
@@ -413,8 +448,8 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
       }
     } else {
       // oversized wave-iteration (very dense scene): per-lane walk
-      if (MODE == PGP_MODE_PLAIN) hit = any_in_run(cand, s, e, x, y, z, a.sq_eps);
-      else nn_id = nearest_in_run(cand, s, e, x, y, z, a.sq_eps);
+      if (MODE == PGP_MODE_PLAIN) hit = any_in_run(cand, s, s + len, x, y, z, a.sq_eps);
+      else nn_id = nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
     }
     float wsum = 0.f;
     if (MODE == PGP_MODE_WEIGHTED && nn_id >= 0) {
@@ -430,10 +465,15 @@ __global__ __launch_bounds__(kTile) void score_hypotheses_flat(ScoreArgs a, cons
     }
     const unsigned long long mask = __ballot(hit);
     if (MODE == PGP_MODE_WEIGHTED && mask) wsum = wave_sum(wsum);  // no hit in the wave: the sum is 0
-    if (lane == 0) {
-      s_cnt[wave][h - h0] = __popcll(mask);
-      if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][h - h0] = wsum;
-    }
+    // the wave's total for hypothesis h is parked in lane (h - h0): two selects instead of an
+    // exec-masked LDS write per hypothesis (hpb <= 64)
+    const bool mine = lane == h - h0;
+    my_cnt = mine ? __popcll(mask) : my_cnt;
+    if (MODE == PGP_MODE_WEIGHTED) my_sum = mine ? wsum : my_sum;
+  }
+  if (lane < h1 - h0) {
+    s_cnt[wave][lane] = my_cnt;
+    if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][lane] = my_sum;
   }
   __syncthreads();
   const int hh = threadIdx.x;
@@ -525,6 +565,7 @@ __global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __res
   float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
   uint32_t s, e;
   cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
+  e += s;
   int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
   if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
     float4 qn = a.Qn[i];
@@ -723,6 +764,7 @@ __global__ __launch_bounds__(256) void count_neighbours(GridDesc g, const uint2*
   const float4 p = P[i];
   uint32_t s, e;
   cell_run(g, words, occ_run, p.x, p.y, p.z, &s, &e, true);
+  e += s;
   int k = 0;
   for (uint32_t j = s; j < e; ++j) {
     const float4 c = cand[j];
