@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void scatter_points(GridDesc g, int r, const f
         if (x < 0 || x >= g.nx) continue;
         float ex = box_dist2(p.x, g.ox + (float)x * g.h, g.h);
         if (ex + ey + ez > reach2) continue;
-        size_t c = ((size_t)z * g.ny + y) * g.nx + x;
+        size_t c = (size_t)grid_word(g, x, y, z) * 32 + grid_bit(x, y, z);
         uint32_t slot = atomicAdd(&cell_ctr[c], 1u);
         if (FILL) cand[cell_start[c] + slot] = p;
       }
@@ -164,12 +164,9 @@ __global__ __launch_bounds__(256) void make_words(GridDesc g, const uint32_t* __
     word_cnt[w] = 0;
     return;
   }
-  size_t row = w / g.nxw;  // = z*ny + y
-  int xw = (int)(w - row * g.nxw);
   uint32_t bits = 0;
-  size_t c0 = row * g.nx + (size_t)xw * 32;
-  int lim = min(32, g.nx - xw * 32);
-  for (int b = 0; b < lim; ++b)
+  const size_t c0 = w * 32;  // the word's 32 cells are consecutive in the blocked numbering
+  for (int b = 0; b < 32; ++b)
     if (cell_start[c0 + b + 1] > cell_start[c0 + b]) bits |= (1u << b);
   words[w].x = bits;
   word_cnt[w] = __popc(bits);
@@ -186,9 +183,7 @@ __global__ __launch_bounds__(256) void fill_occupied(GridDesc g, const uint32_t*
   uint32_t base = word_base[w];
   uint32_t bits = words[w].x;
   words[w].y = base;
-  size_t row = w / g.nxw;
-  int xw = (int)(w - row * g.nxw);
-  size_t c0 = row * g.nx + (size_t)xw * 32;
+  const size_t c0 = w * 32;
   uint32_t k = base;
   while (bits) {
     int b = __ffs(bits) - 1;
@@ -233,11 +228,14 @@ int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, 
     double nx = floor((double)(mx[0] - g->ox) / h) + r + 2;
     double ny = floor((double)(mx[1] - g->oy) / h) + r + 2;
     double nz = floor((double)(mx[2] - g->oz) / h) + r + 2;
-    if (nx <= kMaxDim && ny <= kMaxDim && nz <= kMaxDim && nx * ny * nz <= (double)kMaxCells) {
+    const double padded = (floor((nx + 3) / 4) * 4) * (floor((ny + 3) / 4) * 4) * (floor((nz + 1) / 2) * 2);
+    if (nx <= kMaxDim && ny <= kMaxDim && nz <= kMaxDim && padded <= (double)kMaxCells) {
       g->nx = (int)nx;
       g->ny = (int)ny;
       g->nz = (int)nz;
-      g->nxw = (g->nx + 31) / 32;
+      g->nbx = (g->nx + 3) / 4;
+      g->nby = (g->ny + 3) / 4;
+      g->nbz = (g->nz + 1) / 2;
       *r_out = r;
       return PGP_OK;
     }
@@ -282,10 +280,10 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   int r = 1;
   int rc = choose_grid(mn, mx, delta, &g, &r);
   if (rc != PGP_OK) return rc;
-  const size_t n_cells = (size_t)g.nx * g.ny * g.nz;
+  const size_t n_words = (size_t)g.nbx * g.nby * g.nbz;
+  const size_t n_cells = n_words * 32;  // blocked numbering, padded to whole 4 x 4 x 2 blocks
   const size_t n_scan = n_cells + 1;
   const int n_tiles = (int)((n_scan + kScanTile - 1) / kScanTile);
-  const size_t n_words = (size_t)g.nz * g.ny * g.nxw;
 
   if ((rc = ctx->d_cell_start.ensure(n_scan * 4)) != PGP_OK) return rc;
   if ((rc = ctx->d_cell_tmp.ensure(n_scan * 4)) != PGP_OK) return rc;

@@ -96,29 +96,42 @@ __device__ __forceinline__ float wave_sum(float v) {
 // save / branch / restore triple; both loads are issued unconditionally from always-valid addresses
 // (entry 0 when the position is outside the grid or the cell is empty) and the result is selected.
 // Returns the run as (start, count).
-// Validity is tested on the truncated integers with one unsigned compare per axis.  Truncation maps
-// (-1, 0) to cell 0 and the conversion maps NaN to 0 as well (v_cvt_i32_f32 saturates, NaN -> 0):
-// both end in the outermost cell layer, which holds no candidates by construction (choose_grid pads
-// the box by r + 1 cells and the dilation reaches r), so such a position finds nothing -- the same
-// answer as "outside the grid".
+// No validity test: the truncated cell coordinates are CLAMPED into the grid.  A position outside
+// the grid is farther than delta from every scene point (choose_grid pads the box by r + 1 cells),
+// so whatever candidates the boundary cell it is clamped to may hold fail the exact distance test;
+// NaN converts to 0 (v_cvt_i32_f32) and fails `d2 <= eps` as well.  The outermost cell layer is
+// empty in practice (the dilation reaches r cells), so such positions cost one word lookup.
+__device__ __forceinline__ uint32_t mad24(uint32_t a, uint32_t b_uniform, uint32_t c) {
+  // full-rate 24-bit multiply-add (32/64-bit integer multiplies issue at a quarter of the rate);
+  // operands: every axis has <= 1024 cells (grid_index.hip kMaxDim), i.e. <= 256 blocks
+  uint32_t r;
+  asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+  return r;
+}
+
+// float -> int, truncating, with the hardware's total semantics (saturates, NaN -> 0); a C cast is
+// undefined for those inputs and __float2int_rz adds a redundant v_trunc_f32
+__device__ __forceinline__ int cvt_rz(float f) {
+  int r;
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+  return r;
+}
+
 template <bool WAVE_SKIP = false>
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
                                          const uint2* __restrict__ occ_run, float x, float y,
                                          float z, uint32_t* s, uint32_t* n, bool live = true) {
   const float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
-  const int ix = __float2int_rz(fx), iy = __float2int_rz(fy), iz = __float2int_rz(fz);
-  const bool valid = live & ((uint32_t)ix < (uint32_t)g.nx) & ((uint32_t)iy < (uint32_t)g.ny) &
-                     ((uint32_t)iz < (uint32_t)g.nz);
-  const int cx = valid ? ix : 0, cy = valid ? iy : 0, cz = valid ? iz : 0;
-  // 24-bit multiplies (full rate; 32- and 64-bit integer multiplies issue at a quarter of it):
-  // every axis has <= 1024 cells (grid_index.hip kMaxDim), so cz * ny + cy < 2^20, nxw <= 32
-  // (the masks change no value; they let the compiler prove that the operands fit in 24 bits)
-  const uint32_t row = ((uint32_t)cz & 1023u) * ((uint32_t)g.ny & 2047u) + ((uint32_t)cy & 1023u);
-  const uint32_t wi = (row & 0xFFFFFu) * ((uint32_t)g.nxw & 63u) + ((uint32_t)cx >> 5);
+  const int cx = min(max(cvt_rz(fx), 0), g.nx - 1);
+  const int cy = min(max(cvt_rz(fy), 0), g.ny - 1);
+  const int cz = min(max(cvt_rz(fz), 0), g.nz - 1);
+  // blocked numbering (pgp_internal.h grid_word / grid_bit): word = 4 x 4 x 2 block, bit = cell in it
+  const uint32_t brow = mad24((uint32_t)cz >> 1, (uint32_t)g.nby, (uint32_t)cy >> 2);
+  const uint32_t wi = mad24(brow, (uint32_t)g.nbx, (uint32_t)cx >> 2);
   const unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
   const unsigned lo = (unsigned)(wv & 0xFFFFFFFFull), base = (unsigned)(wv >> 32);
-  const int bit = cx & 31;
-  const bool occ = valid & (((lo >> bit) & 1u) != 0u);
+  const int bit = ((cz & 1) << 4) | ((cy & 3) << 2) | (cx & 3);
+  const bool occ = live & (((lo >> bit) & 1u) != 0u);
   if (WAVE_SKIP && __ballot(occ) == 0ull) {  // wave-uniform: no lane has a candidate run
     *s = 0u;
     *n = 0u;
@@ -377,7 +390,10 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int qi = tile * kTile + threadIdx.x;
   const bool live = qi < a.nQ;
-  float4 q = live ? a.Q[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // a lane past the end of the model carries a NaN point: it lands in cell 0 and can never pass
+  // `d2 <= eps`, so the loop needs no liveness test
+  const float qnan = __int_as_float(0x7FC00000);
+  float4 q = live ? a.Q[qi] : make_float4(qnan, qnan, qnan, 0.f);
   float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == PGP_MODE_WEIGHTED && live) qn = a.Qn[qi];
   float4* ent = s_ent[wave];
@@ -397,7 +413,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
     const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
     uint32_t s, len;
-    cell_run<true>(a.g, words, occ_run, x, y, z, &s, &len, live);
+    cell_run<true>(a.g, words, occ_run, x, y, z, &s, &len);
     // slot allocation in the concatenated run of the wave, in LANE order: an inclusive DPP scan of
     // the run lengths (no LDS); the total lands in an SGPR, so everything below branches scalar.
     // Skipped when no lane owns a run (35 % of the wave-iterations at C2).

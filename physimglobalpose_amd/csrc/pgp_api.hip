@@ -756,7 +756,7 @@ int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info) {
     info->n_cells = ctx->n_cells;
     info->n_candidates = ctx->n_cand;
     info->n_occupied = ctx->n_occ;
-    info->bytes_index = (long long)((size_t)ctx->grid.nz * ctx->grid.ny * ctx->grid.nxw * 8 +
+    info->bytes_index = (long long)((size_t)ctx->grid.nbx * ctx->grid.nby * ctx->grid.nbz * 8 +
                                     (size_t)ctx->n_occ * 8 + (size_t)ctx->n_cand * 16);
     info->build_ms = ctx->build_ms;
   }

@@ -27,7 +27,10 @@ struct GridDesc {
   float ox, oy, oz;   // origin (min corner of cell (0,0,0))
   float h, inv_h;     // cell edge (>= delta) and its float reciprocal
   int nx, ny, nz;     // cells per axis
-  int nxw;            // 32-bit bitmap words per x-row = ceil(nx/32)
+  // Cells are numbered in BLOCKS of 4 x 4 x 2 (x, y, z) = 32 cells = one occupancy word, blocks in
+  // (z, y, x) order: a compact patch of query points then touches few words, few run descriptors
+  // and neighbouring candidate runs -- the vector L1 counts distinct lines per instruction.
+  int nbx, nby, nbz;  // blocks per axis = ceil(nx/4), ceil(ny/4), ceil(nz/2)
   float reach;        // delta + margin: a point is a candidate of every cell within `reach`
 };
 
@@ -59,7 +62,7 @@ struct pgp_ctx {
   pgp::DevBuf d_cell_start;  // uint32 [n_cells+1]  (build-time scratch: full-grid CSR)
   pgp::DevBuf d_cell_tmp;    // uint32 [n_cells+1]  (counts, then fill cursors)
   pgp::DevBuf d_scan_tmp;    // uint32 block sums
-  pgp::DevBuf d_bitmap;      // uint2 {occupancy bits, rank base} [nz*ny*nxw]
+  pgp::DevBuf d_bitmap;      // uint2 {occupancy bits, rank base} [nbz*nby*nbx]
   pgp::DevBuf d_occ_start;   // uint2 {start, count} per occupied cell [n_occ]
   long long n_occ = 0;
   pgp::DevBuf d_cand;        // float4 {x,y,z,bits(i)} [n_cand]
@@ -113,6 +116,14 @@ struct pgp_ctx {
 };
 
 namespace pgp {
+
+// cell (x, y, z) -> position in the blocked numbering (word index * 32 + bit)
+__host__ __device__ inline uint32_t grid_word(const GridDesc& g, int x, int y, int z) {
+  return ((uint32_t)(z >> 1) * (uint32_t)g.nby + (uint32_t)(y >> 2)) * (uint32_t)g.nbx + (uint32_t)(x >> 2);
+}
+__host__ __device__ inline uint32_t grid_bit(int x, int y, int z) {
+  return (uint32_t)(((z & 1) << 4) | ((y & 3) << 2) | (x & 3));
+}
 
 // grid_index.hip
 int build_index(pgp_ctx* ctx, const float* h_xyz, float delta);
