@@ -379,8 +379,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
 // points per lane in VGPRs, stages its 1024-point target chunk in LDS and publishes each source
 // point's best (d2, j) with one 64-bit atomic min -- min over the key is min d2, then lowest j,
 // i.e. exactly what the strict `<` scan of the persistent kernel returns.
-constexpr int kNnThreads = 256;
-constexpr int kNnTgt = 1024;
+constexpr int kNnThreads = 128;   // 512 source points per workgroup: 2500 sources -> 5 workgroups, 98 % full
+constexpr int kNnTgt = 512;    // 8 KB of LDS per 2-wave workgroup: 8 waves per SIMD resident
 
 __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
   __shared__ float4 s_t[kNnTgt];
@@ -393,30 +393,73 @@ __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
   const int base = blockIdx.x * kNnThreads * kIcpR;
   const int t0 = blockIdx.y * kNnTgt;
   const int tn = min(kNnTgt, a.n_tgt - t0);
-  for (int j = tid; j < tn; j += kNnThreads) s_t[j] = a.tgt[t0 + j];
-  float x[kIcpR], y[kIcpR], z[kIcpR], best[kIcpR];
+  // the tile is padded to a multiple of four with NaN points (a NaN distance never improves)
+  const int tn4 = (tn + 3) & ~3;
+  const float qnan = __int_as_float(0x7FC00000);
+  for (int j = tid; j < tn4; j += kNnThreads) s_t[j] = j < tn ? a.tgt[t0 + j] : make_float4(qnan, qnan, qnan, 0.f);
+  // Two source points per packed-fp32 register pair: the three differences, three squares and two
+  // sums of a (source, target) pair are v_pk_* instructions shared by two pairs (4 VALU per pair
+  // instead of 8; same operations, each rounded separately -- the file is built -ffp-contract=off).
+  // The best-so-far update (two selects per pair) runs only when some lane of the wave improved:
+  // after the first few hundred targets of a tile that is rare.
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  static_assert(kIcpR == 4, "two register pairs per lane");
+  v2f X[2], Y[2], Z[2];
+  float best[kIcpR];
   int bj[kIcpR];
+  const int* jprev = a.ws_j + (size_t)pose * a.n_src;  // correspondences of the previous iteration (-1: none)
 #pragma unroll
   for (int r = 0; r < kIcpR; ++r) {
     int i = base + r * kNnThreads + tid;
     float4 s = i < a.n_src ? a.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    x[r] = row_xf(g00, g01, g02, g03, s.x, s.y, s.z);
-    y[r] = row_xf(g10, g11, g12, g13, s.x, s.y, s.z);
-    z[r] = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+    const float sx = row_xf(g00, g01, g02, g03, s.x, s.y, s.z);
+    const float sy = row_xf(g10, g11, g12, g13, s.x, s.y, s.z);
+    const float sz = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+    X[r >> 1][r & 1] = sx;
+    Y[r >> 1][r & 1] = sy;
+    Z[r >> 1][r & 1] = sz;
+    // Bound from the previous iteration: the distance to last iteration's correspondence is an upper
+    // bound on this iteration's minimum, so the search starts just ABOVE it (next float up, so that
+    // this very candidate and every tie with it are still found, in scan order) instead of at
+    // FLT_MAX -- after that, improvements (the slow path below) are rare from the first target on,
+    // and the workgroups of tiles that hold nothing closer write no key at all.
     best[r] = FLT_MAX;
     bj[r] = -1;
+    const int jp = i < a.n_src ? jprev[i] : -1;
+    if (jp >= 0) {
+      const float4 m = a.tgt[jp];
+      const float dx = __fsub_rn(sx, m.x), dy = __fsub_rn(sy, m.y), dz = __fsub_rn(sz, m.z);
+      const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
+      if (d2 < FLT_MAX) best[r] = __uint_as_float(__float_as_uint(d2) + 1u);  // d2 >= 0: next float up
+    }
   }
   __syncthreads();
-  for (int j = 0; j < tn; ++j) {
-    const float4 m = s_t[j];
+  for (int j = 0; j < tn4; j += 4) {
+    // four targets per trip: their LDS reads are issued together, ahead of the arithmetic
+    float4 m[4];
 #pragma unroll
-    for (int r = 0; r < kIcpR; ++r) {
-      float dx = __fsub_rn(x[r], m.x), dy = __fsub_rn(y[r], m.y), dz = __fsub_rn(z[r], m.z);
-      float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
-      if (d2 < best[r]) {
-        best[r] = d2;
-        bj[r] = t0 + j;
+    for (int k = 0; k < 4; ++k) m[k] = s_t[j + k];
+    v2f d2[4][2];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const v2f dx = X[p] - m[k].x, dy = Y[p] - m[k].y, dz = Z[p] - m[k].z;
+        d2[k][p] = dx * dx + (dy * dy + dz * dz);
+        any |= (d2[k][p].x < best[2 * p]) | (d2[k][p].y < best[2 * p + 1]);
       }
+    if (__ballot(any)) {  // in target order, against the bound as it tightens
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const bool c0 = d2[k][p].x < best[2 * p], c1 = d2[k][p].y < best[2 * p + 1];
+          best[2 * p] = c0 ? d2[k][p].x : best[2 * p];
+          best[2 * p + 1] = c1 ? d2[k][p].y : best[2 * p + 1];
+          bj[2 * p] = c0 ? t0 + j + k : bj[2 * p];
+          bj[2 * p + 1] = c1 ? t0 + j + k : bj[2 * p + 1];
+        }
     }
   }
   unsigned long long* kw = a.ws_key + (size_t)pose * a.n_src;
@@ -491,6 +534,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.st_done = a.st_it + n;
   a.n_done = a.st_done + n;
   PGP_HIP(hipMemsetAsync(a.ws_key, 0xFF, need * 8, stream));
+  PGP_HIP(hipMemsetAsync(a.ws_j, 0xFF, need * 4, stream));  // no previous correspondence yet
   PGP_HIP(hipMemsetAsync(a.st_it, 0, (size_t)n * 8 + 4, stream));
   {
     std::vector<double> e0((size_t)n, (double)FLT_MAX);

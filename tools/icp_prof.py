@@ -1,0 +1,14 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from physimglobalpose_amd import LcpScorer, synth
+rng = np.random.default_rng(0)
+M, _ = synth.make_model(rng, 5000); M = M.astype(np.float32)
+R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8); t = np.array([0.1, 0.0, 0.7])
+S = (M[rng.choice(5000, 2500, replace=False)] @ R.T + t).astype(np.float32)
+Tinv = np.linalg.inv(synth._se3(R, t))
+sc = LcpScorer()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+G = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(5)), 0.005 * rng.standard_normal(3))) for _ in range(n)])
+for _ in range(3):
+    sc.icp_refine(S, M, G, trim=0.9, max_iterations=10)
