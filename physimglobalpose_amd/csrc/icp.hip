@@ -20,8 +20,9 @@
 // Mapping to the machine, two forms with identical results:
 //   split (default)  per iteration, icp_nn_split searches the correspondences with a grid of
 //                    (source chunks x target chunks x poses) workgroups -- 4 source points per lane
-//                    in VGPRs, a 1024-point target chunk in LDS, one 64-bit atomic-min key per
-//                    source point -- and icp_refine<true> (one workgroup per pose) selects,
+//                    as two packed-fp32 register pairs, a 512-point target chunk in LDS read four
+//                    targets per trip, the bound seeded from the previous iteration, one 64-bit
+//                    atomic-min key per source point -- and icp_refine<true> (one workgroup per pose) selects,
 //                    reduces and solves; the host enqueues the iterations and tests a device
 //                    counter every fourth one;
 //   persistent       icp_refine<false>: ONE WORKGROUP (1024 threads) PER POSE runs every iteration
