@@ -236,10 +236,17 @@ def main():
     stream = torch.cuda.current_stream(dev)
     state = {"k": 0, "argmax": None}
 
+    # The exchange's tail (wait for the collective, arg-max, re-zeroing the vector) runs on its own
+    # stream, beside the next steps' scoring kernels: the main stream carries scoring only and
+    # waits, per step, on an event recorded two steps earlier.
+    post = torch.cuda.Stream(dev) if multi else None
+
+    ready = [torch.cuda.Event() for _ in range(n_buf)] if multi else []
+
     def finish(b):
-        """Complete the exchange that was started on buffer b: every rank then holds all scores
-        (north_star: "RCCL all-reduce over xGMI of the per-hypothesis LCP scores") and takes the
-        arg-max locally."""
+        """Complete the exchange that was started on buffer b (call with `post` current): every rank
+        then holds all scores (north_star: "RCCL all-reduce over xGMI of the per-hypothesis LCP
+        scores") and takes the arg-max locally."""
         if works[b] is not None:
             works[b].wait()          # stream-level wait under nccl; host wait under gloo
             works[b] = None
@@ -251,16 +258,22 @@ def main():
             return
         b = state["k"] % n_buf
         state["k"] += 1
-        finish(b)
         buf = bufs[b]
-        buf.zero_()                  # every rank fills only its slice of a zeroed vector: sum == gather
+        with torch.cuda.stream(post):
+            finish(b)
+            buf.zero_()              # every rank fills only its slice of a zeroed vector: sum == gather
+            ready[b].record(post)
+        stream.wait_event(ready[b])
         sc.score_device(d_T, buf[rank * n_h:(rank + 1) * n_h], d_counts, d_best, mode=mode,
                         gate_deg=w.gate_deg, stream=stream)
         works[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
 
     def drain():
-        for b in range(n_buf):
-            finish((state["k"] + b) % n_buf)
+        if multi:
+            with torch.cuda.stream(post):
+                for b in range(n_buf):
+                    finish((state["k"] + b) % n_buf)
+            stream.wait_stream(post)
 
     for _ in range(args.warmup):
         step()
@@ -276,6 +289,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issue = time.perf_counter() - t0   # host time to ENQUEUE the steps (the GPU may still be busy)
     drain()                          # every step's exchange and arg-max complete inside the timed region
     torch.cuda.synchronize()
     if multi:
@@ -317,6 +331,7 @@ def main():
             "metric": "pose hypotheses/sec LCP-scored (50k-pt scene x 5k-pt model)",
             "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "host_issue_ms_per_step": t_issue / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 (BASELINE.json configs[1]): 1 object, 5000-pt model vs "
