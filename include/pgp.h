@@ -199,6 +199,19 @@ int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const fl
 int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, int n, float radius,
                               int min_neighbors, unsigned char* keep, float* nrm_out, int* n_kept);
 
+/* Depth image -> camera-frame cloud in front of the segment (PPE/misc/utilities.cpp:47-61 decode,
+ * PPE/segmentation/Segmentation.cpp:219 mask, utilities.cpp:190-206 / 210-231 back-projection).
+ * image: rows x cols, either the raw 16-bit PNG samples (raw16 != 0: rotated right by 3 and divided
+ * by 10000 as the reference does) or depth in metres as float (raw16 == 0); mask (nullable, rows x
+ * cols bytes): a pixel with mask == 0 is dropped; K: 3x3 row-major intrinsics.  Pixels with
+ * z_min < depth < z_max (0.1, 2.0 in the reference) are emitted IN ROW-MAJOR ORDER as
+ * x = (v - cx) * depth / fx, y = (u - cy) * depth / fy, z = depth, float operations in that order:
+ * the reference's list, bit for bit.  xyz_out receives min(*n_out, cap) points; *n_out the full
+ * count.  Host pointers, synchronous. */
+int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsigned char* mask, int rows,
+                          int cols, const float K[9], double z_min, double z_max, float* xyz_out, int cap,
+                          int* n_out);
+
 /* Replaces UCTState::computeCost (PPE/hypothesis_verification/mcts/UCTState.cpp:93-116) for n
  * rendered depth images against one observed image (all rows x cols float, row-major, metres):
  * render_score[i] = obScore + renScore - intScore with the pixel tests of the reference and

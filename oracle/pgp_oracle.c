@@ -1028,6 +1028,32 @@ int orc_greedy_cluster(const float* T, const float* scores, int n, float best_sc
   return n_rep;
 }
 
+int orc_backproject(const void* image, int raw16, const unsigned char* mask, int rows, int cols,
+                    const float K[9], double z_min, double z_max, float* xyz_out) {
+  const float fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+  int n = 0;
+  for (int u = 0; u < rows; ++u)
+    for (int v = 0; v < cols; ++v) {
+      const size_t i = (size_t)u * cols + v;
+      float depth;
+      if (raw16) {
+        unsigned short s = ((const unsigned short*)image)[i];
+        s = (unsigned short)(s << 13 | s >> 3);       /* utilities.cpp:57 */
+        depth = (float)s / 10000;                      /* :59 */
+      } else {
+        depth = ((const float*)image)[i];
+      }
+      if (mask && mask[i] == 0) depth = 0.f;           /* Segmentation.cpp:219 depthImage.mul(objMask) */
+      if (depth > z_min && depth < z_max) {            /* utilities.cpp:197: double comparison */
+        xyz_out[3 * (size_t)n] = (float)((v - cx) * depth / fx);
+        xyz_out[3 * (size_t)n + 1] = (float)((u - cy) * depth / fy);
+        xyz_out[3 * (size_t)n + 2] = depth;
+        ++n;
+      }
+    }
+  return n;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

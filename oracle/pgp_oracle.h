@@ -144,6 +144,12 @@ void orc_pose_error(const float test[16], const float gt[16], const float sym[3]
 int orc_greedy_cluster(const float* T, const float* scores, int n, float best_score, float accept_fraction,
                        const float sym[3], float rot_thresh, float trans_thresh, int* rep_out, int* assign);
 
+/* Depth image -> cloud (PPE/misc/utilities.cpp:47-61 decode, Segmentation.cpp:219 mask,
+ * utilities.cpp:190-206 back-projection), scan order.  image: raw 16-bit samples (raw16) or float
+ * metres; mask nullable; K row-major 3x3.  Returns the number of points written (<= rows*cols). */
+int orc_backproject(const void* image, int raw16, const unsigned char* mask, int rows, int cols,
+                    const float K[9], double z_min, double z_max, float* xyz_out);
+
 int orc_max_threads(void);
 
 #ifdef __cplusplus

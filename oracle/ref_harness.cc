@@ -565,4 +565,40 @@ int ref_greedy_cluster(const float* T, const float* scores, int n, float best_sc
   return (int)clustered.size();
 }
 
+// ---- depth image -> cloud ------------------------------------------------------
+// utilities.cpp is unbuildable here (OpenCV/PCL/ROS through common_io.h); the two loop bodies are
+// restated with the reference's types (unsigned short sample, Eigen::Matrix3f intrinsics).
+
+// misc/utilities.cpp:47-61 (readDepthImage), per sample
+void ref_decode_depth(const unsigned short* raw, int n, float* out) {
+  for (int i = 0; i < n; ++i) {
+    unsigned short depthShort = raw[i];
+    depthShort = (depthShort << 13 | depthShort >> 3);
+    float depth = (float)depthShort / 10000;
+    out[i] = depth;
+  }
+}
+
+// misc/utilities.cpp:190-206 (convert3dUnOrganized) on objDepth = depth .* mask (Segmentation.cpp:219)
+int ref_backproject(const float* depth_img, const unsigned char* mask, int rows, int cols, const float* K9,
+                    float* xyz_out) {
+  Eigen::Matrix3f camIntrinsic;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) camIntrinsic(r, c) = K9[3 * r + c];
+  int imgWidth = cols;
+  int imgHeight = rows;
+  int n = 0;
+  for (int u = 0; u < imgHeight; u++)
+    for (int v = 0; v < imgWidth; v++) {
+      float depth = depth_img[(size_t)u * cols + v] * (mask ? (mask[(size_t)u * cols + v] ? 1.f : 0.f) : 1.f);
+      if (depth > 0.1 && depth < 2.0) {
+        xyz_out[3 * n] = (float)((v - camIntrinsic(0, 2)) * depth / camIntrinsic(0, 0));
+        xyz_out[3 * n + 1] = (float)((u - camIntrinsic(1, 2)) * depth / camIntrinsic(1, 1));
+        xyz_out[3 * n + 2] = depth;
+        ++n;
+      }
+    }
+  return n;
+}
+
 }  // extern "C"

@@ -63,6 +63,8 @@ SIGNATURES = {
                                         C.c_int, C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_radius_outlier_filter": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, C.c_int,
                                             C.POINTER(C.c_ubyte), _f, _i]),
+    "pgp_backproject_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f,
+                                        C.c_double, C.c_double, _f, C.c_int, _i]),
     "pgp_depth_cost": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_int, C.c_int, C.c_float, _f, _i]),
     "pgp_cluster_poses": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, _f, C.POINTER(ClusterParams), _i,
                                     C.c_int, _i, _i]),

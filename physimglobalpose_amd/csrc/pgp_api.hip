@@ -148,7 +148,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
@@ -609,6 +609,48 @@ int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, 
     }
   }
   *n_kept = kept;
+  return PGP_OK;
+}
+
+int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsigned char* mask, int rows,
+                          int cols, const float K[9], double z_min, double z_max, float* xyz_out, int cap,
+                          int* n_out) {
+  if (!ctx || rows < 0 || cols < 0 || cap < 0 || !K || !n_out || (cap > 0 && !xyz_out) ||
+      ((size_t)rows * cols > 0 && !image) || (size_t)rows * cols > ((size_t)1 << 30)) {
+    set_error("pgp_backproject_depth: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_out = 0;
+  const size_t n = (size_t)rows * cols;
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t img_bytes = (n * (raw16 ? 2 : 4) + 255) & ~(size_t)255;
+  const size_t mask_bytes = (n + 255) & ~(size_t)255;
+  const size_t nb = (n + 255) / 256;
+  const size_t ctr_bytes = ((nb + 1) * 4 + 255) & ~(size_t)255;
+  const size_t scan_bytes = ((nb / 2048 + 4) * 4 + 255) & ~(size_t)255;
+  const size_t xyz_bytes = (size_t)cap * 12;
+  int rc = ctx->d_bp.ensure(img_bytes + mask_bytes + ctr_bytes + scan_bytes + xyz_bytes + 256);
+  if (rc != PGP_OK) return rc;
+  unsigned char* base = ctx->d_bp.as<unsigned char>();
+  void* d_img = base;
+  unsigned char* d_mask = mask ? base + img_bytes : nullptr;
+  uint32_t* d_ctr = reinterpret_cast<uint32_t*>(base + img_bytes + mask_bytes);
+  uint32_t* d_scan = reinterpret_cast<uint32_t*>(base + img_bytes + mask_bytes + ctr_bytes);
+  float* d_xyz = reinterpret_cast<float*>(base + img_bytes + mask_bytes + ctr_bytes + scan_bytes);
+  PGP_HIP(hipMemcpyAsync(d_img, image, n * (raw16 ? 2 : 4), hipMemcpyHostToDevice, st));
+  if (mask) PGP_HIP(hipMemcpyAsync(d_mask, mask, n, hipMemcpyHostToDevice, st));
+  int total = 0;
+  rc = launch_backproject(ctx, d_img, raw16 != 0, d_mask, rows, cols, K, z_min, z_max, d_ctr, d_scan, d_xyz, cap,
+                          &total, st);
+  if (rc != PGP_OK) return rc;
+  *n_out = total;
+  const int n_copy = total < cap ? total : cap;
+  if (n_copy > 0) {
+    PGP_HIP(hipMemcpyAsync(xyz_out, d_xyz, (size_t)n_copy * 12, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+  }
   return PGP_OK;
 }
 

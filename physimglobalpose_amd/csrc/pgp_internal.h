@@ -86,6 +86,7 @@ struct pgp_ctx {
   pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
 
   pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
+  pgp::DevBuf d_bp;      // back-projection staging: image | mask | counters | scan scratch | xyz
   pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
 
   // ICP (host API staging + per-pose correspondence workspace)
@@ -161,6 +162,11 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
 
 int launch_pose_error(pgp_ctx* ctx, const float* d_test, const float* d_gt, int n, const float sym[3],
                       float* d_rot, float* d_trans, hipStream_t st);
+
+// backproject.hip
+int launch_backproject(pgp_ctx* ctx, const void* d_img, bool raw16, const unsigned char* d_mask, int rows,
+                       int cols, const float K[9], double z_min, double z_max, uint32_t* d_ctr,
+                       uint32_t* d_scan_tmp, float* d_xyz, int cap, int* n_host, hipStream_t st);
 
 // rigid_fit.hip
 int launch_rigid(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n, const float cP[3],

@@ -167,6 +167,22 @@ class LcpScorer:
         return keep[:n].astype(bool), (nout[:n] if nout is not None else None)
 
     # ---- MCTS leaf cost (UCTState::computeCost) ---------------------------------------------------------
+    def backproject_depth(self, image, K, mask=None, z_min=0.1, z_max=2.0):
+        """image (rows, cols): uint16 raw PNG samples or float32 metres; K 3x3; mask (rows, cols) or None
+        -> (n, 3) float32 camera-frame cloud in the reference's scan order."""
+        image = np.ascontiguousarray(image)
+        assert image.dtype in (np.uint16, np.float32) and image.ndim == 2
+        rows, cols = image.shape
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        out = np.zeros((max(rows * cols, 1), 3), np.float32)
+        n = C.c_int(0)
+        _lib.check(self._lib.pgp_backproject_depth(
+            self._h, image.ctypes.data_as(C.c_void_p), int(image.dtype == np.uint16),
+            None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)), rows, cols, _fp(K9),
+            C.c_double(z_min), C.c_double(z_max), _fp(out), rows * cols, C.byref(n)))
+        return out[: n.value].copy()
+
     def depth_cost(self, observed, rendered, threshold=0.01):
         """observed (rows,cols) f32, rendered (n,rows,cols) f32 -> (render_score (n,), counts (n,3))."""
         obs = np.ascontiguousarray(observed, np.float32)

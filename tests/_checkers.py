@@ -79,6 +79,8 @@ def oracle_lib():
         L.orc_icp.argtypes = [_f, C.c_int, _f, C.c_int, _f, C.c_int, C.c_float, C.c_float, C.c_float, _f]
         L.orc_pose_error.argtypes = [_f, _f, _f, _f, _f]
         L.orc_greedy_cluster.argtypes = [_f, _f, C.c_int, C.c_float, C.c_float, _f, C.c_float, C.c_float, _i, _i]
+        L.orc_backproject.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f, C.c_double,
+                                      C.c_double, _f]
         _oracle = L
     return _oracle
 
@@ -261,6 +263,37 @@ def ref_greedy_cluster(T, scores, best_score, sym=(0, 0, 0)):
     return rep[:k].copy()
 
 
+def _bp_args(image, mask, K):
+    image = np.ascontiguousarray(image)
+    assert image.dtype in (np.uint16, np.float32) and image.ndim == 2
+    m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+    return image, m, _f32(K).reshape(9)
+
+
+def oracle_backproject(image, mask, K, z_min=0.1, z_max=2.0):
+    """orc_backproject: image (rows, cols) uint16 raw samples or float32 metres -> (n, 3) cloud."""
+    image, m, K9 = _bp_args(image, mask, K)
+    rows, cols = image.shape
+    out = np.zeros((max(rows * cols, 1), 3), np.float32)
+    n = oracle_lib().orc_backproject(image.ctypes.data_as(C.c_void_p), int(image.dtype == np.uint16),
+                                     None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)), rows, cols,
+                                     _fp(K9), C.c_double(z_min), C.c_double(z_max), _fp(out))
+    return out[:n].copy()
+
+
+def ref_backproject(raw16, mask, K):
+    """The Eigen-typed harness restatement: decode (utilities.cpp:47-61) + back-project (:190-206)."""
+    raw16, m, K9 = _bp_args(raw16, mask, K)
+    rows, cols = raw16.shape
+    L = ref_lib()
+    depth = np.zeros(rows * cols, np.float32)
+    L.ref_decode_depth(raw16.ctypes.data_as(C.POINTER(C.c_ushort)), rows * cols, _fp(depth))
+    out = np.zeros((max(rows * cols, 1), 3), np.float32)
+    n = L.ref_backproject(_fp(depth), None if m is None else m.ctypes.data_as(C.POINTER(C.c_ubyte)), rows, cols,
+                          _fp(K9), _fp(out))
+    return depth.reshape(rows, cols), out[:n].copy()
+
+
 def have_ref():
     return os.path.exists(REF_SO)
 
@@ -298,6 +331,8 @@ def ref_lib():
                                             _i, C.c_int, _i, C.c_int]
         L.ref_pose_error.argtypes = [_f, _f, _f, _f, _f]
         L.ref_greedy_cluster.argtypes = [_f, _f, C.c_int, C.c_float, _f, _i]
+        L.ref_decode_depth.argtypes = [C.POINTER(C.c_ushort), C.c_int, _f]
+        L.ref_backproject.argtypes = [_f, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f, _f]
         _ref = L
     return _ref
 

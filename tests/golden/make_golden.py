@@ -177,6 +177,7 @@ def main():
     print("rigid_fit:", np.bincount(status, minlength=3), f"{os.path.getsize(path)/1024:.0f} KiB")
     congruent_cases()
     cluster_cases()
+    backproject_case()
     weights_case()
     test_scene_case()
 
@@ -234,6 +235,39 @@ def test_scene_case():
     path = os.path.join(HERE, "test_scene_segments.npz")
     np.savez_compressed(path, **out)
     print("test_scene_segments:", f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+def backproject_case():
+    """(12) depth decode + back-projection (utilities.cpp:47-61, 190-206) of a window of the reference's
+    test-scene/ frame through the Eigen-typed harness: raw 16-bit samples, class mask, shifted
+    intrinsics in; per class the decoded depth and the cloud, in the reference's scan order, out."""
+    from PIL import Image
+    from _checkers import ref_backproject
+    d = "/root/reference/test-scene/"
+    raw = np.array(Image.open(d + "frame-000000.depth.png")).astype(np.uint16)
+    mask = np.array(Image.open(d + "frame-000000.mask.png"))
+    if mask.ndim == 3:
+        mask = mask[..., 0]
+    vs, us = np.nonzero(mask == 8)
+    yc, xc = int(np.median(vs)), int(np.median(us))
+    y0, y1, x0, x1 = yc - 80, yc + 80, xc - 100, xc + 100     # 160 x 200 window on the largest object
+    raw, mask = np.ascontiguousarray(raw[y0:y1, x0:x1]), np.ascontiguousarray(mask[y0:y1, x0:x1])
+    K = np.array([[6.13998108e+02, 0, 3.22453583e+02 - x0], [0, 6.13998169e+02, 2.39678940e+02 - y0], [0, 0, 1]], np.float32)
+    out = {"raw": raw, "mask": mask.astype(np.uint8), "K": K}
+
+    def digest(a):   # the expected outputs are kept as count + SHA-256 of the float32 bytes + a sample
+        import hashlib
+        return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).digest(), np.uint8)
+
+    depth, cloud = ref_backproject(raw, None, K)
+    out["depth_sha"], out["all_n"], out["all_sha"], out["all_sample"] = digest(depth), len(cloud), digest(cloud), cloud[::97]
+    for cls in [c for c in np.unique(mask) if c != 0]:
+        _, cloud = ref_backproject(raw, (mask == cls).astype(np.uint8), K)
+        out[f"n_{cls}"], out[f"sha_{cls}"], out[f"sample_{cls}"] = len(cloud), digest(cloud), cloud[::97]
+        print(f"backproject class {cls}: {len(cloud)} points")
+    path = os.path.join(HERE, "backproject.npz")
+    np.savez_compressed(path, **out)
+    print("backproject:", raw.shape, out["all_n"], f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def congruent_cases():
@@ -310,6 +344,9 @@ def cluster_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "backproject":
+        backproject_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "cluster":
         cluster_cases()
         sys.exit(0)
