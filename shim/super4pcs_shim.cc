@@ -515,12 +515,18 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
     pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, m.prob.data());
   }
 
+  const auto t_start = std::chrono::steady_clock::now();
+  auto ms_since = [](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
   // ---- device state: scene index, validation model, search model
   SHIM_PGP(pgp_create(&ctx, -1));
   SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), m.prob.data(), seg.n, delta));
   SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
   SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
 
+  const double ms_setup = ms_since(t_start);
+  const auto t_bases = std::chrono::steady_clock::now();
   // ---- Step 1: base selection (base.cc:1831-1848)
   unsigned seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
   if (const char* s = getenv("PGP_SHIM_SEED")) { seed = (unsigned)strtoul(s, nullptr, 10); srand(seed); }
@@ -532,6 +538,8 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
     if (m.SelectQuadrilateralStoCS(generator, b.ids, b.inv1, b.inv2)) bases.push_back(b);
   }
 
+  const double ms_bases = ms_since(t_bases);
+  const auto t_cs = std::chrono::steady_clock::now();
   // ---- Step 2: congruent sets (base.cc:1855-1874, 1929-1993) -> (base, quad) pairs
   std::vector<int> base_ids, quad_ids;  // n x 4 each
   std::vector<int> quads;
@@ -573,6 +581,8 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
       }
     }
   }
+  const double ms_cs = ms_since(t_cs);
+  const auto t_fit = std::chrono::steady_clock::now();
   const int n_pairs = (int)(base_ids.size() / 4);
   std::vector<float> T((size_t)n_pairs * 16);
   std::vector<double> pose((size_t)n_pairs * 16);
@@ -593,9 +603,11 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
 
   // ---- Step 3: verification (base.cc:1885-1901), operMode = 1 -> WeightedVerify
   const int n_h = (int)allPose.size();
+  const double ms_fit = ms_since(t_fit);
   if (getenv("PGP_SHIM_VERBOSE"))
     std::cerr << "[libsuper4pcs shim] bases " << bases.size() << ", congruent pairs " << n_pairs
-              << ", transforms " << n_h << std::endl;
+              << ", transforms " << n_h << "; ms: setup " << ms_setup << ", base selection " << ms_bases
+              << ", congruent sets " << ms_cs << ", rigid fits " << ms_fit << std::endl;
   std::vector<float> lcp(n_h);
   int best = -1;
   float best_lcp = 0.f;
