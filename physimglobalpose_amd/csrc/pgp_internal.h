@@ -101,6 +101,11 @@ struct pgp_ctx {
   pgp::DevBuf d_best;     // 2 x uint64 packed argmax + {index, score bits}
   pgp::DevBuf d_hits;     // [nQ] int (pgp_registered)
 
+  // pinned host staging for the host-pointer scoring call (transforms in, scores | counts | best out)
+  void* h_pin = nullptr;
+  size_t h_pin_cap = 0;
+  pgp::DevBuf d_out;      // scores | counts | best of one host-pointer call, contiguous: ONE copy back
+
   // tuning knobs (env PGP_UNROLL / PGP_HPB at pgp_create; defaults chosen by measurement)
   int unroll = 0;      // <= 0: wave-flattened candidate phase (default); > 0: per-lane walk
   int hpb_override = 0;
