@@ -214,3 +214,41 @@ def test_large_and_odd_batch_sizes():
         sw, _, bi, _ = sc.score(w.T[:n], PGP_MODE_WEIGHTED, w.gate_deg)
         assert np.allclose(sw, swo[:n], rtol=0, atol=2e-6)
         assert bi == (int(np.argmax(sw)) if sw.max() > 0 else -1)
+
+
+def test_queries_around_the_grid_boundary():
+    """The cell lookup clamps instead of testing validity: queries just inside, on and far outside
+    the padded grid (incl. the scene's extreme points, NaN and huge coordinates) must count exactly
+    as the oracle does."""
+    rng = np.random.default_rng(123)
+    delta = np.float32(0.01)
+    # scene: the six faces of a box, so that extreme points sit on every side of the bounding box
+    n = 3000
+    P = rng.uniform(-0.2, 0.2, (n, 3)).astype(np.float32)
+    face = rng.integers(0, 6, n)
+    P[np.arange(n), face % 3] = np.where(face < 3, -0.2, 0.2).astype(np.float32)
+    Pn = np.zeros_like(P)
+    Pn[np.arange(n), face % 3] = np.where(face < 3, -1, 1)
+    Pw = rng.random(n).astype(np.float32)
+    # model: scene points displaced by up to 3 delta along each axis (in / on / outside the reach)
+    Q = (P[rng.choice(n, 700, replace=False)] + rng.uniform(-3, 3, (700, 3)).astype(np.float32) * delta).astype(np.float32)
+    Qn = np.tile(np.array([0, 0, 1], np.float32), (700, 1))
+    Ts = []
+    for k in range(40):
+        T = np.eye(4)
+        T[:3, 3] = rng.choice([-1, 0, 1], 3) * rng.choice([0.0, 0.5, 1.0, 1.02, 2.0, 40.0]) * float(delta)
+        Ts.append(synth.colmajor16(T))
+    T = np.eye(4); T[:3, 3] = 1e30; Ts.append(synth.colmajor16(T))
+    T = np.eye(4); T[0, 3] = np.nan; Ts.append(synth.colmajor16(T))
+    T = np.eye(4); T[1, 1] = np.inf; Ts.append(synth.colmajor16(T))
+    Ts = np.stack(Ts).astype(np.float32)
+    sc = LcpScorer()
+    sc.init(P, Pn, Pw, Q, Qn, float(delta))
+    orc = Oracle(P, Pn, Pw, Q, Qn, use_kd=False)
+    s, c, bi, _ = sc.score(Ts)
+    so, bio, _ = orc.score_batch(Ts, float(delta), mode=0)
+    assert np.array_equal(s, so) and bi == bio
+    sw = sc.score(Ts, PGP_MODE_WEIGHTED, 30.0)[0]
+    swo, _, _ = orc.score_batch(Ts, float(delta), mode=1, gate_deg=30.0)
+    assert np.allclose(sw, swo, rtol=0, atol=2e-6)
+    assert s[-3:].max() == 0 and sw[-3:].max() == 0
