@@ -29,3 +29,26 @@ for mode, name in ((PGP_MODE_PLAIN, "plain"), (PGP_MODE_WEIGHTED, "weighted")):
         torch.cuda.synchronize()
         best.append((time.perf_counter() - t0) / 200 * 1e6)
     print(f"{name}: step {min(best):.1f} us (min of 5 x 200), best index {int(db[0])}")
+
+# the same steps replayed from a HIP graph (one captured scoring call per replay)
+for mode, name in ((PGP_MODE_PLAIN, "plain"), (PGP_MODE_WEIGHTED, "weighted")):
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        sc.score_device(dT, ds, dc, db, mode=mode, stream=side)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=side):
+            sc.score_device(dT, ds, dc, db, mode=mode, stream=side)
+    torch.cuda.current_stream().wait_stream(side)
+    best = []
+    for rep in range(5):
+        for _ in range(20):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            g.replay()
+        torch.cuda.synchronize()
+        best.append((time.perf_counter() - t0) / 200 * 1e6)
+    print(f"{name}: graph replay step {min(best):.1f} us (min of 5 x 200), best index {int(db[0])}")
