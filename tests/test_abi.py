@@ -95,3 +95,33 @@ def test_bad_arguments_are_rejected():
     assert lib.pgp_create(None, 0) == -1
     assert lib.pgp_running_best(None, 3, None, None) == -1
     assert lib.pgp_set_scene(None, None, None, None, 0, C.c_float(0.005)) == -1
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/pgp.h must be usable from C (the boundary is a C ABI): compile a C99 and a C++11
+    translation unit that include it, and link a C program against libpgp.so that takes the address
+    of every declared entry point (no GPU call is made)."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    names = _declared()
+    src = tmp_path / "use_pgp.c"
+    src.write_text('#include "pgp.h"\n#include <stdio.h>\ntypedef void (*fn)(void);\nint main(void) {\n  fn f[] = {\n'
+                   + "".join(f"    (fn)&{n},\n" for n in names)
+                   + "  };\n  printf(\"%d %d\\n\", (int)(sizeof f / sizeof f[0]), pgp_version());\n  return 0;\n}\n")
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.join(ROOT, "physimglobalpose_amd")
+    exe = tmp_path / "use_pgp"
+    r = subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", inc, str(src), "-o", str(exe),
+                        "-L", libdir, "-lpgp", f"-Wl,-rpath,{libdir}", "-Wl,-rpath-link,/opt/rocm/lib"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    cpp = tmp_path / "use_pgp.cc"
+    cpp.write_text('#include "pgp.h"\nint f() { return pgp_version(); }\n')
+    r = subprocess.run(["g++", "-std=c++11", "-pedantic", "-Wall", "-Werror", "-I", inc, "-c", str(cpp), "-o",
+                        str(tmp_path / "use_pgp.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([str(exe)], capture_output=True, text=True, env=dict(os.environ, LD_LIBRARY_PATH="/opt/rocm/lib"))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] == str(len(names))
