@@ -290,9 +290,16 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   if ((rc = ctx->d_scan_tmp.ensure((size_t)n_tiles * 4 + 4)) != PGP_OK) return rc;
   if ((rc = ctx->d_bitmap.ensure(n_words * 8)) != PGP_OK) return rc;
 
-  hipEvent_t e0, e1;
-  PGP_HIP(hipEventCreate(&e0));
-  PGP_HIP(hipEventCreate(&e1));
+  struct EventPair {  // destroyed on every return path
+    hipEvent_t a = nullptr, b = nullptr;
+    ~EventPair() {
+      if (a) (void)hipEventDestroy(a);
+      if (b) (void)hipEventDestroy(b);
+    }
+  } ev;
+  PGP_HIP(hipEventCreate(&ev.a));
+  PGP_HIP(hipEventCreate(&ev.b));
+  const hipEvent_t e0 = ev.a, e1 = ev.b;
   PGP_HIP(hipEventRecord(e0, st));
 
   uint32_t* ctr = ctx->d_cell_tmp.as<uint32_t>();
@@ -328,8 +335,6 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   PGP_HIP(hipStreamSynchronize(st));
   ctx->n_occ = (long long)n_occ;
   PGP_HIP(hipEventElapsedTime(&ctx->build_ms, e0, e1));
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
 
   ctx->grid = g;
   ctx->n_cells = (long long)n_cells;

@@ -513,13 +513,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.energy = d_energy;
   a.iters = d_iters;
   const size_t lds = (size_t)kTgtTile * sizeof(float4);
-  static bool attr_set = false;
-  if (!attr_set) {
+  if (!ctx->icp_attr_set) {  // per context = per device (function attributes are per device)
     PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+    ctx->icp_attr_set = true;
   }
   if (!split) {
     hipLaunchKernelGGL(icp_refine<false>, dim3(n), dim3(kIcpThreads), lds, stream, a);

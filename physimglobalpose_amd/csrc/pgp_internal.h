@@ -91,6 +91,7 @@ struct pgp_ctx {
 
   // ICP (host API staging + per-pose correspondence workspace)
   pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_T, d_icp_out, d_icp_ws;
+  bool icp_attr_set = false;   // dynamic-LDS limit of the ICP kernels raised on this device
 
   // scoring workspace
   int cap_h = 0;
