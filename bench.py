@@ -130,6 +130,21 @@ def other_rows(sc, w, torch):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps, r
 
+    # the live mode of the reference (operMode 1 -> WeightedVerify): same batch, same clouds
+    dT = torch.from_numpy(w.T[:N_HYP]).cuda()
+    ds = torch.zeros(N_HYP, device="cuda")
+    dc = torch.zeros(N_HYP, dtype=torch.int32, device="cuda")
+    db = torch.zeros(2, dtype=torch.int32, device="cuda")
+    for _ in range(20):
+        sc.score_device(dT, ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(200):
+        sc.score_device(dT, ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+    torch.cuda.synchronize()
+    dtw = (time.perf_counter() - t0) / 200
+    out["weighted_lcp"] = {"hypotheses_per_s": N_HYP / dtw, "ms_per_step": dtw * 1e3, "gate_deg": float(w.gate_deg),
+                           "algorithmic_bytes_per_hypothesis": algorithmic_bytes_per_hypothesis(N_SCENE, N_MODEL, "weighted")}
     # ICP: 64 poses, 2500-pt segment vs 5000-pt model, 10 iterations each (trim 0.9)
     seg = w.Q_xyz[rng.choice(len(w.Q_xyz), 2500, replace=False)]
     R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8)
