@@ -32,6 +32,7 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 
 N_SCENE, N_MODEL, N_HYP = 50000, 5000, 4096   # BASELINE.json configs[1] (C2)
 TIMING_STRIDE = 8   # every 8th launch of the timed region carries HIP events
+BUCKET = 8          # steps whose score vectors share one all-reduce (N > 1)
 
 
 def algorithmic_bytes_per_hypothesis(n_scene, n_model, mode):
@@ -239,56 +240,70 @@ def main():
     sc.reserve(n_h)
     T_all = torch.from_numpy(w.T).to(dev)
     d_T = T_all[rank * n_h:(rank + 1) * n_h].contiguous()
-    # two score vectors: the all-reduce of step k (RCCL's own stream) overlaps the scoring kernel
-    # of step k+1 (this stream); a buffer is reused only after its collective and arg-max are done
+    # Bucketed exchange: the score vectors of BUCKET consecutive steps share one all-reduce (one
+    # collective launch costs the scoring stream ~11 us -- tools/dist_overhead.py -- which is 12 % of
+    # a 95 us step; per-step messages are 4 B x world x n_h, far below the bandwidth regime).  Two
+    # buckets alternate: the collective of one runs on RCCL's stream while the scoring kernels
+    # fill the other.  Each step's vector is still all-reduced in full and arg-maxed locally.
     n_buf = 2 if multi else 1
-    bufs = [torch.zeros(world * n_h, dtype=torch.float32, device=dev) for _ in range(n_buf)]
+    n_slot = BUCKET if multi else 1
+    bufs = [torch.zeros(n_slot, world * n_h, dtype=torch.float32, device=dev) for _ in range(n_buf)]
     works = [None] * n_buf
-    d_scores_all = bufs[0]
+    d_scores_all = bufs[0][0]
     d_scores = d_scores_all[rank * n_h:(rank + 1) * n_h]
     d_counts = torch.zeros(n_h, dtype=torch.int32, device=dev)
     d_best = torch.zeros(2, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    state = {"k": 0, "argmax": None}
+    state = {"k": 0, "argmax": None, "open": None}
 
-    # The exchange's tail (wait for the collective, arg-max, re-zeroing the vector) runs on its own
+    # The exchange's tail (wait for the collective, arg-max, re-zeroing the bucket) runs on its own
     # stream, beside the next steps' scoring kernels: the main stream carries scoring only and
-    # waits, per step, on an event recorded two steps earlier.
+    # waits, once per bucket, on an event recorded a bucket earlier.
     post = torch.cuda.Stream(dev) if multi else None
-
     ready = [torch.cuda.Event() for _ in range(n_buf)] if multi else []
 
     def finish(b):
-        """Complete the exchange that was started on buffer b (call with `post` current): every rank
-        then holds all scores (north_star: "RCCL all-reduce over xGMI of the per-hypothesis LCP
-        scores") and takes the arg-max locally."""
+        """Complete the exchange that was started on bucket b (call with `post` current): every rank
+        then holds all scores of the bucket's steps (north_star: "RCCL all-reduce over xGMI of the
+        per-hypothesis LCP scores") and takes each step's arg-max locally."""
         if works[b] is not None:
             works[b].wait()          # stream-level wait under nccl; host wait under gloo
             works[b] = None
-            state["argmax"] = torch.argmax(bufs[b])
+            state["argmax"] = torch.argmax(bufs[b], dim=1)
+
+    def exchange(b):
+        works[b] = dist.all_reduce(bufs[b], op=dist.ReduceOp.SUM, async_op=True)
+        state["open"] = None
 
     def step():
         if not multi:
             sc.score_device(d_T, d_scores, d_counts, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
             return
-        b = state["k"] % n_buf
+        k = state["k"]
         state["k"] += 1
-        buf = bufs[b]
-        with torch.cuda.stream(post):
-            finish(b)
-            buf.zero_()              # every rank fills only its slice of a zeroed vector: sum == gather
-            ready[b].record(post)
-        stream.wait_event(ready[b])
-        sc.score_device(d_T, buf[rank * n_h:(rank + 1) * n_h], d_counts, d_best, mode=mode,
+        b, j = (k // BUCKET) % n_buf, k % BUCKET
+        if j == 0:                   # a new bucket: its previous contents must be consumed and cleared
+            with torch.cuda.stream(post):
+                finish(b)
+                bufs[b].zero_()      # every rank fills only its slice of a zeroed vector: sum == gather
+                ready[b].record(post)
+            stream.wait_event(ready[b])
+            state["open"] = b
+        sc.score_device(d_T, bufs[b][j, rank * n_h:(rank + 1) * n_h], d_counts, d_best, mode=mode,
                         gate_deg=w.gate_deg, stream=stream)
-        works[b] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        state["last"] = (b, j)
+        if j == BUCKET - 1:
+            exchange(b)
 
     def drain():
         if multi:
+            if state["open"] is not None:        # a partly filled bucket: exchange what it holds
+                exchange(state["open"])
             with torch.cuda.stream(post):
                 for b in range(n_buf):
-                    finish((state["k"] + b) % n_buf)
+                    finish(b)
             stream.wait_stream(post)
+            state["k"] = 0                       # the next step starts a fresh bucket
 
     for _ in range(args.warmup):
         step()
@@ -321,13 +336,13 @@ def main():
     # sanity inside the bench: the device result of the last step matches a host-pointer call
     best = d_best.cpu().numpy()
     s_host, _, bi_host, _ = sc.score(w.T[rank * n_h:(rank + 1) * n_h], mode, w.gate_deg)
-    last = bufs[(state["k"] - 1) % n_buf] if multi else d_scores_all
+    last = bufs[state["last"][0]][state["last"][1]] if multi else d_scores_all
     assert np.array_equal(s_host, last[rank * n_h:(rank + 1) * n_h].cpu().numpy()) and bi_host == int(best[0])
     if multi:
         # the combined vector of the last step: every slice present, arg-max = the global best
         s_all = last.cpu().numpy()
         assert (s_all.reshape(world, n_h).max(axis=1) > 0).all()
-        assert int(state["argmax"]) == int(np.argmax(s_all))
+        assert int(torch.argmax(last)) == int(np.argmax(s_all))
 
     if rank == 0:
         total_h = n_h * world * args.steps
@@ -353,7 +368,9 @@ def main():
                                    "50000-pt synthetic scene, 4096 hypotheses per GPU per step, "
                                    f"{args.mode} LCP, delta 5 mm",
                        "n_scene": N_SCENE, "n_model": N_MODEL, "hypotheses_per_gpu": n_h,
-                       "mode": args.mode, "sharding": f"hypotheses x{world}, clouds replicated"},
+                       "mode": args.mode, "sharding": f"hypotheses x{world}, clouds replicated",
+                       "exchange": (f"one all-reduce(SUM) per {BUCKET} steps (bucketed), overlapped with scoring"
+                                    if multi else "none (one rank)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": f"score_hypotheses<{args.mode}>", "launches": launches,
