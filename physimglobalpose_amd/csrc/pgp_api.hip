@@ -129,7 +129,8 @@ int pgp_create(pgp_ctx** out, int device_id) {
   int rc = ctx->d_best.ensure(32);
   if (rc == PGP_OK && hipMemset(ctx->d_best.p, 0, 32) != hipSuccess) rc = PGP_EHIP;  // key + ticket armed
   if (rc != PGP_OK) {
-    hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
+    ctx->d_best.release();
     delete ctx;
     return rc;
   }
