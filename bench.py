@@ -42,6 +42,23 @@ def algorithmic_bytes_per_hypothesis(n_scene, n_model, mode):
     return 24 * n_model + 28 * n_scene + 52
 
 
+def usable_cpus(n_threads_max):
+    """Threads worth starting: the CPUs this process may run on, capped by the cgroup CPU quota (the
+    GPU box shows 256 logical CPUs but grants a quota of 16 -- more threads than that only add
+    throttling) and by what the OpenMP runtime offers."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = f"{n} schedulable CPUs"
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            q = max(1, int(-(-int(quota) // int(period))))
+            if q < n:
+                n, note = q, f"cgroup CPU quota {q} of {n} logical CPUs"
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, n_threads_max)), note
+
+
 def cpu_baseline(w, mode, budget_s=8.0):
     """Time the CPU path on this box's cores.  The C restatement (oracle/pgp_oracle.c, OpenMP) is
     always there ("port"); where the prebuilt oracle/_ref/libpgp_ref.so travelled along, the harness
@@ -50,7 +67,7 @@ def cpu_baseline(w, mode, budget_s=8.0):
     ("reference") since it is the faster of the two."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from _checkers import Oracle, oracle_lib
-    cores = int(oracle_lib().orc_max_threads())
+    cores, cores_note = usable_cpus(int(oracle_lib().orc_max_threads()))
     orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
     m = 0 if mode == "plain" else 1
     # warm the thread pool up (the first parallel regions after an idle spell run far below
@@ -72,7 +89,7 @@ def cpu_baseline(w, mode, budget_s=8.0):
     port = {
         "value": n / dt, "unit": "hypotheses/s", "cores": cores, "kind": "port",
         "sample": f"{n} hypotheses of the same C2 batch (cycled), kd-tree oracle "
-                  f"(oracle/pgp_oracle.c, OpenMP x{cores}), {dt:.1f} s",
+                  f"(oracle/pgp_oracle.c, OpenMP x{cores}; {cores_note}), {dt:.1f} s",
         "one_thread_value": n1 / dt1,
     }
     if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libpgp_ref.so")):
@@ -107,7 +124,7 @@ def cpu_baseline(w, mode, budget_s=8.0):
     return {
         "value": per * cores / dtr, "unit": "hypotheses/s", "cores": cores, "kind": "reference",
         "sample": f"{per} hypotheses of the same C2 batch per thread x {cores} threads, one instance of the "
-                  f"reference kd-tree (oracle/_ref, kdtree.h + Eigen loop bodies) per thread, {dtr:.1f} s",
+                  f"reference kd-tree (oracle/_ref, kdtree.h + Eigen loop bodies) per thread; {cores_note}; {dtr:.1f} s",
         "one_thread_value": r1,
         "agrees_with_port": bool(np.array_equal(s_ref, s_port)),
         "port": port,
