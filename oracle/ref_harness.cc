@@ -15,6 +15,7 @@
 //     project rules forbid).  The loop bodies of those functions are therefore RESTATED below
 //     with the same Eigen types and the same expression shapes (so that Eigen's evaluation
 //     order, which fixes the float bits, is the reference's), each citing the lines it follows.
+//   * S4/io/io.cc DOES build unmodified (Eigen only): see oracle/ref_io_harness.cc, linked into the same .so;
 //   * parity status: NN query pinned against reference code run here; Verify/WeightedVerify/
 //     rigid-fit loop bodies are a restatement (the reference ships no golden vectors for them,
 //     SURVEY.md section 4).

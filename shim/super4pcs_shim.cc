@@ -419,6 +419,32 @@ void set_identity(std::pair<Eigen::Isometry3d, float>& h) {
 
 }  // namespace
 
+// What the reference's reader + CleanInvalidNormals leave in Point3D::normal(): unit normals
+// (Point3D::set_normal, shared4pcs.h:85-87), zero where the squared norm is < 0.01
+// (utils/geometry.h:57-84).
+static void clean_normals(std::vector<float>& n) {
+  for (size_t i = 0; i + 2 < n.size(); i += 3) {
+    Vec3 v(n[i], n[i + 1], n[i + 2]);
+    v = v.normalized();                            // set_normal() while reading
+    if (v.squaredNorm() < 0.01f) v.setZero();      // CleanInvalidNormals
+    n[i] = v(0); n[i + 1] = v(1); n[i + 2] = v(2);
+  }
+}
+
+// C-linkage probe for the tests: read one cloud the way the entry point does (reader + normal
+// cleaning) into caller arrays; returns the point count or -1.
+extern "C" int super4pcs_shim_read_cloud(const char* path, float* xyz, float* nrm, int cap) {
+  Cloud c;
+  if (!read_ply(path, c)) return -1;
+  clean_normals(c.nrm);
+  for (int i = 0; i < c.n && i < cap; ++i)
+    for (int k = 0; k < 3; ++k) {
+      xyz[3 * i + k] = c.xyz[3 * (size_t)i + k];
+      nrm[3 * i + k] = c.nrm[3 * (size_t)i + k];
+    }
+  return c.n;
+}
+
 bool super4pcs_shim_read_ply(const std::string& path, std::vector<float>& xyz, std::vector<float>& normals) {
   Cloud c;
   if (!read_ply(path, c)) return false;
@@ -482,16 +508,8 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   };
   Cloud seg = own(segment), qval = own(model_validation), qsearch = own(model_search);
   if (seg.n == 0 || qval.n == 0 || qsearch.n == 0) return;
-  auto unit = [](std::vector<float>& n) {  // Point3D::set_normal (shared4pcs.h:85-87)
-    for (size_t i = 0; i + 2 < n.size(); i += 3) {
-      Vec3 v(n[i], n[i + 1], n[i + 2]);
-      if (v.squaredNorm() < 0.01f) v.setZero();  // CleanInvalidNormals (utils/geometry.h:57-84)
-      else v = v.normalized();
-      n[i] = v(0); n[i + 1] = v(1); n[i + 2] = v(2);
-    }
-  };
-  unit(seg.nrm);
-  unit(qval.nrm);
+  clean_normals(seg.nrm);
+  clean_normals(qval.nrm);
 
   // ---- init(): centring (base.cc:242-268)
   float cP[3], cQ[3];

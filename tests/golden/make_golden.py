@@ -178,6 +178,7 @@ def main():
     congruent_cases()
     cluster_cases()
     backproject_case()
+    ply_reader_case()
     weights_case()
     test_scene_case()
 
@@ -270,6 +271,31 @@ def backproject_case():
     print("backproject:", raw.shape, out["all_n"], f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
+def ply_reader_case():
+    """(13) the file hand-off: PLY files in pcl::io::savePLYFile's PointXYZRGBNormal layout (written by
+    tests/test_ply_reader.py's writer) and what the REFERENCE'S OWN reader returns for them
+    (S4/io/io.cc + Utils::CleanInvalidNormals, compiled unmodified into oracle/_ref)."""
+    import ctypes as C
+    import tempfile
+    from test_ply_reader import ascii_ply, tricky_cloud, read_with
+    L = ref_lib()
+    L.ref_read_cloud.argtypes = [C.c_char_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int]
+    rng = np.random.default_rng(20261013)
+    out = {"n_files": 3}
+    with tempfile.TemporaryDirectory() as d:
+        for k, n in enumerate((6, 40, 300)):
+            xyz, nrm = tricky_cloud(rng, n)
+            blob = ascii_ply(xyz, nrm)
+            p = os.path.join(d, f"c{k}.ply")
+            with open(p, "wb") as f:
+                f.write(blob)
+            x, nn = read_with(L.ref_read_cloud, p)
+            out[f"ply_{k}"], out[f"xyz_{k}"], out[f"nrm_{k}"] = np.frombuffer(blob, np.uint8), x, nn
+    path = os.path.join(HERE, "ply_reader.npz")
+    np.savez_compressed(path, **out)
+    print("ply_reader:", f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
 def congruent_cases():
     """(8) congruent-set extraction on the reference's own PairCreationFunctor / IntersectionFunctor /
     IndexedNormalSet: pair lists (as sets) and congruent quads (in the reference's order)."""
@@ -344,6 +370,9 @@ def cluster_cases():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ply":
+        ply_reader_case()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "backproject":
         backproject_case()
         sys.exit(0)

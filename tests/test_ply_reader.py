@@ -1,0 +1,84 @@
+"""The file hand-off of the drop-in boundary: the shim's PLY reader + normal cleaning against the
+REFERENCE'S OWN reader (S4/io/io.cc + io_ply.h, compiled unmodified into oracle/_ref, followed by
+Utils::CleanInvalidNormals as in S4/super4pcs_test.cc:58-89) on files in the layout
+pcl::io::savePLYFile writes for PointXYZRGBNormal.  A committed fixture (PLY text + what the
+reference reader returned) lets the comparison run where /root/reference is absent."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from _checkers import have_ref, ref_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "shim", "libsuper4pcs.so")
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ply_reader.npz")
+_f = C.POINTER(C.c_float)
+
+pytestmark = pytest.mark.skipif(not os.path.exists(SHIM), reason="shim/libsuper4pcs.so not built (needs Eigen)")
+
+
+def ascii_ply(xyz, nrm):
+    """PointXYZRGBNormal as pcl::io::savePLYFile writes it (ASCII): x y z r g b nx ny nz curvature."""
+    hdr = ("ply\nformat ascii 1.0\ncomment PCL generated\nelement vertex %d\nproperty float x\nproperty float y\n"
+           "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\n"
+           "property float ny\nproperty float nz\nproperty float curvature\nelement camera 1\n"
+           "property float view_px\nend_header\n") % len(xyz)
+    body = "".join("%.9g %.9g %.9g %d %d %d %.9g %.9g %.9g 0\n" % (*p, 10 + i % 200, 20, 30, *q)
+                   for i, (p, q) in enumerate(zip(xyz, nrm)))
+    return (hdr + body + "0\n").encode()
+
+
+def tricky_cloud(rng, n):
+    xyz = (rng.standard_normal((n, 3)) * rng.choice([1e-3, 0.1, 1.0, 37.0], (n, 1))).astype(np.float32)
+    nrm = rng.standard_normal((n, 3)).astype(np.float32)
+    nrm[0] = 0.0                                  # zero normal -> stays zero
+    nrm[1] = [1e-3, 0, 0]                         # tiny normal: normalised BEFORE the 0.01 test
+    nrm[2] = [0.05, 0.05, 0.0]                    # squared norm 0.005 < 0.01 before normalisation
+    nrm[3] *= 1e4                                 # long normal
+    nrm[4] = [0, -0.0, 1]
+    return xyz, nrm
+
+
+def read_with(fn, path, cap=100000):
+    xyz, nrm = np.zeros((cap, 3), np.float32), np.zeros((cap, 3), np.float32)
+    n = fn(path.encode(), xyz.ctypes.data_as(_f), nrm.ctypes.data_as(_f), cap)
+    assert n >= 0, "reader failed"
+    return xyz[:n].copy(), nrm[:n].copy()
+
+
+def shim_reader():
+    L = C.CDLL(SHIM)
+    L.super4pcs_shim_read_cloud.argtypes = [C.c_char_p, _f, _f, C.c_int]
+    return L.super4pcs_shim_read_cloud
+
+
+def test_shim_reader_matches_the_committed_reference_output(tmp_path):
+    g = np.load(GOLD)
+    for k in range(int(g["n_files"])):
+        p = str(tmp_path / f"cloud_{k}.ply")
+        with open(p, "wb") as f:
+            f.write(g[f"ply_{k}"].tobytes())
+        xyz, nrm = read_with(shim_reader(), p)
+        assert np.array_equal(xyz, g[f"xyz_{k}"])
+        assert np.array_equal(nrm, g[f"nrm_{k}"])
+
+
+@pytest.mark.skipif(not have_ref(), reason="needs oracle/_ref (build container)")
+def test_shim_reader_matches_the_reference_reader_live(tmp_path):
+    L = ref_lib()
+    L.ref_read_cloud.argtypes = [C.c_char_p, _f, _f, C.c_int]
+    rng = np.random.default_rng(17)
+    for k, n in enumerate((1, 5, 64, 2000)):
+        xyz, nrm = tricky_cloud(rng, max(n, 5))
+        xyz, nrm = xyz[:n], nrm[:n]
+        p = str(tmp_path / f"c{k}.ply")
+        with open(p, "wb") as f:
+            f.write(ascii_ply(xyz, nrm))
+        x_ref, n_ref = read_with(L.ref_read_cloud, p)
+        x_shim, n_shim = read_with(shim_reader(), p)
+        assert len(x_ref) == n
+        assert np.array_equal(x_shim, x_ref)
+        assert np.array_equal(n_shim, n_ref)
+        assert np.array_equal(x_ref, xyz)          # %.9g round-trips float32
