@@ -64,6 +64,11 @@ struct Cloud {
 // PLY: header-driven reader for what pcl::io::savePLYFile writes (ASCII by default, also
 // binary_little_endian): vertex properties x y z [nx ny nz | normal_x normal_y normal_z] plus
 // anything else, which is skipped (S4/io/io_ply.h reads the same columns, :270-277,311-317).
+// ASCII files give the reference reader's positions and normals bit for bit
+// (tests/test_ply_reader.py, against S4/io/io.cc compiled unmodified).  binary_little_endian is an
+// extension: the reference's binary reader assumes all-float vertex records and misreads the files
+// PCL writes with uchar colours (checked against the same build), so the node's ASCII default is
+// the only form the two can be compared on.
 // ---------------------------------------------------------------------------------------------
 struct PlyProp {
   std::string name, type;
