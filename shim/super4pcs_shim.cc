@@ -450,6 +450,19 @@ extern "C" int super4pcs_shim_read_cloud(const char* path, float* xyz, float* nr
   return c.n;
 }
 
+// C-linkage probe for the tests: decode a greyscale PNG into 16-bit samples (8-bit files are widened);
+// returns 0, or -1 when the file cannot be read / is not a supported PNG, -2 when cap is too small.
+extern "C" int super4pcs_shim_read_png(const char* path, unsigned short* px, int cap, int* rows, int* cols) {
+  std::vector<uint16_t> v;
+  int r = 0, c = 0;
+  if (!read_png_gray(path, v, r, c)) return -1;
+  *rows = r;
+  *cols = c;
+  if ((long long)r * c > cap) return -2;
+  std::copy(v.begin(), v.end(), px);
+  return 0;
+}
+
 bool super4pcs_shim_read_ply(const std::string& path, std::vector<float>& xyz, std::vector<float>& normals) {
   Cloud c;
   if (!read_ply(path, c)) return false;

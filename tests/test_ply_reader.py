@@ -82,3 +82,33 @@ def test_shim_reader_matches_the_reference_reader_live(tmp_path):
         assert np.array_equal(x_shim, x_ref)
         assert np.array_equal(n_shim, n_ref)
         assert np.array_equal(x_ref, xyz)          # %.9g round-trips float32
+
+
+def test_shim_png_decoder_matches_pil(tmp_path):
+    """The probability image (cv::imread of a CV_16UC1 PNG at base.cc:317; OpenCV is not in this image)
+    is decoded by the shim's own inflate + unfilter code: compare with PIL on 16- and 8-bit greyscale
+    images whose rows make the encoder pick different scanline filters."""
+    from PIL import Image
+    L = C.CDLL(SHIM)
+    L.super4pcs_shim_read_png.argtypes = [C.c_char_p, C.POINTER(C.c_ushort), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:97, 0:131]
+    images = [
+        rng.integers(0, 65536, (48, 64)).astype(np.uint16),                       # noise
+        ((xx * 500 + yy * 37) % 65536).astype(np.uint16),                         # ramps (Sub / Up / Paeth rows)
+        np.where((xx // 16 + yy // 16) % 2 == 0, 10000, 0).astype(np.uint16),     # flat blocks
+        np.zeros((1, 1), np.uint16),
+        rng.integers(0, 256, (33, 21)).astype(np.uint8),                          # 8-bit
+        (np.clip(10000 * np.exp(-((xx - 60) ** 2 + (yy - 40) ** 2) / 900.0), 0, 10000)).astype(np.uint16),
+    ]
+    for k, img in enumerate(images):
+        p = str(tmp_path / f"img_{k}.png")
+        Image.fromarray(img).save(p)
+        want = np.array(Image.open(p)).astype(np.uint16)
+        out = np.zeros(img.size, np.uint16)
+        rows, cols = C.c_int(0), C.c_int(0)
+        rc = L.super4pcs_shim_read_png(p.encode(), out.ctypes.data_as(C.POINTER(C.c_ushort)), out.size,
+                                       C.byref(rows), C.byref(cols))
+        assert rc == 0 and (rows.value, cols.value) == img.shape
+        assert np.array_equal(out.reshape(img.shape), want)
+    assert L.super4pcs_shim_read_png(str(tmp_path / "missing.png").encode(), None, 0, C.byref(rows), C.byref(cols)) == -1
