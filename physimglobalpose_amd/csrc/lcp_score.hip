@@ -34,6 +34,7 @@
 #include <hip/hip_ext.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace pgp {
@@ -202,10 +203,19 @@ struct ScoreArgs {
   int nQ;
   const float* T;
   int n_h, hpb, n_tiles, n_chunks;
+  int n_big, hpb_tail;  // chunks [0, n_big) hold hpb hypotheses each, the rest hpb_tail (chunk_range)
   float sq_eps, gate_lo, gate_hi;
   int* partial_cnt;     // [n_tiles][n_h]
   float* partial_sum;   // [n_tiles][n_h] (weighted only)
 };
+
+// Hypothesis range of a chunk.  The last chunks are smaller: workgroups are dispatched in block
+// order, so the batch ends on short workgroups and the idle tail of the launch shrinks.
+__device__ __forceinline__ void chunk_range(const ScoreArgs& a, int chunk, int* h0, int* h1) {
+  const int big = min(chunk, a.n_big), small = chunk - big;
+  *h0 = big * a.hpb + small * a.hpb_tail;
+  *h1 = min(*h0 + (chunk < a.n_big ? a.hpb : a.hpb_tail), a.n_h);
+}
 
 // U hypotheses are in flight per lane: their word loads, then their offset loads, then their
 // candidate trips are issued back to back, so a wave keeps U independent dependency chains in
@@ -231,8 +241,8 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
   float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
   if (MODE == PGP_MODE_WEIGHTED && live) qn = a.Qn[qi];
 
-  const int h0 = chunk * a.hpb;
-  const int h1 = min(h0 + a.hpb, a.n_h);
+  int h0, h1;
+  chunk_range(a, chunk, &h0, &h1);
   for (int hb = h0; hb < h1; hb += U) {
     Xf m[U];
     float x[U], y[U], z[U];
@@ -403,8 +413,8 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const unsigned long long le_mask = lt_mask | (1ull << lane);
   const uint32_t le_lo = (uint32_t)le_mask, le_hi = (uint32_t)(le_mask >> 32);
 
-  const int h0 = chunk * a.hpb;
-  const int h1 = min(h0 + a.hpb, a.n_h);
+  int h0, h1;
+  chunk_range(a, chunk, &h0, &h1);
   int my_cnt = 0;
   float my_sum = 0.f;
   for (int h = h0; h < h1; ++h) {
@@ -741,7 +751,16 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     if (ctx->hpb_override <= 0 && hpb > 16) hpb = 16;
     if (hpb > kMaxHpb) hpb = kMaxHpb;
     a.hpb = hpb;
-    a.n_chunks = (n_h + hpb - 1) / hpb;
+    // the last tail_pct % of the hypotheses go in chunks of hpb_tail (C2, tools/tune.py: 10 % in chunks
+    // of 2 -> 87-88 us plain / 114-116 us weighted against 90.5 / 119.5 us with uniform chunks; 20-40 %
+    // or chunks of 1, 3, 4 gain less)
+    static const int tail_pct = getenv("PGP_TAIL_PCT") ? atoi(getenv("PGP_TAIL_PCT")) : 10;
+    static const int tail_hpb = getenv("PGP_TAIL_HPB") ? atoi(getenv("PGP_TAIL_HPB")) : 2;
+    a.hpb_tail = tail_hpb > 0 && tail_hpb <= hpb ? tail_hpb : hpb;
+    int n_tail_h = (int)((long long)n_h * (tail_pct < 0 ? 0 : tail_pct > 100 ? 100 : tail_pct) / 100);
+    a.n_big = (n_h - n_tail_h) / hpb;
+    n_tail_h = n_h - a.n_big * hpb;
+    a.n_chunks = a.n_big + (n_tail_h + a.hpb_tail - 1) / a.hpb_tail;
     a.partial_cnt = ctx->d_partial.as<int>();
     a.partial_sum = reinterpret_cast<float*>(a.partial_cnt + (size_t)a.n_tiles * ctx->cap_h);
     int chunks_pad = (a.n_chunks + 7) / 8 * 8;
