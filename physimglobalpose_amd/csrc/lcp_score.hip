@@ -9,7 +9,8 @@
 // Mapping to the machine
 //   lane            = one validation-model point (kept in VGPRs for the whole block: it is
 //                     re-used by every hypothesis of the block's chunk, so it never needs LDS)
-//   workgroup       = 256 model points (4 wave64) x a chunk of `hpb` hypotheses
+//   workgroup       = 256 model points (4 wave64) x a chunk of `hpb` hypotheses (8 at C2; the last
+//                     10 % of a batch in chunks of 2 so that the launch ends on short workgroups)
 //   hypothesis      = wave-uniform: its 4x4 is read with scalar loads (one 64 B line) and lives
 //                     in SGPRs; the transform is 9 mul + 9 add per lane, no contraction
 //   inlier count    = __ballot + popcount per wave, 4 wave totals combined in LDS in fixed order,
@@ -309,10 +310,12 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
 // instructions per hypothesis on ~132 candidates.  Two experiments that kept the per-lane walk
 // (software pipelining across hypotheses; 16-lane groups per run) issued MORE such instructions
 // and were slower (157 and 203 us vs 125 us).  Here the runs of a wave are flattened: the lanes
-// that own a run are compacted into an LDS table, every candidate slot w of the concatenated runs
-// gets its owner from an LDS owner map, and lane (w mod 64) tests candidate w -- so a load
-// instruction serves 64 useful candidates and a wave-iteration needs ceil(W/64) ~ 2.1 of them.
-// Per-owner results are combined with LDS atomics (or / 64-bit min) and read back by the owner.
+// that own a run are compacted (in lane order) into an LDS table, the slots of the concatenated
+// runs are handed out by a DPP prefix scan of the run lengths, each run's first slot is marked in
+// an LDS bit array, and lane (w mod 64) tests candidate slot w after resolving its owner with a
+// ballot and a popcount over those marks (flat_batch) -- so a load instruction serves 64 useful
+// candidates and a wave-iteration needs ceil(W/64) ~ 2 of them.  Per-owner results are combined
+// through LDS (store / 64-bit min) and read back by the owner.
 // Arithmetic per (query, candidate) pair is unchanged; results are identical.
 constexpr int kFlatCap = 1024;  // candidate slots per wave-iteration served by the flat path
 
