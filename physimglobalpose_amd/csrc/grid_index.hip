@@ -6,11 +6,12 @@
 // tree walk per lane is the wrong shape for 64-wide wavefronts, so the device index is a uniform
 // grid with DILATED per-cell candidate lists:
 //
-//   cell(x)      = floor((x - origin) * inv_h), h >= delta
+//   cell(x)      = floor((x - origin) * inv_h), h = 0.85 delta by default (choose_grid)
 //   cand(c)      = every scene point within `reach` = delta + margin of the box of cell c
-//   words        = per 32 cells along x: {occupancy bits, rank base}   (1.6 MB at C2, L2-resident)
+//   words        = per block of 4 x 4 x 2 cells (cells are numbered block-major, pgp_internal.h
+//                  grid_word / grid_bit): {occupancy bits, rank base}   (2.9 MB at C2, L2-resident)
 //   occ_run      = {start, count} per OCCUPIED cell (rank = base + popcount of lower bits) into
-//                  one float4 array {x,y,z,bits(id)} of all candidate lists (2.3 MB at C2)
+//                  one float4 array {x,y,z,bits(id)} of all candidate lists (3.3 MB at C2)
 //
 // A query is then: one 8-byte word, (if the bit is set) one 8-byte offset pair, one contiguous
 // float4 run -- no neighbour-cell gather, no tree; ~78 % of C2 queries end at the word.  Exactness: the scoring kernel applies the reference's float
@@ -18,8 +19,8 @@
 // choose_grid) covers the float rounding of cell(x), so cand(cell(x)) is a superset of the
 // scene points that pass the test for x.  The result equals an exhaustive scan.
 //
-// HBM layout: 27 copies of each point on average (h = delta) = 21.6 MB at |P| = 50 k; the index
-// trades capacity (288 GB) for one-run locality.
+// HBM layout: 28 copies of each point on average (h = 0.85 delta, two dilation rings) = 22.6 MB at
+// |P| = 50 k; the index trades capacity (288 GB) for one-run locality.
 
 #include "pgp_internal.h"
 
