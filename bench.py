@@ -195,6 +195,18 @@ def other_rows(sc, w, torch):
     qd = rng.integers(0, len(w.Qs_xyz), (10000, 4)).astype(np.int32)
     dt3, _ = timed(lambda: sc.rigid_from_congruent(b, qd, w.centroid_P, w.centroid_Q))
     out["rigid_fit"] = {"pairs": 10000, "fits_per_s": 10000 / dt3, "ms_per_call": dt3 * 1e3}
+    # MCTS leaf cost: 64 rendered 640 x 480 depth images against one observed image (host pointers)
+    obs = rng.uniform(0.4, 1.2, (480, 640)).astype(np.float32)
+    ren = (obs[None] + rng.normal(0, 0.02, (64, 480, 640))).astype(np.float32)
+    dt5, _ = timed(lambda: sc.depth_cost(obs, ren, 0.01), reps=3)
+    out["depth_cost"] = {"images": 64, "pixels": 640 * 480, "images_per_s": 64 / dt5, "ms_per_call": dt5 * 1e3,
+                         "note": "host pointers: 79 MB of rendered depth cross PCIe per call"}
+    # depth image -> segment cloud (decode + mask + back-projection, ordered compaction)
+    raw = rng.integers(2000, 60000, (480, 640)).astype(np.uint16)
+    msk = (rng.random((480, 640)) < 0.5).astype(np.uint8)
+    Kc = np.array([[614.0, 0, 322.5], [0, 614.0, 239.7], [0, 0, 1]], np.float32)
+    dt6, cloud = timed(lambda: sc.backproject_depth(raw, Kc, msk))
+    out["backproject"] = {"pixels": 640 * 480, "points": int(len(cloud)), "ms_per_call": dt6 * 1e3}
     # greedy clustering of the C2 batch by its own weighted scores (all 4096 admitted: fraction 0)
     sw, _, _, bs = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
     dt4, (rep, _) = timed(lambda: sc.cluster_poses(w.T, sw + np.float32(1e-6), bs, accept_fraction=0.0))
