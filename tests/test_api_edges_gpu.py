@@ -68,3 +68,38 @@ def test_rigid_fit_empty_batch_and_state_errors():
     T, pose, st, rms = sc.rigid_from_congruent(np.array([[0, 1, 2, 3]], np.int32), np.array([[0, 1, 2, 3]], np.int32),
                                                np.zeros(3), np.zeros(3))
     assert st[0] == 2 and np.isnan(T).all()
+
+
+def test_distinct_contexts_are_safe_from_different_threads():
+    """One context per call-site, not shared: two host threads, each with its own context (the
+    reference's commented-out per-object threads, SceneCfg.cpp:377,404-405), score concurrently --
+    ctypes drops the GIL during the calls -- and both get the oracle's scores."""
+    import threading
+    from physimglobalpose_amd import PGP_MODE_WEIGHTED
+    from _checkers import Oracle
+    ws = [synth.make_workload(5000, 700, 256, config_id=81 + k) for k in range(2)]
+    want = []
+    for w in ws:
+        orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+        want.append((orc.score_batch(w.T, w.delta, mode=0)[0], orc.score_batch(w.T, w.delta, mode=1, gate_deg=w.gate_deg)[0]))
+    errors = []
+
+    def work(k):
+        try:
+            w = ws[k]
+            sc = LcpScorer(0)
+            sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+            for _ in range(30):
+                s = sc.score(w.T)[0]
+                sw = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)[0]
+                assert np.array_equal(s, want[k][0])
+                assert np.allclose(sw, want[k][1], rtol=0, atol=2e-6)
+        except Exception as e:  # noqa: BLE001 - reported to the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
