@@ -226,6 +226,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a
+    # version banner through C stdio, flushed at exit, i.e. AFTER anything Python printed): keep the
+    # real stdout aside, point fd 1 at stderr for the whole run, and write the line to the saved
+    # descriptor at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -414,9 +422,10 @@ def main():
                 out["other_rows"] = other_rows(sc, w, torch)
             except Exception as e:  # secondary numbers must never take the headline line down
                 out["other_rows"] = {"error": repr(e)}
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if multi:
         dist.destroy_process_group()
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":

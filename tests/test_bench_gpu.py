@@ -35,7 +35,8 @@ def test_single_gpu_line():
     out = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2"], cwd=ROOT,
                          capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = out.stdout.splitlines()          # the contract: stdout is ONE JSON line, nothing else
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     assert len(lines) == 1
     d = _check(lines[0], 1)
     cb = d["cpu_baseline"]
@@ -51,7 +52,8 @@ def test_two_ranks_on_one_gpu_functional():
                           "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True,
                          timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = out.stdout.splitlines()          # the contract: stdout is ONE JSON line, nothing else
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     assert len(lines) == 1                      # rank 0 only
     d = _check(lines[0], 2)
     assert "cpu_baseline" not in d              # N = 1 only
@@ -64,6 +66,7 @@ def test_one_rank_through_rccl():
     out = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    lines = out.stdout.splitlines()          # the contract: stdout is ONE JSON line, nothing else
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     assert len(lines) == 1
     _check(lines[0], 1)
