@@ -2,7 +2,8 @@
 """Randomised parity soak for the rows beside the scoring loop: congruent sets (pairs as sets, quads
 in order), rigid fits (bit-exact centred transform / status / rms), pose clustering (identical
 representatives and assignments), back-projection (bit-exact list) -- libpgp.so against the CPU
-oracle for FUZZ_SECONDS (default 90).  Test infrastructure (uses oracle/)."""
+oracle for FUZZ_SECONDS (default 90).  Test infrastructure: lives under tests/ because it uses the oracle as its checker; run by hand
+(python tests/soak_parity.py), not collected by pytest."""
 import os
 import sys
 import time
@@ -10,7 +11,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.dirname(os.path.abspath(__file__))]
 from physimglobalpose_amd import LcpScorer, synth  # noqa: E402
 from _checkers import (CongruentChecker, oracle_backproject, oracle_greedy_cluster,  # noqa: E402
                        oracle_rigid_from_pairs)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity soak: libpgp.so against the CPU oracle over random scenes, models, radii,
 hypothesis mixes and both modes, for FUZZ_SECONDS (default 120).  Exact equality for plain counts /
-scores / best index, 2e-6 absolute for weighted scores.  Test infrastructure (uses oracle/)."""
+scores / best index, 2e-6 absolute for weighted scores.  Test infrastructure: lives under tests/ because it uses the oracle as its checker; run by hand
+(python tests/soak_parity.py), not collected by pytest."""
 import os
 import sys
 import time
@@ -9,7 +10,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+sys.path[:0] = [ROOT, os.path.dirname(os.path.abspath(__file__))]
 from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth  # noqa: E402
 from _checkers import Oracle, oracle_lib  # noqa: E402
 
