@@ -119,14 +119,21 @@ __device__ __forceinline__ int cvt_rz(float f) {
   return r;
 }
 
+// min(max(v, 0), hi) in one instruction (hi >= 0 is wave-uniform)
+__device__ __forceinline__ int clamp0(int v, int hi_uniform) {
+  int r;
+  asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi_uniform));
+  return r;
+}
+
 template <bool WAVE_SKIP = false>
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
                                          const uint2* __restrict__ occ_run, float x, float y,
                                          float z, uint32_t* s, uint32_t* n, bool live = true) {
   const float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
-  const int cx = min(max(cvt_rz(fx), 0), g.nx - 1);
-  const int cy = min(max(cvt_rz(fy), 0), g.ny - 1);
-  const int cz = min(max(cvt_rz(fz), 0), g.nz - 1);
+  const int cx = clamp0(cvt_rz(fx), g.nx - 1);
+  const int cy = clamp0(cvt_rz(fy), g.ny - 1);
+  const int cz = clamp0(cvt_rz(fz), g.nz - 1);
   // blocked numbering (pgp_internal.h grid_word / grid_bit): word = 4 x 4 x 2 block, bit = cell in it
   const uint32_t brow = mad24((uint32_t)cz >> 1, (uint32_t)g.nby, (uint32_t)cy >> 2);
   const uint32_t wi = mad24(brow, (uint32_t)g.nbx, (uint32_t)cx >> 2);
@@ -400,7 +407,6 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   if (chunk >= a.n_chunks) return;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   const int qi = tile * kTile + threadIdx.x;
   const bool live = qi < a.nQ;
   // a lane past the end of the model carries a NaN point: it lands in cell 0 and can never pass
@@ -413,7 +419,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   unsigned long long* res = s_res[wave];
   unsigned long long* marks = s_marks[wave];
   if (lane < kFlatCap / 64 + 4) marks[lane] = 0ull;
-  const unsigned long long le_mask = lt_mask | (1ull << lane);
+  const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane (lane 63: all ones)
   const uint32_t le_lo = (uint32_t)le_mask, le_hi = (uint32_t)(le_mask >> 32);
 
   int h0, h1;
@@ -443,7 +449,8 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       // nothing to test in this wave-iteration
     } else if (W <= (uint32_t)kFlatCap) {
       const bool act = len > 0;
-      const int r = __popcll(am & lt_mask);  // owners are numbered in lane order = start order
+      // owners are numbered in lane order = start order: # owning lanes below this one (v_mbcnt)
+      const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
       if (act) {
         // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
         ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
