@@ -1,19 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- pose hypotheses/sec LCP-scored (BASELINE.json metric) on MI355X.
 
-A "step" = one pass of the hot path over one batch: every rank LCP-scores its shard of
-hypotheses (C2: 4096 per GPU, 5 000-pt model vs 50 000-pt scene, plain LCP = the reference's
-Verify without early-out) with the clouds, the index and the transforms already resident in HBM,
-then (N > 1) the per-hypothesis scores are combined with one RCCL all-reduce and the arg-max is
-taken.  value = hypotheses all ranks scored / max-over-ranks wall time.
+A "step" = one pass of the hot path over one batch: every rank LCP-scores its shard of hypotheses
+(C2: 4096 per GPU, 5 000-pt model vs 50 000-pt scene) with the clouds, the index and the transforms
+already resident in HBM; the timed loop rotates through 8 DISTINCT hypothesis batches.  Default mode
+is WEIGHTED LCP = the reference's live verifier (operMode 1 -> WeightedVerify, base.cc:300,1733-1766);
+`--mode plain` (Verify without early-out) is reported under other_rows.  With N > 1 ranks the
+per-hypothesis scores are combined with RCCL all-reduces (physimglobalpose_amd.sharding.
+BucketedExchange: the class a streaming caller uses) and arg-maxed; `per_call` then reports the
+UNBUCKETED form next to it -- one all-reduce + arg-max + host sync per batch, the latency a caller
+that needs each batch's scores before it proceeds (HypothesisSelection.cpp:248-257) would see.
+value = hypotheses all ranks scored / max-over-ranks wall time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode plain|weighted]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--mode weighted|plain]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the round prompt): metric/value/unit/... plus
-"roofline" (dominant kernel, algorithmic bytes / HIP-event duration vs the 8 TB/s HBM peak) and
-"cpu_baseline" (the CPU oracle timed on this box's host cores, rank 0, N = 1 only).
+Prints ONE JSON line on rank 0: metric/value/unit/... plus "roofline" (dominant kernel: its live
+HIP-event duration against the units that can bind it -- vector L1, VALU issue, HBM -- with the
+per-launch counter values of profiles/pmc_current.json when they were collected on this very kernel
+source) and "cpu_baseline" (the CPU oracle timed on this box's host cores, rank 0, N = 1 only).
 """
 from __future__ import annotations
 
@@ -29,17 +35,86 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
+# (tools/peaks.hip measured 1096-1108 G/s for v_add/v_mul_f32 at 8 waves per SIMD)
+VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
+# vector L1 (TCP): one 64-byte cache-line access per clock per CU (tools/peaks.hip: 607 G lines/s with
+# 64 distinct lines per load instruction)
+L1_PEAK_GLINES = 256 * 2.4
 
 N_SCENE, N_MODEL, N_HYP = 50000, 5000, 4096   # BASELINE.json configs[1] (C2)
+N_BATCH = 8         # distinct hypothesis batches the timed loop rotates through
 TIMING_STRIDE = 8   # every 8th launch of the timed region carries HIP events
-BUCKET = 8          # steps whose score vectors share one all-reduce (N > 1)
+BUCKET = 8          # steps whose score vectors share one all-reduce (N > 1, throughput form)
 
 
 def algorithmic_bytes_per_hypothesis(n_scene, n_model, mode):
-    """plain 12|Q|+12|P|+52, weighted 24|Q|+28|P|+52."""
+    """plain 12|Q|+12|P|+52, weighted 24|Q|+28|P|+52 -- the bytes a
+    scan-and-count over both clouds would move.  The grid index never touches most of them, so this
+    is a MODEL figure and does not bound the kernel (reported as such)."""
     if mode == "plain":
         return 12 * n_model + 12 * n_scene + 52
     return 24 * n_model + 28 * n_scene + 52
+
+
+def kernel_source_id():
+    """sha256[:16] over the sources that define the scoring kernel and its index: the PMC counters
+    in profiles/pmc_current.json are only used when they were collected on this very code."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lcp_score.hip", "grid_index.hip", "pgp_internal.h"):
+        h.update(open(os.path.join(ROOT, "physimglobalpose_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def roofline_block(mode, n_h, kern_avg_ms, launches):
+    """The dominant kernel against every unit that can bind it.  Durations are live (HIP events on
+    the launch stream); instruction / cache-access / byte counts per launch come from the committed
+    rocprofv3 PMC passes (tools/collect_pmc.sh -> profiles/pmc_current.json) and are used only if
+    that file was produced from the same kernel source (else the fractions are null)."""
+    kname = f"score_hypotheses_flat<{0 if mode == 'plain' else 1}>"
+    B_h = algorithmic_bytes_per_hypothesis(N_SCENE, N_MODEL, mode)
+    t = kern_avg_ms * 1e-3
+    out = {"kernel": kname, "launches": launches, "timed_every": TIMING_STRIDE, "avg_kernel_ms": kern_avg_ms,
+           "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+           "algorithmic_model": {"bytes_per_hypothesis": B_h, "GBps": (B_h * n_h / t / 1e9) if launches else None,
+                                 "hbm_peak_GBps": HBM_PEAK_GBPS,
+                                 "note": "SURVEY 8(d) scan model, NON-BINDING: the grid index skips almost "
+                                         "all of these bytes, so this figure may exceed the HBM peak"}}
+    path = os.path.join(ROOT, "profiles", "pmc_current.json")
+    try:
+        pmc = json.load(open(path))
+    except Exception:
+        out["counters"] = "profiles/pmc_current.json missing"
+        return out
+    c = pmc.get("kernels", {}).get(kname)
+    if pmc.get("source_id") != kernel_source_id() or not c or not launches:
+        out["counters"] = (f"profiles/pmc_current.json is for source {pmc.get('source_id')}, this build is "
+                           f"{kernel_source_id()}: counter-based fractions withheld")
+        return out
+    units = {}
+    if c.get("SQ_INSTS_VALU"):
+        a = c["SQ_INSTS_VALU"] / t / 1e9
+        units["valu_issue"] = {"achieved": a, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": a / VALU_PEAK_GINSTR,
+                               "per_launch": c["SQ_INSTS_VALU"]}
+    if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+        a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / t / 1e9
+        units["vector_l1"] = {"achieved": a, "peak": L1_PEAK_GLINES, "unit": "G line-accesses/s", "frac": a / L1_PEAK_GLINES,
+                              "per_launch": c["TCP_TOTAL_CACHE_ACCESSES_sum"]}
+    if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
+        # KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        a = traffic / t / 1e9
+        units["hbm"] = {"achieved": a, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": a / HBM_PEAK_GBPS,
+                        "per_launch": traffic}
+        out["traffic"] = traffic
+    out["units"] = units
+    out["counters"] = f"profiles/pmc_current.json ({pmc.get('collected', '?')}), same kernel source {pmc.get('source_id')}"
+    if units:
+        b = max(units, key=lambda k: units[k]["frac"])
+        out.update(bound=b, achieved=units[b]["achieved"], peak=units[b]["peak"], unit=units[b]["unit"],
+                   frac=units[b]["frac"])
+    return out
 
 
 def usable_cpus(n_threads_max):
@@ -131,11 +206,11 @@ def cpu_baseline(w, mode, budget_s=8.0):
     }
 
 
-def other_rows(sc, w, torch):
+def other_rows(sc, w, torch, mode_name, d_batches):
     """Secondary measurements for the other rows of SURVEY section 8 (not the headline metric):
     weighted LCP, batched ICP, congruent-set extraction, rigid fits.  Device time via host wall
     clock around synchronous C-ABI calls, inputs staged per call (PCIe inclusive)."""
-    from physimglobalpose_amd import PGP_MODE_WEIGHTED, synth
+    from physimglobalpose_amd import PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
     out = {}
     rng = np.random.default_rng(0)
 
@@ -148,21 +223,27 @@ def other_rows(sc, w, torch):
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / reps, r
 
-    # the live mode of the reference (operMode 1 -> WeightedVerify): same batch, same clouds
-    dT = torch.from_numpy(w.T[:N_HYP]).cuda()
+    # the other scoring mode (the headline is --mode; default weighted = the reference's live mode):
+    # same clouds, the same rotation of distinct batches
+    o_name = "plain" if mode_name == "weighted" else "weighted"
+    o_mode = PGP_MODE_WEIGHTED if o_name == "weighted" else PGP_MODE_PLAIN
     ds = torch.zeros(N_HYP, device="cuda")
     dc = torch.zeros(N_HYP, dtype=torch.int32, device="cuda")
     db = torch.zeros(2, dtype=torch.int32, device="cuda")
-    for _ in range(20):
-        sc.score_device(dT, ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+    for k in range(20):
+        sc.score_device(d_batches[k % len(d_batches)], ds, dc, db, mode=o_mode, gate_deg=w.gate_deg)
     torch.cuda.synchronize()
+    sc.set_kernel_timing(TIMING_STRIDE)
+    sc.kernel_timing(reset=True)
     t0 = time.perf_counter()
-    for _ in range(200):
-        sc.score_device(dT, ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+    for k in range(200):
+        sc.score_device(d_batches[k % len(d_batches)], ds, dc, db, mode=o_mode, gate_deg=w.gate_deg)
     torch.cuda.synchronize()
     dtw = (time.perf_counter() - t0) / 200
-    out["weighted_lcp"] = {"hypotheses_per_s": N_HYP / dtw, "ms_per_step": dtw * 1e3, "gate_deg": float(w.gate_deg),
-                           "algorithmic_bytes_per_hypothesis": algorithmic_bytes_per_hypothesis(N_SCENE, N_MODEL, "weighted")}
+    launches, kern_ms = sc.kernel_timing(reset=True)
+    sc.set_kernel_timing(False)
+    out[o_name + "_lcp"] = {"hypotheses_per_s": N_HYP / dtw, "ms_per_step": dtw * 1e3, "gate_deg": float(w.gate_deg),
+                            "roofline": roofline_block(o_name, N_HYP, kern_ms / max(launches, 1), launches)}
     # ICP: 64 poses, 2500-pt segment vs 5000-pt model, 10 iterations each (trim 0.9)
     seg = w.Q_xyz[rng.choice(len(w.Q_xyz), 2500, replace=False)]
     R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8)
@@ -208,12 +289,56 @@ def other_rows(sc, w, torch):
     dt6, cloud = timed(lambda: sc.backproject_depth(raw, Kc, msk))
     out["backproject"] = {"pixels": 640 * 480, "points": int(len(cloud)), "ms_per_call": dt6 * 1e3}
     # greedy clustering of the C2 batch by its own weighted scores (all 4096 admitted: fraction 0)
-    sw, _, _, bs = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
-    dt4, (rep, _) = timed(lambda: sc.cluster_poses(w.T, sw + np.float32(1e-6), bs, accept_fraction=0.0))
-    m = len(w.T)
+    Tc = w.T[:N_HYP]
+    sw, _, _, bs = sc.score(Tc, PGP_MODE_WEIGHTED, w.gate_deg)
+    dt4, (rep, _) = timed(lambda: sc.cluster_poses(Tc, sw + np.float32(1e-6), bs, accept_fraction=0.0))
+    m = len(Tc)
     out["cluster"] = {"poses": m, "clusters": int(len(rep)), "pair_tests_per_s": m * (m - 1) / 2 / dt4,
                       "ms_per_call": dt4 * 1e3}
     return out
+
+
+def drop_in_row():
+    """End-to-end time of the drop-in boundary per object: shim/test_shim (prebuilt in the build
+    container, it needs Eigen) calls getProbableTransformsSuper4PCS on a synthetic segment the way
+    ObjectPoseCandidateSet.cpp:53-68 does -- file hand-off and in-memory overload, 3 calls each in
+    one process, the first (context + code-object load) reported apart."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "shim", "test_shim")
+    if not os.path.exists(exe):
+        return {"error": "shim/test_shim not built (needs Eigen: make -C shim in the build container)"}
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from _dropin import make_dropin_case
+    with tempfile.TemporaryDirectory() as d:
+        args, case = make_dropin_case(d)
+        out = {"case": case["info"]}
+        for name, extra in (("file_path", {}), ("in_memory", {"SHIM_TEST_INMEMORY": "1"})):
+            env = dict(os.environ, PGP_SHIM_SEED="12345", SHIM_TEST_REPEAT="3", **extra)
+            r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                out[name] = {"error": r.stderr[-300:]}
+                continue
+            ms = [float(x) for l in r.stdout.splitlines() if l.startswith("ELAPSED_MS") for x in l.split()[1:]]
+            out[name] = {"first_call_ms": ms[0], "drop_in_ms_per_object": min(ms[1:]) if len(ms) > 1 else ms[0],
+                         "calls_ms": ms}
+        return out
+
+
+def native_multi_row(n_dev, mode_name, steps):
+    """The single-process multi-GPU path behind the C ABI (pgp_multi_*: one host thread + stream per
+    device, RCCL all-reduce issued from C++), measured in a CHILD process after the ranks have left
+    their GPUs -- never inside the timed region, never able to take the headline line down."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "native_multi_bench.py"), "--devices", str(n_dev),
+           "--mode", mode_name, "--steps", str(steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+        if r.returncode != 0:
+            return {"error": r.stderr[-400:]}
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def main():
@@ -221,7 +346,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mode", choices=["plain", "weighted"], default="plain")
+    ap.add_argument("--mode", choices=["plain", "weighted"], default="weighted")
     ap.add_argument("--hyp", type=int, default=N_HYP, help="hypotheses per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -264,87 +389,37 @@ def main():
             dist.init_process_group(backend)
 
     from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
+    from physimglobalpose_amd.sharding import BucketedExchange
 
     mode = PGP_MODE_PLAIN if args.mode == "plain" else PGP_MODE_WEIGHTED
     n_h = args.hyp
-    # every rank builds the same scene/model (replicated) and takes its own slice of
-    # a world*n_h hypothesis batch (weak scaling: per-GPU work fixed)
-    w = synth.make_workload(N_SCENE, N_MODEL, n_h * world, config_id=2)
+    # every rank builds the same scene/model (replicated); the hypothesis list holds
+    # N_BATCH distinct batches of world*n_h hypotheses, rank r takes slice r of each (weak scaling:
+    # per-GPU work fixed)
+    w = synth.make_workload(N_SCENE, N_MODEL, n_h * world * N_BATCH, config_id=2)
     sc = LcpScorer(dev_index)
     t0 = time.perf_counter()
     sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
     cold_ms = (time.perf_counter() - t0) * 1e3
     sc.reserve(n_h)
-    T_all = torch.from_numpy(w.T).to(dev)
-    d_T = T_all[rank * n_h:(rank + 1) * n_h].contiguous()
-    # Bucketed exchange: the score vectors of BUCKET consecutive steps share one all-reduce (one
-    # collective launch costs the scoring stream ~11 us -- tools/dist_overhead.py -- which is 12 % of
-    # a 95 us step; per-step messages are 4 B x world x n_h, far below the bandwidth regime).  Two
-    # buckets alternate: the collective of one runs on RCCL's stream while the scoring kernels
-    # fill the other.  Each step's vector is still all-reduced in full and arg-maxed locally.
-    n_buf = 2 if multi else 1
-    n_slot = BUCKET if multi else 1
-    bufs = [torch.zeros(n_slot, world * n_h, dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    works = [None] * n_buf
-    d_scores_all = bufs[0][0]
-    d_scores = d_scores_all[rank * n_h:(rank + 1) * n_h]
+    T_all = torch.from_numpy(w.T).to(dev).view(N_BATCH, world, n_h, 16)
+    d_batches = [T_all[b, rank].contiguous() for b in range(N_BATCH)]
     d_counts = torch.zeros(n_h, dtype=torch.int32, device=dev)
     d_best = torch.zeros(2, dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev)
-    state = {"k": 0, "argmax": None, "open": None}
-
-    # The exchange's tail (wait for the collective, arg-max, re-zeroing the bucket) runs on its own
-    # stream, beside the next steps' scoring kernels: the main stream carries scoring only and
-    # waits, once per bucket, on an event recorded a bucket earlier.
-    post = torch.cuda.Stream(dev) if multi else None
-    ready = [torch.cuda.Event() for _ in range(n_buf)] if multi else []
-
-    def finish(b):
-        """Complete the exchange that was started on bucket b (call with `post` current): every rank
-        then holds all scores of the bucket's steps (north_star: "RCCL all-reduce over xGMI of the
-        per-hypothesis LCP scores") and takes each step's arg-max locally."""
-        if works[b] is not None:
-            works[b].wait()          # stream-level wait under nccl; host wait under gloo
-            works[b] = None
-            state["argmax"] = torch.argmax(bufs[b], dim=1)
-
-    def exchange(b):
-        works[b] = dist.all_reduce(bufs[b], op=dist.ReduceOp.SUM, async_op=True)
-        state["open"] = None
+    ex = BucketedExchange(n_h, rank, world, dev, bucket=BUCKET, force=multi)
+    state = {"k": 0}
 
     def step():
-        if not multi:
-            sc.score_device(d_T, d_scores, d_counts, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
-            return
-        k = state["k"]
+        b = state["k"] % N_BATCH
         state["k"] += 1
-        b, j = (k // BUCKET) % n_buf, k % BUCKET
-        if j == 0:                   # a new bucket: its previous contents must be consumed and cleared
-            with torch.cuda.stream(post):
-                finish(b)
-                bufs[b].zero_()      # every rank fills only its slice of a zeroed vector: sum == gather
-                ready[b].record(post)
-            stream.wait_event(ready[b])
-            state["open"] = b
-        sc.score_device(d_T, bufs[b][j, rank * n_h:(rank + 1) * n_h], d_counts, d_best, mode=mode,
-                        gate_deg=w.gate_deg, stream=stream)
-        state["last"] = (b, j)
-        if j == BUCKET - 1:
-            exchange(b)
-
-    def drain():
-        if multi:
-            if state["open"] is not None:        # a partly filled bucket: exchange what it holds
-                exchange(state["open"])
-            with torch.cuda.stream(post):
-                for b in range(n_buf):
-                    finish(b)
-            stream.wait_stream(post)
-            state["k"] = 0                       # the next step starts a fresh bucket
+        sc.score_device(d_batches[b], ex.slot(), d_counts, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
+        ex.commit()
+        state["last_batch"] = b
 
     for _ in range(args.warmup):
         step()
-    drain()
+    ex.drain()
     torch.cuda.synchronize()
     # HIP events on every 8th launch of the timed region: a timed dispatch costs the stream ~8 us,
     # so timing all of them would take 7 % off the throughput being measured
@@ -357,7 +432,7 @@ def main():
     for _ in range(args.steps):
         step()
     t_issue = time.perf_counter() - t0   # host time to ENQUEUE the steps (the GPU may still be busy)
-    drain()                          # every step's exchange and arg-max complete inside the timed region
+    ex.drain()                       # every step's exchange and arg-max complete inside the timed region
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -372,28 +447,51 @@ def main():
 
     # sanity inside the bench: the device result of the last step matches a host-pointer call
     best = d_best.cpu().numpy()
-    s_host, _, bi_host, _ = sc.score(w.T[rank * n_h:(rank + 1) * n_h], mode, w.gate_deg)
-    last = bufs[state["last"][0]][state["last"][1]] if multi else d_scores_all
+    lb = state["last_batch"]
+    T_last = w.T.reshape(N_BATCH, world, n_h, 16)[lb, rank]
+    s_host, _, bi_host, _ = sc.score(T_last, mode, w.gate_deg)
+    last = ex.last_vector()
     assert np.array_equal(s_host, last[rank * n_h:(rank + 1) * n_h].cpu().numpy()) and bi_host == int(best[0])
+    per_call = None
     if multi:
         # the combined vector of the last step: every slice present, arg-max = the global best
         s_all = last.cpu().numpy()
         assert (s_all.reshape(world, n_h).max(axis=1) > 0).all()
         assert int(torch.argmax(last)) == int(np.argmax(s_all))
+        # ---- per-call (unbucketed) form: score -> ONE all-reduce -> arg-max on the device with the
+        # exact near-tie settlement over the combined vector -> host sync, batch by batch
+        T_full = [T_all[b].reshape(world * n_h, 16).contiguous() for b in range(N_BATCH)]
+        vec = torch.zeros(world * n_h, dtype=torch.float32, device=dev)
+        k_pc = max(20, min(args.steps, 100))
 
+        def call(b):
+            vec.zero_()
+            sc.score_device(d_batches[b], vec[rank * n_h:(rank + 1) * n_h], d_counts, None, mode=mode,
+                            gate_deg=w.gate_deg, stream=stream)
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            sc.settle_best_device(T_full[b], vec, d_best, mode=mode, gate_deg=w.gate_deg, stream=stream)
+            torch.cuda.synchronize()
+
+        for b in range(4):
+            call(b % N_BATCH)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(k_pc):
+            call(k % N_BATCH)
+        dist.barrier()
+        dpc = time.perf_counter() - t0
+        t = torch.tensor([dpc], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dpc = float(t.item())
+        per_call = {"ms_per_step": dpc / k_pc * 1e3, "value": n_h * world * k_pc / dpc, "steps": k_pc,
+                    "form": "score slice -> one all-reduce(SUM) -> device arg-max with near-tie settlement -> "
+                            "host sync, per batch (what sharding.ShardedScorer.score does)"}
+
+    out = None
     if rank == 0:
         total_h = n_h * world * args.steps
         value = total_h / dt
-        B_h = algorithmic_bytes_per_hypothesis(N_SCENE, N_MODEL, args.mode)
         kern_avg_ms = kern_ms / max(launches, 1)
-        achieved = B_h * n_h / (kern_avg_ms * 1e-3) / 1e9 if launches else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(f"score_hypotheses_{args.mode}_bytes_per_launch")
-            except Exception:
-                traffic = None
         out = {
             "metric": "pose hypotheses/sec LCP-scored (50k-pt scene x 5k-pt model)",
             "value": value, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
@@ -402,29 +500,43 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C2 (BASELINE.json configs[1]): 1 object, 5000-pt model vs "
-                                   "50000-pt synthetic scene, 4096 hypotheses per GPU per step, "
-                                   f"{args.mode} LCP, delta 5 mm",
+                                   "50000-pt synthetic scene, 4096 hypotheses per GPU per step "
+                                   f"({N_BATCH} distinct batches in rotation), {args.mode} LCP"
+                                   + (" = the reference's live WeightedVerify" if args.mode == "weighted" else "")
+                                   + ", delta 5 mm",
                        "n_scene": N_SCENE, "n_model": N_MODEL, "hypotheses_per_gpu": n_h,
+                       "distinct_batches": N_BATCH,
                        "mode": args.mode, "sharding": f"hypotheses x{world}, clouds replicated",
-                       "exchange": (f"one all-reduce(SUM) per {BUCKET} steps (bucketed), overlapped with scoring"
+                       "exchange": (f"sharding.BucketedExchange: one all-reduce(SUM) per {BUCKET} steps, overlapped "
+                                    "with scoring (throughput form; per_call = the unbucketed latency form)"
                                     if multi else "none (one rank)")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": f"score_hypotheses<{args.mode}>", "launches": launches,
-                         "timed_every": TIMING_STRIDE,
-                         "avg_kernel_ms": kern_avg_ms, "algorithmic_bytes_per_hypothesis": B_h},
+            "roofline": roofline_block(args.mode, n_h, kern_avg_ms, launches),
             "index": sc.index_info(), "cold_setup_ms": cold_ms,
             "best_index": int(best[0]),
         }
+        if per_call is not None:
+            out["per_call"] = per_call
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.mode)
             try:
-                out["other_rows"] = other_rows(sc, w, torch)
+                out["other_rows"] = other_rows(sc, w, torch, args.mode, d_batches)
             except Exception as e:  # secondary numbers must never take the headline line down
                 out["other_rows"] = {"error": repr(e)}
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+            try:
+                out["other_rows"]["drop_in"] = drop_in_row()
+            except Exception as e:
+                out["other_rows"]["drop_in"] = {"error": repr(e)}
     if multi:
+        dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if world > 1 and os.environ.get("PGP_BENCH_NATIVE_MULTI", "1") != "0":
+            # every rank has finished its timed work: the native group takes the same `world` devices
+            del sc
+            torch.cuda.synchronize()
+            out["native_multi"] = native_multi_row(min(world, torch.cuda.device_count()), args.mode,
+                                                   max(20, min(args.steps, 100)))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     os.close(real_stdout)
 
 

@@ -93,10 +93,30 @@ int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_de
  * stream) and not synchronised: for callers that keep the hypothesis batch resident (bench.py,
  * multi-GPU sharding).  d_best (nullable) receives 2 ints: {best_index, float bits of best
  * score}.  No allocation happens inside when n_h <= the capacity reserved by
- * pgp_reserve(); otherwise PGP_ESTATE. */
+ * pgp_reserve(); otherwise PGP_ESTATE.
+ * A context serves ONE stream at a time: its workspaces (partials, arg-max key, ticket) are
+ * shared by every queued call, so the *_device calls of one context must all go to the same
+ * stream (or be ordered by the caller's events); different contexts are independent.
+ * pgp_set_scene / pgp_set_model / pgp_set_search_model / a growing pgp_reserve wait for
+ * everything queued on the device (hipDeviceSynchronize) before they replace arrays a queued
+ * launch may still be reading.
+ * Weighted mode: hypotheses within 1.6e-5 of the maximum are re-summed on the device in the
+ * reference's order (sequential float adds in model order, base.cc:1759) and their score entries
+ * overwritten with that value, so best_index is the reference's also under near-ties; all other
+ * weighted scores carry the library's fixed summation tree (within 2e-6 of the reference). */
 int pgp_reserve(pgp_ctx* ctx, int max_hypotheses);
 int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
                          float* d_scores, int* d_counts, int* d_best, void* stream);
+
+/* Arg-max over a COMPLETE score vector assembled from several partial calls (the slices of
+ * several devices after the score all-reduce, or several batches of one object): publishes
+ * d_best = {best_index, float bits of best score} with the rule of base.cc:1891 (lowest index of
+ * the maximum, -1 when the maximum is not > 0) and, in weighted mode, the exact near-tie
+ * settlement described above -- d_T must hold ALL n_h transforms and the context the clouds the
+ * scores were computed on; settled entries of d_scores are overwritten with the reference-order
+ * value.  Device pointers, enqueued on `stream`. */
+int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
+                           float* d_scores, int* d_best, void* stream);
 
 /* Replaces `registered_indices = temp_registered_indices` (base.cc:1897): the scene-point ids
  * matched under ONE transform, in model-point order.  ids has capacity nQ; *n receives the
@@ -245,6 +265,38 @@ int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h
 /* The pose distance alone, for n pairs (test[i], gt[i]) of 4x4 col-major transforms. */
 int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, const float sym_deg[3],
                    float* rot_err_deg, float* trans_err);
+
+/* ---- several GPUs of one node (north_star; SceneCfg.cpp:376-406 and
+ * HypothesisSelection.cpp:248-257 are the consumers) -----------------------------------------------
+ * A pgp_multi is a group of devices in ONE process: one pgp_ctx, one host thread and one stream per
+ * device, the clouds and the index replicated on each.  pgp_multi_score_lcp block-partitions the
+ * n_h hypotheses (pgp_multi_slice: contiguous slices, sizes differing by at most one), every device
+ * scores its slice into a zero-initialised full-length vector, ONE RCCL all-reduce(sum) over xGMI
+ * (scores as float, counts as int32, grouped) leaves every device with all of them, and device 0
+ * takes the arg-max (pgp_settle_best_device) and copies the arrays back.  Outputs are those of
+ * pgp_score_lcp on one device, bit for bit (plain) / with the same summation tree (weighted).
+ * device_ids NULL = devices 0 .. n_dev-1; n_dev <= 0 = every visible device.  RCCL (librccl.so.1)
+ * is bound at run time and only when the group has more than one device (or
+ * PGP_MULTI_FORCE_COLLECTIVE=1).  Calls on one pgp_multi must not overlap. */
+typedef struct pgp_multi pgp_multi;
+int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev);
+int pgp_multi_destroy(pgp_multi* m);
+int pgp_multi_size(const pgp_multi* m);
+pgp_ctx* pgp_multi_context(pgp_multi* m, int k);       /* device k's context, for the other entry points */
+int pgp_multi_slice(int n_total, int k, int n_dev, int* lo, int* hi);   /* host helper: device k's [lo, hi) */
+int pgp_multi_set_scene(pgp_multi* m, const float* xyz, const float* nrm, const float* weight, int n,
+                        float delta);
+int pgp_multi_set_model(pgp_multi* m, const float* xyz, const float* nrm, int n);
+int pgp_multi_score_lcp(pgp_multi* m, const float* T, int n_h, int mode, float gate_deg, float* scores,
+                        int* counts, int* best_index, float* best_score);
+/* The two halves of pgp_multi_score_lcp, for callers that score one resident batch repeatedly
+ * (bench.py): copy the transforms to every device once, then score what is there. */
+int pgp_multi_upload(pgp_multi* m, const float* T, int n_h);
+int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts,
+                             int* best_index, float* best_score);
+/* Host wall clock of the last scoring call in ms: upload (pinned copy + H2D enqueue), enqueue
+ * (kernels + collective issued on every device), total (until the results are back). */
+int pgp_multi_last_timing(pgp_multi* m, float* upload_ms, float* enqueue_ms, float* total_ms);
 
 /* Per-kernel timing for bench.py's roofline line.  enable = N >= 1: every Nth pgp_score_lcp[_device]
  * call (the 1st, N+1st, ...) attaches a start and a stop HIP event to its dominant kernel's dispatch

@@ -46,6 +46,8 @@ SIGNATURES = {
     "pgp_reserve": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_score_lcp_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgp_settle_best_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_registered": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _i, _i]),
     "pgp_running_best": (C.c_int, [_f, C.c_int, _i, _i]),
     "pgp_set_search_model": (C.c_int, [C.c_void_p, _f, C.c_int]),
@@ -69,6 +71,17 @@ SIGNATURES = {
     "pgp_cluster_poses": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, _f, C.POINTER(ClusterParams), _i,
                                     C.c_int, _i, _i]),
     "pgp_pose_error": (C.c_int, [C.c_void_p, _f, _f, C.c_int, _f, _f, _f]),
+    "pgp_multi_create": (C.c_int, [C.POINTER(C.c_void_p), _i, C.c_int]),
+    "pgp_multi_destroy": (C.c_int, [C.c_void_p]),
+    "pgp_multi_size": (C.c_int, [C.c_void_p]),
+    "pgp_multi_context": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "pgp_multi_slice": (C.c_int, [C.c_int, C.c_int, C.c_int, _i, _i]),
+    "pgp_multi_set_scene": (C.c_int, [C.c_void_p, _f, _f, _f, C.c_int, C.c_float]),
+    "pgp_multi_set_model": (C.c_int, [C.c_void_p, _f, _f, C.c_int]),
+    "pgp_multi_score_lcp": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_int, C.c_float, _f, _i, _i, _f]),
+    "pgp_multi_upload": (C.c_int, [C.c_void_p, _f, C.c_int]),
+    "pgp_multi_score_uploaded": (C.c_int, [C.c_void_p, C.c_int, C.c_float, _f, _i, _i, _f]),
+    "pgp_multi_last_timing": (C.c_int, [C.c_void_p, _f, _f, _f]),
     "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),
     "pgp_get_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),

@@ -481,6 +481,17 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     set_error("icp: empty source or target cloud");
     return PGP_EINVAL;
   }
+  // the pose index rides on gridDim.z (<= 65535): larger batches go in slices
+  constexpr int kMaxPoses = 32768;
+  if (n > kMaxPoses) {
+    for (int off = 0; off < n; off += kMaxPoses) {
+      const int m = n - off < kMaxPoses ? n - off : kMaxPoses;
+      int rc = launch_icp(ctx, d_src, n_src, d_tgt, n_tgt, d_T + 16 * (size_t)off, m, prm,
+                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream);
+      if (rc != PGP_OK) return rc;
+    }
+    return PGP_OK;
+  }
   IcpArgs a{};
   a.src = d_src;
   a.tgt = d_tgt;
@@ -545,6 +556,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   for (int it = 0; it < a.max_iter; ++it) {
     hipLaunchKernelGGL(icp_nn_split, gnn, dim3(kNnThreads), 0, stream, a);
     hipLaunchKernelGGL(icp_refine<true>, dim3(n), dim3(kIcpThreads), lds, stream, a);
+    if (it == 0) PGP_HIP(hipGetLastError());   // a bad launch configuration shows on the first pair
     if ((it & 3) == 3) {  // every 4 iterations: has every pose stopped?
       int done = 0;
       PGP_HIP(hipMemcpyAsync(&done, a.n_done, 4, hipMemcpyDeviceToHost, stream));

@@ -527,19 +527,190 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   }
 }
 
+// One model point (Morton position i) under one transform: the scene id it registers to (after
+// the normal gate in weighted mode), or -1.  Per-lane walk of the candidate run.
+template <int MODE>
+__device__ __forceinline__ int point_hit(const ScoreArgs& a, const Xf& m, int i) {
+  const float4 q = a.Q[i];
+  const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
+  const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
+  const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
+  uint32_t s, e;
+  cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
+  e += s;
+  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+  if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
+    const float4 qn = a.Qn[i];
+    const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
+    const float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
+    const float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
+    const float4 pn = a.Pnw[id];
+    const float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+    if (!gate_ok(dot, a.gate_lo, a.gate_hi)) id = -1;
+  }
+  return id;
+}
+
+// One transform, per-model-point result in ORIGINAL model order (the Q arrays are Morton-sorted;
+// q.w carries the original index): hit id after the gate, or -1.
+template <int MODE>
+__global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __restrict__ hits) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.nQ) return;
+  const Xf m = load_xf(a.T, 0);
+  hits[__float_as_int(a.Q[i].w)] = point_hit<MODE>(a, m, i);
+}
+
 // Sum the per-tile partials in tile order, form the score exactly as the reference does
 // (Scalar(good_points)/Scalar(number_of_points), base.cc:1730 / weighted_match/Scalar(n), :1765)
 // and fold the batch arg-max: key = score bits << 32 | ~index, so the maximum key is the highest
 // score at its LOWEST index = what `lcp > best_LCP_` (strict, base.cc:1891) ends on.
 // The last block to finish (ticket) publishes {best index, best score bits} and re-arms the key
 // and the ticket for the next call, so a scoring call is two launches: score + finalize.
-__global__ __launch_bounds__(256) void finalize_scores(const int* __restrict__ partial_cnt,
+//
+// Weighted mode, returned best pose (base.cc:1759,1891): the reference accumulates
+// `weighted_match += w[hit]` sequentially in model order, this library in a fixed tree (per wave,
+// per tile), so two hypotheses whose scores differ by less than that re-association (<= 2e-6
+// observed over 1.4e5 hypotheses) could swap places.  The last block therefore looks for
+// hypotheses within kRefineTol of the maximum; if there is more than one, each of them (in index
+// order, at most kRefineCap) is re-scored EXACTLY as the reference does it -- registered weights
+// scattered to original model order, then ONE lane adds them sequentially in float -- its score
+// entry is overwritten with that value, and the arg-max is taken over the exact values with the
+// reference's strict `>`.  With a single candidate the arg-max cannot depend on the association
+// and nothing more runs.
+constexpr float kRefineTol = 1.6e-5f;   // 8 x the largest tree-vs-sequential deviation observed
+constexpr int kRefineCap = 128;
+constexpr int kSeqChunk = 2048;         // floats staged through LDS per step of the sequential sum
+
+__device__ float refine_exact(const ScoreArgs& a, int h, float* __restrict__ seq, float* s_stage,
+                              float* s_out) {
+  const Xf m = load_xf(a.T, h);
+  const int nQ4 = (a.nQ + 3) & ~3;
+  for (int i = threadIdx.x; i < nQ4; i += blockDim.x) {
+    if (i < a.nQ) {
+      const int id = point_hit<PGP_MODE_WEIGHTED>(a, m, i);
+      // adding +0.0f is the identity on the reference's running sum (which starts at +0.0f)
+      seq[__float_as_int(a.Q[i].w)] = id >= 0 ? a.Pnw[id].w : 0.0f;
+    } else {
+      seq[i] = 0.0f;   // padding up to a multiple of four
+    }
+  }
+  __syncthreads();
+  float S = 0.0f;   // lane 0's running sum (base.cc:1737 `Scalar weighted_match = 0`)
+  for (int c0 = 0; c0 < nQ4; c0 += kSeqChunk) {
+    const int len = min(kSeqChunk, nQ4 - c0);
+    for (int i = threadIdx.x; i < len; i += blockDim.x) s_stage[i] = seq[c0 + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float4* v = reinterpret_cast<const float4*>(s_stage);
+      for (int i = 0; i < len / 4; ++i) {
+        const float4 w = v[i];
+        S = __fadd_rn(S, w.x);
+        S = __fadd_rn(S, w.y);
+        S = __fadd_rn(S, w.z);
+        S = __fadd_rn(S, w.w);
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *s_out = __fdiv_rn(S, (float)a.nQ);   // base.cc:1765
+  __syncthreads();
+  return *s_out;
+}
+
+// Called by all 256 threads of ONE block with kk = the arg-max key over the (tree-summed) score
+// vector: publishes {best index, best score bits}, settling weighted near-ties exactly (above).
+__device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int mode, int refine, float* scores,
+                                   const unsigned long long kk, int* __restrict__ best,
+                                   float* __restrict__ seq, unsigned long long* s_key) {
+  if (kk == 0) {
+    if (threadIdx.x == 0) {
+      best[0] = -1;
+      best[1] = 0;  // best_LCP_ = 0.0f
+    }
+    return;
+  }
+  int bi = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+  float bs = __uint_as_float((unsigned)(kk >> 32));
+  if (mode == PGP_MODE_WEIGHTED && refine) {
+    __shared__ int s_red[4];
+    __shared__ float s_stage[kSeqChunk];
+    __shared__ float s_exact;
+    const float thr = bs - kRefineTol;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < n_h; i += blockDim.x) cnt += scores[i] >= thr ? 1 : 0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) s_red[wave] = cnt;
+    __syncthreads();
+    cnt = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    __syncthreads();
+    if (cnt >= 2) {
+      int cur = -1, done = 0, ebi = -1;
+      float ebest = 0.0f;
+      for (; done < kRefineCap; ++done) {
+        // next candidate in index order
+        int nxt = 0x7FFFFFFF;
+        for (int i = cur + 1 + threadIdx.x; i < n_h; i += blockDim.x)
+          if (scores[i] >= thr) { nxt = i; break; }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) nxt = min(nxt, __shfl_xor(nxt, off, 64));
+        if (lane == 0) s_red[wave] = nxt;
+        __syncthreads();
+        nxt = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+        __syncthreads();
+        if (nxt == 0x7FFFFFFF) break;
+        const float e = refine_exact(a, nxt, seq, s_stage, &s_exact);
+        if (threadIdx.x == 0) scores[nxt] = e;   // the reference's value, bit for bit
+        if (e > ebest) {                          // strict >, ascending index (base.cc:1891)
+          ebest = e;
+          ebi = nxt;
+        }
+        cur = nxt;
+      }
+      // candidates past the cap (pathological: > kRefineCap near-equal hypotheses) keep their
+      // tree-summed values and can only take over with a strictly greater one
+      unsigned long long rest = 0;
+      for (int i = cur + 1 + threadIdx.x; i < n_h; i += blockDim.x) {
+        const float v = scores[i];
+        if (v >= thr && v > ebest) {
+          const unsigned long long kx = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)i);
+          rest = kx > rest ? kx : rest;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) {
+        unsigned long long o = __shfl_xor(rest, off, 64);
+        rest = o > rest ? o : rest;
+      }
+      if (lane == 0) s_key[wave] = rest;
+      __syncthreads();
+      rest = s_key[0];
+      for (int w = 1; w < 4; ++w) rest = s_key[w] > rest ? s_key[w] : rest;
+      if (rest) {
+        ebi = (int)(0xFFFFFFFFu - (unsigned)(rest & 0xFFFFFFFFull));
+        ebest = __uint_as_float((unsigned)(rest >> 32));
+      }
+      if (ebi >= 0) {
+        bi = ebi;
+        bs = ebest;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    best[0] = bi;
+    best[1] = (int)__float_as_uint(bs);
+  }
+}
+
+__global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const int* __restrict__ partial_cnt,
                                                        const float* __restrict__ partial_sum,
-                                                       int n_tiles, int n_h, int nQ, int mode,
-                                                       float* __restrict__ scores,
-                                                       int* __restrict__ counts,
-                                                       unsigned long long* best_key,
-                                                       unsigned int* ticket, int* __restrict__ best) {
+                                                       int n_tiles, int n_h, int nQ, int mode, int refine,
+                                                       float* scores, int* __restrict__ counts,
+                                                       unsigned long long* best_key, unsigned long long* runner_key,
+                                                       unsigned int* ticket, int* __restrict__ best,
+                                                       float* __restrict__ seq) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long key = 0;
   if (h < n_h) {
@@ -555,64 +726,107 @@ __global__ __launch_bounds__(256) void finalize_scores(const int* __restrict__ p
     if (score > 0.f)  // NaN and <= 0 never become best (best_LCP_ starts at 0, strict >)
       key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
   }
+  // block top-2: the wave maximum, then the maximum of what is left (keys > 0 are unique: they carry h)
+  const unsigned long long mykey = key;
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
     unsigned long long o = __shfl_xor(key, off, 64);
     key = o > key ? o : key;
   }
-  __shared__ unsigned long long s_key[4];
-  if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
-  __syncthreads();
+  unsigned long long key2 = mykey == key ? 0ull : mykey;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    unsigned long long o = __shfl_xor(key2, off, 64);
+    key2 = o > key2 ? o : key2;
+  }
+  __shared__ unsigned long long s_key[4], s_key2[4];
+  __shared__ unsigned long long s_kk, s_kk2;
+  __shared__ int s_last;
+  if ((threadIdx.x & 63) == 0) {
+    s_key[threadIdx.x >> 6] = key;
+    s_key2[threadIdx.x >> 6] = key2;
+  }
+  __syncthreads();   // also: every wave's score stores have left the CU (s_waitcnt vmcnt(0) + barrier)
   if (threadIdx.x == 0) {
-    unsigned long long k = s_key[0];
-    for (int w = 1; w < 4; ++w) k = s_key[w] > k ? s_key[w] : k;
-    if (k) atomicMax(best_key, k);   // device-scope atomics: performed at L2, visible to every XCD
+    unsigned long long k = 0, k2 = 0;
+    for (int w = 0; w < 4; ++w) {
+      const unsigned long long a1 = s_key[w], a2 = s_key2[w];
+      if (a1 > k) { k2 = k > a2 ? k : a2; k = a1; }
+      else if (a1 > k2) k2 = a1;
+      // a2 <= a1: it can only displace the runner-up
+      if (a2 > k2 && a2 != k) k2 = a2;
+    }
+    // global top-2 with two atomics per block (device scope: performed at L2, visible to every XCD):
+    // every value except the final maximum is pushed to the runner-up slot, either by the block that
+    // displaced it from the first slot or by its own block when it lost there
+    if (k) {
+      const unsigned long long old = atomicMax(best_key, k);
+      const unsigned long long push = old < k ? old : k;
+      if (push) atomicMax(runner_key, push);
+    }
+    if (k2) atomicMax(runner_key, k2);
     __threadfence();
-    if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
-      __threadfence();
-      const unsigned long long kk = atomicExch(best_key, 0ull);  // read the result and re-arm
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back completes before the ticket
+    const bool last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    if (last) {
+      __threadfence();   // acquire: this CU's L1 holds no stale line of the other blocks' scores
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_kk = atomicExch(best_key, 0ull);  // read the result and re-arm
+      s_kk2 = atomicExch(runner_key, 0ull);
       atomicExch(ticket, 0u);
-      if (kk == 0) {
-        best[0] = -1;
-        best[1] = 0;  // best_LCP_ = 0.0f
-      } else {
-        best[0] = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
-        best[1] = (int)(unsigned)(kk >> 32);
-      }
+    }
+    s_last = last ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- the last block of the launch: publish (and, in weighted mode, settle near-ties exactly) ----
+  const unsigned long long kk = s_kk, kk2 = s_kk2;
+  const bool near_tie = mode == PGP_MODE_WEIGHTED && refine && kk2 != 0ull &&
+                        __uint_as_float((unsigned)(kk2 >> 32)) >= __uint_as_float((unsigned)(kk >> 32)) - kRefineTol;
+  if (near_tie) {
+    settle_and_publish(a, n_h, mode, refine, scores, kk, best, seq, s_key);
+  } else if (threadIdx.x == 0) {
+    if (kk == 0) {
+      best[0] = -1;
+      best[1] = 0;  // best_LCP_ = 0.0f
+    } else {
+      best[0] = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+      best[1] = (int)(unsigned)(kk >> 32);
     }
   }
+}
+
+// The same publication over a COMPLETE score vector that was assembled elsewhere (the slices of
+// several devices after the all-reduce, pgp_settle_best_device): one block finds the arg-max key
+// and settles near-ties with this device's copy of the clouds and the full transform list.
+__global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs a, int n_h, int mode, int refine,
+                                                          float* scores, int* __restrict__ best,
+                                                          float* __restrict__ seq) {
+  __shared__ unsigned long long s_key[4];
+  unsigned long long key = 0;
+  for (int h = threadIdx.x; h < n_h; h += blockDim.x) {
+    const float score = scores[h];
+    if (score > 0.f) {
+      const unsigned long long k = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
+      key = k > key ? k : key;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    unsigned long long o = __shfl_xor(key, off, 64);
+    key = o > key ? o : key;
+  }
+  if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+  __syncthreads();
+  key = s_key[0];
+  for (int w = 1; w < 4; ++w) key = s_key[w] > key ? s_key[w] : key;
+  __syncthreads();
+  settle_and_publish(a, n_h, mode, refine, scores, key, best, seq, s_key);
 }
 
 __global__ void publish_none(int* __restrict__ best) {  // empty hypothesis list (base.cc:1791-1794)
   best[0] = -1;
   best[1] = 0;
-}
-
-// One transform, per-model-point result in ORIGINAL model order (the Q arrays are Morton-sorted;
-// q.w carries the original index): hit id after the gate, or -1.
-template <int MODE>
-__global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __restrict__ hits) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.nQ) return;
-  const Xf m = load_xf(a.T, 0);
-  float4 q = a.Q[i];
-  float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
-  float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
-  float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
-  uint32_t s, e;
-  cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
-  e += s;
-  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
-  if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
-    float4 qn = a.Qn[i];
-    float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
-    float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
-    float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
-    float4 pn = a.Pnw[id];
-    float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
-    if (!gate_ok(dot, a.gate_lo, a.gate_hi)) id = -1;
-  }
-  hits[__float_as_int(q.w)] = id;
 }
 
 // base.cc:1756-1758 evaluated on the host, exactly as the reference evaluates it.
@@ -789,12 +1003,29 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
       ctx->ev_used += 2;
     }
     launch_variant(mode, ctx->unroll, grid, stream, a, ev0, ev1);
-    hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream,
+    hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream, a,
                        (const int*)a.partial_cnt, (const float*)a.partial_sum, a.n_tiles, n_h, a.nQ,
-                       mode, d_scores, d_counts, key, ticket, d_best ? d_best : best_local);
+                       mode, ctx->refine_best ? 1 : 0, d_scores, d_counts, key, key + 3, ticket,
+                       d_best ? d_best : best_local, ctx->d_seq.as<float>());
   } else {
     hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best ? d_best : best_local);
   }
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
+                       int* d_best, hipStream_t stream) {
+  if (n_h <= 0) {
+    hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best);
+    PGP_HIP(hipGetLastError());
+    return PGP_OK;
+  }
+  ScoreArgs a{};
+  int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
+  if (rc != PGP_OK) return rc;
+  hipLaunchKernelGGL(settle_best_kernel, dim3(1), dim3(256), 0, stream, a, n_h, mode, ctx->refine_best ? 1 : 0,
+                     d_scores, d_best, ctx->d_seq.as<float>());
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

@@ -120,6 +120,7 @@ int pgp_create(pgp_ctx** out, int device_id) {
   ctx->device = device_id;
   if (const char* v = getenv("PGP_UNROLL")) ctx->unroll = atoi(v);
   if (const char* v = getenv("PGP_HPB")) ctx->hpb_override = atoi(v);
+  if (const char* v = getenv("PGP_REFINE")) ctx->refine_best = atoi(v) != 0;
   e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
     set_error("hipStreamCreate failed: %s", hipGetErrorString(e));
@@ -147,7 +148,7 @@ int pgp_destroy(pgp_ctx* ctx) {
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
-                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_Qs, &ctx->d_ids,
+                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
@@ -234,6 +235,8 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
     return PGP_EINVAL;
   }
   DeviceGuard guard(ctx->device);
+  // *_device calls may still be queued on the caller's stream and read the arrays replaced below
+  PGP_HIP(hipDeviceSynchronize());
   ctx->has_index = false;
   ctx->nP = n;
   ctx->has_scene_normals = nrm != nullptr;
@@ -262,6 +265,7 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
     return PGP_EINVAL;
   }
   DeviceGuard guard(ctx->device);
+  PGP_HIP(hipDeviceSynchronize());   // see pgp_set_scene
   ctx->nQ = n;
   ctx->has_model_normals = nrm != nullptr;
   // Morton order: neighbouring lanes hold neighbouring model points, so under any rigid
@@ -303,6 +307,7 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
   if ((rc = ctx->d_Q.ensure(hq.size() * sizeof(float4))) != PGP_OK) return rc;
   if ((rc = ctx->d_Qn.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
   if ((rc = ctx->d_hits.ensure(hq.size() * sizeof(int))) != PGP_OK) return rc;
+  if ((rc = ctx->d_seq.ensure((hq.size() + 4) * sizeof(float))) != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(ctx->d_Q.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipMemcpyAsync(ctx->d_Qn.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipStreamSynchronize(ctx->stream));
@@ -322,6 +327,7 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
   }
   DeviceGuard guard(ctx->device);
   if (max_hypotheses <= ctx->cap_h) return PGP_OK;
+  PGP_HIP(hipDeviceSynchronize());   // the workspaces replaced below may be in use by queued launches
   int rc;
   size_t cap = (size_t)max_hypotheses;
   size_t tiles = (size_t)tiles_for(ctx->nQ);
@@ -342,6 +348,16 @@ int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, floa
   DeviceGuard guard(ctx->device);
   return launch_score(ctx, d_T, n_h, mode, gate_deg, d_scores, d_counts, d_best,
                       static_cast<hipStream_t>(stream));
+}
+
+int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
+                           float* d_scores, int* d_best, void* stream) {
+  if (!ctx || n_h < 0 || !d_best || (n_h > 0 && (!d_T || !d_scores))) {
+    set_error("pgp_settle_best_device: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_settle_best(ctx, d_T, n_h, mode, gate_deg, d_scores, d_best, static_cast<hipStream_t>(stream));
 }
 
 int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_deg, float* scores,
@@ -442,6 +458,7 @@ int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
     return PGP_EINVAL;
   }
   DeviceGuard guard(ctx->device);
+  PGP_HIP(hipDeviceSynchronize());   // see pgp_set_scene
   std::vector<float4> hq((size_t)std::max(n, 1));
   for (int i = 0; i < n; ++i)
     hq[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],

@@ -101,6 +101,8 @@ struct pgp_ctx {
   pgp::DevBuf d_counts;   // [cap_h] int
   pgp::DevBuf d_best;     // 2 x uint64 packed argmax + {index, score bits}
   pgp::DevBuf d_hits;     // [nQ] int (pgp_registered)
+  pgp::DevBuf d_seq;      // [nQ rounded up to 4] float: registered weights in original model order
+                          // (finalize_scores' exact re-score of near-best hypotheses)
 
   // pinned host staging for the host-pointer scoring call (transforms in, scores | counts | best out)
   void* h_pin = nullptr;
@@ -110,6 +112,7 @@ struct pgp_ctx {
   // tuning knobs (env PGP_UNROLL / PGP_HPB at pgp_create; defaults chosen by measurement)
   int unroll = 0;      // <= 0: wave-flattened candidate phase (default); > 0: per-lane walk
   int hpb_override = 0;
+  bool refine_best = true;   // PGP_REFINE=0 switches the exact near-tie re-score off (timing A/B only)
 
   // optional per-kernel timing (pgp_set_kernel_timing)
   int timing = 0;               // 0 off, N >= 1: every Nth scoring launch carries start/stop events
@@ -148,6 +151,8 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
 int tiles_for(int nQ);
 int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
                  float* d_scores, int* d_counts, int* d_best, hipStream_t stream);
+int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
+                       int* d_best, hipStream_t stream);
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream);
 void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);

@@ -303,6 +303,22 @@ class LcpScorer:
             C.c_void_p(d_best.data_ptr()) if d_best is not None else None,
             C.c_void_p(stream)))
 
+    def settle_best_device(self, d_T, d_scores, d_best, mode=PGP_MODE_WEIGHTED, gate_deg=30.0, stream=None):
+        """Arg-max (+ exact weighted near-tie settlement) over a complete device score vector that was
+        assembled from several calls / several ranks; d_T holds ALL its transforms."""
+        import torch
+        n_h = int(d_T.shape[0])
+        assert d_T.is_cuda and d_T.dtype == torch.float32 and d_T.is_contiguous()
+        assert d_scores.is_cuda and d_scores.dtype == torch.float32 and d_scores.is_contiguous() and d_scores.numel() >= n_h
+        assert d_best.is_cuda and d_best.dtype == torch.int32 and d_best.numel() >= 2
+        if stream is None:
+            stream = torch.cuda.current_stream(d_T.device).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        _lib.check(self._lib.pgp_settle_best_device(
+            self._h, C.c_void_p(d_T.data_ptr()), n_h, int(mode), C.c_float(gate_deg),
+            C.c_void_p(d_scores.data_ptr()), C.c_void_p(d_best.data_ptr()), C.c_void_p(stream)))
+
     def set_kernel_timing(self, enable=True):
         """True / 1: time every scoring launch; N > 1: every Nth; False / 0: off."""
         _lib.check(self._lib.pgp_set_kernel_timing(self._h, int(enable)))
@@ -317,3 +333,73 @@ class LcpScorer:
         info = _lib.IndexInfo()
         _lib.check(self._lib.pgp_get_index_info(self._h, C.byref(info)))
         return {k: getattr(info, k) for k, _ in info._fields_}
+
+
+class MultiGpuScorer:
+    """One (scene, model) pair replicated on several GPUs of the node, hypotheses block-partitioned,
+    scores combined with one RCCL all-reduce inside libpgp.so (pgp_multi_*, csrc/multi_gpu.hip):
+    the single-process form of the sharding the node's callers see (SceneCfg.cpp:376-406)."""
+
+    def __init__(self, device_ids=None):
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        if device_ids is None:
+            ids, n = None, 0
+        else:
+            arr = np.ascontiguousarray(device_ids, np.int32)
+            ids, n = arr.ctypes.data_as(_i), len(arr)
+        _lib.check(self._lib.pgp_multi_create(C.byref(h), ids, n))
+        self._h = h
+        self.n_devices = int(self._lib.pgp_multi_size(h))
+        self.nQ = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pgp_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def slice_of(n_total, k, n_dev):
+        lo, hi = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().pgp_multi_slice(int(n_total), int(k), int(n_dev), C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def init(self, P_xyz, P_nrm, P_w, Q_xyz, Q_nrm, delta=0.005):
+        xyz, nrm, w = _f32(P_xyz, 3), _f32(P_nrm, 3), _f32(P_w)
+        _lib.check(self._lib.pgp_multi_set_scene(self._h, _fp(xyz), _fp(nrm), _fp(w), len(xyz), C.c_float(delta)))
+        q, qn = _f32(Q_xyz, 3), _f32(Q_nrm, 3)
+        _lib.check(self._lib.pgp_multi_set_model(self._h, _fp(q), _fp(qn), len(q)))
+        self.nQ = len(q)
+
+    def _out(self, n_h):
+        return np.zeros(n_h, np.float32), np.zeros(n_h, np.int32), C.c_int(-1), C.c_float(0)
+
+    def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
+        """Same contract as LcpScorer.score: (scores, counts, best_index, best_score)."""
+        T = _f32(T, 16)
+        s, c, bi, bs = self._out(len(T))
+        _lib.check(self._lib.pgp_multi_score_lcp(self._h, _fp(T), len(T), int(mode), C.c_float(gate_deg), _fp(s),
+                                                 c.ctypes.data_as(_i), C.byref(bi), C.byref(bs)))
+        return s, c, bi.value, float(np.float32(bs.value))
+
+    def upload(self, T):
+        T = _f32(T, 16)
+        _lib.check(self._lib.pgp_multi_upload(self._h, _fp(T), len(T)))
+        self._n_up = len(T)
+
+    def score_uploaded(self, mode=PGP_MODE_PLAIN, gate_deg=30.0):
+        s, c, bi, bs = self._out(self._n_up)
+        _lib.check(self._lib.pgp_multi_score_uploaded(self._h, int(mode), C.c_float(gate_deg), _fp(s),
+                                                      c.ctypes.data_as(_i), C.byref(bi), C.byref(bs)))
+        return s, c, bi.value, float(np.float32(bs.value))
+
+    def last_timing(self):
+        a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
+        _lib.check(self._lib.pgp_multi_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"upload_ms": a.value, "enqueue_ms": b.value, "total_ms": c.value}

@@ -652,6 +652,7 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   std::vector<int> selected(n_h > 0 ? n_h : 1);
   int n_sel = 0;
   pgp_running_best(lcp.data(), n_h, selected.data(), &n_sel);
+  hypothesisSet.clear();   // the reference REPLACES the list by the running-best subsequence (allPose.clear(), base.cc:1903)
   for (int k = 0; k < n_sel; ++k) hypothesisSet.push_back(allPose[selected[k]]);  // base.cc:1903-1908
   if (best >= 0) {
     bestHypothesis = std::make_pair(allPose[best].first, best_lcp);

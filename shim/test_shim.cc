@@ -2,6 +2,8 @@
 // (PPE/hypothesis_generation/ObjectPoseCandidateSet.cpp:53-68 + PPE/data_layer/Objects.cpp:31-49):
 // loads PPFMap.txt the way Objects::readPPFMap does, calls getProbableTransformsSuper4PCS exactly
 // as CongruentSetMatching::generate does, and prints the outputs for tests/test_shim_gpu.py.
+#include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -50,21 +52,39 @@ int main(int argc, char** argv) {
   best.second = 0;
   std::vector<std::pair<Eigen::Isometry3d, float> > hyps;
   std::vector<int> registered;
-  if (std::getenv("SHIM_TEST_INMEMORY")) {
-    std::vector<float> sx, sn, vx, vn, qx, qn;
-    std::vector<unsigned short> px;
-    int rows = 0, cols = 0;
-    if (!super4pcs_shim_read_ply(argv[1], sx, sn) || !super4pcs_shim_read_ply(argv[2], vx, vn) ||
-        !super4pcs_shim_read_ply(argv[3], qx, qn)) return 3;
-    const bool have = super4pcs_shim_read_png16(argv[4], px, rows, cols);
-    const Super4PCSCloudView s = {sx.data(), sn.data(), (int)(sx.size() / 3)};
-    const Super4PCSCloudView v = {vx.data(), vn.data(), (int)(vx.size() / 3)};
-    const Super4PCSCloudView q = {qx.data(), qn.data(), (int)(qx.size() / 3)};
-    getProbableTransformsSuper4PCS(s, v, q, have ? px.data() : nullptr, rows, cols, best, hyps, PPFMap, K, registered);
-  } else {
-    getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMap, 0, K, "synthetic_object",
-                                   "./", registered);
+  // SHIM_TEST_REPEAT=n: the same call n times in one process (bench.py's drop_in row: the first call
+  // pays context creation and the code-object load); every call starts from fresh output containers
+  const int repeat = std::getenv("SHIM_TEST_REPEAT") ? std::max(1, std::atoi(std::getenv("SHIM_TEST_REPEAT"))) : 1;
+  std::vector<double> elapsed;
+  for (int rep = 0; rep < repeat; ++rep) {
+    best.first.matrix().setIdentity();
+    best.second = 0;
+    hyps.clear();
+    registered.clear();
+    if (std::getenv("PGP_SHIM_SEED")) std::srand((unsigned)std::atoi(std::getenv("PGP_SHIM_SEED")));
+    const auto t0 = std::chrono::steady_clock::now();
+    if (std::getenv("SHIM_TEST_INMEMORY")) {
+      std::vector<float> sx, sn, vx, vn, qx, qn;
+      std::vector<unsigned short> px;
+      int rows = 0, cols = 0;
+      if (!super4pcs_shim_read_ply(argv[1], sx, sn) || !super4pcs_shim_read_ply(argv[2], vx, vn) ||
+          !super4pcs_shim_read_ply(argv[3], qx, qn)) return 3;
+      const bool have = super4pcs_shim_read_png16(argv[4], px, rows, cols);
+      const Super4PCSCloudView s = {sx.data(), sn.data(), (int)(sx.size() / 3)};
+      const Super4PCSCloudView v = {vx.data(), vn.data(), (int)(vx.size() / 3)};
+      const Super4PCSCloudView q = {qx.data(), qn.data(), (int)(qx.size() / 3)};
+      const auto t1 = std::chrono::steady_clock::now();   // the in-memory caller holds its clouds already
+      getProbableTransformsSuper4PCS(s, v, q, have ? px.data() : nullptr, rows, cols, best, hyps, PPFMap, K, registered);
+      elapsed.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    } else {
+      getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMap, 0, K, "synthetic_object",
+                                     "./", registered);
+      elapsed.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
   }
+  std::printf("ELAPSED_MS");
+  for (double e : elapsed) std::printf(" %.3f", e);
+  std::printf("\n");
   std::printf("PPFMAP %zu\n", PPFMap.size());
   std::printf("BEST_SCORE %.9g\n", best.second);
   std::printf("BEST_POSE");

@@ -181,6 +181,107 @@ def main():
     ply_reader_case()
     weights_case()
     test_scene_case()
+    near_ties_case()
+
+
+def morton_order(Q):
+    """The order pgp_set_model (csrc/pgp_api.hip) puts the validation model in (float32 arithmetic)."""
+    Q = np.ascontiguousarray(Q, np.float32)
+    mn, mx = Q.min(0), Q.max(0)
+    scale = np.where(mx > mn, np.float32(1023.0) / (mx - mn), np.float32(0)).astype(np.float32)
+    c = np.clip(((Q - mn) * scale).astype(np.float32), 0, 1023).astype(np.uint32)
+
+    def spread(v):
+        v = v & 1023
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        v = (v | (v << 2)) & 0x09249249
+        return v
+    code = spread(c[:, 0]) | (spread(c[:, 1]) << 1) | (spread(c[:, 2]) << 2)
+    return np.lexsort((np.arange(len(Q)), code))
+
+
+def tree_sum_score(wq, order):
+    """Emulates the association of the HIP kernel's weighted sum (csrc/lcp_score.hip: wave_sum DPP
+    tree per 64 lanes, 4 waves per 256-point tile added in order, tiles added in order) for per-
+    model-point registered weights wq (0 where nothing registered).  Used only to PICK a fixture on
+    which a tree-summed arg-max differs from the reference's sequential one."""
+    f32 = np.float32
+    nQ = len(wq)
+    v = np.zeros((nQ + 255) // 256 * 256, f32)
+    v[:nQ] = wq[order]
+    v = v.reshape(-1, 64).copy()
+    i = np.arange(64)
+    for perm in (i ^ 1, i ^ 2, (i & ~7) | (7 - (i & 7)), (i & ~15) | (15 - (i & 15))):
+        v = (v + v[:, perm]).astype(f32)
+    ws = ((v[:, 0] + v[:, 16]).astype(f32) + (v[:, 32] + v[:, 48]).astype(f32)).astype(f32)
+    total = f32(0)
+    for t in ws.reshape(-1, 4):
+        f = f32(0)
+        for x in t:
+            f = f32(f + x)
+        total = f32(total + f)
+    return f32(total / f32(nQ))
+
+
+def near_ties_case():
+    """(14) returned best pose under near-ties (base.cc:1759,1891): hypotheses whose weighted scores
+    differ by less than the re-association error of a parallel sum.  6000 small perturbations of the
+    ground-truth pose are scored by the reference harness; a cluster of DISTINCT scores within 3e-6 is
+    made the top of a 256-hypothesis batch (everything scoring higher is dropped), chosen so that the
+    emulated tree sum of the HIP kernel puts a different hypothesis first than the reference's
+    sequential sum does.  Expected outputs are the harness's (sequential) scores / best / running best."""
+    rng = np.random.default_rng(20261101)
+    w = synth.make_workload(6000, 1200, 4, config_id=130)
+    Pw = rng.uniform(0.05, 1.0, len(w.P_xyz)).astype(np.float32)
+    Tg = w.T_gt.reshape(4, 4).T.astype(np.float64)
+    T = np.array([synth.colmajor16(Tg @ synth._se3(synth._random_rot(rng, np.deg2rad(1.5)),
+                                                   0.0008 * rng.standard_normal(3))) for _ in range(6000)], np.float32)
+    ref = Ref(w.P_xyz, w.P_nrm, Pw, w.Q_xyz, w.Q_nrm)
+    order = morton_order(w.Q_xyz)
+    seq, tree = np.zeros(len(T), np.float32), np.zeros(len(T), np.float32)
+    ok = np.zeros(len(T), bool)
+    for h in range(len(T)):
+        ws, reg = ref.weighted_verify(T[h], w.delta)
+        _, _, hits = ref.verify(T[h], w.delta)
+        wq, p = np.zeros(len(w.Q_xyz), np.float32), 0
+        for q in np.flatnonzero(hits >= 0):     # reg is the gated subsequence of the plain hits
+            if p < len(reg) and reg[p] == hits[q]:
+                wq[q] = Pw[hits[q]]
+                p += 1
+        s = np.float32(0)
+        for x in wq[wq != 0]:
+            s = np.float32(s + x)
+        seq[h] = ws
+        ok[h] = p == len(reg) and np.float32(s / np.float32(len(wq))) == np.float32(ws)
+        tree[h] = tree_sum_score(wq, order)
+    print("near_ties: per-point weights reconstructed for", int(ok.sum()), "of", len(T),
+          "max |tree - sequential| =", float(np.abs(tree - seq)[ok].max()))
+    idx = np.flatnonzero(ok)
+    idx = idx[np.argsort(seq[idx], kind="stable")]
+    pick = None
+    for e in range(len(idx) - 1, 200, -1):          # candidate top, from the highest score down
+        top = idx[e]
+        grp = [j for j in idx[max(0, e - 12):e + 1] if seq[top] - seq[j] <= 3e-6]
+        if len(grp) < 3 or len(set(seq[grp].tolist())) < 3:
+            continue
+        t_best = max(grp, key=lambda j: (tree[j], -j))
+        if tree[t_best] > tree[top] or (tree[t_best] == tree[top] and t_best != top):
+            pick = (e, grp, t_best)
+            break
+    assert pick is not None, "no near-tie cluster with a flipping tree sum found"
+    e, grp, t_best = pick
+    rest = rng.choice(idx[:e - len(grp)], 256 - len(grp), replace=False)
+    sel = rng.permutation(np.concatenate([np.array(grp), rest]))
+    Tsel = T[sel]
+    run_case("near_ties", w.P_xyz, w.P_nrm, Pw, w.Q_xyz, w.Q_nrm, Tsel, w.delta,
+             extra={"tree_scores": tree[sel], "cluster": np.flatnonzero(np.isin(sel, grp)).astype(np.int32)})
+    g = np.load(os.path.join(HERE, "near_ties.npz"))
+    tb = int(np.argmax(g["tree_scores"]))
+    print("near_ties: cluster", g["cluster"], "sequential scores", g["wscores"][g["cluster"]],
+          "tree scores", g["tree_scores"][g["cluster"]], "reference best", int(g["best_weighted"]), "tree best", tb)
+    assert tb != int(g["best_weighted"])
 
 
 def weights_case():
@@ -384,6 +485,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "test_scene":
         test_scene_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "near_ties":
+        near_ties_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "weights":
         weights_case()

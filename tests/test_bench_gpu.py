@@ -23,10 +23,19 @@ def _check(line, n):
     assert d["unit"] == "hypotheses/s" and d["higher_is_better"] is True and d["scaling"] == "weak"
     assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "f32"
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert "weighted" in d["config"]["mode"] and d["config"]["distinct_batches"] >= 8   # the live mode, rotating batches
     r = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_model", "counters"):
         assert k in r
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"] == "score_hypotheses_flat<1>"
+    if r["bound"] is not None:      # counters collected on this very kernel source (profiles/pmc_current.json)
+        assert r["bound"] in r["units"] and 0.0 < r["frac"] <= 1.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        assert all(0.0 < u["frac"] <= 1.0 for u in r["units"].values())
+        assert r["traffic"] is None or r["traffic"] > 0
+    else:
+        assert r["frac"] is None and "withheld" in r["counters"] or "missing" in r["counters"]
+    assert "NON-BINDING" in r["algorithmic_model"]["note"]
     assert d["value"] > 1e6 and r["launches"] == 1 and r["timed_every"] == 8   # steps 6: launch 0 is timed
     return d
 
@@ -39,6 +48,7 @@ def test_single_gpu_line():
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     assert len(lines) == 1
     d = _check(lines[0], 1)
+    assert "plain_lcp" in d["other_rows"] and "drop_in" in d["other_rows"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     if cb["kind"] == "reference":               # the prebuilt oracle/_ref travelled along
@@ -57,6 +67,8 @@ def test_two_ranks_on_one_gpu_functional():
     assert len(lines) == 1                      # rank 0 only
     d = _check(lines[0], 2)
     assert "cpu_baseline" not in d              # N = 1 only
+    pc = d["per_call"]                          # the unbucketed latency form next to the throughput form
+    assert pc["ms_per_step"] > 0 and pc["value"] > 0 and "all-reduce" in pc["form"]
 
 
 def test_one_rank_through_rccl():
@@ -69,4 +81,5 @@ def test_one_rank_through_rccl():
     lines = out.stdout.splitlines()          # the contract: stdout is ONE JSON line, nothing else
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     assert len(lines) == 1
-    _check(lines[0], 1)
+    d = _check(lines[0], 1)
+    assert d["per_call"]["ms_per_step"] > 0

@@ -12,7 +12,7 @@ from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-               if os.path.basename(p).startswith(("scene_", "boundary", "normal_gate", "duplicates")))
+               if os.path.basename(p).startswith(("scene_", "boundary", "normal_gate", "duplicates", "near_ties")))
 
 
 @pytest.mark.parametrize("name", CASES)
@@ -38,7 +38,14 @@ def test_hip_matches_golden(name):
     s, c, bi, bs = sc.score(g["T"], PGP_MODE_WEIGHTED, 30.0)
     assert np.allclose(s, g["wscores"], rtol=0, atol=2e-6)
     assert np.array_equal(c, np.diff(g["reg_off"]).astype(np.int32))
-    assert abs(bs - g["wscores"][int(g["best_weighted"])]) <= 2e-6
+    # the returned best pose is the reference's (base.cc:1891), near-ties included: hypotheses within
+    # 1.6e-5 of the maximum are re-summed in the reference's order on the device (finalize_scores)
+    assert bi == int(g["best_weighted"])
+    assert abs(bs - g["wscores"][bi]) <= 2e-6
+    if name == "near_ties":
+        cl = g["cluster"]
+        assert int(np.argmax(g["tree_scores"])) != bi          # a tree-summed arg-max would differ
+        assert np.array_equal(s[cl], g["wscores"][cl]) and np.float32(bs) == g["wscores"][bi]   # exact
     for h, T in enumerate(g["T"]):
         reg = g["reg_flat"][g["reg_off"][h]:g["reg_off"][h + 1]]
         assert np.array_equal(sc.registered(T, PGP_MODE_WEIGHTED, 30.0), reg)

@@ -35,7 +35,7 @@ def _check(w, scorer=None, threads=8, check_registered=4):
     assert np.allclose(s, so, rtol=0, atol=W_TOL), np.abs(s - so).max()
     if bio >= 0:
         assert abs(bs - so[bio]) <= W_TOL
-        assert so[bi] >= so[bio] - W_TOL
+        assert bi == bio   # near-ties are settled in the reference's summation order on the device
     for h in list(range(min(check_registered, w.n_h))) + ([bio] if bio >= 0 else []):
         ws, reg = orc.weighted_verify(w.T[h], w.delta, w.gate_deg)
         assert np.array_equal(sc.registered(w.T[h], PGP_MODE_WEIGHTED, w.gate_deg), reg)

@@ -12,7 +12,7 @@ from _checkers import Oracle
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLD, "*.npz"))
-               if os.path.basename(p).startswith(("scene_", "boundary", "normal_gate", "duplicates")))
+               if os.path.basename(p).startswith(("scene_", "boundary", "normal_gate", "duplicates", "near_ties")))
 
 
 def load(name):

@@ -105,3 +105,48 @@ def test_sharded_equals_unsharded(world, n_h):
             assert np.array_equal(p, s_ref[:n])
             exp = int(np.argmax(s_ref[:n])) if s_ref[:n].max() > 0 else -1
             assert obi == exp
+
+
+def _bucket_worker(rank, world, port, n_local, n_batches, bucket, q):
+    from physimglobalpose_amd.sharding import BucketedExchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ex = BucketedExchange(n_local, rank, world, "cpu", bucket=bucket)
+        seen = []
+        for b in range(n_batches):
+            g = torch.Generator().manual_seed(1000 * b + rank)
+            ex.slot().copy_(torch.rand(n_local, generator=g))    # "scoring" this rank's slice of batch b
+            ex.commit()
+            if ex.argmax is not None:
+                seen.append(ex.argmax.clone())
+        ex.drain()
+        q.put((rank, ex.last_vector().numpy().copy(), ex.argmax.numpy().copy(), len(seen)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket,n_batches", [(1, 3), (4, 10), (8, 8)])
+def test_bucketed_exchange_gathers_every_batch(bucket, n_batches):
+    """The pipelined exchange bench.py times (two alternating buckets, one all-reduce per bucket):
+    after drain() the last batch's vector holds every rank's slice and the arg-max is the global one."""
+    world, n_local = 2, 33
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bucket_worker, args=(r, world, port, n_local, n_batches, bucket, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    b = n_batches - 1
+    want = torch.cat([torch.rand(n_local, generator=torch.Generator().manual_seed(1000 * b + r))
+                      for r in range(world)]).numpy()
+    for rank, vec, am, n_seen in results:
+        assert np.array_equal(vec, want), f"rank {rank}"
+        j = b % bucket
+        assert int(am[j]) == int(np.argmax(want))

@@ -16,86 +16,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "shim", "test_shim")
 
 
-def write_ply(path, xyz, nrm, binary):
-    """PointXYZRGBNormal layout of pcl::io::savePLYFile: x y z red green blue nx ny nz curvature."""
-    n = len(xyz)
-    hdr = ("ply\nformat %s 1.0\ncomment PCL generated\nelement vertex %d\nproperty float x\nproperty float y\n"
-           "property float z\nproperty uchar red\nproperty uchar green\nproperty uchar blue\nproperty float nx\n"
-           "property float ny\nproperty float nz\nproperty float curvature\nelement camera 1\n"
-           "property float view_px\nend_header\n") % ("binary_little_endian" if binary else "ascii", n)
-    with open(path, "wb") as f:
-        f.write(hdr.encode())
-        if binary:
-            rec = np.zeros(n, dtype=[("p", "<f4", 3), ("c", "u1", 3), ("n", "<f4", 3), ("k", "<f4")])
-            rec["p"], rec["n"], rec["c"] = xyz, nrm, 128
-            f.write(rec.tobytes())
-            f.write(np.zeros(1, "<f4").tobytes())
-        else:
-            for p, q in zip(xyz, nrm):
-                f.write(("%.9g %.9g %.9g 128 128 128 %.9g %.9g %.9g 0\n" % (*p, *q)).encode())
-            f.write(b"0\n")
-
-
-def ppf_map(P, N, trans_disc=5, rot_disc=10):
-    """Model pair-feature table in the layout of PPFMap.txt (PPE/data_layer/Objects.cpp:31-49), with
-    the features of Match4PCSBase::computePPF (base.cc:582-598) for every ordered pair."""
-    P, N = P.astype(np.float32), N.astype(np.float32)
-    n = len(P)
-    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
-    m = i != j
-    i, j = i[m], j[m]
-    u = P[i] - P[j]
-
-    def ang(a, b):
-        return (np.arctan2(np.linalg.norm(np.cross(a, b), axis=1).astype(np.float32),
-                           np.einsum("ij,ij->i", a, b).astype(np.float32)) * np.float32(180) / np.pi).astype(np.int64)
-
-    def abin(v, d):
-        lo = v - v % d
-        return np.where(v - lo < lo + d - v, lo, lo + d)
-
-    f = np.stack([abin((np.linalg.norm(u, axis=1).astype(np.float32) * np.float32(1000)).astype(np.int64), trans_disc),
-                  abin(ang(N[i], u), rot_disc), abin(ang(N[j], u), rot_disc), abin(ang(N[i], N[j]), rot_disc)], 1)
-    table = {}
-    for key, a, b in zip(map(tuple, f.tolist()), i.tolist(), j.tolist()):
-        table.setdefault(key, []).append((a, b))
-    return table
+from _dropin import make_dropin_case, ppf_map, write_ply  # noqa: F401
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
 @pytest.mark.parametrize("binary", [False, True])
 def test_drop_in_symbol_recovers_the_pose(tmp_path, binary):
-    from PIL import Image
-    w = synth.make_workload(8000, 1500, 4, config_id=91, n_search=800)
-    # a segment as the node produces it: mostly the object, some clutter around it
-    rng = np.random.default_rng(0)
-    obj = np.flatnonzero(w.P_w == 1.0)
-    clutter = rng.choice(np.flatnonzero(w.P_w < 1.0), 1500, replace=False)
-    keep = np.sort(np.concatenate([obj, clutter]))
-    w.P_xyz, w.P_nrm, w.P_w = w.P_xyz[keep], w.P_nrm[keep], w.P_w[keep]
-    # world-frame clouds, as the node hands them over
-    P = w.P_xyz + w.centroid_P
-    Qv = w.Q_xyz + w.centroid_Q
-    Qs = w.Qs_xyz + w.centroid_Q
-    seg, val, search = (str(tmp_path / n) for n in ("pclSegment.ply", "pclModel.ply", "pclModelSampled.ply"))
-    write_ply(seg, P, w.P_nrm, binary)
-    write_ply(val, Qv, w.Q_nrm, binary)
-    write_ply(search, Qs, w.Qs_nrm, binary)
-    fx = fy = 600.0
-    cx, cy = 320.0, 240.0
-    img = np.zeros((480, 640), np.uint16)
-    col = (fx * P[:, 0] / P[:, 2] + cx).astype(int)
-    row = (fy * P[:, 1] / P[:, 2] + cy).astype(int)
-    ok = (row >= 0) & (row < 480) & (col >= 0) & (col < 640)
-    order = np.argsort(w.P_w[ok])                       # object pixels (w = 1) are written last
-    img[row[ok][order], col[ok][order]] = np.round(w.P_w[ok][order] * 10000).astype(np.uint16)
-    png = str(tmp_path / "prob.png")
-    Image.fromarray(img).save(png)
-    table = ppf_map(Qs, w.Qs_nrm)
-    ppf = str(tmp_path / "PPFMap.txt")
-    with open(ppf, "w") as f:
-        for key, pairs in table.items():
-            f.write("%d %d %d %d %d %s\n" % (*key, len(pairs), " ".join("%d %d" % p for p in pairs)))
+    argv, case = make_dropin_case(tmp_path, binary)
+    w, P, Qv, Qs, table = case["w"], case["P"], case["Qv"], case["Qs"], case["table"]
+    seg, val, search, png, ppf, fx, fy, cx, cy = argv
     env = dict(os.environ, PGP_SHIM_SEED="12345", PGP_SHIM_VERBOSE="1")
     out = subprocess.run([BIN, seg, val, search, png, ppf, str(fx), str(fy), str(cx), str(cy)], env=env,
                          capture_output=True, text=True, timeout=600)
@@ -104,7 +33,9 @@ def test_drop_in_symbol_recovers_the_pose(tmp_path, binary):
     out_mem = subprocess.run([BIN, seg, val, search, png, ppf, str(fx), str(fy), str(cx), str(cy)],
                              env=dict(env, SHIM_TEST_INMEMORY="1"), capture_output=True, text=True, timeout=600)
     assert out_mem.returncode == 0, out_mem.stderr[-2000:]
-    assert out_mem.stdout == out.stdout
+    def strip(t):   # wall-clock line aside, the two hand-offs print the same result
+        return [l for l in t.splitlines() if not l.startswith("ELAPSED_MS")]
+    assert strip(out_mem.stdout) == strip(out.stdout)
     lines = {l.split()[0]: l.split()[1:] for l in out.stdout.splitlines() if l and l[0].isupper()}
     assert int(lines["PPFMAP"][0]) == len(table)
     score = float(lines["BEST_SCORE"][0])
