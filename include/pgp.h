@@ -100,10 +100,12 @@ int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_de
  * pgp_set_scene / pgp_set_model / pgp_set_search_model / a growing pgp_reserve wait for
  * everything queued on the device (hipDeviceSynchronize) before they replace arrays a queued
  * launch may still be reading.
- * Weighted mode: hypotheses within 1.6e-5 of the maximum are re-summed on the device in the
- * reference's order (sequential float adds in model order, base.cc:1759) and their score entries
- * overwritten with that value, so best_index is the reference's also under near-ties; all other
- * weighted scores carry the library's fixed summation tree (within 2e-6 of the reference). */
+ * Weighted mode: hypotheses within 4.1 * 2^-24 * sqrt(nQ) * best_score of the maximum (ten standard
+ * deviations of the reference's own summation error; 6.2e-6 at 5000 model points) are re-summed on
+ * the device in the reference's order (sequential float adds in model order, base.cc:1759) and
+ * their score entries overwritten with that value, so best_index is the reference's also under
+ * near-ties; all other weighted scores carry the library's fixed summation tree (within 2e-6 of
+ * the reference at those sizes). */
 int pgp_reserve(pgp_ctx* ctx, int max_hypotheses);
 int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
                          float* d_scores, int* d_counts, int* d_best, void* stream);
@@ -142,6 +144,41 @@ int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info);
 /* Replaces `sampled_Q_3D_ = Q` (base.cc:236): the sparse search model whose points the
  * congruent quads index.  Host pointer, synchronous. */
 int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n);
+
+/* ---- Step 1 of Perform_N_steps: stochastic base selection (base.cc:600-792) on the device -------
+ * pgp_set_ppf_map replaces the node's hand-over of the model's pair-feature table
+ * (std::map<std::vector<int>, std::vector<std::pair<int,int>>> PPFMap, PPE/data_layer/Objects.cpp:31-49;
+ * parameter of getProbableTransformsSuper4PCS): keys[n_keys][4] = the discretised features
+ * (computePPF + approximate_bin, base.cc:582-598,150-160), counts[n_keys] (nullable) and
+ * pairs[sum(counts)][2] (nullable) the pair list of every key in key order (ids into the search
+ * model).  The first occurrence of a key counts, as std::map::insert.  The keys become a device
+ * hash set; the ratio thresholds that stand in for atan2f are measured on the host's libm here. */
+int pgp_set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);
+
+/* Replaces n_attempts calls of Match4PCSBase::SelectQuadrilateralStoCS (base.cc:600-792; the
+ * reference seeds a fresh engine per call, so attempts are independent) + TryQuadrilateral
+ * (:415-464) in ONE launch, on the scene set by pgp_set_scene (positions, normals, weights =
+ * orig_probabilities_) and the table set by pgp_set_ppf_map.  u[n_attempts][4]: the uniform variates
+ * in [0,1) of the four std::discrete_distribution draws, taken by the CALLER from its own engine
+ * (std::generate_canonical<double, 53>, what discrete_distribution::operator() consumes).
+ * ids[n_attempts][4]: scene ids of the base in TryQuadrilateral's order; invariants[n_attempts][2];
+ * status[n_attempts]: 1 = base found, 0 = the reference would have returned false (no candidate
+ * left for the 2nd / 3rd / 4th point).  Host pointers, synchronous. */
+int pgp_select_bases(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, float* invariants, int* status);
+
+/* The pieces of the above, for parity tests and for callers that keep their own sampling loop:
+ * pgp_ppf_features: computePPF for m (i, j) pairs of scene ids -> features[m][4] (-1: not a key,
+ *   NaN inputs) and rows[m] (nullable): index of the key in the table or -1 (PPFMap->find);
+ * pgp_stocs_stage_weights: ONE weighting loop of SelectQuadrilateralStoCS (stage 2: base.cc:625-652,
+ *   3: :662-699, 4: :713-769) for given base points; cur[nP] in = curr_probabilities_ entering the
+ *   loop (stage 2: orig_probabilities_), out = the values the reference leaves (divided by the
+ *   sequential float sum when a candidate is present); *sum, *present as in the reference;
+ * pgp_base_invariants: TryQuadrilateral for m bases given as scene ids[m][4] (reordered in place),
+ *   invariants[m][2], ok[m] (1, or -1 for a bad id). */
+int pgp_ppf_features(pgp_ctx* ctx, const int* pairs, int m, int* features, int* rows);
+int pgp_stocs_stage_weights(pgp_ctx* ctx, int stage, int base1, int base2, int base3, float* cur, float* sum,
+                            int* present);
+int pgp_base_invariants(pgp_ctx* ctx, int* ids, int m, float* invariants, int* ok);
 
 /* Replaces ComputeRigidTransformFromCongruentPair + ComputeRigidTransformation
  * (base.cc:1411-1488, 1504-1614) for n congruent pairs.  base_ids[n][4] index the scene cloud

@@ -27,6 +27,8 @@
 #include <cmath>
 #include <cstring>
 #include <algorithm>
+#include <limits>
+#include <map>
 
 #include "Eigen/Dense"
 #include "shared4pcs.h"
@@ -600,6 +602,274 @@ int ref_backproject(const float* depth_img, const unsigned char* mask, int rows,
       }
     }
   return n;
+}
+
+}  // extern "C"
+
+// ---- base selection (Step 1 of Perform_N_steps) -------------------------------------------------
+// Restated with the reference's types so that every float / double / int conversion is the
+// compiler's own: computePPF (base.cc:582-598) + approximate_bin (:150-160), the three weighting
+// loops of SelectQuadrilateralStoCS (:625-652, :662-699, :713-769), distSegmentToSegment (:81-148,
+// instantiated as the reference instantiates it: Vector3f points, DOUBLE invariants) and
+// TryQuadrilateral (:415-464).  The draws (std::discrete_distribution) are not part of it.
+namespace {
+
+template <typename VectorT, typename S>
+static S distSegmentToSegment_t(const VectorT& p1, const VectorT& p2, const VectorT& q1, const VectorT& q2,
+                                S& invariant1, S& invariant2) {
+  static const S kSmallNumber = 0.0001;
+  VectorT u = p2 - p1;
+  VectorT v = q2 - q1;
+  VectorT w = p1 - q1;
+  S a = u.dot(u);
+  S b = u.dot(v);
+  S c = v.dot(v);
+  S d = u.dot(w);
+  S e = v.dot(w);
+  S f = a * c - b * b;
+  S s1 = 0.0;
+  S s2 = f;
+  S t1 = 0.0;
+  S t2 = f;
+  if (f < kSmallNumber) {
+    s1 = 0.0;
+    s2 = 1.0;
+    t1 = e;
+    t2 = c;
+  } else {
+    s1 = (b * e - c * d);
+    t1 = (a * e - b * d);
+    if (s1 < 0.0) {
+      s1 = 0.0;
+      t1 = e;
+      t2 = c;
+    } else if (s1 > s2) {
+      s1 = s2;
+      t1 = e + b;
+      t2 = c;
+    }
+  }
+  if (t1 < 0.0) {
+    t1 = 0.0;
+    if (-d < 0.0)
+      s1 = 0.0;
+    else if (-d > a)
+      s1 = s2;
+    else {
+      s1 = -d;
+      s2 = a;
+    }
+  } else if (t1 > t2) {
+    t1 = t2;
+    if ((-d + b) < 0.0)
+      s1 = 0;
+    else if ((-d + b) > a)
+      s1 = s2;
+    else {
+      s1 = (-d + b);
+      s2 = a;
+    }
+  }
+  invariant1 = (std::abs(s1) < kSmallNumber ? 0.0 : s1 / s2);
+  invariant2 = (std::abs(t1) < kSmallNumber ? 0.0 : t1 / t2);
+  return (w + (invariant1 * u) - (invariant2 * v)).norm();
+}
+
+struct RefStocs {
+  std::vector<Point3D> sampled_P_3D_;
+  std::vector<float> orig_probabilities_;
+  std::map<std::vector<int>, std::vector<std::pair<int, int> > > PPFMap;
+  int trans_disc = 5, rot_disc = 10;   // base.cc:303-304
+
+  static int approximate_bin(int val, int disc) {
+    int lower_limit = val - (val % disc);
+    int upper_limit = lower_limit + disc;
+    int dist_from_lower = val - lower_limit;
+    int dist_from_upper = upper_limit - val;
+    return (dist_from_lower < dist_from_upper) ? lower_limit : upper_limit;
+  }
+  void computePPF(int pIdx1, int pIdx2, std::vector<int>& ppf_) const {
+    using namespace std;   // as the reference's translation unit (S4/io/io.h:35 leaks it): atan2(float, float)
+    VectorType p1 = sampled_P_3D_[pIdx1].pos();
+    VectorType p2 = sampled_P_3D_[pIdx2].pos();
+    VectorType n1 = sampled_P_3D_[pIdx1].normal();
+    VectorType n2 = sampled_P_3D_[pIdx2].normal();
+    VectorType u = p1 - p2;
+    int ppf_1 = int(u.norm() * 1000);
+    int ppf_2 = int(atan2(n1.cross(u).norm(), n1.dot(u)) * 180 / M_PI);
+    int ppf_3 = int(atan2(n2.cross(u).norm(), n2.dot(u)) * 180 / M_PI);
+    int ppf_4 = int(atan2(n1.cross(n2).norm(), n1.dot(n2)) * 180 / M_PI);
+    ppf_.push_back(approximate_bin(ppf_1, trans_disc));
+    ppf_.push_back(approximate_bin(ppf_2, rot_disc));
+    ppf_.push_back(approximate_bin(ppf_3, rot_disc));
+    ppf_.push_back(approximate_bin(ppf_4, rot_disc));
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+void* ref_stocs_create(const float* P_xyz, const float* P_nrm, const float* prob, int n, const int* keys, int n_keys) {
+  RefStocs* s = new RefStocs();
+  s->sampled_P_3D_.resize(n);
+  for (int i = 0; i < n; ++i) {
+    s->sampled_P_3D_[i] = Point3D(P_xyz[3 * i], P_xyz[3 * i + 1], P_xyz[3 * i + 2]);
+    VectorType nn(P_nrm[3 * i], P_nrm[3 * i + 1], P_nrm[3 * i + 2]);
+    s->sampled_P_3D_[i].set_normal(nn);   // normalises, as the reader does
+    if (s->sampled_P_3D_[i].normal().squaredNorm() < 0.01) s->sampled_P_3D_[i].set_normal(VectorType(0, 0, 0));
+  }
+  s->orig_probabilities_.assign(prob, prob + n);
+  for (int k = 0; k < n_keys; ++k) {
+    std::vector<int> key(keys + 4 * k, keys + 4 * k + 4);
+    s->PPFMap[key];   // only the presence of a key matters for the edge factor
+  }
+  return s;
+}
+void ref_stocs_destroy(void* h) { delete static_cast<RefStocs*>(h); }
+
+void ref_stocs_get_normals(void* h, float* out) {
+  RefStocs* s = static_cast<RefStocs*>(h);
+  for (size_t i = 0; i < s->sampled_P_3D_.size(); ++i)
+    for (int k = 0; k < 3; ++k) out[3 * i + k] = s->sampled_P_3D_[i].normal()(k);
+}
+
+void ref_stocs_ppf(void* h, int i, int j, int* out4) {
+  std::vector<int> f;
+  static_cast<RefStocs*>(h)->computePPF(i, j, f);
+  for (int k = 0; k < 4; ++k) out4[k] = f[k];
+}
+
+// One weighting loop of SelectQuadrilateralStoCS.  stage 2: needs base1; 3: base1, base2; 4: base1..3.
+// cur: curr_probabilities_ in (the previous stage's normalised values; stage 2 starts from
+// orig_probabilities_) and out (normalised by the sequential float sum, as the reference leaves
+// them).  Returns point_present; *sum_out = sum_probabilities.
+int ref_stocs_stage(void* h, int stage, int base1, int base2, int base3, float* cur, float* sum_out) {
+  using namespace std;
+  RefStocs& m = *static_cast<RefStocs*>(h);
+  const std::vector<Point3D>& sampled_P_3D_ = m.sampled_P_3D_;
+  const std::vector<float>& orig_probabilities_ = m.orig_probabilities_;
+  float* curr_probabilities_ = cur;
+  std::vector<int> ppf_;
+  bool point_present = false;
+  float sum_probabilities = 0;
+  const int n = (int)sampled_P_3D_.size();
+  if (stage == 2) {
+    for (int i = 0; i < n; i++) {
+      if (i == base1 || curr_probabilities_[i] == 0) {
+        curr_probabilities_[i] = 0;
+        continue;
+      }
+      ppf_.clear();
+      m.computePPF(base1, i, ppf_);
+      auto it = m.PPFMap.find(ppf_);
+      float edge_i_0 = (it == m.PPFMap.end()) ? 0 : 1;
+      curr_probabilities_[i] = orig_probabilities_[i] * orig_probabilities_[base1] * edge_i_0;
+      if (curr_probabilities_[i] != 0) point_present = true;
+      sum_probabilities += curr_probabilities_[i];
+    }
+  } else if (stage == 3) {
+    VectorType v_1 = sampled_P_3D_[base2].pos() - sampled_P_3D_[base1].pos();
+    for (int i = 0; i < n; i++) {
+      VectorType v_2 = sampled_P_3D_[i].pos() - sampled_P_3D_[base1].pos();
+      float int_angle = acos(v_1.dot(v_2)) * 180 / M_PI;
+      int_angle = std::min(int_angle, 180 - int_angle);
+      if (i == base1 || i == base2 || curr_probabilities_[i] == 0 || int_angle < 30) {
+        curr_probabilities_[i] = 0;
+        continue;
+      }
+      ppf_.clear();
+      m.computePPF(base2, i, ppf_);
+      auto it = m.PPFMap.find(ppf_);
+      float edge_i_1 = (it == m.PPFMap.end()) ? 0 : 1;
+      curr_probabilities_[i] = curr_probabilities_[i] * orig_probabilities_[base2] * edge_i_1;
+      if (curr_probabilities_[i] != 0) point_present = true;
+      sum_probabilities += curr_probabilities_[i];
+    }
+  } else {
+    for (int i = 0; i < n; i++) {
+      if (i == base1 || i == base2 || i == base3 || curr_probabilities_[i] == 0) {
+        curr_probabilities_[i] = 0;
+        continue;
+      }
+      double x1 = sampled_P_3D_[base1].x();
+      double y1 = sampled_P_3D_[base1].y();
+      double z1 = sampled_P_3D_[base1].z();
+      double x2 = sampled_P_3D_[base2].x();
+      double y2 = sampled_P_3D_[base2].y();
+      double z2 = sampled_P_3D_[base2].z();
+      double x3 = sampled_P_3D_[base3].x();
+      double y3 = sampled_P_3D_[base3].y();
+      double z3 = sampled_P_3D_[base3].z();
+      Scalar denom = (-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
+      if (denom != 0) {
+        Scalar A = (-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom;
+        Scalar B = (x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom;
+        Scalar C = (-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom;
+        Scalar planar_distance = std::abs(A * sampled_P_3D_[i].x() + B * sampled_P_3D_[i].y() +
+                                          C * sampled_P_3D_[i].z() - 1.0);
+        if (planar_distance > 0.01 || (sampled_P_3D_[i].pos() - sampled_P_3D_[base1].pos()).norm() < 0.01 ||
+            (sampled_P_3D_[i].pos() - sampled_P_3D_[base2].pos()).norm() < 0.01 ||
+            (sampled_P_3D_[i].pos() - sampled_P_3D_[base3].pos()).norm() < 0.01) {
+          curr_probabilities_[i] = 0;
+          continue;
+        }
+      }
+      ppf_.clear();
+      m.computePPF(base3, i, ppf_);
+      auto it = m.PPFMap.find(ppf_);
+      float edge_i_2 = (it == m.PPFMap.end()) ? 0 : 1;
+      curr_probabilities_[i] = curr_probabilities_[i] * orig_probabilities_[base3] * edge_i_2;
+      if (curr_probabilities_[i] != 0) point_present = true;
+      sum_probabilities += curr_probabilities_[i];
+    }
+  }
+  *sum_out = sum_probabilities;
+  if (point_present == false) return 0;
+  for (int i = 0; i < n; i++) curr_probabilities_[i] /= sum_probabilities;
+  return 1;
+}
+
+// TryQuadrilateral (base.cc:415-464) on four scene ids: reorders them in place, returns the invariants.
+int ref_try_quadrilateral(void* h, int* ids, float* invariant1_out, float* invariant2_out) {
+  RefStocs& m = *static_cast<RefStocs*>(h);
+  std::vector<Point3D> base_3D_(4);
+  for (int k = 0; k < 4; ++k) base_3D_[k] = m.sampled_P_3D_[ids[k]];
+  Scalar invariant1 = 0, invariant2 = 0;
+  Scalar min_distance = std::numeric_limits<Scalar>::max();
+  int best1, best2, best3, best4;
+  best1 = best2 = best3 = best4 = -1;
+  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      if (i == j) continue;
+      int k = 0;
+      while (k == i || k == j) k++;
+      int l = 0;
+      while (l == i || l == j || l == k) l++;
+      double local_invariant1;
+      double local_invariant2;
+      Scalar segment_distance = distSegmentToSegment_t(base_3D_[i].pos(), base_3D_[j].pos(), base_3D_[k].pos(),
+                                                       base_3D_[l].pos(), local_invariant1, local_invariant2);
+      if (segment_distance < min_distance) {
+        min_distance = segment_distance;
+        best1 = i;
+        best2 = j;
+        best3 = k;
+        best4 = l;
+        invariant1 = local_invariant1;
+        invariant2 = local_invariant2;
+      }
+    }
+  }
+  if (best1 < 0 || best2 < 0 || best3 < 0 || best4 < 0) return 0;
+  int tmpId[4] = {ids[0], ids[1], ids[2], ids[3]};
+  ids[0] = tmpId[best1];
+  ids[1] = tmpId[best2];
+  ids[2] = tmpId[best3];
+  ids[3] = tmpId[best4];
+  *invariant1_out = invariant1;
+  *invariant2_out = invariant2;
+  return 1;
 }
 
 }  // extern "C"

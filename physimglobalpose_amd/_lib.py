@@ -51,6 +51,11 @@ SIGNATURES = {
     "pgp_registered": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _i, _i]),
     "pgp_running_best": (C.c_int, [_f, C.c_int, _i, _i]),
     "pgp_set_search_model": (C.c_int, [C.c_void_p, _f, C.c_int]),
+    "pgp_set_ppf_map": (C.c_int, [C.c_void_p, _i, _i, _i, C.c_int]),
+    "pgp_select_bases": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, _i, _f, _i]),
+    "pgp_ppf_features": (C.c_int, [C.c_void_p, _i, C.c_int, _i, _i]),
+    "pgp_stocs_stage_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _i]),
+    "pgp_base_invariants": (C.c_int, [C.c_void_p, _i, C.c_int, _f, _i]),
     "pgp_rigid_from_congruent": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, _f,
                                            C.POINTER(C.c_double), _i, _f]),
     "pgp_rigid_from_congruent_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, _f, _f,

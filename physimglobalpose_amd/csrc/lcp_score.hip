@@ -570,59 +570,79 @@ __global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __res
 //
 // Weighted mode, returned best pose (base.cc:1759,1891): the reference accumulates
 // `weighted_match += w[hit]` sequentially in model order, this library in a fixed tree (per wave,
-// per tile), so two hypotheses whose scores differ by less than that re-association (<= 2e-6
-// observed over 1.4e5 hypotheses) could swap places.  The last block therefore looks for
-// hypotheses within kRefineTol of the maximum; if there is more than one, each of them (in index
-// order, at most kRefineCap) is re-scored EXACTLY as the reference does it -- registered weights
-// scattered to original model order, then ONE lane adds them sequentially in float -- its score
-// entry is overwritten with that value, and the arg-max is taken over the exact values with the
-// reference's strict `>`.  With a single candidate the arg-max cannot depend on the association
-// and nothing more runs.
-constexpr float kRefineTol = 1.6e-5f;   // 8 x the largest tree-vs-sequential deviation observed
+// per tile), so two hypotheses whose scores differ by less than that re-association could swap
+// places.  Size of the effect: each of the reference's c <= nQ additions rounds by at most half an
+// ulp of a partial sum <= S = score * nQ, a random walk with standard deviation of about
+// 0.41 * 2^-24 * S * sqrt(c) <= 0.41 * 2^-24 * sqrt(nQ) * score per score (3.7e-7 at the C2 sizes;
+// largest deviation seen over 1.4e5 hypotheses there: 2e-6); the tree's own error is a log2(nQ) / nQ
+// fraction of that.  Hypotheses within refine_tol() = TEN such deviations of the maximum (6.2e-6
+// at C2) are candidates: if there is more than one (the launch's top-2 keys tell), each of them
+// (in index order, at most kRefineCap) is re-scored EXACTLY as the reference does it -- registered
+// weights scattered to original model order, then ONE lane per candidate adds them sequentially
+// in float -- its score entry is overwritten with that value, and the arg-max is taken over the
+// exact values with the reference's strict `>`.  With a single candidate the arg-max cannot depend
+// on the association and nothing more runs.
 constexpr int kRefineCap = 128;
-constexpr int kSeqChunk = 2048;         // floats staged through LDS per step of the sequential sum
+constexpr int kRefineGroup = 4;         // candidates settled together (one summation lane each)
+constexpr int kSeqChunk = 1024;         // floats per candidate staged through LDS per step
 
-__device__ float refine_exact(const ScoreArgs& a, int h, float* __restrict__ seq, float* s_stage,
-                              float* s_out) {
-  const Xf m = load_xf(a.T, h);
+__device__ __forceinline__ float refine_tol(float best_score, int nQ) {
+  const float rel = fmaxf(4.1f * 5.9604645e-8f * __fsqrt_rn((float)nQ), 4.8e-7f);
+  return best_score * rel;
+}
+
+// Exact scores of G <= kRefineGroup hypotheses hs[0..G) -> s_out[0..G).  All threads of the block.
+__device__ void refine_exact_group(const ScoreArgs& a, const int* hs, int G, float* __restrict__ seq,
+                                   float (*s_stage)[kSeqChunk], float* s_out) {
   const int nQ4 = (a.nQ + 3) & ~3;
-  for (int i = threadIdx.x; i < nQ4; i += blockDim.x) {
-    if (i < a.nQ) {
-      const int id = point_hit<PGP_MODE_WEIGHTED>(a, m, i);
+  // registered weights of every candidate, scattered to ORIGINAL model order: two model points per
+  // thread and trip, so that their lookup chains overlap
+  for (int g = 0; g < G; ++g) {
+    const Xf m = load_xf(a.T, hs[g]);
+    float* row = seq + (size_t)g * nQ4;
+    for (int i0 = threadIdx.x; i0 < nQ4; i0 += 2 * blockDim.x) {
+      const int i1 = i0 + blockDim.x;
+      const int id0 = i0 < a.nQ ? point_hit<PGP_MODE_WEIGHTED>(a, m, i0) : -1;
+      const int id1 = i1 < a.nQ ? point_hit<PGP_MODE_WEIGHTED>(a, m, i1) : -1;
       // adding +0.0f is the identity on the reference's running sum (which starts at +0.0f)
-      seq[__float_as_int(a.Q[i].w)] = id >= 0 ? a.Pnw[id].w : 0.0f;
-    } else {
-      seq[i] = 0.0f;   // padding up to a multiple of four
+      const float w0 = id0 >= 0 ? a.Pnw[id0].w : 0.0f, w1 = id1 >= 0 ? a.Pnw[id1].w : 0.0f;
+      if (i0 < a.nQ) row[__float_as_int(a.Q[i0].w)] = w0;
+      else row[i0] = 0.0f;   // padding up to a multiple of four
+      if (i1 < a.nQ) row[__float_as_int(a.Q[i1].w)] = w1;
+      else if (i1 < nQ4) row[i1] = 0.0f;
     }
   }
   __syncthreads();
-  float S = 0.0f;   // lane 0's running sum (base.cc:1737 `Scalar weighted_match = 0`)
+  float S = 0.0f;   // lane g's running sum (base.cc:1737 `Scalar weighted_match = 0`)
   for (int c0 = 0; c0 < nQ4; c0 += kSeqChunk) {
-    const int len = min(kSeqChunk, nQ4 - c0);
-    for (int i = threadIdx.x; i < len; i += blockDim.x) s_stage[i] = seq[c0 + i];
+    const int len = min(kSeqChunk, nQ4 - c0);   // a multiple of four
+    for (int g = 0; g < G; ++g)
+      for (int i = threadIdx.x; i < len; i += blockDim.x) s_stage[g][i] = seq[(size_t)g * nQ4 + c0 + i];
     __syncthreads();
-    if (threadIdx.x == 0) {
-      const float4* v = reinterpret_cast<const float4*>(s_stage);
-      for (int i = 0; i < len / 4; ++i) {
-        const float4 w = v[i];
-        S = __fadd_rn(S, w.x);
-        S = __fadd_rn(S, w.y);
-        S = __fadd_rn(S, w.z);
-        S = __fadd_rn(S, w.w);
+    if ((int)threadIdx.x < G) {
+      const float4* v = reinterpret_cast<const float4*>(s_stage[threadIdx.x]);
+      const int n4 = len / 4;
+      float4 cur = v[0];
+      for (int i = 0; i < n4; ++i) {
+        const float4 nxt = v[min(i + 1, n4 - 1)];   // the next read is in flight under this trip's adds
+        S = __fadd_rn(S, cur.x);
+        S = __fadd_rn(S, cur.y);
+        S = __fadd_rn(S, cur.z);
+        S = __fadd_rn(S, cur.w);
+        cur = nxt;
       }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *s_out = __fdiv_rn(S, (float)a.nQ);   // base.cc:1765
+  if ((int)threadIdx.x < G) s_out[threadIdx.x] = __fdiv_rn(S, (float)a.nQ);   // base.cc:1765
   __syncthreads();
-  return *s_out;
 }
 
 // Called by all 256 threads of ONE block with kk = the arg-max key over the (tree-summed) score
 // vector: publishes {best index, best score bits}, settling weighted near-ties exactly (above).
 __device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int mode, int refine, float* scores,
-                                   const unsigned long long kk, int* __restrict__ best,
-                                   float* __restrict__ seq, unsigned long long* s_key) {
+                                                const unsigned long long kk, int* __restrict__ best,
+                                                float* __restrict__ seq, unsigned long long* s_key) {
   if (kk == 0) {
     if (threadIdx.x == 0) {
       best[0] = -1;
@@ -634,9 +654,10 @@ __device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int
   float bs = __uint_as_float((unsigned)(kk >> 32));
   if (mode == PGP_MODE_WEIGHTED && refine) {
     __shared__ int s_red[4];
-    __shared__ float s_stage[kSeqChunk];
-    __shared__ float s_exact;
-    const float thr = bs - kRefineTol;
+    __shared__ float s_stage[kRefineGroup][kSeqChunk];
+    __shared__ float s_exact[kRefineGroup];
+    __shared__ int s_cand[kRefineGroup];
+    const float thr = bs - refine_tol(bs, a.nQ);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int cnt = 0;
     for (int i = threadIdx.x; i < n_h; i += blockDim.x) cnt += scores[i] >= thr ? 1 : 0;
@@ -649,25 +670,38 @@ __device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int
     if (cnt >= 2) {
       int cur = -1, done = 0, ebi = -1;
       float ebest = 0.0f;
-      for (; done < kRefineCap; ++done) {
-        // next candidate in index order
-        int nxt = 0x7FFFFFFF;
-        for (int i = cur + 1 + threadIdx.x; i < n_h; i += blockDim.x)
-          if (scores[i] >= thr) { nxt = i; break; }
+      bool more = true;
+      while (more && done < kRefineCap) {
+        // the next (up to) kRefineGroup candidates in index order
+        int G = 0;
+        for (; G < kRefineGroup && done + G < kRefineCap; ++G) {
+          int nxt = 0x7FFFFFFF;
+          for (int i = cur + 1 + threadIdx.x; i < n_h; i += blockDim.x)
+            if (scores[i] >= thr) { nxt = i; break; }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) nxt = min(nxt, __shfl_xor(nxt, off, 64));
-        if (lane == 0) s_red[wave] = nxt;
-        __syncthreads();
-        nxt = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
-        __syncthreads();
-        if (nxt == 0x7FFFFFFF) break;
-        const float e = refine_exact(a, nxt, seq, s_stage, &s_exact);
-        if (threadIdx.x == 0) scores[nxt] = e;   // the reference's value, bit for bit
-        if (e > ebest) {                          // strict >, ascending index (base.cc:1891)
-          ebest = e;
-          ebi = nxt;
+          for (int off = 32; off >= 1; off >>= 1) nxt = min(nxt, __shfl_xor(nxt, off, 64));
+          if (lane == 0) s_red[wave] = nxt;
+          __syncthreads();
+          nxt = min(min(s_red[0], s_red[1]), min(s_red[2], s_red[3]));
+          __syncthreads();
+          if (nxt == 0x7FFFFFFF) { more = false; break; }
+          if (threadIdx.x == 0) s_cand[G] = nxt;
+          cur = nxt;
         }
-        cur = nxt;
+        __syncthreads();
+        if (G == 0) break;
+        refine_exact_group(a, s_cand, G, seq, s_stage, s_exact);
+        for (int g = 0; g < G; ++g) {
+          const float e = s_exact[g];
+          const int h = s_cand[g];
+          if (threadIdx.x == 0) scores[h] = e;   // the reference's value, bit for bit
+          if (e > ebest) {                        // strict >, ascending index (base.cc:1891)
+            ebest = e;
+            ebi = h;
+          }
+        }
+        done += G;
+        __syncthreads();
       }
       // candidates past the cap (pathological: > kRefineCap near-equal hypotheses) keep their
       // tree-summed values and can only take over with a strictly greater one
@@ -782,7 +816,8 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const int* _
   // ---- the last block of the launch: publish (and, in weighted mode, settle near-ties exactly) ----
   const unsigned long long kk = s_kk, kk2 = s_kk2;
   const bool near_tie = mode == PGP_MODE_WEIGHTED && refine && kk2 != 0ull &&
-                        __uint_as_float((unsigned)(kk2 >> 32)) >= __uint_as_float((unsigned)(kk >> 32)) - kRefineTol;
+                        __uint_as_float((unsigned)(kk2 >> 32)) >=
+                            __uint_as_float((unsigned)(kk >> 32)) - refine_tol(__uint_as_float((unsigned)(kk >> 32)), nQ);
   if (near_tie) {
     settle_and_publish(a, n_h, mode, refine, scores, kk, best, seq, s_key);
   } else if (threadIdx.x == 0) {

@@ -150,7 +150,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -238,6 +238,7 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
   // *_device calls may still be queued on the caller's stream and read the arrays replaced below
   PGP_HIP(hipDeviceSynchronize());
   ctx->has_index = false;
+  ctx->prob_cdf_valid = false;
   ctx->nP = n;
   ctx->has_scene_normals = nrm != nullptr;
   std::vector<float4> hp((size_t)std::max(n, 1)), hn((size_t)std::max(n, 1));
@@ -307,7 +308,7 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
   if ((rc = ctx->d_Q.ensure(hq.size() * sizeof(float4))) != PGP_OK) return rc;
   if ((rc = ctx->d_Qn.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
   if ((rc = ctx->d_hits.ensure(hq.size() * sizeof(int))) != PGP_OK) return rc;
-  if ((rc = ctx->d_seq.ensure((hq.size() + 4) * sizeof(float))) != PGP_OK) return rc;
+  if ((rc = ctx->d_seq.ensure(4 * (hq.size() + 4) * sizeof(float))) != PGP_OK) return rc;  // kRefineGroup rows
   PGP_HIP(hipMemcpyAsync(ctx->d_Q.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipMemcpyAsync(ctx->d_Qn.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipStreamSynchronize(ctx->stream));
@@ -474,6 +475,56 @@ int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
   PGP_HIP(hipStreamSynchronize(ctx->stream));
   ctx->nQs = n;
   return PGP_OK;
+}
+
+int pgp_set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys) {
+  if (!ctx || n_keys < 0 || (n_keys > 0 && !keys)) {
+    set_error("pgp_set_ppf_map: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  PGP_HIP(hipDeviceSynchronize());
+  return set_ppf_map(ctx, keys, counts, pairs, n_keys);
+}
+
+int pgp_select_bases(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, float* invariants, int* status) {
+  if (!ctx || n_attempts < 0 || (n_attempts > 0 && (!u || !ids || !invariants || !status))) {
+    set_error("pgp_select_bases: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n_attempts == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  return launch_select_bases(ctx, u, n_attempts, ids, invariants, status, ctx->stream);
+}
+
+int pgp_ppf_features(pgp_ctx* ctx, const int* pairs, int m, int* features, int* rows) {
+  if (!ctx || m < 0 || (m > 0 && (!pairs || !features))) {
+    set_error("pgp_ppf_features: bad argument");
+    return PGP_EINVAL;
+  }
+  if (m == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  return launch_ppf_features(ctx, pairs, m, features, rows, ctx->stream);
+}
+
+int pgp_stocs_stage_weights(pgp_ctx* ctx, int stage, int base1, int base2, int base3, float* cur, float* sum,
+                            int* present) {
+  if (!ctx || !cur || !sum || !present) {
+    set_error("pgp_stocs_stage_weights: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_stage_weights(ctx, stage, base1, base2, base3, cur, sum, present, ctx->stream);
+}
+
+int pgp_base_invariants(pgp_ctx* ctx, int* ids, int m, float* invariants, int* ok) {
+  if (!ctx || m < 0 || (m > 0 && (!ids || !invariants || !ok))) {
+    set_error("pgp_base_invariants: bad argument");
+    return PGP_EINVAL;
+  }
+  if (m == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  return launch_base_invariants(ctx, ids, m, invariants, ok, ctx->stream);
 }
 
 int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const int* d_quad_ids, int n,

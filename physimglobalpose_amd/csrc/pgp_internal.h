@@ -85,6 +85,18 @@ struct pgp_ctx {
   pgp::DevBuf d_ids;     // staged int4 base / quad ids (host API)
   pgp::DevBuf d_rig;     // staged rigid-fit outputs (host API)
 
+  // base selection (base_select.hip): device hash set of the model's pair-feature keys + CSR pair lists
+  bool ppf_ready = false;
+  pgp::DevBuf d_ppf_keys, d_ppf_val, d_ppf_off, d_ppf_pairs;
+  uint32_t ppf_mask = 0;
+  int ppf_shift = 0, ppf_n_keys = 0;
+  long long ppf_n_pairs = 0;
+  std::vector<uint32_t> ppf_off_host;   // pair-list offsets per key, host copy
+  float ppf_tpos[9] = {0}, ppf_tneg[9] = {0};   // ratio thresholds of the 10-degree angle bins (host atan2f)
+  pgp::DevBuf d_prob_cdf;               // double prefix sums of the scene weights (first draw)
+  bool prob_cdf_valid = false;
+  pgp::DevBuf d_sel_ws;                 // base-selection workspace / staging
+
   pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
   pgp::DevBuf d_bp;      // back-projection staging: image | mask | counters | scan scratch | xyz
   pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
@@ -161,6 +173,16 @@ int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream
 // icp.hip
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,
                int n, const pgp_icp_params* prm, float* d_energy, int* d_iters, hipStream_t stream);
+
+// base_select.hip
+int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);
+int ppf_thresholds(float tpos[9], float tneg[9]);
+int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_ids, float* h_inv, int* h_status,
+                        hipStream_t st);
+int launch_ppf_features(pgp_ctx* ctx, const int* h_pairs, int m, int* h_f, int* h_row, hipStream_t st);
+int launch_stage_weights(pgp_ctx* ctx, int stage, int b1, int b2, int b3, float* h_cur, float* h_sum, int* h_present,
+                         hipStream_t st);
+int launch_base_invariants(pgp_ctx* ctx, int* h_ids, int m, float* h_inv, int* h_ok, hipStream_t st);
 
 // depth_cost.hip
 int launch_depth_cost(pgp_ctx* ctx, const float* d_obs, const float* d_ren, int n, int n_pix, float thr,

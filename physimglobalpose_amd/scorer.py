@@ -152,6 +152,54 @@ class LcpScorer:
         _lib.check(self._lib.pgp_find_congruent(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
         return out[: min(n.value, cap)].copy()
 
+    # ---- base selection (base.cc:600-792) -------------------------------------------------------------
+    def set_ppf_map(self, keys, counts=None, pairs=None):
+        """keys (n,4) int: the model's discretised pair features; counts (n,) / pairs (sum,2): their pair lists."""
+        keys = np.ascontiguousarray(keys, np.int32).reshape(-1, 4)
+        c = None if counts is None else np.ascontiguousarray(counts, np.int32)
+        p = None if pairs is None else np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        _lib.check(self._lib.pgp_set_ppf_map(self._h, keys.ctypes.data_as(_i),
+                                             None if c is None else c.ctypes.data_as(_i),
+                                             None if p is None else p.ctypes.data_as(_i), len(keys)))
+
+    def select_bases(self, u):
+        """u (n,4) float64 uniforms in [0,1) -> (ids (n,4), invariants (n,2), status (n,))."""
+        u = np.ascontiguousarray(u, np.float64).reshape(-1, 4)
+        n = len(u)
+        ids = np.zeros((max(n, 1), 4), np.int32)
+        inv = np.zeros((max(n, 1), 2), np.float32)
+        st = np.zeros(max(n, 1), np.int32)
+        _lib.check(self._lib.pgp_select_bases(self._h, u.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                              ids.ctypes.data_as(_i), _fp(inv), st.ctypes.data_as(_i)))
+        return ids[:n], inv[:n], st[:n]
+
+    def ppf_features(self, pairs):
+        """pairs (m,2) scene ids -> (features (m,4), table row (m,) or -1)."""
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        m = len(pairs)
+        f = np.zeros((max(m, 1), 4), np.int32)
+        rows = np.zeros(max(m, 1), np.int32)
+        _lib.check(self._lib.pgp_ppf_features(self._h, pairs.ctypes.data_as(_i), m, f.ctypes.data_as(_i),
+                                              rows.ctypes.data_as(_i)))
+        return f[:m], rows[:m]
+
+    def stocs_stage_weights(self, stage, cur, base1, base2=-1, base3=-1):
+        """One weighting loop of SelectQuadrilateralStoCS -> (cur_out, sum, present)."""
+        cur = np.array(_f32(cur), copy=True)
+        s, p = C.c_float(0), C.c_int(0)
+        _lib.check(self._lib.pgp_stocs_stage_weights(self._h, int(stage), int(base1), int(base2), int(base3),
+                                                     _fp(cur), C.byref(s), C.byref(p)))
+        return cur, float(np.float32(s.value)), bool(p.value)
+
+    def base_invariants(self, ids):
+        """TryQuadrilateral for (m,4) scene ids -> (reordered ids, invariants (m,2), ok (m,))."""
+        ids = np.array(np.ascontiguousarray(ids, np.int32).reshape(-1, 4), copy=True)
+        m = len(ids)
+        inv = np.zeros((max(m, 1), 2), np.float32)
+        ok = np.zeros(max(m, 1), np.int32)
+        _lib.check(self._lib.pgp_base_invariants(self._h, ids.ctypes.data_as(_i), m, _fp(inv), ok.ctypes.data_as(_i)))
+        return ids, inv[:m], ok[:m]
+
     # ---- segment pre-processing (ObjectPoseCandidateSet.cpp:28-51) -----------------------------------
     def radius_outlier_filter(self, xyz, nrm=None, radius=0.03, min_neighbors=10):
         """Returns (keep mask (n,) bool, flipped + re-normalised normals (n,3) or None)."""

@@ -333,8 +333,54 @@ def ref_lib():
         L.ref_greedy_cluster.argtypes = [_f, _f, C.c_int, C.c_float, _f, _i]
         L.ref_decode_depth.argtypes = [C.POINTER(C.c_ushort), C.c_int, _f]
         L.ref_backproject.argtypes = [_f, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f, _f]
+        L.ref_stocs_create.restype = C.c_void_p
+        L.ref_stocs_create.argtypes = [_f, _f, _f, C.c_int, _i, C.c_int]
+        L.ref_stocs_destroy.argtypes = [C.c_void_p]
+        L.ref_stocs_get_normals.argtypes = [C.c_void_p, _f]
+        L.ref_stocs_ppf.argtypes = [C.c_void_p, C.c_int, C.c_int, _i]
+        L.ref_stocs_stage.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f]
+        L.ref_try_quadrilateral.argtypes = [C.c_void_p, _i, _f, _f]
         _ref = L
     return _ref
+
+
+class RefStocs:
+    """Base selection through the Eigen-typed harness (computePPF, the three weighting loops of
+    SelectQuadrilateralStoCS, TryQuadrilateral).  Build container only."""
+
+    def __init__(self, P_xyz, P_nrm, prob, keys):
+        self.L = ref_lib()
+        self.P, self.N, self.prob = _f32(P_xyz), _f32(P_nrm), _f32(prob)
+        self.keys = np.ascontiguousarray(keys, np.int32).reshape(-1, 4)
+        self.n = len(self.P)
+        self.h = self.L.ref_stocs_create(_fp(self.P), _fp(self.N), _fp(self.prob), self.n, _ip(self.keys), len(self.keys))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.ref_stocs_destroy(self.h)
+            self.h = None
+
+    def normals(self):
+        out = np.zeros((self.n, 3), np.float32)
+        self.L.ref_stocs_get_normals(self.h, _fp(out))
+        return out
+
+    def ppf(self, i, j):
+        f = np.zeros(4, np.int32)
+        self.L.ref_stocs_ppf(self.h, int(i), int(j), _ip(f))
+        return f
+
+    def stage(self, stage, cur, b1, b2=-1, b3=-1):
+        cur = np.array(_f32(cur), copy=True)
+        s = C.c_float(0)
+        present = self.L.ref_stocs_stage(self.h, int(stage), int(b1), int(b2), int(b3), _fp(cur), C.byref(s))
+        return cur, float(np.float32(s.value)), bool(present)
+
+    def try_quadrilateral(self, ids):
+        ids = np.array(ids, np.int32)
+        a, b = C.c_float(0), C.c_float(0)
+        ok = self.L.ref_try_quadrilateral(self.h, _ip(ids), C.byref(a), C.byref(b))
+        return ids, np.float32(a.value), np.float32(b.value), bool(ok)
 
 
 class Ref:

@@ -182,6 +182,7 @@ def main():
     weights_case()
     test_scene_case()
     near_ties_case()
+    stocs_case()
 
 
 def morton_order(Q):
@@ -282,6 +283,68 @@ def near_ties_case():
     print("near_ties: cluster", g["cluster"], "sequential scores", g["wscores"][g["cluster"]],
           "tree scores", g["tree_scores"][g["cluster"]], "reference best", int(g["best_weighted"]), "tree best", tb)
     assert tb != int(g["best_weighted"])
+
+
+def stocs_case():
+    """(15) base selection (base.cc:582-598 computePPF, :600-792 the weighting loops of
+    SelectQuadrilateralStoCS, :415-464 TryQuadrilateral) through the Eigen-typed harness: features of
+    4000 point pairs (some with identical points and with zeroed normals), six chains of stage-2/3/4
+    weights (normalised as the reference leaves them) and 96 base pairings."""
+    import tempfile
+    from _checkers import RefStocs
+    from _dropin import make_dropin_case
+    with tempfile.TemporaryDirectory() as d:
+        _, case = make_dropin_case(d, n_scene=6000, n_model=1200, n_search=300)
+    w = case["w"]
+    keys = np.array(sorted(case["table"].keys()), np.int32)
+    rng = np.random.default_rng(20261105)
+    N = w.P_nrm.copy()
+    N[rng.choice(len(N), 12, replace=False)] *= np.float32(0.01)     # cleaned to zero normals by the reader
+    ref = RefStocs(w.P_xyz, N, w.P_w, keys)
+    Ns = ref.normals()
+    n = len(w.P_xyz)
+    pairs = rng.integers(0, n, (4000, 2)).astype(np.int32)
+    pairs[:40, 1] = pairs[:40, 0]                                     # u = 0
+    zero = np.flatnonzero((Ns == 0).all(1))
+    pairs[40:40 + len(zero), 0] = zero
+    feat = np.array([ref.ppf(i, j) for i, j in pairs], np.int32)
+    out = dict(P=w.P_xyz, N=Ns, prob=w.P_w, keys=keys, pairs=pairs, feat=feat)
+    chains = []
+    for c in range(6):
+        b1 = int(rng.choice(n, p=w.P_w.astype(np.float64) / w.P_w.astype(np.float64).sum()))
+        cur2, s2, p2 = ref.stage(2, w.P_w, b1)
+        assert p2
+        b2 = int(rng.choice(n, p=cur2.astype(np.float64) / cur2.astype(np.float64).sum()))
+        cur3, s3, p3 = ref.stage(3, cur2, b1, b2)
+        rec = dict(b=[b1, b2, -1], cur2=cur2, cur3=cur3, s=[s2, s3, 0.0], present=[p2, p3, False])
+        if p3:
+            b3 = int(rng.choice(n, p=cur3.astype(np.float64) / cur3.astype(np.float64).sum()))
+            cur4, s4, p4 = ref.stage(4, cur3, b1, b2, b3)
+            rec.update(b=[b1, b2, b3], cur4=cur4, s=[s2, s3, s4], present=[p2, p3, p4])
+        else:
+            rec["cur4"] = np.zeros(n, np.float32)
+        chains.append(rec)
+        for k in ("cur2", "cur3", "cur4"):
+            out[f"{k}_{c}"] = rec[k]
+        out[f"b_{c}"] = np.array(rec["b"], np.int32)
+        out[f"s_{c}"] = np.array(rec["s"], np.float32)
+        out[f"present_{c}"] = np.array(rec["present"], np.int32)
+    quads = rng.integers(0, n, (96, 4)).astype(np.int32)
+    quads[90:93, 1] = quads[90:93, 0]                                 # coincident points
+    obj = np.flatnonzero(w.P_w == 1.0)
+    quads[:48] = rng.choice(obj, (48, 4))                             # compact bases on the object
+    q_ids, q_inv, q_ok = [], [], []
+    for q in quads:
+        ids, i1, i2, ok = ref.try_quadrilateral(q)
+        q_ids.append(ids)
+        q_inv.append((i1, i2))
+        q_ok.append(ok)
+    out.update(quads=quads, quad_ids=np.array(q_ids, np.int32), quad_inv=np.array(q_inv, np.float32),
+               quad_ok=np.array(q_ok, np.int32))
+    path = os.path.join(HERE, "stocs.npz")
+    np.savez_compressed(path, **out)
+    print(f"stocs: n={n} keys={len(keys)} pairs with a key {int((feat[:, 0] >= 0).sum())}, chains present",
+          [c["present"] for c in chains], f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def weights_case():
@@ -485,6 +548,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "test_scene":
         test_scene_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "stocs":
+        stocs_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "near_ties":
         near_ties_case()

@@ -60,6 +60,27 @@ __global__ __launch_bounds__(256) void l1_kernel(const float* __restrict__ buf, 
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+// The same with 8- and 16-byte loads (the scoring kernel's word / run-descriptor loads are 8 B per
+// lane, its candidate gathers 16 B per lane): VEC floats per lane, lanes STRIDE_VEC vectors apart.
+template <int VEC, int STRIDE_VEC>
+__global__ __launch_bounds__(256) void l1v_kernel(const float* __restrict__ buf, float* out, int words_per_block) {
+  typedef float vec_t __attribute__((ext_vector_type(VEC)));
+  const vec_t* base = reinterpret_cast<const vec_t*>(buf + (size_t)(blockIdx.x % 1024) * words_per_block);
+  const int nv = words_per_block / VEC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int idx = (lane * STRIDE_VEC + wave * (nv / 4)) % nv;
+  float s = 0.f;
+  for (int it = 0; it < kIters / 4; ++it) {
+    vec_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = base[(idx + k * (nv / 8)) % nv];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += v[k][0] + v[k][VEC - 1];
+    idx = (idx + 64 / (4 * VEC)) % nv;
+  }
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 template <class F>
 static float time_ms(F launch, int reps) {
   hipEvent_t e0, e1;
@@ -112,6 +133,15 @@ int main() {
     ms = time_ms([&] { hipLaunchKernelGGL(l1_kernel<4>, dim3(blocks), dim3(256), 0, 0, buf, out, wpb); }, 5);
     printf(", \"l1_16B_stride_Ginstr_per_s\": %.2f, \"l1_16B_stride_Glines_per_s\": %.1f", instr / (ms * 1e-3) / 1e9,
            instr * 16 / (ms * 1e-3) / 1e9);
+    struct V { const char* name; float ms; };
+    const double ins = instr;
+    float m2s = time_ms([&] { hipLaunchKernelGGL((l1v_kernel<2, 8>), dim3(blocks), dim3(256), 0, 0, buf, out, wpb); }, 5);
+    float m4s = time_ms([&] { hipLaunchKernelGGL((l1v_kernel<4, 4>), dim3(blocks), dim3(256), 0, 0, buf, out, wpb); }, 5);
+    float m4c = time_ms([&] { hipLaunchKernelGGL((l1v_kernel<4, 1>), dim3(blocks), dim3(256), 0, 0, buf, out, wpb); }, 5);
+    float m2c = time_ms([&] { hipLaunchKernelGGL((l1v_kernel<2, 1>), dim3(blocks), dim3(256), 0, 0, buf, out, wpb); }, 5);
+    printf(", \"l1_8B_one_line_per_lane_Ginstr_per_s\": %.2f, \"l1_16B_one_line_per_lane_Ginstr_per_s\": %.2f, "
+           "\"l1_16B_contiguous_Ginstr_per_s\": %.2f, \"l1_8B_contiguous_Ginstr_per_s\": %.2f",
+           ins / (m2s * 1e-3) / 1e9, ins / (m4s * 1e-3) / 1e9, ins / (m4c * 1e-3) / 1e9, ins / (m2c * 1e-3) / 1e9);
   }
   printf("}\n");
   return 0;
