@@ -38,9 +38,11 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
 # (tools/peaks.hip measured 1096-1108 G/s for v_add/v_mul_f32 at 8 waves per SIMD)
 VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
-# vector L1 (TCP): one 64-byte cache-line access per clock per CU (tools/peaks.hip: 607 G lines/s with
-# 64 distinct lines per load instruction)
-L1_PEAK_GLINES = 256 * 2.4
+# vector L1 (TCP) tag look-ups, in the unit of the TCP_TOTAL_CACHE_ACCESSES counter: highest rate
+# tools/peaks.hip reaches with L1-resident data, 8-byte loads with every lane in its own line (the
+# shape of the kernel's word / run-descriptor loads): 18.93 G instr/s x 40 look-ups = 757 G/s (16-byte
+# gathers 742, 4-byte scattered loads 607 = one per clock per CU; profiles/r02_peaks.json)
+L1_PEAK_GLINES = 757.0
 
 N_SCENE, N_MODEL, N_HYP = 50000, 5000, 4096   # BASELINE.json configs[1] (C2)
 N_BATCH = 8         # distinct hypothesis batches the timed loop rotates through
@@ -99,7 +101,7 @@ def roofline_block(mode, n_h, kern_avg_ms, launches):
                                "per_launch": c["SQ_INSTS_VALU"]}
     if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / t / 1e9
-        units["vector_l1"] = {"achieved": a, "peak": L1_PEAK_GLINES, "unit": "G line-accesses/s", "frac": a / L1_PEAK_GLINES,
+        units["vector_l1"] = {"achieved": a, "peak": L1_PEAK_GLINES, "unit": "G tag look-ups/s", "frac": a / L1_PEAK_GLINES,
                               "per_launch": c["TCP_TOTAL_CACHE_ACCESSES_sum"]}
     if c.get("FETCH_SIZE") is not None and c.get("WRITE_SIZE") is not None:
         # KB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads)

@@ -215,6 +215,25 @@ int pgp_find_congruent(pgp_ctx* ctx, const float* base, float invariant1, float 
                        const int* P_pairs, int nP, const int* Q_pairs, int nQ, int* quads, int cap,
                        int* n_quads);
 
+/* Replaces the loop `for (auto base_it: baseSet) ExtractCongruentSet(base_it)` of Perform_N_steps
+ * (base.cc:1855-1874 -> :1929-1993, operMode 1) for ALL bases of an object in one pass: for base b,
+ * pairs1 = PPFMap[computePPF(id0, id1)], pairs6 = PPFMap[computePPF(id2, id3)] are looked up in the
+ * device table of pgp_set_ppf_map (which must have been given the pair lists), then
+ * FindCongruentQuadrilaterals(invariant1, invariant2, threshold, ...) as in pgp_find_congruent.
+ * base_ids[n_bases][4]: scene ids in TryQuadrilateral's order; base_xyz[n_bases][4][3]: their
+ * (centred) positions; invariants[n_bases][2].  n_quads[n_bases] receives every base's full quad
+ * count; the sorted quad lists stay ON THE DEVICE until the next call:
+ *   pgp_congruent_batch_quads copies the picked quads (picks[m][2] = (base, j): the j-th quad of
+ *     that base in the reference's order) to the host, quads[m][4];
+ *   pgp_congruent_batch_fit runs ComputeRigidTransformFromCongruentPair (as
+ *     pgp_rigid_from_congruent) on the picked (base, quad) pairs without the quads leaving the
+ *     device: the reference's sampling of <= 100 quads per base (base.cc:1858-1872) decides the picks. */
+int pgp_find_congruent_batch(pgp_ctx* ctx, const int* base_ids, const float* base_xyz, const float* invariants,
+                             int n_bases, float threshold, int* n_quads);
+int pgp_congruent_batch_quads(pgp_ctx* ctx, const int* picks, int m, int* quads);
+int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                            const float centroid_Q[3], float* T, double* pose, int* status, float* rms);
+
 /* ICP refinement.  Replaces the inner loop behind pcl::recognition::TrimmedICP::align
  * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and
  * pcl::IterativeClosestPoint::align (utilities.cpp:697-703; PPE/data_layer/SceneCfg.cpp:101,135-141)

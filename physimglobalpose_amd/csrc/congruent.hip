@@ -136,6 +136,8 @@ struct ConeTable {
   float v[56][3];  // (sinAlpha cos(theta_a), sinAlpha sin(theta_a), cosAlpha)
 };
 
+int cone_for_base(const float base[12], float* cone /*[56][3]*/);   // defined with the batch launcher below
+
 struct CsArgs {
   const float4* Qw;  // world (centred) search model
   const float4* Qu;  // unit-cube image
@@ -267,6 +269,188 @@ __global__ __launch_bounds__(256) void emit_quads(const unsigned long long* __re
   quads[k] = make_int4(p.x, p.y, q.x, q.y);
 }
 
+
+// ---------------- FindCongruentQuadrilaterals for MANY bases in one pass ----------------
+// The drop-in extracts congruent sets for ~100 bases per object (base.cc:1855-1874).  Driven base by
+// base that is ~12 small launches, two host syncs and two list uploads each (24 ms per object,
+// round 1).  Here every base's pair lists are ranges of the device-resident pair-feature table
+// (pgp_set_ppf_map: pairs1 = PPFMap[ppf(b0,b1)], pairs6 = PPFMap[ppf(b2,b3)], base.cc:1970-1981),
+// one thread handles one (base, pair), the P-pairs of all bases share ONE bucket table (the base id
+// is part of the hash and of the entry), and the match keys (base | P-pair | Q-pair) are sorted
+// once -- per base that is the reference's std::set order again.  Same arithmetic per pair as the
+// single-base kernels above; identical lists (tests/test_congruent_batch_gpu.py).
+struct BatchBase {
+  float inv1, inv2;
+  uint32_t p_off, p_cnt, q_off, q_cnt;   // ranges of the table's pair array
+  uint32_t p_flat, q_flat;               // first flat thread index of this base's P / Q pairs
+  int cone_nb;
+  int pad;
+};
+
+struct CsBatchArgs {
+  const float4* Qw;
+  const float4* Qu;
+  int nQs;
+  const int2* pairs;          // the table's pair array
+  const BatchBase* bases;
+  int nb;
+  const float* cones;         // [nb][56][3]
+  float threshold, epsilon, nepsilon;
+  int eg;
+  unsigned bmask;
+  uint32_t* bucket_cnt;
+  const uint32_t* bucket_start;
+  int4* entries;              // {cell_lo, cell_hi, bin | base << 16, P-pair index}
+  uint32_t* q_cnt;
+  const uint32_t* q_start;
+  unsigned long long* keys;   // base << 48 | P-pair << 24 | Q-pair
+  uint32_t total_p, total_q;
+};
+
+__device__ __forceinline__ int base_of(const BatchBase* __restrict__ bases, int nb, uint32_t t, bool q_side) {
+  int lo = 0, hi = nb - 1;   // last base whose first flat index is <= t
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    const uint32_t f = q_side ? bases[mid].q_flat : bases[mid].p_flat;
+    if (f <= t) lo = mid;
+    else hi = mid - 1;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ unsigned bucket_of_b(long long cell, int b, unsigned mask) {
+  unsigned long long h = ((unsigned long long)cell * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)(b + 1) * 0xC2B2AE3D27D4EB4Full);
+  h *= 0xD6E8FEB86659FD93ull;
+  return (unsigned)(h >> 40) & mask;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.total_p) return;
+  const int b = base_of(a.bases, a.nb, t, false);
+  const BatchBase B = a.bases[b];
+  const uint32_t i = t - B.p_flat;
+  const int2 pr = a.pairs[B.p_off + i];
+  if ((unsigned)pr.x >= (unsigned)a.nQs || (unsigned)pr.y >= (unsigned)a.nQs) return;
+  V3 p1 = ld3(a.Qu, pr.x), p2 = ld3(a.Qu, pr.y);
+  V3 n = normalized(vsub(p2, p1));
+  long long c = pos_cell(lerp_pt(p1, p2, B.inv1), a.epsilon, a.eg);
+  int bin = normal_bin(n, a.nepsilon);
+  if (c < 0 || bin < 0) return;  // addElement returns false
+  unsigned bk = bucket_of_b(c, b, a.bmask);
+  uint32_t slot = atomicAdd(&a.bucket_cnt[bk], 1u);
+  if (FILL)
+    a.entries[a.bucket_start[bk] + slot] = make_int4((int)(c & 0xFFFFFFFFll), (int)(c >> 32), bin | (b << 16), (int)i);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(128) void bq_match(CsBatchArgs a) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= a.total_q) return;
+  const int b = base_of(a.bases, a.nb, t, true);
+  const BatchBase B = a.bases[b];
+  const uint32_t i = t - B.q_flat;
+  const int2 qr = a.pairs[B.q_off + i];
+  const float* cone = a.cones + (size_t)b * 168;
+  uint32_t found = 0;
+  const uint32_t out0 = FILL ? a.q_start[t] : 0u;
+  if ((unsigned)qr.x < (unsigned)a.nQs && (unsigned)qr.y < (unsigned)a.nQs) {
+    V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
+    long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
+    if (c >= 0) {
+      unsigned bk = bucket_of_b(c, b, a.bmask);
+      uint32_t s = a.bucket_start[bk], e = a.bucket_start[bk + 1];
+      const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
+      bool any = false;
+      for (uint32_t k = s; k < e && !any; ++k) {
+        int4 en = a.entries[k];
+        any = en.x == clo && en.y == chi && (en.z >> 16) == b;
+      }
+      if (any) {
+        V3 queryn = normalized(vsub(p2, p1));
+        V3 v1 = normalized(queryn);
+        float cq = add(mul(v1.x, 0.f), add(mul(v1.y, 0.f), mul(v1.z, 1.f)));
+        V3 qv;
+        float qw;
+        if (cq < add(-1.0f, 1e-5f)) {
+          float cc = cq > -1.0f ? cq : -1.0f;
+          float w2 = mul(add(1.0f, cc), 0.5f);
+          qw = sqrt_rn(w2);
+          qv = {sqrt_rn(sub(1.0f, w2)), 0.f, 0.f};
+        } else {
+          V3 axis = {sub(mul(0.f, v1.z), mul(1.f, v1.y)), sub(mul(1.f, v1.x), mul(0.f, v1.z)),
+                     sub(mul(0.f, v1.y), mul(0.f, v1.x))};
+          float sq = sqrt_rn(mul(add(1.0f, cq), 2.0f));
+          float invs = fdiv(1.0f, sq);
+          qv = {mul(axis.x, invs), mul(axis.y, invs), mul(axis.z, invs)};
+          qw = mul(sq, 0.5f);
+        }
+        uint32_t colored[11];
+#pragma unroll
+        for (int w = 0; w < 11; ++w) colored[w] = 0u;
+        for (int s2 = 0; s2 < B.cone_nb; ++s2) {
+          V3 v = {cone[3 * s2], cone[3 * s2 + 1], cone[3 * s2 + 2]};
+          V3 uv = cross(qv, v);
+          uv = {add(uv.x, uv.x), add(uv.y, uv.y), add(uv.z, uv.z)};
+          V3 c2 = cross(qv, uv);
+          V3 r = {add(add(v.x, mul(qw, uv.x)), c2.x), add(add(v.y, mul(qw, uv.y)), c2.y),
+                  add(add(v.z, mul(qw, uv.z)), c2.z)};
+          int id = normal_bin(normalized(r), a.nepsilon);
+          if (id >= 0) {
+#pragma unroll
+            for (int w = 0; w < 11; ++w)
+              if (w == (id >> 5)) colored[w] |= 1u << (id & 31);
+          }
+        }
+        V3 queryQ = lerp_pt(ld3(a.Qw, qr.x), ld3(a.Qw, qr.y), B.inv2);
+        for (uint32_t k = s; k < e; ++k) {
+          int4 en = a.entries[k];
+          if (en.x != clo || en.y != chi || (en.z >> 16) != b) continue;
+          const int bin = en.z & 0xFFFF;
+          uint32_t word = 0;
+#pragma unroll
+          for (int w = 0; w < 11; ++w)
+            if (w == (bin >> 5)) word = colored[w];
+          if (!((word >> (bin & 31)) & 1u)) continue;
+          int2 pp = a.pairs[B.p_off + (uint32_t)en.w];
+          V3 w1 = ld3(a.Qw, pp.x), w2 = ld3(a.Qw, pp.y);
+          V3 dd = vsub(w2, w1);
+          V3 ip = {add(w1.x, mul(dd.x, B.inv1)), add(w1.y, mul(dd.y, B.inv1)), add(w1.z, mul(dd.z, B.inv1))};
+          if (sqnorm(vsub(queryQ, ip)) <= a.threshold) {
+            if (FILL)
+              a.keys[out0 + found] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)en.w << 24) |
+                                     (unsigned long long)i;
+            ++found;
+          }
+        }
+      }
+    }
+  }
+  if (!FILL) a.q_cnt[t] = found;
+}
+
+// matches per base = difference of the scanned counts at the base's Q range
+__global__ void batch_base_counts(const uint32_t* __restrict__ q_start, const BatchBase* __restrict__ bases, int nb,
+                                  uint32_t total_q, uint32_t* __restrict__ base_start) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b > nb) return;
+  base_start[b] = b == nb ? q_start[total_q] : q_start[bases[b].q_flat];
+}
+
+// picks (base, j) -> the j-th quad of that base in the reference's order
+__global__ void batch_gather(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ base_start,
+                             const BatchBase* __restrict__ bases, const int2* __restrict__ pairs,
+                             const int2* __restrict__ picks, int m, int4* __restrict__ quads) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= m) return;
+  const int2 pk = picks[t];
+  const BatchBase B = bases[pk.x];
+  const unsigned long long key = keys[base_start[pk.x] + (uint32_t)pk.y];
+  const int2 p = pairs[B.p_off + (uint32_t)((key >> 24) & 0xFFFFFFull)], q = pairs[B.q_off + (uint32_t)(key & 0xFFFFFFull)];
+  quads[t] = make_int4(p.x, p.y, q.x, q.y);
+}
+
 }  // namespace
 
 // PairCreationFunctor::synch3DContent (pairCreationFunctor.h:102-138): centre + ratio of the
@@ -338,31 +522,6 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
     return PGP_ESTATE;
   }
   if (nP <= 0 || nQ <= 0) return PGP_OK;
-  // ---- per-base constants, host libm exactly as the reference evaluates them -------------
-  auto normalized_h = [](const float v[3], float o[3]) {
-    float x = v[0] * v[0], y = v[1] * v[1], z = v[2] * v[2];
-    float t = y + z;
-    float s = x + t;
-    if (s > 0.f) {
-      float n = std::sqrt(s);
-      o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
-    } else {
-      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
-    }
-  };
-  float d01[3], d23[3], u01[3], u23[3];
-  for (int k = 0; k < 3; ++k) {
-    d01[k] = base[3 + k] - base[k];
-    d23[k] = base[9 + k] - base[6 + k];
-  }
-  normalized_h(d01, u01);
-  normalized_h(d23, u23);
-  float cosAlpha;
-  {
-    float x = u01[0] * u23[0], y = u01[1] * u23[1], z = u01[2] * u23[2];
-    float t = y + z;
-    cosAlpha = x + t;  // super4pcs.cc:107-109
-  }
   CsArgs a{};
   const float eps = threshold / ctx->cs_ratio;          // getNormalizedEpsilon
   const int gridDepth = (int)(-std::log2(eps));          // normalset.h:116
@@ -373,22 +532,9 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
   a.eg = (int)std::pow(2, gridDepth);
   a.epsilon = 1.f / (float)a.eg;
   a.nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:88
+  // per-base constants, host libm exactly as the reference evaluates them (cone_for_base)
   ConeTable cone{};
-  {
-    const float alpha = std::acos(cosAlpha);
-    const float perimeter = (float)((double)2.0f * M_PI * (double)std::atan(alpha));
-    const float nbf = 2 * std::ceil(perimeter * 7.0f / 2.0f);
-    const unsigned nb = (nbf == nbf && nbf > 0.f && nbf <= 56.f) ? (unsigned)nbf : 0u;  // NaN: UB in the reference
-    const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
-    const float sinAlpha = std::sin(alpha);
-    cone.nb = (int)nb;
-    for (unsigned s = 0; s < nb; ++s) {
-      float theta = (float)s * angleStep;
-      cone.v[s][0] = sinAlpha * std::cos(theta);
-      cone.v[s][1] = sinAlpha * std::sin(theta);
-      cone.v[s][2] = cosAlpha;
-    }
-  }
+  cone.nb = cone_for_base(base, &cone.v[0][0]);
   // ---- buffers -------------------------------------------------------------------------------
   unsigned nbk = 1024;
   while (nbk < 2u * (unsigned)nP && nbk < (1u << 24)) nbk <<= 1;
@@ -457,6 +603,223 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
   const uint32_t n_emit = total < (uint32_t)cap ? total : (uint32_t)cap;
   hipLaunchKernelGGL(emit_quads, dim3((n_emit + 255) / 256), dim3(256), 0, st,
                      (const unsigned long long*)keys_out, n_emit, a.Pp, a.Qp, reinterpret_cast<int4*>(d_quads));
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+
+namespace {
+
+// Per-base constants of FindCongruentQuadrilaterals that need the host libm (super4pcs.cc:107-109,
+// normalset.hpp:175-196): the cone of half-angle acos(<u01, u23>) as <= 56 sample vectors.
+int cone_for_base(const float base[12], float* cone /*[56][3]*/) {
+  auto normalized_h = [](const float v[3], float o[3]) {
+    float x = v[0] * v[0], y = v[1] * v[1], z = v[2] * v[2];
+    float t = y + z;
+    float s = x + t;
+    if (s > 0.f) {
+      float n = std::sqrt(s);
+      o[0] = v[0] / n; o[1] = v[1] / n; o[2] = v[2] / n;
+    } else {
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    }
+  };
+  float d01[3], d23[3], u01[3], u23[3];
+  for (int k = 0; k < 3; ++k) {
+    d01[k] = base[3 + k] - base[k];
+    d23[k] = base[9 + k] - base[6 + k];
+  }
+  normalized_h(d01, u01);
+  normalized_h(d23, u23);
+  float cosAlpha;
+  {
+    float x = u01[0] * u23[0], y = u01[1] * u23[1], z = u01[2] * u23[2];
+    float t = y + z;
+    cosAlpha = x + t;
+  }
+  const float alpha = std::acos(cosAlpha);
+  const float perimeter = (float)((double)2.0f * M_PI * (double)std::atan(alpha));
+  const float nbf = 2 * std::ceil(perimeter * 7.0f / 2.0f);
+  const unsigned nb = (nbf == nbf && nbf > 0.f && nbf <= 56.f) ? (unsigned)nbf : 0u;
+  const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
+  const float sinAlpha = std::sin(alpha);
+  for (unsigned s = 0; s < nb; ++s) {
+    float theta = (float)s * angleStep;
+    cone[3 * s] = sinAlpha * std::cos(theta);
+    cone[3 * s + 1] = sinAlpha * std::sin(theta);
+    cone[3 * s + 2] = cosAlpha;
+  }
+  return (int)nb;
+}
+
+}  // namespace
+
+// Phase 1 + 2 for all bases: leaves the sorted match keys and the per-base starts in the context.
+int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
+                                int nb, float threshold, int* h_n_quads, hipStream_t st) {
+  ctx->csb_nb = 0;
+  if (ctx->nQs <= 0 || !ctx->d_Qs.p) {
+    set_error("no search model: call pgp_set_search_model first");
+    return PGP_ESTATE;
+  }
+  if (!ctx->ppf_ready || ctx->ppf_n_pairs <= 0) {
+    set_error("no pair-feature table with pair lists: call pgp_set_ppf_map(keys, counts, pairs) first");
+    return PGP_ESTATE;
+  }
+  if (nb > 65535) {
+    set_error("pgp_find_congruent_batch: at most 65535 bases per call");
+    return PGP_EINVAL;
+  }
+  for (int b = 0; b < nb; ++b) h_n_quads[b] = 0;
+  if (nb == 0) return PGP_OK;
+  // ---- which rows of the table are pairs1 / pairs6 of every base: computePPF on the device
+  std::vector<int> edge_pairs((size_t)nb * 4), feat((size_t)nb * 8), rows((size_t)nb * 2);
+  for (int b = 0; b < nb; ++b) {
+    edge_pairs[4 * b] = h_base_ids[4 * b];       // computePPF(base_id1, base_id2)
+    edge_pairs[4 * b + 1] = h_base_ids[4 * b + 1];
+    edge_pairs[4 * b + 2] = h_base_ids[4 * b + 2];   // computePPF(base_id3, base_id4)
+    edge_pairs[4 * b + 3] = h_base_ids[4 * b + 3];
+  }
+  int rc = launch_ppf_features(ctx, edge_pairs.data(), 2 * nb, feat.data(), rows.data(), st);
+  if (rc != PGP_OK) return rc;
+  const float eps = threshold / ctx->cs_ratio;          // getNormalizedEpsilon
+  const int gridDepth = (int)(-std::log2(eps));          // normalset.h:116
+  if (!(eps > 0.f) || gridDepth < 0 || gridDepth > 20) {
+    set_error("find_congruent: threshold %g gives an unusable grid depth %d", (double)threshold, gridDepth);
+    return PGP_EINVAL;
+  }
+  std::vector<BatchBase> hb((size_t)nb);
+  std::vector<float> cones((size_t)nb * 168, 0.f);
+  uint64_t tp = 0, tq = 0;
+  for (int b = 0; b < nb; ++b) {
+    BatchBase& B = hb[b];
+    B.inv1 = h_inv[2 * b];
+    B.inv2 = h_inv[2 * b + 1];
+    const int r1 = rows[2 * b], r6 = rows[2 * b + 1];
+    B.p_off = B.p_cnt = B.q_off = B.q_cnt = 0;
+    if (r1 >= 0 && r6 >= 0) {   // pairs1.size() == 0 || pairs6.size() == 0 -> no quads for this base
+      const uint32_t c1 = ctx->ppf_off_host[r1 + 1] - ctx->ppf_off_host[r1], c6 = ctx->ppf_off_host[r6 + 1] - ctx->ppf_off_host[r6];
+      if (c1 > 0 && c6 > 0) {
+        B.p_off = ctx->ppf_off_host[r1];
+        B.p_cnt = c1;
+        B.q_off = ctx->ppf_off_host[r6];
+        B.q_cnt = c6;
+      }
+    }
+    if (B.p_cnt >= (1u << 24) || B.q_cnt >= (1u << 24)) {
+      set_error("pgp_find_congruent_batch: a pair list exceeds 2^24 entries");
+      return PGP_EINVAL;
+    }
+    B.p_flat = (uint32_t)tp;
+    B.q_flat = (uint32_t)tq;
+    tp += B.p_cnt;
+    tq += B.q_cnt;
+    B.cone_nb = B.p_cnt ? cone_for_base(h_base_xyz + 12 * (size_t)b, cones.data() + 168 * (size_t)b) : 0;
+    B.pad = 0;
+  }
+  if (tp >= (1ull << 31) || tq >= (1ull << 31)) {
+    set_error("pgp_find_congruent_batch: more than 2^31 pairs in one batch");
+    return PGP_EINVAL;
+  }
+  if (tp == 0 || tq == 0) return PGP_OK;
+  CsBatchArgs a{};
+  a.eg = (int)std::pow(2, gridDepth);
+  a.epsilon = 1.f / (float)a.eg;
+  a.nepsilon = (float)((double)(1.0f / 7.0f) + 0.00001);  // normalset.h:88
+  unsigned nbk = 1024;
+  while (nbk < 2u * (unsigned)tp && nbk < (1u << 26)) nbk <<= 1;
+  a.bmask = nbk - 1;
+  const size_t n_cnt = (size_t)nbk + 1 + (size_t)tq + 1;
+  if ((rc = ctx->d_cs_cnt.ensure(n_cnt * 8 + 64)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cs_entries.ensure((size_t)tp * 16 + 16)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure((n_cnt / 2048 + 2) * 4)) != PGP_OK) return rc;
+  // bases | cones | base_start, in one staging buffer
+  const size_t bb = ((size_t)nb * sizeof(BatchBase) + 255) & ~(size_t)255, cb = ((size_t)nb * 168 * 4 + 255) & ~(size_t)255;
+  if ((rc = ctx->d_csb.ensure(bb + cb + ((size_t)nb + 1) * 4 + 64)) != PGP_OK) return rc;
+  unsigned char* sb = ctx->d_csb.as<unsigned char>();
+  BatchBase* d_bases = reinterpret_cast<BatchBase*>(sb);
+  float* d_cones = reinterpret_cast<float*>(sb + bb);
+  uint32_t* d_base_start = reinterpret_cast<uint32_t*>(sb + bb + cb);
+  PGP_HIP(hipMemcpyAsync(d_bases, hb.data(), (size_t)nb * sizeof(BatchBase), hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_cones, cones.data(), (size_t)nb * 168 * 4, hipMemcpyHostToDevice, st));
+  uint32_t* bcnt = ctx->d_cs_cnt.as<uint32_t>();
+  uint32_t* bstart = bcnt + (nbk + 1);
+  uint32_t* qcnt = bstart + (nbk + 1);
+  uint32_t* qstart = qcnt + (tq + 1);
+  a.Qw = ctx->d_Qs.as<float4>();
+  a.Qu = ctx->d_Qs_unit.as<float4>();
+  a.nQs = ctx->nQs;
+  a.pairs = ctx->d_ppf_pairs.as<int2>();
+  a.bases = d_bases;
+  a.nb = nb;
+  a.cones = d_cones;
+  a.threshold = threshold;
+  a.bucket_cnt = bcnt;
+  a.bucket_start = bstart;
+  a.entries = ctx->d_cs_entries.as<int4>();
+  a.q_cnt = qcnt;
+  a.q_start = qstart;
+  a.total_p = (uint32_t)tp;
+  a.total_q = (uint32_t)tq;
+  uint32_t* scan_tmp = ctx->d_scan_tmp.as<uint32_t>();
+  const dim3 gp((unsigned)((tp + 255) / 256)), gq((unsigned)((tq + 127) / 128));
+  PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
+  hipLaunchKernelGGL(bp_entries<false>, gp, dim3(256), 0, st, a);
+  if ((rc = device_exclusive_scan(bcnt, bstart, (size_t)nbk + 1, scan_tmp, st)) != PGP_OK) return rc;
+  PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
+  hipLaunchKernelGGL(bp_entries<true>, gp, dim3(256), 0, st, a);
+  PGP_HIP(hipMemsetAsync(qcnt + tq, 0, 4, st));
+  hipLaunchKernelGGL(bq_match<false>, gq, dim3(128), 0, st, a);
+  if ((rc = device_exclusive_scan(qcnt, qstart, (size_t)tq + 1, scan_tmp, st)) != PGP_OK) return rc;
+  hipLaunchKernelGGL(batch_base_counts, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)qstart,
+                     (const BatchBase*)d_bases, nb, (uint32_t)tq, d_base_start);
+  std::vector<uint32_t> starts((size_t)nb + 1);
+  PGP_HIP(hipMemcpyAsync(starts.data(), d_base_start, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  const uint32_t total = starts[nb];
+  for (int b = 0; b < nb; ++b) h_n_quads[b] = (int)(starts[b + 1] - starts[b]);
+  ctx->csb_nb = nb;
+  ctx->csb_total = total;
+  if (total == 0) return PGP_OK;
+  size_t sort_bytes = 0;
+  hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
+                                           (unsigned long long*)nullptr, (size_t)total, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  if ((rc = ctx->d_cs_keys.ensure((size_t)total * 16 + sort_bytes + 256)) != PGP_OK) return rc;
+  unsigned long long* keys_in = ctx->d_cs_keys.as<unsigned long long>();
+  unsigned long long* keys_out = keys_in + total;
+  void* sort_tmp = keys_out + total;
+  a.keys = keys_in;
+  hipLaunchKernelGGL(bq_match<true>, gq, dim3(128), 0, st, a);
+  he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)total, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+// picks[m][2] = (base, j) -> d_quads[m] (int4), on the sorted keys left by the call above
+int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st) {
+  if (ctx->csb_nb <= 0 || ctx->csb_total == 0) {
+    set_error("no congruent batch: call pgp_find_congruent_batch first");
+    return PGP_ESTATE;
+  }
+  int rc = ctx->d_csb_picks.ensure((size_t)m * 8 + 16);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_csb_picks.p, h_picks, (size_t)m * 8, hipMemcpyHostToDevice, st));
+  const int nb = ctx->csb_nb;
+  const size_t bb = ((size_t)nb * sizeof(BatchBase) + 255) & ~(size_t)255, cb = ((size_t)nb * 168 * 4 + 255) & ~(size_t)255;
+  unsigned char* sb = ctx->d_csb.as<unsigned char>();
+  const BatchBase* d_bases = reinterpret_cast<const BatchBase*>(sb);
+  const uint32_t* d_base_start = reinterpret_cast<const uint32_t*>(sb + bb + cb);
+  const unsigned long long* keys_out = ctx->d_cs_keys.as<unsigned long long>() + ctx->csb_total;
+  hipLaunchKernelGGL(batch_gather, dim3((m + 255) / 256), dim3(256), 0, st, keys_out, d_base_start, d_bases,
+                     (const int2*)ctx->d_ppf_pairs.as<int2>(), (const int2*)ctx->d_csb_picks.as<int2>(), m, d_quads);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

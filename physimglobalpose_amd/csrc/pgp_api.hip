@@ -150,7 +150,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -620,6 +620,74 @@ int pgp_find_congruent(pgp_ctx* ctx, const float* base, float invariant1, float 
     PGP_HIP(hipMemcpyAsync(quads, ctx->d_cs_out.p, (size_t)n_copy * 16, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
   *n_quads = total;
+  return PGP_OK;
+}
+
+int pgp_find_congruent_batch(pgp_ctx* ctx, const int* base_ids, const float* base_xyz, const float* invariants,
+                             int n_bases, float threshold, int* n_quads) {
+  if (!ctx || n_bases < 0 || (n_bases > 0 && (!base_ids || !base_xyz || !invariants || !n_quads))) {
+    set_error("pgp_find_congruent_batch: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_find_congruent_batch(ctx, base_ids, base_xyz, invariants, n_bases, threshold, n_quads, ctx->stream);
+}
+
+int pgp_congruent_batch_quads(pgp_ctx* ctx, const int* picks, int m, int* quads) {
+  if (!ctx || m < 0 || (m > 0 && (!picks || !quads))) {
+    set_error("pgp_congruent_batch_quads: bad argument");
+    return PGP_EINVAL;
+  }
+  if (m == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  int rc = ctx->d_cs_out.ensure((size_t)m * 16);
+  if (rc != PGP_OK) return rc;
+  rc = launch_congruent_batch_gather(ctx, picks, m, ctx->d_cs_out.as<int4>(), ctx->stream);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(quads, ctx->d_cs_out.p, (size_t)m * 16, hipMemcpyDeviceToHost, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  return PGP_OK;
+}
+
+int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                            const float centroid_Q[3], float* T, double* pose, int* status, float* rms) {
+  if (!ctx || m < 0 || !centroid_P || !centroid_Q || (m > 0 && (!picks || !base_ids || !T || !status))) {
+    set_error("pgp_congruent_batch_fit: bad argument");
+    return PGP_EINVAL;
+  }
+  if (m == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)m;
+  int rc;
+  if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
+  int* d_b = ctx->d_ids.as<int>();
+  int* d_q = d_b + 4 * N;
+  // the base of every pick (scene ids), staged from the host; the quads never leave the device
+  std::vector<int> hb(4 * N);
+  for (size_t k = 0; k < N; ++k) {
+    const int b = picks[2 * k];
+    if (b < 0 || b >= ctx->csb_nb) {
+      set_error("pgp_congruent_batch_fit: pick %zu names base %d of %d", k, b, ctx->csb_nb);
+      return PGP_EINVAL;
+    }
+    for (int j = 0; j < 4; ++j) hb[4 * k + j] = base_ids[4 * (size_t)b + j];
+  }
+  PGP_HIP(hipMemcpyAsync(d_b, hb.data(), N * 16, hipMemcpyHostToDevice, st));
+  rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st);
+  if (rc != PGP_OK) return rc;
+  double* d_pose = ctx->d_rig.as<double>();
+  float* d_T = reinterpret_cast<float*>(d_pose + 16 * N);
+  float* d_rms = d_T + 16 * N;
+  int* d_status = reinterpret_cast<int*>(d_rms + N);
+  rc = launch_rigid(ctx, d_b, d_q, m, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms, st);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(T, d_T, N * 64, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemcpyAsync(status, d_status, N * 4, hipMemcpyDeviceToHost, st));
+  if (pose) PGP_HIP(hipMemcpyAsync(pose, d_pose, N * 128, hipMemcpyDeviceToHost, st));
+  if (rms) PGP_HIP(hipMemcpyAsync(rms, d_rms, N * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));   // also: hb is a stack-owned staging vector
   return PGP_OK;
 }
 

@@ -93,6 +93,9 @@ struct pgp_ctx {
   long long ppf_n_pairs = 0;
   std::vector<uint32_t> ppf_off_host;   // pair-list offsets per key, host copy
   float ppf_tpos[9] = {0}, ppf_tneg[9] = {0};   // ratio thresholds of the 10-degree angle bins (host atan2f)
+  pgp::DevBuf d_csb, d_csb_picks;       // batched congruent sets: bases | cones | per-base starts; staged picks
+  int csb_nb = 0;                       // bases of the last pgp_find_congruent_batch (its keys are still resident)
+  uint32_t csb_total = 0;
   pgp::DevBuf d_prob_cdf;               // double prefix sums of the scene weights (first draw)
   bool prob_cdf_valid = false;
   pgp::DevBuf d_sel_ws;                 // base-selection workspace / staging
@@ -158,6 +161,10 @@ int launch_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* d_pa
 int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float inv2, float threshold,
                           const int* d_Pp, int nP, const int* d_Qp, int nQ, int* d_quads, int cap,
                           int* n_quads_host, hipStream_t st);
+
+int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
+                                int nb, float threshold, int* h_n_quads, hipStream_t st);
+int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st);
 
 // lcp_score.hip
 int tiles_for(int nQ);

@@ -200,6 +200,36 @@ class LcpScorer:
         _lib.check(self._lib.pgp_base_invariants(self._h, ids.ctypes.data_as(_i), m, _fp(inv), ok.ctypes.data_as(_i)))
         return ids, inv[:m], ok[:m]
 
+    def find_congruent_batch(self, base_ids, base_xyz, invariants, threshold):
+        """All bases of an object at once (pairs from the device PPF table): returns the quad counts (nb,)."""
+        b = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        x = _f32(base_xyz).reshape(-1, 12)
+        v = _f32(invariants).reshape(-1, 2)
+        n = np.zeros(max(len(b), 1), np.int32)
+        _lib.check(self._lib.pgp_find_congruent_batch(self._h, b.ctypes.data_as(_i), _fp(x), _fp(v), len(b),
+                                                      C.c_float(threshold), n.ctypes.data_as(_i)))
+        return n[: len(b)]
+
+    def congruent_batch_quads(self, picks):
+        pk = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)
+        out = np.zeros((max(len(pk), 1), 4), np.int32)
+        _lib.check(self._lib.pgp_congruent_batch_quads(self._h, pk.ctypes.data_as(_i), len(pk), out.ctypes.data_as(_i)))
+        return out[: len(pk)]
+
+    def congruent_batch_fit(self, picks, base_ids, centroid_P, centroid_Q):
+        pk = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)
+        b = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        n = len(pk)
+        cP, cQ = _f32(centroid_P).reshape(3), _f32(centroid_Q).reshape(3)
+        T = np.zeros((max(n, 1), 16), np.float32)
+        pose = np.zeros((max(n, 1), 16), np.float64)
+        status = np.zeros(max(n, 1), np.int32)
+        rms = np.zeros(max(n, 1), np.float32)
+        _lib.check(self._lib.pgp_congruent_batch_fit(
+            self._h, pk.ctypes.data_as(_i), b.ctypes.data_as(_i), n, _fp(cP), _fp(cQ), _fp(T),
+            pose.ctypes.data_as(C.POINTER(C.c_double)), status.ctypes.data_as(_i), _fp(rms)))
+        return T[:n], pose[:n], status[:n], rms[:n]
+
     # ---- segment pre-processing (ObjectPoseCandidateSet.cpp:28-51) -----------------------------------
     def radius_outlier_filter(self, xyz, nrm=None, radius=0.03, min_neighbors=10):
         """Returns (keep mask (n,) bool, flipped + re-normalised normals (n,3) or None)."""

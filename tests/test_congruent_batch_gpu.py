@@ -1,0 +1,79 @@
+"""All bases of an object in one pass (pgp_find_congruent_batch: pair lists looked up in the device
+pair-feature table, one bucket table and one sort for every base) against the single-base entry
+point (which is pinned on the reference's own IndexedNormalSet, tests/golden/congruent_*.npz):
+identical quad lists, in the same order, and identical rigid fits for picked (base, quad) pairs."""
+import tempfile
+
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import LcpScorer
+from _dropin import make_dropin_case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case():
+    with tempfile.TemporaryDirectory() as d:
+        _, c = make_dropin_case(d, n_scene=8000, n_model=1500, n_search=500)
+    w, table = c["w"], c["table"]
+    keys = np.array(list(table.keys()), np.int32)
+    counts = np.array([len(table[tuple(k)]) for k in keys.tolist()], np.int32)
+    pairs = np.concatenate([np.array(table[tuple(k)], np.int32).reshape(-1, 2) for k in keys.tolist()])
+    sc = LcpScorer()
+    sc.set_scene(w.P_xyz, w.P_nrm, w.P_w, w.delta)
+    sc.set_search_model(w.Qs_xyz)
+    sc.set_ppf_map(keys, counts, pairs)
+    rng = np.random.default_rng(3)
+    ids, inv, status = sc.select_bases(rng.random((96, 4)))
+    ok = status == 1
+    return w, table, keys, sc, ids[ok], inv[ok]
+
+
+def test_batch_equals_base_by_base(case):
+    w, table, keys, sc, ids, inv = case
+    assert len(ids) >= 16
+    base_xyz = w.P_xyz[ids]                                    # (nb, 4, 3)
+    n_quads = sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
+    f01, r01 = sc.ppf_features(ids[:, [0, 1]])
+    f23, r23 = sc.ppf_features(ids[:, [2, 3]])
+    total = 0
+    per_base = []
+    for b in range(len(ids)):
+        if r01[b] < 0 or r23[b] < 0:
+            assert n_quads[b] == 0
+            per_base.append(np.zeros((0, 4), np.int32))
+            continue
+        p1 = np.array(table[tuple(keys[r01[b]].tolist())], np.int32)
+        p6 = np.array(table[tuple(keys[r23[b]].tolist())], np.int32)
+        q = sc.find_congruent(base_xyz[b], inv[b, 0], inv[b, 1], w.delta, p1, p6)
+        assert n_quads[b] == len(q), b
+        per_base.append(q)
+        total += len(q)
+    assert total > 0
+    # the batch's resident lists: every quad of every base, in the reference's order
+    sc.find_congruent_batch(ids, base_xyz, inv, w.delta)       # the single-base calls reused the workspaces
+    picks = np.array([(b, j) for b in range(len(ids)) for j in range(n_quads[b])], np.int32).reshape(-1, 2)
+    got = sc.congruent_batch_quads(picks)
+    assert np.array_equal(got, np.concatenate(per_base))
+    # rigid fits of a sample of picks, without the quads leaving the device
+    rng = np.random.default_rng(5)
+    sel = picks[rng.choice(len(picks), min(len(picks), 2000), replace=False)]
+    T, pose, status, rms = sc.congruent_batch_fit(sel, ids, w.centroid_P, w.centroid_Q)
+    quads_sel = np.array([per_base[b][j] for b, j in sel], np.int32)
+    T2, pose2, status2, rms2 = sc.rigid_from_congruent(ids[sel[:, 0]], quads_sel, w.centroid_P, w.centroid_Q)
+    assert np.array_equal(status, status2) and (status == 1).any()
+    good = status == 1
+    assert np.array_equal(T[good], T2[good]) and np.array_equal(pose[good], pose2[good]) and np.array_equal(rms, rms2)
+
+
+def test_batch_without_pair_lists_is_refused(case):
+    w, table, keys, sc, ids, inv = case
+    other = LcpScorer()
+    other.set_scene(w.P_xyz, w.P_nrm, w.P_w, w.delta)
+    other.set_search_model(w.Qs_xyz)
+    other.set_ppf_map(keys)                                     # presence only
+    from physimglobalpose_amd._lib import PgpError
+    with pytest.raises(PgpError):
+        other.find_congruent_batch(ids, w.P_xyz[ids], inv, w.delta)
