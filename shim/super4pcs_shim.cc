@@ -9,19 +9,23 @@
 // (defined in the reference at S4/super4pcs_test.cc:39-111, declared by its only caller at
 // PPE/hypothesis_generation/ObjectPoseCandidateSet.cpp:5-9) on top of the C ABI of
 // include/pgp.h.  The node links this in place of the reference library and is otherwise
-// unchanged.  Everything data-parallel runs on the GPU (congruent quads, rigid fits, weighted
-// LCP scoring); what stays here is what the reference keeps serial and RNG-driven:
+// unchanged.  Steps 1-3 of Perform_N_steps run on the GPU behind the C ABI: base selection
+// (pgp_select_bases: the weighting loops of SelectQuadrilateralStoCS, the point-pair features, the
+// look-ups in the model's pair-feature table, the draws and TryQuadrilateral, many attempts per
+// launch), congruent sets for all bases at once (pgp_find_congruent_batch), rigid fits
+// (pgp_congruent_batch_fit) and weighted LCP scoring (pgp_score_lcp / pgp_multi_score_lcp).
+// What stays here is the hand-off and the bookkeeping:
 //   file hand-off      PLY x3 + 16-bit probability PNG        super4pcs_test.cc:58-80, base.cc:317-340
-//   init()             centring, per-point weights            base.cc:216-345
-//   base selection     StoCS sampling over the PPF map        base.cc:600-792, 582-598, 150-160
-//   base pairing       TryQuadrilateral / segment distance    base.cc:415-464, 81-148
-//   bookkeeping        <=100 quads per base, running best     base.cc:1855-1874, 1885-1914
+//   init()             centring, per-point weights            base.cc:216-345   (pgp_center, pgp_weights_from_image)
+//   the host's engine  uniform variates of the draws, rand() of the <=100-quads sampling (base.cc:613-617,1858-1866)
+//   bookkeeping        running best, output containers        base.cc:1885-1914
 //
 // Needs Eigen only for the types in the signature (build against the node's Eigen; this
 // repository compiles it against the reference's vendored copy when /root/reference exists).
 // Differences from the reference, all deliberate: read errors return identity/0 instead of
 // exit(-1); hull.ply (hard-coded path, dead code) is not read; base selection gives up after
-// 20 x 100 failed draws instead of looping forever; the best pose is taken from the
+// 20 rounds of 128 attempts instead of looping forever; one engine feeds all attempts (the reference
+// seeds a fresh one from the clock inside every attempt, base.cc:613-614); the best pose is taken from the
 // un-truncated list (the reference indexes the truncated one, base.cc:1787-1790);
 // PGP_SHIM_SEED fixes the RNG seed (the reference seeds from the clock).
 
@@ -242,170 +246,35 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
 }
 
 // ---------------------------------------------------------------------------------------------
-// Host side of Match4PCSBase (serial, RNG-driven parts)
+// Per-thread device state kept across calls: the context (and, with PGP_SHIM_DEVICES > 1, the
+// device group) and the flattened pair-feature table of the object that was matched last -- the
+// node hands the SAME std::map of an object to every request (PPE/data_layer/Objects.cpp:31-49 fills
+// it once), so its 10^4-10^5 keys are flattened and uploaded again only when a different map (by
+// address and size) arrives.  PGP_SHIM_NO_CACHE=1 gives every call a fresh context.
 // ---------------------------------------------------------------------------------------------
-struct Matcher {
-  int nP = 0;
-  std::vector<Vec3> P, Pn;            // centred scene + unit normals (sampled_P_3D_)
-  std::vector<float> prob;            // orig_probabilities_
-  std::map<std::vector<int>, std::vector<std::pair<int, int> > >* PPFMap = nullptr;
-  int trans_disc = 5, rot_disc = 10;  // base.cc:303-304
-
-  static int approximate_bin(int val, int disc) {  // base.cc:150-160
-    int lower = val - (val % disc), upper = lower + disc;
-    return (val - lower < upper - val) ? lower : upper;
-  }
-
-  void computePPF(int i1, int i2, std::vector<int>& ppf) const {  // base.cc:582-598
-    Vec3 p1 = P[i1], p2 = P[i2], n1 = Pn[i1], n2 = Pn[i2];
-    Vec3 u = p1 - p2;
-    int f1 = int(u.norm() * 1000);
-    int f2 = int(std::atan2(n1.cross(u).norm(), n1.dot(u)) * 180 / M_PI);
-    int f3 = int(std::atan2(n2.cross(u).norm(), n2.dot(u)) * 180 / M_PI);
-    int f4 = int(std::atan2(n1.cross(n2).norm(), n1.dot(n2)) * 180 / M_PI);
-    ppf.push_back(approximate_bin(f1, trans_disc));
-    ppf.push_back(approximate_bin(f2, rot_disc));
-    ppf.push_back(approximate_bin(f3, rot_disc));
-    ppf.push_back(approximate_bin(f4, rot_disc));
-  }
-
-  // base.cc:81-148
-  static Scalar distSegmentToSegment(const Vec3& p1, const Vec3& p2, const Vec3& q1, const Vec3& q2,
-                                     double& invariant1, double& invariant2) {
-    static const double kSmallNumber = 0.0001;
-    Vec3 u = p2 - p1, v = q2 - q1, w = p1 - q1;
-    double a = u.dot(u), b = u.dot(v), c = v.dot(v), d = u.dot(w), e = v.dot(w);
-    double f = a * c - b * b;
-    double s1 = 0.0, s2 = f, t1 = 0.0, t2 = f;
-    if (f < kSmallNumber) {
-      s1 = 0.0; s2 = 1.0; t1 = e; t2 = c;
-    } else {
-      s1 = (b * e - c * d);
-      t1 = (a * e - b * d);
-      if (s1 < 0.0) { s1 = 0.0; t1 = e; t2 = c; }
-      else if (s1 > s2) { s1 = s2; t1 = e + b; t2 = c; }
-    }
-    if (t1 < 0.0) {
-      t1 = 0.0;
-      if (-d < 0.0) s1 = 0.0;
-      else if (-d > a) s1 = s2;
-      else { s1 = -d; s2 = a; }
-    } else if (t1 > t2) {
-      t1 = t2;
-      if ((-d + b) < 0.0) s1 = 0;
-      else if ((-d + b) > a) s1 = s2;
-      else { s1 = (-d + b); s2 = a; }
-    }
-    invariant1 = (std::abs(s1) < kSmallNumber ? 0.0 : s1 / s2);
-    invariant2 = (std::abs(t1) < kSmallNumber ? 0.0 : t1 / t2);
-    return (w + ((Scalar)invariant1 * u) - ((Scalar)invariant2 * v)).norm();
-  }
-
-  // base.cc:415-464: best of the 12 pairings of the 4 base points
-  bool TryQuadrilateral(std::array<int, 4>& ids, Scalar& invariant1, Scalar& invariant2) const {
-    Scalar min_distance = std::numeric_limits<Scalar>::max();
-    int best[4] = {-1, -1, -1, -1};
-    for (int i = 0; i < 4; ++i)
-      for (int j = 0; j < 4; ++j) {
-        if (i == j) continue;
-        int k = 0;
-        while (k == i || k == j) k++;
-        int l = 0;
-        while (l == i || l == j || l == k) l++;
-        double li1, li2;
-        Scalar sd = distSegmentToSegment(P[ids[i]], P[ids[j]], P[ids[k]], P[ids[l]], li1, li2);
-        if (sd < min_distance) {
-          min_distance = sd;
-          best[0] = i; best[1] = j; best[2] = k; best[3] = l;
-          invariant1 = (Scalar)li1;
-          invariant2 = (Scalar)li2;
-        }
-      }
-    if (best[0] < 0) return false;
-    std::array<int, 4> tmp = ids;
-    for (int k = 0; k < 4; ++k) ids[k] = tmp[best[k]];
-    return true;
-  }
-
-  // base.cc:600-792: stochastic base sampling weighted by segmentation probability x existence
-  // of the pair feature in the model's PPF map
-  bool SelectQuadrilateralStoCS(std::default_random_engine& gen, std::array<int, 4>& ids, Scalar& inv1,
-                                Scalar& inv2) const {
-    std::vector<int> ppf;
-    std::vector<float> cur(prob);
-    std::discrete_distribution<int> d1(cur.begin(), cur.end());
-    const int base1 = d1(gen);
-    float sum = 0;
-    bool present = false;
-    for (int i = 0; i < nP; ++i) {
-      if (i == base1 || cur[i] == 0) { cur[i] = 0; continue; }
-      ppf.clear();
-      computePPF(base1, i, ppf);
-      float edge = PPFMap->find(ppf) == PPFMap->end() ? 0.f : 1.f;
-      cur[i] = prob[i] * prob[base1] * edge;
-      if (cur[i] != 0) present = true;
-      sum += cur[i];
-    }
-    if (!present) return false;
-    for (int i = 0; i < nP; ++i) cur[i] /= sum;
-    std::discrete_distribution<int> d2(cur.begin(), cur.end());
-    const int base2 = d2(gen);
-
-    sum = 0;
-    present = false;
-    Vec3 v_1 = P[base2] - P[base1];
-    for (int i = 0; i < nP; ++i) {
-      Vec3 v_2 = P[i] - P[base1];
-      float int_angle = std::acos(v_1.dot(v_2)) * 180 / M_PI;  // un-normalised dot, as the reference
-      int_angle = std::min(int_angle, 180 - int_angle);
-      if (i == base1 || i == base2 || cur[i] == 0 || int_angle < 30) { cur[i] = 0; continue; }
-      ppf.clear();
-      computePPF(base2, i, ppf);
-      float edge = PPFMap->find(ppf) == PPFMap->end() ? 0.f : 1.f;
-      cur[i] = cur[i] * prob[base2] * edge;
-      if (cur[i] != 0) present = true;
-      sum += cur[i];
-    }
-    if (!present) return false;
-    for (int i = 0; i < nP; ++i) cur[i] /= sum;
-    std::discrete_distribution<int> d3(cur.begin(), cur.end());
-    const int base3 = d3(gen);
-
-    sum = 0;
-    present = false;
-    const double x1 = P[base1](0), y1 = P[base1](1), z1 = P[base1](2);
-    const double x2 = P[base2](0), y2 = P[base2](1), z2 = P[base2](2);
-    const double x3 = P[base3](0), y3 = P[base3](1), z3 = P[base3](2);
-    for (int i = 0; i < nP; ++i) {
-      if (i == base1 || i == base2 || i == base3 || cur[i] == 0) { cur[i] = 0; continue; }
-      Scalar denom = (-x3 * y2 * z1 + x2 * y3 * z1 + x3 * y1 * z2 - x1 * y3 * z2 - x2 * y1 * z3 + x1 * y2 * z3);
-      if (denom != 0) {  // the 4th point must be close to the plane of the first three
-        Scalar A = (-y2 * z1 + y3 * z1 + y1 * z2 - y3 * z2 - y1 * z3 + y2 * z3) / denom;
-        Scalar B = (x2 * z1 - x3 * z1 - x1 * z2 + x3 * z2 + x1 * z3 - x2 * z3) / denom;
-        Scalar C = (-x2 * y1 + x3 * y1 + x1 * y2 - x3 * y2 - x1 * y3 + x2 * y3) / denom;
-        Scalar planar = std::abs(A * P[i](0) + B * P[i](1) + C * P[i](2) - 1.0);
-        if (planar > 0.01 || (P[i] - P[base1]).norm() < 0.01 || (P[i] - P[base2]).norm() < 0.01 ||
-            (P[i] - P[base3]).norm() < 0.01) {
-          cur[i] = 0;
-          continue;
-        }
-      }
-      ppf.clear();
-      computePPF(base3, i, ppf);
-      float edge = PPFMap->find(ppf) == PPFMap->end() ? 0.f : 1.f;
-      cur[i] = cur[i] * prob[base3] * edge;
-      if (cur[i] != 0) present = true;
-      sum += cur[i];
-    }
-    if (!present) return false;
-    for (int i = 0; i < nP; ++i) cur[i] /= sum;
-    std::discrete_distribution<int> d4(cur.begin(), cur.end());
-    const int base4 = d4(gen);
-    ids = {base1, base2, base3, base4};
-    TryQuadrilateral(ids, inv1, inv2);
-    return true;
+struct ShimState {
+  pgp_ctx* ctx = nullptr;
+  pgp_multi* group = nullptr;
+  const void* map_addr = nullptr;
+  size_t map_size = 0;
+  ~ShimState() {
+    if (group) pgp_multi_destroy(group);
+    if (ctx) pgp_destroy(ctx);
   }
 };
+
+ShimState& shim_state() {
+  static thread_local ShimState st;
+  return st;
+}
+
+int shim_device_count() {   // PGP_SHIM_DEVICES: 1 (default), a number, or "all"
+  const char* v = getenv("PGP_SHIM_DEVICES");
+  if (!v) return 1;
+  if (!strcmp(v, "all")) return 0;
+  const int n = atoi(v);
+  return n > 0 ? n : 1;
+}
 
 void set_identity(std::pair<Eigen::Isometry3d, float>& h) {
   h.first.matrix().setIdentity();
@@ -416,7 +285,6 @@ void set_identity(std::pair<Eigen::Isometry3d, float>& h) {
   do {                                                                                       \
     if ((call) != PGP_OK) {                                                                  \
       std::cerr << "[libsuper4pcs shim] " #call " failed: " << pgp_last_error() << std::endl; \
-      if (ctx) pgp_destroy(ctx);                                                             \
       set_identity(bestHypothesis);                                                          \
       return;                                                                                \
     }                                                                                        \
@@ -533,99 +401,113 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   float cP[3], cQ[3];
   if (pgp_center(seg.xyz.data(), seg.n, qsearch.xyz.data(), qsearch.n, qval.xyz.data(), qval.n, cP, cQ) != PGP_OK) return;
 
-  Matcher m;
-  m.nP = seg.n;
-  m.PPFMap = &PPFMap;
-  m.P.resize(seg.n);
-  m.Pn.resize(seg.n);
-  for (int i = 0; i < seg.n; ++i) {
-    m.P[i] = Vec3(seg.xyz[3 * i], seg.xyz[3 * i + 1], seg.xyz[3 * i + 2]);
-    m.Pn[i] = Vec3(seg.nrm[3 * i], seg.nrm[3 * i + 1], seg.nrm[3 * i + 2]);
-  }
   // ---- per-point weights from the probability image (base.cc:317-340)
-  m.prob.assign(seg.n, 1.f);
+  std::vector<float> prob(seg.n, 1.f);
   if (prob_image && rows > 0 && cols > 0) {
     float K[9];
     for (int r = 0; r < 3; ++r)
       for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
-    pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, m.prob.data());
+    pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, prob.data());
   }
 
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
-  // ---- device state: scene index, validation model, search model
-  SHIM_PGP(pgp_create(&ctx, -1));
-  SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), m.prob.data(), seg.n, delta));
-  SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
+  // ---- device state: scene index, validation model, search model, pair-feature table
+  ShimState local_state;
+  ShimState& st = getenv("PGP_SHIM_NO_CACHE") ? local_state : shim_state();
+  const int n_dev = shim_device_count();   // PGP_SHIM_DEVICES: 1 (default) | n | all
+  if (n_dev != 1) {
+    // hypotheses sharded over the devices of the node (pgp_multi_*: RCCL all-reduce of the scores);
+    // device 0's context of the group also serves the single-device steps
+    if (!st.group) SHIM_PGP(pgp_multi_create(&st.group, nullptr, n_dev));
+    ctx = pgp_multi_context(st.group, 0);
+    SHIM_PGP(pgp_multi_set_scene(st.group, seg.xyz.data(), seg.nrm.data(), prob.data(), seg.n, delta));
+    SHIM_PGP(pgp_multi_set_model(st.group, qval.xyz.data(), qval.nrm.data(), qval.n));
+  } else {
+    if (!st.ctx) SHIM_PGP(pgp_create(&st.ctx, -1));
+    ctx = st.ctx;
+    SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), prob.data(), seg.n, delta));
+    SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
+  }
   SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
+  if (st.map_addr != (const void*)&PPFMap || st.map_size != PPFMap.size()) {
+    // std::map<std::vector<int>, std::vector<std::pair<int,int>>> -> keys | counts | pairs
+    static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int), "pair<int,int> must be two packed ints");
+    std::vector<int> keys, counts, pairs;
+    keys.reserve(4 * PPFMap.size());
+    counts.reserve(PPFMap.size());
+    for (const auto& kv : PPFMap) {
+      if (kv.first.size() != 4) continue;   // computePPF always pushes four features
+      keys.insert(keys.end(), kv.first.begin(), kv.first.end());
+      counts.push_back((int)kv.second.size());
+      const int* p = reinterpret_cast<const int*>(kv.second.data());
+      pairs.insert(pairs.end(), p, p + 2 * kv.second.size());
+    }
+    SHIM_PGP(pgp_set_ppf_map(ctx, keys.data(), counts.data(), pairs.data(), (int)counts.size()));
+    st.map_addr = &PPFMap;
+    st.map_size = PPFMap.size();
+  }
 
   const double ms_setup = ms_since(t_start);
   const auto t_bases = std::chrono::steady_clock::now();
-  // ---- Step 1: base selection (base.cc:1831-1848)
+  // ---- Step 1: base selection (base.cc:1831-1848): rounds of independent attempts, one launch each;
+  // the four uniform variates of an attempt's std::discrete_distribution draws come from this engine
   unsigned seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
   if (const char* s = getenv("PGP_SHIM_SEED")) { seed = (unsigned)strtoul(s, nullptr, 10); srand(seed); }
   std::default_random_engine generator(seed);
-  struct Base { std::array<int, 4> ids; Scalar inv1, inv2; };
-  std::vector<Base> bases;
-  for (int attempt = 0; (int)bases.size() < max_number_of_bases && attempt < 20 * max_number_of_bases; ++attempt) {
-    Base b;
-    if (m.SelectQuadrilateralStoCS(generator, b.ids, b.inv1, b.inv2)) bases.push_back(b);
+  const int attempts_per_round = 128;
+  std::vector<int> base_ids;       // n_bases x 4 (scene ids, TryQuadrilateral's order)
+  std::vector<float> base_inv;     // n_bases x 2
+  {
+    std::vector<double> u(4 * (size_t)attempts_per_round);
+    std::vector<int> ids(4 * (size_t)attempts_per_round), status(attempts_per_round);
+    std::vector<float> inv(2 * (size_t)attempts_per_round);
+    for (int round = 0; round < 20 && (int)(base_ids.size() / 4) < max_number_of_bases; ++round) {
+      for (double& x : u) x = std::generate_canonical<double, 53>(generator);
+      SHIM_PGP(pgp_select_bases(ctx, u.data(), attempts_per_round, ids.data(), inv.data(), status.data()));
+      for (int k = 0; k < attempts_per_round && (int)(base_ids.size() / 4) < max_number_of_bases; ++k) {
+        if (status[k] != 1) continue;
+        base_ids.insert(base_ids.end(), ids.begin() + 4 * k, ids.begin() + 4 * k + 4);
+        base_inv.insert(base_inv.end(), inv.begin() + 2 * k, inv.begin() + 2 * k + 2);
+      }
+    }
   }
+  const int n_bases = (int)(base_ids.size() / 4);
 
   const double ms_bases = ms_since(t_bases);
   const auto t_cs = std::chrono::steady_clock::now();
-  // ---- Step 2: congruent sets (base.cc:1855-1874, 1929-1993) -> (base, quad) pairs
-  std::vector<int> base_ids, quad_ids;  // n x 4 each
-  std::vector<int> quads;
-  for (size_t bi = 0; bi < bases.size(); ++bi) {
-    const Base& b = bases[bi];
-    std::vector<int> ppf_1, ppf_6;
-    m.computePPF(b.ids[0], b.ids[1], ppf_1);
-    m.computePPF(b.ids[2], b.ids[3], ppf_6);
-    auto it1 = PPFMap.find(ppf_1), it6 = PPFMap.find(ppf_6);
-    if (it1 == PPFMap.end() || it6 == PPFMap.end() || it1->second.empty() || it6->second.empty()) continue;
-    float base_xyz[12];
+  // ---- Step 2: congruent sets of every base in one pass (base.cc:1855-1874, 1929-1993), then the
+  // reference's sampling of at most 100 quads per base -> (base, quad) picks
+  std::vector<float> base_xyz(12 * (size_t)n_bases);
+  for (int b = 0; b < n_bases; ++b)
     for (int k = 0; k < 4; ++k)
-      for (int d = 0; d < 3; ++d) base_xyz[3 * k + d] = m.P[b.ids[k]](d);
-    static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int), "pair<int,int> must be two packed ints");
-    const int* p1 = reinterpret_cast<const int*>(it1->second.data());
-    const int* p6 = reinterpret_cast<const int*>(it6->second.data());
-    int n_quads = 0;
-    if (quads.size() < (size_t)4 << 16) quads.resize((size_t)4 << 16);
-    for (;;) {
-      const int cap = (int)(quads.size() / 4);
-      SHIM_PGP(pgp_find_congruent(ctx, base_xyz, b.inv1, b.inv2, delta, p1, (int)it1->second.size(), p6,
-                                  (int)it6->second.size(), quads.data(), cap, &n_quads));
-      if (n_quads <= cap) break;
-      quads.resize((size_t)n_quads * 4);
-    }
-    if (n_quads == 0) continue;
-    std::vector<int> pick;
-    if (n_quads < max_sampled_csets) {
-      for (int j = 0; j < n_quads; ++j) pick.push_back(j);
+      for (int d = 0; d < 3; ++d) base_xyz[12 * (size_t)b + 3 * k + d] = seg.xyz[3 * (size_t)base_ids[4 * b + k] + d];
+  std::vector<int> n_quads(n_bases > 0 ? n_bases : 1, 0);
+  if (n_bases > 0)
+    SHIM_PGP(pgp_find_congruent_batch(ctx, base_ids.data(), base_xyz.data(), base_inv.data(), n_bases, delta,
+                                      n_quads.data()));
+  std::vector<int> picks;   // (base, j) pairs
+  for (int b = 0; b < n_bases; ++b) {
+    const int nq = n_quads[b];
+    if (nq < max_sampled_csets) {
+      for (int j = 0; j < nq; ++j) { picks.push_back(b); picks.push_back(j); }
     } else {  // 100 distinct random quads (the reference iterates an unordered_set; we sort)
       std::set<int> chosen;
-      while ((int)chosen.size() < max_sampled_csets) chosen.insert(rand() % n_quads);
-      pick.assign(chosen.begin(), chosen.end());
-    }
-    for (int j : pick) {
-      for (int k = 0; k < 4; ++k) {
-        base_ids.push_back(b.ids[k]);
-        quad_ids.push_back(quads[4 * (size_t)j + k]);
-      }
+      while ((int)chosen.size() < max_sampled_csets) chosen.insert(rand() % nq);
+      for (int j : chosen) { picks.push_back(b); picks.push_back(j); }
     }
   }
   const double ms_cs = ms_since(t_cs);
   const auto t_fit = std::chrono::steady_clock::now();
-  const int n_pairs = (int)(base_ids.size() / 4);
+  const int n_pairs = (int)(picks.size() / 2);
   std::vector<float> T((size_t)n_pairs * 16);
   std::vector<double> pose((size_t)n_pairs * 16);
   std::vector<int> status(n_pairs);
   if (n_pairs > 0)
-    SHIM_PGP(pgp_rigid_from_congruent(ctx, base_ids.data(), quad_ids.data(), n_pairs, cP, cQ, T.data(),
-                                      pose.data(), status.data(), nullptr));
+    SHIM_PGP(pgp_congruent_batch_fit(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, T.data(), pose.data(),
+                                     status.data(), nullptr));
   // allTransforms / allPose hold only the fits that were pushed (base.cc:1467-1485)
   std::vector<float> allT;
   std::vector<std::pair<Eigen::Isometry3d, float> > allPose;
@@ -641,13 +523,17 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   const int n_h = (int)allPose.size();
   const double ms_fit = ms_since(t_fit);
   if (getenv("PGP_SHIM_VERBOSE"))
-    std::cerr << "[libsuper4pcs shim] bases " << bases.size() << ", congruent pairs " << n_pairs
+    std::cerr << "[libsuper4pcs shim] bases " << n_bases << ", congruent pairs " << n_pairs
               << ", transforms " << n_h << "; ms: setup " << ms_setup << ", base selection " << ms_bases
               << ", congruent sets " << ms_cs << ", rigid fits " << ms_fit << std::endl;
   std::vector<float> lcp(n_h);
   int best = -1;
   float best_lcp = 0.f;
-  SHIM_PGP(pgp_score_lcp(ctx, allT.data(), n_h, PGP_MODE_WEIGHTED, 30.f, lcp.data(), nullptr, &best, &best_lcp));
+  if (st.group)
+    SHIM_PGP(pgp_multi_score_lcp(st.group, allT.data(), n_h, PGP_MODE_WEIGHTED, 30.f, lcp.data(), nullptr, &best,
+                                 &best_lcp));
+  else
+    SHIM_PGP(pgp_score_lcp(ctx, allT.data(), n_h, PGP_MODE_WEIGHTED, 30.f, lcp.data(), nullptr, &best, &best_lcp));
   for (int i = 0; i < n_h; ++i) allPose[i].second = lcp[i];
   std::vector<int> selected(n_h > 0 ? n_h : 1);
   int n_sel = 0;
@@ -664,5 +550,4 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   } else {
     std::cout << "returning identity" << std::endl;  // base.cc:1791-1794
   }
-  pgp_destroy(ctx);
 }
