@@ -183,6 +183,7 @@ def main():
     test_scene_case()
     near_ties_case()
     stocs_case()
+    test_scene_frame_case()
 
 
 def morton_order(Q):
@@ -345,6 +346,21 @@ def stocs_case():
     np.savez_compressed(path, **out)
     print(f"stocs: n={n} keys={len(keys)} pairs with a key {int((feat[:, 0] >= 0).sum())}, chains present",
           [c["present"] for c in chains], f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+def test_scene_frame_case():
+    """(16) the reference's test-scene/ frame as DATA for the configs[4] flow test: raw 16-bit depth
+    samples, class mask (0 / 2 / 3 / 8) and the intrinsics of gt_info.yml.  No reference source text."""
+    from PIL import Image
+    d = "/root/reference/test-scene/"
+    raw = np.array(Image.open(d + "frame-000000.depth.png")).astype(np.uint16)
+    mask = np.array(Image.open(d + "frame-000000.mask.png"))
+    if mask.ndim == 3:
+        mask = mask[..., 0]
+    K = np.array([[6.13998108e+02, 0, 3.22453583e+02], [0, 6.13998169e+02, 2.39678940e+02], [0, 0, 1]], np.float32)
+    path = os.path.join(HERE, "test_scene_frame.npz")
+    np.savez_compressed(path, raw=raw, mask=mask.astype(np.uint8), K=K)
+    print("test_scene_frame:", raw.shape, f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def weights_case():
@@ -548,6 +564,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "test_scene":
         test_scene_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "test_scene_frame":
+        test_scene_frame_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stocs":
         stocs_case()
