@@ -263,6 +263,42 @@ int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const fl
                           float* d_T, int n, const pgp_icp_params* params, float* d_energy,
                           int* d_iters, void* stream);
 
+/* The other ICP forms of the call sites, on the same kernels (csrc/icp.hip).  Fields <= 0 / < 0 switch
+ * a rule off as noted; pgp_icp_default_options() fills the TrimmedICP form of pgp_icp_params.
+ *   greedy_bfs/State.cpp:139-142   pcl::IterativeClosestPoint, setMaxCorrespondenceDistance(max_corr),
+ *                                  50 iterations, setTransformationEpsilon(1e-8):
+ *                                  {50, 1, max_corr, 0, 0, 1e-8f, 0, 1e-12f, 0, 0, 0, 0}
+ *   misc/utilities.cpp:697-703     pcl::IterativeClosestPoint, 100 iterations, PCL defaults:
+ *                                  {100, 1, 0, 0, 0, 0.f, 0, 1e-12f, 0, 0, 0, 0}
+ *   misc/utilities.cpp:709-739     pcl::IterativeClosestPointWithNormals: the same with error_metric 1
+ *   misc/utilities.cpp:744-838     libpointmatcher chain: {100, 0.75f, 0, 0, 0, -1, 0, -1, 0.001f, 0.005f, 4, 0}
+ *   data_layer/SceneCfg.cpp:135-141  table ICP on scene-sized clouds: max_corr 0.01, 50 iterations,
+ *                                  transformation epsilon 1e-9 (nn_search 0 picks the grid search there) */
+typedef struct {
+  int max_iterations;            /* <= 0: 100 */
+  float trim_fraction;           /* (0,1]: keep the |trim * n_src| closest pairs; 1 (or <= 0) = all */
+  float max_corr_dist;           /* > 0: pairs farther than this are dropped (instead of trimming) */
+  float energy_ratio;            /* > 0: go on only while E / E_old < ratio (TrimmedICP); <= 0: off */
+  int error_metric;              /* 0 point-to-point (Horn closed form), 1 point-to-plane (linearised
+                                    least squares; needs target normals) */
+  float transformation_epsilon;  /* >= 0: stop when an iteration's update has cos(angle) >= 1 - eps and
+                                    |t|^2 <= eps (pcl DefaultConvergenceCriteria); < 0: off */
+  float relative_mse;            /* > 0: stop when |E - E_old| / E_old < this; <= 0: off */
+  float absolute_mse;            /* >= 0: stop when |E - E_old| < this (PCL: 1e-12); < 0: off */
+  float min_diff_rot;            /* > 0 with min_diff_trans > 0: libpointmatcher's                  */
+  float min_diff_trans;          /*   DifferentialTransformationChecker on the last smooth_length    */
+  int smooth_length;             /*   iterations (1..8)                                              */
+  int nn_search;                 /* 0 auto, 1 exhaustive scan, 2 uniform grid (needs max_corr_dist > 0) */
+} pgp_icp_options;
+int pgp_icp_default_options(pgp_icp_options* opt);
+/* tgt_nrm: n_tgt x 3 unit normals of the target (nullable unless error_metric is 1).  Otherwise as
+ * pgp_icp_refine / pgp_icp_refine_device (d_tgt_n4: float4 {nx,ny,nz,-}). */
+int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, const float* tgt_nrm,
+                      int n_tgt, float* T, int n, const pgp_icp_options* opt, float* energy, int* iters);
+int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4,
+                             const float* d_tgt_n4, int n_tgt, float* d_T, int n, const pgp_icp_options* opt,
+                             float* d_energy, int* d_iters, void* stream);
+
 /* Segment pre-processing in front of the path (PPE/hypothesis_generation/ObjectPoseCandidateSet.cpp:
  * 28-51): pcl::RadiusOutlierRemoval(radius 0.03, min neighbours 10) followed by
  * flipNormalTowardsViewpoint((0,0,0)) + re-normalisation.  PCL is not vendored, so the

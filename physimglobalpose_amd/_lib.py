@@ -28,6 +28,13 @@ class IcpParams(C.Structure):
                 ("max_corr_dist", C.c_float), ("energy_ratio", C.c_float)]
 
 
+class IcpOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int), ("trim_fraction", C.c_float), ("max_corr_dist", C.c_float),
+                ("energy_ratio", C.c_float), ("error_metric", C.c_int), ("transformation_epsilon", C.c_float),
+                ("relative_mse", C.c_float), ("absolute_mse", C.c_float), ("min_diff_rot", C.c_float),
+                ("min_diff_trans", C.c_float), ("smooth_length", C.c_int), ("nn_search", C.c_int)]
+
+
 class ClusterParams(C.Structure):
     _fields_ = [("accept_fraction", C.c_float), ("rot_thresh_deg", C.c_float), ("trans_thresh", C.c_float)]
 
@@ -71,6 +78,12 @@ SIGNATURES = {
                                  C.POINTER(IcpParams), _f, _i]),
     "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
                                         C.c_int, C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgp_icp_default_options": (C.c_int, [C.POINTER(IcpOptions)]),
+    "pgp_icp_refine_ex": (C.c_int, [C.c_void_p, _f, C.c_int, _f, _f, C.c_int, _f, C.c_int,
+                                    C.POINTER(IcpOptions), _f, _i]),
+    "pgp_icp_refine_ex_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                           C.c_void_p, C.c_int, C.POINTER(IcpOptions), C.c_void_p, C.c_void_p,
+                                           C.c_void_p]),
     "pgp_radius_outlier_filter": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, C.c_int,
                                             C.POINTER(C.c_ubyte), _f, _i]),
     "pgp_backproject_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f,

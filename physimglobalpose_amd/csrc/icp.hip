@@ -37,6 +37,23 @@
 //     across the block in a fixed tree (bit-reproducible), then one lane solves Horn's 4x4
 //     symmetric eigenproblem with cyclic Jacobi sweeps.
 // Algorithmic bytes per pose-iteration: 12|src| + 12|tgt| + 48 + 64.
+//
+// Variants the other call sites need (pgp_icp_options, all on the same kernels):
+//   * stop rules of pcl::registration::DefaultConvergenceCriteria as IterativeClosestPoint sets them
+//     (greedy_bfs/State.cpp:139-142: max_corr, 50 iterations, transformation epsilon 1e-8;
+//     utilities.cpp:697-703: 100 iterations, defaults): the update of an iteration is tested for
+//     cos(angle) >= 1 - eps and |t|^2 <= eps, and the mean squared correspondence distance for a
+//     relative / absolute change below a threshold;
+//   * point-to-plane (pcl::IterativeClosestPointWithNormals, utilities.cpp:709-739): the linearised
+//     least squares of TransformationEstimationPointToPlaneLLS -- 6 x 6 normal equations accumulated
+//     in f64 over the selected pairs, solved by Gaussian elimination with partial pivoting, the
+//     update built from the three angles and applied on the left of the current transform;
+//   * libpointmatcher's chain (utilities.cpp:744-838): exact nearest neighbour (its kd-tree runs with
+//     epsilon 3.16, an approximation this library does not make), TrimmedDistOutlierFilter 0.75 =
+//     trim_fraction, DifferentialTransformationChecker = smoothed rotation / translation change;
+//   * a uniform-grid nearest-neighbour search (icp_nn_grid) when a correspondence cap is set and the
+//     clouds are scene-sized (PPE/data_layer/SceneCfg.cpp:101,135-141: table ICP, max_corr 0.01):
+//     cells of edge max_corr, 27 cells per query, identical (d2, lowest j) results to the scan.
 
 #include "pgp_internal.h"
 
@@ -51,7 +68,8 @@ namespace {
 constexpr int kIcpThreads = 1024;
 constexpr int kIcpR = 4;                 // source points per lane per sweep
 constexpr int kTgtTile = 4096;           // target points per LDS tile (64 KB)
-constexpr int kRed = 16;                 // doubles reduced per thread
+constexpr int kRedPlane = 28;            // point-to-plane: count + 21 (upper triangle of AtA) + 6 (Atb)
+constexpr int kMaxSmooth = 8;            // history length of the differential checker
 
 struct IcpArgs {
   const float4* src;   // [n_src] {x,y,z,-}
@@ -72,6 +90,20 @@ struct IcpArgs {
   int* st_it;          // [n] iterations done
   int* st_done;        // [n] 1 = converged / stopped
   int* n_done;         // [1]
+  // variants (pgp_icp_options)
+  const float4* tgt_n; // target normals {nx,ny,nz,-} (point-to-plane), nullable
+  int metric;          // 0 point-to-point, 1 point-to-plane
+  float t_eps;         // >= 0: stop when the update has cos(angle) >= 1 - eps and |t|^2 <= eps
+  float rel_mse;       // > 0: stop when |E - E_old| / E_old < rel_mse
+  float abs_mse;       // >= 0: stop when |E - E_old| < abs_mse
+  float diff_rot, diff_trans;  // > 0: libpointmatcher DifferentialTransformationChecker thresholds
+  int smooth;          // its smoothLength (1..kMaxSmooth)
+  double* st_hist;     // [n][kMaxSmooth + 1][7]: quaternion + translation of the last absolute transforms
+  // grid search (icp_nn_grid)
+  float gox, goy, goz, ginv_h;
+  int gnx, gny, gnz;
+  const uint32_t* gcell_start;   // [cells + 1]
+  const float4* gpts;            // target points sorted by cell, .w = bits(original index)
 };
 
 __device__ __forceinline__ float row_xf(float a, float b, float c, float t, float x, float y, float z) {
@@ -151,6 +183,131 @@ __device__ void solve_rigid(const double* red, float* G, double (*N)[4], double 
   G[15] = 1.f;
 }
 
+// Point-to-plane update (pcl::registration::TransformationEstimationPointToPlaneLLS): the sums are
+// over the selected pairs with x = G s (the source as currently placed), m its target point, n the
+// target normal: row = (n x x ... precisely a = nz xy - ny xz, b = nx xz - nz xx, c = ny xx - nx xy,
+// nx, ny, nz), rhs = n . (m - x).  red = {count, upper triangle of AtA (21, row-major), Atb (6)}.
+// Solves AtA p = Atb, builds the update from (alpha, beta, gamma, tx, ty, tz) and sets G <- D G.
+__device__ void solve_plane(const double* red, float* G) {
+  if (!(red[0] >= 3.0)) return;
+  double A[6][7];
+  int t = 1;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) {
+      A[r][c] = red[t];
+      A[c][r] = red[t];
+      ++t;
+    }
+  for (int r = 0; r < 6; ++r) A[r][6] = red[22 + r];
+  for (int col = 0; col < 6; ++col) {   // Gaussian elimination, partial pivoting
+    int piv = col;
+    for (int r = col + 1; r < 6; ++r)
+      if (fabs(A[r][col]) > fabs(A[piv][col])) piv = r;
+    if (!(fabs(A[piv][col]) > 1e-300)) return;   // singular: keep G
+    if (piv != col)
+      for (int c = 0; c < 7; ++c) {
+        const double tmp = A[col][c];
+        A[col][c] = A[piv][c];
+        A[piv][c] = tmp;
+      }
+    for (int r = col + 1; r < 6; ++r) {
+      const double f = A[r][col] / A[col][col];
+      for (int c = col; c < 7; ++c) A[r][c] -= f * A[col][c];
+    }
+  }
+  double x[6];
+  for (int r = 5; r >= 0; --r) {
+    double v = A[r][6];
+    for (int c = r + 1; c < 6; ++c) v -= A[r][c] * x[c];
+    x[r] = v / A[r][r];
+  }
+  const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+  const double D[3][4] = {{cg * cb, -sg * ca + cg * sb * sa, sg * sa + cg * sb * ca, x[3]},
+                          {sg * cb, cg * ca + sg * sb * sa, -cg * sa + sg * sb * ca, x[4]},
+                          {-sb, cb * sa, cb * ca, x[5]}};
+  double Gn[3][4];
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) {
+      double v = D[r][0] * (double)G[4 * c] + D[r][1] * (double)G[4 * c + 1] + D[r][2] * (double)G[4 * c + 2];
+      if (c == 3) v += D[r][3];
+      Gn[r][c] = v;
+    }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 4; ++c) G[4 * c + r] = (float)Gn[r][c];
+  G[3] = G[7] = G[11] = 0.f;
+  G[15] = 1.f;
+}
+
+// rotation part of a column-major 4x4 (float) as a unit quaternion (w, x, y, z), double
+__device__ void quat_of(const float* G, double q[4]) {
+  const double m00 = G[0], m10 = G[1], m20 = G[2], m01 = G[4], m11 = G[5], m21 = G[6], m02 = G[8], m12 = G[9], m22 = G[10];
+  const double tr = m00 + m11 + m22;
+  if (tr > 0.0) {
+    const double s = sqrt(tr + 1.0) * 2.0;
+    q[0] = 0.25 * s; q[1] = (m21 - m12) / s; q[2] = (m02 - m20) / s; q[3] = (m10 - m01) / s;
+  } else if (m00 > m11 && m00 > m22) {
+    const double s = sqrt(1.0 + m00 - m11 - m22) * 2.0;
+    q[0] = (m21 - m12) / s; q[1] = 0.25 * s; q[2] = (m01 + m10) / s; q[3] = (m02 + m20) / s;
+  } else if (m11 > m22) {
+    const double s = sqrt(1.0 + m11 - m00 - m22) * 2.0;
+    q[0] = (m02 - m20) / s; q[1] = (m01 + m10) / s; q[2] = 0.25 * s; q[3] = (m12 + m21) / s;
+  } else {
+    const double s = sqrt(1.0 + m22 - m00 - m11) * 2.0;
+    q[0] = (m10 - m01) / s; q[1] = (m02 + m20) / s; q[2] = (m12 + m21) / s; q[3] = 0.25 * s;
+  }
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n > 0.0)
+    for (int k = 0; k < 4; ++k) q[k] /= n;
+}
+
+// Does the iteration that turned G_old into G_new end the loop?  (thread 0)
+//   DefaultConvergenceCriteria: update D = G_new G_old^-1 with cos(angle) >= 1 - eps and |t|^2 <= eps;
+//   relative / absolute change of the mean squared correspondence distance;
+//   DifferentialTransformationChecker: mean over the last `smooth` iterations of the angular distance
+//   between consecutive absolute rotations and of the distance between consecutive translations.
+__device__ bool converged_extra(const IcpArgs& a, int pose, int it_done, const float* G_old, const float* G_new,
+                                double E, double E_old) {
+  bool stop = false;
+  if (a.t_eps >= 0.f) {
+    // D = G_new * inverse(G_old), rigid: R_D = R_n R_o^T, t_D = t_n - R_D t_o
+    double R[3][3];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        R[r][c] = (double)G_new[r] * G_old[c] + (double)G_new[4 + r] * G_old[4 + c] + (double)G_new[8 + r] * G_old[8 + c];
+    double tsq = 0.0;
+    for (int r = 0; r < 3; ++r) {
+      const double td = (double)G_new[12 + r] - (R[r][0] * G_old[12] + R[r][1] * G_old[13] + R[r][2] * G_old[14]);
+      tsq += td * td;
+    }
+    const double cos_angle = 0.5 * (R[0][0] + R[1][1] + R[2][2] - 1.0);
+    if (cos_angle >= 1.0 - (double)a.t_eps && tsq <= (double)a.t_eps) stop = true;
+  }
+  if (a.rel_mse > 0.f && E_old < (double)FLT_MAX && fabs(E - E_old) / E_old < (double)a.rel_mse) stop = true;
+  if (a.abs_mse >= 0.f && E_old < (double)FLT_MAX && fabs(E - E_old) < (double)a.abs_mse) stop = true;
+  if (a.smooth > 0 && a.st_hist) {
+    double* H = a.st_hist + (size_t)pose * (kMaxSmooth + 1) * 7;
+    const int L = a.smooth;
+    // ring of the last L + 1 absolute transforms; slot of iteration k (1-based) is k % (L + 1)
+    double q[4];
+    quat_of(G_new, q);
+    double* cur = H + (size_t)(it_done % (L + 1)) * 7;
+    for (int k = 0; k < 4; ++k) cur[k] = q[k];
+    for (int k = 0; k < 3; ++k) cur[4 + k] = G_new[12 + k];
+    if (it_done > L) {   // rotations.size() > smoothLength
+      double cr = 0.0, ct = 0.0;
+      for (int k = 0; k < L; ++k) {
+        const double* x = H + (size_t)((it_done - k) % (L + 1)) * 7;
+        const double* y = H + (size_t)((it_done - k - 1) % (L + 1)) * 7;
+        const double d = fabs(x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3]);
+        cr += 2.0 * acos(d > 1.0 ? 1.0 : d);   // Quaternion::angularDistance
+        ct += sqrt((x[4] - y[4]) * (x[4] - y[4]) + (x[5] - y[5]) * (x[5] - y[5]) + (x[6] - y[6]) * (x[6] - y[6]));
+      }
+      if (cr / L < (double)a.diff_rot && ct / L < (double)a.diff_trans) stop = true;
+    }
+  }
+  return stop;
+}
+
 // SPLIT = false: persistent kernel, all iterations of one pose in one workgroup (many poses).
 // SPLIT = true : one iteration's selection + update for one pose; the correspondences were
 //                produced by icp_nn_split over many workgroups (few poses: a single pose would
@@ -167,7 +324,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
   __shared__ unsigned s_prefix, s_kleft, s_carry;
   __shared__ double s_energy, s_energy_old;
   __shared__ int s_continue;
-  __shared__ double s_N[4][4], s_V[4][4], s_sum[kRed + 1];
+  __shared__ double s_N[4][4], s_V[4][4], s_sum[kRedPlane + 1];
+  __shared__ float s_G_old[16];
 
   const int pose = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,9 +435,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     }
 
     // ---- 3. f64 sums over the selected pairs (ordered tie handling), fixed-tree reduction ----
-    double acc[kRed];
+    double acc[kRedPlane];
 #pragma unroll
-    for (int k = 0; k < kRed; ++k) acc[k] = 0.0;
+    for (int k = 0; k < kRedPlane; ++k) acc[k] = 0.0;
     double e_acc = 0.0;
     if (tid == 0) s_carry = 0;
     __syncthreads();
@@ -315,7 +473,26 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
         __syncthreads();
       }
       const int jm = i < a.n_src ? jw[i] : -1;
-      if (sel && jm >= 0) {  // jm < 0: a non-finite transformed point has no neighbour
+      if (sel && jm >= 0 && a.metric == 1) {
+        const float4 s = a.src[i];
+        const float4 m = a.tgt[jm];
+        const float4 nn = a.tgt_n[jm];
+        const double sx = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
+        const double sy = row_xf(s_G[1], s_G[5], s_G[9], s_G[13], s.x, s.y, s.z);
+        const double sz = row_xf(s_G[2], s_G[6], s_G[10], s_G[14], s.x, s.y, s.z);
+        const double nx = nn.x, ny = nn.y, nz = nn.z;
+        const double row[6] = {nz * sy - ny * sz, nx * sz - nz * sx, ny * sx - nx * sy, nx, ny, nz};
+        const double rhs = nx * (double)m.x + ny * (double)m.y + nz * (double)m.z - nx * sx - ny * sy - nz * sz;
+        acc[0] += 1.0;
+        int t = 1;
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) acc[t++] += row[r] * row[c];
+#pragma unroll
+        for (int r = 0; r < 6; ++r) acc[22 + r] += row[r] * rhs;
+        e_acc += (double)d2;
+      } else if (sel && jm >= 0) {  // jm < 0: a non-finite transformed point has no neighbour
         float4 s = a.src[i];
         float4 m = a.tgt[jm];
         acc[0] += 1.0;
@@ -330,32 +507,38 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     // wave butterfly, then the 16 wave results through LDS (aliases the target tile: all reads of
     // the tile finished before the barrier after step 1)
 #pragma unroll
-    for (int k = 0; k < kRed; ++k)
+    for (int k = 0; k < kRedPlane; ++k)
       for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
     for (int off = 32; off >= 1; off >>= 1) e_acc += __shfl_xor(e_acc, off, 64);
     __syncthreads();
     if (lane == 0) {
-      for (int k = 0; k < kRed; ++k) s_red[wave * (kRed + 1) + k] = acc[k];
-      s_red[wave * (kRed + 1) + kRed] = e_acc;
+      for (int k = 0; k < kRedPlane; ++k) s_red[wave * (kRedPlane + 1) + k] = acc[k];
+      s_red[wave * (kRedPlane + 1) + kRedPlane] = e_acc;
     }
     __syncthreads();
     if (tid == 0) {
-      for (int k = 0; k <= kRed; ++k) {
+      for (int k = 0; k <= kRedPlane; ++k) {
         double v = 0.0;
-        for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRed + 1) + k];
+        for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRedPlane + 1) + k];
         s_sum[k] = v;
       }
       const double* red = s_sum;
       // progress is judged on the mean squared distance of the selected pairs; with a fixed
       // trim count this is PCL's energy test (E/E_old), and it stays meaningful when a
       // correspondence cap lets |S| change between iterations
-      const double E = red[0] >= 1.0 ? red[kRed] / red[0] : 0.0;
-      // ---- 4. closed-form update, then the progress test (PCL order: update first) ----------
-      solve_rigid(red, s_G, s_N, s_V);
+      const double E = red[0] >= 1.0 ? red[kRedPlane] / red[0] : 0.0;
+      // ---- 4. closed-form update, then the progress tests (PCL order: update first) ----------
+      for (int k = 0; k < 16; ++k) s_G_old[k] = s_G[k];
+      if (a.metric == 1) solve_plane(red, s_G);
+      else solve_rigid(red, s_G, s_N, s_V);
       const double E_old = s_energy_old;
       s_energy = E;
       s_energy_old = E;
-      s_continue = (it + 1 < a.max_iter) && (E / E_old < (double)a.ratio) ? 1 : 0;
+      bool go = it + 1 < a.max_iter;
+      if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;   // TrimmedICP's energy ratio
+      if (red[0] < 1.0) go = false;                                        // no correspondences left
+      if (converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old)) go = false;
+      s_continue = go ? 1 : 0;
     }
     __syncthreads();
     ++it;
@@ -472,21 +655,127 @@ __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
   }
 }
 
+
+// ---- uniform-grid nearest neighbour for capped searches on scene-sized clouds -------------------
+// Cells of edge h >= max_corr over the target's bounding box, every target point in exactly one
+// cell (counting sort by cell id); a query visits the 27 cells around its own.  Every point within
+// max_corr of the query lies in them, so whenever the scan's nearest neighbour passes the cap the two
+// searches return the same (d2, lowest j); when it does not, the pair is unselected either way.
+__global__ __launch_bounds__(256) void grid_bbox(const float4* __restrict__ tgt, int n, float* __restrict__ out6) {
+  __shared__ float s_mn[3][4], s_mx[3][4];
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float4 p = tgt[i];
+    if (!(p.x == p.x && p.y == p.y && p.z == p.z) || fabsf(p.x) > 1e30f || fabsf(p.y) > 1e30f || fabsf(p.z) > 1e30f) continue;
+    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+  }
+  for (int k = 0; k < 3; ++k)
+    for (int off = 32; off >= 1; off >>= 1) {
+      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
+      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
+    }
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 3; ++k) {
+      s_mn[k][threadIdx.x >> 6] = mn[k];
+      s_mx[k][threadIdx.x >> 6] = mx[k];
+    }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const int k = threadIdx.x;
+    out6[k] = fminf(fminf(s_mn[k][0], s_mn[k][1]), fminf(s_mn[k][2], s_mn[k][3]));
+    out6[3 + k] = fmaxf(fmaxf(s_mx[k][0], s_mx[k][1]), fmaxf(s_mx[k][2], s_mx[k][3]));
+  }
+}
+
+__device__ __forceinline__ int grid_cell_of(const IcpArgs& a, float x, float y, float z, int* cx, int* cy, int* cz) {
+  const float fx = (x - a.gox) * a.ginv_h, fy = (y - a.goy) * a.ginv_h, fz = (z - a.goz) * a.ginv_h;
+  if (!(fx >= -1.f && fx < (float)(a.gnx + 1) && fy >= -1.f && fy < (float)(a.gny + 1) && fz >= -1.f && fz < (float)(a.gnz + 1)))
+    return 0;   // farther than one cell from the grid (or NaN): nothing within max_corr
+  *cx = (int)floorf(fx);
+  *cy = (int)floorf(fy);
+  *cz = (int)floorf(fz);
+  return 1;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void grid_scatter(IcpArgs a, uint32_t* __restrict__ cell_ctr, float4* __restrict__ pts) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.n_tgt) return;
+  const float4 p = a.tgt[j];
+  int cx, cy, cz;
+  if (!grid_cell_of(a, p.x, p.y, p.z, &cx, &cy, &cz)) return;
+  if (cx < 0 || cy < 0 || cz < 0 || cx >= a.gnx || cy >= a.gny || cz >= a.gnz) return;
+  const size_t c = ((size_t)cz * a.gny + cy) * a.gnx + cx;
+  const uint32_t slot = atomicAdd(&cell_ctr[c], 1u);
+  if (FILL) pts[a.gcell_start[c] + slot] = make_float4(p.x, p.y, p.z, __int_as_float(j));
+}
+
+__global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
+  const int pose = blockIdx.y;
+  if (a.st_done[pose]) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_src) return;
+  const float* G = a.T + 16 * (size_t)pose;
+  const float4 s = a.src[i];
+  const float x = row_xf(G[0], G[4], G[8], G[12], s.x, s.y, s.z);
+  const float y = row_xf(G[1], G[5], G[9], G[13], s.x, s.y, s.z);
+  const float z = row_xf(G[2], G[6], G[10], G[14], s.x, s.y, s.z);
+  float best = FLT_MAX;
+  int bj = -1;
+  int cx, cy, cz;
+  if (grid_cell_of(a, x, y, z, &cx, &cy, &cz)) {
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= a.gnz) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= a.gny) continue;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, a.gnx - 1);
+        if (x0 > x1) continue;
+        // the three x-neighbours are consecutive cells: one contiguous range of points
+        const size_t c0 = ((size_t)zz * a.gny + yy) * a.gnx + x0;
+        const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
+        for (uint32_t k = b; k < e; ++k) {
+          const float4 m = a.gpts[k];
+          const float dx = __fsub_rn(x, m.x), dyy = __fsub_rn(y, m.y), dzz = __fsub_rn(z, m.z);
+          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
+          const int j = __float_as_int(m.w);
+          if (d2 < best || (d2 == best && j < bj)) {   // the scan's rule: smallest d2, then lowest j
+            best = d2;
+            bj = j;
+          }
+        }
+      }
+    }
+  }
+  if (bj >= 0)
+    a.ws_key[(size_t)pose * a.n_src + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj;
+}
+
 }  // namespace
 
-int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,
-               int n, const pgp_icp_params* prm, float* d_energy, int* d_iters, hipStream_t stream) {
+int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
+               float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream) {
   if (n <= 0) return PGP_OK;
   if (n_src <= 0 || n_tgt <= 0) {
     set_error("icp: empty source or target cloud");
     return PGP_EINVAL;
   }
-  // the pose index rides on gridDim.z (<= 65535): larger batches go in slices
+  if (prm->error_metric == 1 && !d_tgt_n) {
+    set_error("icp: the point-to-plane metric needs target normals");
+    return PGP_EINVAL;
+  }
+  if (prm->error_metric != 0 && prm->error_metric != 1) {
+    set_error("icp: unknown error metric %d", prm->error_metric);
+    return PGP_EINVAL;
+  }
+  // the pose index rides on gridDim.z / .y (<= 65535): larger batches go in slices
   constexpr int kMaxPoses = 32768;
   if (n > kMaxPoses) {
     for (int off = 0; off < n; off += kMaxPoses) {
       const int m = n - off < kMaxPoses ? n - off : kMaxPoses;
-      int rc = launch_icp(ctx, d_src, n_src, d_tgt, n_tgt, d_T + 16 * (size_t)off, m, prm,
+      int rc = launch_icp(ctx, d_src, n_src, d_tgt, d_tgt_n, n_tgt, d_T + 16 * (size_t)off, m, prm,
                           d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream);
       if (rc != PGP_OK) return rc;
     }
@@ -495,6 +784,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   IcpArgs a{};
   a.src = d_src;
   a.tgt = d_tgt;
+  a.tgt_n = d_tgt_n;
   a.n_src = n_src;
   a.n_tgt = n_tgt;
   a.T = d_T;
@@ -508,7 +798,16 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   if (k > n_src) k = n_src;
   a.k_trim = k;
   a.max_corr2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : -1.f;
-  a.ratio = prm->energy_ratio > 0.f ? prm->energy_ratio : 1.f;
+  a.ratio = prm->energy_ratio;            // <= 0: the energy-ratio test is off
+  a.metric = prm->error_metric;
+  a.t_eps = prm->transformation_epsilon;  // < 0: off
+  a.rel_mse = prm->relative_mse;
+  a.abs_mse = prm->absolute_mse;
+  a.diff_rot = prm->min_diff_rot;
+  a.diff_trans = prm->min_diff_trans;
+  a.smooth = (prm->min_diff_rot > 0.f && prm->min_diff_trans > 0.f)
+                 ? (prm->smooth_length < 1 ? 1 : (prm->smooth_length > kMaxSmooth ? kMaxSmooth : prm->smooth_length))
+                 : 0;
   int rc;
   size_t need = (size_t)n * n_src;
   // measured (tools/icp_time.py, 2500 x 5000, 10 iterations): the split path wins at every batch
@@ -517,7 +816,18 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   // asynchronous, graph-capturable)
   bool split = true;
   if (const char* v = getenv("PGP_ICP_SPLIT")) split = atoi(v) != 0;
-  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 : 0;
+  // grid search: only with a correspondence cap; by default when the scan would be >= 2^27 tests per pose
+  bool use_grid = false;
+  if (a.max_corr2 >= 0.f) {
+    if (prm->nn_search == 2) use_grid = true;
+    else if (prm->nn_search == 0) use_grid = (double)n_src * (double)n_tgt >= 134217728.0;
+  } else if (prm->nn_search == 2) {
+    set_error("icp: the grid search needs max_corr_dist > 0");
+    return PGP_EINVAL;
+  }
+  if (use_grid || a.smooth > 0) split = true;   // both live on the host-driven path
+  const size_t hist_bytes = a.smooth > 0 ? (size_t)n * (kMaxSmooth + 1) * 7 * 8 : 0;
+  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 : 0;
   if ((rc = ctx->d_icp_ws.ensure(need * 8 + state_bytes + 64)) != PGP_OK) return rc;
   a.ws_d2 = ctx->d_icp_ws.as<float>();
   a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
@@ -544,17 +854,69 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.st_it = reinterpret_cast<int*>(a.st_E + n);
   a.st_done = a.st_it + n;
   a.n_done = a.st_done + n;
+  a.st_hist = a.smooth > 0 ? reinterpret_cast<double*>(((uintptr_t)(a.n_done + 1) + 15) & ~(uintptr_t)15) : nullptr;
   PGP_HIP(hipMemsetAsync(a.ws_key, 0xFF, need * 8, stream));
   PGP_HIP(hipMemsetAsync(a.ws_j, 0xFF, need * 4, stream));  // no previous correspondence yet
   PGP_HIP(hipMemsetAsync(a.st_it, 0, (size_t)n * 8 + 4, stream));
+  if (a.st_hist) PGP_HIP(hipMemsetAsync(a.st_hist, 0, hist_bytes, stream));
   {
     std::vector<double> e0((size_t)n, (double)FLT_MAX);
     PGP_HIP(hipMemcpyAsync(a.st_E, e0.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream));
     PGP_HIP(hipStreamSynchronize(stream));  // e0 is a stack temporary
   }
+  if (use_grid) {
+    // ---- the target's grid: bounding box (device), cell edge >= max_corr (grown to keep <= 2^26 cells)
+    if ((rc = ctx->d_icp_grid.ensure(64)) != PGP_OK) return rc;
+    float* d_bb = ctx->d_icp_grid.as<float>();
+    hipLaunchKernelGGL(grid_bbox, dim3(1), dim3(256), 0, stream, d_tgt, n_tgt, d_bb);
+    float bb[6];
+    PGP_HIP(hipMemcpyAsync(bb, d_bb, 24, hipMemcpyDeviceToHost, stream));
+    PGP_HIP(hipStreamSynchronize(stream));
+    if (!(bb[0] <= bb[3])) bb[0] = bb[1] = bb[2] = bb[3] = bb[4] = bb[5] = 0.f;   // no finite target point
+    float maxabs = 0.f;
+    for (int q = 0; q < 6; ++q) maxabs = fmaxf(maxabs, fabsf(bb[q]));
+    // margin for the rounding of the cell coordinate: a point within max_corr of a query is at most
+    // one cell away from the query's cell
+    float h = prm->max_corr_dist * 1.001f + 64.f * FLT_EPSILON * maxabs;
+    for (;;) {
+      // one spare cell per axis: the float cell coordinate of a point on the upper face may round up
+      const double nx = floor((double)(bb[3] - bb[0]) / h) + 2, ny = floor((double)(bb[4] - bb[1]) / h) + 2,
+                   nz = floor((double)(bb[5] - bb[2]) / h) + 2;
+      if (nx * ny * nz <= 67108864.0) {
+        a.gnx = (int)nx;
+        a.gny = (int)ny;
+        a.gnz = (int)nz;
+        break;
+      }
+      h *= 1.26f;
+    }
+    a.gox = bb[0];
+    a.goy = bb[1];
+    a.goz = bb[2];
+    a.ginv_h = 1.0f / h;
+    const size_t cells = (size_t)a.gnx * a.gny * a.gnz;
+    const size_t off_pts = ((cells + 1) * 8 + 64 + 255) & ~(size_t)255;
+    if ((rc = ctx->d_icp_grid.ensure(off_pts + (size_t)n_tgt * 16 + 64)) != PGP_OK) return rc;
+    if ((rc = ctx->d_scan_tmp.ensure(((cells + 1) / 2048 + 2) * 4)) != PGP_OK) return rc;
+    unsigned char* gb = ctx->d_icp_grid.as<unsigned char>();
+    uint32_t* ctr = reinterpret_cast<uint32_t*>(gb + 64);
+    uint32_t* start = ctr + (cells + 1);
+    float4* pts = reinterpret_cast<float4*>(gb + off_pts);
+    a.gcell_start = start;
+    a.gpts = pts;
+    const dim3 gt((n_tgt + 255) / 256);
+    PGP_HIP(hipMemsetAsync(ctr, 0, (cells + 1) * 4, stream));
+    hipLaunchKernelGGL(grid_scatter<false>, gt, dim3(256), 0, stream, a, ctr, (float4*)nullptr);
+    if ((rc = device_exclusive_scan(ctr, start, cells + 1, ctx->d_scan_tmp.as<uint32_t>(), stream)) != PGP_OK) return rc;
+    PGP_HIP(hipMemsetAsync(ctr, 0, (cells + 1) * 4, stream));
+    hipLaunchKernelGGL(grid_scatter<true>, gt, dim3(256), 0, stream, a, ctr, pts);
+    PGP_HIP(hipGetLastError());
+  }
   const dim3 gnn((n_src + kNnThreads * kIcpR - 1) / (kNnThreads * kIcpR), (n_tgt + kNnTgt - 1) / kNnTgt, n);
+  const dim3 ggrid((n_src + 255) / 256, n);
   for (int it = 0; it < a.max_iter; ++it) {
-    hipLaunchKernelGGL(icp_nn_split, gnn, dim3(kNnThreads), 0, stream, a);
+    if (use_grid) hipLaunchKernelGGL(icp_nn_grid, ggrid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(icp_nn_split, gnn, dim3(kNnThreads), 0, stream, a);
     hipLaunchKernelGGL(icp_refine<true>, dim3(n), dim3(kIcpThreads), lds, stream, a);
     if (it == 0) PGP_HIP(hipGetLastError());   // a bad launch configuration shows on the first pair
     if ((it & 3) == 3) {  // every 4 iterations: has every pose stopped?

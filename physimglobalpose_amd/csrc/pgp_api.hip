@@ -87,7 +87,7 @@ using namespace pgp;
 
 extern "C" {
 
-int pgp_version(void) { return 100; }
+int pgp_version(void) { return 200; }
 
 const char* pgp_last_error(void) { return g_err; }
 
@@ -149,7 +149,7 @@ int pgp_destroy(pgp_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
-                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
+                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
@@ -691,24 +691,65 @@ int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids,
   return PGP_OK;
 }
 
-int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
-                          float* d_T, int n, const pgp_icp_params* params, float* d_energy,
-                          int* d_iters, void* stream) {
-  if (!ctx || !params || n < 0 || n_src < 0 || n_tgt < 0 || (n > 0 && (!d_src4 || !d_tgt4 || !d_T))) {
-    set_error("pgp_icp_refine_device: bad argument");
+static pgp_icp_options options_of(const pgp_icp_params* p) {
+  pgp_icp_options o;
+  pgp_icp_default_options(&o);
+  o.max_iterations = p->max_iterations;
+  o.trim_fraction = p->trim_fraction;
+  o.max_corr_dist = p->max_corr_dist;
+  o.energy_ratio = p->energy_ratio > 0.f ? p->energy_ratio : 1.f;   // setNewToOldEnergyRatio(1.f), UCTState.cpp:139
+  return o;
+}
+
+int pgp_icp_default_options(pgp_icp_options* opt) {
+  if (!opt) {
+    set_error("pgp_icp_default_options: opt is NULL");
+    return PGP_EINVAL;
+  }
+  opt->max_iterations = 100;
+  opt->trim_fraction = 1.f;
+  opt->max_corr_dist = 0.f;
+  opt->energy_ratio = 1.f;
+  opt->error_metric = 0;
+  opt->transformation_epsilon = -1.f;
+  opt->relative_mse = 0.f;
+  opt->absolute_mse = -1.f;
+  opt->min_diff_rot = 0.f;
+  opt->min_diff_trans = 0.f;
+  opt->smooth_length = 0;
+  opt->nn_search = 0;
+  return PGP_OK;
+}
+
+int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4,
+                             const float* d_tgt_n4, int n_tgt, float* d_T, int n, const pgp_icp_options* opt,
+                             float* d_energy, int* d_iters, void* stream) {
+  if (!ctx || !opt || n < 0 || n_src < 0 || n_tgt < 0 || (n > 0 && (!d_src4 || !d_tgt4 || !d_T))) {
+    set_error("pgp_icp_refine_ex_device: bad argument");
     return PGP_EINVAL;
   }
   DeviceGuard guard(ctx->device);
-  return launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src,
-                    reinterpret_cast<const float4*>(d_tgt4), n_tgt, d_T, n, params, d_energy, d_iters,
+  return launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src, reinterpret_cast<const float4*>(d_tgt4),
+                    reinterpret_cast<const float4*>(d_tgt_n4), n_tgt, d_T, n, opt, d_energy, d_iters,
                     static_cast<hipStream_t>(stream));
 }
 
-int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt,
-                   float* T, int n, const pgp_icp_params* params, float* energy, int* iters) {
-  if (!ctx || !params || n < 0 || n_src < 0 || n_tgt < 0 ||
+int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
+                          float* d_T, int n, const pgp_icp_params* params, float* d_energy,
+                          int* d_iters, void* stream) {
+  if (!params) {
+    set_error("pgp_icp_refine_device: bad argument");
+    return PGP_EINVAL;
+  }
+  const pgp_icp_options o = options_of(params);
+  return pgp_icp_refine_ex_device(ctx, d_src4, n_src, d_tgt4, nullptr, n_tgt, d_T, n, &o, d_energy, d_iters, stream);
+}
+
+int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, const float* tgt_nrm,
+                      int n_tgt, float* T, int n, const pgp_icp_options* opt, float* energy, int* iters) {
+  if (!ctx || !opt || n < 0 || n_src < 0 || n_tgt < 0 ||
       (n > 0 && (!T || (n_src > 0 && !src_xyz) || (n_tgt > 0 && !tgt_xyz)))) {
-    set_error("pgp_icp_refine: bad argument");
+    set_error("pgp_icp_refine_ex: bad argument");
     return PGP_EINVAL;
   }
   if (n == 0) return PGP_OK;
@@ -719,25 +760,42 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
     for (int i = 0; i < m; ++i) v[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
     return v;
   };
-  std::vector<float4> hs = pack(src_xyz, n_src), ht = pack(tgt_xyz, n_tgt);
+  std::vector<float4> hs = pack(src_xyz, n_src), ht = pack(tgt_xyz, n_tgt), hn;
   int rc;
   if ((rc = ctx->d_icp_src.ensure(hs.size() * 16)) != PGP_OK) return rc;
   if ((rc = ctx->d_icp_tgt.ensure(ht.size() * 16)) != PGP_OK) return rc;
   if ((rc = ctx->d_icp_T.ensure((size_t)n * 64)) != PGP_OK) return rc;
   if ((rc = ctx->d_icp_out.ensure((size_t)n * 8)) != PGP_OK) return rc;
+  const float4* d_n = nullptr;
+  if (tgt_nrm) {
+    hn = pack(tgt_nrm, n_tgt);
+    if ((rc = ctx->d_icp_tgt_n.ensure(hn.size() * 16)) != PGP_OK) return rc;
+    PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt_n.p, hn.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
+    d_n = ctx->d_icp_tgt_n.as<float4>();
+  }
   float* d_energy = ctx->d_icp_out.as<float>();
   int* d_iters = reinterpret_cast<int*>(d_energy + n);
   PGP_HIP(hipMemcpyAsync(ctx->d_icp_src.p, hs.data(), (size_t)n_src * 16, hipMemcpyHostToDevice, st));
   PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
   PGP_HIP(hipMemcpyAsync(ctx->d_icp_T.p, T, (size_t)n * 64, hipMemcpyHostToDevice, st));
-  rc = launch_icp(ctx, ctx->d_icp_src.as<float4>(), n_src, ctx->d_icp_tgt.as<float4>(), n_tgt,
-                  ctx->d_icp_T.as<float>(), n, params, d_energy, d_iters, st);
+  rc = launch_icp(ctx, ctx->d_icp_src.as<float4>(), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt,
+                  ctx->d_icp_T.as<float>(), n, opt, d_energy, d_iters, st);
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(T, ctx->d_icp_T.p, (size_t)n * 64, hipMemcpyDeviceToHost, st));
   if (energy) PGP_HIP(hipMemcpyAsync(energy, d_energy, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   if (iters) PGP_HIP(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
   return PGP_OK;
+}
+
+int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt,
+                   float* T, int n, const pgp_icp_params* params, float* energy, int* iters) {
+  if (!params) {
+    set_error("pgp_icp_refine: bad argument");
+    return PGP_EINVAL;
+  }
+  const pgp_icp_options o = options_of(params);
+  return pgp_icp_refine_ex(ctx, src_xyz, n_src, tgt_xyz, nullptr, n_tgt, T, n, &o, energy, iters);
 }
 
 int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, int n, float radius,

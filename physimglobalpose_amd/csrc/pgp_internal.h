@@ -105,7 +105,7 @@ struct pgp_ctx {
   pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
 
   // ICP (host API staging + per-pose correspondence workspace)
-  pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_T, d_icp_out, d_icp_ws;
+  pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_tgt_n, d_icp_T, d_icp_out, d_icp_ws, d_icp_grid;
   bool icp_attr_set = false;   // dynamic-LDS limit of the ICP kernels raised on this device
 
   // scoring workspace
@@ -178,8 +178,8 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
 int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream_t stream);
 
 // icp.hip
-int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, int n_tgt, float* d_T,
-               int n, const pgp_icp_params* prm, float* d_energy, int* d_iters, hipStream_t stream);
+int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
+               float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream);
 
 // base_select.hip
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);

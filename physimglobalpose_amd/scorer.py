@@ -314,6 +314,25 @@ class LcpScorer:
                                             C.byref(prm), _fp(energy), iters.ctypes.data_as(_i)))
         return T, energy, iters
 
+    def icp_refine_ex(self, src_xyz, tgt_xyz, T, tgt_nrm=None, **opts):
+        """The general form (pgp_icp_options): keyword arguments are the option fields, e.g.
+        max_iterations=50, max_corr_dist=0.01, energy_ratio=0, transformation_epsilon=1e-8, absolute_mse=1e-12
+        (greedy_bfs/State.cpp:139-142) or error_metric=1 with tgt_nrm (utilities.cpp:709-739)."""
+        src, tgt, nrm = _f32(src_xyz, 3), _f32(tgt_xyz, 3), _f32(tgt_nrm, 3)
+        T = np.array(_f32(T, 16), copy=True)
+        n = len(T)
+        o = _lib.IcpOptions()
+        _lib.check(self._lib.pgp_icp_default_options(C.byref(o)))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown ICP option {k}")
+            setattr(o, k, v)
+        energy = np.zeros(n, np.float32)
+        iters = np.zeros(n, np.int32)
+        _lib.check(self._lib.pgp_icp_refine_ex(self._h, _fp(src), len(src), _fp(tgt), _fp(nrm), len(tgt), _fp(T), n,
+                                               C.byref(o), _fp(energy), iters.ctypes.data_as(_i)))
+        return T, energy, iters
+
     # ---- verification loop -----------------------------------------------------------------------
     def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         """T: (n_h,16) column-major float transforms.  Returns (scores, counts, best_index, best_score)."""

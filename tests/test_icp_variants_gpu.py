@@ -1,0 +1,85 @@
+"""The ICP forms of the reference's call sites (csrc/icp.hip, pgp_icp_refine_ex) against fixtures from
+an INDEPENDENT implementation (tests/golden/make_icp_golden.py: numpy float64, scipy cKDTree, SVD /
+Kabsch, np.linalg.solve) -- PCL and libpointmatcher are neither vendored in the reference nor
+installed, so agreement of two separately written codes is the pin this path can have.  Also: the
+uniform-grid nearest-neighbour search gives the results of the exhaustive scan bit for bit."""
+import ast
+import os
+
+import numpy as np
+import pytest
+
+from physimglobalpose_amd import LcpScorer, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "icp.npz")
+CASES = ["trimmed", "capped", "plain", "plane", "pointmatcher"]
+
+
+def _pose_diff(A, B):
+    D = np.linalg.inv(A) @ B
+    ang = np.degrees(np.arccos(np.clip((np.trace(D[:3, :3]) - 1) / 2, -1, 1)))
+    return ang, np.linalg.norm(A[:3, 3] - B[:3, 3])
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_matches_the_independent_implementation(name):
+    g = np.load(GOLD)
+    src = g[str(g[f"{name}_src"][0])]
+    opts = ast.literal_eval(str(g[f"{name}_opts"][0]))
+    sc = LcpScorer()
+    G0 = np.stack([synth.colmajor16(G) for G in g["guesses"]])
+    T, energy, iters = sc.icp_refine_ex(src, g["model"], G0, tgt_nrm=g["normals"], **opts)
+    want_it = g[f"{name}_it"]
+    for k in range(len(T)):
+        got = T[k].reshape(4, 4).T.astype(np.float64)
+        ang, dt = _pose_diff(g[f"{name}_G"][k], got)
+        settled = want_it[k] < opts["max_iterations"]
+        if settled:
+            # both codes stopped on their rule: same optimum (float32 vs float64 distances move the stopping
+            # iteration by a step or two at most), same energy
+            assert ang < 0.02 and dt < 5e-5, (name, k, ang, dt, iters[k], want_it[k])
+            assert abs(int(iters[k]) - int(want_it[k])) <= 2, (name, k, iters[k], want_it[k])
+            assert abs(energy[k] - g[f"{name}_E"][k]) <= 0.01 * g[f"{name}_E"][k]
+        else:
+            # iteration cap reached while still moving: the trajectories agree to the accumulated rounding
+            assert int(iters[k]) == int(want_it[k]) and ang < 0.5 and dt < 2e-3, (name, k, ang, dt)
+
+
+def test_grid_search_equals_exhaustive_scan():
+    """Scene-sized capped ICP (SceneCfg.cpp:135-141 form): nn_search=2 (uniform grid) and nn_search=1
+    (exhaustive scan) return identical transforms, energies and iteration counts."""
+    rng = np.random.default_rng(11)
+    w = synth.make_workload(30000, 3000, 2, config_id=141)
+    tgt = w.P_xyz
+    R = synth._random_rot(rng, np.deg2rad(1.5))
+    src = (tgt[rng.choice(len(tgt), 20000, replace=False)] @ R.T + 0.003 * rng.standard_normal(3)
+           + 0.0005 * rng.standard_normal((20000, 3))).astype(np.float32)
+    G0 = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng, np.deg2rad(0.5)), 0.002 * rng.standard_normal(3)))
+                   for _ in range(3)])
+    sc = LcpScorer()
+    kw = dict(max_iterations=12, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
+    Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, nn_search=1, **kw)
+    Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, nn_search=2, **kw)
+    assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
+    assert (Ea < 1e-5).all()      # it did register (rms below 3 mm)
+    # auto picks the grid at this size (20000 x 30000 tests per pose) and agrees as well
+    Tc, Ec, ic = sc.icp_refine_ex(src, tgt, G0, nn_search=0, **kw)
+    assert np.array_equal(Ta, Tc) and np.array_equal(ia, ic)
+
+
+def test_old_entry_point_is_the_trimmed_form():
+    g = np.load(GOLD)
+    sc = LcpScorer()
+    G0 = np.stack([synth.colmajor16(G) for G in g["guesses"]])
+    a = sc.icp_refine(g["seg_c"], g["model"], G0, trim=0.9, max_iterations=60)
+    b = sc.icp_refine_ex(g["seg_c"], g["model"], G0, max_iterations=60, trim_fraction=0.9, energy_ratio=1.0)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_point_to_plane_needs_normals():
+    from physimglobalpose_amd._lib import PgpError
+    g = np.load(GOLD)
+    sc = LcpScorer()
+    with pytest.raises(PgpError):
+        sc.icp_refine_ex(g["seg"], g["model"], synth.colmajor16(g["guesses"][0])[None], error_metric=1)
