@@ -311,6 +311,39 @@ int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const
 int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, int n, float radius,
                               int min_neighbors, unsigned char* keep, float* nrm_out, int* n_kept);
 
+/* pgp_set_scene with DEVICE pointers (d_xyz: n x 3 floats; d_nrm: n x 3 or NULL; d_weight: n or NULL):
+ * the segment a previous device call produced (pgp_backproject_depth_device, pgp_voxel_grid_device)
+ * becomes the scene without a host round trip.  Enqueued on `stream`, which is synchronised (the
+ * index build needs the bounding box and two counts on the host). */
+int pgp_set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, const float* d_weight, int n,
+                         float delta, void* stream);
+
+/* Replaces pcl::VoxelGrid<PointXYZRGB> with setLeafSize(leaf, leaf, leaf) in front of the segment
+ * (PPE/segmentation/Segmentation.cpp:234-237; positions only).  PCL is not vendored: PCL 1.7's
+ * published algorithm -- bounds over the finite points, voxel index (ijk relative to
+ * floor(min * 1/leaf)) = i + j * div_x + k * div_x * div_y, one centroid (float sum / count) per
+ * occupied voxel, leaves in ascending voxel index.  PCL leaves the order in which a voxel's points
+ * are added unspecified (std::sort); here it is the point index, so results are reproducible.
+ * out_xyz receives min(*n_out, cap) leaves; *n_out their full number.  Host pointers, synchronous;
+ * the _device form takes n x 3 / cap x 3 device arrays and synchronises `stream` for the count. */
+int pgp_voxel_grid(pgp_ctx* ctx, const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out);
+int pgp_voxel_grid_device(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, float* d_out_xyz, int cap,
+                          int* n_out, void* stream);
+
+/* Replaces Match4PCSBase::c_dist_pose and c_dist_pose_mean (S4/algorithms/match4pcsBase.cc:1616-1655)
+ * for m pairs of poses: hull_xyz[n_hull][3] = hull_Q_3D (<= 4096 points), T[n_poses][16] =
+ * allTransforms (column-major), pairs[m][2] = (index_1, index_2).  dist_max[m] = the directed
+ * Hausdorff distance max_i min_j |T1 h_i - T2 h_j|; dist_sum[m] (nullable) = sum_i min_j (what the
+ * reference calls the mean distance), added in hull order.  Host pointers, synchronous. */
+int pgp_pose_hausdorff(pgp_ctx* ctx, const float* hull_xyz, int n_hull, const float* T, int n_poses,
+                       const int* pairs, int m, float* dist_max, float* dist_sum);
+
+/* pgp_backproject_depth with DEVICE pointers: d_image (rows x cols, u16 or f32), d_mask (nullable),
+ * d_xyz_out (cap x 3).  *n_out (host) = full count; `stream` is synchronised for it. */
+int pgp_backproject_depth_device(pgp_ctx* ctx, const void* d_image, int raw16, const unsigned char* d_mask,
+                                 int rows, int cols, const float K[9], double z_min, double z_max,
+                                 float* d_xyz_out, int cap, int* n_out, void* stream);
+
 /* Depth image -> camera-frame cloud in front of the segment (PPE/misc/utilities.cpp:47-61 decode,
  * PPE/segmentation/Segmentation.cpp:219 mask, utilities.cpp:190-206 / 210-231 back-projection).
  * image: rows x cols, either the raw 16-bit PNG samples (raw16 != 0: rotated right by 3 and divided
@@ -354,6 +387,11 @@ typedef struct pgp_cluster_params {
 int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h, float best_score,
                       const float sym_deg[3], const pgp_cluster_params* params, int* rep_index, int cap,
                       int* n_rep, int* assignment);
+/* pgp_cluster_poses with DEVICE pointers (d_T n_h x 16, d_scores n_h, d_rep_index n_h ints,
+ * d_assignment n_h ints): *n_rep (host) = number of representatives; `stream` is synchronised. */
+int pgp_cluster_poses_device(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n_h, float best_score,
+                             const float sym_deg[3], const pgp_cluster_params* params, int* d_rep_index,
+                             int* d_assignment, int* n_rep, void* stream);
 /* The pose distance alone, for n pairs (test[i], gt[i]) of 4x4 col-major transforms. */
 int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, const float sym_deg[3],
                    float* rot_err_deg, float* trans_err);

@@ -1054,6 +1054,98 @@ int orc_backproject(const void* image, int raw16, const unsigned char* mask, int
   return n;
 }
 
+/* pcl::VoxelGrid<PointXYZRGB>::applyFilter as Segmentation.cpp:234-237 configures it (leaf 0.01 on
+ * every axis, all data down-sampled, no minimum count), published algorithm of PCL 1.7 (PCL is not
+ * vendored: SURVEY 8c): bounds over the finite points, inverse leaf = 1 / leaf (float),
+ * min_b = (int)floor(min_p * inv), div_b = max_b - min_b + 1, voxel index
+ * ijk0 + ijk1 * div_b0 + ijk2 * div_b0 * div_b1 with ijk = (int)(floor(p * inv) - (float)min_b);
+ * points sorted by voxel index, one centroid per voxel = float sum of its points / count, leaves in
+ * ascending voxel index.  PCL sorts with std::sort, which leaves the order of the points INSIDE a
+ * voxel unspecified; this restatement (and the HIP path) add them in point-index order. */
+typedef struct { long long key; int idx; } orc_vg_item;
+static int orc_vg_cmp(const void* a, const void* b) {
+  const orc_vg_item* x = (const orc_vg_item*)a;
+  const orc_vg_item* y = (const orc_vg_item*)b;
+  if (x->key != y->key) return x->key < y->key ? -1 : 1;
+  return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+int orc_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap) {
+  const float inv = 1.0f / leaf;
+  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+  int finite = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * (size_t)i;
+    if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+    ++finite;
+    for (int k = 0; k < 3; ++k) {
+      if (p[k] < mn[k]) mn[k] = p[k];
+      if (p[k] > mx[k]) mx[k] = p[k];
+    }
+  }
+  if (!finite) return 0;
+  int min_b[3], div_b[3];
+  for (int k = 0; k < 3; ++k) {
+    min_b[k] = (int)floorf(mn[k] * inv);
+    div_b[k] = (int)floorf(mx[k] * inv) - min_b[k] + 1;
+  }
+  orc_vg_item* it = (orc_vg_item*)malloc(sizeof(orc_vg_item) * (size_t)finite);
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * (size_t)i;
+    if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+    const int i0 = (int)(floorf(p[0] * inv) - (float)min_b[0]);
+    const int i1 = (int)(floorf(p[1] * inv) - (float)min_b[1]);
+    const int i2 = (int)(floorf(p[2] * inv) - (float)min_b[2]);
+    it[m].key = (long long)i0 + (long long)i1 * div_b[0] + (long long)i2 * div_b[0] * (long long)div_b[1];
+    it[m].idx = i;
+    ++m;
+  }
+  qsort(it, (size_t)m, sizeof(orc_vg_item), orc_vg_cmp);
+  int n_out = 0;
+  for (int a = 0; a < m;) {
+    int b = a;
+    float c[3] = {0.f, 0.f, 0.f};
+    while (b < m && it[b].key == it[a].key) {
+      const float* p = xyz + 3 * (size_t)it[b].idx;
+      c[0] += p[0];
+      c[1] += p[1];
+      c[2] += p[2];
+      ++b;
+    }
+    const float cnt = (float)(b - a);
+    if (n_out < cap) {
+      out_xyz[3 * (size_t)n_out] = c[0] / cnt;
+      out_xyz[3 * (size_t)n_out + 1] = c[1] / cnt;
+      out_xyz[3 * (size_t)n_out + 2] = c[2] / cnt;
+    }
+    ++n_out;
+    a = b;
+  }
+  free(it);
+  return n_out;
+}
+
+/* Match4PCSBase::c_dist_pose / c_dist_pose_mean (base.cc:1616-1655): directed Hausdorff distance
+ * (maximum, and the SUM the reference calls mean) from the hull under T1 to the hull under T2. */
+void orc_pose_hausdorff(const float* hull, int n_hull, const float T1[16], const float T2[16], float* d_max,
+                        float* d_sum) {
+  float max_distance = 0, mean_distance = 0;
+  for (int ii = 0; ii < n_hull; ++ii) {
+    float min_distance = FLT_MAX;
+    float p[3], q[3];
+    orc_transform_point(T1, hull + 3 * (size_t)ii, p);
+    for (int jj = 0; jj < n_hull; ++jj) {
+      orc_transform_point(T2, hull + 3 * (size_t)jj, q);
+      const float dist = sqrtf(orc_sqdist(p, q));
+      if (dist < min_distance) min_distance = dist;
+    }
+    if (min_distance > max_distance) max_distance = min_distance;
+    mean_distance += min_distance;
+  }
+  *d_max = max_distance;
+  *d_sum = mean_distance;
+}
+
 int orc_max_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

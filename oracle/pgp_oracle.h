@@ -150,6 +150,12 @@ int orc_greedy_cluster(const float* T, const float* scores, int n, float best_sc
 int orc_backproject(const void* image, int raw16, const unsigned char* mask, int rows, int cols,
                     const float K[9], double z_min, double z_max, float* xyz_out);
 
+/* pcl::VoxelGrid as Segmentation.cpp:234-237 sets it up (published PCL 1.7 algorithm; points of a
+ * voxel are added in index order): centroids in ascending voxel index; returns their number. */
+int orc_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap);
+/* c_dist_pose (max) and c_dist_pose_mean (sum), base.cc:1616-1655 */
+void orc_pose_hausdorff(const float* hull, int n_hull, const float T1[16], const float T2[16], float* d_max,
+                        float* d_sum);
 int orc_max_threads(void);
 
 #ifdef __cplusplus

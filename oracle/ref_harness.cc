@@ -25,6 +25,7 @@
 #include <vector>
 #include <array>
 #include <cmath>
+#include <cfloat>
 #include <cstring>
 #include <algorithm>
 #include <limits>
@@ -873,3 +874,31 @@ int ref_try_quadrilateral(void* h, int* ids, float* invariant1_out, float* invar
 }
 
 }  // extern "C"
+
+// c_dist_pose / c_dist_pose_mean (base.cc:1616-1655) with the reference's types: hull_Q_3D as
+// Point3D, allTransforms as Matrix4f, (T * pos.homogeneous()).head<3>(), (p - q).norm().
+extern "C" void ref_pose_hausdorff(const float* hull, int n_hull, const float* T1, const float* T2, float* d_max,
+                                   float* d_sum) {
+  std::vector<Point3D> hull_Q_3D(n_hull);
+  for (int i = 0; i < n_hull; ++i) hull_Q_3D[i] = Point3D(hull[3 * i], hull[3 * i + 1], hull[3 * i + 2]);
+  std::vector<MatrixType> allTransforms(2);
+  allTransforms[0] = Eigen::Map<const MatrixType>(T1);
+  allTransforms[1] = Eigen::Map<const MatrixType>(T2);
+  const int index_1 = 0, index_2 = 1;
+  size_t number_of_points = hull_Q_3D.size();
+  float max_distance = 0;
+  float mean_distance = 0;
+  for (int ii = 0; ii < (int)number_of_points; ii++) {
+    float min_distance = FLT_MAX;
+    Eigen::Matrix<Scalar, 3, 1> p = (allTransforms[index_1] * hull_Q_3D[ii].pos().homogeneous()).head<3>();
+    for (int jj = 0; jj < (int)number_of_points; jj++) {
+      Eigen::Matrix<Scalar, 3, 1> q = (allTransforms[index_2] * hull_Q_3D[jj].pos().homogeneous()).head<3>();
+      float dist = (p - q).norm();
+      if (dist < min_distance) min_distance = dist;
+    }
+    if (min_distance > max_distance) max_distance = min_distance;
+    mean_distance += min_distance;
+  }
+  *d_max = max_distance;
+  *d_sum = mean_distance;
+}

@@ -88,6 +88,14 @@ SIGNATURES = {
                                             C.POINTER(C.c_ubyte), _f, _i]),
     "pgp_backproject_depth": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f,
                                         C.c_double, C.c_double, _f, C.c_int, _i]),
+    "pgp_set_scene_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
+    "pgp_voxel_grid": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _f, C.c_int, _i]),
+    "pgp_voxel_grid_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, _i, C.c_void_p]),
+    "pgp_pose_hausdorff": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _i, C.c_int, _f, _f]),
+    "pgp_backproject_depth_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, _f,
+                                               C.c_double, C.c_double, C.c_void_p, C.c_int, _i, C.c_void_p]),
+    "pgp_cluster_poses_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, _f,
+                                           C.POINTER(ClusterParams), C.c_void_p, C.c_void_p, _i, C.c_void_p]),
     "pgp_depth_cost": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_int, C.c_int, C.c_float, _f, _i]),
     "pgp_cluster_poses": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, _f, C.POINTER(ClusterParams), _i,
                                     C.c_int, _i, _i]),

@@ -263,7 +263,6 @@ int device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t*
 
 int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   const int nP = ctx->nP;
-  hipStream_t st = ctx->stream;
   ctx->has_index = false;
 
   float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
@@ -280,6 +279,14 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   if (finite == 0) {
     for (int k = 0; k < 3; ++k) mn[k] = mx[k] = 0.f;
   }
+  return build_index_bbox(ctx, mn, mx, delta);
+}
+
+// The index of the scene already resident in ctx->d_P, given the bounding box of its finite points.
+int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float delta) {
+  const int nP = ctx->nP;
+  hipStream_t st = ctx->stream;
+  ctx->has_index = false;
   GridDesc g{};
   int r = 1;
   int rc = choose_grid(mn, mx, delta, &g, &r);

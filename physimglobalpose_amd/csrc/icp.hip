@@ -661,33 +661,6 @@ __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
 // cell (counting sort by cell id); a query visits the 27 cells around its own.  Every point within
 // max_corr of the query lies in them, so whenever the scan's nearest neighbour passes the cap the two
 // searches return the same (d2, lowest j); when it does not, the pair is unselected either way.
-__global__ __launch_bounds__(256) void grid_bbox(const float4* __restrict__ tgt, int n, float* __restrict__ out6) {
-  __shared__ float s_mn[3][4], s_mx[3][4];
-  float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float4 p = tgt[i];
-    if (!(p.x == p.x && p.y == p.y && p.z == p.z) || fabsf(p.x) > 1e30f || fabsf(p.y) > 1e30f || fabsf(p.z) > 1e30f) continue;
-    mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
-    mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
-  }
-  for (int k = 0; k < 3; ++k)
-    for (int off = 32; off >= 1; off >>= 1) {
-      mn[k] = fminf(mn[k], __shfl_xor(mn[k], off, 64));
-      mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], off, 64));
-    }
-  if ((threadIdx.x & 63) == 0)
-    for (int k = 0; k < 3; ++k) {
-      s_mn[k][threadIdx.x >> 6] = mn[k];
-      s_mx[k][threadIdx.x >> 6] = mx[k];
-    }
-  __syncthreads();
-  if (threadIdx.x < 3) {
-    const int k = threadIdx.x;
-    out6[k] = fminf(fminf(s_mn[k][0], s_mn[k][1]), fminf(s_mn[k][2], s_mn[k][3]));
-    out6[3 + k] = fmaxf(fmaxf(s_mx[k][0], s_mx[k][1]), fmaxf(s_mx[k][2], s_mx[k][3]));
-  }
-}
-
 __device__ __forceinline__ int grid_cell_of(const IcpArgs& a, float x, float y, float z, int* cx, int* cy, int* cz) {
   const float fx = (x - a.gox) * a.ginv_h, fy = (y - a.goy) * a.ginv_h, fz = (z - a.goz) * a.ginv_h;
   if (!(fx >= -1.f && fx < (float)(a.gnx + 1) && fy >= -1.f && fy < (float)(a.gny + 1) && fz >= -1.f && fz < (float)(a.gnz + 1)))
@@ -866,12 +839,8 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   }
   if (use_grid) {
     // ---- the target's grid: bounding box (device), cell edge >= max_corr (grown to keep <= 2^26 cells)
-    if ((rc = ctx->d_icp_grid.ensure(64)) != PGP_OK) return rc;
-    float* d_bb = ctx->d_icp_grid.as<float>();
-    hipLaunchKernelGGL(grid_bbox, dim3(1), dim3(256), 0, stream, d_tgt, n_tgt, d_bb);
     float bb[6];
-    PGP_HIP(hipMemcpyAsync(bb, d_bb, 24, hipMemcpyDeviceToHost, stream));
-    PGP_HIP(hipStreamSynchronize(stream));
+    if ((rc = device_bbox(ctx, reinterpret_cast<const float*>(d_tgt), n_tgt, 4, bb, bb + 3, stream)) != PGP_OK) return rc;
     if (!(bb[0] <= bb[3])) bb[0] = bb[1] = bb[2] = bb[3] = bb[4] = bb[5] = 0.f;   // no finite target point
     float maxabs = 0.f;
     for (int q = 0; q < 6; ++q) maxabs = fmaxf(maxabs, fabsf(bb[q]));

@@ -150,7 +150,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -877,6 +877,129 @@ int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsi
     PGP_HIP(hipStreamSynchronize(st));
   }
   return PGP_OK;
+}
+
+int pgp_set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, const float* d_weight, int n,
+                         float delta, void* stream) {
+  if (!ctx || n < 0 || (n > 0 && !d_xyz) || !(delta > 0.f) || !std::isfinite(delta)) {
+    set_error("pgp_set_scene_device: bad argument (n=%d, delta=%g)", n, (double)delta);
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  PGP_HIP(hipStreamSynchronize(st));   // the producer of d_xyz
+  PGP_HIP(hipDeviceSynchronize());     // queued launches may still read the arrays replaced below
+  return set_scene_device(ctx, d_xyz, d_nrm, d_weight, n, delta, st);
+}
+
+int pgp_voxel_grid_device(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, float* d_out_xyz, int cap,
+                          int* n_out, void* stream) {
+  if (!ctx || n < 0 || cap < 0 || !n_out || !(leaf > 0.f) || !std::isfinite(leaf) || (n > 0 && !d_xyz) ||
+      (cap > 0 && !d_out_xyz)) {
+    set_error("pgp_voxel_grid_device: bad argument");
+    return PGP_EINVAL;
+  }
+  DeviceGuard guard(ctx->device);
+  return launch_voxel_grid(ctx, d_xyz, n, leaf, d_out_xyz, cap, n_out, static_cast<hipStream_t>(stream));
+}
+
+int pgp_voxel_grid(pgp_ctx* ctx, const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out) {
+  if (!ctx || n < 0 || cap < 0 || !n_out || !(leaf > 0.f) || !std::isfinite(leaf) || (n > 0 && !xyz) ||
+      (cap > 0 && !out_xyz)) {
+    set_error("pgp_voxel_grid: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_out = 0;
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  const size_t in_b = ((size_t)n * 12 + 255) & ~(size_t)255;
+  int rc = ctx->d_pre_io.ensure(in_b + (size_t)std::max(cap, 1) * 12 + 64);
+  if (rc != PGP_OK) return rc;
+  float* d_in = ctx->d_pre_io.as<float>();
+  float* d_out = reinterpret_cast<float*>(ctx->d_pre_io.as<unsigned char>() + in_b);
+  PGP_HIP(hipMemcpyAsync(d_in, xyz, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  rc = launch_voxel_grid(ctx, d_in, n, leaf, d_out, cap, n_out, st);
+  if (rc != PGP_OK) return rc;
+  const int n_copy = *n_out < cap ? *n_out : cap;
+  if (n_copy > 0) {
+    PGP_HIP(hipMemcpyAsync(out_xyz, d_out, (size_t)n_copy * 12, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+  }
+  return PGP_OK;
+}
+
+int pgp_pose_hausdorff(pgp_ctx* ctx, const float* hull_xyz, int n_hull, const float* T, int n_poses,
+                       const int* pairs, int m, float* dist_max, float* dist_sum) {
+  if (!ctx || n_hull < 0 || n_poses < 0 || m < 0 || (n_hull > 0 && !hull_xyz) || (n_poses > 0 && !T) ||
+      (m > 0 && (!pairs || !dist_max))) {
+    set_error("pgp_pose_hausdorff: bad argument");
+    return PGP_EINVAL;
+  }
+  if (m == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  std::vector<float4> hh((size_t)std::max(n_hull, 1));
+  for (int i = 0; i < n_hull; ++i) hh[i] = make_float4(hull_xyz[3 * (size_t)i], hull_xyz[3 * (size_t)i + 1], hull_xyz[3 * (size_t)i + 2], 0.f);
+  const size_t b_h = (hh.size() * 16 + 255) & ~(size_t)255, b_T = ((size_t)std::max(n_poses, 1) * 64 + 255) & ~(size_t)255,
+               b_p = ((size_t)m * 8 + 255) & ~(size_t)255, b_o = ((size_t)m * 4 + 255) & ~(size_t)255;
+  int rc = ctx->d_pre_io.ensure(b_h + b_T + b_p + 2 * b_o);
+  if (rc != PGP_OK) return rc;
+  unsigned char* base = ctx->d_pre_io.as<unsigned char>();
+  float4* d_h = reinterpret_cast<float4*>(base);
+  float* d_T = reinterpret_cast<float*>(base + b_h);
+  int2* d_p = reinterpret_cast<int2*>(base + b_h + b_T);
+  float* d_mx = reinterpret_cast<float*>(base + b_h + b_T + b_p);
+  float* d_sm = reinterpret_cast<float*>(base + b_h + b_T + b_p + b_o);
+  PGP_HIP(hipMemcpyAsync(d_h, hh.data(), (size_t)n_hull * 16, hipMemcpyHostToDevice, st));
+  if (n_poses > 0) PGP_HIP(hipMemcpyAsync(d_T, T, (size_t)n_poses * 64, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_p, pairs, (size_t)m * 8, hipMemcpyHostToDevice, st));
+  rc = launch_pose_hausdorff(ctx, d_h, n_hull, d_T, n_poses, d_p, m, d_mx, d_sm, st);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(dist_max, d_mx, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+  if (dist_sum) PGP_HIP(hipMemcpyAsync(dist_sum, d_sm, (size_t)m * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));   // also: hh is a stack-owned staging vector
+  return PGP_OK;
+}
+
+int pgp_backproject_depth_device(pgp_ctx* ctx, const void* d_image, int raw16, const unsigned char* d_mask,
+                                 int rows, int cols, const float K[9], double z_min, double z_max,
+                                 float* d_xyz_out, int cap, int* n_out, void* stream) {
+  if (!ctx || rows < 0 || cols < 0 || cap < 0 || !K || !n_out || (cap > 0 && !d_xyz_out) ||
+      ((size_t)rows * cols > 0 && !d_image) || (size_t)rows * cols > ((size_t)1 << 30)) {
+    set_error("pgp_backproject_depth_device: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_out = 0;
+  const size_t n = (size_t)rows * cols;
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  const size_t nb = (n + 255) / 256;
+  const size_t ctr_bytes = ((nb + 1) * 4 + 255) & ~(size_t)255;
+  const size_t scan_bytes = ((nb / 2048 + 4) * 4 + 255) & ~(size_t)255;
+  int rc = ctx->d_bp.ensure(ctr_bytes + scan_bytes + 256);
+  if (rc != PGP_OK) return rc;
+  uint32_t* d_ctr = ctx->d_bp.as<uint32_t>();
+  uint32_t* d_scan = reinterpret_cast<uint32_t*>(ctx->d_bp.as<unsigned char>() + ctr_bytes);
+  return launch_backproject(ctx, d_image, raw16 != 0, d_mask, rows, cols, K, z_min, z_max, d_ctr, d_scan, d_xyz_out, cap,
+                            n_out, static_cast<hipStream_t>(stream));
+}
+
+int pgp_cluster_poses_device(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n_h, float best_score,
+                             const float sym_deg[3], const pgp_cluster_params* params, int* d_rep_index,
+                             int* d_assignment, int* n_rep, void* stream) {
+  if (!ctx || n_h < 0 || !n_rep || !sym_deg || (n_h > 0 && (!d_T || !d_scores || !d_rep_index || !d_assignment))) {
+    set_error("pgp_cluster_poses_device: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_rep = 0;
+  if (n_h == 0) return PGP_OK;
+  const pgp_cluster_params dflt = {0.5f, 10.f, 0.02f};  // HypothesisSelection.cpp:70,99
+  if (!params) params = &dflt;
+  DeviceGuard guard(ctx->device);
+  int m = 0;
+  return launch_cluster(ctx, d_T, d_scores, n_h, best_score, sym_deg, params, d_rep_index, d_assignment, &m, n_rep,
+                        static_cast<hipStream_t>(stream));
 }
 
 int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, int n, int rows, int cols,

@@ -100,6 +100,9 @@ struct pgp_ctx {
   bool prob_cdf_valid = false;
   pgp::DevBuf d_sel_ws;                 // base-selection workspace / staging
 
+  pgp::DevBuf d_pre_ws, d_vg_ws, d_pre_io;   // preprocess.hip: bbox partials, voxel-grid workspace, host-API staging
+  bool hd_attr_set = false;
+
   pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
   pgp::DevBuf d_bp;      // back-projection staging: image | mask | counters | scan scratch | xyz
   pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
@@ -152,6 +155,7 @@ __host__ __device__ inline uint32_t grid_bit(int x, int y, int z) {
 
 // grid_index.hip
 int build_index(pgp_ctx* ctx, const float* h_xyz, float delta);
+int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float delta);
 int device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, hipStream_t st);
 
 // congruent.hip
@@ -190,6 +194,15 @@ int launch_ppf_features(pgp_ctx* ctx, const int* h_pairs, int m, int* h_f, int* 
 int launch_stage_weights(pgp_ctx* ctx, int stage, int b1, int b2, int b3, float* h_cur, float* h_sum, int* h_present,
                          hipStream_t st);
 int launch_base_invariants(pgp_ctx* ctx, int* h_ids, int m, float* h_inv, int* h_ok, hipStream_t st);
+
+// preprocess.hip
+int device_bbox(pgp_ctx* ctx, const float* d_pts, int n, int stride, float mn[3], float mx[3], hipStream_t st);
+int launch_voxel_grid(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, float* d_out, int cap, int* n_out,
+                      hipStream_t st);
+int launch_pose_hausdorff(pgp_ctx* ctx, const float4* d_hull, int n_hull, const float* d_T, int n_poses,
+                          const int2* d_pairs, int m, float* d_max, float* d_sum, hipStream_t st);
+int set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, const float* d_w, int n, float delta,
+                     hipStream_t st);
 
 // depth_cost.hip
 int launch_depth_cost(pgp_ctx* ctx, const float* d_obs, const float* d_ren, int n, int n_pix, float thr,

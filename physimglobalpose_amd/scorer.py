@@ -244,6 +244,70 @@ class LcpScorer:
         assert kept.value == int(keep[:n].sum())
         return keep[:n].astype(bool), (nout[:n] if nout is not None else None)
 
+    def voxel_grid(self, xyz, leaf=0.01):
+        """pcl::VoxelGrid(leaf) centroids in ascending voxel index (Segmentation.cpp:234-237)."""
+        xyz = _f32(xyz, 3)
+        n = len(xyz)
+        out = np.zeros((max(n, 1), 3), np.float32)
+        m = C.c_int(0)
+        _lib.check(self._lib.pgp_voxel_grid(self._h, _fp(xyz), n, C.c_float(leaf), _fp(out), n, C.byref(m)))
+        return out[: m.value].copy()
+
+    def pose_hausdorff(self, hull_xyz, T, pairs):
+        """c_dist_pose / c_dist_pose_mean (base.cc:1616-1655) for (m,2) index pairs into T (n,16)."""
+        hull, T = _f32(hull_xyz, 3), _f32(T, 16)
+        pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        m = len(pairs)
+        dmax, dsum = np.zeros(max(m, 1), np.float32), np.zeros(max(m, 1), np.float32)
+        _lib.check(self._lib.pgp_pose_hausdorff(self._h, _fp(hull), len(hull), _fp(T), len(T), pairs.ctypes.data_as(_i), m,
+                                                _fp(dmax), _fp(dsum)))
+        return dmax[:m], dsum[:m]
+
+    # device-resident chain: depth image -> cloud -> voxel grid -> scene index (torch tensors carry the memory)
+    def backproject_depth_device(self, d_image, K, d_mask, d_xyz_out, z_min=0.1, z_max=2.0):
+        import torch
+        rows, cols = d_image.shape
+        assert d_image.is_cuda and d_image.is_contiguous() and d_image.dtype in (torch.uint16, torch.int16, torch.float32)
+        raw16 = int(d_image.dtype != torch.float32)
+        K9 = np.ascontiguousarray(K, np.float32).reshape(9)
+        n = C.c_int(0)
+        st = torch.cuda.current_stream(d_image.device).cuda_stream
+        _lib.check(self._lib.pgp_backproject_depth_device(
+            self._h, C.c_void_p(d_image.data_ptr()), raw16, C.c_void_p(d_mask.data_ptr()) if d_mask is not None else None,
+            rows, cols, _fp(K9), C.c_double(z_min), C.c_double(z_max), C.c_void_p(d_xyz_out.data_ptr()),
+            int(d_xyz_out.shape[0]), C.byref(n), C.c_void_p(st)))
+        return n.value
+
+    def voxel_grid_device(self, d_xyz, n, leaf, d_out):
+        import torch
+        m = C.c_int(0)
+        st = torch.cuda.current_stream(d_xyz.device).cuda_stream
+        _lib.check(self._lib.pgp_voxel_grid_device(self._h, C.c_void_p(d_xyz.data_ptr()), int(n), C.c_float(leaf),
+                                                   C.c_void_p(d_out.data_ptr()), int(d_out.shape[0]), C.byref(m),
+                                                   C.c_void_p(st)))
+        return m.value
+
+    def set_scene_device(self, d_xyz, n, d_nrm=None, d_weight=None, delta=0.005):
+        import torch
+        st = torch.cuda.current_stream(d_xyz.device).cuda_stream
+        _lib.check(self._lib.pgp_set_scene_device(
+            self._h, C.c_void_p(d_xyz.data_ptr()), C.c_void_p(d_nrm.data_ptr()) if d_nrm is not None else None,
+            C.c_void_p(d_weight.data_ptr()) if d_weight is not None else None, int(n), C.c_float(delta), C.c_void_p(st)))
+        self.nP, self.delta = int(n), float(delta)
+
+    def cluster_poses_device(self, d_T, d_scores, best_score, d_rep, d_assign, sym_deg=(0, 0, 0), accept_fraction=0.5,
+                             rot_thresh_deg=10.0, trans_thresh=0.02):
+        import torch
+        sym = np.ascontiguousarray(sym_deg, np.float32)
+        prm = _lib.ClusterParams(float(accept_fraction), float(rot_thresh_deg), float(trans_thresh))
+        n_rep = C.c_int(0)
+        st = torch.cuda.current_stream(d_T.device).cuda_stream
+        _lib.check(self._lib.pgp_cluster_poses_device(
+            self._h, C.c_void_p(d_T.data_ptr()), C.c_void_p(d_scores.data_ptr()), int(d_T.shape[0]), C.c_float(best_score),
+            _fp(sym), C.byref(prm), C.c_void_p(d_rep.data_ptr()), C.c_void_p(d_assign.data_ptr()), C.byref(n_rep),
+            C.c_void_p(st)))
+        return n_rep.value
+
     # ---- MCTS leaf cost (UCTState::computeCost) ---------------------------------------------------------
     def backproject_depth(self, image, K, mask=None, z_min=0.1, z_max=2.0):
         """image (rows, cols): uint16 raw PNG samples or float32 metres; K 3x3; mask (rows, cols) or None

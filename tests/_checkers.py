@@ -81,8 +81,37 @@ def oracle_lib():
         L.orc_greedy_cluster.argtypes = [_f, _f, C.c_int, C.c_float, C.c_float, _f, C.c_float, C.c_float, _i, _i]
         L.orc_backproject.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.c_int, _f, C.c_double,
                                       C.c_double, _f]
+        L.orc_voxel_grid.argtypes = [_f, C.c_int, C.c_float, _f, C.c_int]
+        L.orc_pose_hausdorff.argtypes = [_f, C.c_int, _f, _f, _f, _f]
         _oracle = L
     return _oracle
+
+
+def oracle_voxel_grid(xyz, leaf=0.01):
+    xyz = _f32(xyz).reshape(-1, 3)
+    out = np.zeros((max(len(xyz), 1), 3), np.float32)
+    n = oracle_lib().orc_voxel_grid(_fp(xyz), len(xyz), C.c_float(leaf), _fp(out), len(xyz))
+    return out[:n].copy()
+
+
+def _hausdorff(fn, hull, T, pairs):
+    hull, T = _f32(hull).reshape(-1, 3), _f32(T).reshape(-1, 16)
+    dmax, dsum = np.zeros(len(pairs), np.float32), np.zeros(len(pairs), np.float32)
+    a, b = C.c_float(0), C.c_float(0)
+    for k, (i, j) in enumerate(pairs):
+        fn(_fp(hull), len(hull), _fp(np.ascontiguousarray(T[i])), _fp(np.ascontiguousarray(T[j])), C.byref(a), C.byref(b))
+        dmax[k], dsum[k] = a.value, b.value
+    return dmax, dsum
+
+
+def oracle_pose_hausdorff(hull, T, pairs):
+    return _hausdorff(oracle_lib().orc_pose_hausdorff, hull, T, pairs)
+
+
+def ref_pose_hausdorff(hull, T, pairs):
+    L = ref_lib()
+    L.ref_pose_hausdorff.argtypes = [_f, C.c_int, _f, _f, _f, _f]
+    return _hausdorff(L.ref_pose_hausdorff, hull, T, pairs)
 
 
 class Oracle:

@@ -184,6 +184,7 @@ def main():
     near_ties_case()
     stocs_case()
     test_scene_frame_case()
+    hausdorff_case()
 
 
 def morton_order(Q):
@@ -361,6 +362,29 @@ def test_scene_frame_case():
     path = os.path.join(HERE, "test_scene_frame.npz")
     np.savez_compressed(path, raw=raw, mask=mask.astype(np.uint8), K=K)
     print("test_scene_frame:", raw.shape, f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+def hausdorff_case():
+    """(17) c_dist_pose / c_dist_pose_mean (base.cc:1616-1655) through the Eigen-typed harness: a 300-point
+    hull, 48 transforms (clusters + random), 400 index pairs incl. identical ones."""
+    from _checkers import ref_pose_hausdorff
+    rng = np.random.default_rng(20261109)
+    hull, _ = synth.make_model(rng, 300)
+    hull = hull.astype(np.float32)
+    T = []
+    for k in range(48):
+        if k % 3:
+            M = synth._se3(synth._random_rot(rng, np.deg2rad(8.0)), 0.01 * rng.standard_normal(3) + [0.05, 0.0, 0.8])
+        else:
+            M = synth._se3(synth._random_rot(rng), rng.uniform(-0.3, 0.3, 3))
+        T.append(synth.colmajor16(M))
+    T = np.array(T, np.float32)
+    pairs = rng.integers(0, 48, (400, 2)).astype(np.int32)
+    pairs[:10, 1] = pairs[:10, 0]
+    dmax, dsum = ref_pose_hausdorff(hull, T, pairs)
+    path = os.path.join(HERE, "hausdorff.npz")
+    np.savez_compressed(path, hull=hull, T=T, pairs=pairs, dmax=dmax, dsum=dsum)
+    print("hausdorff: max", float(dmax.max()), "zero pairs", int((dmax == 0).sum()), f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def weights_case():
@@ -567,6 +591,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "test_scene_frame":
         test_scene_frame_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "hausdorff":
+        hausdorff_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "stocs":
         stocs_case()
