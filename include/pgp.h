@@ -125,6 +125,14 @@ int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, fl
  * count.  In plain mode every inlier's nearest scene point is reported. */
 int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int* ids, int* n);
 
+/* Replaces Match4PCSBase::getRegisteredModel (base.cc:347-375; defined but not called by
+ * ComputeTransformation): the scene ids registered by the points of ANOTHER cloud with normals
+ * (sampled_Q_3D_, the search model) under one transform, with the gate on the DIRECTED normal angle
+ * (acos(dot) * 180 / pi < gate_deg; the fold of WeightedVerify is commented out there, :368).
+ * q_xyz / q_nrm: n x 3; ids (capacity n) in cloud order; *n_ids their number.  Host pointers. */
+int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, const float* q_nrm, int n,
+                         float gate_deg, int* ids, int* n_ids);
+
 /* Running-best subsequence of base.cc:1891-1908 over a score vector (host helper): writes the
  * indices i with scores[i] > max(scores[0..i-1], 0) to selected (capacity n_h). */
 int pgp_running_best(const float* scores, int n_h, int* selected, int* n_selected);
@@ -214,6 +222,15 @@ int pgp_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* pairs, 
 int pgp_find_congruent(pgp_ctx* ctx, const float* base, float invariant1, float invariant2, float threshold,
                        const int* P_pairs, int nP, const int* Q_pairs, int nQ, int* quads, int cap,
                        int* n_quads);
+
+/* Replaces Match4PCS::FindCongruentQuadrilaterals (S4/algorithms/4pcs.cc:61-103; the classic 4PCS
+ * matcher, not instantiated by the node): for every Q-pair i, every P-pair id whose invariant point
+ * e1 = p1 + invariant1 (p2 - p1) lies at SQUARED distance < threshold (strict; kdtree.h:491) of
+ * e2 = q1 + invariant2 (q2 - q1) emits (P_pairs[id / 2], Q_pairs[i]) -- `id / 2` as the reference
+ * writes it.  Quads come out in (i, id) order (the reference's kd-tree leaves the order inside one i
+ * unspecified).  Pair lists as in pgp_find_congruent; *n_quads = full count. */
+int pgp_find_congruent_4pcs(pgp_ctx* ctx, float invariant1, float invariant2, float threshold, const int* P_pairs,
+                            int nP, const int* Q_pairs, int nQ, int* quads, int cap, int* n_quads);
 
 /* Replaces the loop `for (auto base_it: baseSet) ExtractCongruentSet(base_it)` of Perform_N_steps
  * (base.cc:1855-1874 -> :1929-1993, operMode 1) for ALL bases of an object in one pass: for base b,

@@ -902,3 +902,62 @@ extern "C" void ref_pose_hausdorff(const float* hull, int n_hull, const float* T
   *d_max = max_distance;
   *d_sum = mean_distance;
 }
+
+// getRegisteredModel (base.cc:347-375) over the harness' validation cloud standing in for
+// sampled_Q_3D_ (any cloud with normals), on the reference's own kd-tree.
+extern "C" int ref_get_registered_model(void* h, const float* T, float delta, int* registered) {
+  RefScene& s = *static_cast<RefScene*>(h);
+  MatrixType mat = Eigen::Map<const MatrixType>(T);
+  const std::vector<Point3D>& sampled_Q_3D_ = s.validation_Q_3D;
+  const std::vector<Point3D>& sampled_P_3D_ = s.sampled_P_3D_;
+  const Scalar epsilon = delta;
+  const size_t number_of_points = sampled_Q_3D_.size();
+  const Scalar sq_eps = epsilon * epsilon;
+  int n = 0;
+  for (int i = 0; i < (int)number_of_points; ++i) {
+    Super4PCS::KdTree<Scalar>::Index resId = s.kd_tree_.doQueryRestrictedClosestIndex(
+        (mat * sampled_Q_3D_[i].pos().homogeneous()).head<3>(), sq_eps);
+    if (resId != Super4PCS::KdTree<Scalar>::invalidIndex()) {
+      VectorType n_q = mat.block<3, 3>(0, 0) * sampled_Q_3D_[i].normal();
+      float angle_n = std::acos(sampled_P_3D_[resId].normal().dot(n_q)) * 180 / M_PI;
+      if (angle_n < 30) registered[n++] = resId;
+    }
+  }
+  return n;
+}
+
+// Match4PCS::FindCongruentQuadrilaterals (S4/algorithms/4pcs.cc:61-103) on the reference's own kd-tree
+// range query (kdtree.h:247-255,470-520); the quads of one Q-pair come out in kd-tree order.
+extern "C" int ref_4pcs_find_congruent(const float* Q_xyz, int nQs, float invariant1, float invariant2,
+                                       float distance_threshold2, const int* P_pairs_flat, int nP,
+                                       const int* Q_pairs_flat, int nQ, int* quads, int cap) {
+  std::vector<Point3D> sampled_Q_3D_(nQs);
+  for (int i = 0; i < nQs; ++i) sampled_Q_3D_[i] = Point3D(Q_xyz[3 * i], Q_xyz[3 * i + 1], Q_xyz[3 * i + 2]);
+  std::vector<std::pair<int, int> > P_pairs(nP), Q_pairs(nQ);
+  for (int i = 0; i < nP; ++i) P_pairs[i] = std::make_pair(P_pairs_flat[2 * i], P_pairs_flat[2 * i + 1]);
+  for (int i = 0; i < nQ; ++i) Q_pairs[i] = std::make_pair(Q_pairs_flat[2 * i], Q_pairs_flat[2 * i + 1]);
+  size_t number_of_points = 2 * P_pairs.size();
+  Super4PCS::KdTree<Scalar> kdtree(number_of_points);
+  for (size_t i = 0; i < P_pairs.size(); ++i) {
+    const VectorType& p1 = sampled_Q_3D_[P_pairs[i].first].pos();
+    const VectorType& p2 = sampled_Q_3D_[P_pairs[i].second].pos();
+    kdtree.add(p1 + invariant1 * (p2 - p1));
+  }
+  kdtree.finalize();
+  int n = 0;
+  for (size_t i = 0; i < Q_pairs.size(); ++i) {
+    const VectorType& p1 = sampled_Q_3D_[Q_pairs[i].first].pos();
+    const VectorType& p2 = sampled_Q_3D_[Q_pairs[i].second].pos();
+    kdtree.doQueryDistProcessIndices(p1 + invariant2 * (p2 - p1), distance_threshold2,
+                                     [&](int id) {
+                                       if (n < cap) {
+                                         quads[4 * n] = P_pairs[id / 2].first;
+                                         quads[4 * n + 1] = P_pairs[id / 2].second;
+                                         quads[4 * n + 2] = Q_pairs[i].first;
+                                         quads[4 * n + 3] = Q_pairs[i].second;
+                                       }
+                                       ++n;
+                                     });
+  }
+  return n;
+}

@@ -56,6 +56,9 @@ SIGNATURES = {
     "pgp_settle_best_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_registered": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _i, _i]),
+    "pgp_registered_model": (C.c_int, [C.c_void_p, _f, _f, _f, C.c_int, C.c_float, _i, _i]),
+    "pgp_find_congruent_4pcs": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, _i, C.c_int, _i, C.c_int,
+                                          _i, C.c_int, _i]),
     "pgp_running_best": (C.c_int, [_f, C.c_int, _i, _i]),
     "pgp_set_search_model": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_set_ppf_map": (C.c_int, [C.c_void_p, _i, _i, _i, C.c_int]),

@@ -451,6 +451,69 @@ __global__ void batch_gather(const unsigned long long* __restrict__ keys, const 
   quads[t] = make_int4(p.x, p.y, q.x, q.y);
 }
 
+
+// ---------------- classic 4PCS quad search (Match4PCS::FindCongruentQuadrilaterals) ----------------
+// S4/algorithms/4pcs.cc:61-103: the invariant points e1 = p1 + invariant1 (p2 - p1) of the P-pairs go
+// into a kd-tree; for every Q-pair the tree is asked for all e1 with |e1 - e2|^2 < distance_threshold2
+// (strict, S4/accelerators/kdtree.h:491; the UNSQUARED threshold is compared with the squared
+// distance, as in the Super4PCS variant) and each hit id emits (P_pairs[id / 2], Q_pairs[i]) -- the
+// `id / 2` is the reference's (its tree holds ONE point per pair, so the quad names the wrong pair for
+// every odd id); it is reproduced as written.  On the device the range query is a tiled scan: a
+// thread per Q-pair, the invariant points of 1024 P-pairs per LDS tile, hits emitted in (i, id) order.
+__global__ __launch_bounds__(256) void invariant_points(const float4* __restrict__ Qw, int nQs, const int2* __restrict__ Pp,
+                                                        int nP, float inv1, float4* __restrict__ e1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nP) return;
+  const int2 pr = Pp[i];
+  const float qnan = __int_as_float(0x7FC00000);
+  if ((unsigned)pr.x >= (unsigned)nQs || (unsigned)pr.y >= (unsigned)nQs) {
+    e1[i] = make_float4(qnan, qnan, qnan, 0.f);   // never within any range
+    return;
+  }
+  const V3 p = lerp_pt(ld3(Qw, pr.x), ld3(Qw, pr.y), inv1);
+  e1[i] = make_float4(p.x, p.y, p.z, 0.f);
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void range_match(const float4* __restrict__ Qw, int nQs, const float4* __restrict__ e1,
+                                                   int nP, const int2* __restrict__ Pp, const int2* __restrict__ Qp, int nQ,
+                                                   float inv2, float sqdist, uint32_t* __restrict__ q_cnt,
+                                                   const uint32_t* __restrict__ q_start, int4* __restrict__ quads,
+                                                   uint32_t cap) {
+  __shared__ float4 s_e[1024];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i < nQ;
+  int2 qr = make_int2(0, 0);
+  V3 e2 = {0.f, 0.f, 0.f};
+  bool ok = false;
+  if (live) {
+    qr = Qp[i];
+    ok = (unsigned)qr.x < (unsigned)nQs && (unsigned)qr.y < (unsigned)nQs;
+    if (ok) e2 = lerp_pt(ld3(Qw, qr.x), ld3(Qw, qr.y), inv2);
+  }
+  uint32_t found = 0;
+  const uint32_t out0 = (FILL && live) ? q_start[i] : 0u;
+  for (int t0 = 0; t0 < nP; t0 += 1024) {
+    const int tn = min(1024, nP - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += blockDim.x) s_e[j] = e1[t0 + j];
+    __syncthreads();
+    if (!ok) continue;
+    for (int j = 0; j < tn; ++j) {
+      const float4 e = s_e[j];
+      const V3 d = {sub(e2.x, e.x), sub(e2.y, e.y), sub(e2.z, e.z)};
+      if (sqnorm(d) < sqdist) {   // strict; NaN never
+        if (FILL && out0 + found < cap) {
+          const int2 pp = Pp[(t0 + j) / 2];   // sic: P_pairs[id / 2]
+          quads[out0 + found] = make_int4(pp.x, pp.y, qr.x, qr.y);
+        }
+        ++found;
+      }
+    }
+  }
+  if (!FILL && live) q_cnt[i] = found;
+}
+
 }  // namespace
 
 // PairCreationFunctor::synch3DContent (pairCreationFunctor.h:102-138): centre + ratio of the
@@ -820,6 +883,42 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
   const unsigned long long* keys_out = ctx->d_cs_keys.as<unsigned long long>() + ctx->csb_total;
   hipLaunchKernelGGL(batch_gather, dim3((m + 255) / 256), dim3(256), 0, st, keys_out, d_base_start, d_bases,
                      (const int2*)ctx->d_ppf_pairs.as<int2>(), (const int2*)ctx->d_csb_picks.as<int2>(), m, d_quads);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+
+int launch_find_congruent_4pcs(pgp_ctx* ctx, float inv1, float inv2, float threshold, const int* d_Pp, int nP,
+                               const int* d_Qp, int nQ, int* d_quads, int cap, int* n_quads_host, hipStream_t st) {
+  *n_quads_host = 0;
+  if (ctx->nQs <= 0 || !ctx->d_Qs.p) {
+    set_error("no search model: call pgp_set_search_model first");
+    return PGP_ESTATE;
+  }
+  if (nP <= 0 || nQ <= 0) return PGP_OK;
+  int rc;
+  if ((rc = ctx->d_cs_entries.ensure((size_t)nP * 16 + 16)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cs_cnt.ensure(((size_t)nQ + 1) * 8 + 64)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure(((size_t)nQ / 2048 + 2) * 4)) != PGP_OK) return rc;
+  float4* e1 = ctx->d_cs_entries.as<float4>();
+  uint32_t* qcnt = ctx->d_cs_cnt.as<uint32_t>();
+  uint32_t* qstart = qcnt + (nQ + 1);
+  const float4* Qw = ctx->d_Qs.as<float4>();
+  const int2* Pp = reinterpret_cast<const int2*>(d_Pp);
+  const int2* Qp = reinterpret_cast<const int2*>(d_Qp);
+  hipLaunchKernelGGL(invariant_points, dim3((nP + 255) / 256), dim3(256), 0, st, Qw, ctx->nQs, Pp, nP, inv1, e1);
+  PGP_HIP(hipMemsetAsync(qcnt + nQ, 0, 4, st));
+  const dim3 gq((nQ + 255) / 256);
+  hipLaunchKernelGGL(range_match<false>, gq, dim3(256), 0, st, Qw, ctx->nQs, (const float4*)e1, nP, Pp, Qp, nQ, inv2,
+                     threshold, qcnt, (const uint32_t*)nullptr, (int4*)nullptr, 0u);
+  if ((rc = device_exclusive_scan(qcnt, qstart, (size_t)nQ + 1, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
+  uint32_t total = 0;
+  PGP_HIP(hipMemcpyAsync(&total, qstart + nQ, 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *n_quads_host = (int)total;
+  if (total == 0 || cap <= 0) return PGP_OK;
+  hipLaunchKernelGGL(range_match<true>, gq, dim3(256), 0, st, Qw, ctx->nQs, (const float4*)e1, nP, Pp, Qp, nQ, inv2,
+                     threshold, qcnt, (const uint32_t*)qstart, reinterpret_cast<int4*>(d_quads), (uint32_t)cap);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

@@ -561,6 +561,36 @@ __global__ __launch_bounds__(256) void registered_points(ScoreArgs a, int* __res
   hits[__float_as_int(a.Q[i].w)] = point_hit<MODE>(a, m, i);
 }
 
+// Match4PCSBase::getRegisteredModel (base.cc:347-375; not called by ComputeTransformation): the
+// verifier's loop over ANOTHER cloud (sampled_Q_3D_, the search model) with the 30-degree gate applied
+// to the directed angle -- the fold `min(a, 180 - a)` is commented out there (:368), so anti-parallel
+// normals do NOT register.  Per point, in cloud order: scene id or -1.
+__global__ __launch_bounds__(256) void registered_model(ScoreArgs a, const float4* __restrict__ q_xyz,
+                                                        const float4* __restrict__ q_nrm, int n,
+                                                        int* __restrict__ hits) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Xf m = load_xf(a.T, 0);
+  const float4 q = q_xyz[i];
+  const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
+  const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
+  const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
+  uint32_t s, e;
+  cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
+  e += s;
+  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+  if (id >= 0) {
+    const float4 qn = q_nrm[i];
+    const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
+    const float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
+    const float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
+    const float4 pn = a.Pnw[id];
+    const float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+    if (!(dot >= a.gate_lo && dot <= 1.0f)) id = -1;   // acos(dot) * 180 / pi < gate, no fold; NaN rejected
+  }
+  hits[i] = id;
+}
+
 // Sum the per-tile partials in tile order, form the score exactly as the reference does
 // (Scalar(good_points)/Scalar(number_of_points), base.cc:1730 / weighted_match/Scalar(n), :1765)
 // and fold the batch arg-max: key = score bits << 32 | ~index, so the maximum key is the highest
@@ -1102,6 +1132,37 @@ int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream
   hipLaunchKernelGGL(count_neighbours, dim3((ctx->nP + 255) / 256), dim3(256), 0, stream, ctx->grid,
                      ctx->d_bitmap.as<uint2>(), ctx->d_occ_start.as<uint2>(), ctx->d_cand.as<float4>(),
                      ctx->d_P.as<float4>(), ctx->nP, radius * radius, d_counts);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q, const float4* d_qn, int n,
+                            float gate_deg, int* d_hits, hipStream_t stream) {
+  if (!ctx->has_scene_normals) {
+    set_error("pgp_registered_model needs scene normals");
+    return PGP_ESTATE;
+  }
+  if (!ctx->has_index) {
+    set_error("no scene index: call pgp_set_scene first");
+    return PGP_ESTATE;
+  }
+  if (ctx->gate_deg_cached != gate_deg) {
+    gate_thresholds(gate_deg, &ctx->gate_lo, &ctx->gate_hi);
+    ctx->gate_deg_cached = gate_deg;
+  }
+  ScoreArgs a{};
+  a.g = ctx->grid;
+  a.words = ctx->d_bitmap.as<uint2>();
+  a.occ_run = ctx->d_occ_start.as<uint2>();
+  a.cand = ctx->d_cand.as<float4>();
+  a.Pnw = ctx->d_Pnw.as<float4>();
+  a.T = d_T16;
+  a.n_h = 1;
+  a.sq_eps = ctx->delta * ctx->delta;
+  a.gate_lo = ctx->gate_lo;
+  a.gate_hi = ctx->gate_hi;
+  if (n == 0) return PGP_OK;
+  hipLaunchKernelGGL(registered_model, dim3((n + 255) / 256), dim3(256), 0, stream, a, d_q, d_qn, n, d_hits);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

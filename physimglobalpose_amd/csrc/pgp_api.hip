@@ -437,6 +437,74 @@ int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int
   return PGP_OK;
 }
 
+int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, const float* q_nrm, int n,
+                         float gate_deg, int* ids, int* n_ids) {
+  if (!ctx || !T16 || !n_ids || n < 0 || (n > 0 && (!q_xyz || !q_nrm || !ids))) {
+    set_error("pgp_registered_model: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_ids = 0;
+  if (n == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  std::vector<float4> hq((size_t)n), hn((size_t)n);
+  for (int i = 0; i < n; ++i) {
+    hq[i] = make_float4(q_xyz[3 * (size_t)i], q_xyz[3 * (size_t)i + 1], q_xyz[3 * (size_t)i + 2], 0.f);
+    hn[i] = make_float4(q_nrm[3 * (size_t)i], q_nrm[3 * (size_t)i + 1], q_nrm[3 * (size_t)i + 2], 0.f);
+  }
+  const size_t N = (size_t)n;
+  int rc = ctx->d_pre_io.ensure(N * 36 + 64 + 256);
+  if (rc != PGP_OK) return rc;
+  unsigned char* base = ctx->d_pre_io.as<unsigned char>();
+  float4* d_q = reinterpret_cast<float4*>(base);
+  float4* d_n = d_q + N;
+  int* d_hits = reinterpret_cast<int*>(d_n + N);
+  float* d_T = reinterpret_cast<float*>(d_hits + N);
+  d_T = reinterpret_cast<float*>(((uintptr_t)d_T + 63) & ~(uintptr_t)63);
+  PGP_HIP(hipMemcpyAsync(d_q, hq.data(), N * 16, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_n, hn.data(), N * 16, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_T, T16, 64, hipMemcpyHostToDevice, st));
+  rc = launch_registered_model(ctx, d_T, d_q, d_n, n, gate_deg, d_hits, st);
+  if (rc != PGP_OK) return rc;
+  std::vector<int> hits(N);
+  PGP_HIP(hipMemcpyAsync(hits.data(), d_hits, N * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  int k = 0;
+  for (int i = 0; i < n; ++i)
+    if (hits[i] >= 0) ids[k++] = hits[i];
+  *n_ids = k;
+  return PGP_OK;
+}
+
+int pgp_find_congruent_4pcs(pgp_ctx* ctx, float invariant1, float invariant2, float threshold, const int* P_pairs,
+                            int nP, const int* Q_pairs, int nQ, int* quads, int cap, int* n_quads) {
+  if (!ctx || !n_quads || nP < 0 || nQ < 0 || cap < 0 || (nP > 0 && !P_pairs) || (nQ > 0 && !Q_pairs) ||
+      (cap > 0 && !quads)) {
+    set_error("pgp_find_congruent_4pcs: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_quads = 0;
+  if (nP == 0 || nQ == 0) return PGP_OK;
+  DeviceGuard guard(ctx->device);
+  hipStream_t st = ctx->stream;
+  int rc;
+  if ((rc = ctx->d_cs_pairs.ensure(((size_t)nP + nQ) * 8)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cs_out.ensure((size_t)std::max(cap, 1) * 16)) != PGP_OK) return rc;
+  int* d_Pp = ctx->d_cs_pairs.as<int>();
+  int* d_Qp = d_Pp + 2 * (size_t)nP;
+  PGP_HIP(hipMemcpyAsync(d_Pp, P_pairs, (size_t)nP * 8, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d_Qp, Q_pairs, (size_t)nQ * 8, hipMemcpyHostToDevice, st));
+  int total = 0;
+  rc = launch_find_congruent_4pcs(ctx, invariant1, invariant2, threshold, d_Pp, nP, d_Qp, nQ, ctx->d_cs_out.as<int>(), cap,
+                                  &total, st);
+  if (rc != PGP_OK) return rc;
+  const int n_copy = std::min(total, cap);
+  if (n_copy > 0) PGP_HIP(hipMemcpyAsync(quads, ctx->d_cs_out.p, (size_t)n_copy * 16, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  *n_quads = total;
+  return PGP_OK;
+}
+
 int pgp_running_best(const float* scores, int n_h, int* selected, int* n_selected) {
   if (n_h < 0 || (n_h > 0 && (!scores || !selected)) || !n_selected) {
     set_error("pgp_running_best: bad argument");

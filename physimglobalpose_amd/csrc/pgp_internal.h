@@ -166,6 +166,8 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
                           const int* d_Pp, int nP, const int* d_Qp, int nQ, int* d_quads, int cap,
                           int* n_quads_host, hipStream_t st);
 
+int launch_find_congruent_4pcs(pgp_ctx* ctx, float inv1, float inv2, float threshold, const int* d_Pp, int nP,
+                               const int* d_Qp, int nQ, int* d_quads, int cap, int* n_quads_host, hipStream_t st);
 int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
                                 int nb, float threshold, int* h_n_quads, hipStream_t st);
 int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st);
@@ -176,6 +178,8 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
                  float* d_scores, int* d_counts, int* d_best, hipStream_t stream);
 int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                        int* d_best, hipStream_t stream);
+int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q, const float4* d_qn, int n,
+                            float gate_deg, int* d_hits, hipStream_t stream);
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream);
 void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);

@@ -427,6 +427,29 @@ class LcpScorer:
                                             ids.ctypes.data_as(_i), C.byref(n)))
         return ids[: n.value].copy()
 
+    def registered_model(self, mat16, q_xyz, q_nrm, gate_deg=30.0):
+        """getRegisteredModel (base.cc:347-375): scene ids registered by another cloud, directed-angle gate."""
+        mat16, q, qn = _f32(mat16).reshape(16), _f32(q_xyz, 3), _f32(q_nrm, 3)
+        ids = np.zeros(max(len(q), 1), np.int32)
+        n = C.c_int(0)
+        _lib.check(self._lib.pgp_registered_model(self._h, _fp(mat16), _fp(q), _fp(qn), len(q), C.c_float(gate_deg),
+                                                  ids.ctypes.data_as(_i), C.byref(n)))
+        return ids[: n.value].copy()
+
+    def find_congruent_4pcs(self, invariant1, invariant2, threshold, P_pairs, Q_pairs, cap=None):
+        """Match4PCS::FindCongruentQuadrilaterals (4pcs.cc:61-103) -> (n,4) quads in (Q-pair, P-pair) order."""
+        Pp = np.ascontiguousarray(P_pairs, np.int32).reshape(-1, 2)
+        Qp = np.ascontiguousarray(Q_pairs, np.int32).reshape(-1, 2)
+        n = C.c_int(0)
+        args = (self._h, C.c_float(invariant1), C.c_float(invariant2), C.c_float(threshold), Pp.ctypes.data_as(_i),
+                len(Pp), Qp.ctypes.data_as(_i), len(Qp))
+        if cap is None:
+            _lib.check(self._lib.pgp_find_congruent_4pcs(*args, None, 0, C.byref(n)))
+            cap = n.value
+        out = np.zeros((max(cap, 1), 4), np.int32)
+        _lib.check(self._lib.pgp_find_congruent_4pcs(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
+        return out[: min(n.value, cap)].copy()
+
     @staticmethod
     def running_best(scores):
         scores = _f32(scores)

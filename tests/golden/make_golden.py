@@ -185,6 +185,7 @@ def main():
     stocs_case()
     test_scene_frame_case()
     hausdorff_case()
+    dead_code_case()
 
 
 def morton_order(Q):
@@ -385,6 +386,46 @@ def hausdorff_case():
     path = os.path.join(HERE, "hausdorff.npz")
     np.savez_compressed(path, hull=hull, T=T, pairs=pairs, dmax=dmax, dsum=dsum)
     print("hausdorff: max", float(dmax.max()), "zero pairs", int((dmax == 0).sum()), f"{os.path.getsize(path)/1024:.0f} KiB")
+
+
+def dead_code_case():
+    """(18) the two functions the node never reaches, through the harness: getRegisteredModel
+    (base.cc:347-375) on the clouds of fixture scene_1, and Match4PCS::FindCongruentQuadrilaterals
+    (4pcs.cc:61-103) on the reference's own kd-tree range query for pair lists of fixture congruent_0."""
+    import ctypes as C
+    L = ref_lib()
+    g = np.load(os.path.join(HERE, "scene_1.npz"))
+    ref = Ref(g["P"], g["Pn"], g["Pw"], g["Q"], g["Qn"])
+    L.ref_get_registered_model.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_int)]
+    flat, off = [], [0]
+    for T in g["T"]:
+        buf = np.zeros(len(g["Q"]), np.int32)
+        n = L.ref_get_registered_model(ref.h, _fp(np.ascontiguousarray(T)), C.c_float(float(g["delta"])),
+                                       buf.ctypes.data_as(C.POINTER(C.c_int)))
+        flat.append(buf[:n].copy())
+        off.append(off[-1] + n)
+    c = np.load(os.path.join(HERE, "congruent_0.npz"))
+    L.ref_4pcs_find_congruent.argtypes = [C.POINTER(C.c_float), C.c_int, C.c_float, C.c_float, C.c_float,
+                                          C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int,
+                                          C.POINTER(C.c_int), C.c_int]
+    out = dict(regm_flat=np.concatenate(flat).astype(np.int32), regm_off=np.array(off, np.int64))
+    for k in range(2):
+        p1, p6 = np.ascontiguousarray(c[f"p1_{k}"]), np.ascontiguousarray(c[f"p6_{k}"])
+        inv1, inv2 = float(c["invs"][k][0]), float(c["invs"][k][1])
+        thr = np.float32(0.0004)       # squared-distance threshold passed unsquared, as the reference does
+        cap = 1 << 22
+        buf = np.zeros((cap, 4), np.int32)
+        n = L.ref_4pcs_find_congruent(_fp(np.ascontiguousarray(c["Qs"])), len(c["Qs"]), C.c_float(inv1), C.c_float(inv2),
+                                      C.c_float(float(thr)), p1.ctypes.data_as(C.POINTER(C.c_int)), len(p1),
+                                      p6.ctypes.data_as(C.POINTER(C.c_int)), len(p6), buf.ctypes.data_as(C.POINTER(C.c_int)), cap)
+        assert n <= cap
+        q = buf[:n]
+        out[f"quads4_{k}"] = q
+        out[f"thr4_{k}"] = thr
+        print(f"4pcs quads base {k}: {n}")
+    path = os.path.join(HERE, "dead_code.npz")
+    np.savez_compressed(path, **out)
+    print("dead_code: registered-model ids", off[-1], f"{os.path.getsize(path)/1024:.0f} KiB")
 
 
 def weights_case():
@@ -591,6 +632,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "test_scene_frame":
         test_scene_frame_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "dead_code":
+        dead_code_case()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hausdorff":
         hausdorff_case()
