@@ -370,6 +370,13 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
   for (int c = 0; c < NC; ++c) en[c] = ent[o[c]];
 #pragma unroll
   for (int c = 0; c < NC; ++c) p[c] = cand[__float_as_uint(en[c].w) + we[c]];
+  if (MODE == PGP_MODE_WEIGHTED) {
+    // keep the 16-byte loads whole: the id (.w) is only used by lanes with an in-range candidate, and
+    // the compiler otherwise narrows the load to 12 bytes and sinks a dependent 4-byte load of the id
+    // into that branch -- one more L1/L2 round trip on the critical chain of every batch with a hit
+#pragma unroll
+    for (int c = 0; c < NC; ++c) asm volatile("" ::"v"(p[c].w));
+  }
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float d2 = sqdist(en[c].x, en[c].y, en[c].z, p[c]);
@@ -426,8 +433,12 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   chunk_range(a, chunk, &h0, &h1);
   int my_cnt = 0;
   float my_sum = 0.f;
+  // the hypothesis' 4x4 for the NEXT trip is requested (scalar loads) at the top of the current one, so
+  // that its latency runs under this trip's vector loads instead of in front of the next transform
+  Xf m_pre = load_xf(Tm, h0);
   for (int h = h0; h < h1; ++h) {
-    const Xf m = load_xf(Tm, h);
+    const Xf m = m_pre;
+    m_pre = load_xf(Tm, min(h + 1, h1 - 1));
     const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
     const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
     const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
@@ -467,6 +478,9 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
         if (MODE == PGP_MODE_PLAIN && left > 128) {
           flat_batch<MODE, 4>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 256;
+        } else if (MODE == PGP_MODE_WEIGHTED && left > 128) {
+          flat_batch<MODE, 3>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
+          w0 += 192;
         } else if (left > 64) {
           flat_batch<MODE, 2>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 128;
