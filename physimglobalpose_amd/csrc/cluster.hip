@@ -245,38 +245,55 @@ __global__ __launch_bounds__(256) void cluster_pair_bits(const float* __restrict
   if ((c & 63) == 0 && threadIdx.x == 0) bits[(size_t)c * W + (c >> 6)] = 0ull;
 }
 
-// The sequential pass.  One block (4 waves).  keep[] (LDS) = representatives so far, by sorted
-// position.  Per tile of 64 candidates: (1) each wave takes 16 of them and looks for a hit among
+// The sequential pass.  One block (16 waves).  keep[] (LDS) = representatives so far, by sorted
+// position.  Per tile of 64 candidates: (1) each wave takes 4 of them and looks for a hit among
 // the representatives of EARLIER tiles (lanes stride over the row's words, first hit = lowest
-// position); (2) wave 0 walks the 64 candidates in order using only the tile's diagonal words.
-__global__ __launch_bounds__(256) void cluster_greedy(const unsigned long long* __restrict__ bits, int m, int W,
+// position; the four rows' loads are issued together -- a single resident block has nothing else to
+// hide a global round trip behind: 911 -> 2xx us at 4096 poses); (2) wave 0 walks the 64 candidates
+// in order using only the tile's diagonal words.
+constexpr int kGreedyThreads = 1024;
+__global__ __launch_bounds__(kGreedyThreads) void cluster_greedy(const unsigned long long* __restrict__ bits, int m, int W,
                                                       const int* __restrict__ idx_sorted, int* __restrict__ rep_out,
                                                       int* __restrict__ assign, int* __restrict__ n_rep_out) {
   extern __shared__ unsigned long long keep[];  // W words
   __shared__ int pre[64];                       // first earlier-tile representative hit, or -1
   __shared__ int n_rep_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = kGreedyThreads / 64, PER = 64 / NW;   // 16 waves, 4 candidates each
   for (int w = threadIdx.x; w < W; w += blockDim.x) keep[w] = 0ull;
   if (threadIdx.x == 0) n_rep_s = 0;
   __syncthreads();
   for (int c0 = 0; c0 < m; c0 += 64) {
     const int wt = c0 >> 6;  // the tile's diagonal word; earlier tiles own words < wt
-    for (int j = wave; j < 64; j += 4) {
-      const int c = c0 + j;
-      int first = -1;
-      if (c < m) {
-        for (int wb = 0; wb < wt && first < 0; wb += 64) {
-          const int w = wb + lane;
-          const unsigned long long x = w < wt ? (bits[(size_t)c * W + w] & keep[w]) : 0ull;
-          const unsigned long long any = __ballot(x != 0ull);
-          if (any) {
-            const int src = __ffsll((long long)any) - 1;
-            const int pos = 64 * w + (__ffsll((long long)x) - 1);
-            first = __shfl(pos, src, 64);
-          }
-        }
+    int first[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) first[k] = -1;
+    for (int wb = 0; wb < wt; wb += 64) {
+      const int w = wb + lane;
+      unsigned long long x[PER];
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const int c = c0 + wave + NW * k;
+        x[k] = (c < m && w < wt && first[k] < 0) ? bits[(size_t)c * W + w] : 0ull;
       }
-      if (lane == 0) pre[j] = first;
+      const unsigned long long kp = w < wt ? keep[w] : 0ull;
+      bool all_found = true;
+#pragma unroll
+      for (int k = 0; k < PER; ++k) {
+        const unsigned long long xk = x[k] & kp;
+        const unsigned long long any = __ballot(xk != 0ull);
+        if (any && first[k] < 0) {
+          const int src = __ffsll((long long)any) - 1;
+          const int pos = 64 * w + (__ffsll((long long)xk) - 1);
+          first[k] = __shfl(pos, src, 64);
+        }
+        all_found &= first[k] >= 0 || c0 + wave + NW * k >= m;
+      }
+      if (all_found) break;
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) pre[wave + NW * k] = first[k];
     }
     __syncthreads();
     if (wave == 0) {
@@ -288,8 +305,12 @@ __global__ __launch_bounds__(256) void cluster_greedy(const unsigned long long* 
       int n_rep = n_rep_s;
       const int jn = m - c0 < 64 ? m - c0 : 64;
       for (int j = 0; j < jn; ++j) {
-        const unsigned long long dj = __shfl(diag, j, 64) & kw;
-        const int pj = __shfl(my_pre, j, 64);
+        // j is wave-uniform: v_readlane (a few cycles) instead of a cross-lane shuffle through the LDS
+        // crossbar (a dependent ~100-cycle trip, twice per step, 64 steps per tile)
+        const unsigned dlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag & 0xFFFFFFFFull), j);
+        const unsigned dhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(diag >> 32), j);
+        const unsigned long long dj = (((unsigned long long)dhi << 32) | dlo) & kw;
+        const int pj = __builtin_amdgcn_readlane(my_pre, j);
         int a;
         if (pj >= 0) {
           a = pj;
@@ -378,7 +399,7 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
   const Sym s = {sym[0], sym[1], sym[2]};
   hipLaunchKernelGGL(cluster_pair_bits, dim3(m), dim3(256), 0, st, inv_c, rot_r, m, W, s, prm->rot_thresh_deg,
                      prm->trans_thresh, bits);
-  hipLaunchKernelGGL(cluster_greedy, dim3(1), dim3(256), (size_t)W * 8, st, bits, m, W, idx_sorted, d_rep,
+  hipLaunchKernelGGL(cluster_greedy, dim3(1), dim3(kGreedyThreads), (size_t)W * 8, st, bits, m, W, idx_sorted, d_rep,
                      d_assign, d_cnt + 1);
   PGP_HIP(hipGetLastError());
   PGP_HIP(hipMemcpyAsync(h_n_rep, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));

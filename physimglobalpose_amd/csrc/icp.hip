@@ -111,61 +111,81 @@ __device__ __forceinline__ float row_xf(float a, float b, float c, float t, floa
 }
 
 // cyclic Jacobi on a symmetric 4x4 (double); returns the eigenvector of the largest eigenvalue.
-// A and V live in LDS: the rotation planes are indexed at run time, and run-time indexed
-// private arrays would be placed in scratch memory (cdna_hip_programming.md rule 20).
-__device__ void largest_eigvec4(double (*A)[4], double (*V)[4], double q[4]) {
+// The rotation planes (p, r) and the inner index are fully unrolled, so every A[..][..] / V[..][..] has
+// compile-time indices and the two matrices live in VGPRs (run-time indexed private arrays would go
+// to scratch, cdna_hip_programming.md rule 20; round 1 kept them in LDS, where the single working
+// lane paid an LDS round trip per element: ~60 of the 96 us of an icp_refine launch).  Same
+// operations in the same order as before (and as oracle/pgp_oracle.c jacobi_eig4).
+__device__ void largest_eigvec4(double (&A)[4][4], double q[4]) {
+  double V[4][4];
+#pragma unroll
   for (int p = 0; p < 4; ++p)
+#pragma unroll
     for (int r = 0; r < 4; ++r) V[p][r] = p == r ? 1.0 : 0.0;
   for (int sweep = 0; sweep < 16; ++sweep) {
     double off = 0.0;
+#pragma unroll
     for (int p = 0; p < 4; ++p)
+#pragma unroll
       for (int r = p + 1; r < 4; ++r) off += A[p][r] * A[p][r];
     if (off < 1e-300) break;
+#pragma unroll
     for (int p = 0; p < 3; ++p)
+#pragma unroll
       for (int r = p + 1; r < 4; ++r) {
-        double apr = A[p][r];
-        if (apr == 0.0) continue;
-        double theta = (A[r][r] - A[p][p]) / (2.0 * apr);
-        double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < 4; ++k) {  // A <- A J
-          double akp = A[k][p], akr = A[k][r];
-          A[k][p] = c * akp - s * akr;
-          A[k][r] = s * akp + c * akr;
-        }
-        for (int k = 0; k < 4; ++k) {  // A <- J^T A
-          double apk = A[p][k], ark = A[r][k];
-          A[p][k] = c * apk - s * ark;
-          A[r][k] = s * apk + c * ark;
-        }
-        for (int k = 0; k < 4; ++k) {
-          double vkp = V[k][p], vkr = V[k][r];
-          V[k][p] = c * vkp - s * vkr;
-          V[k][r] = s * vkp + c * vkr;
+        const double apr = A[p][r];
+        if (apr != 0.0) {
+          const double theta = (A[r][r] - A[p][p]) / (2.0 * apr);
+          const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+          const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // A <- A J
+            const double akp = A[k][p], akr = A[k][r];
+            A[k][p] = c * akp - sn * akr;
+            A[k][r] = sn * akp + c * akr;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {  // A <- J^T A
+            const double apk = A[p][k], ark = A[r][k];
+            A[p][k] = c * apk - sn * ark;
+            A[r][k] = sn * apk + c * ark;
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const double vkp = V[k][p], vkr = V[k][r];
+            V[k][p] = c * vkp - sn * vkr;
+            V[k][r] = sn * vkp + c * vkr;
+          }
         }
       }
   }
   int best = 0;
-  for (int k = 1; k < 4; ++k)
-    if (A[k][k] > A[best][best]) best = k;
-  for (int k = 0; k < 4; ++k) q[k] = V[k][best];
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const double ak = k == 1 ? A[1][1] : (k == 2 ? A[2][2] : A[3][3]);
+    const double ab = best == 0 ? A[0][0] : (best == 1 ? A[1][1] : (best == 2 ? A[2][2] : A[3][3]));
+    if (ak > ab) best = k;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) q[k] = best == 0 ? V[k][0] : (best == 1 ? V[k][1] : (best == 2 ? V[k][2] : V[k][3]));
 }
 
 // Horn's closed form from the f64 sums over the selected pairs:
 // red = {n, sx,sy,sz, mx,my,mz, Sxx,Sxy,Sxz, Syx,Syy,Syz, Szx,Szy,Szz}  (S_ab = sum s_a m_b)
-__device__ void solve_rigid(const double* red, float* G, double (*N)[4], double (*V)[4]) {
+__device__ void solve_rigid(const double* red, float* G) {
   double n = red[0];
   if (!(n >= 1.0)) return;  // nothing selected: keep G
   double sb[3] = {red[1] / n, red[2] / n, red[3] / n}, mb[3] = {red[4] / n, red[5] / n, red[6] / n};
   const double Sxx = red[7] - n * sb[0] * mb[0], Sxy = red[8] - n * sb[0] * mb[1], Sxz = red[9] - n * sb[0] * mb[2];
   const double Syx = red[10] - n * sb[1] * mb[0], Syy = red[11] - n * sb[1] * mb[1], Syz = red[12] - n * sb[1] * mb[2];
   const double Szx = red[13] - n * sb[2] * mb[0], Szy = red[14] - n * sb[2] * mb[1], Szz = red[15] - n * sb[2] * mb[2];
+  double N[4][4];
   N[0][0] = Sxx + Syy + Szz; N[0][1] = Syz - Szy;       N[0][2] = Szx - Sxz;        N[0][3] = Sxy - Syx;
   N[1][0] = Syz - Szy;       N[1][1] = Sxx - Syy - Szz; N[1][2] = Sxy + Syx;        N[1][3] = Szx + Sxz;
   N[2][0] = Szx - Sxz;       N[2][1] = Sxy + Syx;       N[2][2] = -Sxx + Syy - Szz; N[2][3] = Syz + Szy;
   N[3][0] = Sxy - Syx;       N[3][1] = Szx + Sxz;       N[3][2] = Syz + Szy;        N[3][3] = -Sxx - Syy + Szz;
   double q[4];
-  largest_eigvec4(N, V, q);
+  largest_eigvec4(N, q);
   double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (!(nq > 0.0)) return;
   double w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
@@ -324,7 +344,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
   __shared__ unsigned s_prefix, s_kleft, s_carry;
   __shared__ double s_energy, s_energy_old;
   __shared__ int s_continue;
-  __shared__ double s_N[4][4], s_V[4][4], s_sum[kRedPlane + 1];
+  __shared__ double s_sum[kRedPlane + 1];
+  __shared__ unsigned s_sel_bin, s_sel_acc;
   __shared__ float s_G_old[16];
 
   const int pose = blockIdx.x;
@@ -417,16 +438,40 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
           if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-          unsigned kleft = s_kleft, acc = 0;
-          int b = 0;
-          for (; b < 256; ++b) {
-            if (acc + s_hist[b] >= kleft) break;
-            acc += s_hist[b];
+        // the bin that holds the kleft-th element: inclusive scan of the 256 counts on 4 waves (the
+        // serial walk of thread 0 cost an LDS round trip per bin, four times per iteration)
+        unsigned hv = 0, incl = 0;
+        if (tid < 256) {
+          hv = s_hist[tid];
+          incl = hv;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
           }
-          if (b > 255) b = 255;
-          s_kleft = kleft - acc;
-          s_prefix = prefix | ((unsigned)b << shift);
+          if (lane == 63) s_scan[wave] = incl;
+        }
+        if (tid == 0) {
+          s_sel_bin = 255u;
+          s_sel_acc = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (tid < 256) {
+          unsigned woff = 0;
+          for (int w = 0; w < wave; ++w) woff += s_scan[w];
+          incl += woff;
+          const unsigned excl = incl - hv, kleft = s_kleft;
+          if (excl < kleft && kleft <= incl) {   // exactly one bin (counts are non-negative)
+            s_sel_bin = (unsigned)tid;
+            s_sel_acc = excl;
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned acc = s_sel_acc;
+          if (acc == 0xFFFFFFFFu) acc = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];   // rank beyond the population
+          s_kleft = s_kleft - acc;
+          s_prefix = prefix | (s_sel_bin << shift);
         }
         __syncthreads();
       }
@@ -506,9 +551,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     }
     // wave butterfly, then the 16 wave results through LDS (aliases the target tile: all reads of
     // the tile finished before the barrier after step 1)
+    // point-to-point uses the first 16 sums only (the branch is wave-uniform and folds away for k < 16)
 #pragma unroll
     for (int k = 0; k < kRedPlane; ++k)
-      for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+      if (k < 16 || a.metric == 1)
+        for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
     for (int off = 32; off >= 1; off >>= 1) e_acc += __shfl_xor(e_acc, off, 64);
     __syncthreads();
     if (lane == 0) {
@@ -516,12 +563,14 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
       s_red[wave * (kRedPlane + 1) + kRedPlane] = e_acc;
     }
     __syncthreads();
+    if (tid <= kRedPlane) {   // one thread per sum, waves added in order (as thread 0 did alone before)
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRedPlane + 1) + tid];
+      s_sum[tid] = v;
+    }
+    __syncthreads();
     if (tid == 0) {
-      for (int k = 0; k <= kRedPlane; ++k) {
-        double v = 0.0;
-        for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRedPlane + 1) + k];
-        s_sum[k] = v;
-      }
       const double* red = s_sum;
       // progress is judged on the mean squared distance of the selected pairs; with a fixed
       // trim count this is PCL's energy test (E/E_old), and it stays meaningful when a
@@ -530,7 +579,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
       // ---- 4. closed-form update, then the progress tests (PCL order: update first) ----------
       for (int k = 0; k < 16; ++k) s_G_old[k] = s_G[k];
       if (a.metric == 1) solve_plane(red, s_G);
-      else solve_rigid(red, s_G, s_N, s_V);
+      else solve_rigid(red, s_G);
       const double E_old = s_energy_old;
       s_energy = E;
       s_energy_old = E;
