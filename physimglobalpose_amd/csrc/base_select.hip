@@ -257,54 +257,59 @@ __device__ int draw_index(const float* __restrict__ w, int n, double u, double* 
   return r;
 }
 
-// distSegmentToSegment as TryQuadrilateral instantiates it (Vector3f points, double scalars)
+// Closest approach of the segments P(s) = p1 + s u and Q(t) = q1 + t v, s, t in [0, 1]: the parameters
+// are kept as fractions sN / sD and tN / tD of the 2 x 2 system's determinant and clamped edge by edge
+// (the classic closed form the reference's distSegmentToSegment follows, base.cc:81-148).  Arithmetic
+// as TryQuadrilateral instantiates it: float dot products widened to double, double fractions, the
+// invariants narrowed to float before the residual vector is formed.  Returns |w + s u - t v|.
 __device__ float seg_seg(V3 p1, V3 p2, V3 q1, V3 q2, double* invariant1, double* invariant2) {
-  const double kSmallNumber = 0.0001;
+  const double tiny = 0.0001;
   const V3 u = vsub(p2, p1), v = vsub(q2, q1), w = vsub(p1, q1);
-  const double a = dot(u, u), b = dot(u, v), c = dot(v, v), d = dot(u, w), e = dot(v, w);
-  const double f = a * c - b * b;
-  double s1 = 0.0, s2 = f, t1 = 0.0, t2 = f;
-  if (f < kSmallNumber) {
-    s1 = 0.0;
-    s2 = 1.0;
-    t1 = e;
-    t2 = c;
-  } else {
-    s1 = (b * e - c * d);
-    t1 = (a * e - b * d);
-    if (s1 < 0.0) {
-      s1 = 0.0;
-      t1 = e;
-      t2 = c;
-    } else if (s1 > s2) {
-      s1 = s2;
-      t1 = e + b;
-      t2 = c;
+  const double uu = dot(u, u), uv = dot(u, v), vv = dot(v, v), uw = dot(u, w), vw = dot(v, w);
+  const double det = uu * vv - uv * uv;
+  double sN, sD = det, tN, tD = det;
+  if (det < tiny) {            // (almost) parallel: pin s = 0 and project q-side only
+    sN = 0.0;
+    sD = 1.0;
+    tN = vw;
+    tD = vv;
+  } else {                      // interior solution of the unconstrained problem, then the s-edges
+    sN = uv * vw - vv * uw;
+    tN = uu * vw - uv * uw;
+    if (sN < 0.0) {
+      sN = 0.0;
+      tN = vw;
+      tD = vv;
+    } else if (sN > sD) {
+      sN = sD;
+      tN = vw + uv;
+      tD = vv;
     }
   }
-  if (t1 < 0.0) {
-    t1 = 0.0;
-    if (-d < 0.0) s1 = 0.0;
-    else if (-d > a) s1 = s2;
+  if (tN < 0.0) {               // t-edges: re-solve s on the edge t = 0 or t = 1
+    tN = 0.0;
+    const double m = -uw;
+    if (m < 0.0) sN = 0.0;
+    else if (m > uu) sN = sD;
     else {
-      s1 = -d;
-      s2 = a;
+      sN = m;
+      sD = uu;
     }
-  } else if (t1 > t2) {
-    t1 = t2;
-    if ((-d + b) < 0.0) s1 = 0;
-    else if ((-d + b) > a) s1 = s2;
+  } else if (tN > tD) {
+    tN = tD;
+    const double m = -uw + uv;
+    if (m < 0.0) sN = 0;
+    else if (m > uu) sN = sD;
     else {
-      s1 = (-d + b);
-      s2 = a;
+      sN = m;
+      sD = uu;
     }
   }
-  *invariant1 = (fabs(s1) < kSmallNumber ? 0.0 : s1 / s2);
-  *invariant2 = (fabs(t1) < kSmallNumber ? 0.0 : t1 / t2);
-  // (w + (invariant1 * u) - (invariant2 * v)).norm(): the double scalars are narrowed to float by Eigen
-  const float i1 = (float)*invariant1, i2 = (float)*invariant2;
-  const V3 r = {sub(add(w.x, mul(i1, u.x)), mul(i2, v.x)), sub(add(w.y, mul(i1, u.y)), mul(i2, v.y)),
-                sub(add(w.z, mul(i1, u.z)), mul(i2, v.z))};
+  *invariant1 = fabs(sN) < tiny ? 0.0 : sN / sD;
+  *invariant2 = fabs(tN) < tiny ? 0.0 : tN / tD;
+  const float fs = (float)*invariant1, ft = (float)*invariant2;   // Eigen narrows the double scalars
+  const V3 r = {sub(add(w.x, mul(fs, u.x)), mul(ft, v.x)), sub(add(w.y, mul(fs, u.y)), mul(ft, v.y)),
+                sub(add(w.z, mul(fs, u.z)), mul(ft, v.z))};
   return norm(r);
 }
 

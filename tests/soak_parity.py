@@ -47,9 +47,11 @@ def main():
         ties = len(P) != len(w.P_xyz)
         if not ties:                # with duplicates the NN id (hence normal / weight) may differ
             gate = float(rng.choice([10.0, 30.0, 60.0, 90.0]))
-            sw = sc.score(T, PGP_MODE_WEIGHTED, gate)[0]
-            swo, _, _ = orc.score_batch(T, delta, mode=1, gate_deg=gate, threads=threads)
+            sw, _, biw, bsw = sc.score(T, PGP_MODE_WEIGHTED, gate)
+            swo, biwo, _ = orc.score_batch(T, delta, mode=1, gate_deg=gate, threads=threads)
             assert np.allclose(sw, swo, rtol=0, atol=2e-6), f"weighted mismatch, seed {seed}"
+            # the returned best pose is the reference's, near-ties included (exact settlement on the device)
+            assert biw == biwo and (biw < 0 or abs(bsw - swo[biw]) <= 2e-6), f"weighted best mismatch, seed {seed}"
         n_cases += 1
         n_hyp += n_h
     print(f"fuzz ok: {n_cases} random cases, {n_hyp} hypotheses, {time.time() - t0:.0f} s, seeds {seed0}..{seed0 + n_cases - 1}")
