@@ -226,9 +226,33 @@ int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, 
     g->h = h;
     g->inv_h = 1.0f / h;
     g->reach = reach;
-    g->ox = mn[0] - pad;
-    g->oy = mn[1] - pad;
-    g->oz = mn[2] - pad;
+    // origin ON the lattice of pitch 1 / inv_h (GridDesc): cell 0 is lattice cell k0, at most 1.5 cells
+    // below mn - pad.  The scoring kernel then finds a cell as round(x * inv_h) - k0 with one fused
+    // multiply-add; that and floor((x - origin) * inv_h) differ by the rounding of `origin`, of h vs
+    // 1 / inv_h and of the products -- a few ulp of the coordinate, far inside `margin`.
+    const double k0d[3] = {floor((double)(mn[0] - pad) * g->inv_h), floor((double)(mn[1] - pad) * g->inv_h),
+                           floor((double)(mn[2] - pad) * g->inv_h)};
+    g->magic_ok = 1;
+    for (int k = 0; k < 3; ++k)
+      if (!(fabs(k0d[k]) < (double)((1 << 22) - 4 * kMaxDim))) g->magic_ok = 0;
+    if (g->magic_ok) {
+      g->k0x = (int)k0d[0];
+      g->k0y = (int)k0d[1];
+      g->k0z = (int)k0d[2];
+      g->ox = ((float)g->k0x - 0.5f) * h;
+      g->oy = ((float)g->k0y - 0.5f) * h;
+      g->oz = ((float)g->k0z - 0.5f) * h;
+      // h and 1 / inv_h differ in the last place: with a large lattice number the product can land
+      // above mn - pad by that much; one more cell of padding restores the invariant
+      if (!(g->ox <= mn[0] - pad)) { g->k0x -= 1; g->ox = ((float)g->k0x - 0.5f) * h; }
+      if (!(g->oy <= mn[1] - pad)) { g->k0y -= 1; g->oy = ((float)g->k0y - 0.5f) * h; }
+      if (!(g->oz <= mn[2] - pad)) { g->k0z -= 1; g->oz = ((float)g->k0z - 0.5f) * h; }
+    } else {
+      g->k0x = g->k0y = g->k0z = 0;
+      g->ox = mn[0] - pad;
+      g->oy = mn[1] - pad;
+      g->oz = mn[2] - pad;
+    }
     double nx = floor((double)(mx[0] - g->ox) / h) + r + 2;
     double ny = floor((double)(mx[1] - g->oy) / h) + r + 2;
     double nz = floor((double)(mx[2] - g->oz) / h) + r + 2;
@@ -324,7 +348,7 @@ int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float d
   uint32_t total = 0;
   PGP_HIP(hipMemcpyAsync(&total, start + n_cells, 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
-  if ((rc = ctx->d_cand.ensure(((size_t)total + 1) * sizeof(float4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_cand.ensure(((size_t)total + 1 + 256) * sizeof(float4))) != PGP_OK) return rc;
   PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
   if (nP > 0)
     hipLaunchKernelGGL(scatter_points<true>, dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(),

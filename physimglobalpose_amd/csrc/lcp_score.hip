@@ -13,9 +13,13 @@
 //                     10 % of a batch in chunks of 2 so that the launch ends on short workgroups)
 //   hypothesis      = wave-uniform: its 4x4 is read with scalar loads (one 64 B line) and lives
 //                     in SGPRs; the transform is 9 mul + 9 add per lane, no contraction
-//   inlier count    = __ballot + popcount per wave, 4 wave totals combined in LDS in fixed order,
-//                     one (tile, hypothesis) partial per block, summed by finalize_scores in tile
-//                     order => no atomics on the data path, bit-reproducible run to run
+//   cell look-up    = one v_fma per axis leaves the lattice cell in the mantissa (cell_bits), the block
+//                     coordinates are cut out with v_bfe: 9 VALU from position to word address
+//   inlier count    = __ballot + popcount per wave, packed per group of 4 hypotheses on the SCALAR unit;
+//                     weighted mode parks each lane's registered weight in LDS and reduces a group at
+//                     once; 4 wave totals combined in LDS in fixed order, one (tile, hypothesis) partial
+//                     per block, summed by finalize_scores in tile order => no atomics on the data
+//                     path, bit-reproducible run to run
 //   block -> (chunk, tile) is XCD-aware: blocks that share blockIdx%8 (one XCD, one L2) work on
 //                     the same hypothesis chunks, so the cells those poses touch stay in that L2.
 //
@@ -34,6 +38,7 @@
 
 #include <hip/hip_ext.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -49,8 +54,8 @@ struct Xf {  // one hypothesis, wave-uniform (SGPRs)
   float m00, m10, m20, m01, m11, m21, m02, m12, m22, m03, m13, m23;
 };
 
-__device__ __forceinline__ Xf load_xf(const float* __restrict__ T, int h) {
-  const float4* c = reinterpret_cast<const float4*>(T + 16 * (size_t)h);  // column-major 4x4
+__device__ __forceinline__ Xf load_xf(const float* __restrict__ T, uint32_t h) {
+  const float4* c = reinterpret_cast<const float4*>(T + 16u * h);   // < 2^28 hypotheses  // column-major 4x4
   float4 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
   Xf x;
   x.m00 = c0.x; x.m10 = c0.y; x.m20 = c0.z;
@@ -124,6 +129,49 @@ __device__ __forceinline__ int clamp0(int v, int hi_uniform) {
   int r;
   asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi_uniform));
   return r;
+}
+
+// ---- instruction selection for the scoring loop ------------------------------------------------------
+// Issue cost per wave64 instruction on gfx950, measured (tools/valu_rates.hip, profiles/r02_valu_rates.json):
+// ~2.5 cycles for v_add/sub/mul_f32, v_add_u32, v_and/or/xor, v_lshrrev, v_mov with VGPR operands; ~4.2
+// cycles for everything else that matters here (any VOP3: fma, mad24, med3, bfe, bcnt, lshl_or; cvt; cmp;
+// DPP; the packed-f32 ops; ANY op with an SGPR source) -- and ~23 cycles for v_cndmask_b32 in its VOP2 form
+// (implicit VCC), against 4.3 for the VOP3 form with the mask in an SGPR pair.  The helpers below keep
+// selects in the VOP3 form; wave-uniform per-hypothesis counts stay on the scalar unit.
+
+// mask bit of this lane ? a : b, as v_cndmask_b32_e64 with the mask in an SGPR pair
+__device__ __forceinline__ float sel_mask(unsigned long long m, float a, float b) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+__device__ __forceinline__ uint32_t sel_mask(unsigned long long m, uint32_t a, uint32_t b) {
+  uint32_t r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+  return r;
+}
+
+// Cell number of one coordinate in the low mantissa bits: t = x * inv_h + (1.5 * 2^23 - k0) is rounded ONCE,
+// to the integer round(x * inv_h) - k0 (+ 1.5 * 2^23) -- the exact nearest lattice cell, no float error at
+// all -- and its bit pattern is 0x4B400000 + cell.  Positive floats order like their bit patterns and
+// negative floats / NaN patterns are negative or huge integers, so ONE signed clamp of the bits does what
+// truncation + two-sided clamp did: two instructions per axis instead of four (subtract, scale, truncate,
+// clamp).  The clamp is to [0, n_max - 1] with n_max the LONGEST axis, the same two registers for all three
+// axes (a VOP3 instruction reads one SGPR; per-axis bounds would cost three more registers, and this kernel
+// sits on the 64-VGPR / 78-SGPR limits of 8 waves per SIMD): on a shorter axis a position beyond the grid
+// can therefore land up to n_max - n cells outside it, and the word index is limited once more
+// (v_min_u32).  Such a position ALIASES onto some word inside the array -- exact: whatever candidates the
+// word lists fail the reference's float distance test (a position outside the grid is farther than
+// delta from every scene point, choose_grid pads r + 1 cells; NaN fails every comparison).  Without
+// any clamp the look-up was as fast, but far-out positions scattered over the whole array (+40 % HBM
+// traffic, profiles/r02_pmc_noclamp.json).
+constexpr int kMagicBits = 0x4B400000;   // bit pattern of 1.5 * 2^23
+__device__ __forceinline__ uint32_t cell_bits(float x, float inv_h_vgpr, float c_uniform, int lo_vgpr, int hi_uniform) {
+  float t;
+  asm("v_fma_f32 %0, %1, %2, %3" : "=v"(t) : "v"(x), "v"(inv_h_vgpr), "s"(c_uniform));
+  int b;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(b) : "v"(__float_as_int(t)), "v"(lo_vgpr), "s"(hi_uniform));
+  return (uint32_t)b;
 }
 
 template <bool WAVE_SKIP = false>
@@ -213,8 +261,11 @@ struct ScoreArgs {
   int n_h, hpb, n_tiles, n_chunks;
   int n_big, hpb_tail;  // chunks [0, n_big) hold hpb hypotheses each, the rest hpb_tail (chunk_range)
   float sq_eps, gate_lo, gate_hi;
-  int* partial_cnt;     // [n_tiles][n_h]
-  float* partial_sum;   // [n_tiles][n_h] (weighted only)
+  float cell_c[3];      // 1.5 * 2^23 - k0 per axis (cell_bits)
+  uint32_t last_word;   // number of occupancy words - 1
+  int cell_hi;          // kMagicBits + (cells of the longest axis) - 1
+  uint2* partial;       // [n_tiles][n_h] {inlier count, bits of the weight sum (weighted only)}: ONE 8-byte
+                        // load per (tile, hypothesis) in finalize_scores
 };
 
 // Hypothesis range of a chunk.  The last chunks are smaller: workgroups are dispatched in block
@@ -299,13 +350,12 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
     int c = 0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; ++w) c += s_cnt[w][hh];
-    a.partial_cnt[(size_t)tile * a.n_h + h0 + hh] = c;
+    float f = 0.f;
     if (MODE == PGP_MODE_WEIGHTED) {
-      float f = 0.f;
 #pragma unroll
       for (int w = 0; w < kTile / 64; ++w) f += s_sum[w][hh];
-      a.partial_sum[(size_t)tile * a.n_h + h0 + hh] = f;
     }
+    a.partial[(size_t)tile * a.n_h + h0 + hh] = make_uint2((uint32_t)c, __float_as_uint(f));
   }
 }
 
@@ -353,9 +403,9 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
                                            const float4* ent, unsigned long long* res,
                                            const unsigned long long* marks, uint32_t start_key, uint32_t W,
                                            uint32_t w0, int lane, uint32_t le_lo, uint32_t le_hi) {
-  // a lane past the last slot resolves to the LAST owner and repeats its last candidate (valid
-  // owner, valid candidate); it is masked out of the result: no exec-mask branches in the batch
-  uint32_t we[NC];
+  // a lane past the last slot resolves to the LAST owner and reads on past its run (the candidate array
+  // is padded by 256 entries, grid_index.hip); it is masked out of the result: no exec-mask branches and
+  // no index clamp in the batch
   int o[NC];
   float4 en[NC], p[NC];
 #pragma unroll
@@ -364,12 +414,17 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
     const unsigned long long word = marks[wb >> 6];        // same address in every lane: one broadcast read
     const int before = __popcll(__ballot(start_key < wb)); // owners whose run starts before this chunk
     o[c] = before - 1 + __popc((uint32_t)word & le_lo) + __popc((uint32_t)(word >> 32) & le_hi);
-    we[c] = min(wb + lane, W - 1u);
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) en[c] = ent[o[c]];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) p[c] = cand[__float_as_uint(en[c].w) + we[c]];
+  for (int c = 0; c < NC; ++c) {
+#if defined(PGP_ABLATE) && PGP_ABLATE == 1
+    p[c] = cand[lane];            // timing experiment: one contiguous, always-cached 1 KB instead of the gather
+#else
+    p[c] = cand[__float_as_uint(en[c].w) + (w0 + 64 * c + lane)];
+#endif
+  }
   if (MODE == PGP_MODE_WEIGHTED) {
     // keep the 16-byte loads whole: the id (.w) is only used by lanes with an in-range candidate, and
     // the compiler otherwise narrows the load to 12 bytes and sinks a dependent 4-byte load of the id
@@ -380,7 +435,11 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     const float d2 = sqdist(en[c].x, en[c].y, en[c].z, p[c]);
+#if defined(PGP_ABLATE) && PGP_ABLATE == 3
+    if (d2 == -1.0f) {            // timing experiment: no result traffic
+#else
     if (w0 + 64 * c + lane < W && d2 <= a.sq_eps) {
+#endif
       if (MODE == PGP_MODE_PLAIN) {
         res[o[c]] = 1ull;  // benign race: every writer stores the same value
       } else {
@@ -390,15 +449,22 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
   }
 }
 
+// Hypotheses whose per-lane registered weights are parked in LDS before ONE reduction of the group
+// (weighted mode): a 64-lane DPP tree per hypothesis cost 12 VALU per wave-trip; four rows of 64 floats
+// are summed by 16 lanes each (4 sequential adds, then 4 DPP steps) for 9 VALU per FOUR trips.  (Eight rows
+// would halve that again, but their 8 KB push the workgroup past 20 KB of LDS = 7 workgroups per CU.)
+constexpr int kSumGroup = 4;
+
 // The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
 // with FOUR vector loads per hypothesis instead of scalar loads.
-template <int MODE>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat(ScoreArgs a, const float* __restrict__ Tm,
-                                                               const uint2* __restrict__ words,
-                                                               const uint2* __restrict__ occ_run,
-                                                               const float4* __restrict__ cand,
-                                                               const float4* __restrict__ Pnw) {
+template <int MODE, int NCW>   // NCW: widest batch (chunks of 64 slots) in weighted mode
+__device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float* __restrict__ Tm,
+                                                const uint2* __restrict__ words,
+                                                const uint2* __restrict__ occ_run,
+                                                const float4* __restrict__ cand,
+                                                const float4* __restrict__ Pnw) {
+  constexpr bool kW = MODE == PGP_MODE_WEIGHTED;
   __shared__ int s_cnt[kTile / 64][kMaxHpb];
   __shared__ float s_sum[kTile / 64][kMaxHpb];
   __shared__ float4 s_ent[kTile / 64][64];                 // {x', y', z', bits(run start - prefix)}
@@ -406,6 +472,8 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   // run-start bits of the wave's concatenated runs; 4 spare words: the last batch may look one
   // to three chunks past the end (they stay zero)
   __shared__ unsigned long long s_marks[kTile / 64][kFlatCap / 64 + 4];
+  __shared__ float s_w[kW ? kTile / 64 : 1][kW ? kSumGroup : 1][64];   // registered weight per (hypothesis, lane)
+  __shared__ float4 s_qn[kW ? kTile : 1];                                 // model normals of the tile
 
   const int L = blockIdx.x;
   const int xcd = L & 7, seq = L >> 3;
@@ -416,69 +484,102 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qi = tile * kTile + threadIdx.x;
   const bool live = qi < a.nQ;
-  // a lane past the end of the model carries a NaN point: it lands in cell 0 and can never pass
+  // a lane past the end of the model carries a NaN point: it lands in some cell and can never pass
   // `d2 <= eps`, so the loop needs no liveness test
   const float qnan = __int_as_float(0x7FC00000);
   float4 q = live ? a.Q[qi] : make_float4(qnan, qnan, qnan, 0.f);
-  float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (MODE == PGP_MODE_WEIGHTED && live) qn = a.Qn[qi];
+  // weighted mode: the model normal is needed once per trip with a neighbour; it waits in LDS (a linear,
+  // conflict-free 16-byte read) instead of holding three registers through the candidate phase
+  if (kW) s_qn[threadIdx.x] = live ? a.Qn[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
   float4* ent = s_ent[wave];
   unsigned long long* res = s_res[wave];
   unsigned long long* marks = s_marks[wave];
   if (lane < kFlatCap / 64 + 4) marks[lane] = 0ull;
   const unsigned long long le_mask = (2ull << lane) - 1ull;  // bits 0..lane (lane 63: all ones)
   const uint32_t le_lo = (uint32_t)le_mask, le_hi = (uint32_t)(le_mask >> 32);
+  const unsigned long long* words64 = reinterpret_cast<const unsigned long long*>(words);
+  const unsigned long long* run64 = reinterpret_cast<const unsigned long long*>(occ_run);
+  // wave-uniform constants of cell_bits that must sit in VGPRs (one SGPR per VOP3 instruction)
+  const float inv_h_v = a.g.inv_h;
+  const int cell_lo_v = kMagicBits;
 
   int h0, h1;
   chunk_range(a, chunk, &h0, &h1);
-  int my_cnt = 0;
-  float my_sum = 0.f;
-  // the hypothesis' 4x4 for the NEXT trip is requested (scalar loads) at the top of the current one, so
-  // that its latency runs under this trip's vector loads instead of in front of the next transform
-  Xf m_pre = load_xf(Tm, h0);
-  for (int h = h0; h < h1; ++h) {
-    const Xf m = m_pre;
-    m_pre = load_xf(Tm, min(h + 1, h1 - 1));
+  // Per group of kSumGroup hypotheses, on the scalar unit: the wave's inlier counts, one byte each (a count
+  // is <= 64), and which rows of s_w were written (a wave-iteration in which no lane has a neighbour writes
+  // nothing).  Scalar and vector instructions cost the SIMD the same ~4 issue cycles each here and add up
+  // (tools/valu_rates.hip; a wave-iteration with every cell empty takes (VALU + SALU) x 4 cycles), so the
+  // per-trip bookkeeping is kept to a handful of scalar instructions and off the empty path.
+  unsigned long long cnt_pack = 0ull;
+  uint32_t wrote = 0u;
+
+  // one hypothesis (slot hs = h - h0 of the chunk) under its 4x4 `m`
+  auto trip = [&](const int hs, const Xf& m) {
+    const int gs = hs & (kSumGroup - 1);   // slot in the group
+#if defined(PGP_ABLATE) && PGP_ABLATE == 7
+    // timing experiment: no transform (and the 8 KB of words of experiment 4)
+    const float x = q.x + m.m03, y = q.y + m.m13, z = q.z + m.m23;
+#else
     const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
     const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
     const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
-    uint32_t s, len;
-    cell_run<true>(a.g, words, occ_run, x, y, z, &s, &len);
+#endif
+    // cell -> occupancy word (blocked numbering, pgp_internal.h grid_word / grid_bit)
+    const uint32_t bx = cell_bits(x, inv_h_v, a.cell_c[0], cell_lo_v, a.cell_hi);
+    const uint32_t by = cell_bits(y, inv_h_v, a.cell_c[1], cell_lo_v, a.cell_hi);
+    const uint32_t bz = cell_bits(z, inv_h_v, a.cell_c[2], cell_lo_v, a.cell_hi);
+    const uint32_t brow = mad24(__builtin_amdgcn_ubfe(bz, 1, 9), (uint32_t)a.g.nby, __builtin_amdgcn_ubfe(by, 2, 8));
+    const uint32_t wi = min(mad24(brow, (uint32_t)a.g.nbx, __builtin_amdgcn_ubfe(bx, 2, 8)), a.last_word);
+#if defined(PGP_ABLATE) && (PGP_ABLATE == 4 || PGP_ABLATE == 7)
+    const unsigned long long wv = words64[wi & 1023u];   // timing experiment: occupancy words from 8 KB
+#elif defined(PGP_ABLATE) && PGP_ABLATE == 6
+    const unsigned long long wv = (unsigned long long)(wi >> 31);   // timing experiment: no word load (all empty)
+#elif defined(PGP_ABLATE) && PGP_ABLATE == 8
+    const unsigned long long wv = words64[wi] & ~0xFFFFFFFFull;    // timing experiment: real word load, all empty
+#else
+    const unsigned long long wv = words64[wi];
+#endif
+    const uint32_t lo = (uint32_t)wv, base = (uint32_t)(wv >> 32);
+    const uint32_t bit = (bx & 3u) | ((by & 3u) << 2) | ((bz & 1u) << 4);
+    // lanes whose cell holds a candidate run; the second look-up runs for those lanes only
+    const bool occ = __builtin_amdgcn_ubfe(lo, bit, 1) != 0u;
+    const unsigned long long am = __ballot(occ);
+    if (am == 0ull) return;   // 35 % of the wave-iterations at C2 end here: count 0, no row of s_w
+    uint32_t s = 0u, len = 0u;
+    if (occ) {
+      const uint32_t k = base + __popc(__builtin_amdgcn_ubfe(lo, 0, bit));
+      const unsigned long long rv = run64[k];  // {start, count}, count >= 1
+      s = (uint32_t)rv;
+      len = (uint32_t)(rv >> 32);
+    }
     // slot allocation in the concatenated run of the wave, in LANE order: an inclusive DPP scan of
     // the run lengths (no LDS); the total lands in an SGPR, so everything below branches scalar.
-    // Skipped when no lane owns a run (35 % of the wave-iterations at C2).
-    const unsigned long long am = __ballot(len > 0);
-    uint32_t pre = 0, W = 0;
-    if (am) {
-      const uint32_t incl = wave_inclusive_scan(len);
-      W = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-      pre = incl - len;
-    }
-    bool hit = false;
-    int nn_id = -1;
-    if (W == 0) {
-      // nothing to test in this wave-iteration
-    } else if (W <= (uint32_t)kFlatCap) {
-      const bool act = len > 0;
+    const uint32_t incl = wave_inclusive_scan(len);
+    const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);   // >= 1
+    const uint32_t pre = incl - len;
+    // result of the candidate phase per owner lane: plain 0 / 1, weighted the scene id of the nearest
+    // candidate within delta (all ones = -1: none)
+    uint32_t rlo = kW ? 0xFFFFFFFFu : 0u;
+    if (W <= (uint32_t)kFlatCap) {
       // owners are numbered in lane order = start order: # owning lanes below this one (v_mbcnt)
       const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-      if (act) {
+      if (occ) {
         // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
         ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
-        res[r] = MODE == PGP_MODE_PLAIN ? 0ull : ~0ull;
+        res[r] = kW ? ~0ull : 0ull;
         atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
       }
       __builtin_amdgcn_wave_barrier();
-      const uint32_t start_key = act ? pre : 0xFFFFFFFFu;
+      const uint32_t start_key = sel_mask(am, pre, 0xFFFFFFFFu);
       // batches of NC chunks of 64 slots: owner resolution, then ALL candidate loads, then tests.
       // Half of the non-empty wave-iterations need a single chunk (median W = 6 at C2), so the
       // batch width follows what is left instead of always issuing four chunks.
       for (uint32_t w0 = 0; w0 < W;) {
         const uint32_t left = W - w0;
-        if (MODE == PGP_MODE_PLAIN && left > 128) {
+        if (!kW && left > 128) {
           flat_batch<MODE, 4>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 256;
-        } else if (MODE == PGP_MODE_WEIGHTED && left > 128) {
+        } else if (kW && NCW >= 3 && left > 128) {
           flat_batch<MODE, 3>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 192;
         } else if (left > 64) {
@@ -491,39 +592,82 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
       }
       __builtin_amdgcn_wave_barrier();
       if ((uint32_t)lane < ((W + 63u) >> 6)) marks[lane] = 0ull;  // clear the bits for the next iteration
-      if (act) {
-        const unsigned long long rv = res[r];
-        if (MODE == PGP_MODE_PLAIN) hit = rv != 0ull;
-        else nn_id = rv == ~0ull ? -1 : (int)(unsigned)(rv & 0xFFFFFFFFull);
-      }
+      // the low word of the owner's result: plain 0 / 1; weighted the id of the minimum key, -1 if none
+      if (occ) rlo = reinterpret_cast<const uint32_t*>(res)[2 * r];
     } else {
       // oversized wave-iteration (very dense scene): per-lane walk
-      if (MODE == PGP_MODE_PLAIN) hit = any_in_run(cand, s, s + len, x, y, z, a.sq_eps);
-      else nn_id = nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
+      if (!kW) rlo = any_in_run(cand, s, s + len, x, y, z, a.sq_eps) ? 1u : 0u;
+      else rlo = (uint32_t)nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
     }
-    float wsum = 0.f;
-    if (MODE == PGP_MODE_WEIGHTED && nn_id >= 0) {
-      const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
-      const float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
-      const float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
-      const float4 pn = Pnw[nn_id];
-      const float dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
-      if (gate_ok(dot, a.gate_lo, a.gate_hi)) {
-        hit = true;
-        wsum = pn.w;
+    unsigned long long hm;   // lanes whose model point registers under this hypothesis
+    if (!kW) {
+      hm = __ballot(rlo != 0u);
+    } else {
+      const int nn_id = (int)rlo;
+      if (__ballot(nn_id >= 0) == 0ull) return;   // no lane has a neighbour within delta
+      float dot = 2.0f, pw = 0.0f;   // dot = 2 fails the gate
+#if defined(PGP_ABLATE) && PGP_ABLATE == 5
+      if (nn_id == -2) {        // timing experiment: no normal gate, no weight gather
+#else
+      if (nn_id >= 0) {
+#endif
+        const float4 pn = Pnw[nn_id];
+        const float4 qn = s_qn[threadIdx.x];
+        const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
+        const float ny = rot_row(m.m10, m.m11, m.m12, qn.x, qn.y, qn.z);
+        const float nz = rot_row(m.m20, m.m21, m.m22, qn.x, qn.y, qn.z);
+        dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
+        pw = pn.w;
       }
+      hm = __ballot(gate_ok(dot, a.gate_lo, a.gate_hi));
+      // this lane's registered weight (0 when it does not register), reduced once per group
+      s_w[wave][gs][lane] = sel_mask(hm, pw, 0.0f);
+      wrote |= 1u << gs;
     }
-    const unsigned long long mask = __ballot(hit);
-    if (MODE == PGP_MODE_WEIGHTED && mask) wsum = wave_sum(wsum);  // no hit in the wave: the sum is 0
-    // the wave's total for hypothesis h is parked in lane (h - h0): two selects instead of an
-    // exec-masked LDS write per hypothesis (hpb <= 64)
-    const bool mine = lane == h - h0;
-    my_cnt = mine ? __popcll(mask) : my_cnt;
-    if (MODE == PGP_MODE_WEIGHTED) my_sum = mine ? wsum : my_sum;
-  }
-  if (lane < h1 - h0) {
-    s_cnt[wave][lane] = my_cnt;
-    if (MODE == PGP_MODE_WEIGHTED) s_sum[wave][lane] = my_sum;
+    cnt_pack |= (unsigned long long)(uint32_t)__popcll(hm) << (8 * gs);
+  };
+
+  // after the last hypothesis of a group (slots g0s .. g0s + n - 1 of the chunk): lane 16k publishes slot k
+  auto publish = [&](const int g0s, const int n) {
+    int pl = lane;
+    asm volatile("" : "+v"(pl));   // the lane arithmetic is redone here, once per group, not held in registers
+    const int k = pl >> 4;
+    const bool pub = (pl & 15) == 0 && k < n;
+    if (pub) s_cnt[wave][g0s + k] = (int)((cnt_pack >> (8 * k)) & 0xFFull);
+    if (kW) {
+      // lanes 16k .. 16k+15 (one DPP row) sum row k of the group: 4 consecutive floats each, in order, then
+      // the four DPP steps that fold a row (xor 1, xor 2, half-row mirror, row mirror).  A FIXED association:
+      // same bits every run; the reference's own (sequential) order is restored for near-ties by
+      // finalize_scores.
+      float t = 0.0f;
+      if (wrote != 0u) {
+        __builtin_amdgcn_wave_barrier();
+        const float4 v0 = *reinterpret_cast<const float4*>(&s_w[wave][k][(pl & 15) * 4]);
+        t = __fadd_rn(__fadd_rn(__fadd_rn(v0.x, v0.y), v0.z), v0.w);
+        t = dpp_step<0xB1>(t);   // quad_perm [1,0,3,2]
+        t = dpp_step<0x4E>(t);   // quad_perm [2,3,0,1]
+        t = dpp_step<0x141>(t);  // row_half_mirror
+        t = dpp_step<0x140>(t);  // row_mirror
+        // a row nobody wrote holds an older group's values: its sum is 0
+        t = ((wrote >> k) & 1u) != 0u ? t : 0.0f;
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (pub) s_sum[wave][g0s + k] = t;
+    }
+    cnt_pack = 0ull;
+    wrote = 0u;
+  };
+
+  // the hypothesis' 4x4 for the NEXT trip is requested (scalar loads) at the top of the current one, so
+  // that its latency runs under this trip's vector loads instead of in front of the next transform.
+  // (Two trips per pass with a register set each -- no copies -- measured the same and cost 8 SGPRs.)
+  const int n_slots = h1 - h0;
+  Xf m_pre = load_xf(Tm, (uint32_t)h0);
+  for (int hs = 0; hs < n_slots; ++hs) {
+    const Xf m = m_pre;
+    m_pre = load_xf(Tm, (uint32_t)(h0 + min(hs + 1, n_slots - 1)));
+    trip(hs, m);
+    if (((hs & (kSumGroup - 1)) == kSumGroup - 1) || hs == n_slots - 1) publish(hs & ~(kSumGroup - 1), (hs & (kSumGroup - 1)) + 1);
   }
   __syncthreads();
   const int hh = threadIdx.x;
@@ -531,14 +675,23 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     int c = 0;
 #pragma unroll
     for (int w = 0; w < kTile / 64; ++w) c += s_cnt[w][hh];
-    a.partial_cnt[(size_t)tile * a.n_h + h0 + hh] = c;
-    if (MODE == PGP_MODE_WEIGHTED) {
-      float f = 0.f;
+    float f = 0.f;
+    if (kW) {
 #pragma unroll
       for (int w = 0; w < kTile / 64; ++w) f += s_sum[w][hh];
-      a.partial_sum[(size_t)tile * a.n_h + h0 + hh] = f;
     }
+    a.partial[(size_t)tile * a.n_h + h0 + hh] = make_uint2((uint32_t)c, __float_as_uint(f));
   }
+}
+
+// 8 waves per SIMD: 64 VGPRs, 78 SGPRs, 20 KB of LDS per workgroup.  All three limits were hit while this
+// kernel was shaped (tools/ab_step.sh A/B runs): a 7-wave build with 72 VGPRs is 6 %
+// slower, three-chunk weighted batches with spills 12 % slower, 8 KB more LDS = 7 workgroups per CU 7 %.
+template <int MODE>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat(
+    ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
+    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
+  score_flat_body<MODE, 3>(a, Tm, words, occ_run, cand, Pnw);
 }
 
 // One model point (Morton position i) under one transform: the scene id it registers to (after
@@ -782,8 +935,7 @@ __device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int
   }
 }
 
-__global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const int* __restrict__ partial_cnt,
-                                                       const float* __restrict__ partial_sum,
+__global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2* __restrict__ partial,
                                                        int n_tiles, int n_h, int nQ, int mode, int refine,
                                                        float* scores, int* __restrict__ counts,
                                                        unsigned long long* best_key, unsigned long long* runner_key,
@@ -794,9 +946,20 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const int* _
   if (h < n_h) {
     int c = 0;
     float f = 0.f;
-    for (int t = 0; t < n_tiles; ++t) {
-      c += partial_cnt[(size_t)t * n_h + h];
-      if (mode == PGP_MODE_WEIGHTED) f += partial_sum[(size_t)t * n_h + h];
+    // the partials were written by the kernel before this one, on every die: each load is a trip to the
+    // memory side, so sixteen tiles' loads are issued together and then added IN TILE ORDER (a dependent
+    // load-add chain took 20 round trips, ~9 of this kernel's 12 us at C2)
+    for (int t0 = 0; t0 < n_tiles; t0 += 16) {
+      uint2 pp[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pp[j] = partial[(size_t)min(t0 + j, n_tiles - 1) * n_h + h];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (t0 + j < n_tiles) {
+          c += (int)pp[j].x;
+          f += __uint_as_float(pp[j].y);
+        }
+      }
     }
     float score = (mode == PGP_MODE_PLAIN) ? __fdiv_rn((float)c, (float)nQ) : __fdiv_rn(f, (float)nQ);
     scores[h] = score;
@@ -938,7 +1101,9 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
                     hipEvent_t ev1) {
   // default by measurement at C2 (tools/tune.py): wave-flattened 112 us plain / 157 us weighted vs
   // per-lane walk (U = 2) 125 / 170 us
-  if (unroll <= 0) {  // wave-flattened candidate phase
+  // (a scene so far from the origin that its lattice numbers leave the mantissa trick's range takes the
+  // per-lane kernel, which finds cells by subtraction and truncation)
+  if (unroll <= 0 && a.g.magic_ok) {  // wave-flattened candidate phase
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T,
                             a.words, a.occ_run, a.cand, a.Pnw);
@@ -977,6 +1142,11 @@ int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
     ctx->gate_deg_cached = gate_deg;
   }
   a->g = ctx->grid;
+  a->cell_c[0] = 12582912.0f - (float)ctx->grid.k0x;
+  a->cell_c[1] = 12582912.0f - (float)ctx->grid.k0y;
+  a->cell_c[2] = 12582912.0f - (float)ctx->grid.k0z;
+  a->cell_hi = kMagicBits + std::max(ctx->grid.nx, std::max(ctx->grid.ny, ctx->grid.nz)) - 1;
+  a->last_word = (uint32_t)ctx->grid.nbx * (uint32_t)ctx->grid.nby * (uint32_t)ctx->grid.nbz - 1u;
   a->words = ctx->d_bitmap.as<uint2>();
   a->occ_run = ctx->d_occ_start.as<uint2>();
   a->cand = ctx->d_cand.as<float4>();
@@ -1064,8 +1234,7 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     a.n_big = (n_h - n_tail_h) / hpb;
     n_tail_h = n_h - a.n_big * hpb;
     a.n_chunks = a.n_big + (n_tail_h + a.hpb_tail - 1) / a.hpb_tail;
-    a.partial_cnt = ctx->d_partial.as<int>();
-    a.partial_sum = reinterpret_cast<float*>(a.partial_cnt + (size_t)a.n_tiles * ctx->cap_h);
+    a.partial = ctx->d_partial.as<uint2>();
     int chunks_pad = (a.n_chunks + 7) / 8 * 8;
     dim3 grid((unsigned)(chunks_pad * a.n_tiles));
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1083,7 +1252,7 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     }
     launch_variant(mode, ctx->unroll, grid, stream, a, ev0, ev1);
     hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream, a,
-                       (const int*)a.partial_cnt, (const float*)a.partial_sum, a.n_tiles, n_h, a.nQ,
+                       (const uint2*)a.partial, a.n_tiles, n_h, a.nQ,
                        mode, ctx->refine_best ? 1 : 0, d_scores, d_counts, key, key + 3, ticket,
                        d_best ? d_best : best_local, ctx->d_seq.as<float>());
   } else {

@@ -23,10 +23,16 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 // Uniform grid over the (centred) scene cloud.  cell(x) = floor((x - origin) * inv_h).
+// The origin lies on the lattice of pitch 1 / inv_h: origin = (k0 - 0.5) / inv_h, so that the cell is also
+// round_to_nearest(x * inv_h) - k0 -- ONE fused multiply-add against the constant 1.5 * 2^23 - k0 leaves
+// the cell number in the low mantissa bits (lcp_score.hip cell_bits); the two statements differ by float
+// rounding only, which the dilation margin of the candidate lists covers (grid_index.hip choose_grid).
 struct GridDesc {
   float ox, oy, oz;   // origin (min corner of cell (0,0,0))
   float h, inv_h;     // cell edge (>= delta) and its float reciprocal
   int nx, ny, nz;     // cells per axis
+  int k0x, k0y, k0z;  // lattice number of cell 0 per axis
+  int magic_ok;       // |k0| small enough for the mantissa trick (else the scoring falls back to cell_run)
   // Cells are numbered in BLOCKS of 4 x 4 x 2 (x, y, z) = 32 cells = one occupancy word, blocks in
   // (z, y, x) order: a compact patch of query points then touches few words, few run descriptors
   // and neighbouring candidate runs -- the vector L1 counts distinct lines per instruction.
