@@ -35,9 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# the same guide: 256 CUs x 4 SIMD-32, a wave64 VALU instruction issues over 2 cycles at 2.4 GHz
-# (tools/peaks.hip measured 1096-1108 G/s for v_add/v_mul_f32 at 8 waves per SIMD)
-VALU_PEAK_GINSTR = 256 * 4 * 2.4 / 2.0
+# 256 CUs x 4 SIMDs at 2.4 GHz.  Issue cost per wave64 instruction, measured with inline asm at 8 waves per
+# SIMD (tools/valu_rates.hip -> profiles/r02_valu_rates.json): 2.5 cycles for the simple VOP2 ops on
+# registers, 4.2 for everything else, 4.4 for packed / 64-bit ops, 4.2 for a scalar instruction.  (Round 2
+# first priced every VALU op at 2 cycles: tools/peaks.hip's "v_add_f32" loop had been compiled to
+# v_pk_add_f32, two adds per instruction.)
+N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
+VALU_CYCLES_DEFAULT = 4.0   # used only if the counters file carries no static mix of the kernel
+SALU_CYCLES = 4.2
 # vector L1 (TCP) tag look-ups, in the unit of the TCP_TOTAL_CACHE_ACCESSES counter: highest rate
 # tools/peaks.hip reaches with L1-resident data, 8-byte loads with every lane in its own line (the
 # shape of the kernel's word / run-descriptor loads): 18.93 G instr/s x 40 look-ups = 757 G/s (16-byte
@@ -96,9 +101,22 @@ def roofline_block(mode, n_h, kern_avg_ms, launches):
         return out
     units = {}
     if c.get("SQ_INSTS_VALU"):
+        # a wave64 VALU instruction occupies its SIMD for 2.5 .. 4.4 cycles depending on its class
+        # (tools/valu_rates.hip); the kernel's own static mix (tools/valu_mix.py, stored with the counters)
+        # gives the average, the counter the number of instructions
+        mix = (pmc.get("valu_mix") or {}).get(kname) or {}
+        cyc = mix.get("avg_cycles_per_valu") or VALU_CYCLES_DEFAULT
+        peak = N_SIMD * CLOCK_GHZ / cyc
         a = c["SQ_INSTS_VALU"] / t / 1e9
-        units["valu_issue"] = {"achieved": a, "peak": VALU_PEAK_GINSTR, "unit": "G wave-instr/s", "frac": a / VALU_PEAK_GINSTR,
-                               "per_launch": c["SQ_INSTS_VALU"]}
+        units["valu_issue"] = {"achieved": a, "peak": peak, "unit": "G wave-instr/s", "frac": a / peak,
+                               "per_launch": c["SQ_INSTS_VALU"], "avg_cycles_per_instr": cyc,
+                               "classes_static": mix.get("classes")}
+    if c.get("SQ_INSTS_SALU"):
+        # one scalar instruction per ~4.2 cycles per SIMD (tools/valu_rates.hip, s_add_u32 at 8 waves)
+        peak = N_SIMD * CLOCK_GHZ / SALU_CYCLES
+        a = c["SQ_INSTS_SALU"] / t / 1e9
+        units["salu_issue"] = {"achieved": a, "peak": peak, "unit": "G wave-instr/s", "frac": a / peak,
+                               "per_launch": c["SQ_INSTS_SALU"]}
     if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
         a = c["TCP_TOTAL_CACHE_ACCESSES_sum"] / t / 1e9
         units["vector_l1"] = {"achieved": a, "peak": L1_PEAK_GLINES, "unit": "G tag look-ups/s", "frac": a / L1_PEAK_GLINES,

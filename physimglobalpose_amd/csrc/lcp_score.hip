@@ -403,10 +403,12 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
                                            const float4* ent, unsigned long long* res,
                                            const unsigned long long* marks, uint32_t start_key, uint32_t W,
                                            uint32_t w0, int lane, uint32_t le_lo, uint32_t le_hi) {
-  // a lane past the last slot resolves to the LAST owner and reads on past its run (the candidate array
-  // is padded by 256 entries, grid_index.hip); it is masked out of the result: no exec-mask branches and
-  // no index clamp in the batch
+  // a lane past the last slot resolves to the LAST owner and repeats its last candidate (valid owner, valid
+  // candidate, the SAME cache line); it is masked out of the result: no exec-mask branches in the batch.
+  // (Letting those lanes read on past the run saved the clamp and cost 33 % more HBM traffic: a wave-
+  // iteration with 6 slots then touched a whole KB of lines nobody needs, profiles/r02_pmc_noclamp.json.)
   int o[NC];
+  uint32_t we[NC];
   float4 en[NC], p[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
@@ -414,6 +416,7 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
     const unsigned long long word = marks[wb >> 6];        // same address in every lane: one broadcast read
     const int before = __popcll(__ballot(start_key < wb)); // owners whose run starts before this chunk
     o[c] = before - 1 + __popc((uint32_t)word & le_lo) + __popc((uint32_t)(word >> 32) & le_hi);
+    we[c] = min(wb + lane, W - 1u);
   }
 #pragma unroll
   for (int c = 0; c < NC; ++c) en[c] = ent[o[c]];
@@ -422,7 +425,7 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
 #if defined(PGP_ABLATE) && PGP_ABLATE == 1
     p[c] = cand[lane];            // timing experiment: one contiguous, always-cached 1 KB instead of the gather
 #else
-    p[c] = cand[__float_as_uint(en[c].w) + (w0 + 64 * c + lane)];
+    p[c] = cand[__float_as_uint(en[c].w) + we[c]];
 #endif
   }
   if (MODE == PGP_MODE_WEIGHTED) {
@@ -682,6 +685,12 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     }
     a.partial[(size_t)tile * a.n_h + h0 + hh] = make_uint2((uint32_t)c, __float_as_uint(f));
   }
+#if defined(PGP_ABLATE) && PGP_ABLATE == 9
+  // timing experiment: what a per-block agent-scope release + ticket would cost (fused finalize)
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned int*>(a.partial) + 2 * chunk + 1, 1u);
+#endif
 }
 
 // 8 waves per SIMD: 64 VGPRs, 78 SGPRs, 20 KB of LDS per workgroup.  All three limits were hit while this

@@ -31,9 +31,13 @@ done
 if [ -x /tmp/peaks ]; then
   rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_peaks -- /tmp/peaks > $OUT/peaks_under_pmc.json 2> $OUT/pmc_peaks.err
 fi
+# static VALU mix of the kernels as built (tools/valu_mix.py prices the VALU unit with it)
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math --cuda-device-only \
+  -S $REPO/physimglobalpose_amd/csrc/lcp_score.hip -o $OUT/lcp_score.s 2> $OUT/lcp_score_s.err
 python3 - "$OUT" "$REPO" <<'PY'
 import csv, glob, sys, collections, json, re, hashlib, os, datetime
 out, repo = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.join(repo, "tools"))
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
@@ -48,7 +52,14 @@ for k, d in agg.items():
 h = hashlib.sha256()
 for f in ("lcp_score.hip", "grid_index.hip", "pgp_internal.h"):
     h.update(open(os.path.join(repo, "physimglobalpose_amd", "csrc", f), "rb").read())
-doc = {"source_id": h.hexdigest()[:16], "collected": datetime.date.today().isoformat(),
+try:
+    import valu_mix
+    text = open(out + "/lcp_score.s").read()
+    mix = {"score_hypotheses_flat<0>": valu_mix.kernel_mix(text, "score_hypotheses_flatILi0E"),
+           "score_hypotheses_flat<1>": valu_mix.kernel_mix(text, "score_hypotheses_flatILi1E")}
+except Exception as e:   # the counters are still worth keeping
+    mix = {"error": repr(e)}
+doc = {"source_id": h.hexdigest()[:16], "collected": datetime.date.today().isoformat(), "valu_mix": mix,
        "how": "tools/collect_pmc.sh: rocprofv3 --pmc <group> --kernel-trace, one group per pass, over "
               "`python3 bench.py --mode <mode> --steps 20 --warmup 3 --no-cpu-baseline` (C2, 8 distinct batches "
               "in rotation); values are averages per launch; FETCH_SIZE / WRITE_SIZE in KB",
