@@ -308,6 +308,12 @@ def other_rows(sc, w, torch, mode_name, d_batches):
     Kc = np.array([[614.0, 0, 322.5], [0, 614.0, 239.7], [0, 0, 1]], np.float32)
     dt6, cloud = timed(lambda: sc.backproject_depth(raw, Kc, msk))
     out["backproject"] = {"pixels": 640 * 480, "points": int(len(cloud)), "ms_per_call": dt6 * 1e3}
+    # the segment's own pre-processing (Segmentation.cpp:234-246): 1 cm voxel grid, then MLS normals at 2 cm
+    seg_in = np.ascontiguousarray(w.P_xyz[:20000])
+    dt7, seg = timed(lambda: sc.voxel_grid(seg_in, 0.01))
+    dt8, mls = timed(lambda: sc.mls_normals(seg, 0.02))
+    out["segment_preprocess"] = {"points_in": int(len(seg_in)), "voxel_leaves": int(len(seg)), "voxel_grid_ms": dt7 * 1e3,
+                                 "mls_points_out": int(len(mls[3])), "mls_ms": dt8 * 1e3}
     # greedy clustering of the C2 batch by its own weighted scores (all 4096 admitted: fraction 0)
     Tc = w.T[:N_HYP]
     sw, _, _, bs = sc.score(Tc, PGP_MODE_WEIGHTED, w.gate_deg)

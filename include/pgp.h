@@ -16,7 +16,11 @@
  * Every function returns 0 on success or a negative PGP_E* code; pgp_last_error() then holds a
  * message for the calling thread.  A context is bound to one HIP device; calls on one context
  * must not overlap (the reference is single-threaded: main.cpp:212), distinct contexts are
- * independent.  There is NO CPU fallback: without a usable HIP device pgp_create() fails.
+ * independent.  The *_device entry points queue their kernels on the caller's stream and return; a
+ * context serves ONE such stream at a time (its workspaces are shared), and any later call on the
+ * context -- pgp_set_model, pgp_set_scene, a host-pointer scoring call ... -- is ordered behind the
+ * queued work by an event, so the arrays a queued kernel reads are never rewritten under it.
+ * There is NO CPU fallback: without a usable HIP device pgp_create() fails.
  */
 #ifndef PGP_H
 #define PGP_H
@@ -346,6 +350,22 @@ int pgp_set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, c
 int pgp_voxel_grid(pgp_ctx* ctx, const float* xyz, int n, float leaf, float* out_xyz, int cap, int* n_out);
 int pgp_voxel_grid_device(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, float* d_out_xyz, int cap,
                           int* n_out, void* stream);
+
+/* Replaces pcl::MovingLeastSquares<PointXYZRGB, PointXYZRGBNormal> as PPE/segmentation/Segmentation.cpp:
+ * 239-246 configures it: setComputeNormals(true), setPolynomialFit(true) (order 2), setSearchRadius(radius =
+ * 0.02), kd-tree radius search, no upsampling -- the step that gives the (voxel-gridded) segment its normals.
+ * PCL is not vendored: PCL 1.7's published computeMLSPointNormal, in double where PCL uses double
+ * (csrc/mls.hip lists the steps).  A point with fewer than 3 neighbours inside the radius (itself included)
+ * is dropped, as performProcessing does; with fewer than 6 it keeps the plane's projection and normal.
+ * Outputs, in input order, min(*n_out, cap) rows: out_xyz the smoothed positions, out_nrm (nullable) the
+ * normals -- NOT re-normalised and not oriented, as PCL 1.7 leaves them (the node normalises and flips them
+ * towards the camera afterwards, ObjectPoseCandidateSet.cpp:39-51 = pgp_radius_outlier_filter) --,
+ * out_curvature (nullable) = |lambda_min / trace|, out_index (nullable) the input index of each row.
+ * Host pointers, synchronous; the _device form takes device arrays and synchronises `stream` for the count. */
+int pgp_mls_normals(pgp_ctx* ctx, const float* xyz, int n, float radius, float* out_xyz, float* out_nrm,
+                    float* out_curvature, int* out_index, int cap, int* n_out);
+int pgp_mls_normals_device(pgp_ctx* ctx, const float* d_xyz, int n, float radius, float* d_out_xyz, float* d_out_nrm,
+                           float* d_out_curvature, int* d_out_index, int cap, int* n_out, void* stream);
 
 /* Replaces Match4PCSBase::c_dist_pose and c_dist_pose_mean (S4/algorithms/match4pcsBase.cc:1616-1655)
  * for m pairs of poses: hull_xyz[n_hull][3] = hull_Q_3D (<= 4096 points), T[n_poses][16] =

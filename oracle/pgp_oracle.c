@@ -1153,3 +1153,186 @@ int orc_max_threads(void) {
   return 1;
 #endif
 }
+
+/* ---- moving least squares (pcl::MovingLeastSquares as PPE/segmentation/Segmentation.cpp:239-246 sets it up) ----
+ * PCL is not vendored: PCL 1.7's published MovingLeastSquares::computeMLSPointNormal (polynomial fit of
+ * order 2, no upsampling, normals on), pcl::eigen33 / computeRoots, Eigen's unitOrthogonal and LLT, restated
+ * step by step in double where PCL uses double.  Neighbours: brute force, squared distance in float (x, y, z
+ * order) STRICTLY below (float)(radius^2) as FLANN's radius search, visited in index order (PCL: by
+ * distance; the double sums differ in their last bits).  Points with fewer than 3 neighbours are dropped. */
+static void mls_roots2(double b, double c, double r[3]) {
+  r[0] = 0.0;
+  double d = b * b - 4.0 * c;
+  if (d < 0.0) d = 0.0;
+  double sd = sqrt(d);
+  r[2] = 0.5 * (b + sd);
+  r[1] = 0.5 * (b - sd);
+}
+
+static void mls_roots3(const double m[6], double r[3]) { /* m = {xx, xy, xz, yy, yz, zz} */
+  double c0 = m[0] * m[3] * m[5] + 2.0 * m[1] * m[2] * m[4] - m[0] * m[4] * m[4] - m[3] * m[2] * m[2] - m[5] * m[1] * m[1];
+  double c1 = m[0] * m[3] - m[1] * m[1] + m[0] * m[5] - m[2] * m[2] + m[3] * m[5] - m[4] * m[4];
+  double c2 = m[0] + m[3] + m[5];
+  if (fabs(c0) < DBL_EPSILON) {
+    mls_roots2(c2, c1, r);
+    return;
+  }
+  const double s_inv3 = 1.0 / 3.0, s_sqrt3 = sqrt(3.0);
+  double c2_over_3 = c2 * s_inv3;
+  double a_over_3 = (c1 - c2 * c2_over_3) * s_inv3;
+  if (a_over_3 > 0.0) a_over_3 = 0.0;
+  double half_b = 0.5 * (c0 + c2_over_3 * (2.0 * c2_over_3 * c2_over_3 - c1));
+  double q = half_b * half_b + a_over_3 * a_over_3 * a_over_3;
+  if (q > 0.0) q = 0.0;
+  double rho = sqrt(-a_over_3);
+  double theta = atan2(sqrt(-q), half_b) * s_inv3;
+  double ct = cos(theta), st = sin(theta);
+  r[0] = c2_over_3 + 2.0 * rho * ct;
+  r[1] = c2_over_3 - rho * (ct + s_sqrt3 * st);
+  r[2] = c2_over_3 - rho * (ct - s_sqrt3 * st);
+  if (r[0] >= r[1]) { double t = r[0]; r[0] = r[1]; r[1] = t; }
+  if (r[1] >= r[2]) {
+    double t = r[1]; r[1] = r[2]; r[2] = t;
+    if (r[0] >= r[1]) { double u = r[0]; r[0] = r[1]; r[1] = u; }
+  }
+  if (r[0] <= 0.0) mls_roots2(c2, c1, r);
+}
+
+static void mls_eigen33(const double cov[6], double* eval, double evec[3]) {
+  double scale = 0.0, m[6], r[3];
+  for (int k = 0; k < 6; ++k) scale = fmax(scale, fabs(cov[k]));
+  if (scale <= DBL_MIN) scale = 1.0;
+  for (int k = 0; k < 6; ++k) m[k] = cov[k] / scale;
+  mls_roots3(m, r);
+  *eval = r[0] * scale;
+  double r0[3] = {m[0] - r[0], m[1], m[2]}, r1[3] = {m[1], m[3] - r[0], m[4]}, r2[3] = {m[2], m[4], m[5] - r[0]};
+  double v1[3] = {r0[1] * r1[2] - r0[2] * r1[1], r0[2] * r1[0] - r0[0] * r1[2], r0[0] * r1[1] - r0[1] * r1[0]};
+  double v2[3] = {r0[1] * r2[2] - r0[2] * r2[1], r0[2] * r2[0] - r0[0] * r2[2], r0[0] * r2[1] - r0[1] * r2[0]};
+  double v3[3] = {r1[1] * r2[2] - r1[2] * r2[1], r1[2] * r2[0] - r1[0] * r2[2], r1[0] * r2[1] - r1[1] * r2[0]};
+  double l1 = v1[0] * v1[0] + v1[1] * v1[1] + v1[2] * v1[2], l2 = v2[0] * v2[0] + v2[1] * v2[1] + v2[2] * v2[2],
+         l3 = v3[0] * v3[0] + v3[1] * v3[1] + v3[2] * v3[2];
+  const double* v = v3;
+  double l = l3;
+  if (l1 >= l2 && l1 >= l3) { v = v1; l = l1; }
+  else if (l2 >= l1 && l2 >= l3) { v = v2; l = l2; }
+  double s = sqrt(l);
+  for (int k = 0; k < 3; ++k) evec[k] = v[k] / s;
+}
+
+static void mls_unit_orthogonal(const double n[3], double o[3]) {
+  const double prec = 1e-12;
+  int x_small = fabs(n[0]) <= fabs(n[2]) * prec, y_small = fabs(n[1]) <= fabs(n[2]) * prec;
+  if (!x_small || !y_small) {
+    double inv = 1.0 / sqrt(n[0] * n[0] + n[1] * n[1]);
+    o[0] = -n[1] * inv; o[1] = n[0] * inv; o[2] = 0.0;
+  } else {
+    double inv = 1.0 / sqrt(n[1] * n[1] + n[2] * n[2]);
+    o[0] = 0.0; o[1] = -n[2] * inv; o[2] = n[1] * inv;
+  }
+}
+
+static void mls_llt6(double A[6][6], double b[6]) {
+  for (int j = 0; j < 6; ++j) {
+    double d = A[j][j];
+    for (int k = 0; k < j; ++k) d -= A[j][k] * A[j][k];
+    double l = sqrt(d);
+    A[j][j] = l;
+    for (int i = j + 1; i < 6; ++i) {
+      double s = A[i][j];
+      for (int k = 0; k < j; ++k) s -= A[i][k] * A[j][k];
+      A[i][j] = s / l;
+    }
+  }
+  for (int i = 0; i < 6; ++i) {
+    double s = b[i];
+    for (int k = 0; k < i; ++k) s -= A[i][k] * b[k];
+    b[i] = s / A[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = b[i];
+    for (int k = i + 1; k < 6; ++k) s -= A[k][i] * b[k];
+    b[i] = s / A[i][i];
+  }
+}
+
+int orc_mls(const float* xyz, int n, float radius, float* out_xyz, float* out_nrm, float* out_curv, int* out_idx,
+            int cap) {
+  const float r2 = (float)((double)radius * (double)radius);
+  const double gauss = (double)radius * (double)radius;
+  int* nb = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * (size_t)i;
+    if (!(isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]))) continue;
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) {
+      const float* q = xyz + 3 * (size_t)j;
+      float dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
+      float d2 = (dx * dx + dy * dy) + dz * dz;
+      if (d2 < r2) nb[cnt++] = j;
+    }
+    if (cnt < 3) continue;
+    double sx = 0, sy = 0, sz = 0;
+    for (int k = 0; k < cnt; ++k) {
+      const float* q = xyz + 3 * (size_t)nb[k];
+      sx += (double)q[0]; sy += (double)q[1]; sz += (double)q[2];
+    }
+    double mx = sx / cnt, my = sy / cnt, mz = sz / cnt;
+    double cov[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < cnt; ++k) {
+      const float* q = xyz + 3 * (size_t)nb[k];
+      double dx = (double)q[0] - mx, dy = (double)q[1] - my, dz = (double)q[2] - mz;
+      cov[0] += dx * dx; cov[1] += dx * dy; cov[2] += dx * dz; cov[3] += dy * dy; cov[4] += dy * dz; cov[5] += dz * dz;
+    }
+    double eval, nr[3];
+    mls_eigen33(cov, &eval, nr);
+    double dpl = -(nr[0] * mx + nr[1] * my + nr[2] * mz);
+    double pt[3] = {(double)p[0], (double)p[1], (double)p[2]};
+    double dist = pt[0] * nr[0] + pt[1] * nr[1] + pt[2] * nr[2] + dpl;
+    for (int k = 0; k < 3; ++k) pt[k] -= dist * nr[k];
+    float curv = (float)(cov[0] + cov[3] + cov[5]);
+    if (curv != 0.f) curv = fabsf((float)(eval / (double)curv));
+    double on[3] = {nr[0], nr[1], nr[2]};
+    if (cnt >= 6) {
+      double va[3], ua[3], A[6][6], b[6];
+      mls_unit_orthogonal(nr, va);
+      ua[0] = nr[1] * va[2] - nr[2] * va[1];
+      ua[1] = nr[2] * va[0] - nr[0] * va[2];
+      ua[2] = nr[0] * va[1] - nr[1] * va[0];
+      memset(A, 0, sizeof(A));
+      memset(b, 0, sizeof(b));
+      for (int k = 0; k < cnt; ++k) {
+        const float* q = xyz + 3 * (size_t)nb[k];
+        double dx = (double)q[0] - pt[0], dy = (double)q[1] - pt[1], dz = (double)q[2] - pt[2];
+        float sqr = (float)(dx * dx + dy * dy + dz * dz);
+        double w = exp(-(double)sqr / gauss);
+        double u = dx * ua[0] + dy * ua[1] + dz * ua[2], v = dx * va[0] + dy * va[1] + dz * va[2];
+        double f = dx * nr[0] + dy * nr[1] + dz * nr[2];
+        double t[6] = {1.0, v, v * v, u, u * v, u * u};
+        for (int r = 0; r < 6; ++r) {
+          double wr = w * t[r];
+          b[r] += wr * f;
+          for (int c = 0; c <= r; ++c) A[r][c] += wr * t[c];
+        }
+      }
+      mls_llt6(A, b);
+      if (isfinite(b[0])) {
+        for (int k = 0; k < 3; ++k) {
+          pt[k] += b[0] * nr[k];
+          on[k] = nr[k] - b[3] * ua[k] - b[1] * va[k];
+        }
+      }
+    }
+    if (m < cap) {
+      for (int k = 0; k < 3; ++k) {
+        out_xyz[3 * (size_t)m + k] = (float)pt[k];
+        if (out_nrm) out_nrm[3 * (size_t)m + k] = (float)on[k];
+      }
+      if (out_curv) out_curv[m] = curv;
+      if (out_idx) out_idx[m] = i;
+    }
+    ++m;
+  }
+  free(nb);
+  return m;
+}

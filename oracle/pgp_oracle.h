@@ -153,6 +153,12 @@ int orc_backproject(const void* image, int raw16, const unsigned char* mask, int
 /* pcl::VoxelGrid as Segmentation.cpp:234-237 sets it up (published PCL 1.7 algorithm; points of a
  * voxel are added in index order): centroids in ascending voxel index; returns their number. */
 int orc_voxel_grid(const float* xyz, int n, float leaf, float* out_xyz, int cap);
+
+/* pcl::MovingLeastSquares (polynomial order 2, normals, no upsampling; Segmentation.cpp:239-246), PCL 1.7's
+ * published algorithm restated (PCL is not vendored): smoothed points, un-normalised normals, curvatures and
+ * input indices of the points with >= 3 neighbours, in input order; returns their number. */
+int orc_mls(const float* xyz, int n, float radius, float* out_xyz, float* out_nrm, float* out_curv, int* out_idx,
+            int cap);
 /* c_dist_pose (max) and c_dist_pose_mean (sum), base.cc:1616-1655 */
 void orc_pose_hausdorff(const float* hull, int n_hull, const float T1[16], const float T2[16], float* d_max,
                         float* d_sum);

@@ -71,6 +71,31 @@ struct DeviceGuard {
   }
 };
 
+// Entry-point guard of a context: selects its device and orders this call behind whatever an earlier
+// *_device call queued on the CALLER's stream -- those calls return without synchronising while the
+// kernels they launched still read the context's arrays (clouds, index, workspaces), and the host-pointer
+// entry points rewrite those arrays on the context's own non-blocking stream.
+struct CtxGuard : DeviceGuard {
+  explicit CtxGuard(pgp_ctx* ctx) : DeviceGuard(ctx->device) {
+    if (ok && ctx->device_work_pending) {
+      if (hipStreamWaitEvent(ctx->stream, ctx->ev_device_work, 0) == hipSuccess) ctx->device_work_pending = false;
+      else (void)hipDeviceSynchronize();
+    }
+  }
+};
+
+// after a *_device entry point has queued work on `stream`
+inline void note_device_work(pgp_ctx* ctx, hipStream_t stream) {
+  if (stream == ctx->stream) return;
+  if (!ctx->ev_device_work && hipEventCreateWithFlags(&ctx->ev_device_work, hipEventDisableTiming) != hipSuccess) {
+    ctx->ev_device_work = nullptr;
+    (void)hipStreamSynchronize(stream);   // no event: fall back to completing the work now
+    return;
+  }
+  if (hipEventRecord(ctx->ev_device_work, stream) == hipSuccess) ctx->device_work_pending = true;
+  else (void)hipStreamSynchronize(stream);
+}
+
 inline uint32_t spread10(uint32_t v) {
   v &= 1023u;
   v = (v | (v << 16)) & 0x030000FFu;
@@ -141,7 +166,9 @@ int pgp_create(pgp_ctx** out, int device_id) {
 
 int pgp_destroy(pgp_ctx* ctx) {
   if (!ctx) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
+  if (ctx->device_work_pending) (void)hipEventSynchronize(ctx->ev_device_work);
+  if (ctx->ev_device_work) (void)hipEventDestroy(ctx->ev_device_work);
   if (ctx->stream) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)e;
@@ -150,7 +177,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -234,7 +261,7 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
     set_error("pgp_set_scene: bad argument (n=%d, delta=%g)", n, (double)delta);
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   // *_device calls may still be queued on the caller's stream and read the arrays replaced below
   PGP_HIP(hipDeviceSynchronize());
   ctx->has_index = false;
@@ -265,7 +292,7 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
     set_error("pgp_set_model: bad argument (n=%d)", n);
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   PGP_HIP(hipDeviceSynchronize());   // see pgp_set_scene
   ctx->nQ = n;
   ctx->has_model_normals = nrm != nullptr;
@@ -326,7 +353,7 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
     set_error("pgp_reserve: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   if (max_hypotheses <= ctx->cap_h) return PGP_OK;
   PGP_HIP(hipDeviceSynchronize());   // the workspaces replaced below may be in use by queued launches
   int rc;
@@ -346,9 +373,11 @@ int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, floa
     set_error("pgp_score_lcp_device: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
-  return launch_score(ctx, d_T, n_h, mode, gate_deg, d_scores, d_counts, d_best,
-                      static_cast<hipStream_t>(stream));
+  CtxGuard guard(ctx);
+  const int rc = launch_score(ctx, d_T, n_h, mode, gate_deg, d_scores, d_counts, d_best,
+                              static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
 }
 
 int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
@@ -357,8 +386,10 @@ int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, fl
     set_error("pgp_settle_best_device: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
-  return launch_settle_best(ctx, d_T, n_h, mode, gate_deg, d_scores, d_best, static_cast<hipStream_t>(stream));
+  CtxGuard guard(ctx);
+  const int rc = launch_settle_best(ctx, d_T, n_h, mode, gate_deg, d_scores, d_best, static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
 }
 
 int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_deg, float* scores,
@@ -367,7 +398,7 @@ int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_de
     set_error("pgp_score_lcp: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   int rc = pgp_reserve(ctx, n_h);
   if (rc != PGP_OK) return rc;
   hipStream_t st = ctx->stream;
@@ -419,7 +450,7 @@ int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int
     set_error("pgp_registered: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   int rc = pgp_reserve(ctx, 1);
   if (rc != PGP_OK) return rc;
   hipStream_t st = ctx->stream;
@@ -445,7 +476,7 @@ int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, con
   }
   *n_ids = 0;
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   std::vector<float4> hq((size_t)n), hn((size_t)n);
   for (int i = 0; i < n; ++i) {
@@ -485,7 +516,7 @@ int pgp_find_congruent_4pcs(pgp_ctx* ctx, float invariant1, float invariant2, fl
   }
   *n_quads = 0;
   if (nP == 0 || nQ == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   int rc;
   if ((rc = ctx->d_cs_pairs.ensure(((size_t)nP + nQ) * 8)) != PGP_OK) return rc;
@@ -526,7 +557,7 @@ int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
     set_error("pgp_set_search_model: bad argument (n=%d)", n);
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   PGP_HIP(hipDeviceSynchronize());   // see pgp_set_scene
   std::vector<float4> hq((size_t)std::max(n, 1));
   for (int i = 0; i < n; ++i)
@@ -550,7 +581,7 @@ int pgp_set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int*
     set_error("pgp_set_ppf_map: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   PGP_HIP(hipDeviceSynchronize());
   return set_ppf_map(ctx, keys, counts, pairs, n_keys);
 }
@@ -561,7 +592,7 @@ int pgp_select_bases(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, fl
     return PGP_EINVAL;
   }
   if (n_attempts == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   return launch_select_bases(ctx, u, n_attempts, ids, invariants, status, ctx->stream);
 }
 
@@ -571,7 +602,7 @@ int pgp_ppf_features(pgp_ctx* ctx, const int* pairs, int m, int* features, int* 
     return PGP_EINVAL;
   }
   if (m == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   return launch_ppf_features(ctx, pairs, m, features, rows, ctx->stream);
 }
 
@@ -581,7 +612,7 @@ int pgp_stocs_stage_weights(pgp_ctx* ctx, int stage, int base1, int base2, int b
     set_error("pgp_stocs_stage_weights: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   return launch_stage_weights(ctx, stage, base1, base2, base3, cur, sum, present, ctx->stream);
 }
 
@@ -591,7 +622,7 @@ int pgp_base_invariants(pgp_ctx* ctx, int* ids, int m, float* invariants, int* o
     return PGP_EINVAL;
   }
   if (m == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   return launch_base_invariants(ctx, ids, m, invariants, ok, ctx->stream);
 }
 
@@ -602,9 +633,11 @@ int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const i
     set_error("pgp_rigid_from_congruent_device: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
-  return launch_rigid(ctx, d_base_ids, d_quad_ids, n, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms,
-                      static_cast<hipStream_t>(stream));
+  CtxGuard guard(ctx);
+  const int rc = launch_rigid(ctx, d_base_ids, d_quad_ids, n, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms,
+                              static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
 }
 
 int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_ids, int n,
@@ -615,7 +648,7 @@ int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_
     return PGP_EINVAL;
   }
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t N = (size_t)n;
   int rc;
@@ -645,7 +678,7 @@ int pgp_extract_pairs(pgp_ctx* ctx, float pair_distance, float eps, int* pairs, 
     set_error("pgp_extract_pairs: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   int rc = ctx->d_cs_out.ensure((size_t)std::max(cap, 1) * 8);
   if (rc != PGP_OK) return rc;
@@ -670,7 +703,7 @@ int pgp_find_congruent(pgp_ctx* ctx, const float* base, float invariant1, float 
   }
   *n_quads = 0;
   if (nP == 0 || nQ == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   int rc;
   if ((rc = ctx->d_cs_pairs.ensure(((size_t)nP + nQ) * 8)) != PGP_OK) return rc;
@@ -697,7 +730,7 @@ int pgp_find_congruent_batch(pgp_ctx* ctx, const int* base_ids, const float* bas
     set_error("pgp_find_congruent_batch: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   return launch_find_congruent_batch(ctx, base_ids, base_xyz, invariants, n_bases, threshold, n_quads, ctx->stream);
 }
 
@@ -707,7 +740,7 @@ int pgp_congruent_batch_quads(pgp_ctx* ctx, const int* picks, int m, int* quads)
     return PGP_EINVAL;
   }
   if (m == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   int rc = ctx->d_cs_out.ensure((size_t)m * 16);
   if (rc != PGP_OK) return rc;
   rc = launch_congruent_batch_gather(ctx, picks, m, ctx->d_cs_out.as<int4>(), ctx->stream);
@@ -724,7 +757,7 @@ int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids,
     return PGP_EINVAL;
   }
   if (m == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t N = (size_t)m;
   int rc;
@@ -796,10 +829,12 @@ int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const
     set_error("pgp_icp_refine_ex_device: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
-  return launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src, reinterpret_cast<const float4*>(d_tgt4),
+  CtxGuard guard(ctx);
+  const int rc = launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src, reinterpret_cast<const float4*>(d_tgt4),
                     reinterpret_cast<const float4*>(d_tgt_n4), n_tgt, d_T, n, opt, d_energy, d_iters,
                     static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
 }
 
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
@@ -821,7 +856,7 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
     return PGP_EINVAL;
   }
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   auto pack = [](const float* xyz, int m) {
     std::vector<float4> v((size_t)std::max(m, 1));
@@ -877,7 +912,7 @@ int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, 
   // the scene index with delta = radius answers "points within radius" for the cloud itself
   int rc = pgp_set_scene(ctx, xyz, nullptr, nullptr, n, radius);
   if (rc != PGP_OK) return rc;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   if ((rc = ctx->d_counts.ensure((size_t)n * sizeof(int))) != PGP_OK) return rc;
   rc = launch_count_neighbours(ctx, radius, ctx->d_counts.as<int>(), ctx->stream);
   if (rc != PGP_OK) return rc;
@@ -916,7 +951,7 @@ int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsi
   *n_out = 0;
   const size_t n = (size_t)rows * cols;
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t img_bytes = (n * (raw16 ? 2 : 4) + 255) & ~(size_t)255;
   const size_t mask_bytes = (n + 255) & ~(size_t)255;
@@ -953,7 +988,7 @@ int pgp_set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, c
     set_error("pgp_set_scene_device: bad argument (n=%d, delta=%g)", n, (double)delta);
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = static_cast<hipStream_t>(stream);
   PGP_HIP(hipStreamSynchronize(st));   // the producer of d_xyz
   PGP_HIP(hipDeviceSynchronize());     // queued launches may still read the arrays replaced below
@@ -967,7 +1002,7 @@ int pgp_voxel_grid_device(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, f
     set_error("pgp_voxel_grid_device: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   return launch_voxel_grid(ctx, d_xyz, n, leaf, d_out_xyz, cap, n_out, static_cast<hipStream_t>(stream));
 }
 
@@ -979,7 +1014,7 @@ int pgp_voxel_grid(pgp_ctx* ctx, const float* xyz, int n, float leaf, float* out
   }
   *n_out = 0;
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t in_b = ((size_t)n * 12 + 255) & ~(size_t)255;
   int rc = ctx->d_pre_io.ensure(in_b + (size_t)std::max(cap, 1) * 12 + 64);
@@ -997,6 +1032,56 @@ int pgp_voxel_grid(pgp_ctx* ctx, const float* xyz, int n, float leaf, float* out
   return PGP_OK;
 }
 
+int pgp_mls_normals_device(pgp_ctx* ctx, const float* d_xyz, int n, float radius, float* d_out_xyz, float* d_out_nrm,
+                           float* d_out_curvature, int* d_out_index, int cap, int* n_out, void* stream) {
+  if (!ctx || n < 0 || cap < 0 || !n_out || !(radius > 0.f) || !std::isfinite(radius) || (n > 0 && !d_xyz) ||
+      (cap > 0 && !d_out_xyz)) {
+    set_error("pgp_mls_normals_device: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_out = 0;
+  if (n == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  return launch_mls(ctx, d_xyz, n, radius, d_out_xyz, d_out_nrm, d_out_curvature, d_out_index, cap, n_out,
+                    static_cast<hipStream_t>(stream));
+}
+
+int pgp_mls_normals(pgp_ctx* ctx, const float* xyz, int n, float radius, float* out_xyz, float* out_nrm,
+                    float* out_curvature, int* out_index, int cap, int* n_out) {
+  if (!ctx || n < 0 || cap < 0 || !n_out || !(radius > 0.f) || !std::isfinite(radius) || (n > 0 && !xyz) ||
+      (cap > 0 && !out_xyz)) {
+    set_error("pgp_mls_normals: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_out = 0;
+  if (n == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t rows = (size_t)std::max(cap, 1);
+  const size_t b_in = ((size_t)n * 12 + 255) & ~(size_t)255, b_3 = (rows * 12 + 255) & ~(size_t)255,
+               b_1 = (rows * 4 + 255) & ~(size_t)255;
+  int rc = ctx->d_pre_io.ensure(b_in + 2 * b_3 + 2 * b_1);
+  if (rc != PGP_OK) return rc;
+  unsigned char* base = ctx->d_pre_io.as<unsigned char>();
+  float* d_in = reinterpret_cast<float*>(base);
+  float* d_x = reinterpret_cast<float*>(base + b_in);
+  float* d_n = reinterpret_cast<float*>(base + b_in + b_3);
+  float* d_c = reinterpret_cast<float*>(base + b_in + 2 * b_3);
+  int* d_i = reinterpret_cast<int*>(base + b_in + 2 * b_3 + b_1);
+  PGP_HIP(hipMemcpyAsync(d_in, xyz, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  rc = launch_mls(ctx, d_in, n, radius, d_x, d_n, d_c, d_i, cap, n_out, st);
+  if (rc != PGP_OK) return rc;
+  const size_t m = (size_t)(*n_out < cap ? *n_out : cap);
+  if (m > 0) {
+    PGP_HIP(hipMemcpyAsync(out_xyz, d_x, m * 12, hipMemcpyDeviceToHost, st));
+    if (out_nrm) PGP_HIP(hipMemcpyAsync(out_nrm, d_n, m * 12, hipMemcpyDeviceToHost, st));
+    if (out_curvature) PGP_HIP(hipMemcpyAsync(out_curvature, d_c, m * 4, hipMemcpyDeviceToHost, st));
+    if (out_index) PGP_HIP(hipMemcpyAsync(out_index, d_i, m * 4, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+  }
+  return PGP_OK;
+}
+
 int pgp_pose_hausdorff(pgp_ctx* ctx, const float* hull_xyz, int n_hull, const float* T, int n_poses,
                        const int* pairs, int m, float* dist_max, float* dist_sum) {
   if (!ctx || n_hull < 0 || n_poses < 0 || m < 0 || (n_hull > 0 && !hull_xyz) || (n_poses > 0 && !T) ||
@@ -1005,7 +1090,7 @@ int pgp_pose_hausdorff(pgp_ctx* ctx, const float* hull_xyz, int n_hull, const fl
     return PGP_EINVAL;
   }
   if (m == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   std::vector<float4> hh((size_t)std::max(n_hull, 1));
   for (int i = 0; i < n_hull; ++i) hh[i] = make_float4(hull_xyz[3 * (size_t)i], hull_xyz[3 * (size_t)i + 1], hull_xyz[3 * (size_t)i + 2], 0.f);
@@ -1041,7 +1126,7 @@ int pgp_backproject_depth_device(pgp_ctx* ctx, const void* d_image, int raw16, c
   *n_out = 0;
   const size_t n = (size_t)rows * cols;
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   const size_t nb = (n + 255) / 256;
   const size_t ctr_bytes = ((nb + 1) * 4 + 255) & ~(size_t)255;
   const size_t scan_bytes = ((nb / 2048 + 4) * 4 + 255) & ~(size_t)255;
@@ -1064,7 +1149,7 @@ int pgp_cluster_poses_device(pgp_ctx* ctx, const float* d_T, const float* d_scor
   if (n_h == 0) return PGP_OK;
   const pgp_cluster_params dflt = {0.5f, 10.f, 0.02f};  // HypothesisSelection.cpp:70,99
   if (!params) params = &dflt;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   int m = 0;
   return launch_cluster(ctx, d_T, d_scores, n_h, best_score, sym_deg, params, d_rep_index, d_assignment, &m, n_rep,
                         static_cast<hipStream_t>(stream));
@@ -1077,7 +1162,7 @@ int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, i
     return PGP_EINVAL;
   }
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t npix = (size_t)rows * cols;
   const size_t img_bytes = (npix * 4 + 15) & ~(size_t)15;
@@ -1118,7 +1203,7 @@ int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h
   if (n_h == 0) return PGP_OK;
   const pgp_cluster_params dflt = {0.5f, 10.f, 0.02f};  // HypothesisSelection.cpp:70,99
   if (!params) params = &dflt;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t nT = (size_t)n_h * 64, nS = ((size_t)n_h * 4 + 63) & ~(size_t)63;
   int rc = ctx->d_cl_io.ensure(nT + 3 * nS);
@@ -1148,7 +1233,7 @@ int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, cons
     return PGP_EINVAL;
   }
   if (n == 0) return PGP_OK;
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
   const size_t nT = (size_t)n * 64, nS = ((size_t)n * 4 + 63) & ~(size_t)63;
   int rc = ctx->d_cl_io.ensure(2 * nT + 2 * nS);
@@ -1183,7 +1268,7 @@ int pgp_get_kernel_timing(pgp_ctx* ctx, int* launches, float* total_ms, int rese
     set_error("pgp_get_kernel_timing: bad argument");
     return PGP_EINVAL;
   }
-  DeviceGuard guard(ctx->device);
+  CtxGuard guard(ctx);
   float sum = 0.f;
   for (size_t k = 0; k + 1 < ctx->ev_used; k += 2) {
     PGP_HIP(hipEventSynchronize(ctx->ev[k + 1]));

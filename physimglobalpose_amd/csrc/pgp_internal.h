@@ -54,6 +54,10 @@ struct DevBuf {
 struct pgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // internal stream for the synchronous host-pointer API
+  // a *_device call returns with its kernels still queued on the caller's stream; the next entry point
+  // makes `stream` wait for this event before it touches the context's arrays (pgp_api.hip CtxGuard)
+  hipEvent_t ev_device_work = nullptr;
+  bool device_work_pending = false;
 
   // scene
   int nP = 0;
@@ -107,6 +111,7 @@ struct pgp_ctx {
   pgp::DevBuf d_sel_ws;                 // base-selection workspace / staging
 
   pgp::DevBuf d_pre_ws, d_vg_ws, d_pre_io;   // preprocess.hip: bbox partials, voxel-grid workspace, host-API staging
+  pgp::DevBuf d_mls_ws;                      // mls.hip: sort keys, sorted cloud, per-point results
   bool hd_attr_set = false;
 
   pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
@@ -213,6 +218,10 @@ int launch_pose_hausdorff(pgp_ctx* ctx, const float4* d_hull, int n_hull, const 
                           const int2* d_pairs, int m, float* d_max, float* d_sum, hipStream_t st);
 int set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, const float* d_w, int n, float delta,
                      hipStream_t st);
+
+// mls.hip
+int launch_mls(pgp_ctx* ctx, const float* d_xyz, int n, float radius, float* d_out_xyz, float* d_out_nrm,
+               float* d_out_curv, int* d_out_index, int cap, int* n_out, hipStream_t st);
 
 // depth_cost.hip
 int launch_depth_cost(pgp_ctx* ctx, const float* d_obs, const float* d_ren, int n, int n_pix, float thr,

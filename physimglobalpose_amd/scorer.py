@@ -253,6 +253,29 @@ class LcpScorer:
         _lib.check(self._lib.pgp_voxel_grid(self._h, _fp(xyz), n, C.c_float(leaf), _fp(out), n, C.byref(m)))
         return out[: m.value].copy()
 
+    def mls_normals(self, xyz, radius=0.02):
+        """pcl::MovingLeastSquares (polynomial order 2, normals, no upsampling; Segmentation.cpp:239-246):
+        (smoothed xyz, un-normalised normals, curvature, input index) of the points with >= 3 neighbours."""
+        xyz = _f32(xyz, 3)
+        n = len(xyz)
+        cap = max(n, 1)
+        ox, on = np.zeros((cap, 3), np.float32), np.zeros((cap, 3), np.float32)
+        oc, oi = np.zeros(cap, np.float32), np.zeros(cap, np.int32)
+        m = C.c_int(0)
+        _lib.check(self._lib.pgp_mls_normals(self._h, _fp(xyz), n, C.c_float(radius), _fp(ox), _fp(on), _fp(oc),
+                                             oi.ctypes.data_as(_i), cap, C.byref(m)))
+        return ox[: m.value].copy(), on[: m.value].copy(), oc[: m.value].copy(), oi[: m.value].copy()
+
+    def mls_normals_device(self, d_xyz, n, radius, d_out_xyz, d_out_nrm=None, d_out_curv=None, d_out_index=None):
+        import torch
+        m = C.c_int(0)
+        st = torch.cuda.current_stream(d_xyz.device).cuda_stream
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        _lib.check(self._lib.pgp_mls_normals_device(self._h, p(d_xyz), int(n), C.c_float(radius), p(d_out_xyz), p(d_out_nrm),
+                                                    p(d_out_curv), p(d_out_index), int(d_out_xyz.shape[0]), C.byref(m),
+                                                    C.c_void_p(st)))
+        return m.value
+
     def pose_hausdorff(self, hull_xyz, T, pairs):
         """c_dist_pose / c_dist_pose_mean (base.cc:1616-1655) for (m,2) index pairs into T (n,16)."""
         hull, T = _f32(hull_xyz, 3), _f32(T, 16)

@@ -83,6 +83,7 @@ def oracle_lib():
                                       C.c_double, _f]
         L.orc_voxel_grid.argtypes = [_f, C.c_int, C.c_float, _f, C.c_int]
         L.orc_pose_hausdorff.argtypes = [_f, C.c_int, _f, _f, _f, _f]
+        L.orc_mls.argtypes = [_f, C.c_int, C.c_float, _f, _f, _f, _i, C.c_int]
         _oracle = L
     return _oracle
 
@@ -92,6 +93,15 @@ def oracle_voxel_grid(xyz, leaf=0.01):
     out = np.zeros((max(len(xyz), 1), 3), np.float32)
     n = oracle_lib().orc_voxel_grid(_fp(xyz), len(xyz), C.c_float(leaf), _fp(out), len(xyz))
     return out[:n].copy()
+
+
+def oracle_mls(xyz, radius=0.02):
+    """C restatement of pcl::MovingLeastSquares (order 2, normals): (xyz, normals, curvature, input index)."""
+    xyz = _f32(xyz).reshape(-1, 3)
+    n = max(len(xyz), 1)
+    ox, on, oc, oi = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32), np.zeros(n, np.float32), np.zeros(n, np.int32)
+    m = oracle_lib().orc_mls(_fp(xyz), len(xyz), C.c_float(radius), _fp(ox), _fp(on), _fp(oc), oi.ctypes.data_as(_i), n)
+    return ox[:m].copy(), on[:m].copy(), oc[:m].copy(), oi[:m].copy()
 
 
 def _hausdorff(fn, hull, T, pairs):

@@ -103,3 +103,31 @@ def test_distinct_contexts_are_safe_from_different_threads():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_set_model_after_queued_device_scoring_does_not_overwrite_under_the_kernel():
+    """A *_device call returns with its kernels queued on the caller's stream; a following
+    pgp_set_model (which rewrites the model arrays on the context's own stream) must be ordered
+    behind them (pgp.h: the context waits on an event).  A long queue in front of the scoring call
+    makes the race certain without that ordering."""
+    import torch
+    from physimglobalpose_amd import PGP_MODE_PLAIN
+    w = synth.make_workload(20000, 2000, 512, config_id=2)
+    sc = LcpScorer(0)
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    sc.reserve(w.n_h)
+    want, _, _, _ = sc.score(w.T, PGP_MODE_PLAIN)
+    other = np.ascontiguousarray(w.Q_xyz[::-1] + np.float32(0.05))   # same size: no reallocation, no implicit sync
+    dT = torch.from_numpy(w.T).cuda()
+    ds = torch.zeros(w.n_h, device="cuda")
+    side = torch.cuda.Stream()
+    busy = torch.randn(4096, 4096, device="cuda")
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                busy = busy @ busy * 1e-4     # keeps the stream busy for milliseconds
+            sc.score_device(dT, ds, mode=PGP_MODE_PLAIN, stream=side)
+        sc.set_model(other, w.Q_nrm)          # returns once the NEW model is resident
+        side.synchronize()
+        assert np.array_equal(ds.cpu().numpy(), want)
+        sc.set_model(w.Q_xyz, w.Q_nrm)

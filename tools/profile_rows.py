@@ -83,6 +83,8 @@ for _ in range(REPS):
     sc.cluster_poses(w.T, sw + np.float32(1e-6), bs, accept_fraction=0.0)
     sc.depth_cost(obs, ren, 0.01)
     sc.backproject_depth(raw, Kc, msk)
+    seg = sc.voxel_grid(w.P_xyz[:20000], 0.01)
+    sc.mls_normals(seg, 0.02)
 flt = LcpScorer(0)
 for _ in range(REPS):
     flt.radius_outlier_filter(cw.P_xyz, cw.P_nrm, 0.03, 10)
