@@ -99,6 +99,72 @@ double ply_read_bin(const unsigned char* p, const std::string& t) {
   return 0;
 }
 
+// One decimal number of an ASCII vertex line as a correctly rounded double -- what `stream >> double` and
+// strtod return.  Fast path (Clinger): at most 15 significant digits and a decimal exponent within +-22 make
+// mantissa and power of ten both exact doubles, so ONE multiplication or division rounds correctly; anything
+// else (long mantissas, nan / inf, hex floats) goes to strtod itself.
+inline bool ascii_number(const char** pp, double* out) {
+  static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                                    1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char* p = *pp;
+  while (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v') ++p;
+  const char* start = p;
+  bool neg = false;
+  if (*p == '+' || *p == '-') neg = *p++ == '-';
+  unsigned long long mant = 0;
+  int digits = 0, exp10 = 0;
+  bool any = false, fast = true;
+  while (*p >= '0' && *p <= '9') {
+    any = true;
+    if (mant || *p != '0') {
+      if (digits < 15) { mant = mant * 10 + (unsigned)(*p - '0'); ++digits; }
+      else fast = false;
+    }
+    ++p;
+  }
+  if (*p == '.') {
+    ++p;
+    while (*p >= '0' && *p <= '9') {
+      any = true;
+      if (mant || *p != '0') {
+        if (digits < 15) { mant = mant * 10 + (unsigned)(*p - '0'); ++digits; --exp10; }
+        else fast = false;
+      } else {
+        --exp10;   // a leading zero of the fraction
+      }
+      ++p;
+    }
+  }
+  if (any && (*p == 'e' || *p == 'E')) {
+    const char* q = p + 1;
+    bool eneg = false;
+    if (*q == '+' || *q == '-') eneg = *q++ == '-';
+    if (*q >= '0' && *q <= '9') {
+      int e = 0;
+      while (*q >= '0' && *q <= '9') {
+        if (e < 10000) e = e * 10 + (*q - '0');
+        ++q;
+      }
+      exp10 += eneg ? -e : e;
+      p = q;
+    }
+  }
+  const bool end_ok = *p == '\0' || *p == ' ' || *p == '\t' || *p == '\n' || *p == '\r' || *p == '\f' || *p == '\v';
+  if (any && fast && end_ok && exp10 >= -22 && exp10 <= 22) {
+    double d = (double)mant;   // < 10^15 < 2^53: exact
+    d = exp10 < 0 ? d / kPow10[-exp10] : d * kPow10[exp10];
+    *out = neg ? -d : d;
+    *pp = p;
+    return true;
+  }
+  char* end = nullptr;
+  const double d = std::strtod(start, &end);
+  if (end == start) return false;
+  *out = d;
+  *pp = end;
+  return true;
+}
+
 bool read_ply(const std::string& path, Cloud& out) {
   std::ifstream f(path.c_str(), std::ios::binary);
   if (!f) return false;
@@ -151,9 +217,20 @@ bool read_ply(const std::string& path, Cloud& out) {
   out.nrm.assign((size_t)n_vertex * 3, 0.f);
   std::vector<double> v(props.size());
   if (ascii) {
+    // the vertex block in one read, numbers by ascii_number(): stream extraction of 43 000 doubles was 4.3 of
+    // the drop-in's 6 ms per object
+    const std::streampos here = f.tellg();
+    f.seekg(0, std::ios::end);
+    const std::streamoff len = f.tellg() - here;
+    f.seekg(here);
+    if (len < 0) return false;
+    std::vector<char> text((size_t)len + 1);
+    if (len > 0 && !f.read(text.data(), len)) return false;
+    text[(size_t)len] = '\0';
+    const char* p = text.data();
     for (long i = 0; i < n_vertex; ++i) {
       for (size_t k = 0; k < props.size(); ++k)
-        if (!(f >> v[k])) return false;
+        if (!ascii_number(&p, &v[k])) return false;
       out.xyz[3 * i] = (float)v[ix]; out.xyz[3 * i + 1] = (float)v[iy]; out.xyz[3 * i + 2] = (float)v[iz];
       if (inx >= 0 && iny >= 0 && inz >= 0) {
         out.nrm[3 * i] = (float)v[inx]; out.nrm[3 * i + 1] = (float)v[iny]; out.nrm[3 * i + 2] = (float)v[inz];
@@ -316,6 +393,15 @@ extern "C" int super4pcs_shim_read_cloud(const char* path, float* xyz, float* nr
       nrm[3 * i + k] = c.nrm[3 * (size_t)i + k];
     }
   return c.n;
+}
+
+// C-linkage probe for the tests: the reader's number parser on a whitespace-separated list; returns how many
+// numbers it produced (it stops at the first token it rejects).
+extern "C" int super4pcs_shim_parse_numbers(const char* text, double* out, int cap) {
+  const char* p = text;
+  int n = 0;
+  while (n < cap && ascii_number(&p, &out[n])) ++n;
+  return n;
 }
 
 // C-linkage probe for the tests: decode a greyscale PNG into 16-bit samples (8-bit files are widened);

@@ -112,3 +112,27 @@ def test_shim_png_decoder_matches_pil(tmp_path):
         assert rc == 0 and (rows.value, cols.value) == img.shape
         assert np.array_equal(out.reshape(img.shape), want)
     assert L.super4pcs_shim_read_png(str(tmp_path / "missing.png").encode(), None, 0, C.byref(rows), C.byref(cols)) == -1
+
+
+def test_number_parser_rounds_like_strtod():
+    """the reader's fast decimal path (<= 15 digits, |exponent| <= 22: one exact multiply / divide) and its
+    strtod fallback against Python's float(), which is correctly rounded"""
+    L = C.CDLL(SHIM)
+    L.super4pcs_shim_parse_numbers.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.c_int]
+    rng = np.random.default_rng(5)
+    toks = []
+    for _ in range(20000):
+        nd = int(rng.integers(1, 20))
+        digits = "".join(rng.choice(list("0123456789"), nd))
+        cut = int(rng.integers(0, nd + 1))
+        tok = ("-" if rng.random() < 0.4 else "") + (digits[:cut] or "0") + ("." + digits[cut:] if cut < nd else "")
+        if rng.random() < 0.3:
+            tok += "e%+d" % int(rng.integers(-30, 31))
+        toks.append(tok)
+    toks += ["0", "-0", "0.0", "1e22", "1e23", "9007199254740993", "0.1", "123456789012345", "1234567890123456",
+             "4.9e-324", "1.7976931348623157e308", "00012.5000", ".5", "5.", "+3.25", "1E5", "1e-22", "1e-23"]
+    out = np.zeros(len(toks), np.float64)
+    n = L.super4pcs_shim_parse_numbers((" ".join(toks) + "\n").encode(), out.ctypes.data_as(C.POINTER(C.c_double)), len(toks))
+    assert n == len(toks)
+    want = np.array([float(t) for t in toks])
+    assert np.array_equal(out.view(np.uint64), want.view(np.uint64))
