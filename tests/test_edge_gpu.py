@@ -98,6 +98,29 @@ def test_large_coordinates_and_large_extent():
     assert np.array_equal(s, so) and bi == bio and c.max() > 100
 
 
+def test_scene_beyond_the_lattice_range_of_the_mantissa_trick():
+    """The scoring kernel finds a cell as round(x * inv_h) - k0 in the mantissa of one fused multiply-add,
+    which holds lattice numbers below 2^22.  A scene at 10^5 m with delta = 2 cm is at lattice number
+    ~5.9 million: the library must notice (GridDesc.magic_ok) and score with the truncation kernel --
+    same counts, scores and best index as the oracle, in both modes."""
+    rng = np.random.default_rng(14)
+    P = (rng.uniform(0, 3.0, (6000, 3)) + 1.0e5).astype(np.float32)
+    Q = (P[rng.integers(0, len(P), 400)].astype(np.float64) + rng.normal(0, 0.006, (400, 3))).astype(np.float32)
+    Pn = synth._unit(rng.standard_normal(P.shape)).astype(np.float32)
+    Qn = synth._unit(rng.standard_normal(Q.shape)).astype(np.float32)
+    w = rng.uniform(0, 1, len(P)).astype(np.float32)
+    T = np.stack([I16] + [synth.colmajor16(synth._se3(np.eye(3), 0.01 * rng.standard_normal(3))) for _ in range(15)])
+    sc = LcpScorer()
+    sc.init(P, Pn, w, Q, Qn, 0.02)
+    orc = Oracle(P, Pn, w, Q, Qn)
+    s, c, bi, _ = sc.score(T)
+    so, bio, _ = orc.score_batch(T, 0.02, mode=0)
+    assert np.array_equal(s, so) and bi == bio and c.max() > 50
+    s, c, bi, _ = sc.score(T, PGP_MODE_WEIGHTED, 30.0)
+    so, bio, _ = orc.score_batch(T, 0.02, mode=1, gate_deg=30.0)
+    assert np.allclose(s, so, rtol=0, atol=2e-6) and bi == bio
+
+
 @pytest.mark.parametrize("delta", [0.001, 0.02, 0.1])
 def test_other_radii(delta):
     w = synth.make_workload(4000, 400, 40, config_id=41)
