@@ -245,64 +245,70 @@ __global__ __launch_bounds__(256) void cluster_pair_bits(const float* __restrict
   if ((c & 63) == 0 && threadIdx.x == 0) bits[(size_t)c * W + (c >> 6)] = 0ull;
 }
 
-// The sequential pass.  One block (16 waves).  keep[] (LDS) = representatives so far, by sorted
-// position.  Per tile of 64 candidates: (1) each wave takes 4 of them and looks for a hit among
-// the representatives of EARLIER tiles (lanes stride over the row's words, first hit = lowest
-// position; the four rows' loads are issued together -- a single resident block has nothing else to
-// hide a global round trip behind: 911 -> 2xx us at 4096 poses); (2) wave 0 walks the 64 candidates
-// in order using only the tile's diagonal words.
+// The sequential pass.  One block (16 waves).  keep[] (LDS) = representatives so far, by sorted position.
+// Tile t = candidates 64 t .. 64 t + 63.  A candidate joins the representative at the LOWEST position it is
+// adjacent to, else it becomes one; its row of the bit matrix is needed (a) against the representatives of
+// tiles 0 .. t-2, (b) against those of tile t-1, (c) against the tile's own earlier candidates (the diagonal
+// word).  Only (c) is serial.  The work is software-pipelined across tiles with ONE barrier per tile:
+//   wave 0, iteration t    : (b) with the word it prefetched, then requests tile t+1's two words, then the
+//                            64-step walk (c) of tile t under those loads' latency
+//   waves 1-15, iteration t: (a) for tile t+1 -- keep[0 .. t-1] are final -- with the rows they requested
+//                            during iteration t-1; then request tile t+2's rows
+// so no global round trip is ever waited for with nothing else to do (a single resident block has no other
+// wave to hide it behind).  911 us (round 1) -> 449 us (16 waves, batched row loads, v_readlane in the walk)
+// -> pipelined: see DESIGN.md section 4.
 constexpr int kGreedyThreads = 1024;
+constexpr int kGreedyA = kGreedyThreads / 64 - 1;           // 15 look-ahead waves
+constexpr int kGreedyPer = (64 + kGreedyA - 1) / kGreedyA;  // 5 candidates each
 __global__ __launch_bounds__(kGreedyThreads) void cluster_greedy(const unsigned long long* __restrict__ bits, int m, int W,
                                                       const int* __restrict__ idx_sorted, int* __restrict__ rep_out,
                                                       int* __restrict__ assign, int* __restrict__ n_rep_out) {
   extern __shared__ unsigned long long keep[];  // W words
-  __shared__ int pre[64];                       // first earlier-tile representative hit, or -1
-  __shared__ int n_rep_s;
+  __shared__ int pre[2][64];                    // first hit among tiles <= t-2 per candidate of tile t, or -1
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int NW = kGreedyThreads / 64, PER = 64 / NW;   // 16 waves, 4 candidates each
+  const int n_tiles = (m + 63) >> 6;
   for (int w = threadIdx.x; w < W; w += blockDim.x) keep[w] = 0ull;
-  if (threadIdx.x == 0) n_rep_s = 0;
+  if (threadIdx.x < 128) pre[threadIdx.x >> 6][threadIdx.x & 63] = -1;
   __syncthreads();
-  for (int c0 = 0; c0 < m; c0 += 64) {
-    const int wt = c0 >> 6;  // the tile's diagonal word; earlier tiles own words < wt
-    int first[PER];
+
+  // ---- wave 0: the walk ----
+  unsigned long long w_prev = 0ull, w_diag = 0ull;   // candidate's words t-1 and t (tile t), prefetched
+  unsigned long long kw_prev = 0ull;                 // keep[t-1]
+  int n_rep = 0;
+  // ---- waves 1-15: rows (first 64 words) of the candidates they will test next ----
+  unsigned long long x_next[kGreedyPer];
 #pragma unroll
-    for (int k = 0; k < PER; ++k) first[k] = -1;
-    for (int wb = 0; wb < wt; wb += 64) {
-      const int w = wb + lane;
-      unsigned long long x[PER];
+  for (int k = 0; k < kGreedyPer; ++k) x_next[k] = 0ull;
+  if (wave == 0) {
+    const int c = lane;
+    w_diag = c < m ? bits[(size_t)c * W + 0] : 0ull;
+  } else {
+    // rows of tile 1 (tested during iteration 0 against nothing: tile 1 has no tile <= -1 ... kept uniform)
 #pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const int c = c0 + wave + NW * k;
-        x[k] = (c < m && w < wt && first[k] < 0) ? bits[(size_t)c * W + w] : 0ull;
-      }
-      const unsigned long long kp = w < wt ? keep[w] : 0ull;
-      bool all_found = true;
-#pragma unroll
-      for (int k = 0; k < PER; ++k) {
-        const unsigned long long xk = x[k] & kp;
-        const unsigned long long any = __ballot(xk != 0ull);
-        if (any && first[k] < 0) {
-          const int src = __ffsll((long long)any) - 1;
-          const int pos = 64 * w + (__ffsll((long long)xk) - 1);
-          first[k] = __shfl(pos, src, 64);
-        }
-        all_found &= first[k] >= 0 || c0 + wave + NW * k >= m;
-      }
-      if (all_found) break;
+    for (int k = 0; k < kGreedyPer; ++k) {
+      const int slot = (wave - 1) + kGreedyA * k, c = 64 + slot;
+      x_next[k] = (slot < 64 && c < m && lane < W) ? bits[(size_t)c * W + lane] : 0ull;
     }
-    if (lane == 0) {
-#pragma unroll
-      for (int k = 0; k < PER; ++k) pre[wave + NW * k] = first[k];
-    }
-    __syncthreads();
+  }
+
+  for (int t = 0; t < n_tiles; ++t) {
+    const int c0 = t << 6;
     if (wave == 0) {
       const int c = c0 + lane;
-      const unsigned long long diag = c < m ? bits[(size_t)c * W + wt] : 0ull;
-      const int my_pre = c < m ? pre[lane] : 0;
+      int my_pre = pre[t & 1][lane];                       // (a), computed during iteration t-1
+      if (my_pre < 0 && t >= 1) {                          // (b)
+        const unsigned long long x = w_prev & kw_prev;
+        if (x) my_pre = 64 * (t - 1) + (__ffsll((long long)x) - 1);
+      }
+      const unsigned long long diag = w_diag;
+      // tile t+1's words t and t+1, in flight under the walk
+      const int cn = c + 64;
+      if (t + 1 < n_tiles) {
+        w_prev = cn < m ? bits[(size_t)cn * W + t] : 0ull;
+        w_diag = cn < m ? bits[(size_t)cn * W + t + 1] : 0ull;
+      }
       unsigned long long kw = 0ull;
       int my_assign = my_pre;
-      int n_rep = n_rep_s;
       const int jn = m - c0 < 64 ? m - c0 : 64;
       for (int j = 0; j < jn; ++j) {
         // j is wave-uniform: v_readlane (a few cycles) instead of a cross-lane shuffle through the LDS
@@ -325,14 +331,142 @@ __global__ __launch_bounds__(kGreedyThreads) void cluster_greedy(const unsigned 
         if (lane == j) my_assign = a;
       }
       if (c < m) assign[idx_sorted[c]] = idx_sorted[my_assign];
-      if (lane == 0) {
-        keep[wt] = kw;
-        n_rep_s = n_rep;
+      if (lane == 0) keep[t] = kw;
+      kw_prev = kw;
+    } else if (t + 1 < n_tiles) {
+      // (a) for tile t+1: words 0 .. t-1
+      unsigned long long x_load[kGreedyPer];
+#pragma unroll
+      for (int k = 0; k < kGreedyPer; ++k) {   // tile t+2's rows, used in the next iteration
+        const int slot = (wave - 1) + kGreedyA * k, c = c0 + 128 + slot;
+        x_load[k] = (slot < 64 && c < m && lane < W) ? bits[(size_t)c * W + lane] : 0ull;
       }
+      const unsigned long long kp0 = lane < t && lane < W ? keep[lane] : 0ull;   // words < t only
+#pragma unroll
+      for (int k = 0; k < kGreedyPer; ++k) {
+        const int slot = (wave - 1) + kGreedyA * k;   // wave-uniform
+        if (slot >= 64) continue;
+        const int c = c0 + 64 + slot;
+        int first = -1;
+        if (c < m) {
+          unsigned long long xk = x_next[k] & kp0;
+          unsigned long long any = __ballot(xk != 0ull);
+          if (any) {
+            const int src = __ffsll((long long)any) - 1;
+            first = __shfl(64 * lane + (__ffsll((long long)xk) - 1), src, 64);
+          } else {
+            for (int wb = 64; wb < t; wb += 64) {   // more than 4096 poses: the words past the prefetched 64
+              const int w = wb + lane;
+              xk = (w < t) ? (bits[(size_t)c * W + w] & keep[w]) : 0ull;
+              any = __ballot(xk != 0ull);
+              if (any) {
+                const int src = __ffsll((long long)any) - 1;
+                first = __shfl(64 * w + (__ffsll((long long)xk) - 1), src, 64);
+                break;
+              }
+            }
+          }
+        }
+        if (lane == 0) pre[(t + 1) & 1][slot] = first;
+      }
+#pragma unroll
+      for (int k = 0; k < kGreedyPer; ++k) x_next[k] = x_load[k];
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *n_rep_out = n_rep_s;
+  if (threadIdx.x == 0) *n_rep_out = n_rep;
+}
+
+// ---- the same pass for m <= 4096 poses (W <= 64 words): every candidate's state lives in a register ----------
+// Thread tid owns candidates tid, tid + 1024, ... (<= 4): `pre` = position of the first representative of an
+// EARLIER tile it is adjacent to, or -1.  Tile t's 64 candidates are then the lanes of ONE wave, wave t mod 16,
+// which walks the tile; the walk itself is the minimal recurrence
+//     kw |= (diag_j & kw) == 0 && !pre_j ? 1 << j : 0          (j = 0 .. 63)
+// on the scalar unit, fully unrolled (two v_readlane + s_and / s_cselect / s_or per step, no branch), since a
+// candidate's diagonal word only holds bits below j: assignments and the representative list follow from the
+// final kw in parallel.  After the barrier every thread PUSHES tile t's representatives onto its own later
+// candidates (word t of their rows, requested one iteration earlier; two register sets alternate so that no
+// copy waits for a load).  The barrier waits for LDS only (s_waitcnt lgkmcnt(0); s_barrier): __syncthreads()
+// would drain the prefetches.  449 us (two barriers, a branchy 64-step walk) -> see DESIGN.md section 4.
+constexpr int kSmallMax = 4096;
+__global__ __launch_bounds__(kGreedyThreads) void cluster_greedy_small(const unsigned long long* __restrict__ bits, int m, int W,
+                                                            const int* __restrict__ idx_sorted, int* __restrict__ rep_out,
+                                                            int* __restrict__ assign, int* __restrict__ n_rep_out) {
+  __shared__ unsigned long long keep[kSmallMax / 64];
+  __shared__ int n_rep_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  const int n_tiles = (m + 63) >> 6;
+  constexpr int K = kSmallMax / kGreedyThreads;   // 4 candidates per thread
+  int pre[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) pre[k] = -1;
+  if (tid == 0) n_rep_s = 0;
+  auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  // word `t` of the rows of this thread's candidates that lie in tiles > t (0 otherwise)
+  auto load_words = [&](int t, unsigned long long (&wd)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int c = tid + kGreedyThreads * k;
+      wd[k] = (t < n_tiles && c < m && c >= 64 * (t + 1)) ? bits[(size_t)c * W + t] : 0ull;
+    }
+  };
+  // diagonal word of the candidate this lane holds in tile t (if this wave walks tile t)
+  auto load_diag = [&](int t) -> unsigned long long {
+    const int c = 64 * t + lane;
+    return (t < n_tiles && (t & 15) == wave && c < m) ? bits[(size_t)c * W + t] : 0ull;
+  };
+  auto iteration = [&](const int t, const unsigned long long (&w_prev)[K], unsigned long long (&w_next)[K],
+                       const unsigned long long diag, unsigned long long& diag_next) {
+    // 1. push tile t-1's representatives (keep[t-1] is final since the last barrier)
+    if (t >= 1) {
+      const unsigned long long kp = keep[t - 1];
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const unsigned long long x = w_prev[k] & kp;
+        if (pre[k] < 0 && x) pre[k] = 64 * (t - 1) + (__ffsll((long long)x) - 1);
+      }
+    }
+    // 2. requests for the next iteration's push and the next walk of this wave
+    load_words(t, w_next);
+    diag_next = load_diag(t + 1);
+    // 3. the walk, by the wave that owns tile t
+    if ((t & 15) == wave) {
+      const int kk = t >> 4, c0 = t << 6, c = c0 + lane;
+      const int my_pre = kk == 0 ? pre[0] : kk == 1 ? pre[1] : kk == 2 ? pre[2] : pre[3];
+      const unsigned long long cannot = __ballot(my_pre >= 0 || c >= m);   // lanes that cannot become representatives
+      const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
+      unsigned long long kw = 0ull;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
+        const unsigned long long bit = ~cannot & (1ull << j);
+        kw |= (dj & kw) ? 0ull : bit;
+      }
+      // assignments and representatives from the final kw (bits >= j of diag_j are zero)
+      const unsigned long long dk = diag & kw;
+      const int a = my_pre >= 0 ? my_pre : dk ? c0 + (__ffsll((long long)dk) - 1) : c;
+      if (c < m) assign[idx_sorted[c]] = idx_sorted[a];
+      const int n0 = n_rep_s;
+      if ((kw >> lane) & 1ull) rep_out[n0 + __popcll(kw & ((1ull << lane) - 1ull))] = idx_sorted[c];
+      if (lane == 0) {
+        keep[t] = kw;
+        n_rep_s = n0 + __popcll(kw);
+      }
+    }
+    lds_barrier();
+  };
+  unsigned long long wA[K], wB[K], dA, dB;
+#pragma unroll
+  for (int k = 0; k < K; ++k) wA[k] = wB[k] = 0ull;
+  dA = load_diag(0);
+  dB = 0ull;
+  __syncthreads();
+  for (int t = 0; t < n_tiles; t += 2) {
+    iteration(t, wA, wB, dA, dB);
+    if (t + 1 < n_tiles) iteration(t + 1, wB, wA, dB, dA);
+  }
+  if (tid == 0) *n_rep_out = n_rep_s;
 }
 
 }  // namespace
@@ -399,8 +533,12 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
   const Sym s = {sym[0], sym[1], sym[2]};
   hipLaunchKernelGGL(cluster_pair_bits, dim3(m), dim3(256), 0, st, inv_c, rot_r, m, W, s, prm->rot_thresh_deg,
                      prm->trans_thresh, bits);
-  hipLaunchKernelGGL(cluster_greedy, dim3(1), dim3(kGreedyThreads), (size_t)W * 8, st, bits, m, W, idx_sorted, d_rep,
-                     d_assign, d_cnt + 1);
+  if (m <= kSmallMax)
+    hipLaunchKernelGGL(cluster_greedy_small, dim3(1), dim3(kGreedyThreads), 0, st, bits, m, W, idx_sorted, d_rep, d_assign,
+                       d_cnt + 1);
+  else
+    hipLaunchKernelGGL(cluster_greedy, dim3(1), dim3(kGreedyThreads), (size_t)W * 8, st, bits, m, W, idx_sorted, d_rep,
+                       d_assign, d_cnt + 1);
   PGP_HIP(hipGetLastError());
   PGP_HIP(hipMemcpyAsync(h_n_rep, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
