@@ -394,8 +394,10 @@ __global__ __launch_bounds__(kGreedyThreads) void cluster_greedy_small(const uns
                                                             int* __restrict__ assign, int* __restrict__ n_rep_out) {
   __shared__ unsigned long long keep[kSmallMax / 64];
   __shared__ int n_rep_s;
+  __shared__ int s_idx[kSmallMax];   // idx_sorted: the walker's stores must not wait for a dependent global load
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
   const int n_tiles = (m + 63) >> 6;
+  for (int c = tid; c < m; c += kGreedyThreads) s_idx[c] = idx_sorted[c];
   constexpr int K = kSmallMax / kGreedyThreads;   // 4 candidates per thread
   int pre[K];
 #pragma unroll
@@ -446,9 +448,9 @@ __global__ __launch_bounds__(kGreedyThreads) void cluster_greedy_small(const uns
       // assignments and representatives from the final kw (bits >= j of diag_j are zero)
       const unsigned long long dk = diag & kw;
       const int a = my_pre >= 0 ? my_pre : dk ? c0 + (__ffsll((long long)dk) - 1) : c;
-      if (c < m) assign[idx_sorted[c]] = idx_sorted[a];
+      if (c < m) assign[s_idx[c]] = s_idx[a];
       const int n0 = n_rep_s;
-      if ((kw >> lane) & 1ull) rep_out[n0 + __popcll(kw & ((1ull << lane) - 1ull))] = idx_sorted[c];
+      if ((kw >> lane) & 1ull) rep_out[n0 + __popcll(kw & ((1ull << lane) - 1ull))] = s_idx[c];
       if (lane == 0) {
         keep[t] = kw;
         n_rep_s = n0 + __popcll(kw);
