@@ -137,6 +137,18 @@ int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int
 int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, const float* q_nrm, int n,
                          float gate_deg, int* ids, int* n_ids);
 
+/* Weighted mode, the running-best LIST (base.cc:1891-1908, what the drop-in returns as hypothesisSet): with
+ * pgp_set_exact_records(ctx, 1) every later weighted scoring call on the context also re-scores, exactly as
+ * the reference sums (sequential float adds in model order), every hypothesis whose score comes within the
+ * summation tolerance of the running maximum before it -- the records and whatever could displace or tie one;
+ * pgp_running_best over the returned scores is then the reference's list, entry for entry.  Costs one more
+ * single-block launch and ~ln(n_h) exact re-scores per call; off by default (the best pose is exact either way).
+ * pgp_settle_records_device does the same for a score vector assembled elsewhere (the slices of several
+ * devices), like pgp_settle_best_device. */
+int pgp_set_exact_records(pgp_ctx* ctx, int on);
+int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
+                              void* stream);
+
 /* Running-best subsequence of base.cc:1891-1908 over a score vector (host helper): writes the
  * indices i with scores[i] > max(scores[0..i-1], 0) to selected (capacity n_h). */
 int pgp_running_best(const float* scores, int n_h, int* selected, int* n_selected);

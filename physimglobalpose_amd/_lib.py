@@ -96,6 +96,8 @@ SIGNATURES = {
     "pgp_mls_normals": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_float, _f, _f, _f, _i, C.c_int, _i]),
     "pgp_mls_normals_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int, _i, C.c_void_p]),
+    "pgp_set_exact_records": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgp_settle_records_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),
     "pgp_voxel_grid_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_int, _i, C.c_void_p]),
     "pgp_pose_hausdorff": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _i, C.c_int, _f, _f]),
     "pgp_backproject_depth_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, _f,

@@ -1075,6 +1075,73 @@ __global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs a, int n_h, 
   settle_and_publish(a, n_h, mode, refine, scores, key, best, seq, s_key);
 }
 
+// ---- exact scores at every decision of the running-best walk (base.cc:1891-1908) ---------------------------
+// The reference keeps hypothesis i when lcp_i > best so far (strict); the list of those records is what the
+// drop-in returns as hypothesisSet.  With tree-summed weighted scores an entry within the re-association error
+// of the then-running maximum could enter or stay out differently from the reference (DESIGN.md section 2,
+// divergence iv).  This kernel (one block; opt-in, pgp_set_exact_records) finds every NEAR-RECORD -- a
+// hypothesis whose tree score reaches the running maximum of the tree scores before it minus twice the
+// settlement tolerance -- and overwrites its score with the reference's own sequential sum
+// (refine_exact_group).  The running maximum is always attained at a record, every record and every
+// hypothesis that could displace or tie one is a near-record, and their values are now the reference's bit
+// for bit: the host walk over the score vector (pgp_running_best) returns the reference's list.  About
+// ln(n_h) + a few candidates per call; past kRecordCap (pathological) the rest keep their tree values.
+constexpr int kRecordCap = 512;
+__global__ __launch_bounds__(256) void settle_records_kernel(ScoreArgs a, int n_h, float* scores, float* __restrict__ seq,
+                                                             int* __restrict__ n_settled) {
+  __shared__ float s_cmax[256];
+  __shared__ int s_cnt[256];
+  __shared__ int s_list[kRecordCap];
+  __shared__ float s_stage[kRefineGroup][kSeqChunk];
+  __shared__ float s_exact[kRefineGroup];
+  __shared__ int s_cand[kRefineGroup];
+  const int tid = threadIdx.x;
+  const int per = (n_h + 255) / 256, lo = tid * per, hi = min(lo + per, n_h);
+  float m = 0.f;   // records are > 0 (best_LCP_ starts at 0)
+  for (int h = lo; h < hi; ++h) m = fmaxf(m, scores[h]);
+  s_cmax[tid] = m;
+  __syncthreads();
+  float run = 0.f;   // running maximum of the tree scores before this thread's chunk
+  for (int t = 0; t < tid; ++t) run = fmaxf(run, s_cmax[t]);
+  int cnt = 0;
+  {
+    float r = run;
+    for (int h = lo; h < hi; ++h) {
+      const float v = scores[h];
+      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), a.nQ)) ++cnt;
+      r = fmaxf(r, v);
+    }
+  }
+  s_cnt[tid] = cnt;
+  __syncthreads();
+  int off = 0;
+  for (int t = 0; t < tid; ++t) off += s_cnt[t];
+  {
+    float r = run;
+    for (int h = lo; h < hi; ++h) {
+      const float v = scores[h];
+      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), a.nQ)) {
+        if (off < kRecordCap) s_list[off] = h;
+        ++off;
+      }
+      r = fmaxf(r, v);
+    }
+  }
+  __syncthreads();
+  int total = 0;
+  for (int t = 0; t < 256; ++t) total += s_cnt[t];
+  total = min(total, kRecordCap);
+  for (int g0 = 0; g0 < total; g0 += kRefineGroup) {
+    const int G = min(kRefineGroup, total - g0);
+    if (tid < G) s_cand[tid] = s_list[g0 + tid];
+    __syncthreads();
+    refine_exact_group(a, s_cand, G, seq, s_stage, s_exact);
+    if (tid < G) scores[s_cand[tid]] = s_exact[tid];   // the reference's value, bit for bit
+    __syncthreads();
+  }
+  if (tid == 0 && n_settled) *n_settled = total;
+}
+
 __global__ void publish_none(int* __restrict__ best) {  // empty hypothesis list (base.cc:1791-1794)
   best[0] = -1;
   best[1] = 0;
@@ -1268,6 +1335,7 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best ? d_best : best_local);
   }
   PGP_HIP(hipGetLastError());
+  if (ctx->exact_records && n_h > 0) return launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, stream);
   return PGP_OK;
 }
 
@@ -1283,6 +1351,18 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
   if (rc != PGP_OK) return rc;
   hipLaunchKernelGGL(settle_best_kernel, dim3(1), dim3(256), 0, stream, a, n_h, mode, ctx->refine_best ? 1 : 0,
                      d_scores, d_best, ctx->d_seq.as<float>());
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+int launch_settle_records(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
+                          hipStream_t stream) {
+  if (n_h <= 0 || mode != PGP_MODE_WEIGHTED) return PGP_OK;   // plain counts are exact already
+  ScoreArgs a{};
+  int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
+  if (rc != PGP_OK) return rc;
+  hipLaunchKernelGGL(settle_records_kernel, dim3(1), dim3(256), 0, stream, a, n_h, d_scores, ctx->d_seq.as<float>(),
+                     (int*)nullptr);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

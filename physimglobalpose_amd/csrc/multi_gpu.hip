@@ -391,6 +391,11 @@ int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scor
     hipStream_t st = m->stream[0];
     int r = pgp_settle_best_device(m->ctx[0], m->d_T[0].as<float>(), n_h, mode, gate_deg, d_s, d_b, st);
     if (r != PGP_OK) return r;
+    // pgp_set_exact_records on device 0's context (pgp_multi_context(m, 0)) covers the group's calls too
+    if (m->ctx[0]->exact_records) {
+      r = pgp_settle_records_device(m->ctx[0], m->d_T[0].as<float>(), n_h, mode, gate_deg, d_s, st);
+      if (r != PGP_OK) return r;
+    }
     if (n_h > 0) PGP_HIP(hipMemcpyAsync(pin_out, d_s, (size_t)n_h * 8, hipMemcpyDeviceToHost, st));
     PGP_HIP(hipMemcpyAsync(pin_out + (size_t)n_h * 8, d_b, 8, hipMemcpyDeviceToHost, st));
     PGP_HIP(hipStreamSynchronize(st));

@@ -380,6 +380,27 @@ int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, floa
   return rc;
 }
 
+int pgp_set_exact_records(pgp_ctx* ctx, int on) {
+  if (!ctx) {
+    set_error("pgp_set_exact_records: ctx is NULL");
+    return PGP_EINVAL;
+  }
+  ctx->exact_records = on != 0;
+  return PGP_OK;
+}
+
+int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
+                              void* stream) {
+  if (!ctx || n_h < 0 || (n_h > 0 && (!d_T || !d_scores))) {
+    set_error("pgp_settle_records_device: bad argument");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx);
+  const int rc = launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
+}
+
 int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
                            float* d_scores, int* d_best, void* stream) {
   if (!ctx || n_h < 0 || !d_best || (n_h > 0 && (!d_T || !d_scores))) {

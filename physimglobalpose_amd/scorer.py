@@ -473,6 +473,11 @@ class LcpScorer:
         _lib.check(self._lib.pgp_find_congruent_4pcs(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
         return out[: min(n.value, cap)].copy()
 
+    def set_exact_records(self, on=True):
+        """Weighted scoring calls also settle every near-record of the running-best walk exactly
+        (pgp_set_exact_records): running_best(scores) is then the reference's list."""
+        _lib.check(self._lib.pgp_set_exact_records(self._h, int(bool(on))))
+
     @staticmethod
     def running_best(scores):
         scores = _f32(scores)

@@ -615,6 +615,8 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   std::vector<float> lcp(n_h);
   int best = -1;
   float best_lcp = 0.f;
+  // hypothesisSet is the running-best list: its entries are decided on exact (reference-order) sums
+  SHIM_PGP(pgp_set_exact_records(ctx, 1));
   if (st.group)
     SHIM_PGP(pgp_multi_score_lcp(st.group, allT.data(), n_h, PGP_MODE_WEIGHTED, 30.f, lcp.data(), nullptr, &best,
                                  &best_lcp));
