@@ -76,8 +76,10 @@ struct DeviceGuard {
 // kernels they launched still read the context's arrays (clouds, index, workspaces), and the host-pointer
 // entry points rewrite those arrays on the context's own non-blocking stream.
 struct CtxGuard : DeviceGuard {
-  explicit CtxGuard(pgp_ctx* ctx) : DeviceGuard(ctx->device) {
-    if (ok && ctx->device_work_pending) {
+  // join = false for the *_device entry points themselves: they queue on the caller's stream, behind whatever
+  // the caller queued there before, and must not touch another stream while the caller may be capturing a graph
+  explicit CtxGuard(pgp_ctx* ctx, bool join = true) : DeviceGuard(ctx->device) {
+    if (join && ok && ctx->device_work_pending) {
       if (hipStreamWaitEvent(ctx->stream, ctx->ev_device_work, 0) == hipSuccess) ctx->device_work_pending = false;
       else (void)hipDeviceSynchronize();
     }
@@ -87,6 +89,11 @@ struct CtxGuard : DeviceGuard {
 // after a *_device entry point has queued work on `stream`
 inline void note_device_work(pgp_ctx* ctx, hipStream_t stream) {
   if (stream == ctx->stream) return;
+  // a stream that is being captured into a graph runs nothing now: an event recorded there would be a graph
+  // node, and the context's own stream waiting on it would invalidate the capture.  Whoever replays the
+  // graph orders the replays against later calls on the context.
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
   if (!ctx->ev_device_work && hipEventCreateWithFlags(&ctx->ev_device_work, hipEventDisableTiming) != hipSuccess) {
     ctx->ev_device_work = nullptr;
     (void)hipStreamSynchronize(stream);   // no event: fall back to completing the work now
@@ -373,7 +380,7 @@ int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, floa
     set_error("pgp_score_lcp_device: bad argument");
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   const int rc = launch_score(ctx, d_T, n_h, mode, gate_deg, d_scores, d_counts, d_best,
                               static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
@@ -395,7 +402,7 @@ int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode,
     set_error("pgp_settle_records_device: bad argument");
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   const int rc = launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
   return rc;
@@ -407,7 +414,7 @@ int pgp_settle_best_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, fl
     set_error("pgp_settle_best_device: bad argument");
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   const int rc = launch_settle_best(ctx, d_T, n_h, mode, gate_deg, d_scores, d_best, static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
   return rc;
@@ -654,7 +661,7 @@ int pgp_rigid_from_congruent_device(pgp_ctx* ctx, const int* d_base_ids, const i
     set_error("pgp_rigid_from_congruent_device: bad argument");
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   const int rc = launch_rigid(ctx, d_base_ids, d_quad_ids, n, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms,
                               static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
@@ -850,7 +857,7 @@ int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const
     set_error("pgp_icp_refine_ex_device: bad argument");
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   const int rc = launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src, reinterpret_cast<const float4*>(d_tgt4),
                     reinterpret_cast<const float4*>(d_tgt_n4), n_tgt, d_T, n, opt, d_energy, d_iters,
                     static_cast<hipStream_t>(stream));
@@ -1009,7 +1016,7 @@ int pgp_set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, c
     set_error("pgp_set_scene_device: bad argument (n=%d, delta=%g)", n, (double)delta);
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   hipStream_t st = static_cast<hipStream_t>(stream);
   PGP_HIP(hipStreamSynchronize(st));   // the producer of d_xyz
   PGP_HIP(hipDeviceSynchronize());     // queued launches may still read the arrays replaced below
@@ -1023,7 +1030,7 @@ int pgp_voxel_grid_device(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, f
     set_error("pgp_voxel_grid_device: bad argument");
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   return launch_voxel_grid(ctx, d_xyz, n, leaf, d_out_xyz, cap, n_out, static_cast<hipStream_t>(stream));
 }
 
@@ -1062,7 +1069,7 @@ int pgp_mls_normals_device(pgp_ctx* ctx, const float* d_xyz, int n, float radius
   }
   *n_out = 0;
   if (n == 0) return PGP_OK;
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   return launch_mls(ctx, d_xyz, n, radius, d_out_xyz, d_out_nrm, d_out_curvature, d_out_index, cap, n_out,
                     static_cast<hipStream_t>(stream));
 }
@@ -1147,7 +1154,7 @@ int pgp_backproject_depth_device(pgp_ctx* ctx, const void* d_image, int raw16, c
   *n_out = 0;
   const size_t n = (size_t)rows * cols;
   if (n == 0) return PGP_OK;
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   const size_t nb = (n + 255) / 256;
   const size_t ctr_bytes = ((nb + 1) * 4 + 255) & ~(size_t)255;
   const size_t scan_bytes = ((nb / 2048 + 4) * 4 + 255) & ~(size_t)255;
@@ -1170,7 +1177,7 @@ int pgp_cluster_poses_device(pgp_ctx* ctx, const float* d_T, const float* d_scor
   if (n_h == 0) return PGP_OK;
   const pgp_cluster_params dflt = {0.5f, 10.f, 0.02f};  // HypothesisSelection.cpp:70,99
   if (!params) params = &dflt;
-  CtxGuard guard(ctx);
+  CtxGuard guard(ctx, false);
   int m = 0;
   return launch_cluster(ctx, d_T, d_scores, n_h, best_score, sym_deg, params, d_rep_index, d_assignment, &m, n_rep,
                         static_cast<hipStream_t>(stream));
