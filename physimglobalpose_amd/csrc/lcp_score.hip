@@ -1079,22 +1079,20 @@ __global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs a, int n_h, 
 // The reference keeps hypothesis i when lcp_i > best so far (strict); the list of those records is what the
 // drop-in returns as hypothesisSet.  With tree-summed weighted scores an entry within the re-association error
 // of the then-running maximum could enter or stay out differently from the reference (DESIGN.md section 2,
-// divergence iv).  This kernel (one block; opt-in, pgp_set_exact_records) finds every NEAR-RECORD -- a
+// divergence iv).  Three small launches (opt-in, pgp_set_exact_records) find every NEAR-RECORD -- a
 // hypothesis whose tree score reaches the running maximum of the tree scores before it minus twice the
-// settlement tolerance -- and overwrites its score with the reference's own sequential sum
-// (refine_exact_group).  The running maximum is always attained at a record, every record and every
+// settlement tolerance --, compute the registered weight of every (near-record, model point) in parallel and
+// overwrite each near-record's score with the reference's own sequential sum, one lane per near-record.  The running maximum is always attained at a record, every record and every
 // hypothesis that could displace or tie one is a near-record, and their values are now the reference's bit
 // for bit: the host walk over the score vector (pgp_running_best) returns the reference's list.  About
 // ln(n_h) + a few candidates per call; past kRecordCap (pathological) the rest keep their tree values.
-constexpr int kRecordCap = 512;
-__global__ __launch_bounds__(256) void settle_records_kernel(ScoreArgs a, int n_h, float* scores, float* __restrict__ seq,
-                                                             int* __restrict__ n_settled) {
+constexpr int kRecordCap = 128;
+
+// 1. the near-records, in index order (one block)
+__global__ __launch_bounds__(256) void records_find(int n_h, int nQ, const float* __restrict__ scores,
+                                                    int* __restrict__ list, int* __restrict__ count) {
   __shared__ float s_cmax[256];
   __shared__ int s_cnt[256];
-  __shared__ int s_list[kRecordCap];
-  __shared__ float s_stage[kRefineGroup][kSeqChunk];
-  __shared__ float s_exact[kRefineGroup];
-  __shared__ int s_cand[kRefineGroup];
   const int tid = threadIdx.x;
   const int per = (n_h + 255) / 256, lo = tid * per, hi = min(lo + per, n_h);
   float m = 0.f;   // records are > 0 (best_LCP_ starts at 0)
@@ -1108,7 +1106,7 @@ __global__ __launch_bounds__(256) void settle_records_kernel(ScoreArgs a, int n_
     float r = run;
     for (int h = lo; h < hi; ++h) {
       const float v = scores[h];
-      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), a.nQ)) ++cnt;
+      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), nQ)) ++cnt;
       r = fmaxf(r, v);
     }
   }
@@ -1120,26 +1118,69 @@ __global__ __launch_bounds__(256) void settle_records_kernel(ScoreArgs a, int n_
     float r = run;
     for (int h = lo; h < hi; ++h) {
       const float v = scores[h];
-      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), a.nQ)) {
-        if (off < kRecordCap) s_list[off] = h;
+      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), nQ)) {
+        if (off < kRecordCap) list[off] = h;
         ++off;
       }
       r = fmaxf(r, v);
     }
   }
-  __syncthreads();
-  int total = 0;
-  for (int t = 0; t < 256; ++t) total += s_cnt[t];
-  total = min(total, kRecordCap);
-  for (int g0 = 0; g0 < total; g0 += kRefineGroup) {
-    const int G = min(kRefineGroup, total - g0);
-    if (tid < G) s_cand[tid] = s_list[g0 + tid];
+  if (tid == 255) *count = min(off, kRecordCap);   // the last thread's running offset is the total
+}
+
+// 2. the registered weight of every (near-record, model point), one row of nQ4 floats per near-record in
+//    ORIGINAL model order (+0.0f where the point does not register: the identity on the running sum)
+__global__ __launch_bounds__(256) void records_weights(ScoreArgs a, const int* __restrict__ list,
+                                                       const int* __restrict__ count, float* __restrict__ seq) {
+  const int k = blockIdx.y;
+  if (k >= *count) return;
+  const int nQ4 = (a.nQ + 3) & ~3;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nQ4) return;
+  float* row = seq + (size_t)k * nQ4;
+  if (i >= a.nQ) {   // padding up to a multiple of four
+    row[i] = 0.0f;
+    return;
+  }
+  const Xf m = load_xf(a.T, (uint32_t)list[k]);
+  const int id = point_hit<PGP_MODE_WEIGHTED>(a, m, i);
+  row[__float_as_int(a.Q[i].w)] = id >= 0 ? a.Pnw[id].w : 0.0f;
+}
+
+// 3. a block per kRefineGroup near-records: their rows are staged through LDS (the whole block loads, at
+//    bandwidth) and ONE lane per near-record adds its row sequentially in model order (base.cc:1759), then
+//    overwrites the score with the reference's value (base.cc:1765).  Blocks run side by side, so the time is
+//    one row's 5000 dependent adds whatever the number of near-records.
+__global__ __launch_bounds__(256) void records_sum(int nQ, const int* __restrict__ list, const int* __restrict__ count,
+                                                   const float* __restrict__ seq, float* __restrict__ scores) {
+  __shared__ float s_stage[kRefineGroup][kSeqChunk];
+  const int g0 = blockIdx.x * kRefineGroup;
+  const int n = *count;
+  if (g0 >= n) return;
+  const int G = min(kRefineGroup, n - g0);
+  const int nQ4 = (nQ + 3) & ~3;
+  float S = 0.0f;   // lane g's running sum (base.cc:1737 `Scalar weighted_match = 0`)
+  for (int c0 = 0; c0 < nQ4; c0 += kSeqChunk) {
+    const int len = min(kSeqChunk, nQ4 - c0);   // a multiple of four
+    for (int g = 0; g < G; ++g)
+      for (int i = threadIdx.x; i < len; i += blockDim.x) s_stage[g][i] = seq[(size_t)(g0 + g) * nQ4 + c0 + i];
     __syncthreads();
-    refine_exact_group(a, s_cand, G, seq, s_stage, s_exact);
-    if (tid < G) scores[s_cand[tid]] = s_exact[tid];   // the reference's value, bit for bit
+    if ((int)threadIdx.x < G) {
+      const float4* v = reinterpret_cast<const float4*>(s_stage[threadIdx.x]);
+      const int n4 = len / 4;
+      float4 cur = v[0];
+      for (int i = 0; i < n4; ++i) {
+        const float4 nxt = v[min(i + 1, n4 - 1)];   // the next read is in flight under this trip's adds
+        S = __fadd_rn(S, cur.x);
+        S = __fadd_rn(S, cur.y);
+        S = __fadd_rn(S, cur.z);
+        S = __fadd_rn(S, cur.w);
+        cur = nxt;
+      }
+    }
     __syncthreads();
   }
-  if (tid == 0 && n_settled) *n_settled = total;
+  if ((int)threadIdx.x < G) scores[list[g0 + threadIdx.x]] = __fdiv_rn(S, (float)nQ);
 }
 
 __global__ void publish_none(int* __restrict__ best) {  // empty hypothesis list (base.cc:1791-1794)
@@ -1355,14 +1396,26 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
   return PGP_OK;
 }
 
+int records_workspace_bytes(int nQ) { return (int)(((size_t)(((nQ > 0 ? nQ : 1) + 3) & ~3) * kRecordCap + kRecordCap + 64) * 4); }
+
 int launch_settle_records(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                           hipStream_t stream) {
   if (n_h <= 0 || mode != PGP_MODE_WEIGHTED) return PGP_OK;   // plain counts are exact already
   ScoreArgs a{};
   int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
-  hipLaunchKernelGGL(settle_records_kernel, dim3(1), dim3(256), 0, stream, a, n_h, d_scores, ctx->d_seq.as<float>(),
-                     (int*)nullptr);
+  if (ctx->d_rec_ws.cap < (size_t)records_workspace_bytes(ctx->nQ)) {
+    set_error("exact records: workspace not reserved (pgp_set_exact_records after pgp_set_model)");
+    return PGP_ESTATE;
+  }
+  int* list = ctx->d_rec_ws.as<int>();          // [kRecordCap] near-records | count | weights
+  int* count = list + kRecordCap;
+  float* seq = reinterpret_cast<float*>(list + kRecordCap + 64);
+  hipLaunchKernelGGL(records_find, dim3(1), dim3(256), 0, stream, n_h, a.nQ, (const float*)d_scores, list, count);
+  hipLaunchKernelGGL(records_weights, dim3((a.nQ + 3 + 255) / 256, kRecordCap), dim3(256), 0, stream, a, (const int*)list,
+                     (const int*)count, seq);
+  hipLaunchKernelGGL(records_sum, dim3((kRecordCap + kRefineGroup - 1) / kRefineGroup), dim3(256), 0, stream, a.nQ,
+                     (const int*)list, (const int*)count, (const float*)seq, d_scores);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

@@ -182,7 +182,7 @@ int pgp_destroy(pgp_ctx* ctx) {
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
-                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
+                    &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
@@ -343,6 +343,7 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
   if ((rc = ctx->d_Qn.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
   if ((rc = ctx->d_hits.ensure(hq.size() * sizeof(int))) != PGP_OK) return rc;
   if ((rc = ctx->d_seq.ensure(4 * (hq.size() + 4) * sizeof(float))) != PGP_OK) return rc;  // kRefineGroup rows
+  if (ctx->exact_records && (rc = ctx->d_rec_ws.ensure((size_t)records_workspace_bytes(n))) != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(ctx->d_Q.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipMemcpyAsync(ctx->d_Qn.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipStreamSynchronize(ctx->stream));
@@ -392,6 +393,11 @@ int pgp_set_exact_records(pgp_ctx* ctx, int on) {
     set_error("pgp_set_exact_records: ctx is NULL");
     return PGP_EINVAL;
   }
+  if (on) {
+    CtxGuard guard(ctx);
+    int rc = ctx->d_rec_ws.ensure((size_t)records_workspace_bytes(ctx->nQ));
+    if (rc != PGP_OK) return rc;
+  }
   ctx->exact_records = on != 0;
   return PGP_OK;
 }
@@ -403,7 +409,9 @@ int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode,
     return PGP_EINVAL;
   }
   CtxGuard guard(ctx, false);
-  const int rc = launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, static_cast<hipStream_t>(stream));
+  int rc = ctx->d_rec_ws.ensure((size_t)records_workspace_bytes(ctx->nQ));
+  if (rc != PGP_OK) return rc;
+  rc = launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
   return rc;
 }

@@ -143,6 +143,7 @@ struct pgp_ctx {
   int hpb_override = 0;
   bool refine_best = true;   // PGP_REFINE=0 switches the exact near-tie re-score off (timing A/B only)
   bool exact_records = false;   // pgp_set_exact_records: weighted scores exact at every running-best decision
+  pgp::DevBuf d_rec_ws;         // its workspace: near-record list | count | weights [nQ][kRecordCap]
 
   // optional per-kernel timing (pgp_set_kernel_timing)
   int timing = 0;               // 0 off, N >= 1: every Nth scoring launch carries start/stop events
@@ -192,6 +193,7 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
                        int* d_best, hipStream_t stream);
 int launch_settle_records(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                           hipStream_t stream);
+int records_workspace_bytes(int nQ);
 int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q, const float4* d_qn, int n,
                             float gate_deg, int* d_hits, hipStream_t stream);
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
