@@ -47,7 +47,7 @@ namespace pgp {
 
 namespace {
 
-constexpr int kTile = 256;    // model points per workgroup
+constexpr int kTile = 256;    // model points per workgroup (512 = 8 waves: +6 us per C2 step at its best hpb)
 constexpr int kMaxHpb = 64;   // hypotheses per workgroup (LDS partial slots)
 
 struct Xf {  // one hypothesis, wave-uniform (SGPRs)

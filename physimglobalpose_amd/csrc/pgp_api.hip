@@ -74,14 +74,26 @@ struct DeviceGuard {
 // Entry-point guard of a context: selects its device and orders this call behind whatever an earlier
 // *_device call queued on the CALLER's stream -- those calls return without synchronising while the
 // kernels they launched still read the context's arrays (clouds, index, workspaces), and the host-pointer
-// entry points rewrite those arrays on the context's own non-blocking stream.
+// entry points rewrite those arrays on the context's own non-blocking stream.  The *_device call only notes
+// the stream (an event record per call costs the scoring step 3 us: a barrier packet between back-to-back
+// steps); the event is recorded HERE, at the stream's tail -- behind everything queued before -- when a later
+// call actually needs the order.
 struct CtxGuard : DeviceGuard {
   // join = false for the *_device entry points themselves: they queue on the caller's stream, behind whatever
   // the caller queued there before, and must not touch another stream while the caller may be capturing a graph
   explicit CtxGuard(pgp_ctx* ctx, bool join = true) : DeviceGuard(ctx->device) {
     if (join && ok && ctx->device_work_pending) {
-      if (hipStreamWaitEvent(ctx->stream, ctx->ev_device_work, 0) == hipSuccess) ctx->device_work_pending = false;
-      else (void)hipDeviceSynchronize();
+      bool ordered = false;
+      if (!ctx->ev_device_work && hipEventCreateWithFlags(&ctx->ev_device_work, hipEventDisableTiming) != hipSuccess)
+        ctx->ev_device_work = nullptr;
+      if (ctx->ev_device_work && hipEventRecord(ctx->ev_device_work, ctx->device_work_stream) == hipSuccess &&
+          hipStreamWaitEvent(ctx->stream, ctx->ev_device_work, 0) == hipSuccess)
+        ordered = true;
+      if (!ordered) {   // e.g. the caller has destroyed that stream since (then its work is complete anyway)
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+      }
+      ctx->device_work_pending = false;
     }
   }
 };
@@ -89,18 +101,12 @@ struct CtxGuard : DeviceGuard {
 // after a *_device entry point has queued work on `stream`
 inline void note_device_work(pgp_ctx* ctx, hipStream_t stream) {
   if (stream == ctx->stream) return;
-  // a stream that is being captured into a graph runs nothing now: an event recorded there would be a graph
-  // node, and the context's own stream waiting on it would invalidate the capture.  Whoever replays the
-  // graph orders the replays against later calls on the context.
+  // a stream that is being captured into a graph runs nothing now; whoever replays the graph orders the
+  // replays against later calls on the context
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
-  if (!ctx->ev_device_work && hipEventCreateWithFlags(&ctx->ev_device_work, hipEventDisableTiming) != hipSuccess) {
-    ctx->ev_device_work = nullptr;
-    (void)hipStreamSynchronize(stream);   // no event: fall back to completing the work now
-    return;
-  }
-  if (hipEventRecord(ctx->ev_device_work, stream) == hipSuccess) ctx->device_work_pending = true;
-  else (void)hipStreamSynchronize(stream);
+  ctx->device_work_stream = stream;
+  ctx->device_work_pending = true;
 }
 
 inline uint32_t spread10(uint32_t v) {
@@ -174,7 +180,7 @@ int pgp_create(pgp_ctx** out, int device_id) {
 int pgp_destroy(pgp_ctx* ctx) {
   if (!ctx) return PGP_OK;
   CtxGuard guard(ctx);
-  if (ctx->device_work_pending) (void)hipEventSynchronize(ctx->ev_device_work);
+  if (ctx->device_work_pending) (void)hipDeviceSynchronize();
   if (ctx->ev_device_work) (void)hipEventDestroy(ctx->ev_device_work);
   if (ctx->stream) {
     hipError_t e = hipStreamSynchronize(ctx->stream);

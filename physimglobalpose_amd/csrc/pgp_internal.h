@@ -57,6 +57,7 @@ struct pgp_ctx {
   // a *_device call returns with its kernels still queued on the caller's stream; the next entry point
   // makes `stream` wait for this event before it touches the context's arrays (pgp_api.hip CtxGuard)
   hipEvent_t ev_device_work = nullptr;
+  hipStream_t device_work_stream = nullptr;   // the caller's stream of the last *_device call
   bool device_work_pending = false;
 
   // scene
