@@ -18,8 +18,8 @@
  * must not overlap (the reference is single-threaded: main.cpp:212), distinct contexts are
  * independent.  The *_device entry points queue their kernels on the caller's stream and return; a
  * context serves ONE such stream at a time (its workspaces are shared), and any later call on the
- * context -- pgp_set_model, pgp_set_scene, a host-pointer scoring call ... -- is ordered behind the
- * queued work by an event, so the arrays a queued kernel reads are never rewritten under it.
+ * host-pointer call on the context -- pgp_set_model, pgp_set_scene, pgp_score_lcp ... -- first waits for
+ * the queued work (a device synchronisation), so the arrays a queued kernel reads are never rewritten under it.
  * There is NO CPU fallback: without a usable HIP device pgp_create() fails.
  */
 #ifndef PGP_H

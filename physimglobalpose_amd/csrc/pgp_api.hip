@@ -74,25 +74,17 @@ struct DeviceGuard {
 // Entry-point guard of a context: selects its device and orders this call behind whatever an earlier
 // *_device call queued on the CALLER's stream -- those calls return without synchronising while the
 // kernels they launched still read the context's arrays (clouds, index, workspaces), and the host-pointer
-// entry points rewrite those arrays on the context's own non-blocking stream.  The *_device call only notes
-// the stream (an event record per call costs the scoring step 3 us: a barrier packet between back-to-back
-// steps); the event is recorded HERE, at the stream's tail -- behind everything queued before -- when a later
-// call actually needs the order.
+// entry points rewrite those arrays on the context's own non-blocking stream.  The *_device call only sets
+// a flag; the next host-pointer call (synchronous by contract anyway) drains the device first.  Two things
+// that were tried and dropped: an event recorded after every *_device call cost the scoring step 3 us (a
+// barrier packet between back-to-back steps); recording it lazily here, on the caller's stream, is unsafe --
+// the caller may have destroyed that stream, and HIP dereferences the stale handle.
 struct CtxGuard : DeviceGuard {
   // join = false for the *_device entry points themselves: they queue on the caller's stream, behind whatever
-  // the caller queued there before, and must not touch another stream while the caller may be capturing a graph
+  // the caller queued there before, and must not synchronise anything while the caller may be capturing a graph
   explicit CtxGuard(pgp_ctx* ctx, bool join = true) : DeviceGuard(ctx->device) {
     if (join && ok && ctx->device_work_pending) {
-      bool ordered = false;
-      if (!ctx->ev_device_work && hipEventCreateWithFlags(&ctx->ev_device_work, hipEventDisableTiming) != hipSuccess)
-        ctx->ev_device_work = nullptr;
-      if (ctx->ev_device_work && hipEventRecord(ctx->ev_device_work, ctx->device_work_stream) == hipSuccess &&
-          hipStreamWaitEvent(ctx->stream, ctx->ev_device_work, 0) == hipSuccess)
-        ordered = true;
-      if (!ordered) {   // e.g. the caller has destroyed that stream since (then its work is complete anyway)
-        (void)hipGetLastError();
-        (void)hipDeviceSynchronize();
-      }
+      (void)hipDeviceSynchronize();
       ctx->device_work_pending = false;
     }
   }
@@ -105,7 +97,6 @@ inline void note_device_work(pgp_ctx* ctx, hipStream_t stream) {
   // replays against later calls on the context
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
-  ctx->device_work_stream = stream;
   ctx->device_work_pending = true;
 }
 
@@ -180,8 +171,6 @@ int pgp_create(pgp_ctx** out, int device_id) {
 int pgp_destroy(pgp_ctx* ctx) {
   if (!ctx) return PGP_OK;
   CtxGuard guard(ctx);
-  if (ctx->device_work_pending) (void)hipDeviceSynchronize();
-  if (ctx->ev_device_work) (void)hipEventDestroy(ctx->ev_device_work);
   if (ctx->stream) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)e;

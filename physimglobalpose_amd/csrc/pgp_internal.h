@@ -54,10 +54,8 @@ struct DevBuf {
 struct pgp_ctx {
   int device = 0;
   hipStream_t stream = nullptr;  // internal stream for the synchronous host-pointer API
-  // a *_device call returns with its kernels still queued on the caller's stream; the next entry point
-  // makes `stream` wait for this event before it touches the context's arrays (pgp_api.hip CtxGuard)
-  hipEvent_t ev_device_work = nullptr;
-  hipStream_t device_work_stream = nullptr;   // the caller's stream of the last *_device call
+  // a *_device call returns with its kernels still queued on the caller's stream; the next host-pointer
+  // entry point drains the device before it touches the context's arrays (pgp_api.hip CtxGuard)
   bool device_work_pending = false;
 
   // scene
