@@ -64,3 +64,19 @@ def test_device_pointer_form():
     assert m == len(host[3])
     assert np.array_equal(ox[:m].cpu().numpy(), host[0]) and np.array_equal(on[:m].cpu().numpy(), host[1])
     assert np.array_equal(oc[:m].cpu().numpy(), host[2]) and np.array_equal(oi[:m].cpu().numpy(), host[3])
+
+
+def test_degenerate_neighbourhoods_follow_the_restatement():
+    """collinear points, an exact planar lattice, coincident points: whatever PCL's closed forms make of a
+    rank-deficient covariance (zero roots, zero-length cross products -> NaN), the kernel makes the same"""
+    sc = LcpScorer(0)
+    line = np.stack([np.arange(12) * 0.004, np.zeros(12), np.full(12, 0.5)], 1).astype(np.float32)
+    lattice = np.stack(np.meshgrid(np.arange(8) * 0.005, np.arange(8) * 0.005, [0.7], indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    same = np.tile(np.array([[0.1, 0.2, 0.6]], np.float32), (9, 1))
+    for cloud in (line, lattice, same, np.vstack([line, lattice + np.float32(1.0)])):
+        got, want = sc.mls_normals(cloud, 0.02), oracle_mls(cloud, 0.02)
+        assert np.array_equal(got[3], want[3])
+        for g, w in zip(got[:3], want[:3]):
+            assert np.array_equal(np.isnan(g), np.isnan(w))
+            ok = ~np.isnan(w)
+            assert np.allclose(g[ok], w[ok], rtol=1e-5, atol=2e-6)
