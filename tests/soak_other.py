@@ -70,6 +70,8 @@ def main():
         K = np.array([[rng.uniform(200, 900), 0, cols / 2], [0, rng.uniform(200, 900), rows / 2], [0, 0, 1]], np.float32)
         assert np.array_equal(sc.backproject_depth(raw, K, mask), oracle_backproject(raw, mask, K)), f"backproject, case {n}"
         n += 1
+        if n % 100 == 0:   # a silent GPU job is taken for hung after a few minutes
+            print(f"... {n} cases, {time.time() - t0:.0f} s", flush=True)
     print(f"fuzz ok: {n} random cases of congruent sets / rigid fits / clustering / back-projection, {time.time() - t0:.0f} s")
 
 

@@ -53,6 +53,8 @@ def main():
             # the returned best pose is the reference's, near-ties included (exact settlement on the device)
             assert biw == biwo and (biw < 0 or abs(bsw - swo[biw]) <= 2e-6), f"weighted best mismatch, seed {seed}"
         n_cases += 1
+        if n_cases % 100 == 0:   # a silent GPU job is taken for hung after a few minutes
+            print(f"... {n_cases} cases, {time.time() - t0:.0f} s", flush=True)
         n_hyp += n_h
     print(f"fuzz ok: {n_cases} random cases, {n_hyp} hypotheses, {time.time() - t0:.0f} s, seeds {seed0}..{seed0 + n_cases - 1}")
 
