@@ -42,6 +42,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 namespace pgp {
 
@@ -49,6 +50,19 @@ namespace {
 
 constexpr int kTile = 256;    // model points per workgroup (512 = 8 waves: +6 us per C2 step at its best hpb)
 constexpr int kMaxHpb = 64;   // hypotheses per workgroup (LDS partial slots)
+
+#if defined(PGP_ABLATE) && PGP_ABLATE == 10
+// timing experiment: where a wave's time goes.  s_memtime stamps around the phases of a trip, summed per wave
+// in SGPRs and added to g_phase at the end (read by pgp_debug_phase_cycles).  The stamps wait for the scalar
+// loads in flight, so the figures are a decomposition, not the undisturbed kernel.
+constexpr int kPhaseWaves = 65536;
+__device__ unsigned long long g_phase[kPhaseWaves][8];   // one row per wave of the launch: no atomics (they would dominate)
+#define PGP_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define PGP_PHASE(idx, t0, t1) ph[idx] += (t1) - (t0)
+#else
+#define PGP_STAMP(var)
+#define PGP_PHASE(idx, t0, t1)
+#endif
 
 struct Xf {  // one hypothesis, wave-uniform (SGPRs)
   float m00, m10, m20, m01, m11, m21, m02, m12, m22, m03, m13, m23;
@@ -515,10 +529,14 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
   // per-trip bookkeeping is kept to a handful of scalar instructions and off the empty path.
   unsigned long long cnt_pack = 0ull;
   uint32_t wrote = 0u;
+#if defined(PGP_ABLATE) && PGP_ABLATE == 10
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
 
   // one hypothesis (slot hs = h - h0 of the chunk) under its 4x4 `m`
   auto trip = [&](const int hs, const Xf& m) {
     const int gs = hs & (kSumGroup - 1);   // slot in the group
+    PGP_STAMP(t_a);
 #if defined(PGP_ABLATE) && PGP_ABLATE == 7
     // timing experiment: no transform (and the 8 KB of words of experiment 4)
     const float x = q.x + m.m03, y = q.y + m.m13, z = q.z + m.m23;
@@ -547,6 +565,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     // lanes whose cell holds a candidate run; the second look-up runs for those lanes only
     const bool occ = __builtin_amdgcn_ubfe(lo, bit, 1) != 0u;
     const unsigned long long am = __ballot(occ);
+    PGP_STAMP(t_b);   // the occupancy word has arrived
+    PGP_PHASE(0, t_a, t_b);
     if (am == 0ull) return;   // 35 % of the wave-iterations at C2 end here: count 0, no row of s_w
     uint32_t s = 0u, len = 0u;
     if (occ) {
@@ -560,6 +580,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     const uint32_t incl = wave_inclusive_scan(len);
     const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);   // >= 1
     const uint32_t pre = incl - len;
+    PGP_STAMP(t_c);   // run descriptors + scan
+    PGP_PHASE(1, t_b, t_c);
     // result of the candidate phase per owner lane: plain 0 / 1, weighted the scene id of the nearest
     // candidate within delta (all ones = -1: none)
     uint32_t rlo = kW ? 0xFFFFFFFFu : 0u;
@@ -573,6 +595,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
       }
       __builtin_amdgcn_wave_barrier();
+      PGP_STAMP(t_d);   // owner table written
+      PGP_PHASE(2, t_c, t_d);
       const uint32_t start_key = sel_mask(am, pre, 0xFFFFFFFFu);
       // batches of NC chunks of 64 slots: owner resolution, then ALL candidate loads, then tests.
       // Half of the non-empty wave-iterations need a single chunk (median W = 6 at C2), so the
@@ -594,6 +618,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         }
       }
       __builtin_amdgcn_wave_barrier();
+      PGP_STAMP(t_e);   // all batches done
+      PGP_PHASE(3, t_d, t_e);
       if ((uint32_t)lane < ((W + 63u) >> 6)) marks[lane] = 0ull;  // clear the bits for the next iteration
       // the low word of the owner's result: plain 0 / 1; weighted the id of the minimum key, -1 if none
       if (occ) rlo = reinterpret_cast<const uint32_t*>(res)[2 * r];
@@ -602,6 +628,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       if (!kW) rlo = any_in_run(cand, s, s + len, x, y, z, a.sq_eps) ? 1u : 0u;
       else rlo = (uint32_t)nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
     }
+    PGP_STAMP(t_f);   // results read back
     unsigned long long hm;   // lanes whose model point registers under this hypothesis
     if (!kW) {
       hm = __ballot(rlo != 0u);
@@ -628,6 +655,9 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       wrote |= 1u << gs;
     }
     cnt_pack |= (unsigned long long)(uint32_t)__popcll(hm) << (8 * gs);
+    PGP_STAMP(t_g);   // gate + weight parked
+    PGP_PHASE(4, t_f, t_g);
+    PGP_PHASE(5, t_b, t_g);   // the whole non-empty part
   };
 
   // after the last hypothesis of a group (slots g0s .. g0s + n - 1 of the chunk): lane 16k publishes slot k
@@ -672,6 +702,13 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     trip(hs, m);
     if (((hs & (kSumGroup - 1)) == kSumGroup - 1) || hs == n_slots - 1) publish(hs & ~(kSumGroup - 1), (hs & (kSumGroup - 1)) + 1);
   }
+#if defined(PGP_ABLATE) && PGP_ABLATE == 10
+  if (lane == 0) {
+    const int wid = (blockIdx.x * (kTile / 64) + wave) % kPhaseWaves;
+    for (int k = 0; k < 8; ++k) g_phase[wid][k] = ph[k];
+    g_phase[wid][7] = 1ull;   // this wave ran
+  }
+#endif
   __syncthreads();
   const int hh = threadIdx.x;
   if (hh < h1 - h0) {
@@ -1506,5 +1543,21 @@ int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }
+
+#if defined(PGP_ABLATE) && PGP_ABLATE == 10
+extern "C" int pgp_debug_phase_cycles(unsigned long long* out16, int reset) {
+  // sums over the waves of the LAST launch(es) since the last reset: out16[0..6] phase ticks, out16[7] waves
+  std::vector<unsigned long long> h((size_t)kPhaseWaves * 8);
+  if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_phase), h.size() * 8) != hipSuccess) return -1;
+  for (int k = 0; k < 16; ++k) out16[k] = 0;
+  for (int w = 0; w < kPhaseWaves; ++w)
+    for (int k = 0; k < 8; ++k) out16[k] += h[(size_t)w * 8 + k];
+  if (reset) {
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), h.data(), h.size() * 8) != hipSuccess) return -1;
+  }
+  return 0;
+}
+#endif
 
 }  // namespace pgp
