@@ -272,8 +272,9 @@ int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids,
  * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and
  * pcl::IterativeClosestPoint::align (utilities.cpp:697-703; PPE/data_layer/SceneCfg.cpp:101,135-141)
  * for a batch of n initial guesses at once.  PCL is not vendored in the reference, so the
- * arithmetic is this library's own statement of the algorithm: nearest neighbour by
- * exhaustive search, keep the |trim*n_src| closest pairs (or those within max_corr_dist), Horn's
+ * arithmetic is this library's own statement of the algorithm: exact nearest neighbour
+ * (an index over the static target, identical to an exhaustive search: smallest d2, then lowest
+ * index), keep the |trim*n_src| closest pairs (or those within max_corr_dist), Horn's
  * closed-form rigid update, repeat while mean-squared-distance / previous < energy_ratio. */
 typedef struct {
   int max_iterations;    /* <= 0: 100 (utilities.cpp:698); TrimmedICP itself is unbounded */
@@ -289,13 +290,23 @@ typedef struct {
  * Host pointers, synchronous. */
 int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt,
                    float* T, int n, const pgp_icp_params* params, float* energy, int* iters);
-/* Device pointers: d_src / d_tgt are float4 arrays {x,y,z,-}; enqueued on `stream`.  The
+/* Device pointers: d_src / d_tgt are float4 arrays {x,y,z,-}; enqueued on `stream`.  Default
+ * (target index fits LDS, n_src <= 4096): the index is built (the call synchronises once, for the
+ * target's bounding box) and ONE launch runs every iteration of every pose.  Otherwise the
  * iterations are driven from the host (many workgroups per pose) and the call synchronises the
- * stream every four iterations to test for convergence; PGP_ICP_SPLIT=0 selects the single-launch
- * persistent kernel instead (never synchronises, same results, slower). */
+ * stream every four iterations to test for convergence.  Checker paths, same results:
+ * PGP_ICP_NN=scan (exhaustive search), PGP_ICP_PERSIST=0 (index, host-driven iterations),
+ * PGP_ICP_SPLIT=0/1 (the exhaustive persistent / host-driven kernels). */
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
                           float* d_T, int n, const pgp_icp_params* params, float* d_energy,
                           int* d_iters, void* stream);
+
+/* The index over the target is built per call unless the caller vouches that the target has not
+ * changed: after pgp_icp_target_token(ctx, token != 0), *_device calls with the same (d_tgt pointer,
+ * n_tgt, token) reuse the resident index (the reference builds TrimmedICP's search structure once per
+ * model, UCTState.cpp:137-139).  token 0 (default) = rebuild on every call.  The host-pointer calls do
+ * this by themselves with a hash of the target's coordinates. */
+int pgp_icp_target_token(pgp_ctx* ctx, unsigned long long token);
 
 /* The other ICP forms of the call sites, on the same kernels (csrc/icp.hip).  Fields <= 0 / < 0 switch
  * a rule off as noted; pgp_icp_default_options() fills the TrimmedICP form of pgp_icp_params.
@@ -322,7 +333,10 @@ typedef struct {
   float min_diff_rot;            /* > 0 with min_diff_trans > 0: libpointmatcher's                  */
   float min_diff_trans;          /*   DifferentialTransformationChecker on the last smooth_length    */
   int smooth_length;             /*   iterations (1..8)                                              */
-  int nn_search;                 /* 0 auto, 1 exhaustive scan, 2 uniform grid (needs max_corr_dist > 0) */
+  int nn_search;                 /* 0 auto, 1 exhaustive scan, 2 uniform grid (needs max_corr_dist > 0),
+                                    3 exact index of the static target held in LDS (fails when the target
+                                    does not fit: > ~6000 points); auto = 3 when it fits, else 2 for capped
+                                    scene-sized searches, else 1.  All four return identical results. */
 } pgp_icp_options;
 int pgp_icp_default_options(pgp_icp_options* opt);
 /* tgt_nrm: n_tgt x 3 unit normals of the target (nullable unless error_metric is 1).  Otherwise as

@@ -59,6 +59,7 @@
 
 #include <cfloat>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace pgp {
@@ -70,6 +71,29 @@ constexpr int kIcpR = 4;                 // source points per lane per sweep
 constexpr int kTgtTile = 4096;           // target points per LDS tile (64 KB)
 constexpr int kRedPlane = 28;            // point-to-plane: count + 21 (upper triangle of AtA) + 6 (Atb)
 constexpr int kMaxSmooth = 8;            // history length of the differential checker
+
+// ---- exact nearest-neighbour index over the STATIC target cloud ---------------------------------
+// The target (the object model: UCTState.cpp:137-139, utilities.cpp:666-676 build a TrimmedICP over it
+// once and query it for every iteration) does not move, so one index serves all poses and iterations:
+//   * a uniform grid of cells numbered row-major (x fastest), the target points sorted by cell (.w
+//     keeps the original index), 16-bit cell starts: the cells [x0, x1] of one (y, z) row are ONE
+//     contiguous run of points;
+//   * per cell a REPRESENTATIVE: the target point nearest to the cell's centre.  A query's distance to
+//     the representative of its own (clamped) cell is an upper bound U on its nearest-neighbour
+//     distance -- a true candidate, so the search only has to visit the rows that meet the ball of
+//     radius U, and the answer (smallest d2, then lowest original index: the exhaustive scan's rule) is
+//     exact however loose U is.  The previous iteration's correspondence tightens U further.
+//     Cost grows with U (a query visits (2U/h + 1)^2 rows), i.e. the index is at its best once the
+//     poses are within a centimetre or two; a lane's loop nest is rows x points and nothing deeper,
+//     because a wave pays the PRODUCT of the per-level maximum trip counts of its lanes (a four-level
+//     nest over occupancy blocks measured 16 000 VALU instructions per wave-query, this one ~600).
+// The whole index is one byte image (<= ~150 KB at 5000 points) that a workgroup copies into LDS.
+struct NnGeom {
+  float ox, oy, oz, inv_h, h;
+  int nx, ny, nz;        // cells per axis
+  int n_cells;
+  uint32_t off_start, off_rep, bytes;   // byte offsets inside the image (points at 0)
+};
 
 struct IcpArgs {
   const float4* src;   // [n_src] {x,y,z,-}
@@ -104,6 +128,10 @@ struct IcpArgs {
   int gnx, gny, gnz;
   const uint32_t* gcell_start;   // [cells + 1]
   const float4* gpts;            // target points sorted by cell, .w = bits(original index)
+  // exact index of the static target (icp_nn_index / icp_persist_index)
+  NnGeom nn;
+  const unsigned char* nn_image; // the LDS image of the index, in HBM: points | start16 | rep16 | mask
+  int* ws_pos;                   // [n][n_src] position (in the image's point order) of the last correspondence
 };
 
 __device__ __forceinline__ float row_xf(float a, float b, float c, float t, float x, float y, float z) {
@@ -170,6 +198,62 @@ __device__ void largest_eigvec4(double (&A)[4][4], double q[4]) {
   for (int k = 0; k < 4; ++k) q[k] = best == 0 ? V[k][0] : (best == 1 ? V[k][1] : (best == 2 ? V[k][2] : V[k][3]));
 }
 
+// The same eigenvector without iterating over rotations: Horn's N is symmetric and traceless, so its
+// characteristic polynomial is l^4 + c2 l^2 + c1 l + c0 with c2 = -tr(N^2)/2, c1 = -tr(N^3)/3, c0 = det N
+// (Newton's identities); it is convex and increasing beyond its largest root, so Newton's iteration from
+// the Gershgorin bound descends monotonically onto that root (Horn 1987 section 4; Theobald 2005), and
+// every non-zero column of adj(N - l I) is the eigenvector.  ~400 f64 operations against ~50 Jacobi
+// rotations of four divisions / square roots each: 27 us -> 2 us of ONE lane per ICP iteration
+// (tools/icp_phases.py).  Returns false -- the caller falls back to the Jacobi sweeps -- when the largest
+// eigenvalue is (nearly) double: the adjugate then vanishes and the rotation is not unique.
+__device__ __forceinline__ double det3(double a, double b, double c, double d, double e, double f, double g, double h,
+                                       double i) {
+  return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
+__device__ bool largest_eigvec4_direct(const double (&N)[4][4], double q[4]) {
+  const double a00 = N[0][0], a01 = N[0][1], a02 = N[0][2], a03 = N[0][3], a11 = N[1][1], a12 = N[1][2], a13 = N[1][3],
+               a22 = N[2][2], a23 = N[2][3], a33 = N[3][3];
+  // N^2 (symmetric)
+  const double m00 = a00 * a00 + a01 * a01 + a02 * a02 + a03 * a03, m01 = a00 * a01 + a01 * a11 + a02 * a12 + a03 * a13,
+               m02 = a00 * a02 + a01 * a12 + a02 * a22 + a03 * a23, m03 = a00 * a03 + a01 * a13 + a02 * a23 + a03 * a33,
+               m11 = a01 * a01 + a11 * a11 + a12 * a12 + a13 * a13, m12 = a01 * a02 + a11 * a12 + a12 * a22 + a13 * a23,
+               m13 = a01 * a03 + a11 * a13 + a12 * a23 + a13 * a33, m22 = a02 * a02 + a12 * a12 + a22 * a22 + a23 * a23,
+               m23 = a02 * a03 + a12 * a13 + a22 * a23 + a23 * a33, m33 = a03 * a03 + a13 * a13 + a23 * a23 + a33 * a33;
+  const double p2 = m00 + m11 + m22 + m33;
+  const double p3 = (m00 * a00 + m11 * a11 + m22 * a22 + m33 * a33) +
+                    2.0 * (m01 * a01 + m02 * a02 + m03 * a03 + m12 * a12 + m13 * a13 + m23 * a23);
+  const double det = a00 * det3(a11, a12, a13, a12, a22, a23, a13, a23, a33) - a01 * det3(a01, a12, a13, a02, a22, a23, a03, a23, a33) +
+                     a02 * det3(a01, a11, a13, a02, a12, a23, a03, a13, a33) - a03 * det3(a01, a11, a12, a02, a12, a22, a03, a13, a23);
+  const double c2 = -0.5 * p2, c1 = -p3 / 3.0, c0 = det;
+  double lam = fmax(fmax(fabs(a00) + fabs(a01) + fabs(a02) + fabs(a03), fabs(a01) + fabs(a11) + fabs(a12) + fabs(a13)),
+                    fmax(fabs(a02) + fabs(a12) + fabs(a22) + fabs(a23), fabs(a03) + fabs(a13) + fabs(a23) + fabs(a33)));
+  if (!(lam > 0.0)) return false;
+  for (int it = 0; it < 64; ++it) {
+    const double l2 = lam * lam;
+    const double P = (l2 + c2) * l2 + c1 * lam + c0, dP = (4.0 * l2 + 2.0 * c2) * lam + c1;
+    if (!(dP > 0.0)) break;
+    const double nl = lam - P / dP;
+    if (!(nl < lam)) break;   // monotone from above: no further descent = converged to the rounding of P
+    lam = nl;
+  }
+  const double b00 = a00 - lam, b11 = a11 - lam, b22 = a22 - lam, b33 = a33 - lam;
+  // adj(B), B = N - lam I symmetric: cofactor(i, j) = (-1)^(i+j) det(B without row i and column j)
+  const double k00 = det3(b11, a12, a13, a12, b22, a23, a13, a23, b33), k11 = det3(b00, a02, a03, a02, b22, a23, a03, a23, b33),
+               k22 = det3(b00, a01, a03, a01, b11, a13, a03, a13, b33), k33 = det3(b00, a01, a02, a01, b11, a12, a02, a12, b22);
+  const double k01 = -det3(a01, a12, a13, a02, b22, a23, a03, a23, b33), k02 = det3(a01, b11, a13, a02, a12, a23, a03, a13, b33),
+               k03 = -det3(a01, b11, a12, a02, a12, b22, a03, a13, a23), k12 = -det3(b00, a01, a03, a02, a12, a23, a03, a13, b33),
+               k13 = det3(b00, a01, a02, a02, a12, b22, a03, a13, a23), k23 = -det3(b00, a01, a02, a01, b11, a12, a03, a13, a23);
+  // adj(B) = kappa v v^T: the column with the largest diagonal entry is the best conditioned one
+  const double d0 = fabs(k00), d1 = fabs(k11), d2 = fabs(k22), d3 = fabs(k33);
+  const double dm = fmax(fmax(d0, d1), fmax(d2, d3));
+  if (!(dm > 1e-6 * lam * lam * lam)) return false;
+  if (d0 == dm) { q[0] = k00; q[1] = k01; q[2] = k02; q[3] = k03; }
+  else if (d1 == dm) { q[0] = k01; q[1] = k11; q[2] = k12; q[3] = k13; }
+  else if (d2 == dm) { q[0] = k02; q[1] = k12; q[2] = k22; q[3] = k23; }
+  else { q[0] = k03; q[1] = k13; q[2] = k23; q[3] = k33; }
+  return true;
+}
+
 // Horn's closed form from the f64 sums over the selected pairs:
 // red = {n, sx,sy,sz, mx,my,mz, Sxx,Sxy,Sxz, Syx,Syy,Syz, Szx,Szy,Szz}  (S_ab = sum s_a m_b)
 __device__ void solve_rigid(const double* red, float* G) {
@@ -185,7 +269,7 @@ __device__ void solve_rigid(const double* red, float* G) {
   N[2][0] = Szx - Sxz;       N[2][1] = Sxy + Syx;       N[2][2] = -Sxx + Syy - Szz; N[2][3] = Syz + Szy;
   N[3][0] = Sxy - Syx;       N[3][1] = Szx + Sxz;       N[3][2] = Syz + Szy;        N[3][3] = -Sxx - Syy + Szz;
   double q[4];
-  largest_eigvec4(N, q);
+  if (!largest_eigvec4_direct(N, q)) largest_eigvec4(N, q);
   double nq = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   if (!(nq > 0.0)) return;
   double w = q[0] / nq, x = q[1] / nq, y = q[2] / nq, z = q[3] / nq;
@@ -775,10 +859,684 @@ __global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
     a.ws_key[(size_t)pose * a.n_src + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj;
 }
 
+
+// ---- the exact index: build ----------------------------------------------------------------------
+__device__ __forceinline__ int nn_axis(float v, float o, float inv_h, int n) {
+  // monotone in v (every step is): the cells of [x - r, x + r] bracket the cell of any point in between
+  float f = __fmul_rn(__fsub_rn(v, o), inv_h);
+  f = fminf(fmaxf(f, 0.f), (float)(n - 1));   // NaN -> 0
+  return (int)f;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void nnidx_scatter(const float4* __restrict__ tgt, int n_tgt, NnGeom g,
+                                                     uint32_t* __restrict__ ctr, const uint32_t* __restrict__ start,
+                                                     float4* __restrict__ pts) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_tgt) return;
+  const float4 p = tgt[j];
+  const uint32_t c = ((uint32_t)nn_axis(p.z, g.oz, g.inv_h, g.nz) * (uint32_t)g.ny + (uint32_t)nn_axis(p.y, g.oy, g.inv_h, g.ny)) *
+                         (uint32_t)g.nx + (uint32_t)nn_axis(p.x, g.ox, g.inv_h, g.nx);
+  const uint32_t slot = atomicAdd(&ctr[c], 1u);
+  if (FILL) pts[start[c] + slot] = make_float4(p.x, p.y, p.z, __int_as_float(j));
+}
+
+// representative of every cell: exhaustive nearest point (in image order) of the cell's centre;
+// grid (cells / 256, target chunks of 512), one 64-bit atomic-min key per cell
+__global__ __launch_bounds__(256) void nnidx_rep(const float4* __restrict__ pts, int n_tgt, NnGeom g,
+                                                 unsigned long long* __restrict__ key) {
+  __shared__ float4 s_t[512];
+  const int t0 = blockIdx.y * 512, tn = min(512, n_tgt - t0);
+  for (int k = threadIdx.x; k < tn; k += 256) s_t[k] = pts[t0 + k];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= g.n_cells) return;
+  const int cx = c % g.nx, cy = (c / g.nx) % g.ny, cz = c / (g.nx * g.ny);
+  const float x = g.ox + ((float)cx + 0.5f) * g.h, y = g.oy + ((float)cy + 0.5f) * g.h, z = g.oz + ((float)cz + 0.5f) * g.h;
+  float best = FLT_MAX;
+  int bp = -1;
+  for (int k = 0; k < tn; ++k) {
+    const float4 m = s_t[k];
+    const float dx = x - m.x, dy = y - m.y, dz = z - m.z;
+    const float d2 = dx * dx + (dy * dy + dz * dz);
+    if (d2 < best) {
+      best = d2;
+      bp = t0 + k;
+    }
+  }
+  if (bp >= 0) atomicMin(&key[c], ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bp);
+}
+
+// the 16-bit tables of the image
+__global__ __launch_bounds__(256) void nnidx_pack(NnGeom g, const uint32_t* __restrict__ start,
+                                                  const unsigned long long* __restrict__ key,
+                                                  unsigned char* __restrict__ image) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  uint16_t* s16 = reinterpret_cast<uint16_t*>(image + g.off_start);
+  uint16_t* r16 = reinterpret_cast<uint16_t*>(image + g.off_rep);
+  if (c <= g.n_cells) s16[c] = (uint16_t)start[c];
+  if (c < g.n_cells) {
+    const unsigned long long k = key[c];
+    r16[c] = k == ~0ull ? (uint16_t)0 : (uint16_t)(k & 0xFFFFull);   // no finite point at all: any position
+  }
+}
+
+// ---- the exact index: query (all tables in LDS) ----------------------------------------------------
+struct NnLds {
+  const float4* pts;
+  const uint16_t* start;
+  const uint16_t* rep;
+  // per query of this workgroup (persist across the iterations of the persistent kernel)
+  float* d2;          // squared distance of the correspondence (FLT_MAX: none)
+  uint16_t* pos;      // its position in the image (0xFFFF: none)
+  uint16_t* order;    // the queries sorted by estimated search cost, dearest first
+};
+constexpr int kNnClasses = 16;
+
+// (d2, original index) as ONE unsigned 64-bit key: d2 >= +0, so the float bits order like the values,
+// and key < best is exactly the scan's rule (smaller d2, then lower index).  The initial key
+// (FLT_MAX, 0) rejects NaN, +inf and d2 == FLT_MAX as the scan's strict `<` against FLT_MAX does.
+__device__ __forceinline__ void nn_consider(float x, float y, float z, const float4 m, int pos,
+                                            unsigned long long& best, int& bpos) {
+  const float dx = __fsub_rn(x, m.x), dy = __fsub_rn(y, m.y), dz = __fsub_rn(z, m.z);
+  const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dy, dy), __fmul_rn(dz, dz)));
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(m.w);
+  if (key < best) {
+    best = key;
+    bpos = pos;
+  }
+}
+constexpr unsigned long long kNnNone = (unsigned long long)0x7F7FFFFFu << 32;   // (FLT_MAX, 0)
+
+__device__ __forceinline__ int nn_cell_of(const NnGeom& g, float x, float y, float z) {
+  return (nn_axis(z, g.oz, g.inv_h, g.nz) * g.ny + nn_axis(y, g.oy, g.inv_h, g.ny)) * g.nx + nn_axis(x, g.ox, g.inv_h, g.nx);
+}
+
+// The box of cells that can hold a point with computed d2 <= best: every such point lies within r of
+// the query in each coordinate (1e-4 relative + 4e-7 |coordinates| cover the rounding of d2 and of x -/+ r).
+struct NnBox {
+  int x0, x1, y0, y1, z0, z1;
+};
+__device__ __forceinline__ NnBox nn_box(const NnGeom& g, float x, float y, float z, float best_d2) {
+  const float r = sqrtf(best_d2) * 1.0001f + 4e-7f * (fabsf(x) + fabsf(y) + fabsf(z));
+  NnBox b;
+  b.x0 = nn_axis(x - r, g.ox, g.inv_h, g.nx);
+  b.x1 = nn_axis(x + r, g.ox, g.inv_h, g.nx);
+  b.y0 = nn_axis(y - r, g.oy, g.inv_h, g.ny);
+  b.y1 = nn_axis(y + r, g.oy, g.inv_h, g.ny);
+  b.z0 = nn_axis(z - r, g.oz, g.inv_h, g.nz);
+  b.z1 = nn_axis(z + r, g.oz, g.inv_h, g.nz);
+  return b;
+}
+
+// Phase A for one query: the bound from the representative of its cell and from its previous
+// correspondence; returns the cost class of the search that remains (0 cheapest .. 15 = plain scan).
+__device__ __forceinline__ int nn_bound(const NnGeom& g, const NnLds& t, float x, float y, float z, int prev_pos,
+                                        unsigned long long& best, int& bpos) {
+  best = kNnNone;
+  bpos = -1;
+  const int p = t.rep[nn_cell_of(g, x, y, z)];
+  nn_consider(x, y, z, t.pts[p], p, best, bpos);
+  if (prev_pos >= 0) nn_consider(x, y, z, t.pts[prev_pos], prev_pos, best, bpos);
+  if (bpos < 0) return kNnClasses - 1;   // no bound (a non-finite or astronomically far query): the plain scan
+  const NnBox b = nn_box(g, x, y, z, __uint_as_float((unsigned)(best >> 32)));
+  const int cost = (b.y1 - b.y0 + 1) * (b.z1 - b.z0 + 1) * (b.x1 - b.x0 + 3);   // rows x (row overhead + cells)
+  const int c = 31 - __clz(cost);   // cost >= 3
+  return c < kNnClasses - 2 ? c : kNnClasses - 2;
+}
+
+// Phase B for one query, shared by a group of L lanes (a power of two, consecutive lanes of one wave):
+// lane `sub` takes the rows sub, sub + L, ... of the search box (or, without a bound, every L-th target
+// point); the group's results are merged by the caller.  The row loop is the cost of a far query
+// (~(2U/h + 1)^2 pi/4 rows): everything in it works in CELL UNITS on values prepared once per query.
+__device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n_tgt, float x, float y, float z,
+                                          int sub, int L, unsigned long long& best, int& bpos) {
+  if (bpos < 0) {
+    for (int k = sub; k < n_tgt; k += L) nn_consider(x, y, z, t.pts[k], k, best, bpos);
+    return;
+  }
+  const float bound = __uint_as_float((unsigned)(best >> 32));
+  const NnBox b = nn_box(g, x, y, z, bound);
+  const float mag = fabsf(x) + fabsf(y) + fabsf(z) + fabsf(g.ox) + fabsf(g.oy) + fabsf(g.oz);
+  // query in cell units relative to the grid origin; a cell c spans [c, c + 1].  Slack of the row tests:
+  // 1e-4 cell for the float cell boundaries (values <= 2^7 cells carry <= 2^-16 cell of rounding)
+  // + the rounding of the coordinates themselves.
+  const float fx = (x - g.ox) * g.inv_h, fy = (y - g.oy) * g.inv_h, fz = (z - g.oz) * g.inv_h;
+  const float slack = 2e-4f + 2e-6f * mag * g.inv_h;
+  const float inv_h2 = g.inv_h * g.inv_h;
+  const bool wide = b.x1 - b.x0 >= 3;
+  const int nyb = b.y1 - b.y0 + 1;
+  // (cz, cy) of this lane's first row, then steps of L rows
+  int iz = sub / nyb;
+  int cz = b.z0 + iz, cy = b.y0 + (sub - iz * nyb);
+  const int step_z = L / nyb, step_y = L - step_z * nyb;
+  while (cz <= b.z1) {
+    // distance (cells) from the query to the row's (y, z) square: max(|f - (c + 1/2)| - 1/2 - slack, 0)
+    const float gy = fmaxf(fabsf(fy - ((float)cy + 0.5f)) - (0.5f + slack), 0.f);
+    const float gz = fmaxf(fabsf(fz - ((float)cz + 0.5f)) - (0.5f + slack), 0.f);
+    const float lim = __uint_as_float((unsigned)(best >> 32)) * inv_h2 * 1.0001f;   // best d2 in cells^2, rounded up
+    const float rem = lim - (gy * gy + gz * gz);
+    if (rem >= 0.f) {   // else the whole row lies beyond the best distance so far
+      int x0 = b.x0, x1 = b.x1;
+      if (wide) {   // the chord of the ball on this row instead of the box's full width
+        const float hw = __builtin_sqrtf(rem) * 1.0001f + slack;
+        x0 = max(x0, (int)fmaxf(fx - hw, 0.f));
+        x1 = min(x1, (int)fminf(fx + hw, (float)(g.nx - 1)));
+      }
+      if (x0 <= x1) {
+        const int row = (cz * g.ny + cy) * g.nx;
+        const int kb = t.start[row + x0], ke = t.start[row + x1 + 1];
+        for (int k = kb; k < ke; k += 2) {   // two LDS reads in flight; the last point of an odd run counts twice
+          const int k1 = min(k + 1, ke - 1);
+          const float4 m0 = t.pts[k], m1 = t.pts[k1];
+          nn_consider(x, y, z, m0, k, best, bpos);
+          nn_consider(x, y, z, m1, k1, best, bpos);
+        }
+      }
+    }
+    cy += step_y;
+    cz += step_z;
+    if (cy > b.y1) {
+      cy -= nyb;
+      ++cz;
+    }
+  }
+}
+
+// LDS layout of a workgroup that answers n_q queries: image | d2[n_q] | pos[n_q] | order[n_q]
+__device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* smem, int n_q, int tid, int nthreads) {
+  const uint4* src = reinterpret_cast<const uint4*>(a.nn_image);
+  uint4* dst = reinterpret_cast<uint4*>(smem);
+  const int n16 = (int)(a.nn.bytes >> 4);
+  for (int k = tid; k < n16; k += nthreads) dst[k] = src[k];
+  NnLds t;
+  t.pts = reinterpret_cast<const float4*>(smem);
+  t.start = reinterpret_cast<const uint16_t*>(smem + a.nn.off_start);
+  t.rep = reinterpret_cast<const uint16_t*>(smem + a.nn.off_rep);
+  t.d2 = reinterpret_cast<float*>(smem + a.nn.bytes);
+  t.pos = reinterpret_cast<uint16_t*>(t.d2 + n_q);
+  t.order = t.pos + n_q;
+  return t;
+}
+__host__ __device__ inline size_t nn_lds_bytes(uint32_t image_bytes, int n_q) { return (size_t)image_bytes + 8 * (size_t)n_q + 16; }
+
+// All n_q queries of a workgroup (source points q_base .. q_base + n_q - 1 under the pose G), in two
+// phases with the work BALANCED in between: a wave pays for its dearest lane (and, in a loop nest, for
+// the per-level maxima of all its lanes), and a few far queries per wave -- segmentation bleed, the rim
+// of a misaligned segment -- made every wave as slow as an exhaustive scan.  Phase A bounds every query
+// and files it under the log2 of its search cost (rows x cells of its box); a query of class c then gets
+// 2^(c - kNnBaseClass) LANES (1 .. 64, consecutive in one wave) that share its rows and merge their
+// results with cross-lane exchanges: every lane of phase B carries about the same work.
+// Needs R >= ceil(n_q / NT).  In: t.pos[q] = previous correspondence (0xFFFF none).
+// Out: t.d2[q], t.pos[q].  Ends with a barrier.
+constexpr int kNnBaseClass = 6;   // <= 127 cost units: one lane
+__device__ __forceinline__ int nn_class_lanes_log2(int c) {
+  const int l = c - kNnBaseClass;
+  return l < 0 ? 0 : (l > 6 ? 6 : l);
+}
+struct NnSched {
+  unsigned cnt[kNnClasses];        // queries per class, then their offset in `order` (dearest class first)
+  unsigned slot_end[kNnClasses];   // end of the class's lane slots
+  unsigned n_slots;
+};
+template <int NT, int R>
+__device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
+                                               NnSched* sch /* LDS */, int tid) {
+  const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
+              g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
+  if (tid < kNnClasses) sch->cnt[tid] = 0;
+  __syncthreads();
+  unsigned tag[R];   // class << 16 | rank inside the class
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int q = r * NT + tid;
+    tag[r] = 0;
+    if (q < n_q) {
+      const float4 s = a.src[q_base + q];
+      const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                  z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+      unsigned long long best;
+      int bpos;
+      const unsigned pp = t.pos[q];
+      const int c = nn_bound(a.nn, t, x, y, z, pp == 0xFFFFu ? -1 : (int)pp, best, bpos);
+      t.d2[q] = __uint_as_float((unsigned)(best >> 32));
+      t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
+      tag[r] = ((unsigned)c << 16) | atomicAdd(&sch->cnt[c], 1u);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {   // dearest class first: offsets of the classes in `order` and in the lane slots
+    unsigned acc = 0, slots = 0;
+    for (int c = kNnClasses - 1; c >= 0; --c) {
+      const unsigned n = sch->cnt[c];
+      sch->cnt[c] = acc;
+      acc += n;
+      slots += n << nn_class_lanes_log2(c);
+      sch->slot_end[c] = slots;
+    }
+    sch->n_slots = slots;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int q = r * NT + tid;
+    if (q < n_q) t.order[sch->cnt[tag[r] >> 16] + (tag[r] & 0xFFFFu)] = (uint16_t)q;
+  }
+  __syncthreads();
+  const unsigned n_slots = sch->n_slots;
+  int c = kNnClasses - 1;   // class of the current slot: slots only grow
+  for (unsigned s0 = 0; s0 < n_slots; s0 += NT) {   // uniform trip count: the exchanges below need whole waves
+    const unsigned sl = s0 + (unsigned)tid;
+    const bool valid = sl < n_slots;
+    unsigned long long best = kNnNone;
+    int bpos = -1, q = 0, lg = 0, sub = 0;
+    if (valid) {
+      while (sl >= sch->slot_end[c]) --c;
+      lg = nn_class_lanes_log2(c);
+      const unsigned first = c == kNnClasses - 1 ? 0u : sch->slot_end[c + 1];
+      const unsigned rel = sl - first;
+      sub = (int)(rel & ((1u << lg) - 1u));
+      q = t.order[sch->cnt[c] + (rel >> lg)];
+      const float4 s = a.src[q_base + q];
+      const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                  z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+      const unsigned pp = t.pos[q];
+      bpos = pp == 0xFFFFu ? -1 : (int)pp;
+      if (bpos >= 0) best = ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned)__float_as_int(t.pts[bpos].w);
+      nn_search(a.nn, t, a.n_tgt, x, y, z, sub, 1 << lg, best, bpos);
+    }
+    // merge the lanes of a group: class regions start at multiples of their group size, so the partners
+    // lane ^ off (off < L) work on the same query
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned lo = __shfl_xor((unsigned)best, off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+      const int pp = __shfl_xor(bpos, off, 64);
+      const unsigned long long pk = ((unsigned long long)hi << 32) | lo;
+      if (off < (1 << lg) && pk < best) {
+        best = pk;
+        bpos = pp;
+      }
+    }
+    if (valid && sub == 0) {
+      t.d2[q] = bpos < 0 ? FLT_MAX : __uint_as_float((unsigned)(best >> 32));
+      t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
+    }
+  }
+  __syncthreads();
+}
+
+// Split-path correspondences through the index: grid (source chunks of 1024, poses); the workgroup
+// copies the image into LDS and answers its 1024 queries.  Same keys as icp_nn_split.
+constexpr int kIdxThreads = 1024;
+__global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ NnSched s_sch;
+  const int pose = blockIdx.y;
+  if (a.st_done[pose]) return;
+  const int tid = threadIdx.x;
+  const int q_base = blockIdx.x * kIdxThreads, n_q = min(kIdxThreads, a.n_src - q_base);
+  const NnLds t = nn_load_image(a, smem, kIdxThreads, tid, kIdxThreads);
+  const size_t o = (size_t)pose * a.n_src + q_base + tid;
+  if (tid < n_q) {
+    const int pp = a.ws_pos[o];
+    t.pos[tid] = (uint16_t)(pp < 0 ? 0xFFFF : pp);
+  }
+  __syncthreads();
+  nn_all_queries<kIdxThreads, 1>(a, t, a.T + 16 * (size_t)pose, q_base, n_q, &s_sch, tid);
+  if (tid < n_q) {
+    const unsigned pp = t.pos[tid];
+    a.ws_pos[o] = pp == 0xFFFFu ? -1 : (int)pp;
+    a.ws_key[o] = pp == 0xFFFFu ? ~0ull
+                                : (((unsigned long long)__float_as_uint(t.d2[tid]) << 32) | (unsigned)__float_as_int(t.pts[pp].w));
+  }
+}
+
+// ONE WORKGROUP PER POSE, every iteration inside the launch, correspondences through the index in LDS:
+// the image is copied once; squared distances and correspondences of the pose's source points live in
+// LDS from search to selection to sums, so an iteration reads only the source cloud (L2) from memory
+// (the target points of the sums are read from the image).  Selection, sums, their reduction tree,
+// the closed-form update and the stop rules are those of icp_refine, operation for operation: the two
+// kernels (and the exhaustive searches) give bit-identical transforms, energies and iteration counts.
+constexpr int kPiR = 4;   // source points per thread: n_src <= 4096
+template <int METRIC>
+__global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double s_red[(kIcpThreads / 64) * (kRedPlane + 1)];
+  __shared__ float s_G[16];
+  __shared__ unsigned s_hist[256];
+  __shared__ unsigned s_scan[kIcpThreads / 64];
+  __shared__ unsigned s_prefix, s_kleft;
+  __shared__ unsigned s_tie[kPiR * (kIcpThreads / 64)];
+  static_assert(kPiR * (kIcpThreads / 64) == 64, "one wave scans the tie counts");
+  __shared__ double s_energy, s_energy_old;
+  __shared__ int s_continue;
+  __shared__ double s_sum[kRedPlane + 1];
+  __shared__ unsigned s_sel_bin, s_sel_acc;
+  __shared__ float s_G_old[16];
+  __shared__ NnSched s_sch;
+
+  const int pose = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* Tg = a.T + 16 * (size_t)pose;
+  const NnLds t = nn_load_image(a, smem, a.n_src, tid, kIcpThreads);
+  for (int q = tid; q < a.n_src; q += kIcpThreads) t.pos[q] = 0xFFFF;   // no previous correspondence yet
+  if (tid < 16) s_G[tid] = Tg[tid];
+  if (tid == 0) {
+    s_energy_old = (double)FLT_MAX;   // PCL: energy starts at numeric_limits<float>::max()
+    s_energy = 0.0;
+  }
+  __syncthreads();
+
+  int it = 0;
+#ifdef PGP_ICP_STAMPS   // diagnostic build only (tools/icp_phases.py): thread 0 of pose 0 times the phases (cycles, summed
+  // over the iterations) and reports them in energy[1..5] (poses 1..7 leave their energies alone)
+  unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
+#define PGP_STAMP(k) do { if (pose == 0 && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) > 0) st_acc[k] += now - st_prev; st_prev = now; } } while (0)
+#else
+#define PGP_STAMP(k) do { } while (0)
+#endif
+  for (;;) {
+    PGP_STAMP(0);
+    // ---- 1. correspondences ---------------------------------------------------------------------
+    nn_all_queries<kIcpThreads, kPiR>(a, t, s_G, 0, a.n_src, &s_sch, tid);
+    PGP_STAMP(1);
+
+    // ---- 2. selection threshold: k-th smallest d2 by radix select on the float bits ---------
+    unsigned thr_key = 0xFFFFFFFFu, ties_to_take = 0xFFFFFFFFu;  // default: take everything
+    if (a.max_corr2 < 0.f && a.k_trim < a.n_src) {
+      if (tid == 0) {
+        s_prefix = 0;
+        s_kleft = (unsigned)a.k_trim;
+      }
+      for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        const unsigned prefix = s_prefix;
+        const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int i = tid; i < a.n_src; i += kIcpThreads) {
+          const unsigned key = __float_as_uint(t.d2[i]);
+          if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        unsigned hv = 0, incl = 0;
+        if (tid < 256) {
+          hv = s_hist[tid];
+          incl = hv;
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) {
+            const unsigned tt = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += tt;
+          }
+          if (lane == 63) s_scan[wave] = incl;
+        }
+        if (tid == 0) {
+          s_sel_bin = 255u;
+          s_sel_acc = 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        if (tid < 256) {
+          unsigned woff = 0;
+          for (int w = 0; w < wave; ++w) woff += s_scan[w];
+          incl += woff;
+          const unsigned excl = incl - hv, kleft = s_kleft;
+          if (excl < kleft && kleft <= incl) {
+            s_sel_bin = (unsigned)tid;
+            s_sel_acc = excl;
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned acc = s_sel_acc;
+          if (acc == 0xFFFFFFFFu) acc = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
+          s_kleft = s_kleft - acc;
+          s_prefix = prefix | (s_sel_bin << shift);
+        }
+        __syncthreads();
+      }
+      thr_key = s_prefix;
+      ties_to_take = s_kleft;
+    }
+
+    PGP_STAMP(2);
+    // ---- 3. f64 sums over the selected pairs (ordered tie handling), fixed-tree reduction ----
+    constexpr int kNs = METRIC == 1 ? kRedPlane : 16;   // sums in use
+    double acc[kNs];
+#pragma unroll
+    for (int k = 0; k < kNs; ++k) acc[k] = 0.0;
+    double e_acc = 0.0;
+    // ties at the threshold are taken in index order (as icp_refine does, there with an ordered scan per
+    // sweep of the cloud): one ballot per sweep, the per-(sweep, wave) counts scanned once by wave 0
+    const bool ranked = a.max_corr2 < 0.f && thr_key != 0xFFFFFFFFu;
+    unsigned before[kPiR];
+    if (ranked) {
+#pragma unroll
+      for (int r = 0; r < kPiR; ++r) {
+        const int i = r * kIcpThreads + tid;
+        const bool tie = i < a.n_src && __float_as_uint(t.d2[i]) == thr_key;
+        const unsigned long long bm = __ballot(tie);
+        before[r] = __popcll(bm & ((1ull << lane) - 1ull));
+        if (lane == 0) s_tie[r * (kIcpThreads / 64) + wave] = __popcll(bm);
+      }
+      __syncthreads();
+      if (wave == 0) {   // exclusive scan of the 64 counts in (sweep, wave) order = index order
+        const unsigned v = s_tie[lane];
+        unsigned incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+          const unsigned tt = __shfl_up(incl, off, 64);
+          if (lane >= off) incl += tt;
+        }
+        s_tie[lane] = incl - v;
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < kPiR; ++r) {
+      const int i = r * kIcpThreads + tid;
+      if (r * kIcpThreads >= a.n_src) break;
+      unsigned key = 0xFFFFFFFFu;
+      float d2 = 0.f;
+      if (i < a.n_src) {
+        d2 = t.d2[i];
+        key = __float_as_uint(d2);
+      }
+      bool sel;
+      if (a.max_corr2 >= 0.f) {
+        sel = i < a.n_src && d2 <= a.max_corr2;
+      } else if (!ranked) {
+        sel = i < a.n_src;
+      } else {
+        const bool tie = i < a.n_src && key == thr_key;
+        sel = i < a.n_src && (key < thr_key || (tie && s_tie[r * (kIcpThreads / 64) + wave] + before[r] < ties_to_take));
+      }
+      const unsigned pm = i < a.n_src ? (unsigned)t.pos[i] : 0xFFFFu;   // 0xFFFF: a non-finite point has no neighbour
+      if constexpr (METRIC == 1) {
+        if (sel && pm != 0xFFFFu) {
+          const float4 s = a.src[i];
+          const float4 m = t.pts[pm];
+          const float4 nn = a.tgt_n[__float_as_int(m.w)];
+          const double px = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
+          const double py = row_xf(s_G[1], s_G[5], s_G[9], s_G[13], s.x, s.y, s.z);
+          const double pz = row_xf(s_G[2], s_G[6], s_G[10], s_G[14], s.x, s.y, s.z);
+          const double nx = nn.x, ny = nn.y, nz = nn.z;
+          const double row[6] = {nz * py - ny * pz, nx * pz - nz * px, ny * px - nx * py, nx, ny, nz};
+          const double rhs = nx * (double)m.x + ny * (double)m.y + nz * (double)m.z - nx * px - ny * py - nz * pz;
+          acc[0] += 1.0;
+          int tt = 1;
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+            for (int c = rr; c < 6; ++c) acc[tt++] += row[rr] * row[c];
+#pragma unroll
+          for (int rr = 0; rr < 6; ++rr) acc[22 + rr] += row[rr] * rhs;
+          e_acc += (double)d2;
+        }
+      } else if (sel && pm != 0xFFFFu) {
+        const float4 s = a.src[i];
+        const float4 m = t.pts[pm];
+        const float s0 = s.x, s1 = s.y, s2 = s.z;
+        acc[0] += 1.0;
+        acc[1] += s0; acc[2] += s1; acc[3] += s2;
+        acc[4] += m.x; acc[5] += m.y; acc[6] += m.z;
+        acc[7] += (double)s0 * m.x; acc[8] += (double)s0 * m.y; acc[9] += (double)s0 * m.z;
+        acc[10] += (double)s1 * m.x; acc[11] += (double)s1 * m.y; acc[12] += (double)s1 * m.z;
+        acc[13] += (double)s2 * m.x; acc[14] += (double)s2 * m.y; acc[15] += (double)s2 * m.z;
+        e_acc += (double)d2;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kNs; ++k)
+      for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
+    for (int off = 32; off >= 1; off >>= 1) e_acc += __shfl_xor(e_acc, off, 64);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < kRedPlane; ++k) s_red[wave * (kRedPlane + 1) + k] = k < kNs ? acc[k < kNs ? k : 0] : 0.0;
+      s_red[wave * (kRedPlane + 1) + kRedPlane] = e_acc;
+    }
+    __syncthreads();
+    if (tid <= kRedPlane) {
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRedPlane + 1) + tid];
+      s_sum[tid] = v;
+    }
+    __syncthreads();
+    PGP_STAMP(3);
+    if (tid == 0) {
+      const double* red = s_sum;
+      const double E = red[0] >= 1.0 ? red[kRedPlane] / red[0] : 0.0;
+      for (int k = 0; k < 16; ++k) s_G_old[k] = s_G[k];
+      if constexpr (METRIC == 1) solve_plane(red, s_G);
+      else solve_rigid(red, s_G);
+      PGP_STAMP(4);
+      const double E_old = s_energy_old;
+      s_energy = E;
+      s_energy_old = E;
+      bool go = it + 1 < a.max_iter;
+      if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;
+      if (red[0] < 1.0) go = false;
+      if (converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old)) go = false;
+      s_continue = go ? 1 : 0;
+      PGP_STAMP(5);
+    }
+    __syncthreads();
+    ++it;
+    if (!s_continue) break;
+  }
+  if (tid < 16) Tg[tid] = s_G[tid];
+  if (tid == 0) {
+#ifdef PGP_ICP_STAMPS
+    if (pose == 0 && a.energy && a.n >= 8)
+      for (int k = 1; k < 6; ++k) a.energy[k] = (float)st_acc[k];
+    if (a.energy && (pose == 0 || pose >= 8 || a.n < 8)) a.energy[pose] = (float)s_energy;
+#else
+    if (a.energy) a.energy[pose] = (float)s_energy;
+#endif
+    if (a.iters) a.iters[pose] = it;
+  }
+}
+
 }  // namespace
 
+// Builds the exact index of the target in ctx->d_icp_grid (image | counters | starts | keys) when its
+// image fits one workgroup's LDS.  *fits = false (and PGP_OK): the caller keeps the exhaustive search.
+static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q, IcpArgs* a, bool* fits, hipStream_t stream,
+                          unsigned long long token) {
+  *fits = false;
+  static_assert(sizeof(NnGeom) <= sizeof(ctx->icp_idx_geom), "NnGeom outgrew its slot in the context");
+  if (token != 0 && ctx->icp_idx_valid && ctx->icp_idx_token == token && ctx->icp_idx_tgt == (const void*)d_tgt &&
+      ctx->icp_idx_ntgt == n_tgt) {
+    NnGeom g;
+    memcpy(&g, ctx->icp_idx_geom, sizeof g);
+    if ((long long)nn_lds_bytes(g.bytes, n_q) + 8 * 1024 <= 160 * 1024) {   // the resident index serves this call too
+      a->nn = g;
+      a->nn_image = ctx->d_icp_grid.as<unsigned char>();
+      *fits = true;
+      return PGP_OK;
+    }
+  }
+  ctx->icp_idx_valid = false;
+  constexpr int kLdsBytes = 160 * 1024, kScratch = 8 * 1024;   // static LDS of icp_persist_index + slack
+  if (n_tgt < 1 || n_tgt > 65535) return PGP_OK;                // 16-bit positions
+  // n_q = queries a workgroup keeps in LDS (8 B each)
+  const long long avail = (long long)kLdsBytes - kScratch - 16ll * n_tgt - 8ll * n_q - 128;
+  if (avail < 4096) return PGP_OK;
+  // per cell: 2 B start + 2 B representative
+  long long budget = avail / 4 - 64;
+  if (budget > 32768) budget = 32768;
+  if (budget < 64 || budget * 8 < n_tgt) return PGP_OK;         // cells would hold > 8 points on average
+  float bb[6];
+  int rc;
+  if ((rc = device_bbox(ctx, reinterpret_cast<const float*>(d_tgt), n_tgt, 4, bb, bb + 3, stream)) != PGP_OK) return rc;
+  if (!(bb[0] <= bb[3])) bb[0] = bb[1] = bb[2] = bb[3] = bb[4] = bb[5] = 0.f;   // no finite target point
+  double ext[3];
+  for (int k = 0; k < 3; ++k) ext[k] = fmax((double)bb[3 + k] - (double)bb[k], 1e-6);
+  // cell edge from the spacing of a surface sampling of the box: ~3 points per occupied cell
+  const double area = 2.0 * (ext[0] * ext[1] + ext[1] * ext[2] + ext[2] * ext[0]);
+  double h = 1.7 * sqrt(area / (double)n_tgt);
+  if (const char* v = getenv("PGP_ICP_CELL")) h *= atof(v);       // tuning: cell edge multiplier
+  NnGeom g{};
+  for (;;) {
+    const long long nx = (long long)floor(ext[0] / h) + 1, ny = (long long)floor(ext[1] / h) + 1, nz = (long long)floor(ext[2] / h) + 1;
+    if (nx * ny * nz <= budget) {
+      g.nx = (int)nx;
+      g.ny = (int)ny;
+      g.nz = (int)nz;
+      break;
+    }
+    h *= 1.05;
+  }
+  g.h = (float)h;
+  g.inv_h = 1.0f / g.h;
+  g.ox = bb[0];
+  g.oy = bb[1];
+  g.oz = bb[2];
+  g.n_cells = g.nx * g.ny * g.nz;
+  g.off_start = (uint32_t)n_tgt * 16u;
+  g.off_rep = (g.off_start + (uint32_t)(g.n_cells + 1) * 2u + 15u) & ~15u;
+  g.bytes = (g.off_rep + (uint32_t)g.n_cells * 2u + 15u) & ~15u;
+  if ((long long)nn_lds_bytes(g.bytes, n_q) + kScratch > kLdsBytes) return PGP_OK;
+  const size_t nc1 = (size_t)g.n_cells + 1;
+  const size_t off_ctr = ((size_t)g.bytes + 255) & ~(size_t)255, off_st = off_ctr + ((nc1 * 4 + 255) & ~(size_t)255),
+               off_key = off_st + ((nc1 * 4 + 255) & ~(size_t)255);
+  if ((rc = ctx->d_icp_grid.ensure(off_key + (size_t)g.n_cells * 8 + 256)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure((nc1 / 2048 + 2) * 4)) != PGP_OK) return rc;
+  unsigned char* image = ctx->d_icp_grid.as<unsigned char>();
+  uint32_t* ctr = reinterpret_cast<uint32_t*>(image + off_ctr);
+  uint32_t* start = reinterpret_cast<uint32_t*>(image + off_st);
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(image + off_key);
+  const dim3 gt((n_tgt + 255) / 256);
+  PGP_HIP(hipMemsetAsync(ctr, 0, nc1 * 4, stream));
+  hipLaunchKernelGGL(nnidx_scatter<false>, gt, dim3(256), 0, stream, d_tgt, n_tgt, g, ctr, (const uint32_t*)nullptr,
+                     (float4*)nullptr);
+  if ((rc = device_exclusive_scan(ctr, start, nc1, ctx->d_scan_tmp.as<uint32_t>(), stream)) != PGP_OK) return rc;
+  PGP_HIP(hipMemsetAsync(ctr, 0, nc1 * 4, stream));
+  PGP_HIP(hipMemsetAsync(key, 0xFF, (size_t)g.n_cells * 8, stream));
+  hipLaunchKernelGGL(nnidx_scatter<true>, gt, dim3(256), 0, stream, d_tgt, n_tgt, g, ctr, (const uint32_t*)start,
+                     reinterpret_cast<float4*>(image));
+  hipLaunchKernelGGL(nnidx_rep, dim3((g.n_cells + 255) / 256, (n_tgt + 511) / 512), dim3(256), 0, stream,
+                     reinterpret_cast<const float4*>(image), n_tgt, g, key);
+  hipLaunchKernelGGL(nnidx_pack, dim3((g.n_cells + 1 + 255) / 256), dim3(256), 0, stream, g, (const uint32_t*)start,
+                     (const unsigned long long*)key, image);
+  PGP_HIP(hipGetLastError());
+  a->nn = g;
+  a->nn_image = image;
+  *fits = true;
+  memcpy(ctx->icp_idx_geom, &g, sizeof g);
+  ctx->icp_idx_valid = token != 0;
+  ctx->icp_idx_token = token;
+  ctx->icp_idx_tgt = (const void*)d_tgt;
+  ctx->icp_idx_ntgt = n_tgt;
+  ctx->icp_idx_nq = n_q;
+  return PGP_OK;
+}
+
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
-               float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream) {
+               float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
+               unsigned long long tgt_token) {
   if (n <= 0) return PGP_OK;
   if (n_src <= 0 || n_tgt <= 0) {
     set_error("icp: empty source or target cloud");
@@ -798,7 +1556,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     for (int off = 0; off < n; off += kMaxPoses) {
       const int m = n - off < kMaxPoses ? n - off : kMaxPoses;
       int rc = launch_icp(ctx, d_src, n_src, d_tgt, d_tgt_n, n_tgt, d_T + 16 * (size_t)off, m, prm,
-                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream);
+                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream, tgt_token);
       if (rc != PGP_OK) return rc;
     }
     return PGP_OK;
@@ -847,9 +1605,33 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     set_error("icp: the grid search needs max_corr_dist > 0");
     return PGP_EINVAL;
   }
-  if (use_grid || a.smooth > 0) split = true;   // both live on the host-driven path
+  // exact index of the static target: the default whenever its image fits a workgroup's LDS.  The
+  // exhaustive searches stay as the checker paths (nn_search 1, PGP_ICP_NN=scan, or PGP_ICP_SPLIT set).
+  bool use_index = false, persist_index = false;
+  {
+    const char* env_nn = getenv("PGP_ICP_NN");
+    const bool legacy = getenv("PGP_ICP_SPLIT") != nullptr;
+    bool want = !use_grid && !legacy && (prm->nn_search == 0 || prm->nn_search == 3);
+    if (env_nn && !strcmp(env_nn, "scan")) want = false;
+    if (env_nn && !strcmp(env_nn, "index") && !use_grid && prm->nn_search != 1) want = true;
+    bool want_persist = n_src <= kPiR * kIcpThreads;
+    if (const char* v = getenv("PGP_ICP_PERSIST")) want_persist = want_persist && atoi(v) != 0;
+    if (want) {
+      // one persistent workgroup per pose keeps all n_src correspondences in LDS; the host-driven path 1024
+      if (want_persist) {
+        if ((rc = build_nn_index(ctx, d_tgt, n_tgt, n_src, &a, &use_index, stream, tgt_token)) != PGP_OK) return rc;
+        persist_index = use_index;
+      }
+      if (!use_index && (rc = build_nn_index(ctx, d_tgt, n_tgt, kIdxThreads, &a, &use_index, stream, tgt_token)) != PGP_OK) return rc;
+      if (!use_index && prm->nn_search == 3) {
+        set_error("icp: the target (%d points) does not fit the LDS index", n_tgt);
+        return PGP_EINVAL;
+      }
+    }
+  }
+  if (use_grid || a.smooth > 0 || use_index) split = true;   // all live on the host-driven path
   const size_t hist_bytes = a.smooth > 0 ? (size_t)n * (kMaxSmooth + 1) * 7 * 8 : 0;
-  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 : 0;
+  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 + (use_index ? need * 4 + 64 : 0) : 0;
   if ((rc = ctx->d_icp_ws.ensure(need * 8 + state_bytes + 64)) != PGP_OK) return rc;
   a.ws_d2 = ctx->d_icp_ws.as<float>();
   a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
@@ -861,7 +1643,24 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_nn_index),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_persist_index<0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_persist_index<1>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     ctx->icp_attr_set = true;
+  }
+  if (persist_index) {
+    if (a.smooth > 0) {
+      a.st_hist = reinterpret_cast<double*>(((uintptr_t)(a.ws_j + need) + 15) & ~(uintptr_t)15);
+      PGP_HIP(hipMemsetAsync(a.st_hist, 0, hist_bytes, stream));
+    }
+    const size_t plds = nn_lds_bytes(a.nn.bytes, n_src);
+    if (a.metric == 1) hipLaunchKernelGGL(icp_persist_index<1>, dim3(n), dim3(kIcpThreads), plds, stream, a);
+    else hipLaunchKernelGGL(icp_persist_index<0>, dim3(n), dim3(kIcpThreads), plds, stream, a);
+    PGP_HIP(hipGetLastError());
+    return PGP_OK;
   }
   if (!split) {
     hipLaunchKernelGGL(icp_refine<false>, dim3(n), dim3(kIcpThreads), lds, stream, a);
@@ -877,6 +1676,10 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.st_done = a.st_it + n;
   a.n_done = a.st_done + n;
   a.st_hist = a.smooth > 0 ? reinterpret_cast<double*>(((uintptr_t)(a.n_done + 1) + 15) & ~(uintptr_t)15) : nullptr;
+  if (use_index) {
+    a.ws_pos = reinterpret_cast<int*>(((uintptr_t)(a.n_done + 1) + hist_bytes + 31) & ~(uintptr_t)15);
+    PGP_HIP(hipMemsetAsync(a.ws_pos, 0xFF, need * 4, stream));   // no previous correspondence yet
+  }
   PGP_HIP(hipMemsetAsync(a.ws_key, 0xFF, need * 8, stream));
   PGP_HIP(hipMemsetAsync(a.ws_j, 0xFF, need * 4, stream));  // no previous correspondence yet
   PGP_HIP(hipMemsetAsync(a.st_it, 0, (size_t)n * 8 + 4, stream));
@@ -887,6 +1690,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     PGP_HIP(hipStreamSynchronize(stream));  // e0 is a stack temporary
   }
   if (use_grid) {
+    ctx->icp_idx_valid = false;   // d_icp_grid is about to hold the capped search's grid
     // ---- the target's grid: bounding box (device), cell edge >= max_corr (grown to keep <= 2^26 cells)
     float bb[6];
     if ((rc = device_bbox(ctx, reinterpret_cast<const float*>(d_tgt), n_tgt, 4, bb, bb + 3, stream)) != PGP_OK) return rc;
@@ -934,6 +1738,9 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   const dim3 ggrid((n_src + 255) / 256, n);
   for (int it = 0; it < a.max_iter; ++it) {
     if (use_grid) hipLaunchKernelGGL(icp_nn_grid, ggrid, dim3(256), 0, stream, a);
+    else if (use_index)
+      hipLaunchKernelGGL(icp_nn_index, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
+                         nn_lds_bytes(a.nn.bytes, kIdxThreads), stream, a);
     else hipLaunchKernelGGL(icp_nn_split, gnn, dim3(kNnThreads), 0, stream, a);
     hipLaunchKernelGGL(icp_refine<true>, dim3(n), dim3(kIcpThreads), lds, stream, a);
     if (it == 0) PGP_HIP(hipGetLastError());   // a bad launch configuration shows on the first pair

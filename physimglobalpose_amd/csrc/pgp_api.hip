@@ -863,9 +863,18 @@ int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const
   CtxGuard guard(ctx, false);
   const int rc = launch_icp(ctx, reinterpret_cast<const float4*>(d_src4), n_src, reinterpret_cast<const float4*>(d_tgt4),
                     reinterpret_cast<const float4*>(d_tgt_n4), n_tgt, d_T, n, opt, d_energy, d_iters,
-                    static_cast<hipStream_t>(stream));
+                    static_cast<hipStream_t>(stream), ctx->icp_user_token);
   note_device_work(ctx, static_cast<hipStream_t>(stream));
   return rc;
+}
+
+int pgp_icp_target_token(pgp_ctx* ctx, unsigned long long token) {
+  if (!ctx) {
+    set_error("pgp_icp_target_token: ctx is NULL");
+    return PGP_EINVAL;
+  }
+  ctx->icp_user_token = token;
+  return PGP_OK;
 }
 
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
@@ -894,26 +903,50 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
     for (int i = 0; i < m; ++i) v[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
     return v;
   };
-  std::vector<float4> hs = pack(src_xyz, n_src), ht = pack(tgt_xyz, n_tgt), hn;
+  // The target is the object's model, the same from call to call (TrimmedICP::init builds its search
+  // structure once per model: UCTState.cpp:137-139): a hash of its coordinates tells whether the copy
+  // and the index already resident on the device are this target's, and the upload + build are skipped.
+  auto hash_of = [](const float* xyz, int m) {
+    unsigned long long hsh = 0x9E3779B97F4A7C15ull ^ (unsigned long long)m;
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(xyz);
+    for (size_t i = 0, e = 3 * (size_t)m; i < e; ++i) hsh = (hsh ^ w[i]) * 0x100000001B3ull + (hsh >> 29);
+    return hsh | 1ull;   // never 0
+  };
+  std::vector<float4> hs = pack(src_xyz, n_src);
   int rc;
   if ((rc = ctx->d_icp_src.ensure(hs.size() * 16)) != PGP_OK) return rc;
-  if ((rc = ctx->d_icp_tgt.ensure(ht.size() * 16)) != PGP_OK) return rc;
+  if ((rc = ctx->d_icp_tgt.ensure((size_t)std::max(n_tgt, 1) * 16)) != PGP_OK) return rc;
   if ((rc = ctx->d_icp_T.ensure((size_t)n * 64)) != PGP_OK) return rc;
   if ((rc = ctx->d_icp_out.ensure((size_t)n * 8)) != PGP_OK) return rc;
+  const unsigned long long tok = hash_of(tgt_xyz, n_tgt);
+  if (!(tok == ctx->icp_host_token && n_tgt == ctx->icp_host_ntgt)) {
+    const std::vector<float4> ht = pack(tgt_xyz, n_tgt);
+    ctx->icp_host_token = 0;
+    ctx->icp_idx_valid = false;
+    PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
+    PGP_HIP(hipStreamSynchronize(st));   // ht is a temporary
+    ctx->icp_host_token = tok;
+    ctx->icp_host_ntgt = n_tgt;
+  }
   const float4* d_n = nullptr;
   if (tgt_nrm) {
-    hn = pack(tgt_nrm, n_tgt);
-    if ((rc = ctx->d_icp_tgt_n.ensure(hn.size() * 16)) != PGP_OK) return rc;
-    PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt_n.p, hn.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
+    const unsigned long long ntok = hash_of(tgt_nrm, n_tgt);
+    if ((rc = ctx->d_icp_tgt_n.ensure((size_t)std::max(n_tgt, 1) * 16)) != PGP_OK) return rc;
+    if (ntok != ctx->icp_host_ntoken) {
+      const std::vector<float4> hn = pack(tgt_nrm, n_tgt);
+      ctx->icp_host_ntoken = 0;
+      PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt_n.p, hn.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
+      PGP_HIP(hipStreamSynchronize(st));
+      ctx->icp_host_ntoken = ntok;
+    }
     d_n = ctx->d_icp_tgt_n.as<float4>();
   }
   float* d_energy = ctx->d_icp_out.as<float>();
   int* d_iters = reinterpret_cast<int*>(d_energy + n);
   PGP_HIP(hipMemcpyAsync(ctx->d_icp_src.p, hs.data(), (size_t)n_src * 16, hipMemcpyHostToDevice, st));
-  PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
   PGP_HIP(hipMemcpyAsync(ctx->d_icp_T.p, T, (size_t)n * 64, hipMemcpyHostToDevice, st));
   rc = launch_icp(ctx, ctx->d_icp_src.as<float4>(), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt,
-                  ctx->d_icp_T.as<float>(), n, opt, d_energy, d_iters, st);
+                  ctx->d_icp_T.as<float>(), n, opt, d_energy, d_iters, st, tok);
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(T, ctx->d_icp_T.p, (size_t)n * 64, hipMemcpyDeviceToHost, st));
   if (energy) PGP_HIP(hipMemcpyAsync(energy, d_energy, (size_t)n * 4, hipMemcpyDeviceToHost, st));

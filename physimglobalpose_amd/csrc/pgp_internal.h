@@ -120,6 +120,16 @@ struct pgp_ctx {
   // ICP (host API staging + per-pose correspondence workspace)
   pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_tgt_n, d_icp_T, d_icp_out, d_icp_ws, d_icp_grid;
   bool icp_attr_set = false;   // dynamic-LDS limit of the ICP kernels raised on this device
+  // the exact index of the ICP target (icp.hip build_nn_index) stays valid across calls while the caller
+  // vouches for the target: token != 0 and the same (pointer, size, token) = the same points
+  bool icp_idx_valid = false;
+  unsigned long long icp_idx_token = 0;
+  const void* icp_idx_tgt = nullptr;
+  int icp_idx_ntgt = 0, icp_idx_nq = 0;
+  alignas(8) unsigned char icp_idx_geom[96] = {0};
+  unsigned long long icp_user_token = 0;                    // pgp_icp_target_token: device-pointer calls
+  unsigned long long icp_host_token = 0, icp_host_ntoken = 0;   // hash of the last uploaded host target / normals
+  int icp_host_ntgt = 0;
 
   // scoring workspace
   int cap_h = 0;
@@ -202,7 +212,8 @@ int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream
 
 // icp.hip
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
-               float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream);
+               float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
+               unsigned long long tgt_token = 0);
 
 // base_select.hip
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);

@@ -1,0 +1,20 @@
+"""Where one ICP iteration of the persistent indexed kernel spends its time: run with the diagnostic
+library (make -C physimglobalpose_amd/csrc icpstamps; cp tools/ab/libpgp_icpstamps.so physimglobalpose_amd/libpgp.so).
+Thread 0 of pose 0 sums s_memrealtime deltas per phase (100 MHz ticks -> us)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import numpy as np
+from physimglobalpose_amd import LcpScorer, synth
+rng = np.random.default_rng(0)
+M, _ = synth.make_model(rng, 5000); M = M.astype(np.float32)
+R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8); t = np.array([0.1, 0.0, 0.7])
+S = (M[rng.choice(5000, 2500, replace=False)] @ R.T + t).astype(np.float32)
+Tinv = np.linalg.inv(synth._se3(R, t))
+sc = LcpScorer()
+for n in (8, 64, 256):
+    G = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(5)), 0.005 * rng.standard_normal(3))) for _ in range(n)])
+    for iters in (1, 10, 30):
+        T, e, it = sc.icp_refine(S, M, G, trim=0.9, max_iterations=iters)
+        ticks = e[1:6].astype(np.float64)
+        us = ticks / 100.0 / it[0]          # s_memrealtime: 100 MHz
+        print(f"poses {n:4d} iterations {it[0]:3d}: per iteration  nn {us[0]:7.1f}  select {us[1]:7.1f}  sums+reduce {us[2]:7.1f}  solve {us[3]:7.1f}  stop rules {us[4]:7.1f}  us  (total {us.sum():7.1f})")
