@@ -264,18 +264,26 @@ def other_rows(sc, w, torch, mode_name, d_batches):
     sc.set_kernel_timing(False)
     out[o_name + "_lcp"] = {"hypotheses_per_s": N_HYP / dtw, "ms_per_step": dtw * 1e3, "gate_deg": float(w.gate_deg),
                             "roofline": roofline_block(o_name, N_HYP, kern_ms / max(launches, 1), launches)}
-    # ICP: 64 poses, 2500-pt segment vs 5000-pt model, 10 iterations each (trim 0.9)
+    # ICP (UCTState::performTrICP form, trim 0.9): 2500-pt segment vs the 5000-pt model, 10 iterations per pose.
+    # Guesses = ground truth perturbed by <= 5 degrees about the CAMERA origin (0.7 m away: the segment starts up
+    # to 6 cm off the model, the dear regime of the index) + 5 mm; "poses" = 64 is the round-1/2 point.
     seg = w.Q_xyz[rng.choice(len(w.Q_xyz), 2500, replace=False)]
     R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8)
     S = (seg @ R.T + np.array([0.1, 0.0, 0.7])).astype(np.float32)
     Tinv = np.linalg.inv(synth._se3(R, np.array([0.1, 0.0, 0.7])))
-    G = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(5)), 0.005 * rng.standard_normal(3)))
-                  for _ in range(64)])
-    dt, (_, _, its) = timed(lambda: sc.icp_refine(S, w.Q_xyz, G, trim=0.9, max_iterations=10), reps=3)
-    n_it = int(its.sum())
-    out["icp"] = {"poses": 64, "n_src": 2500, "n_tgt": len(w.Q_xyz), "iterations_total": n_it,
-                  "pose_iterations_per_s": n_it / dt, "ms_per_call": dt * 1e3,
-                  "algorithmic_GBps": n_it * (12 * 2500 + 12 * len(w.Q_xyz) + 112) / dt / 1e9}
+    G_all = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(5)), 0.005 * rng.standard_normal(3)))
+                      for _ in range(1024)])
+    icp = {}
+    for n_p in (64, 256, 1024):
+        G = G_all[:n_p]
+        dt, (_, _, its) = timed(lambda: sc.icp_refine(S, w.Q_xyz, G, trim=0.9, max_iterations=10), reps=3)
+        n_it = int(its.sum())
+        icp[str(n_p)] = {"iterations_total": n_it, "pose_iterations_per_s": n_it / dt, "ms_per_call": dt * 1e3}
+    out["icp"] = {"poses": 64, "n_src": 2500, "n_tgt": len(w.Q_xyz), "iterations_total": icp["64"]["iterations_total"],
+                  "pose_iterations_per_s": icp["64"]["pose_iterations_per_s"], "ms_per_call": icp["64"]["ms_per_call"],
+                  "algorithmic_GBps": icp["64"]["pose_iterations_per_s"] * (12 * 2500 + 12 * len(w.Q_xyz) + 112) / 1e9,
+                  "by_poses": icp,
+                  "search": "exact index of the static target in LDS, one persistent workgroup per pose (csrc/icp.hip)"}
     # congruent sets on a 1000-pt search model
     w2 = synth.make_workload(4000, 2000, 4, config_id=3, n_search=1000)
     sc.set_search_model(w2.Qs_xyz)
@@ -321,6 +329,66 @@ def other_rows(sc, w, torch, mode_name, d_batches):
     m = len(Tc)
     out["cluster"] = {"poses": m, "clusters": int(len(rep)), "pair_tests_per_s": m * (m - 1) / 2 / dt4,
                       "ms_per_call": dt4 * 1e3}
+    out.update(config_rows(torch, timed))
+    return out
+
+
+def config_rows(torch, timed):
+    """BASELINE.json configs[2] and configs[3] on ONE GPU, host wall clock around the C-ABI calls.
+    configs[2]: per object (50 000-pt scene, 5000-pt model) score 16 384 hypotheses (weighted, device-resident
+    transforms) -> greedy clustering of the scored poses -> trimmed ICP (30 iterations) of the 64 best from
+    their own poses (UCTState::performTrICP: segment -> model, the NEAR regime of the index).
+    configs[3]: 6 objects, 65 536 hypotheses in total, one context per object, all scored back to back."""
+    from physimglobalpose_amd import LcpScorer, PGP_MODE_WEIGHTED, synth
+    out = {}
+
+    def inv16(T16):
+        return synth.colmajor16(np.linalg.inv(np.asarray(T16, np.float64).reshape(4, 4).T))
+
+    w = synth.make_workload(50000, 5000, 16384, config_id=210)
+    sc = LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    n = len(w.T)
+    dT = torch.from_numpy(w.T).cuda()
+    ds = torch.zeros(n, device="cuda")
+    dc = torch.zeros(n, dtype=torch.int32, device="cuda")
+    db = torch.zeros(2, dtype=torch.int32, device="cuda")
+    sc.reserve(n)
+    t_score, _ = timed(lambda: sc.score_device(dT, ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg), reps=20)
+    s = ds.cpu().numpy()
+    bs = float(s.max())
+    t_cluster, (rep, _) = timed(lambda: sc.cluster_poses(w.T, s, bs), reps=3)     # reference rule: prune < 0.5 best
+    top = np.argsort(-s, kind="stable")[:64]
+    seg = np.ascontiguousarray(w.P_xyz[w.P_w == 1.0])
+    G = np.stack([inv16(w.T[h]) for h in top])
+    t_icp, (_, _, its) = timed(lambda: sc.icp_refine(seg, w.Q_xyz, G, trim=0.9, max_iterations=30), reps=3)
+    total = t_score + t_cluster + t_icp
+    out["config2_object"] = {
+        "workload": "1 of the 3 objects of configs[2]: 50k-pt scene, 5k-pt model, 16384 hypotheses, ICP of the top 64",
+        "score_ms": t_score * 1e3, "score_hypotheses_per_s": n / t_score, "cluster_ms": t_cluster * 1e3,
+        "clusters": int(len(rep)), "icp_ms": t_icp * 1e3, "icp_segment_points": int(len(seg)),
+        "icp_iterations_total": int(its.sum()), "icp_pose_iterations_per_s": float(its.sum()) / t_icp,
+        "object_ms": total * 1e3, "three_objects_ms": 3e3 * total, "hypotheses_per_s_end_to_end": n / total}
+    del sc
+    counts = [16384, 12288, 12288, 8192, 8192, 8192]
+    scs, Ts, outs = [], [], []
+    for k, m in enumerate(counts):
+        wk = synth.make_workload(20000, 3000, m, config_id=300 + k)
+        sk = LcpScorer()
+        sk.init(wk.P_xyz, wk.P_nrm, wk.P_w, wk.Q_xyz, wk.Q_nrm, wk.delta)
+        sk.reserve(m)
+        scs.append((sk, wk.gate_deg))
+        Ts.append(torch.from_numpy(wk.T).cuda())
+        outs.append((torch.zeros(m, device="cuda"), torch.zeros(m, dtype=torch.int32, device="cuda"),
+                     torch.zeros(2, dtype=torch.int32, device="cuda")))
+
+    def all_objects():
+        for (sk, gate), T, (a, b, c) in zip(scs, Ts, outs):
+            sk.score_device(T, a, b, c, mode=PGP_MODE_WEIGHTED, gate_deg=gate)
+
+    t_all, _ = timed(all_objects, reps=20)
+    out["config3_one_gpu"] = {"workload": "configs[3] on ONE GPU: 6 objects (20k-pt scenes, 3k-pt models), 65536 hypotheses",
+                              "ms": t_all * 1e3, "hypotheses_per_s": sum(counts) / t_all}
     return out
 
 

@@ -907,17 +907,48 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   // structure once per model: UCTState.cpp:137-139): a hash of its coordinates tells whether the copy
   // and the index already resident on the device are this target's, and the upload + build are skipped.
   auto hash_of = [](const float* xyz, int m) {
-    unsigned long long hsh = 0x9E3779B97F4A7C15ull ^ (unsigned long long)m;
+    // four independent multiply-xor chains over the 32-bit words (a single chain is latency-bound: 20 us at 5000 points)
     const uint32_t* w = reinterpret_cast<const uint32_t*>(xyz);
-    for (size_t i = 0, e = 3 * (size_t)m; i < e; ++i) hsh = (hsh ^ w[i]) * 0x100000001B3ull + (hsh >> 29);
+    const size_t e = 3 * (size_t)m;
+    unsigned long long h0 = 0x9E3779B97F4A7C15ull ^ (unsigned long long)m, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull,
+                       h3 = 0x27D4EB2F165667C5ull;
+    size_t i = 0;
+    for (; i + 4 <= e; i += 4) {
+      h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
+      h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull + (h1 >> 31);
+      h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull + (h2 >> 27);
+      h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull + (h3 >> 30);
+    }
+    for (; i < e; ++i) h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
+    const unsigned long long hsh = h0 ^ (h1 * 0x9E3779B97F4A7C15ull) ^ (h2 << 17 | h2 >> 47) ^ (h3 * 0xC2B2AE3D27D4EB4Full);
     return hsh | 1ull;   // never 0
   };
-  std::vector<float4> hs = pack(src_xyz, n_src);
+  // One device block [src | T | energy | iters] and its pinned host image: ONE copy in ([src | T]) and ONE
+  // copy out ([T | energy | iters]) -- the caller's arrays are pageable, and five pageable copies cost
+  // more than ten ICP iterations of one pose.
   int rc;
-  if ((rc = ctx->d_icp_src.ensure(hs.size() * 16)) != PGP_OK) return rc;
+  const size_t off_T = (size_t)std::max(n_src, 1) * 16, off_e = off_T + (size_t)n * 64, off_i = off_e + (size_t)n * 4,
+               total = off_i + (size_t)n * 4;
+  if ((rc = ctx->d_icp_src.ensure(total)) != PGP_OK) return rc;
   if ((rc = ctx->d_icp_tgt.ensure((size_t)std::max(n_tgt, 1) * 16)) != PGP_OK) return rc;
-  if ((rc = ctx->d_icp_T.ensure((size_t)n * 64)) != PGP_OK) return rc;
-  if ((rc = ctx->d_icp_out.ensure((size_t)n * 8)) != PGP_OK) return rc;
+  if (total + 64 > ctx->h_pin_cap) {
+    if (ctx->h_pin) {
+      hipError_t e = hipHostFree(ctx->h_pin);
+      (void)e;
+      ctx->h_pin = nullptr;
+      ctx->h_pin_cap = 0;
+    }
+    const size_t want = total + total / 4 + 64;
+    PGP_HIP(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
+    ctx->h_pin_cap = want;
+  }
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
+  {
+    float4* ps = reinterpret_cast<float4*>(pin);
+    for (int i = 0; i < n_src; ++i)
+      ps[i] = make_float4(src_xyz[3 * (size_t)i], src_xyz[3 * (size_t)i + 1], src_xyz[3 * (size_t)i + 2], 0.f);
+    std::memcpy(pin + off_T, T, (size_t)n * 64);
+  }
   const unsigned long long tok = hash_of(tgt_xyz, n_tgt);
   if (!(tok == ctx->icp_host_token && n_tgt == ctx->icp_host_ntgt)) {
     const std::vector<float4> ht = pack(tgt_xyz, n_tgt);
@@ -941,17 +972,19 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
     }
     d_n = ctx->d_icp_tgt_n.as<float4>();
   }
-  float* d_energy = ctx->d_icp_out.as<float>();
-  int* d_iters = reinterpret_cast<int*>(d_energy + n);
-  PGP_HIP(hipMemcpyAsync(ctx->d_icp_src.p, hs.data(), (size_t)n_src * 16, hipMemcpyHostToDevice, st));
-  PGP_HIP(hipMemcpyAsync(ctx->d_icp_T.p, T, (size_t)n * 64, hipMemcpyHostToDevice, st));
-  rc = launch_icp(ctx, ctx->d_icp_src.as<float4>(), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt,
-                  ctx->d_icp_T.as<float>(), n, opt, d_energy, d_iters, st, tok);
+  unsigned char* dev = ctx->d_icp_src.as<unsigned char>();
+  float* d_T = reinterpret_cast<float*>(dev + off_T);
+  float* d_energy = reinterpret_cast<float*>(dev + off_e);
+  int* d_iters = reinterpret_cast<int*>(dev + off_i);
+  PGP_HIP(hipMemcpyAsync(dev, pin, off_e, hipMemcpyHostToDevice, st));
+  rc = launch_icp(ctx, reinterpret_cast<const float4*>(dev), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt, d_T, n, opt,
+                  d_energy, d_iters, st, tok);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(T, ctx->d_icp_T.p, (size_t)n * 64, hipMemcpyDeviceToHost, st));
-  if (energy) PGP_HIP(hipMemcpyAsync(energy, d_energy, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  if (iters) PGP_HIP(hipMemcpyAsync(iters, d_iters, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  std::memcpy(T, pin + off_T, (size_t)n * 64);
+  if (energy) std::memcpy(energy, pin + off_e, (size_t)n * 4);
+  if (iters) std::memcpy(iters, pin + off_i, (size_t)n * 4);
   return PGP_OK;
 }
 

@@ -11,10 +11,14 @@ R = synth._rot_axis_angle([0.2, 0.5, -0.4], 0.8); t = np.array([0.1, 0.0, 0.7])
 S = (M[rng.choice(5000, 2500, replace=False)] @ R.T + t).astype(np.float32)
 Tinv = np.linalg.inv(synth._se3(R, t))
 sc = LcpScorer()
-for n in (8, 64, 256):
+for n in (16, 64, 256):
     G = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(5)), 0.005 * rng.standard_normal(3))) for _ in range(n)])
     for iters in (1, 10, 30):
         T, e, it = sc.icp_refine(S, M, G, trim=0.9, max_iterations=iters)
         ticks = e[1:6].astype(np.float64)
         us = ticks / 100.0 / it[0]          # s_memrealtime: 100 MHz
+        dbg = e[8:16].astype(np.float64); nq = max(dbg[4], 1)
+        if dbg[4] > 0:
+            print(f"    per query: rows {dbg[0]/nq:7.1f}  live rows {dbg[1]/nq:7.1f}  points {dbg[2]/nq:7.1f}  lanes {dbg[3]/nq:5.2f}   (queries {nq/it[0]:.0f} per iteration)")
+        print(f"    nn split: bounds {dbg[5]/100/it[0]:6.1f}  sort {dbg[6]/100/it[0]:6.1f}  search {dbg[7]/100/it[0]:6.1f} us per iteration")
         print(f"poses {n:4d} iterations {it[0]:3d}: per iteration  nn {us[0]:7.1f}  select {us[1]:7.1f}  sums+reduce {us[2]:7.1f}  solve {us[3]:7.1f}  stop rules {us[4]:7.1f}  us  (total {us.sum():7.1f})")
