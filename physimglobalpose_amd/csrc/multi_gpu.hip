@@ -15,6 +15,13 @@
 // (dlopen of librccl.so.1, the library torch's "nccl" backend is): libpgp.so has no link-time
 // dependency on it and a single-device group needs no collective at all (PGP_MULTI_FORCE_COLLECTIVE=1
 // runs a one-rank communicator anyway -- the GPU test of the exchange path on a 1-GPU box).
+//
+// PGP_MULTI_EMULATE=n (n >= 2): n logical members on ONE device, each with its own context, worker
+// thread and stream -- every N > 1 branch below (zeroed full-length vectors, slice offsets, the
+// exchange, settlement and exact records across slices) runs on a 1-GPU box.  RCCL refuses a
+// communicator with a device listed twice, so the exchange is a sum kernel of this file with the
+// all-reduce's semantics (every member ends up with the element-wise sum); everything else is the
+// production code path.  A test vehicle, never a performance configuration.
 
 #include "pgp_internal.h"
 
@@ -137,6 +144,9 @@ struct pgp_multi {
   std::vector<hipStream_t> stream;
   std::vector<Worker*> worker;
   bool use_coll = false;
+  bool emulate = false;   // PGP_MULTI_EMULATE: members share one device, exchange = emulate_allreduce
+  std::vector<hipEvent_t> ev;   // emulate: one event per member
+  DevBuf d_sum;                 // emulate: the summed vector before it is handed to every member
   Rccl rccl;
   std::vector<ncclComm_t> comm;
   // per device: the full transform list and the full-length {scores | counts} vector
@@ -148,6 +158,23 @@ struct pgp_multi {
 };
 
 namespace {
+
+// out[i] = sum over members of in[k][i]: floats for the scores, ints for the counts (every element is
+// non-zero in at most one member, so the order of the additions cannot matter -- as in the RCCL sum)
+__global__ __launch_bounds__(256) void emulate_sum(const float* const* __restrict__ in, int n_members, int n_h,
+                                                   float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n_h) return;
+  if (i < n_h) {
+    float s = 0.f;
+    for (int k = 0; k < n_members; ++k) s += in[k][i];
+    out[i] = s;
+  } else {
+    int s = 0;
+    for (int k = 0; k < n_members; ++k) s += reinterpret_cast<const int*>(in[k])[i];
+    reinterpret_cast<int*>(out)[i] = s;
+  }
+}
 
 int run_all(pgp_multi* m, const std::function<int(int)>& fn) {
   for (int k = 0; k < m->n; ++k) m->worker[k]->post([&fn, k] { return fn(k); });
@@ -204,17 +231,21 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
               e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     return PGP_ENODEV;
   }
+  int emulate = 0;
+  if (const char* v = getenv("PGP_MULTI_EMULATE")) emulate = atoi(v);
+  if (emulate >= 2) n_dev = emulate;   // n logical members on the first listed device
   if (n_dev <= 0) n_dev = visible;  // every visible device
   pgp_multi* m = new pgp_multi();
   m->n = n_dev;
+  m->emulate = emulate >= 2;
   for (int k = 0; k < n_dev; ++k) {
-    const int d = device_ids ? device_ids[k] : k;
+    const int d = m->emulate ? (device_ids ? device_ids[0] : 0) : (device_ids ? device_ids[k] : k);
     if (d < 0 || d >= visible) {
       set_error("device %d out of range (%d devices)", d, visible);
       delete m;
       return PGP_EINVAL;
     }
-    for (int j = 0; j < k; ++j)
+    for (int j = 0; j < k && !m->emulate; ++j)
       if (m->dev[j] == d) {
         set_error("device %d listed twice", d);
         delete m;
@@ -242,7 +273,14 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
   });
   const char* force = getenv("PGP_MULTI_FORCE_COLLECTIVE");
   m->use_coll = n_dev > 1 || (force && atoi(force) != 0);
-  if (rc == PGP_OK && m->use_coll) {
+  if (rc == PGP_OK && m->emulate) {
+    m->ev.assign(n_dev, nullptr);
+    rc = run_all(m, [m](int k) -> int {
+      PGP_HIP(hipEventCreateWithFlags(&m->ev[k], hipEventDisableTiming));
+      return PGP_OK;
+    });
+  }
+  if (rc == PGP_OK && m->use_coll && !m->emulate) {
     if (!load_rccl(&m->rccl)) rc = PGP_ENODEV;
     if (rc == PGP_OK) {
       m->comm.assign(n_dev, nullptr);
@@ -281,6 +319,8 @@ int pgp_multi_destroy(pgp_multi* m) {
       m->d_T[k].release();
       m->d_all[k].release();
       m->d_best[k].release();
+      if (k < (int)m->ev.size() && m->ev[k]) (void)hipEventDestroy(m->ev[k]);
+      if (k == 0) m->d_sum.release();
       if (m->stream[k]) (void)hipStreamDestroy(m->stream[k]);
       if (m->ctx[k]) pgp_destroy(m->ctx[k]);
       return PGP_OK;
@@ -362,11 +402,52 @@ int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scor
     int* d_c = reinterpret_cast<int*>(d_s + n_h);
     // every device fills only its slice of a zeroed vector: the sum over devices is the gather
     if (n_h > 0 && m->n > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)n_h * 8, m->stream[k]));
-    return pgp_score_lcp_device(m->ctx[k], m->d_T[k].as<float>() + 16 * (size_t)lo, hi - lo, mode, gate_deg,
-                                d_s + lo, d_c + lo, nullptr, m->stream[k]);
+    // the exact-records pass (pgp_set_exact_records on member 0's context) belongs to the COMPLETE vector,
+    // below; running it on member 0's slice as well would only repeat three launches
+    const bool records = m->ctx[k]->exact_records;
+    m->ctx[k]->exact_records = false;
+    const int r = pgp_score_lcp_device(m->ctx[k], m->d_T[k].as<float>() + 16 * (size_t)lo, hi - lo, mode, gate_deg,
+                                       d_s + lo, d_c + lo, nullptr, m->stream[k]);
+    m->ctx[k]->exact_records = records;
+    if (r == PGP_OK && m->emulate) PGP_HIP(hipEventRecord(m->ev[k], m->stream[k]));
+    return r;
   });
   if (rc != PGP_OK) return rc;
-  if (m->use_coll && n_h > 0) {
+  if (m->emulate && m->n > 1 && n_h > 0) {
+    // the all-reduce on one device: member 0's stream waits for every slice, sums the vectors, and hands
+    // the sum to every member (whose streams then wait for it)
+    Worker* w0 = m->worker[0];
+    w0->post([m, n_h]() -> int {
+      hipStream_t st = m->stream[0];
+      int r;
+      if ((r = m->d_sum.ensure((size_t)n_h * 8 + (size_t)m->n * sizeof(float*) + 64)) != PGP_OK) return r;
+      float* d_out = m->d_sum.as<float>();
+      const float** d_ptrs = reinterpret_cast<const float**>(m->d_sum.as<unsigned char>() + (((size_t)n_h * 8 + 15) & ~(size_t)15));
+      std::vector<const float*> ptrs(m->n);
+      for (int k = 0; k < m->n; ++k) {
+        ptrs[k] = m->d_all[k].as<float>();
+        if (k > 0) PGP_HIP(hipStreamWaitEvent(st, m->ev[k], 0));
+      }
+      PGP_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), (size_t)m->n * sizeof(float*), hipMemcpyHostToDevice, st));
+      PGP_HIP(hipStreamSynchronize(st));   // ptrs is a stack temporary
+      hipLaunchKernelGGL(emulate_sum, dim3((2 * n_h + 255) / 256), dim3(256), 0, st, d_ptrs, m->n, n_h, d_out);
+      PGP_HIP(hipGetLastError());
+      for (int k = 0; k < m->n; ++k)
+        PGP_HIP(hipMemcpyAsync(m->d_all[k].p, d_out, (size_t)n_h * 8, hipMemcpyDeviceToDevice, st));
+      PGP_HIP(hipEventRecord(m->ev[0], st));
+      return PGP_OK;
+    });
+    rc = w0->wait();
+    if (rc != PGP_OK) {
+      set_error("device %d: %s", m->dev[0], w0->err);
+      return rc;
+    }
+    rc = run_all(m, [m](int k) -> int {
+      if (k > 0) PGP_HIP(hipStreamWaitEvent(m->stream[k], m->ev[0], 0));
+      return PGP_OK;
+    });
+    if (rc != PGP_OK) return rc;
+  } else if (m->use_coll && n_h > 0) {
     ncclResult_t nr = m->rccl.GroupStart();
     for (int k = 0; k < m->n && nr == ncclSuccess; ++k) {
       float* d_s = m->d_all[k].as<float>();

@@ -404,9 +404,13 @@ int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode,
     return PGP_EINVAL;
   }
   CtxGuard guard(ctx, false);
-  int rc = ctx->d_rec_ws.ensure((size_t)records_workspace_bytes(ctx->nQ));
-  if (rc != PGP_OK) return rc;
-  rc = launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, static_cast<hipStream_t>(stream));
+  // queue-only entry: no allocation here (a hipFree / hipMalloc would synchronise the device and break a
+  // capture); the workspace is reserved by pgp_set_exact_records / pgp_set_model
+  if (ctx->d_rec_ws.cap < (size_t)records_workspace_bytes(ctx->nQ)) {
+    set_error("pgp_settle_records_device: workspace not reserved (call pgp_set_exact_records(ctx, 1) after pgp_set_model)");
+    return PGP_ESTATE;
+  }
+  int rc = launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
   return rc;
 }

@@ -611,6 +611,11 @@ class MultiGpuScorer:
                                                       c.ctypes.data_as(_i), C.byref(bi), C.byref(bs)))
         return s, c, bi.value, float(np.float32(bs.value))
 
+    def set_exact_records(self, on=True):
+        """pgp_set_exact_records on member 0's context: the group's running-best list is then the reference's."""
+        ctx0 = self._lib.pgp_multi_context(self._h, 0)
+        _lib.check(self._lib.pgp_set_exact_records(C.c_void_p(ctx0), 1 if on else 0))
+
     def last_timing(self):
         a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
         _lib.check(self._lib.pgp_multi_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
