@@ -651,6 +651,7 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
     set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
     return PGP_EHIP;
   }
+  ctx->csb_nb = 0;   // the batch's sorted keys (if any) are overwritten here
   if ((rc = ctx->d_cs_keys.ensure((size_t)total * 16 + sort_bytes + 256)) != PGP_OK) return rc;
   unsigned long long* keys_in = ctx->d_cs_keys.as<unsigned long long>();
   unsigned long long* keys_out = keys_in + total;
@@ -841,9 +842,12 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   PGP_HIP(hipStreamSynchronize(st));
   const uint32_t total = starts[nb];
   for (int b = 0; b < nb; ++b) h_n_quads[b] = (int)(starts[b + 1] - starts[b]);
-  ctx->csb_nb = nb;
-  ctx->csb_total = total;
-  if (total == 0) return PGP_OK;
+  if (total == 0) {   // a valid, empty batch: every pick is out of range
+    ctx->csb_starts = starts;
+    ctx->csb_nb = nb;
+    ctx->csb_total = 0;
+    return PGP_OK;
+  }
   size_t sort_bytes = 0;
   hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
                                            (unsigned long long*)nullptr, (size_t)total, 0, 64, st);
@@ -863,14 +867,31 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     return PGP_EHIP;
   }
   PGP_HIP(hipGetLastError());
+  // only now do the sorted keys exist: the batch becomes visible to pgp_congruent_batch_quads / _fit
+  ctx->csb_starts = starts;
+  ctx->csb_nb = nb;
+  ctx->csb_total = total;
   return PGP_OK;
 }
 
 // picks[m][2] = (base, j) -> d_quads[m] (int4), on the sorted keys left by the call above
 int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st) {
-  if (ctx->csb_nb <= 0 || ctx->csb_total == 0) {
-    set_error("no congruent batch: call pgp_find_congruent_batch first");
+  if (ctx->csb_nb <= 0 || (int)ctx->csb_starts.size() != ctx->csb_nb + 1) {
+    set_error("no congruent batch: call pgp_find_congruent_batch first (a later pgp_find_congruent, "
+              "pgp_set_ppf_map or pgp_set_search_model discards it)");
     return PGP_ESTATE;
+  }
+  for (int k = 0; k < m; ++k) {   // a bad pick would read past the sorted keys on the device
+    const int b = h_picks[2 * (size_t)k], j = h_picks[2 * (size_t)k + 1];
+    if (b < 0 || b >= ctx->csb_nb) {
+      set_error("congruent batch: pick %d names base %d of %d", k, b, ctx->csb_nb);
+      return PGP_EINVAL;
+    }
+    const uint32_t nq = ctx->csb_starts[b + 1] - ctx->csb_starts[b];
+    if (j < 0 || (uint32_t)j >= nq) {
+      set_error("congruent batch: pick %d names quad %d of %u of base %d", k, j, nq, b);
+      return PGP_EINVAL;
+    }
   }
   int rc = ctx->d_csb_picks.ensure((size_t)m * 8 + 16);
   if (rc != PGP_OK) return rc;

@@ -594,6 +594,7 @@ int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
   }
   CtxGuard guard(ctx);
   PGP_HIP(hipDeviceSynchronize());   // see pgp_set_scene
+  ctx->csb_nb = 0;   // a resident congruent batch belongs to the old search model
   std::vector<float4> hq((size_t)std::max(n, 1));
   for (int i = 0; i < n; ++i)
     hq[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2],

@@ -103,8 +103,10 @@ struct pgp_ctx {
   std::vector<uint32_t> ppf_off_host;   // pair-list offsets per key, host copy
   float ppf_tpos[9] = {0}, ppf_tneg[9] = {0};   // ratio thresholds of the 10-degree angle bins (host atan2f)
   pgp::DevBuf d_csb, d_csb_picks;       // batched congruent sets: bases | cones | per-base starts; staged picks
-  int csb_nb = 0;                       // bases of the last pgp_find_congruent_batch (its keys are still resident)
+  int csb_nb = 0;                       // bases of the last pgp_find_congruent_batch (its keys are still resident);
+                                        // 0 as soon as d_cs_keys / d_ppf_pairs / the search model are rewritten
   uint32_t csb_total = 0;
+  std::vector<uint32_t> csb_starts;     // per-base starts in the sorted keys (nb + 1), host copy: picks are checked here
   pgp::DevBuf d_prob_cdf;               // double prefix sums of the scene weights (first draw)
   bool prob_cdf_valid = false;
   pgp::DevBuf d_sel_ws;                 // base-selection workspace / staging

@@ -77,3 +77,42 @@ def test_batch_without_pair_lists_is_refused(case):
     from physimglobalpose_amd._lib import PgpError
     with pytest.raises(PgpError):
         other.find_congruent_batch(ids, w.P_xyz[ids], inv, w.delta)
+
+
+def test_stale_batches_and_bad_picks_are_refused(case):
+    """The resident quad lists die with the buffers they index: a single-base pgp_find_congruent, a new
+    pair-feature table or a new search model discard them (PGP_ESTATE instead of quads gathered from
+    overwritten keys), and a pick outside a base's list is PGP_EINVAL, not a device read past the end."""
+    w, table, keys, sc, ids, inv = case
+    from physimglobalpose_amd._lib import PgpError
+    base_xyz = w.P_xyz[ids]
+    n_quads = sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
+    b = int(np.argmax(n_quads))
+    assert n_quads[b] > 0
+    ok = sc.congruent_batch_quads(np.array([[b, 0], [b, n_quads[b] - 1]], np.int32))
+    assert ok.shape == (2, 4)
+    for bad in ([[b, n_quads[b]]], [[b, -1]], [[len(ids), 0]], [[-1, 0]]):
+        with pytest.raises(PgpError):
+            sc.congruent_batch_quads(np.array(bad, np.int32))
+        with pytest.raises(PgpError):
+            sc.congruent_batch_fit(np.array(bad, np.int32), ids, w.centroid_P, w.centroid_Q)
+    # a single-base call overwrites the sorted keys
+    f01, r01 = sc.ppf_features(ids[b:b + 1, [0, 1]])
+    f23, r23 = sc.ppf_features(ids[b:b + 1, [2, 3]])
+    p1 = np.array(table[tuple(keys[r01[0]].tolist())], np.int32)
+    p6 = np.array(table[tuple(keys[r23[0]].tolist())], np.int32)
+    sc.find_congruent(base_xyz[b], inv[b, 0], inv[b, 1], w.delta, p1, p6)
+    with pytest.raises(PgpError):
+        sc.congruent_batch_quads(np.array([[b, 0]], np.int32))
+    # ... and so do a new table and a new search model
+    counts = np.array([len(table[tuple(k)]) for k in keys.tolist()], np.int32)
+    pairs = np.concatenate([np.array(table[tuple(k)], np.int32).reshape(-1, 2) for k in keys.tolist()])
+    for invalidate in (lambda: sc.set_ppf_map(keys, counts, pairs), lambda: sc.set_search_model(w.Qs_xyz)):
+        sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
+        assert sc.congruent_batch_quads(np.array([[b, 0]], np.int32)).shape == (1, 4)
+        invalidate()
+        with pytest.raises(PgpError):
+            sc.congruent_batch_quads(np.array([[b, 0]], np.int32))
+    sc.set_ppf_map(keys, counts, pairs)
+    sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
+    assert sc.congruent_batch_quads(np.array([[b, 0]], np.int32)).shape == (1, 4)
