@@ -310,6 +310,48 @@ def other_rows(sc, w, torch, mode_name, d_batches):
     dt5, _ = timed(lambda: sc.depth_cost(obs, ren, 0.01), reps=3)
     out["depth_cost"] = {"images": 64, "pixels": 640 * 480, "images_per_s": 64 / dt5, "ms_per_call": dt5 * 1e3,
                          "note": "host pointers: 79 MB of rendered depth cross PCIe per call"}
+    # the same 64 leaf states rendered AND costed in HBM (csrc/render.hip -> pgp_depth_cost_device): a 20 480-triangle
+    # mesh (the size of the reference's models_visualization/*.ply) under 64 poses over a parent image
+    def ico(level):
+        t = (1 + 5 ** 0.5) / 2
+        v = [np.array(p, float) / np.linalg.norm(p) for p in [(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t),
+             (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)]]
+        f = [(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8),
+             (3, 9, 4), (3, 4, 2), (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)]
+        for _ in range(level):
+            cache, nf = {}, []
+            def mid(a, b):
+                k = (min(a, b), max(a, b))
+                if k not in cache:
+                    m = v[a] + v[b]
+                    v.append(m / np.linalg.norm(m))
+                    cache[k] = len(v) - 1
+                return cache[k]
+            for a, b, c in f:
+                ab, bc, ca = mid(a, b), mid(b, c), mid(c, a)
+                nf += [(a, ab, ca), (b, bc, ab), (c, ca, bc), (ab, bc, ca)]
+            f = nf
+        return (np.array(v) * np.array([0.10, 0.06, 0.04])).astype(np.float32), np.array(f, np.int32)
+    mv, mf = ico(5)
+    Kc0 = np.array([[614.0, 0, 322.5], [0, 614.0, 239.7], [0, 0, 1]], np.float32)
+    cam = sc.camera(Kc0, 480, 640, 0.1, 1.0)
+    Tl = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng), [rng.uniform(-0.15, 0.15), rng.uniform(-0.1, 0.1),
+                                                                       rng.uniform(0.5, 0.9)])) for _ in range(64)])
+    d_v, d_f, d_Tl = torch.from_numpy(mv).cuda(), torch.from_numpy(mf).cuda(), torch.from_numpy(Tl).cuda()
+    d_par, d_ob = torch.from_numpy(obs).cuda().clamp(max=0.95), torch.from_numpy(obs).cuda()
+    d_img = torch.empty((64, 480, 640), dtype=torch.float32, device="cuda")
+    d_cnt = torch.empty((64, 3), dtype=torch.int32, device="cuda")
+    d_sc = torch.empty(64, dtype=torch.float32, device="cuda")
+
+    def leaf_states():
+        sc.render_depth_device(d_v, d_f, d_Tl, cam, d_parent=d_par, d_depth=d_img)
+        sc.depth_cost_device(d_ob, d_img, 0.01, d_counts=d_cnt, d_scores=d_sc)
+
+    dt9, _ = timed(leaf_states, reps=10)
+    dt9r, _ = timed(lambda: sc.render_depth_device(d_v, d_f, d_Tl, cam, d_parent=d_par, d_depth=d_img), reps=10)
+    out["leaf_states_device"] = {"images": 64, "pixels": 640 * 480, "triangles": int(len(mf)), "vertices": int(len(mv)),
+                                 "render_ms": dt9r * 1e3, "render_and_cost_ms": dt9 * 1e3, "states_per_s": 64 / dt9,
+                                 "note": "rendered and costed in HBM: no image crosses PCIe (only 64 x 3 tallies would)"}
     # depth image -> segment cloud (decode + mask + back-projection, ordered compaction)
     raw = rng.integers(2000, 60000, (480, 640)).astype(np.uint16)
     msk = (rng.random((480, 640)) < 0.5).astype(np.uint8)

@@ -25,6 +25,8 @@
 #ifndef PGP_H
 #define PGP_H
 
+#include <stddef.h>
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -428,6 +430,38 @@ int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsi
  * three integer tallies per image.  Host pointers, synchronous. */
 int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, int n, int rows, int cols,
                    float threshold, float* render_score, int* counts);
+
+/* Device-pointer form of pgp_depth_cost: d_observed (rows x cols) and d_rendered (n x rows x cols) are
+ * float images in HBM, d_counts (n x 3 ints, {obScore, renScore, intScore}) and d_scores (nullable, n
+ * floats = renderScore) are written there too; enqueued on `stream`, no synchronisation, no allocation. */
+int pgp_depth_cost_device(pgp_ctx* ctx, const float* d_observed, const float* d_rendered, int n, int rows, int cols,
+                          float threshold, int* d_counts, float* d_scores, void* stream);
+
+/* Depth images of a posed object for a batch of MCTS leaf states, rendered in HBM.  Replaces the OpenGL
+ * pass behind UCTState::render (PPE/hypothesis_verification/mcts/UCTState.cpp:44-72 ->
+ * src/3rdparty/depth_sim/src/renderScene.cpp:45-72): the object is drawn under each of the n poses with
+ * the camera's intrinsics, fragments beyond z_max are dropped (renderScene.cpp:69: 1 m), and every
+ * image starts from the parent state's image, the nearer surface winning (UCTState.cpp:62-68).
+ *   vertices: n_vert x vertex_stride floats (stride 3 or 4), object frame
+ *   triangles: n_tri x 3 vertex indices, or NULL = every vertex is splatted into its nearest pixel
+ *   T: n x 16 column-major float, object -> camera frame (convertToWorld/convertToCamera done by the caller)
+ *   parent (nullable): parent_stride == 0: ONE rows x cols image under all n; else image i at parent + i * parent_stride
+ *   depth: n x rows x cols floats, metres, 0 = no surface
+ * The rasterisation rules (pixel centres, inclusive edges, perspective-correct depth, atomic-min z-buffer)
+ * are stated in csrc/render.hip; OpenGL's are implementation-defined, so parity with the reference's
+ * renderer is unpinned and tests/_checkers.py restates the rules in numpy float32, bit for bit. */
+typedef struct {
+  int rows, cols;
+  float fx, fy, cx, cy;
+  float z_near;   /* points / triangles with a vertex at z <= z_near are dropped (<= 0: 0) */
+  float z_max;    /* fragments with z > z_max are dropped (<= 0: no limit); the reference uses 1.0 */
+} pgp_camera;
+int pgp_render_depth_device(pgp_ctx* ctx, const float* d_vertices, int vertex_stride, int n_vert, const int* d_triangles,
+                            int n_tri, const float* d_T, int n, const pgp_camera* cam, const float* d_parent,
+                            size_t parent_stride, float* d_depth, void* stream);
+/* Host pointers, synchronous (tests, small callers): parent is ONE image or NULL. */
+int pgp_render_depth(pgp_ctx* ctx, const float* vertices, int n_vert, const int* triangles, int n_tri, const float* T,
+                     int n, const pgp_camera* cam, const float* parent, float* depth);
 
 /* Replaces HypothesisSelection::greedyClustering (PPE/hypothesis_verification/HypothesisSelection.cpp:
  * 66-115) and its pose distance utilities::getPoseError (PPE/misc/utilities.cpp:514-548) for one

@@ -1,0 +1,111 @@
+"""CPU restatement (numpy float32, operation for operation) of csrc/render.hip -- TEST INFRASTRUCTURE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this file; nothing in
+physimglobalpose_amd/ does.  It restates the rules of the device depth renderer that replaces the
+OpenGL pass behind UCTState::render (PPE/hypothesis_verification/mcts/UCTState.cpp:44-72 ->
+src/3rdparty/depth_sim/src/renderScene.cpp:45-72) and the merge with the parent state's image
+(UCTState.cpp:62-68); the drop of depths beyond z_max is renderScene.cpp:69.  PARITY UNPINNED against
+the reference's renderer: OpenGL rasterisation is implementation-defined and neither pcl::simulation
+nor a GL context exists in this image; what is pinned is HIP path == this file, bit for bit."""
+import numpy as np
+
+F = np.float32
+
+
+def _row(a, b, c, t, x, y, z):
+    return ((a * x + b * y) + c * z) + t      # every product and sum rounded to float32 (arrays are float32)
+
+
+def project(vertices, T16, cam):
+    """-> px, py, z, valid (float32 arrays); T16 column-major object -> camera"""
+    v = np.asarray(vertices, F)
+    G = np.asarray(T16, F)
+    x = _row(G[0], G[4], G[8], G[12], v[:, 0], v[:, 1], v[:, 2])
+    y = _row(G[1], G[5], G[9], G[13], v[:, 0], v[:, 1], v[:, 2])
+    z = _row(G[2], G[6], G[10], G[14], v[:, 0], v[:, 1], v[:, 2])
+    valid = z > F(max(cam["z_near"], 0.0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        px = (F(cam["fx"]) * x) / z + F(cam["cx"])
+        py = (F(cam["fy"]) * y) / z + F(cam["cy"])
+    return px.astype(F), py.astype(F), z.astype(F), valid
+
+
+def _start(cam, parent):
+    rows, cols = cam["rows"], cam["cols"]
+    d = np.full((rows, cols), np.inf, F)
+    if parent is not None:
+        p = np.asarray(parent, F)
+        d = np.where(p > 0, p, d).astype(F)
+    return d
+
+
+def _finish(d):
+    d = d.copy()
+    d[np.isinf(d)] = 0.0
+    return d
+
+
+def _zmax(cam):
+    return F(cam["z_max"]) if cam["z_max"] > 0 else F(3.0e38)
+
+
+def splat(vertices, T16, cam, parent=None):
+    px, py, z, valid = project(vertices, T16, cam)
+    d = _start(cam, parent)
+    fu, fv = np.rint(px), np.rint(py)
+    ok = valid & (z <= _zmax(cam)) & (fu >= 0) & (fu < cam["cols"]) & (fv >= 0) & (fv < cam["rows"])
+    np.minimum.at(d, (fv[ok].astype(int), fu[ok].astype(int)), z[ok])
+    return _finish(d)
+
+
+def _edge(ax, ay, bx, by, px, py):
+    return (bx - ax) * (py - ay) - (by - ay) * (px - ax)
+
+
+def raster(vertices, triangles, T16, cam, parent=None):
+    px, py, z, valid = project(vertices, T16, cam)
+    d = _start(cam, parent)
+    rows, cols = cam["rows"], cam["cols"]
+    zn, zm = F(max(cam["z_near"], 0.0)), _zmax(cam)
+    half = F(0.5)
+    for i0, i1, i2 in np.asarray(triangles, np.int64).reshape(-1, 3):
+        if not (valid[i0] and valid[i1] and valid[i2]):
+            continue
+        x0, y0, z0 = px[i0], py[i0], z[i0]
+        x1, y1, z1 = px[i1], py[i1], z[i1]
+        x2, y2, z2 = px[i2], py[i2], z[i2]
+        area = _edge(x0, y0, x1, y1, x2, y2)
+        if not (area != 0):
+            continue
+        sgn = F(1.0) if area > 0 else F(-1.0)
+        minx, maxx = min(x0, x1, x2), max(x0, x1, x2)
+        miny, maxy = min(y0, y1, y2), max(y0, y1, y2)
+        if not (maxx >= 0 and maxy >= 0 and minx <= F(cols) and miny <= F(rows)):
+            continue
+        xa = int(max(np.ceil(F(minx - half)), F(0))); xb = int(min(np.floor(F(maxx - half)), F(cols - 1)))
+        ya = int(max(np.ceil(F(miny - half)), F(0))); yb = int(min(np.floor(F(maxy - half)), F(rows - 1)))
+        if xa > xb or ya > yb:
+            continue
+        cx = (np.arange(xa, xb + 1).astype(F) + half)[None, :]
+        cy = (np.arange(ya, yb + 1).astype(F) + half)[:, None]
+        e0 = sgn * _edge(x1, y1, x2, y2, cx, cy)
+        e1 = sgn * _edge(x2, y2, x0, y0, cx, cy)
+        e2 = sgn * _edge(x0, y0, x1, y1, cx, cy)
+        inside = (e0 >= 0) & (e1 >= 0) & (e2 >= 0)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            den = ((e0 / z0) + (e1 / z1)) + (e2 / z2)
+            zz = ((sgn * area) / den).astype(F)
+        keep = inside & (zz > zn) & (zz <= zm)
+        sub = d[ya:yb + 1, xa:xb + 1]
+        sub[keep] = np.minimum(sub[keep], zz[keep])
+    return _finish(d)
+
+
+def depth_cost(observed, rendered, thr=0.01):
+    """UCTState::computeCost (UCTState.cpp:93-116): integer tallies {obScore, renScore, intScore} per image"""
+    o = np.asarray(observed, F)
+    out = []
+    for r in np.asarray(rendered, F):
+        far = np.abs(o - r) > F(thr)
+        out.append([int(((o > 0) & far).sum()), int(((r > 0) & far).sum()), int(((o > 0) & (r > 0) & far).sum())])
+    return np.array(out, np.int32)

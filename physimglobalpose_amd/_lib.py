@@ -35,6 +35,11 @@ class IcpOptions(C.Structure):
                 ("min_diff_trans", C.c_float), ("smooth_length", C.c_int), ("nn_search", C.c_int)]
 
 
+class Camera(C.Structure):
+    _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
+                ("cy", C.c_float), ("z_near", C.c_float), ("z_max", C.c_float)]
+
+
 class ClusterParams(C.Structure):
     _fields_ = [("accept_fraction", C.c_float), ("rot_thresh_deg", C.c_float), ("trans_thresh", C.c_float)]
 
@@ -106,6 +111,11 @@ SIGNATURES = {
     "pgp_cluster_poses_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_float, _f,
                                            C.POINTER(ClusterParams), C.c_void_p, C.c_void_p, _i, C.c_void_p]),
     "pgp_depth_cost": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_int, C.c_int, C.c_float, _f, _i]),
+    "pgp_depth_cost_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "pgp_render_depth_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                          C.c_int, C.POINTER(Camera), C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "pgp_render_depth": (C.c_int, [C.c_void_p, _f, C.c_int, _i, C.c_int, _f, C.c_int, C.POINTER(Camera), _f, _f]),
     "pgp_cluster_poses": (C.c_int, [C.c_void_p, _f, _f, C.c_int, C.c_float, _f, C.POINTER(ClusterParams), _i,
                                     C.c_int, _i, _i]),
     "pgp_pose_error": (C.c_int, [C.c_void_p, _f, _f, C.c_int, _f, _f, _f]),

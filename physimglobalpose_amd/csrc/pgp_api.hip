@@ -179,7 +179,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -1291,6 +1291,68 @@ int pgp_depth_cost(pgp_ctx* ctx, const float* observed, const float* rendered, i
       counts[3 * i + 2] = hc[3 * i + 2];
     }
   }
+  return PGP_OK;
+}
+
+int pgp_depth_cost_device(pgp_ctx* ctx, const float* d_observed, const float* d_rendered, int n, int rows, int cols,
+                          float threshold, int* d_counts, float* d_scores, void* stream) {
+  if (!ctx || n < 0 || rows < 0 || cols < 0 || (n > 0 && (!d_observed || !d_rendered || !d_counts))) {
+    set_error("pgp_depth_cost_device: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n == 0) return PGP_OK;
+  CtxGuard guard(ctx, false);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int rc = launch_depth_cost(ctx, d_observed, d_rendered, n, (int)((size_t)rows * cols), threshold, d_counts, st);
+  if (rc == PGP_OK && d_scores) rc = launch_cost_scores(d_counts, n, d_scores, st);
+  note_device_work(ctx, st);
+  return rc;
+}
+
+int pgp_render_depth_device(pgp_ctx* ctx, const float* d_vertices, int vertex_stride, int n_vert, const int* d_triangles,
+                            int n_tri, const float* d_T, int n, const pgp_camera* cam, const float* d_parent,
+                            size_t parent_stride, float* d_depth, void* stream) {
+  if (!ctx || !cam || n < 0 || n_vert < 0 || n_tri < 0 || (n > 0 && (!d_T || !d_depth)) || (n_vert > 0 && !d_vertices)) {
+    set_error("pgp_render_depth_device: bad argument");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx, false);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rc = launch_render_depth(ctx, d_vertices, vertex_stride, n_vert, d_triangles, n_tri, d_T, n, cam, d_parent,
+                                     parent_stride, d_depth, st);
+  note_device_work(ctx, st);
+  return rc;
+}
+
+int pgp_render_depth(pgp_ctx* ctx, const float* vertices, int n_vert, const int* triangles, int n_tri, const float* T,
+                     int n, const pgp_camera* cam, const float* parent, float* depth) {
+  if (!ctx || !cam || n < 0 || n_vert < 0 || n_tri < 0 || (n > 0 && (!T || !depth)) || (n_vert > 0 && !vertices) ||
+      cam->rows <= 0 || cam->cols <= 0) {
+    set_error("pgp_render_depth: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t n_pix = (size_t)cam->rows * cam->cols;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t off_t = up((size_t)std::max(n_vert, 1) * 12), off_T = off_t + up((size_t)std::max(n_tri, 1) * 12),
+               off_p = off_T + up((size_t)n * 64), off_o = off_p + up(n_pix * 4), total = off_o + n_pix * 4 * (size_t)n;
+  int rc = ctx->d_render_io.ensure(total);
+  if (rc != PGP_OK) return rc;
+  unsigned char* d = ctx->d_render_io.as<unsigned char>();
+  if (n_vert > 0) PGP_HIP(hipMemcpyAsync(d, vertices, (size_t)n_vert * 12, hipMemcpyHostToDevice, st));
+  if (triangles && n_tri > 0) PGP_HIP(hipMemcpyAsync(d + off_t, triangles, (size_t)n_tri * 12, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipMemcpyAsync(d + off_T, T, (size_t)n * 64, hipMemcpyHostToDevice, st));
+  if (parent) PGP_HIP(hipMemcpyAsync(d + off_p, parent, n_pix * 4, hipMemcpyHostToDevice, st));
+  rc = launch_render_depth(ctx, reinterpret_cast<const float*>(d), 3, n_vert,
+                           triangles ? reinterpret_cast<const int*>(d + off_t) : nullptr, n_tri,
+                           reinterpret_cast<const float*>(d + off_T), n, cam,
+                           parent ? reinterpret_cast<const float*>(d + off_p) : nullptr, 0,
+                           reinterpret_cast<float*>(d + off_o), st);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(depth, d + off_o, n_pix * 4 * (size_t)n, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
   return PGP_OK;
 }
 

@@ -116,6 +116,7 @@ struct pgp_ctx {
   bool hd_attr_set = false;
 
   pgp::DevBuf d_depth;   // depth-cost staging: observed | rendered[n] | counts
+  pgp::DevBuf d_render_ws, d_render_io;   // render.hip: projected vertices [n][n_vert]; host-API staging
   pgp::DevBuf d_bp;      // back-projection staging: image | mask | counters | scan scratch | xyz
   pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
 
@@ -243,6 +244,12 @@ int launch_mls(pgp_ctx* ctx, const float* d_xyz, int n, float radius, float* d_o
 // depth_cost.hip
 int launch_depth_cost(pgp_ctx* ctx, const float* d_obs, const float* d_ren, int n, int n_pix, float thr,
                       int* d_counts, hipStream_t stream);
+
+// render.hip
+int launch_render_depth(pgp_ctx* ctx, const float* d_verts, int stride, int n_vert, const int* d_tris, int n_tri,
+                        const float* d_T, int n, const pgp_camera* cam, const float* d_parent, size_t parent_stride,
+                        float* d_depth, hipStream_t st);
+int launch_cost_scores(const int* d_counts, int n, float* d_scores, hipStream_t st);
 
 // cluster.hip
 int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n, float best_score,

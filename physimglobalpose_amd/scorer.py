@@ -359,6 +359,61 @@ class LcpScorer:
                                             C.c_float(threshold), _fp(score), counts.ctypes.data_as(_i)))
         return score, counts
 
+    def depth_cost_device(self, d_observed, d_rendered, threshold=0.01, d_counts=None, d_scores=None, stream=None):
+        """cuda float32 tensors: observed (rows,cols), rendered (n,rows,cols) -> (d_counts (n,3) int32, d_scores (n,))
+        on the device; enqueued, no synchronisation."""
+        import torch
+        n, rows, cols = d_rendered.shape
+        assert d_observed.is_cuda and d_rendered.is_cuda and d_observed.is_contiguous() and d_rendered.is_contiguous()
+        if d_counts is None:
+            d_counts = torch.empty((n, 3), dtype=torch.int32, device=d_rendered.device)
+        if d_scores is None:
+            d_scores = torch.empty(n, dtype=torch.float32, device=d_rendered.device)
+        st = stream if isinstance(stream, int) else (stream or torch.cuda.current_stream(d_rendered.device)).cuda_stream
+        _lib.check(self._lib.pgp_depth_cost_device(self._h, C.c_void_p(d_observed.data_ptr()), C.c_void_p(d_rendered.data_ptr()),
+                                                   int(n), int(rows), int(cols), C.c_float(threshold),
+                                                   C.c_void_p(d_counts.data_ptr()), C.c_void_p(d_scores.data_ptr()),
+                                                   C.c_void_p(st)))
+        return d_counts, d_scores
+
+    @staticmethod
+    def camera(K, rows, cols, z_near=0.1, z_max=1.0):
+        """pgp_camera from a 3x3 intrinsic matrix; z_max 1.0 = renderScene.cpp:69."""
+        K = np.asarray(K, np.float32)
+        return _lib.Camera(int(rows), int(cols), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]),
+                           float(z_near), float(z_max))
+
+    def render_depth(self, vertices, triangles, T, cam, parent=None):
+        """Host arrays: vertices (n_vert,3), triangles (n_tri,3) int32 or None (point splat), T (n,16) col-major
+        object -> camera, parent (rows,cols) or None -> depth (n,rows,cols) float32."""
+        v = _f32(vertices, 3)
+        T = _f32(T, 16)
+        tri = None if triangles is None else np.ascontiguousarray(triangles, np.int32).reshape(-1, 3)
+        par = None if parent is None else np.ascontiguousarray(parent, np.float32)
+        out = np.zeros((len(T), cam.rows, cam.cols), np.float32)
+        _lib.check(self._lib.pgp_render_depth(self._h, _fp(v), len(v), None if tri is None else tri.ctypes.data_as(_i),
+                                              0 if tri is None else len(tri), _fp(T), len(T), C.byref(cam),
+                                              None if par is None else _fp(par), _fp(out)))
+        return out
+
+    def render_depth_device(self, d_vertices, d_triangles, d_T, cam, d_parent=None, d_depth=None, stream=None):
+        """cuda tensors: vertices (n_vert,3|4) float32, triangles (n_tri,3) int32 or None, T (n,16), parent None |
+        (rows,cols) shared | (n,rows,cols) one per image -> d_depth (n,rows,cols); enqueued, no synchronisation."""
+        import torch
+        n = int(d_T.shape[0])
+        if d_depth is None:
+            d_depth = torch.empty((n, cam.rows, cam.cols), dtype=torch.float32, device=d_T.device)
+        stride = 0
+        if d_parent is not None and d_parent.dim() == 3:
+            stride = cam.rows * cam.cols
+        st = stream if isinstance(stream, int) else (stream or torch.cuda.current_stream(d_T.device)).cuda_stream
+        _lib.check(self._lib.pgp_render_depth_device(
+            self._h, C.c_void_p(d_vertices.data_ptr()), int(d_vertices.shape[1]), int(d_vertices.shape[0]),
+            C.c_void_p(0 if d_triangles is None else d_triangles.data_ptr()), 0 if d_triangles is None else int(d_triangles.shape[0]),
+            C.c_void_p(d_T.data_ptr()), n, C.byref(cam), C.c_void_p(0 if d_parent is None else d_parent.data_ptr()),
+            C.c_size_t(stride), C.c_void_p(d_depth.data_ptr()), C.c_void_p(st)))
+        return d_depth
+
     # ---- hypothesis clustering (HypothesisSelection::greedyClustering) ---------------------------
     def cluster_poses(self, T, scores, best_score=None, sym_deg=(0, 0, 0), accept_fraction=0.5,
                       rot_thresh_deg=10.0, trans_thresh=0.02):
