@@ -39,7 +39,10 @@ HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # SIMD (tools/valu_rates.hip -> profiles/r02_valu_rates.json): 2.5 cycles for the simple VOP2 ops on
 # registers, 4.2 for everything else, 4.4 for packed / 64-bit ops, 4.2 for a scalar instruction.  (Round 2
 # first priced every VALU op at 2 cycles: tools/peaks.hip's "v_add_f32" loop had been compiled to
-# v_pk_add_f32, two adds per instruction.)
+# v_pk_add_f32, two adds per instruction.)  Cross-checked in FLOP/s against the spec (tools/fp32_peak.hip ->
+# profiles/r03_valu_rates.json): v_pk_fma_f32 149.6 TFLOP/s = 95 % of the 157.3 TFLOP/s FP32 vector peak at 4.18
+# cycles per instruction and 2.39 GHz in-kernel, plain v_fma_f32 84.7 TFLOP/s at 3.7 cycles -- the spec peak
+# is the PACKED rate, a wave64 v_fma_f32 does not issue in 2 cycles, and these costs are the roofline's unit.
 N_SIMD, CLOCK_GHZ = 256 * 4, 2.4
 VALU_CYCLES_DEFAULT = 4.0   # used only if the counters file carries no static mix of the kernel
 SALU_CYCLES = 4.2
