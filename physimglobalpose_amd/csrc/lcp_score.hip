@@ -1008,7 +1008,11 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
       }
     }
     float score = (mode == PGP_MODE_PLAIN) ? __fdiv_rn((float)c, (float)nQ) : __fdiv_rn(f, (float)nQ);
-    scores[h] = score;
+    // write-through (global_store ... sc1): the score leaves this XCD's L2 for memory, where the block that
+    // settles a near-tie -- on whatever die -- can read it after ONE acquire of its own, taken only in that
+    // rare case.  (A plain store + a release fence per block + an acquire in the last block cost this launch
+    // two ~3.5 us fences on its critical chain, every call: MI355X_MICROARCH.md, __threadfence row.)
+    __hip_atomic_store(&scores[h], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (counts) counts[h] = c;
     if (score > 0.f)  // NaN and <= 0 never become best (best_LCP_ starts at 0, strict >)
       key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
@@ -1033,7 +1037,8 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
     s_key[threadIdx.x >> 6] = key;
     s_key2[threadIdx.x >> 6] = key2;
   }
-  __syncthreads();   // also: every wave's score stores have left the CU (s_waitcnt vmcnt(0) + barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's write-through score stores are complete ...
+  __syncthreads();                                    // ... and so are every wave's of this block, before its ticket
   if (threadIdx.x == 0) {
     unsigned long long k = 0, k2 = 0;
     for (int w = 0; w < 4; ++w) {
@@ -1052,12 +1057,11 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
       if (push) atomicMax(runner_key, push);
     }
     if (k2) atomicMax(runner_key, k2);
-    __threadfence();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back completes before the ticket
+    // device-scope atomics are performed at the memory side and need no fence to be seen by the other dies;
+    // they must only have been performed before this block's ticket is
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const bool last = atomicAdd(ticket, 1u) == gridDim.x - 1;
     if (last) {
-      __threadfence();   // acquire: this CU's L1 holds no stale line of the other blocks' scores
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       s_kk = atomicExch(best_key, 0ull);  // read the result and re-arm
       s_kk2 = atomicExch(runner_key, 0ull);
       atomicExch(ticket, 0u);
@@ -1072,6 +1076,13 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
                         __uint_as_float((unsigned)(kk2 >> 32)) >=
                             __uint_as_float((unsigned)(kk >> 32)) - refine_tol(__uint_as_float((unsigned)(kk >> 32)), nQ);
   if (near_tie) {
+    // the other blocks' scores are in memory (write-through stores, drained before their tickets); this CU's
+    // L1 may hold stale lines of them: one agent-scope acquire by one lane, completed before anyone reads
+    if (threadIdx.x == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
     settle_and_publish(a, n_h, mode, refine, scores, kk, best, seq, s_key);
   } else if (threadIdx.x == 0) {
     if (kk == 0) {
@@ -1372,7 +1383,13 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     // 4 hypotheses per block to amortise the model-point load
     long long work = (long long)n_h * a.n_tiles;
     int hpb = ctx->hpb_override > 0 ? ctx->hpb_override : (int)(work / 10240);
-    if (hpb < 4) hpb = 4;
+    // small batches: a workgroup's trips run one after the other (~1.2 us each), so with few workgroups per
+    // CU the launch lasts as long as its longest workgroup: 2 hypotheses per block up to 512, 3 up to 768, 4
+    // beyond (tools/small_batch.py: 512 hypotheses 29.4 -> 26.1 us, 256: 23.1 -> 19.9 us; 1024: 38.9 at 4, 40.0 at 2)
+    if (hpb < 4 && ctx->hpb_override <= 0) {
+      hpb = (int)(work / 5120);
+      hpb = hpb < 2 ? 2 : (hpb > 4 ? 4 : hpb);
+    }
     // more than 16 per block never paid (tools/tune.py: 16 384 hypotheses 313 us at 8..16 vs 325 us
     // at 32; 65 536 hypotheses 1168 us at 16 vs 1201 us at 64); an explicit PGP_HPB may go to 64
     if (ctx->hpb_override <= 0 && hpb > 16) hpb = 16;

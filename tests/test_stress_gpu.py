@@ -88,3 +88,47 @@ def test_wave_total_above_flat_capacity():
     for h in range(3):
         _, reg = orc.weighted_verify(T[h], delta)
         assert np.array_equal(sc.registered(T[h], PGP_MODE_WEIGHTED), reg)
+
+
+def test_near_tie_settlement_reads_fresh_scores_across_blocks_and_calls():
+    """finalize_scores hands every block's scores to the ONE block that settles a near-tie through
+    write-through stores and a single acquire (no release fence per block): alternate crowded batches that
+    reuse the same score buffer, so a stale cache line of the previous call's scores -- on any die -- would
+    move the arg-max or its score.  Several finalize blocks (thousands of hypotheses), near-ties in every
+    call, device-resident buffers, 60 calls back to back plus background scoring load in between."""
+    import torch
+    w = synth.make_workload(20000, 2000, 1024, config_id=5)
+    rng = np.random.default_rng(55)
+    sc = LcpScorer(0)
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
+    s0 = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)[0]
+    order = np.argsort(-s0)
+    batches = []
+    for k in range(3):     # three batches, each with ~60 near-copies of a different good pose spread over all blocks
+        base = w.T[order[k]].reshape(4, 4, order="F").astype(np.float64)
+        crowd = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng, 2e-4), 2e-5 * rng.standard_normal(3)) @ base)
+                          for _ in range(60)])
+        others = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng, 0.05), 0.004 * rng.standard_normal(3)) @
+                                            w.T[h].reshape(4, 4, order="F").astype(np.float64))
+                           for h in order[rng.integers(3, 400, 2940)]])
+        T = np.concatenate([others, crowd])[rng.permutation(3000)].astype(np.float32)
+        so, bio, _ = orc.score_batch(T, w.delta, mode=1, gate_deg=w.gate_deg, threads=8)
+        batches.append((torch.from_numpy(T).cuda(), bio, so[bio]))
+    n = 3000
+    sc.reserve(n)
+    ds = torch.zeros(n, device="cuda")
+    db = torch.zeros(2, dtype=torch.int32, device="cuda")
+    results = []
+    for it in range(60):
+        dT, bio, bso = batches[it % 3]
+        sc.score_device(dT, ds, None, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+        results.append((db.clone(), ds[bio:bio + 1].clone()))
+        if it % 7 == 3:                     # other work between the calls: the caches are not left as they were
+            sc.score_device(batches[(it + 1) % 3][0][:1024].contiguous(), ds[:1024], None, None, mode=PGP_MODE_PLAIN)
+    torch.cuda.synchronize()
+    for it, (b, sv) in enumerate(results):
+        _, bio, bso = batches[it % 3]
+        b = b.cpu().numpy()
+        assert int(b[0]) == bio, (it, int(b[0]), bio)
+        assert np.float32(b[1:].view(np.float32)[0]) == bso and np.float32(sv.item()) == bso, it
