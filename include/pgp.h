@@ -80,6 +80,12 @@ int pgp_weights_from_image(const float* P_xyz, int n, const float centroid_P[3],
 int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float* weight, int n,
                   float delta);
 
+/* Replaces the weights of the resident scene (n must be the scene's point count) without touching
+ * its points or index: the per-point probabilities come from an image (base.cc:317-340) that a caller
+ * can still be decoding while pgp_set_scene builds the index from the coordinates.  Host pointer,
+ * synchronous.  pgp_multi_set_scene_weights: the same on every device of a group. */
+int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n);
+
 /* Replaces `validation_Q_3D = Q_validation` (base.cc:237).  Host pointers, synchronous. */
 int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n);
 
@@ -514,6 +520,7 @@ pgp_ctx* pgp_multi_context(pgp_multi* m, int k);       /* device k's context, fo
 int pgp_multi_slice(int n_total, int k, int n_dev, int* lo, int* hi);   /* host helper: device k's [lo, hi) */
 int pgp_multi_set_scene(pgp_multi* m, const float* xyz, const float* nrm, const float* weight, int n,
                         float delta);
+int pgp_multi_set_scene_weights(pgp_multi* m, const float* weight, int n);
 int pgp_multi_set_model(pgp_multi* m, const float* xyz, const float* nrm, int n);
 int pgp_multi_score_lcp(pgp_multi* m, const float* T, int n_h, int mode, float gate_deg, float* scores,
                         int* counts, int* best_index, float* best_score);

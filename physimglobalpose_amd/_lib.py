@@ -88,6 +88,8 @@ SIGNATURES = {
                                         C.c_int, C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_icp_default_options": (C.c_int, [C.POINTER(IcpOptions)]),
     "pgp_icp_target_token": (C.c_int, [C.c_void_p, C.c_ulonglong]),
+    "pgp_set_scene_weights": (C.c_int, [C.c_void_p, _f, C.c_int]),
+    "pgp_multi_set_scene_weights": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_icp_refine_ex": (C.c_int, [C.c_void_p, _f, C.c_int, _f, _f, C.c_int, _f, C.c_int,
                                     C.POINTER(IcpOptions), _f, _i]),
     "pgp_icp_refine_ex_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int,

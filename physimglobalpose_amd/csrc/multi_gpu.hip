@@ -353,6 +353,14 @@ int pgp_multi_set_scene(pgp_multi* m, const float* xyz, const float* nrm, const 
   return run_all(m, [=](int k) -> int { return pgp_set_scene(m->ctx[k], xyz, nrm, weight, n, delta); });
 }
 
+int pgp_multi_set_scene_weights(pgp_multi* m, const float* weight, int n) {
+  if (!m) {
+    set_error("pgp_multi_set_scene_weights: handle is NULL");
+    return PGP_EINVAL;
+  }
+  return run_all(m, [=](int k) -> int { return pgp_set_scene_weights(m->ctx[k], weight, n); });
+}
+
 int pgp_multi_set_model(pgp_multi* m, const float* xyz, const float* nrm, int n) {
   if (!m) {
     set_error("pgp_multi_set_model: handle is NULL");

@@ -289,6 +289,26 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
   return build_index(ctx, xyz, delta);
 }
 
+int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n) {
+  if (!ctx || n < 0 || (n > 0 && !weight)) {
+    set_error("pgp_set_scene_weights: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n != ctx->nP) {
+    set_error("pgp_set_scene_weights: %d weights for a scene of %d points", n, ctx->nP);
+    return PGP_ESTATE;
+  }
+  if (n == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  int rc = ctx->d_pre_io.ensure((size_t)n * 4);
+  if (rc != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, weight, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = launch_scene_weights(ctx, ctx->d_pre_io.as<float>(), n, ctx->stream)) != PGP_OK) return rc;
+  PGP_HIP(hipStreamSynchronize(ctx->stream));   // `weight` is the caller's
+  ctx->prob_cdf_valid = false;                  // base selection draws from these weights
+  return PGP_OK;
+}
+
 int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
   if (!ctx || n < 0 || (n > 0 && !xyz)) {
     set_error("pgp_set_model: bad argument (n=%d)", n);

@@ -227,6 +227,21 @@ int device_bbox3(pgp_ctx* ctx, const float* d_xyz, int n, int stride, float mn[3
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void scene_weights(float4* __restrict__ Pnw, const float* __restrict__ w, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) Pnw[i].w = w[i];
+}
+}  // namespace
+
+// the weights of the resident scene replaced (d_w: n device floats); enqueued on st
+int launch_scene_weights(pgp_ctx* ctx, const float* d_w, int n, hipStream_t st) {
+  if (n <= 0) return PGP_OK;
+  hipLaunchKernelGGL(scene_weights, dim3((n + 255) / 256), dim3(256), 0, st, ctx->d_Pnw.as<float4>(), d_w, n);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
 int device_bbox(pgp_ctx* ctx, const float* d_pts, int n, int stride, float mn[3], float mx[3], hipStream_t st) {
   return device_bbox3(ctx, d_pts, n, stride, mn, mx, st);
 }

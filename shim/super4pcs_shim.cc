@@ -38,12 +38,14 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <map>
 #include <random>
 #include <set>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <zlib.h>
@@ -99,11 +101,14 @@ double ply_read_bin(const unsigned char* p, const std::string& t) {
   return 0;
 }
 
-// One decimal number of an ASCII vertex line as a correctly rounded double -- what `stream >> double` and
-// strtod return.  Fast path (Clinger): at most 15 significant digits and a decimal exponent within +-22 make
-// mantissa and power of ten both exact doubles, so ONE multiplication or division rounds correctly; anything
-// else (long mantissas, nan / inf, hex floats) goes to strtod itself.
-inline bool ascii_number(const char** pp, double* out) {
+// One decimal number of an ASCII vertex line as the FLOAT the reference reads: fscanf("%f", &float)
+// (S4/io/io_ply.h:272-296) converts decimal -> float with ONE rounding (strtof).  Fast path (Clinger): at
+// most 15 significant digits and a decimal exponent within +-22 make mantissa and power of ten both exact
+// doubles, so one multiplication or division gives the correctly rounded DOUBLE; casting that to float is a
+// second rounding and agrees with strtof unless the double sits on (or within one double-ulp of) the midpoint
+// of two floats -- 29 discarded mantissa bits reading 0x0FFFFFFF .. 0x10000001 -- or outside the normal
+// float range; those, long mantissas, nan / inf and hex floats go to strtof itself.
+inline bool ascii_number(const char** pp, float* out) {
   static const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
                                     1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
   const char* p = *pp;
@@ -153,14 +158,21 @@ inline bool ascii_number(const char** pp, double* out) {
   if (any && fast && end_ok && exp10 >= -22 && exp10 <= 22) {
     double d = (double)mant;   // < 10^15 < 2^53: exact
     d = exp10 < 0 ? d / kPow10[-exp10] : d * kPow10[exp10];
-    *out = neg ? -d : d;
-    *pp = p;
-    return true;
+    uint64_t bits;
+    std::memcpy(&bits, &d, 8);
+    const uint32_t low = (uint32_t)(bits & 0x1FFFFFFFull);          // the mantissa bits a float drops
+    const int e2 = (int)((bits >> 52) & 0x7FF) - 1023;
+    const bool midpoint = low >= 0x0FFFFFFFu && low <= 0x10000001u;
+    if (mant == 0 || (!midpoint && e2 >= -126 && e2 <= 126)) {
+      *out = neg ? -(float)d : (float)d;
+      *pp = p;
+      return true;
+    }
   }
   char* end = nullptr;
-  const double d = std::strtod(start, &end);
+  const float f = std::strtof(start, &end);
   if (end == start) return false;
-  *out = d;
+  *out = f;
   *pp = end;
   return true;
 }
@@ -216,6 +228,7 @@ bool read_ply(const std::string& path, Cloud& out) {
   out.xyz.assign((size_t)n_vertex * 3, 0.f);
   out.nrm.assign((size_t)n_vertex * 3, 0.f);
   std::vector<double> v(props.size());
+  std::vector<float> vf(props.size());
   if (ascii) {
     // the vertex block in one read, numbers by ascii_number(): stream extraction of 43 000 doubles was 4.3 of
     // the drop-in's 6 ms per object
@@ -230,10 +243,10 @@ bool read_ply(const std::string& path, Cloud& out) {
     const char* p = text.data();
     for (long i = 0; i < n_vertex; ++i) {
       for (size_t k = 0; k < props.size(); ++k)
-        if (!ascii_number(&p, &v[k])) return false;
-      out.xyz[3 * i] = (float)v[ix]; out.xyz[3 * i + 1] = (float)v[iy]; out.xyz[3 * i + 2] = (float)v[iz];
+        if (!ascii_number(&p, &vf[k])) return false;
+      out.xyz[3 * i] = vf[ix]; out.xyz[3 * i + 1] = vf[iy]; out.xyz[3 * i + 2] = vf[iz];
       if (inx >= 0 && iny >= 0 && inz >= 0) {
-        out.nrm[3 * i] = (float)v[inx]; out.nrm[3 * i + 1] = (float)v[iny]; out.nrm[3 * i + 2] = (float)v[inz];
+        out.nrm[3 * i] = vf[inx]; out.nrm[3 * i + 1] = vf[iny]; out.nrm[3 * i + 2] = vf[inz];
       }
     }
   } else {
@@ -292,32 +305,41 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
   std::vector<unsigned char> raw((stride + 1) * (size_t)rows);
   uLongf raw_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
-  std::vector<unsigned char> prev(stride, 0), cur(stride);
+  // undo the scanline filters IN PLACE, one specialised loop per row (the filter type is per row; a switch
+  // inside the per-byte loop made this the dearest part of the whole file hand-off: 1.7 ms of 2 at 640 x 480 x 16 bit)
   px.assign((size_t)rows * cols, 0);
+  const std::vector<unsigned char> zero_row(stride, 0);
+  const size_t B = (size_t)bpp;
   for (int r = 0; r < rows; ++r) {
-    const unsigned char* in = raw.data() + (stride + 1) * (size_t)r;
-    const int ft = in[0];
-    for (size_t i = 0; i < stride; ++i) {
-      int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= (size_t)bpp ? prev[i - bpp] : 0;
-      int x = in[1 + i], rec;
-      switch (ft) {
-        case 0: rec = x; break;
-        case 1: rec = x + a; break;
-        case 2: rec = x + b; break;
-        case 3: rec = x + ((a + b) >> 1); break;
-        case 4: {
-          int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-          int pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          rec = x + pr;
-          break;
+    unsigned char* cur = raw.data() + (stride + 1) * (size_t)r + 1;
+    const unsigned char* prev = r > 0 ? cur - (stride + 1) : zero_row.data();
+    switch (cur[-1]) {
+      case 0: break;
+      case 1:
+        for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + cur[i - B]);
+        break;
+      case 2:
+        for (size_t i = 0; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]);
+        break;
+      case 3:
+        for (size_t i = 0; i < B && i < stride; ++i) cur[i] = (unsigned char)(cur[i] + (prev[i] >> 1));
+        for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
+        break;
+      case 4:
+        for (size_t i = 0; i < B && i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]);   // a = c = 0: predictor b
+        for (size_t i = B; i < stride; ++i) {
+          const int a = cur[i - B], b2 = prev[i], c = prev[i - B];
+          const int p = a + b2 - c, pa = std::abs(p - a), pb = std::abs(p - b2), pc = std::abs(p - c);
+          cur[i] = (unsigned char)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b2 : c)));
         }
-        default: return false;
-      }
-      cur[i] = (unsigned char)(rec & 0xFF);
+        break;
+      default: return false;
     }
-    for (int cidx = 0; cidx < cols; ++cidx)
-      px[(size_t)r * cols + cidx] = depth == 16 ? (uint16_t)((cur[2 * cidx] << 8) | cur[2 * cidx + 1]) : cur[cidx];
-    prev.swap(cur);
+    uint16_t* out = px.data() + (size_t)r * cols;
+    if (depth == 16)
+      for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = (uint16_t)((cur[2 * cidx] << 8) | cur[2 * cidx + 1]);
+    else
+      for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = cur[cidx];
   }
   return true;
 }
@@ -326,14 +348,18 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
 // Per-thread device state kept across calls: the context (and, with PGP_SHIM_DEVICES > 1, the
 // device group) and the flattened pair-feature table of the object that was matched last -- the
 // node hands the SAME std::map of an object to every request (PPE/data_layer/Objects.cpp:31-49 fills
-// it once), so its 10^4-10^5 keys are flattened and uploaded again only when a different map (by
-// address and size) arrives.  PGP_SHIM_NO_CACHE=1 gives every call a fresh context.
+// it once), so its 10^4-10^5 keys are flattened and uploaded again only when a different map arrives:
+// different address, size, first / last entry (keys, pair counts, first pairs) or target context.  A caller
+// that rebuilds a map IN PLACE with the same size and the same two end entries would still be taken for the
+// old one: such callers set PGP_SHIM_NO_CACHE=1 (every call gets a fresh context and uploads its map).
 // ---------------------------------------------------------------------------------------------
 struct ShimState {
   pgp_ctx* ctx = nullptr;
   pgp_multi* group = nullptr;
   const void* map_addr = nullptr;
   size_t map_size = 0;
+  unsigned long long map_print = 0;   // fingerprint of the map's two end entries
+  const void* map_ctx = nullptr;      // the context the table was uploaded to
   ~ShimState() {
     if (group) pgp_multi_destroy(group);
     if (ctx) pgp_destroy(ctx);
@@ -397,7 +423,7 @@ extern "C" int super4pcs_shim_read_cloud(const char* path, float* xyz, float* nr
 
 // C-linkage probe for the tests: the reader's number parser on a whitespace-separated list; returns how many
 // numbers it produced (it stops at the first token it rejects).
-extern "C" int super4pcs_shim_parse_numbers(const char* text, double* out, int cap) {
+extern "C" int super4pcs_shim_parse_numbers(const char* text, float* out, int cap) {
   const char* p = text;
   int n = 0;
   while (n < cap && ascii_number(&p, &out[n])) ++n;
@@ -432,6 +458,14 @@ bool super4pcs_shim_read_png16(const std::string& path, std::vector<unsigned sho
   return true;
 }
 
+static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
+                       const Super4PCSCloudView& model_search,
+                       const std::function<const unsigned short*(int*, int*)>& image,
+                       std::pair<Eigen::Isometry3d, float>& bestHypothesis,
+                       std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
+                       std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
+                       Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points);
+
 void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std::string input3,
                                     std::pair<Eigen::Isometry3d, float>& bestHypothesis,
                                     std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
@@ -442,20 +476,54 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
   (void)max_count_ppf; (void)objName; (void)scenePath;
   set_identity(bestHypothesis);
   // ---- file hand-off (super4pcs_test.cc:58-80): set1 = segment, set2 = validation model, set3 = search model
+  // the four files are parsed on four host threads (three ASCII PLYs + the PNG's inflate): the parse was
+  // ~1.7 of the drop-in's 3.6 ms per object on one thread
   Cloud seg, qval, qsearch;
-  if (!read_ply(input1, seg) || !read_ply(input2, qval) || !read_ply(input3, qsearch)) {
+  std::vector<uint16_t> px;
+  int rows = 0, cols = 0;
+  bool ok1 = false, ok2 = false, ok3 = false, have = false;
+  const auto t_files = std::chrono::steady_clock::now();
+  double ms_part[4] = {0, 0, 0, 0};
+  auto timed = [&](int k, const std::function<void()>& fn) {
+    const auto t0 = std::chrono::steady_clock::now();
+    fn();
+    ms_part[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  };
+  // the PNG (inflate + unfilter: the longest of the four) keeps decoding while the clouds are centred,
+  // uploaded and indexed; the match waits for it only where the weights are first needed
+  std::thread t4([&] { timed(3, [&] { have = read_png_gray(probImagePath, px, rows, cols); }); });
+  {
+    std::thread t2([&] { timed(1, [&] { ok2 = read_ply(input2, qval); }); });
+    std::thread t3([&] { timed(2, [&] { ok3 = read_ply(input3, qsearch); }); });
+    timed(0, [&] { ok1 = read_ply(input1, seg); });
+    t2.join();
+    t3.join();
+  }
+  if (!ok1 || !ok2 || !ok3) {
+    t4.join();
     std::cerr << "[libsuper4pcs shim] cannot read the input PLY files" << std::endl;
     return;
   }
-  std::vector<uint16_t> px;
-  int rows = 0, cols = 0;
-  const bool have = read_png_gray(probImagePath, px, rows, cols);
-  if (!have) std::cerr << "[libsuper4pcs shim] no probability image at " << probImagePath << ": weights = 1" << std::endl;
   const Super4PCSCloudView vs = {seg.xyz.data(), seg.nrm.data(), seg.n};
   const Super4PCSCloudView vq = {qval.xyz.data(), qval.nrm.data(), qval.n};
   const Super4PCSCloudView vqs = {qsearch.xyz.data(), qsearch.nrm.data(), qsearch.n};
-  getProbableTransformsSuper4PCS(vs, vq, vqs, have ? px.data() : nullptr, rows, cols, bestHypothesis, hypothesisSet,
-                                 PPFMap, camIntrinsic, registered_points);
+  bool joined = false;
+  auto image = [&](int* r, int* c) -> const unsigned short* {
+    if (!joined) {
+      t4.join();
+      joined = true;
+      if (getenv("PGP_SHIM_VERBOSE"))
+        std::cerr << "[libsuper4pcs shim] file hand-off: image ready " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_files).count()
+                  << " ms after the call (segment " << ms_part[0] << ", validation model " << ms_part[1] << ", search model " << ms_part[2]
+                  << ", probability image " << ms_part[3] << " ms, in parallel)" << std::endl;
+      if (!have) std::cerr << "[libsuper4pcs shim] no probability image at " << probImagePath << ": weights = 1" << std::endl;
+    }
+    *r = rows;
+    *c = cols;
+    return have ? px.data() : nullptr;
+  };
+  match_impl(vs, vq, vqs, image, bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
+  if (!joined) t4.join();
 }
 
 void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
@@ -465,6 +533,20 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
                                     std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
                                     std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
                                     Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points) {
+  match_impl(segment, model_validation, model_search,
+             [&](int* r, int* c) -> const unsigned short* { *r = rows; *c = cols; return prob_image; },
+             bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
+}
+
+// `image` hands over the probability image when the weights are needed (the file entry point is still
+// decoding it on another thread while the clouds are uploaded and indexed)
+static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
+                       const Super4PCSCloudView& model_search,
+                       const std::function<const unsigned short*(int*, int*)>& image,
+                       std::pair<Eigen::Isometry3d, float>& bestHypothesis,
+                       std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
+                       std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
+                       Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points) {
   const float delta = 0.005f;              // super4pcs_test.cc:20
   const int max_number_of_bases = 100;     // base.cc:290
   const int max_sampled_csets = 100;       // base.cc:1858
@@ -487,15 +569,6 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
   float cP[3], cQ[3];
   if (pgp_center(seg.xyz.data(), seg.n, qsearch.xyz.data(), qsearch.n, qval.xyz.data(), qval.n, cP, cQ) != PGP_OK) return;
 
-  // ---- per-point weights from the probability image (base.cc:317-340)
-  std::vector<float> prob(seg.n, 1.f);
-  if (prob_image && rows > 0 && cols > 0) {
-    float K[9];
-    for (int r = 0; r < 3; ++r)
-      for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
-    pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, prob.data());
-  }
-
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -509,16 +582,29 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
     // device 0's context of the group also serves the single-device steps
     if (!st.group) SHIM_PGP(pgp_multi_create(&st.group, nullptr, n_dev));
     ctx = pgp_multi_context(st.group, 0);
-    SHIM_PGP(pgp_multi_set_scene(st.group, seg.xyz.data(), seg.nrm.data(), prob.data(), seg.n, delta));
+    SHIM_PGP(pgp_multi_set_scene(st.group, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_multi_set_model(st.group, qval.xyz.data(), qval.nrm.data(), qval.n));
   } else {
     if (!st.ctx) SHIM_PGP(pgp_create(&st.ctx, -1));
     ctx = st.ctx;
-    SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), prob.data(), seg.n, delta));
+    SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
   }
   SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
-  if (st.map_addr != (const void*)&PPFMap || st.map_size != PPFMap.size()) {
+  unsigned long long print = 0x9E3779B97F4A7C15ull;
+  if (!PPFMap.empty()) {
+    auto mix = [&print](long long v) { print = (print ^ (unsigned long long)v) * 0x100000001B3ull + (print >> 31); };
+    const auto& a = *PPFMap.begin();
+    const auto& b = *PPFMap.rbegin();
+    for (int v : a.first) mix(v);
+    mix((long long)a.second.size());
+    if (!a.second.empty()) { mix(a.second.front().first); mix(a.second.front().second); mix(a.second.back().first); mix(a.second.back().second); }
+    for (int v : b.first) mix(v);
+    mix((long long)b.second.size());
+    if (!b.second.empty()) { mix(b.second.front().first); mix(b.second.front().second); mix(b.second.back().first); mix(b.second.back().second); }
+  }
+  if (st.map_addr != (const void*)&PPFMap || st.map_size != PPFMap.size() || st.map_print != print ||
+      st.map_ctx != (const void*)ctx) {
     // std::map<std::vector<int>, std::vector<std::pair<int,int>>> -> keys | counts | pairs
     static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int), "pair<int,int> must be two packed ints");
     std::vector<int> keys, counts, pairs;
@@ -534,8 +620,24 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
     SHIM_PGP(pgp_set_ppf_map(ctx, keys.data(), counts.data(), pairs.data(), (int)counts.size()));
     st.map_addr = &PPFMap;
     st.map_size = PPFMap.size();
+    st.map_print = print;
+    st.map_ctx = ctx;
   }
 
+  // ---- per-point weights from the probability image (base.cc:317-340), once the image is there
+  {
+    int rows = 0, cols = 0;
+    const unsigned short* prob_image = image(&rows, &cols);
+    if (prob_image && rows > 0 && cols > 0) {
+      std::vector<float> prob(seg.n, 1.f);
+      float K[9];
+      for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
+      pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, prob.data());
+      if (st.group) SHIM_PGP(pgp_multi_set_scene_weights(st.group, prob.data(), seg.n));
+      else SHIM_PGP(pgp_set_scene_weights(ctx, prob.data(), seg.n));
+    }
+  }
   const double ms_setup = ms_since(t_start);
   const auto t_bases = std::chrono::steady_clock::now();
   // ---- Step 1: base selection (base.cc:1831-1848): rounds of independent attempts, one launch each;
