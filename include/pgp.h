@@ -145,6 +145,16 @@ int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int
 int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, const float* q_nrm, int n,
                          float gate_deg, int* ids, int* n_ids);
 
+/* Opt-in: plain-mode scores and counts as the reference's Verify returns them, WITH its early termination
+ * (base.cc:1708,1725-1727: a hypothesis that can no longer beat the running best stops, and its
+ * allPose[i].second is the fraction counted so far -- an order-dependent lower bound).  Off (default):
+ * every hypothesis is counted completely.  Best index and best score are the same either way.  Costs up to
+ * one more pass over the batch.  Applies to pgp_score_lcp / pgp_score_lcp_device in PGP_MODE_PLAIN;
+ * pgp_verify_early_out_device applies it to a complete vector assembled elsewhere (d_scores / d_counts hold
+ * the TRUE values of all n_h hypotheses, e.g. after the all-reduce of a device group). */
+int pgp_set_verify_early_out(pgp_ctx* ctx, int on);
+int pgp_verify_early_out_device(pgp_ctx* ctx, const float* d_T, int n_h, float* d_scores, int* d_counts, void* stream);
+
 /* Weighted mode, the running-best LIST (base.cc:1891-1908, what the drop-in returns as hypothesisSet): with
  * pgp_set_exact_records(ctx, 1) every later weighted scoring call on the context also re-scores, exactly as
  * the reference sums (sequential float adds in model order), every hypothesis whose score comes within the

@@ -1231,6 +1231,81 @@ __global__ __launch_bounds__(256) void records_sum(int nQ, const int* __restrict
   if ((int)threadIdx.x < G) scores[list[g0 + threadIdx.x]] = __fdiv_rn(S, (float)nQ);
 }
 
+// ---- Verify's early termination, reproduced (base.cc:1699-1731, opt-in: pgp_set_verify_early_out) -----------
+// The reference's plain verifier stops a hypothesis as soon as it can no longer beat the running best:
+//   terminate_value = (int)(best_LCP_ * N);  after model point i:  if (N - i + good < terminate_value) break;
+// and returns good / N at that point, so what it writes to allPose[i].second for a hypothesis that is not a
+// new best is a LOWER BOUND that depends on the order of the batch and of the model.  The scoring kernel
+// counts every hypothesis completely (its counts are the true ones; best index and best score never differ,
+// since a hypothesis that would become the best can not terminate early).  With the option on, a second
+// pass rewrites the scores and counts of the others to the reference's values:
+//   * best_LCP_ in front of hypothesis h = the maximum of the TRUE scores before it (a terminated
+//     hypothesis returns less than the best it was compared with), an exclusive prefix maximum;
+//   * a hypothesis whose true count reaches its terminate_value runs to the end (N - i + good_i >
+//     good_final >= terminate_value for every i): untouched;
+//   * the others walk the model in ORIGINAL order, 64 points per wave-step (hit test = the per-lane
+//     candidate walk of pgp_registered), prefix counts by ballot, and stop at the first i that satisfies
+//     the reference's test.
+// Cost: up to one more pass over (hypotheses x model), typically half of it; results equal the reference's
+// Verify bit for bit (tests/golden/*.npz early_out_scores, from the Eigen harness).
+__global__ __launch_bounds__(1024) void early_out_terminate_values(const int* __restrict__ counts, int n_h, int nQ,
+                                                                    int* __restrict__ tv) {
+  __shared__ float s_wave[16];
+  __shared__ float s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) s_carry = 0.f;   // best_LCP_ starts at 0
+  __syncthreads();
+  for (int base = 0; base < n_h; base += 1024) {
+    const int h = base + tid;
+    const float sc = h < n_h ? __fdiv_rn((float)counts[h], (float)nQ) : 0.f;
+    float incl = sc;   // inclusive prefix maximum inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl = fmaxf(incl, o);
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    float before = s_carry;   // maximum of everything in front of this wave
+    for (int w = 0; w < wave; ++w) before = fmaxf(before, s_wave[w]);
+    float excl = __shfl_up(incl, 1, 64);
+    excl = lane == 0 ? before : fmaxf(before, excl);
+    // (int)(best_LCP_ * number_of_points): float x float(size_t), truncated
+    if (h < n_h) tv[h] = (int)__fmul_rn(excl, (float)nQ);
+    __syncthreads();
+    if (tid == 1023) s_carry = fmaxf(before, incl);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void early_out_walk(ScoreArgs a, const int* __restrict__ qpos, const int* __restrict__ tv,
+                                                      float* __restrict__ scores, int* __restrict__ counts) {
+  const int lane = threadIdx.x & 63;
+  const int h = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per hypothesis
+  if (h >= a.n_h) return;
+  const int term = tv[h], N = a.nQ;
+  if (counts[h] >= term) return;   // runs to the end in the reference too: the true count stands
+  const Xf m = load_xf(a.T, (uint32_t)h);
+  int good = 0;
+  for (int i0 = 0; i0 < N; i0 += 64) {
+    const int i = i0 + lane;
+    const bool hit = i < N && point_hit<PGP_MODE_PLAIN>(a, m, qpos[i]) >= 0;
+    const unsigned long long bm = __ballot(hit);
+    const int good_i = good + __popcll(bm & ((2ull << lane) - 1ull));   // hits among points 0 .. i
+    const unsigned long long stop = __ballot(i < N && N - i + good_i < term);
+    if (stop) {
+      const int first = __ffsll((long long)stop) - 1;
+      const int g = __shfl(good_i, first, 64);
+      if (lane == 0) {
+        counts[h] = g;
+        scores[h] = __fdiv_rn((float)g, (float)N);
+      }
+      return;
+    }
+    good += __popcll(bm);
+  }
+}
+
 __global__ void publish_none(int* __restrict__ best) {  // empty hypothesis list (base.cc:1791-1794)
   best[0] = -1;
   best[1] = 0;
@@ -1424,13 +1499,36 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     launch_variant(mode, ctx->unroll, grid, stream, a, ev0, ev1);
     hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream, a,
                        (const uint2*)a.partial, a.n_tiles, n_h, a.nQ,
-                       mode, ctx->refine_best ? 1 : 0, d_scores, d_counts, key, key + 3, ticket,
+                       mode, ctx->refine_best ? 1 : 0, d_scores,
+                       d_counts ? d_counts : (ctx->verify_early_out && mode == PGP_MODE_PLAIN ? ctx->d_counts.as<int>() : nullptr),
+                       key, key + 3, ticket,
                        d_best ? d_best : best_local, ctx->d_seq.as<float>());
   } else {
     hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best ? d_best : best_local);
   }
   PGP_HIP(hipGetLastError());
   if (ctx->exact_records && n_h > 0) return launch_settle_records(ctx, d_T, n_h, mode, gate_deg, d_scores, stream);
+  if (ctx->verify_early_out && mode == PGP_MODE_PLAIN && n_h > 0)
+    return launch_verify_early_out(ctx, d_T, n_h, d_scores, d_counts ? d_counts : ctx->d_counts.as<int>(), stream);
+  return PGP_OK;
+}
+
+// scores / counts of a COMPLETE plain-mode batch (true counts in) rewritten to what the reference's Verify
+// returns with its early termination; queue-only
+int launch_verify_early_out(pgp_ctx* ctx, const float* d_T, int n_h, float* d_scores, int* d_counts, hipStream_t stream) {
+  if (n_h <= 0) return PGP_OK;
+  ScoreArgs a{};
+  int rc = fill_args(ctx, d_T, n_h, PGP_MODE_PLAIN, 30.f, &a);
+  if (rc != PGP_OK) return rc;
+  if (ctx->d_eo_ws.cap < (size_t)n_h * sizeof(int) || !ctx->d_Qpos.p) {
+    set_error("verify early-out: workspace not reserved (pgp_reserve / pgp_set_model)");
+    return PGP_ESTATE;
+  }
+  int* tv = ctx->d_eo_ws.as<int>();
+  hipLaunchKernelGGL(early_out_terminate_values, dim3(1), dim3(1024), 0, stream, (const int*)d_counts, n_h, a.nQ, tv);
+  hipLaunchKernelGGL(early_out_walk, dim3((n_h + 3) / 4), dim3(256), 0, stream, a, (const int*)ctx->d_Qpos.as<int>(),
+                     (const int*)tv, d_scores, d_counts);
+  PGP_HIP(hipGetLastError());
   return PGP_OK;
 }
 

@@ -385,7 +385,8 @@ int pgp_multi_upload(pgp_multi* m, const float* T, int n_h) {
     int r;
     if ((r = m->d_T[k].ensure(nT)) != PGP_OK) return r;
     if ((r = m->d_all[k].ensure((size_t)n_h * 8)) != PGP_OK) return r;
-    if ((r = pgp_reserve(m->ctx[k], hi - lo)) != PGP_OK) return r;
+    // member 0 also works on the complete vector (settlement, exact records, Verify's early termination)
+    if ((r = pgp_reserve(m->ctx[k], k == 0 ? n_h : hi - lo)) != PGP_OK) return r;
     // every device holds ALL transforms: device 0 needs them to settle near-ties across slices
     // (64 B per hypothesis: 4 MB at 65 536 -- each device pulls its copy over its own PCIe link)
     if (nT) PGP_HIP(hipMemcpyAsync(m->d_T[k].p, m->h_pin, nT, hipMemcpyHostToDevice, m->stream[k]));
@@ -412,11 +413,13 @@ int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scor
     if (n_h > 0 && m->n > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)n_h * 8, m->stream[k]));
     // the exact-records pass (pgp_set_exact_records on member 0's context) belongs to the COMPLETE vector,
     // below; running it on member 0's slice as well would only repeat three launches
-    const bool records = m->ctx[k]->exact_records;
+    const bool records = m->ctx[k]->exact_records, early = m->ctx[k]->verify_early_out;
     m->ctx[k]->exact_records = false;
+    m->ctx[k]->verify_early_out = false;   // Verify's early termination depends on ALL earlier hypotheses: below
     const int r = pgp_score_lcp_device(m->ctx[k], m->d_T[k].as<float>() + 16 * (size_t)lo, hi - lo, mode, gate_deg,
                                        d_s + lo, d_c + lo, nullptr, m->stream[k]);
     m->ctx[k]->exact_records = records;
+    m->ctx[k]->verify_early_out = early;
     if (r == PGP_OK && m->emulate) PGP_HIP(hipEventRecord(m->ev[k], m->stream[k]));
     return r;
   });
@@ -483,6 +486,11 @@ int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scor
     // pgp_set_exact_records on device 0's context (pgp_multi_context(m, 0)) covers the group's calls too
     if (m->ctx[0]->exact_records) {
       r = pgp_settle_records_device(m->ctx[0], m->d_T[0].as<float>(), n_h, mode, gate_deg, d_s, st);
+      if (r != PGP_OK) return r;
+    }
+    // pgp_set_verify_early_out on member 0's context: applied to the complete vector of true counts
+    if (m->ctx[0]->verify_early_out && mode == PGP_MODE_PLAIN && n_h > 0) {
+      r = pgp_verify_early_out_device(m->ctx[0], m->d_T[0].as<float>(), n_h, d_s, reinterpret_cast<int*>(d_s + n_h), st);
       if (r != PGP_OK) return r;
     }
     if (n_h > 0) PGP_HIP(hipMemcpyAsync(pin_out, d_s, (size_t)n_h * 8, hipMemcpyDeviceToHost, st));

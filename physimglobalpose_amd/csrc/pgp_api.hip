@@ -176,7 +176,7 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
-                    &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_T, &ctx->d_partial,
+                    &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
@@ -356,11 +356,15 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
   int rc;
   if ((rc = ctx->d_Q.ensure(hq.size() * sizeof(float4))) != PGP_OK) return rc;
   if ((rc = ctx->d_Qn.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_Qpos.ensure(hq.size() * sizeof(int))) != PGP_OK) return rc;
+  std::vector<int> hpos((size_t)std::max(n, 1), 0);
+  for (int s = 0; s < n; ++s) hpos[order[s]] = s;
   if ((rc = ctx->d_hits.ensure(hq.size() * sizeof(int))) != PGP_OK) return rc;
   if ((rc = ctx->d_seq.ensure(4 * (hq.size() + 4) * sizeof(float))) != PGP_OK) return rc;  // kRefineGroup rows
   if (ctx->exact_records && (rc = ctx->d_rec_ws.ensure((size_t)records_workspace_bytes(n))) != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(ctx->d_Q.p, hq.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipMemcpyAsync(ctx->d_Qn.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipMemcpyAsync(ctx->d_Qpos.p, hpos.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipStreamSynchronize(ctx->stream));
   // the per-tile partial buffer depends on the model size
   if (ctx->cap_h > 0) {
@@ -386,6 +390,7 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
   if ((rc = ctx->d_partial.ensure(tiles * cap * (sizeof(int) + sizeof(float)))) != PGP_OK) return rc;
   if ((rc = ctx->d_scores.ensure(cap * sizeof(float))) != PGP_OK) return rc;
   if ((rc = ctx->d_counts.ensure(cap * sizeof(int))) != PGP_OK) return rc;
+  if ((rc = ctx->d_eo_ws.ensure(cap * sizeof(int) + 64)) != PGP_OK) return rc;
   ctx->cap_h = max_hypotheses;
   return PGP_OK;
 }
@@ -415,6 +420,30 @@ int pgp_set_exact_records(pgp_ctx* ctx, int on) {
   }
   ctx->exact_records = on != 0;
   return PGP_OK;
+}
+
+int pgp_set_verify_early_out(pgp_ctx* ctx, int on) {
+  if (!ctx) {
+    set_error("pgp_set_verify_early_out: ctx is NULL");
+    return PGP_EINVAL;
+  }
+  ctx->verify_early_out = on != 0;
+  return PGP_OK;
+}
+
+int pgp_verify_early_out_device(pgp_ctx* ctx, const float* d_T, int n_h, float* d_scores, int* d_counts, void* stream) {
+  if (!ctx || n_h < 0 || (n_h > 0 && (!d_T || !d_scores || !d_counts))) {
+    set_error("pgp_verify_early_out_device: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n_h > ctx->cap_h) {
+    set_error("pgp_verify_early_out_device: %d hypotheses exceed the reserved capacity %d (pgp_reserve)", n_h, ctx->cap_h);
+    return PGP_ESTATE;
+  }
+  CtxGuard guard(ctx, false);
+  const int rc = launch_verify_early_out(ctx, d_T, n_h, d_scores, d_counts, static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
 }
 
 int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,

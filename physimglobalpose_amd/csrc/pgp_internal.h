@@ -82,6 +82,9 @@ struct pgp_ctx {
   bool has_model_normals = false;
   pgp::DevBuf d_Q;       // float4 {x,y,z,bits(orig i)} in Morton order [nQ]
   pgp::DevBuf d_Qn;      // float4 {nx,ny,nz,0}          in Morton order [nQ]
+  pgp::DevBuf d_Qpos;    // int: Morton position of ORIGINAL model point i [nQ] (Verify's early-out walks in model order)
+  bool verify_early_out = false;   // pgp_set_verify_early_out: plain scores as the reference's Verify returns them
+  pgp::DevBuf d_eo_ws;             // its workspace: terminate value per hypothesis
 
   // search model (congruent-set side, sampled_Q_3D_)
   int nQs = 0;
@@ -205,6 +208,7 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
                        int* d_best, hipStream_t stream);
 int launch_settle_records(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                           hipStream_t stream);
+int launch_verify_early_out(pgp_ctx* ctx, const float* d_T, int n_h, float* d_scores, int* d_counts, hipStream_t stream);
 int records_workspace_bytes(int nQ);
 int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q, const float4* d_qn, int n,
                             float gate_deg, int* d_hits, hipStream_t stream);

@@ -542,6 +542,11 @@ class LcpScorer:
         return sel[: n.value].copy()
 
     # ---- device-resident path (torch tensors only carry memory + stream) --------------------------
+    def set_verify_early_out(self, on=True):
+        """plain-mode scores / counts as the reference's Verify returns them, with its early termination
+        (base.cc:1708,1725-1727); off = every hypothesis counted completely"""
+        _lib.check(self._lib.pgp_set_verify_early_out(self._h, int(bool(on))))
+
     def reserve(self, max_hypotheses):
         _lib.check(self._lib.pgp_reserve(self._h, int(max_hypotheses)))
 
@@ -670,6 +675,10 @@ class MultiGpuScorer:
         """pgp_set_exact_records on member 0's context: the group's running-best list is then the reference's."""
         ctx0 = self._lib.pgp_multi_context(self._h, 0)
         _lib.check(self._lib.pgp_set_exact_records(C.c_void_p(ctx0), 1 if on else 0))
+
+    def set_verify_early_out(self, on=True):
+        ctx0 = self._lib.pgp_multi_context(self._h, 0)
+        _lib.check(self._lib.pgp_set_verify_early_out(C.c_void_p(ctx0), 1 if on else 0))
 
     def last_timing(self):
         a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
