@@ -377,6 +377,19 @@ int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const
 int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, int n, float radius,
                               int min_neighbors, unsigned char* keep, float* nrm_out, int* n_kept);
 
+/* The part of a segment that the objects already placed do NOT explain, in front of the ICP refinement of
+ * the next object (UCTState::performTrICP, PPE/hypothesis_verification/mcts/UCTState.cpp:142-174): a segment
+ * point is dropped when any point of any placed object's model, moved to that object's pose, lies within
+ * `radius` of it (pointRemovalThreshold = 0.008, UCTState.cpp:9; strictly below, as FLANN's radius search).
+ *   seg_xyz: n x 3; model_xyz: the placed objects' model points one object after the other;
+ *   model_offsets[n_objects + 1]: object k owns points model_offsets[k] .. model_offsets[k + 1] - 1;
+ *   T: n_objects x 16 column-major float, model -> the segment's frame (the objects' poses);
+ *   keep[n]: 1 = unexplained (stays in the cloud handed to pgp_icp_refine), *n_kept (nullable) their number.
+ * n_objects == 0 keeps everything (the reference skips the step for the first object).  Host pointers,
+ * synchronous.  PCL / FLANN are not vendored: unpinned against their bits. */
+int pgp_unexplained_segment(pgp_ctx* ctx, const float* seg_xyz, int n, const float* model_xyz, const int* model_offsets,
+                            const float* T, int n_objects, float radius, unsigned char* keep, int* n_kept);
+
 /* pgp_set_scene with DEVICE pointers (d_xyz: n x 3 floats; d_nrm: n x 3 or NULL; d_weight: n or NULL):
  * the segment a previous device call produced (pgp_backproject_depth_device, pgp_voxel_grid_device)
  * becomes the scene without a host round trip.  Enqueued on `stream`, which is synchronised (the

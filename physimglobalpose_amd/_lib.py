@@ -89,6 +89,7 @@ SIGNATURES = {
     "pgp_icp_default_options": (C.c_int, [C.POINTER(IcpOptions)]),
     "pgp_icp_target_token": (C.c_int, [C.c_void_p, C.c_ulonglong]),
     "pgp_set_scene_weights": (C.c_int, [C.c_void_p, _f, C.c_int]),
+    "pgp_unexplained_segment": (C.c_int, [C.c_void_p, _f, C.c_int, _f, _i, _f, C.c_int, C.c_float, C.c_char_p, _i]),
     "pgp_multi_set_scene_weights": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_icp_refine_ex": (C.c_int, [C.c_void_p, _f, C.c_int, _f, _f, C.c_int, _f, C.c_int,
                                     C.POINTER(IcpOptions), _f, _i]),

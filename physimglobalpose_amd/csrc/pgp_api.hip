@@ -1091,6 +1091,58 @@ int pgp_radius_outlier_filter(pgp_ctx* ctx, const float* xyz, const float* nrm, 
   return PGP_OK;
 }
 
+int pgp_unexplained_segment(pgp_ctx* ctx, const float* seg_xyz, int n, const float* model_xyz, const int* model_offsets,
+                            const float* T, int n_objects, float radius, unsigned char* keep, int* n_kept) {
+  if (!ctx || n < 0 || n_objects < 0 || (n > 0 && (!seg_xyz || !keep)) || !(radius > 0.f) ||
+      (n_objects > 0 && (!model_offsets || !T))) {
+    set_error("pgp_unexplained_segment: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n_kept) *n_kept = 0;
+  if (n == 0) return PGP_OK;
+  int n_model = 0;
+  for (int k = 0; k < n_objects; ++k) {
+    if (model_offsets[k] < 0 || model_offsets[k + 1] < model_offsets[k]) {
+      set_error("pgp_unexplained_segment: model_offsets must be non-decreasing from 0");
+      return PGP_EINVAL;
+    }
+    n_model = model_offsets[k + 1];
+  }
+  if (n_model > 0 && !model_xyz) {
+    set_error("pgp_unexplained_segment: model_xyz is NULL");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx);
+  hipStream_t st = ctx->stream;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t off_m = up((size_t)n * 12), off_o = off_m + up((size_t)std::max(n_model, 1) * 12),
+               off_T = off_o + up(((size_t)n_objects + 1) * 4), off_e = off_T + up((size_t)std::max(n_objects, 1) * 64),
+               total = off_e + (size_t)n * 4;
+  int rc = ctx->d_pre_io.ensure(total);
+  if (rc != PGP_OK) return rc;
+  unsigned char* d = ctx->d_pre_io.as<unsigned char>();
+  PGP_HIP(hipMemcpyAsync(d, seg_xyz, (size_t)n * 12, hipMemcpyHostToDevice, st));
+  if (n_objects > 0) {
+    if (n_model > 0) PGP_HIP(hipMemcpyAsync(d + off_m, model_xyz, (size_t)n_model * 12, hipMemcpyHostToDevice, st));
+    PGP_HIP(hipMemcpyAsync(d + off_o, model_offsets, ((size_t)n_objects + 1) * 4, hipMemcpyHostToDevice, st));
+    PGP_HIP(hipMemcpyAsync(d + off_T, T, (size_t)n_objects * 64, hipMemcpyHostToDevice, st));
+  }
+  rc = launch_explained_points(ctx, reinterpret_cast<const float*>(d), n, reinterpret_cast<const float*>(d + off_m),
+                               reinterpret_cast<const int*>(d + off_o), reinterpret_cast<const float*>(d + off_T), n_objects,
+                               radius, reinterpret_cast<unsigned int*>(d + off_e), st);
+  if (rc != PGP_OK) return rc;
+  std::vector<unsigned int> he((size_t)n);
+  PGP_HIP(hipMemcpyAsync(he.data(), d + off_e, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  int kept = 0;
+  for (int i = 0; i < n; ++i) {
+    keep[i] = he[i] ? 0 : 1;
+    kept += keep[i];
+  }
+  if (n_kept) *n_kept = kept;
+  return PGP_OK;
+}
+
 int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsigned char* mask, int rows,
                           int cols, const float K[9], double z_min, double z_max, float* xyz_out, int cap,
                           int* n_out) {

@@ -235,6 +235,8 @@ int launch_base_invariants(pgp_ctx* ctx, int* h_ids, int m, float* h_inv, int* h
 // preprocess.hip
 int device_bbox(pgp_ctx* ctx, const float* d_pts, int n, int stride, float mn[3], float mx[3], hipStream_t st);
 int launch_scene_weights(pgp_ctx* ctx, const float* d_w, int n, hipStream_t st);
+int launch_explained_points(pgp_ctx* ctx, const float* d_seg, int n, const float* d_model, const int* d_model_off,
+                            const float* d_T, int n_obj, float radius, unsigned int* d_explained, hipStream_t st);
 int launch_voxel_grid(pgp_ctx* ctx, const float* d_xyz, int n, float leaf, float* d_out, int cap, int* n_out,
                       hipStream_t st);
 int launch_pose_hausdorff(pgp_ctx* ctx, const float4* d_hull, int n_hull, const float* d_T, int n_poses,

@@ -234,6 +234,70 @@ __global__ __launch_bounds__(256) void scene_weights(float4* __restrict__ Pnw, c
 }
 }  // namespace
 
+// ---- points of a segment that already-placed objects explain (UCTState::performTrICP, UCTState.cpp:142-174) ----
+// The reference moves every placed object's model to its pose, builds one kd-tree over all of them and
+// removes each segment point that has ANY such point within pointRemovalThreshold (8 mm, UCTState.cpp:9;
+// FLANN's radius search keeps a neighbour when its squared distance is strictly below radius^2).
+// Here: grid (segment chunks of 256, objects); a workgroup moves a tile of 1024 model points to the object's
+// pose in LDS -- pose rows as ((r0 x + r1 y) + r2 z) + t, float -- and every lane tests its segment point
+// against the tile (broadcast reads), leaving as soon as the whole wave is explained; explained[i] |= 1.
+// Squared distance as FLANN's L2 accumulates it, (dx^2 + dy^2) + dz^2.  PCL / FLANN are not vendored:
+// unpinned against their bits, pinned against oracle/preprocess_oracle.py.
+namespace {
+struct ExplainArgs {
+  const float* seg;          // n x 3
+  int n;
+  const float* model;        // all objects' model points, 3 floats each
+  const int* model_off;      // [K + 1] point offsets into `model`
+  const float* T;            // K x 16 column-major: model -> the segment's frame
+  float r2;
+  unsigned int* explained;   // [n] zeroed by the caller
+};
+__global__ __launch_bounds__(256) void explained_points(ExplainArgs a) {
+  __shared__ float4 s_m[1024];
+  const int k = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float* G = a.T + 16 * (size_t)k;
+  const int m0 = a.model_off[k], m1 = a.model_off[k + 1];
+  const float qnan = __int_as_float(0x7FC00000);
+  const float x = i < a.n ? a.seg[3 * (size_t)i] : qnan, y = i < a.n ? a.seg[3 * (size_t)i + 1] : qnan,
+              z = i < a.n ? a.seg[3 * (size_t)i + 2] : qnan;
+  bool hit = false;
+  for (int t0 = m0; t0 < m1; t0 += 1024) {
+    const int tn = min(1024, m1 - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < tn; j += 256) {
+      const float* p = a.model + 3 * (size_t)(t0 + j);
+      s_m[j] = make_float4(__fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(G[0], p[0]), __fmul_rn(G[4], p[1])), __fmul_rn(G[8], p[2])), G[12]),
+                           __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(G[1], p[0]), __fmul_rn(G[5], p[1])), __fmul_rn(G[9], p[2])), G[13]),
+                           __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(G[2], p[0]), __fmul_rn(G[6], p[1])), __fmul_rn(G[10], p[2])), G[14]), 0.f);
+    }
+    __syncthreads();
+    if (__ballot(!hit && i < a.n) != 0ull) {   // a wave whose points are all explained only keeps the barriers
+      for (int j = 0; j < tn; ++j) {
+        const float4 m = s_m[j];
+        const float dx = __fsub_rn(x, m.x), dy = __fsub_rn(y, m.y), dz = __fsub_rn(z, m.z);
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        hit |= d2 < a.r2;
+      }
+    }
+  }
+  if (hit && i < a.n) a.explained[i] = 1u;   // benign race across objects: every writer stores 1
+}
+}  // namespace
+
+int launch_explained_points(pgp_ctx* ctx, const float* d_seg, int n, const float* d_model, const int* d_model_off,
+                            const float* d_T, int n_obj, float radius, unsigned int* d_explained, hipStream_t st) {
+  (void)ctx;
+  if (n <= 0) return PGP_OK;
+  PGP_HIP(hipMemsetAsync(d_explained, 0, (size_t)n * 4, st));
+  if (n_obj <= 0) return PGP_OK;
+  ExplainArgs a{d_seg, n, d_model, d_model_off, d_T, radius * radius, d_explained};
+  hipLaunchKernelGGL(explained_points, dim3((n + 255) / 256, n_obj), dim3(256), 0, st, a);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
 // the weights of the resident scene replaced (d_w: n device floats); enqueued on st
 int launch_scene_weights(pgp_ctx* ctx, const float* d_w, int n, hipStream_t st) {
   if (n <= 0) return PGP_OK;

@@ -359,6 +359,24 @@ class LcpScorer:
                                             C.c_float(threshold), _fp(score), counts.ctypes.data_as(_i)))
         return score, counts
 
+    def unexplained_segment(self, seg_xyz, models, poses, radius=0.008):
+        """UCTState::performTrICP's pre-filter (UCTState.cpp:142-174): models = list of (m_k,3) clouds of the objects
+        already placed, poses = (K,16) column-major model -> segment frame.  Returns keep (n,) bool."""
+        seg = _f32(seg_xyz, 3)
+        K = len(models)
+        off = np.zeros(K + 1, np.int32)
+        for k, m in enumerate(models):
+            off[k + 1] = off[k] + len(m)
+        allm = _f32(np.concatenate([np.asarray(m, np.float32).reshape(-1, 3) for m in models]) if K else np.zeros((0, 3)), 3)
+        T = _f32(np.asarray(poses, np.float32).reshape(-1, 16) if K else np.zeros((0, 16)), 16)
+        keep = np.zeros(max(len(seg), 1), np.uint8)
+        n_kept = C.c_int(0)
+        _lib.check(self._lib.pgp_unexplained_segment(self._h, _fp(seg), len(seg), _fp(allm), off.ctypes.data_as(_i), _fp(T), K,
+                                                     C.c_float(radius), keep.ctypes.data_as(C.c_char_p), C.byref(n_kept)))
+        keep = keep[:len(seg)].astype(bool)
+        assert int(keep.sum()) == n_kept.value
+        return keep
+
     def depth_cost_device(self, d_observed, d_rendered, threshold=0.01, d_counts=None, d_scores=None, stream=None):
         """cuda float32 tensors: observed (rows,cols), rendered (n,rows,cols) -> (d_counts (n,3) int32, d_scores (n,))
         on the device; enqueued, no synchronisation."""
