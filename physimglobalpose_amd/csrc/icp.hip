@@ -58,6 +58,10 @@
 #include "pgp_internal.h"
 
 #include <cfloat>
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -1061,7 +1065,7 @@ __device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n
       ++cz;
     }
   }
-#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS >= 2
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 2
   if (t.dbg) {
     atomicAdd(&t.dbg[0], dbg_rows);
     atomicAdd(&t.dbg[1], dbg_live);
@@ -1072,8 +1076,8 @@ __device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n
 #endif
 }
 
-// LDS layout of a workgroup that answers n_q queries: image | d2[n_q] | pos[n_q] | order[n_q]
-__device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* smem, int n_q, int tid, int nthreads) {
+// LDS layout of a workgroup that answers up to n_q_cap queries: image | d2[n_q_cap] | pos[n_q_cap] | order[n_q_cap]
+__device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* smem, int n_q_cap, int tid, int nthreads) {
   const uint4* src = reinterpret_cast<const uint4*>(a.nn_image);
   uint4* dst = reinterpret_cast<uint4*>(smem);
   const int n16 = (int)(a.nn.bytes >> 4);
@@ -1083,14 +1087,17 @@ __device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* 
   t.start = reinterpret_cast<const uint16_t*>(smem + a.nn.off_start);
   t.rep = reinterpret_cast<const uint16_t*>(smem + a.nn.off_rep);
   t.d2 = reinterpret_cast<float*>(smem + a.nn.bytes);
-  t.pos = reinterpret_cast<uint16_t*>(t.d2 + n_q);
-  t.order = t.pos + n_q;
+  t.pos = reinterpret_cast<uint16_t*>(t.d2 + n_q_cap);
+  t.order = t.pos + n_q_cap;
 #ifdef PGP_ICP_STAMPS
   t.dbg = nullptr;
 #endif
   return t;
 }
 __host__ __device__ inline size_t nn_lds_bytes(uint32_t image_bytes, int n_q) { return (size_t)image_bytes + 8 * (size_t)n_q + 16; }
+// source point q of the workgroup (q_base + q of the cloud): an L2 read.  (A copy of the workgroup's source
+// points in LDS, 12 B each, measured +-1 %: the searches are bound by the LDS gather rate, not by this read.)
+__device__ __forceinline__ float4 nn_src(const IcpArgs& a, const NnLds&, int q_base, int q) { return a.src[q_base + q]; }
 
 // All n_q queries of a workgroup (source points q_base .. q_base + n_q - 1 under the pose G), in two
 // phases with the work BALANCED in between: a wave pays for its dearest lane (and, in a loop nest, for
@@ -1130,7 +1137,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     const int q = r * NT + tid;
     tag[r] = 0;
     if (q < n_q) {
-      const float4 s = a.src[q_base + q];
+      const float4 s = nn_src(a, t, q_base, q);
       const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
                   z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
       unsigned long long best;
@@ -1176,10 +1183,13 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       const unsigned rel = sl - first;
       nsub = (int)(rel & ((1u << nlg) - 1u));
       nq = t.order[sch->cnt[c] + (rel >> nlg)];
-      ns = a.src[q_base + nq];
+      ns = nn_src(a, t, q_base, nq);
     }
   };
   fetch((unsigned)tid);
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS >= 3
+  const unsigned long long wv0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (unsigned s0 = 0; s0 < n_slots; s0 += NT) {   // uniform trip count: the exchanges below need whole waves
     const unsigned sl = s0 + (unsigned)tid;
     const bool valid = sl < n_slots;
@@ -1213,6 +1223,15 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
     }
   }
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS >= 3
+  if ((tid & 63) == 0 && t.dbg) {   // per-wave time in the search loop: sum over waves, maximum, wave 0's
+    const unsigned dtw = (unsigned)(__builtin_amdgcn_s_memrealtime() - wv0);
+    atomicAdd(&t.dbg[0], dtw);
+    atomicMax(&t.dbg[1], dtw);
+    if (tid == 0) t.dbg[2] += dtw;
+    if (tid == NT - 64) t.dbg[3] += dtw;
+  }
+#endif
   __syncthreads();
   PGP_NN_STAMP(7);
 #undef PGP_NN_STAMP
@@ -1414,7 +1433,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       const unsigned pm = i < a.n_src ? (unsigned)t.pos[i] : 0xFFFFu;   // 0xFFFF: a non-finite point has no neighbour
       if constexpr (METRIC == 1) {
         if (sel && pm != 0xFFFFu) {
-          const float4 s = a.src[i];
+          const float4 s = nn_src(a, t, 0, i);
           const float4 m = t.pts[pm];
           const float4 nn = a.tgt_n[__float_as_int(m.w)];
           const double px = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
@@ -1434,7 +1453,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
           e_acc += (double)d2;
         }
       } else if (sel && pm != 0xFFFFu) {
-        const float4 s = a.src[i];
+        const float4 s = nn_src(a, t, 0, i);
         const float4 m = t.pts[pm];
         const float s0 = s.x, s1 = s.y, s2 = s.z;
         acc[0] += 1.0;
@@ -1502,6 +1521,61 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 }
 
 }  // namespace
+
+// Morton key of a source point at 2 mm resolution (13 bits per axis: +-8 m around the origin, clamped beyond --
+// the order only has to be coherent, and the sort's cost grows with the key bits): the source cloud is
+// put in this order once per call, so that the 64 queries of a wave are neighbours in space under every pose
+// -- they then read the SAME rows of the index (LDS broadcasts instead of bank conflicts: the searches are
+// bound by the LDS gather rate) and need similar work.  Every path below sees the permuted cloud; nothing
+// that is returned depends on the order except the last bits of the f64 sums.
+namespace {
+__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
+  v &= 0x1FFFFFull;
+  v = (v | (v << 32)) & 0x1F00000000FFFFull;
+  v = (v | (v << 16)) & 0x1F0000FF0000FFull;
+  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
+  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
+  v = (v | (v << 2)) & 0x1249249249249249ull;
+  return v;
+}
+__global__ __launch_bounds__(256) void icp_src_keys(const float4* __restrict__ src, int n, unsigned long long* __restrict__ keys) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = src[i];
+  auto q = [](float v) -> unsigned long long {
+    const float f = fminf(fmaxf(v * 512.f + 4096.f, 0.f), 8191.f);   // NaN -> 0
+    return (unsigned long long)f;
+  };
+  keys[i] = spread21(q(p.x)) | (spread21(q(p.y)) << 1) | (spread21(q(p.z)) << 2);
+}
+}  // namespace
+
+static int sort_source(pgp_ctx* ctx, const float4* d_src, int n_src, const float4** d_sorted, hipStream_t stream) {
+  const size_t N = (size_t)n_src;
+  size_t tmp_bytes = 0;
+  hipError_t he = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
+                                            (float4*)nullptr, (float4*)nullptr, N, 0, 39, stream);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  const size_t off_k2 = (N * 8 + 255) & ~(size_t)255, off_v = 2 * off_k2, off_tmp = off_v + ((N * 16 + 255) & ~(size_t)255);
+  int rc = ctx->d_icp_sort.ensure(off_tmp + tmp_bytes + 256);
+  if (rc != PGP_OK) return rc;
+  unsigned char* b = ctx->d_icp_sort.as<unsigned char>();
+  unsigned long long* k_in = reinterpret_cast<unsigned long long*>(b);
+  unsigned long long* k_out = reinterpret_cast<unsigned long long*>(b + off_k2);
+  float4* v_out = reinterpret_cast<float4*>(b + off_v);
+  hipLaunchKernelGGL(icp_src_keys, dim3((n_src + 255) / 256), dim3(256), 0, stream, d_src, n_src, k_in);
+  he = rocprim::radix_sort_pairs(b + off_tmp, tmp_bytes, k_in, k_out, const_cast<float4*>(d_src), v_out, N, 0, 39, stream);   // stable
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
+  PGP_HIP(hipGetLastError());
+  *d_sorted = v_out;
+  return PGP_OK;
+}
 
 // Builds the exact index of the target in ctx->d_icp_grid (image | counters | starts | keys) when its
 // image fits one workgroup's LDS.  *fits = false (and PGP_OK): the caller keeps the exhaustive search.
@@ -1630,6 +1704,14 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (rc != PGP_OK) return rc;
     }
     return PGP_OK;
+  }
+  // spatially coherent source order (see sort_source); PGP_ICP_SORT=0 keeps the caller's order (A/B)
+  {
+    const char* v = getenv("PGP_ICP_SORT");
+    if (n_src >= 128 && !(v && atoi(v) == 0)) {
+      int rcs = sort_source(ctx, d_src, n_src, &d_src, stream);
+      if (rcs != PGP_OK) return rcs;
+    }
   }
   IcpArgs a{};
   a.src = d_src;

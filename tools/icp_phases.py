@@ -20,5 +20,7 @@ for n in (16, 64, 256):
         dbg = e[8:16].astype(np.float64); nq = max(dbg[4], 1)
         if dbg[4] > 0:
             print(f"    per query: rows {dbg[0]/nq:7.1f}  live rows {dbg[1]/nq:7.1f}  points {dbg[2]/nq:7.1f}  lanes {dbg[3]/nq:5.2f}   (queries {nq/it[0]:.0f} per iteration)")
+        if os.environ.get("ICP_WAVES"):
+            print(f"    search loop per wave (sum over iterations, us): mean {dbg[0]/100/16:.1f}  wave0 {dbg[2]/100:.1f}  last wave {dbg[3]/100:.1f}  (max single {dbg[1]/100:.1f})")
         print(f"    nn split: bounds {dbg[5]/100/it[0]:6.1f}  sort {dbg[6]/100/it[0]:6.1f}  search {dbg[7]/100/it[0]:6.1f} us per iteration")
         print(f"poses {n:4d} iterations {it[0]:3d}: per iteration  nn {us[0]:7.1f}  select {us[1]:7.1f}  sums+reduce {us[2]:7.1f}  solve {us[3]:7.1f}  stop rules {us[4]:7.1f}  us  (total {us.sum():7.1f})")
