@@ -58,10 +58,6 @@
 #include "pgp_internal.h"
 
 #include <cfloat>
-#include <cstring>
-
-#include <rocprim/rocprim.hpp>
-
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -99,6 +95,7 @@ struct NnGeom {
                          // an LDS round trip each, mostly to find the row empty), and there are (2U/h)^2 of them
   int nx, ny, nz;        // cells per axis
   int n_cells;
+  int strip_shift;       // cell >> strip_shift = its strip (<= 512 strips): the secondary key of the query sort
   uint32_t off_start, off_rep, bytes;   // byte offsets inside the image (points at 0)
 };
 
@@ -936,12 +933,15 @@ struct NnLds {
   // per query of this workgroup (persist across the iterations of the persistent kernel)
   float* d2;          // squared distance of the correspondence (FLT_MAX: none)
   uint16_t* pos;      // its position in the image (0xFFFF: none)
-  uint16_t* order;    // the queries sorted by estimated search cost, dearest first
+  uint16_t* order;    // the queries sorted by estimated search cost (dearest first), then by where they fall
+  uint32_t* bins;     // kNnBins 16-bit counters / offsets of that sort, two per word
 #ifdef PGP_ICP_STAMPS
   unsigned* dbg;      // diagnostic build: rows / live rows / points / lane slots / queries
 #endif
 };
 constexpr int kNnClasses = 16;
+constexpr int kNnStrips = 512;                       // runs of neighbouring cells a class is subdivided into
+constexpr int kNnBins = kNnClasses * kNnStrips;      // 16 KB of 16-bit counters
 
 // (d2, original index) as ONE unsigned 64-bit key: d2 >= +0, so the float bits order like the values,
 // and key < best is exactly the scan's rule (smaller d2, then lower index).  The initial key
@@ -983,10 +983,11 @@ __device__ __forceinline__ NnBox nn_box(const NnGeom& g, float x, float y, float
 // correspondence; returns the cost class of the search that remains (0 cheapest .. 15 = plain scan).
 __device__ __forceinline__ int nn_cost(const NnBox& b) { return (b.y1 - b.y0 + 1) * (b.z1 - b.z0 + 1) * (((b.x1 - b.x0) >> 2) + 3); }
 __device__ __forceinline__ int nn_bound(const NnGeom& g, const NnLds& t, float x, float y, float z, int prev_pos,
-                                        unsigned long long& best, int& bpos) {
+                                        unsigned long long& best, int& bpos, int& cell) {
   best = kNnNone;
   bpos = -1;
-  const int p = t.rep[nn_cell_of(g, x, y, z)];
+  cell = nn_cell_of(g, x, y, z);
+  const int p = t.rep[cell];
   nn_consider(x, y, z, t.pts[p], p, best, bpos);
   if (prev_pos >= 0) nn_consider(x, y, z, t.pts[prev_pos], prev_pos, best, bpos);
   if (bpos < 0) return kNnClasses - 1;   // no bound (a non-finite or astronomically far query): the plain scan
@@ -1076,7 +1077,7 @@ __device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n
 #endif
 }
 
-// LDS layout of a workgroup that answers up to n_q_cap queries: image | d2[n_q_cap] | pos[n_q_cap] | order[n_q_cap]
+// LDS layout of a workgroup that answers up to n_q_cap queries: image | d2[n_q_cap] | pos[n_q_cap] | order[n_q_cap] | bins
 __device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* smem, int n_q_cap, int tid, int nthreads) {
   const uint4* src = reinterpret_cast<const uint4*>(a.nn_image);
   uint4* dst = reinterpret_cast<uint4*>(smem);
@@ -1089,12 +1090,15 @@ __device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* 
   t.d2 = reinterpret_cast<float*>(smem + a.nn.bytes);
   t.pos = reinterpret_cast<uint16_t*>(t.d2 + n_q_cap);
   t.order = t.pos + n_q_cap;
+  t.bins = reinterpret_cast<uint32_t*>(smem + ((a.nn.bytes + 8 * (size_t)n_q_cap + 15) & ~(size_t)15));
 #ifdef PGP_ICP_STAMPS
   t.dbg = nullptr;
 #endif
   return t;
 }
-__host__ __device__ inline size_t nn_lds_bytes(uint32_t image_bytes, int n_q) { return (size_t)image_bytes + 8 * (size_t)n_q + 16; }
+__host__ __device__ inline size_t nn_lds_bytes(uint32_t image_bytes, int n_q) {
+  return (((size_t)image_bytes + 8 * (size_t)n_q + 15) & ~(size_t)15) + 2 * (size_t)kNnBins;
+}
 // source point q of the workgroup (q_base + q of the cloud): an L2 read.  (A copy of the workgroup's source
 // points in LDS, 12 B each, measured +-1 %: the searches are bound by the LDS gather rate, not by this read.)
 __device__ __forceinline__ float4 nn_src(const IcpArgs& a, const NnLds&, int q_base, int q) { return a.src[q_base + q]; }
@@ -1114,16 +1118,21 @@ __device__ __forceinline__ int nn_class_lanes_log2(int c) {
   return l < 0 ? 0 : (l > 6 ? 6 : l);
 }
 struct NnSched {
-  unsigned cnt[kNnClasses];        // queries per class, then their offset in `order` (dearest class first)
+  unsigned cnt[kNnClasses + 1];    // offset of every class in `order` (dearest class first); [kNnClasses] = n_q
   unsigned slot_end[kNnClasses];   // end of the class's lane slots
   unsigned n_slots;
+  unsigned wave_sum[16];
 };
 template <int NT, int R>
 __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
                                                NnSched* sch /* LDS */, int tid) {
   const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
               g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
-  if (tid < kNnClasses) sch->cnt[tid] = 0;
+  static_assert(kNnBins / 2 == 4 * NT, "four counter words per thread");
+  {   // zero the sort's counters
+    uint4* b4 = reinterpret_cast<uint4*>(t.bins);
+    b4[tid] = make_uint4(0u, 0u, 0u, 0u);
+  }
   __syncthreads();
 #ifdef PGP_ICP_STAMPS
   unsigned long long st0 = __builtin_amdgcn_s_memrealtime();
@@ -1131,7 +1140,13 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
 #else
 #define PGP_NN_STAMP(k) do { } while (0)
 #endif
-  unsigned tag[R];   // class << 16 | rank inside the class
+  // Sort key = (15 - class) * 512 + strip: dearest class first (the lane groups of phase B need whole classes in
+  // a row), and inside a class the queries of one strip -- a run of neighbouring cells of the index -- side by
+  // side: the 64 lanes of a wave then walk the SAME rows of the same points, which LDS serves as broadcasts
+  // instead of 64-way gathers (phase B is bound by the LDS gather rate).  One counting-sort pass over 8192
+  // 16-bit counters; the order inside a bin is whatever the atomics made it.
+  const int strip_shift = a.nn.strip_shift;
+  unsigned tag[R];   // key << 16 | rank inside the bin
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int q = r * NT + tid;
@@ -1141,32 +1156,65 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
                   z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
       unsigned long long best;
-      int bpos;
+      int bpos, cell;
       const unsigned pp = t.pos[q];
-      const int c = nn_bound(a.nn, t, x, y, z, pp == 0xFFFFu ? -1 : (int)pp, best, bpos);
+      const int c = nn_bound(a.nn, t, x, y, z, pp == 0xFFFFu ? -1 : (int)pp, best, bpos, cell);
       t.d2[q] = __uint_as_float((unsigned)(best >> 32));
       t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
-      tag[r] = ((unsigned)c << 16) | atomicAdd(&sch->cnt[c], 1u);
+      const unsigned key = (unsigned)(kNnClasses - 1 - c) * kNnStrips + (unsigned)min(cell >> strip_shift, kNnStrips - 1);
+      const unsigned old = atomicAdd(&t.bins[key >> 1], (key & 1u) ? 0x10000u : 1u);
+      tag[r] = (key << 16) | ((key & 1u) ? (old >> 16) : (old & 0xFFFFu));
     }
   }
   __syncthreads();
   PGP_NN_STAMP(5);
-  if (tid == 0) {   // dearest class first: offsets of the classes in `order` and in the lane slots
-    unsigned acc = 0, slots = 0;
+  {   // exclusive scan of the 8192 counters, 8 per thread, in key order
+    uint4* b4 = reinterpret_cast<uint4*>(t.bins);
+    const uint4 w = b4[tid];
+    const unsigned c0 = w.x & 0xFFFFu, c1 = w.x >> 16, c2 = w.y & 0xFFFFu, c3 = w.y >> 16, c4 = w.z & 0xFFFFu, c5 = w.z >> 16,
+                   c6 = w.w & 0xFFFFu, c7 = w.w >> 16;
+    const unsigned mine = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    unsigned incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const unsigned o = __shfl_up(incl, off, 64);
+      if ((tid & 63) >= off) incl += o;
+    }
+    if ((tid & 63) == 63) sch->wave_sum[tid >> 6] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int wv = 0; wv < (tid >> 6); ++wv) base += sch->wave_sum[wv];
+    unsigned e = base + incl - mine;   // queries in front of this thread's first bin
+    // a class owns 512 bins = 64 threads = one wave: its first thread holds the class offset
+    if ((tid & 63) == 0) sch->cnt[kNnClasses - 1 - (tid >> 6)] = e;
+    uint4 o4;
+    o4.x = e | ((e + c0) << 16);
+    e += c0 + c1;
+    o4.y = e | ((e + c2) << 16);
+    e += c2 + c3;
+    o4.z = e | ((e + c4) << 16);
+    e += c4 + c5;
+    o4.w = e | ((e + c6) << 16);
+    b4[tid] = o4;
+  }
+  __syncthreads();
+  if (tid == 0) {   // the lane slots of the classes, dearest first
+    unsigned slots = 0;
     for (int c = kNnClasses - 1; c >= 0; --c) {
-      const unsigned n = sch->cnt[c];
-      sch->cnt[c] = acc;
-      acc += n;
-      slots += n << nn_class_lanes_log2(c);
+      const unsigned first = sch->cnt[c], next = c == 0 ? (unsigned)n_q : sch->cnt[c - 1];
+      slots += (next - first) << nn_class_lanes_log2(c);
       sch->slot_end[c] = slots;
     }
     sch->n_slots = slots;
   }
-  __syncthreads();
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     const int q = r * NT + tid;
-    if (q < n_q) t.order[sch->cnt[tag[r] >> 16] + (tag[r] & 0xFFFFu)] = (uint16_t)q;
+    if (q < n_q) {
+      const unsigned key = tag[r] >> 16;
+      const unsigned off = (key & 1u) ? (t.bins[key >> 1] >> 16) : (t.bins[key >> 1] & 0xFFFFu);
+      t.order[off + (tag[r] & 0xFFFFu)] = (uint16_t)q;
+    }
   }
   __syncthreads();
   PGP_NN_STAMP(6);
@@ -1522,61 +1570,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 
 }  // namespace
 
-// Morton key of a source point at 2 mm resolution (13 bits per axis: +-8 m around the origin, clamped beyond --
-// the order only has to be coherent, and the sort's cost grows with the key bits): the source cloud is
-// put in this order once per call, so that the 64 queries of a wave are neighbours in space under every pose
-// -- they then read the SAME rows of the index (LDS broadcasts instead of bank conflicts: the searches are
-// bound by the LDS gather rate) and need similar work.  Every path below sees the permuted cloud; nothing
-// that is returned depends on the order except the last bits of the f64 sums.
-namespace {
-__device__ __forceinline__ unsigned long long spread21(unsigned long long v) {
-  v &= 0x1FFFFFull;
-  v = (v | (v << 32)) & 0x1F00000000FFFFull;
-  v = (v | (v << 16)) & 0x1F0000FF0000FFull;
-  v = (v | (v << 8)) & 0x100F00F00F00F00Full;
-  v = (v | (v << 4)) & 0x10C30C30C30C30C3ull;
-  v = (v | (v << 2)) & 0x1249249249249249ull;
-  return v;
-}
-__global__ __launch_bounds__(256) void icp_src_keys(const float4* __restrict__ src, int n, unsigned long long* __restrict__ keys) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = src[i];
-  auto q = [](float v) -> unsigned long long {
-    const float f = fminf(fmaxf(v * 512.f + 4096.f, 0.f), 8191.f);   // NaN -> 0
-    return (unsigned long long)f;
-  };
-  keys[i] = spread21(q(p.x)) | (spread21(q(p.y)) << 1) | (spread21(q(p.z)) << 2);
-}
-}  // namespace
-
-static int sort_source(pgp_ctx* ctx, const float4* d_src, int n_src, const float4** d_sorted, hipStream_t stream) {
-  const size_t N = (size_t)n_src;
-  size_t tmp_bytes = 0;
-  hipError_t he = rocprim::radix_sort_pairs(nullptr, tmp_bytes, (unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                            (float4*)nullptr, (float4*)nullptr, N, 0, 39, stream);
-  if (he != hipSuccess) {
-    set_error("rocprim::radix_sort_pairs (size query) failed: %s", hipGetErrorString(he));
-    return PGP_EHIP;
-  }
-  const size_t off_k2 = (N * 8 + 255) & ~(size_t)255, off_v = 2 * off_k2, off_tmp = off_v + ((N * 16 + 255) & ~(size_t)255);
-  int rc = ctx->d_icp_sort.ensure(off_tmp + tmp_bytes + 256);
-  if (rc != PGP_OK) return rc;
-  unsigned char* b = ctx->d_icp_sort.as<unsigned char>();
-  unsigned long long* k_in = reinterpret_cast<unsigned long long*>(b);
-  unsigned long long* k_out = reinterpret_cast<unsigned long long*>(b + off_k2);
-  float4* v_out = reinterpret_cast<float4*>(b + off_v);
-  hipLaunchKernelGGL(icp_src_keys, dim3((n_src + 255) / 256), dim3(256), 0, stream, d_src, n_src, k_in);
-  he = rocprim::radix_sort_pairs(b + off_tmp, tmp_bytes, k_in, k_out, const_cast<float4*>(d_src), v_out, N, 0, 39, stream);   // stable
-  if (he != hipSuccess) {
-    set_error("rocprim::radix_sort_pairs failed: %s", hipGetErrorString(he));
-    return PGP_EHIP;
-  }
-  PGP_HIP(hipGetLastError());
-  *d_sorted = v_out;
-  return PGP_OK;
-}
-
 // Builds the exact index of the target in ctx->d_icp_grid (image | counters | starts | keys) when its
 // image fits one workgroup's LDS.  *fits = false (and PGP_OK): the caller keeps the exhaustive search.
 static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q, IcpArgs* a, bool* fits, hipStream_t stream,
@@ -1598,7 +1591,7 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
   constexpr int kLdsBytes = 160 * 1024, kScratch = 8 * 1024;   // static LDS of icp_persist_index + slack
   if (n_tgt < 1 || n_tgt > 65535) return PGP_OK;                // 16-bit positions
   // n_q = queries a workgroup keeps in LDS (8 B each)
-  const long long avail = (long long)kLdsBytes - kScratch - 16ll * n_tgt - 8ll * n_q - 128;
+  const long long avail = (long long)kLdsBytes - kScratch - 16ll * n_tgt - 8ll * n_q - 2ll * kNnBins - 128;
   if (avail < 4096) return PGP_OK;
   // per cell: 2 B start + 2 B representative
   long long budget = avail / 4 - 64;
@@ -1639,6 +1632,8 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
   g.oy = bb[1];
   g.oz = bb[2];
   g.n_cells = g.nx * g.ny * g.nz;
+  g.strip_shift = 0;
+  while ((g.n_cells >> g.strip_shift) > kNnStrips) ++g.strip_shift;
   g.off_start = (uint32_t)n_tgt * 16u;
   g.off_rep = (g.off_start + (uint32_t)(g.n_cells + 1) * 2u + 15u) & ~15u;
   g.bytes = (g.off_rep + (uint32_t)g.n_cells * 2u + 15u) & ~15u;
@@ -1704,14 +1699,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (rc != PGP_OK) return rc;
     }
     return PGP_OK;
-  }
-  // spatially coherent source order (see sort_source); PGP_ICP_SORT=0 keeps the caller's order (A/B)
-  {
-    const char* v = getenv("PGP_ICP_SORT");
-    if (n_src >= 128 && !(v && atoi(v) == 0)) {
-      int rcs = sort_source(ctx, d_src, n_src, &d_src, stream);
-      if (rcs != PGP_OK) return rcs;
-    }
   }
   IcpArgs a{};
   a.src = d_src;

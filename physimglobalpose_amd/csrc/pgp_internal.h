@@ -124,7 +124,7 @@ struct pgp_ctx {
   pgp::DevBuf d_cl_keys, d_cl_ws, d_cl_io;   // pose clustering: sort keys, pose tables + bit matrix, host-API staging
 
   // ICP (host API staging + per-pose correspondence workspace)
-  pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_tgt_n, d_icp_T, d_icp_out, d_icp_ws, d_icp_grid, d_icp_sort;
+  pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_tgt_n, d_icp_T, d_icp_out, d_icp_ws, d_icp_grid;
   bool icp_attr_set = false;   // dynamic-LDS limit of the ICP kernels raised on this device
   // the exact index of the ICP target (icp.hip build_nn_index) stays valid across calls while the caller
   // vouches for the target: token != 0 and the same (pointer, size, token) = the same points

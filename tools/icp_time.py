@@ -15,15 +15,6 @@ S0 = (M[rng.choice(5000, 2500, replace=False)] @ R.T + t).astype(np.float32)
 S1 = S0.copy()
 k = rng.choice(2500, 250, replace=False)
 S1[k] += rng.uniform(-0.15, 0.15, (250, 3)).astype(np.float32)
-if os.environ.get("ICP_SORT_SRC"):      # experiment: source points in Morton order (spatially coherent waves)
-    def morton(P):
-        q = np.clip(((P - P.min(0)) / (np.ptp(P, axis=0) + 1e-9) * 1023).astype(np.uint64), 0, 1023)
-        def spread(v):
-            v = (v | (v << 16)) & 0x030000FF; v = (v | (v << 8)) & 0x0300F00F; v = (v | (v << 4)) & 0x030C30C3; v = (v | (v << 2)) & 0x09249249
-            return v
-        return spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
-    o = np.argsort(morton(S0.astype(np.float64)), kind="stable")
-    S0, S1 = S0[o], S1[o]
 Tinv = np.linalg.inv(synth._se3(R, t))
 sc = LcpScorer()
 PATHS = [("index persistent", {"PGP_ICP_NN": "index", "PGP_ICP_PERSIST": "1"}),
