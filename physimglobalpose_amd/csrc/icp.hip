@@ -416,6 +416,32 @@ __device__ __attribute__((noinline)) bool converged_extra(const IcpArgs& a, int 
   return stop;
 }
 
+// Sum of one double per lane over the wave, the same value in every lane, on the DPP path: four steps inside
+// each row of 16 lanes (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror: two register
+// moves + one v_add_f64 each, no LDS), then the four row sums are read with v_readlane and added in row order.
+// A FIXED tree: ((r0 + r1) + r2) + r3 of balanced 16-lane trees -- every kernel of this file reduces with it,
+// so they agree bit for bit.  (__shfl_xor on doubles = 12 ds_bpermute round trips per value; the 17 sums of an
+// iteration spent ~5 us in them.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_add_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int plo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+  const int phi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+  return v + __hiloint2double(phi, plo);
+}
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v = dpp_add_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v = dpp_add_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v = dpp_add_f64<0x141>(v);   // row_half_mirror
+  v = dpp_add_f64<0x140>(v);   // row_mirror: every lane of a row holds the row's sum
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const double r0 = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+  const double r1 = __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+  const double r2 = __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+  const double r3 = __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+  return ((r0 + r1) + r2) + r3;
+}
+
 // SPLIT = false: persistent kernel, all iterations of one pose in one workgroup (many poses).
 // SPLIT = true : one iteration's selection + update for one pose; the correspondences were
 //                produced by icp_nn_split over many workgroups (few poses: a single pose would
@@ -643,8 +669,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
 #pragma unroll
     for (int k = 0; k < kRedPlane; ++k)
       if (k < 16 || a.metric == 1)
-        for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
-    for (int off = 32; off >= 1; off >>= 1) e_acc += __shfl_xor(e_acc, off, 64);
+        acc[k] = wave_sum_f64(acc[k]);
+    e_acc = wave_sum_f64(e_acc);
     __syncthreads();
     if (lane == 0) {
       for (int k = 0; k < kRedPlane; ++k) s_red[wave * (kRedPlane + 1) + k] = acc[k];
@@ -1256,8 +1282,14 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     }
     // merge the lanes of a group: class regions start at multiples of their group size, so the partners
     // lane ^ off (off < L) work on the same query
+    // (most waves hold single-lane queries only: no exchange at all)
+    const bool b0 = __ballot(lg >= 1) != 0ull, b1 = __ballot(lg >= 2) != 0ull, b2 = __ballot(lg >= 3) != 0ull,
+               b3 = __ballot(lg >= 4) != 0ull, b4 = __ballot(lg >= 5) != 0ull, b5 = __ballot(lg >= 6) != 0ull;
+    const bool need[6] = {b0, b1, b2, b3, b4, b5};
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
+    for (int st = 0; st < 6; ++st) {
+      if (!need[st]) break;   // wave-uniform
+      const int off = 1 << st;
       const unsigned lo = __shfl_xor((unsigned)best, off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
       const int pp = __shfl_xor(bpos, off, 64);
       const unsigned long long pk = ((unsigned long long)hi << 32) | lo;
@@ -1515,8 +1547,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     }
 #pragma unroll
     for (int k = 0; k < kNs; ++k)
-      for (int off = 32; off >= 1; off >>= 1) acc[k] += __shfl_xor(acc[k], off, 64);
-    for (int off = 32; off >= 1; off >>= 1) e_acc += __shfl_xor(e_acc, off, 64);
+      acc[k] = wave_sum_f64(acc[k]);
+    e_acc = wave_sum_f64(e_acc);
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
