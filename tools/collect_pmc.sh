@@ -28,6 +28,7 @@ for MODE in weighted plain; do
   done
 done
 # calibration of the L1 counter unit on a known access pattern (tools/peaks.hip: 64 / 16 / 4 lines per load)
+if [ -x $REPO/tools/ab/peaks ]; then cp $REPO/tools/ab/peaks /tmp/peaks; fi
 if [ -x /tmp/peaks ]; then
   rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/pmc_peaks -- /tmp/peaks > $OUT/peaks_under_pmc.json 2> $OUT/pmc_peaks.err
 fi

@@ -88,4 +88,36 @@ for _ in range(REPS):
 flt = LcpScorer(0)
 for _ in range(REPS):
     flt.radius_outlier_filter(cw.P_xyz, cw.P_nrm, 0.03, 10)
+
+# round 3: ICP checker paths, leaf-state rendering + cost in HBM, Verify's early termination, unexplained segment
+os.environ["PGP_ICP_NN"] = "scan"
+sc.icp_refine(S, w.Q_xyz, G, trim=0.9, max_iterations=10)                 # icp_nn_split + icp_refine<true>
+os.environ["PGP_ICP_NN"] = "index"
+os.environ["PGP_ICP_PERSIST"] = "0"
+sc.icp_refine(S, w.Q_xyz, G, trim=0.9, max_iterations=10)                 # icp_nn_index + icp_refine<true>
+os.environ.pop("PGP_ICP_NN")
+os.environ.pop("PGP_ICP_PERSIST")
+import torch  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from test_render_gpu import icosphere  # noqa: E402
+mv, mf = icosphere(5, 0.1)
+cam = sc.camera(Kc, 480, 640, 0.1, 1.0)
+Tl = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng), [rng.uniform(-0.15, 0.15), rng.uniform(-0.1, 0.1),
+                                                                   rng.uniform(0.5, 0.9)])) for _ in range(64)])
+d_v, d_f, d_Tl = torch.from_numpy(mv).cuda(), torch.from_numpy(mf).cuda(), torch.from_numpy(Tl).cuda()
+d_par, d_ob = torch.from_numpy(obs).cuda().clamp(max=0.95), torch.from_numpy(obs).cuda()
+d_pts = torch.from_numpy(w.Q_xyz.astype(np.float32)).cuda()
+for _ in range(REPS):
+    d_img = sc.render_depth_device(d_v, d_f, d_Tl, cam, d_parent=d_par)
+    sc.depth_cost_device(d_ob, d_img, 0.01)
+    sc.render_depth_device(d_pts, None, d_Tl, cam, d_parent=d_par, d_depth=d_img)
+torch.cuda.synchronize()
+sc.set_verify_early_out(True)
+for _ in range(REPS):
+    sc.score(w.T, 0)
+sc.set_verify_early_out(False)
+models = [w.Q_xyz, w.Q_xyz[:1500]]
+poses = np.stack([w.T_gt, w.T[7]])
+for _ in range(REPS):
+    sc.unexplained_segment(w.P_xyz[:3000], models, poses, 0.008)
 print("profile_rows done")
