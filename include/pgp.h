@@ -352,9 +352,9 @@ typedef struct {
   float min_diff_trans;          /*   DifferentialTransformationChecker on the last smooth_length    */
   int smooth_length;             /*   iterations (1..8)                                              */
   int nn_search;                 /* 0 auto, 1 exhaustive scan, 2 uniform grid (needs max_corr_dist > 0),
-                                    3 exact index of the static target held in LDS (fails when the target
-                                    does not fit: > ~6000 points); auto = 3 when it fits, else 2 for capped
-                                    scene-sized searches, else 1.  All four return identical results. */
+                                    3 exact index of the static target (its image in LDS up to ~6000 points,
+                                    read from L2 beyond; fails above 65 535 points); auto = 3 when it applies,
+                                    else 2 for capped scene-sized searches, else 1.  All return identical results. */
 } pgp_icp_options;
 int pgp_icp_default_options(pgp_icp_options* opt);
 /* tgt_nrm: n_tgt x 3 unit normals of the target (nullable unless error_metric is 1).  Otherwise as

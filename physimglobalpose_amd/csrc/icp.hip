@@ -136,6 +136,7 @@ struct IcpArgs {
   NnGeom nn;
   const unsigned char* nn_image; // the LDS image of the index, in HBM: points | start16 | rep16 | mask
   int* ws_pos;                   // [n][n_src] position (in the image's point order) of the last correspondence
+  int nn_image_in_lds;           // 1: a workgroup copies the image into LDS; 0: it is read where it lies (L2)
 };
 
 __device__ __forceinline__ float row_xf(float a, float b, float c, float t, float x, float y, float z) {
@@ -1103,27 +1104,38 @@ __device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n
 #endif
 }
 
-// LDS layout of a workgroup that answers up to n_q_cap queries: image | d2[n_q_cap] | pos[n_q_cap] | order[n_q_cap] | bins
+// LDS layout of a workgroup that answers up to n_q_cap queries: [image |] d2[n_q_cap] | pos[n_q_cap] | order[n_q_cap] | bins.
+// IMG_LDS = false: the image stays where it was built (HBM, L2-resident) -- targets whose image does not fit a
+// CU's LDS (beyond ~6000 points); the tables are then read with global loads, everything else is the same code.
+template <bool IMG_LDS>
 __device__ __forceinline__ NnLds nn_load_image(const IcpArgs& a, unsigned char* smem, int n_q_cap, int tid, int nthreads) {
-  const uint4* src = reinterpret_cast<const uint4*>(a.nn_image);
-  uint4* dst = reinterpret_cast<uint4*>(smem);
-  const int n16 = (int)(a.nn.bytes >> 4);
-  for (int k = tid; k < n16; k += nthreads) dst[k] = src[k];
   NnLds t;
-  t.pts = reinterpret_cast<const float4*>(smem);
-  t.start = reinterpret_cast<const uint16_t*>(smem + a.nn.off_start);
-  t.rep = reinterpret_cast<const uint16_t*>(smem + a.nn.off_rep);
-  t.d2 = reinterpret_cast<float*>(smem + a.nn.bytes);
+  size_t base = 0;
+  if (IMG_LDS) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.nn_image);
+    uint4* dst = reinterpret_cast<uint4*>(smem);
+    const int n16 = (int)(a.nn.bytes >> 4);
+    for (int k = tid; k < n16; k += nthreads) dst[k] = src[k];
+    t.pts = reinterpret_cast<const float4*>(smem);
+    t.start = reinterpret_cast<const uint16_t*>(smem + a.nn.off_start);
+    t.rep = reinterpret_cast<const uint16_t*>(smem + a.nn.off_rep);
+    base = a.nn.bytes;
+  } else {
+    t.pts = reinterpret_cast<const float4*>(a.nn_image);
+    t.start = reinterpret_cast<const uint16_t*>(a.nn_image + a.nn.off_start);
+    t.rep = reinterpret_cast<const uint16_t*>(a.nn_image + a.nn.off_rep);
+  }
+  t.d2 = reinterpret_cast<float*>(smem + base);
   t.pos = reinterpret_cast<uint16_t*>(t.d2 + n_q_cap);
   t.order = t.pos + n_q_cap;
-  t.bins = reinterpret_cast<uint32_t*>(smem + ((a.nn.bytes + 8 * (size_t)n_q_cap + 15) & ~(size_t)15));
+  t.bins = reinterpret_cast<uint32_t*>(smem + ((base + 8 * (size_t)n_q_cap + 15) & ~(size_t)15));
 #ifdef PGP_ICP_STAMPS
   t.dbg = nullptr;
 #endif
   return t;
 }
-__host__ __device__ inline size_t nn_lds_bytes(uint32_t image_bytes, int n_q) {
-  return (((size_t)image_bytes + 8 * (size_t)n_q + 15) & ~(size_t)15) + 2 * (size_t)kNnBins;
+__host__ __device__ inline size_t nn_lds_bytes(uint32_t image_bytes, int n_q, bool image_in_lds = true) {
+  return (((image_in_lds ? (size_t)image_bytes : 0) + 8 * (size_t)n_q + 15) & ~(size_t)15) + 2 * (size_t)kNnBins;
 }
 // source point q of the workgroup (q_base + q of the cloud): an L2 read.  (A copy of the workgroup's source
 // points in LDS, 12 B each, measured +-1 %: the searches are bound by the LDS gather rate, not by this read.)
@@ -1320,6 +1332,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
 // Split-path correspondences through the index: grid (source chunks of 1024, poses); the workgroup
 // copies the image into LDS and answers its 1024 queries.  Same keys as icp_nn_split.
 constexpr int kIdxThreads = 1024;
+template <bool IMG_LDS>
 __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ NnSched s_sch;
@@ -1327,7 +1340,7 @@ __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
   if (a.st_done[pose]) return;
   const int tid = threadIdx.x;
   const int q_base = blockIdx.x * kIdxThreads, n_q = min(kIdxThreads, a.n_src - q_base);
-  const NnLds t = nn_load_image(a, smem, kIdxThreads, tid, kIdxThreads);
+  const NnLds t = nn_load_image<IMG_LDS>(a, smem, kIdxThreads, tid, kIdxThreads);
   const size_t o = (size_t)pose * a.n_src + q_base + tid;
   if (tid < n_q) {
     const int pp = a.ws_pos[o];
@@ -1350,7 +1363,7 @@ __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
 // the closed-form update and the stop rules are those of icp_refine, operation for operation: the two
 // kernels (and the exhaustive searches) give bit-identical transforms, energies and iteration counts.
 constexpr int kPiR = 4;   // source points per thread: n_src <= 4096
-template <int METRIC>
+template <int METRIC, bool IMG_LDS>
 __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_red[(kIcpThreads / 64) * (kRedPlane + 1)];
@@ -1373,10 +1386,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 #ifdef PGP_ICP_STAMPS
   __shared__ unsigned s_dbg[8];
   if (tid < 8) s_dbg[tid] = 0;
-  NnLds t = nn_load_image(a, smem, a.n_src, tid, kIcpThreads);
+  NnLds t = nn_load_image<IMG_LDS>(a, smem, a.n_src, tid, kIcpThreads);
   t.dbg = s_dbg;
 #else
-  const NnLds t = nn_load_image(a, smem, a.n_src, tid, kIcpThreads);
+  const NnLds t = nn_load_image<IMG_LDS>(a, smem, a.n_src, tid, kIcpThreads);
 #endif
   for (int q = tid; q < a.n_src; q += kIcpThreads) t.pos[q] = 0xFFFF;   // no previous correspondence yet
   if (tid < 16) s_G[tid] = Tg[tid];
@@ -1608,27 +1621,33 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
                           unsigned long long token) {
   *fits = false;
   static_assert(sizeof(NnGeom) <= sizeof(ctx->icp_idx_geom), "NnGeom outgrew its slot in the context");
+  constexpr int kLdsBytes = 160 * 1024, kScratch = 8 * 1024;   // static LDS of icp_persist_index + slack
+  bool force_global = false;
+  if (const char* v = getenv("PGP_ICP_IMAGE")) force_global = !strcmp(v, "global");   // A/B knob
   if (token != 0 && ctx->icp_idx_valid && ctx->icp_idx_token == token && ctx->icp_idx_tgt == (const void*)d_tgt &&
       ctx->icp_idx_ntgt == n_tgt) {
     NnGeom g;
     memcpy(&g, ctx->icp_idx_geom, sizeof g);
-    if ((long long)nn_lds_bytes(g.bytes, n_q) + 8 * 1024 <= 160 * 1024) {   // the resident index serves this call too
+    const bool in_lds = !force_global && (long long)nn_lds_bytes(g.bytes, n_q) + kScratch <= kLdsBytes;
+    if (in_lds || (long long)nn_lds_bytes(g.bytes, n_q, false) + kScratch <= kLdsBytes) {   // the resident index serves this call too
       a->nn = g;
       a->nn_image = ctx->d_icp_grid.as<unsigned char>();
+      a->nn_image_in_lds = in_lds ? 1 : 0;
       *fits = true;
       return PGP_OK;
     }
   }
   ctx->icp_idx_valid = false;
-  constexpr int kLdsBytes = 160 * 1024, kScratch = 8 * 1024;   // static LDS of icp_persist_index + slack
   if (n_tgt < 1 || n_tgt > 65535) return PGP_OK;                // 16-bit positions
-  // n_q = queries a workgroup keeps in LDS (8 B each)
+  if ((long long)nn_lds_bytes(0, n_q, false) + kScratch > kLdsBytes) return PGP_OK;   // the per-query arrays alone do not fit
+  // n_q = queries a workgroup keeps in LDS (8 B each).  When the image (16 B per point + 4 B per cell) fits beside
+  // them it is copied into LDS; else it is read from L2 and the cell count is bounded by the 16-bit tables only.
   const long long avail = (long long)kLdsBytes - kScratch - 16ll * n_tgt - 8ll * n_q - 2ll * kNnBins - 128;
-  if (avail < 4096) return PGP_OK;
   // per cell: 2 B start + 2 B representative
   long long budget = avail / 4 - 64;
+  bool in_lds = !force_global && avail >= 4096 && budget >= 64 && budget * 8 >= n_tgt;   // else cells would hold > 8 points on average
+  if (!in_lds) budget = 32768;
   if (budget > 32768) budget = 32768;
-  if (budget < 64 || budget * 8 < n_tgt) return PGP_OK;         // cells would hold > 8 points on average
   float bb[6];
   int rc;
   if ((rc = device_bbox(ctx, reinterpret_cast<const float*>(d_tgt), n_tgt, 4, bb, bb + 3, stream)) != PGP_OK) return rc;
@@ -1669,7 +1688,7 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
   g.off_start = (uint32_t)n_tgt * 16u;
   g.off_rep = (g.off_start + (uint32_t)(g.n_cells + 1) * 2u + 15u) & ~15u;
   g.bytes = (g.off_rep + (uint32_t)g.n_cells * 2u + 15u) & ~15u;
-  if ((long long)nn_lds_bytes(g.bytes, n_q) + kScratch > kLdsBytes) return PGP_OK;
+  if (in_lds && (long long)nn_lds_bytes(g.bytes, n_q) + kScratch > kLdsBytes) in_lds = false;
   const size_t nc1 = (size_t)g.n_cells + 1;
   const size_t off_ctr = ((size_t)g.bytes + 255) & ~(size_t)255, off_st = off_ctr + ((nc1 * 4 + 255) & ~(size_t)255),
                off_key = off_st + ((nc1 * 4 + 255) & ~(size_t)255);
@@ -1695,6 +1714,7 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
   PGP_HIP(hipGetLastError());
   a->nn = g;
   a->nn_image = image;
+  a->nn_image_in_lds = in_lds ? 1 : 0;
   *fits = true;
   memcpy(ctx->icp_idx_geom, &g, sizeof g);
   ctx->icp_idx_valid = token != 0;
@@ -1814,12 +1834,10 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_nn_index),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_persist_index<0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_persist_index<1>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    const void* big[] = {reinterpret_cast<const void*>(icp_nn_index<true>), reinterpret_cast<const void*>(icp_nn_index<false>),
+                         reinterpret_cast<const void*>(icp_persist_index<0, true>), reinterpret_cast<const void*>(icp_persist_index<1, true>),
+                         reinterpret_cast<const void*>(icp_persist_index<0, false>), reinterpret_cast<const void*>(icp_persist_index<1, false>)};
+    for (const void* f : big) PGP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     ctx->icp_attr_set = true;
   }
   if (persist_index) {
@@ -1827,9 +1845,15 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       a.st_hist = reinterpret_cast<double*>(((uintptr_t)(a.ws_j + need) + 15) & ~(uintptr_t)15);
       PGP_HIP(hipMemsetAsync(a.st_hist, 0, hist_bytes, stream));
     }
-    const size_t plds = nn_lds_bytes(a.nn.bytes, n_src);
-    if (a.metric == 1) hipLaunchKernelGGL(icp_persist_index<1>, dim3(n), dim3(kIcpThreads), plds, stream, a);
-    else hipLaunchKernelGGL(icp_persist_index<0>, dim3(n), dim3(kIcpThreads), plds, stream, a);
+    const bool il = a.nn_image_in_lds != 0;
+    const size_t plds = nn_lds_bytes(a.nn.bytes, n_src, il);
+    if (a.metric == 1) {
+      if (il) hipLaunchKernelGGL((icp_persist_index<1, true>), dim3(n), dim3(kIcpThreads), plds, stream, a);
+      else hipLaunchKernelGGL((icp_persist_index<1, false>), dim3(n), dim3(kIcpThreads), plds, stream, a);
+    } else {
+      if (il) hipLaunchKernelGGL((icp_persist_index<0, true>), dim3(n), dim3(kIcpThreads), plds, stream, a);
+      else hipLaunchKernelGGL((icp_persist_index<0, false>), dim3(n), dim3(kIcpThreads), plds, stream, a);
+    }
     PGP_HIP(hipGetLastError());
     return PGP_OK;
   }
@@ -1909,9 +1933,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   const dim3 ggrid((n_src + 255) / 256, n);
   for (int it = 0; it < a.max_iter; ++it) {
     if (use_grid) hipLaunchKernelGGL(icp_nn_grid, ggrid, dim3(256), 0, stream, a);
+    else if (use_index && a.nn_image_in_lds)
+      hipLaunchKernelGGL(icp_nn_index<true>, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
+                         nn_lds_bytes(a.nn.bytes, kIdxThreads, true), stream, a);
     else if (use_index)
-      hipLaunchKernelGGL(icp_nn_index, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
-                         nn_lds_bytes(a.nn.bytes, kIdxThreads), stream, a);
+      hipLaunchKernelGGL(icp_nn_index<false>, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
+                         nn_lds_bytes(a.nn.bytes, kIdxThreads, false), stream, a);
     else hipLaunchKernelGGL(icp_nn_split, gnn, dim3(kNnThreads), 0, stream, a);
     hipLaunchKernelGGL(icp_refine<true>, dim3(n), dim3(kIcpThreads), lds, stream, a);
     if (it == 0) PGP_HIP(hipGetLastError());   // a bad launch configuration shows on the first pair

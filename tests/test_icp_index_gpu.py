@@ -118,18 +118,30 @@ def test_default_path_is_the_index_and_matches_oracle():
     assert np.array_equal(it, ito) and np.abs(T - To).max() < 2e-6 and np.allclose(e, eo, rtol=1e-4, atol=1e-12)
 
 
-def test_target_too_large_for_lds_falls_back_or_reports():
+def test_targets_beyond_lds_use_the_same_index_from_l2(monkeypatch):
+    """A 12 000-point target does not fit a CU's LDS beside the per-query arrays: the image stays in HBM / L2 and
+    the same search reads it there -- still bit-identical to the scan; the 16-bit tables end at 65 535 points."""
     from physimglobalpose_amd._lib import PgpError
     rng = np.random.default_rng(27)
-    M = rng.uniform(-0.2, 0.2, (12000, 3)).astype(np.float32)
-    S = (M[:300] + 0.001).astype(np.float32)
-    G = synth.colmajor16(np.eye(4))[None]
+    M = synth.make_model(rng, 12000)[0].astype(np.float32)
+    R = synth._random_rot(rng)
+    S = (M[rng.choice(12000, 3000, replace=False)] @ R.T + [0.1, 0.0, 0.6] + 0.0005 * rng.standard_normal((3000, 3))).astype(np.float32)
+    Tinv = np.linalg.inv(synth._se3(R, [0.1, 0.0, 0.6]))
+    G = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(rng, np.deg2rad(4)), 0.004 * rng.standard_normal(3)))
+                  for _ in range(5)])
+    _three_ways(monkeypatch, S, M, G, max_iterations=12, trim_fraction=0.9, energy_ratio=1.0)
+    # the LDS-sized problem through the L2 path as well (A/B knob)
+    S2, M2, N2, G2 = _problem(31, 3000, 1700, 4)
+    monkeypatch.setenv("PGP_ICP_IMAGE", "global")
+    _three_ways(monkeypatch, S2, M2, G2, **FORMS["trimmed"])
+    monkeypatch.delenv("PGP_ICP_IMAGE")
     sc = LcpScorer()
-    a = sc.icp_refine_ex(S, M, G, max_iterations=3, nn_search=0)      # auto: exhaustive scan
-    b = sc.icp_refine_ex(S, M, G, max_iterations=3, nn_search=1)
+    big = rng.uniform(-0.2, 0.2, (70000, 3)).astype(np.float32)
+    a = sc.icp_refine_ex(S[:200], big, G[:1], max_iterations=2, nn_search=0)      # auto: exhaustive scan
+    b = sc.icp_refine_ex(S[:200], big, G[:1], max_iterations=2, nn_search=1)
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
     with pytest.raises(PgpError):
-        sc.icp_refine_ex(S, M, G, max_iterations=3, nn_search=3)
+        sc.icp_refine_ex(S[:200], big, G[:1], max_iterations=2, nn_search=3)
 
 
 def test_resident_index_is_reused_and_never_stale(monkeypatch):
