@@ -181,6 +181,8 @@ typedef struct {
   long long n_occupied;                 /* cells with a non-empty candidate list */
   long long bytes_index;                /* query-time index: words + occupied offsets + lists */
   float build_ms;                       /* device time of the last index build */
+  int sparse;                           /* 1: hashed table of the occupied 4x4x2 blocks, 0: dense block array */
+  long long n_blocks;                   /* blocks in the table (sparse) or in the dense array */
 } pgp_index_info;
 int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info);
 

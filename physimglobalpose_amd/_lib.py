@@ -20,7 +20,8 @@ class IndexInfo(C.Structure):
                 ("grid_nx", C.c_int), ("grid_ny", C.c_int), ("grid_nz", C.c_int),
                 ("cell_size", C.c_float), ("delta", C.c_float),
                 ("n_cells", C.c_longlong), ("n_candidates", C.c_longlong),
-                ("n_occupied", C.c_longlong), ("bytes_index", C.c_longlong), ("build_ms", C.c_float)]
+                ("n_occupied", C.c_longlong), ("bytes_index", C.c_longlong), ("build_ms", C.c_float),
+                ("sparse", C.c_int), ("n_blocks", C.c_longlong)]
 
 
 class IcpParams(C.Structure):

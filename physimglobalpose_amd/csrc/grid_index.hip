@@ -19,6 +19,13 @@
 // choose_grid) covers the float rounding of cell(x), so cand(cell(x)) is a superset of the
 // scene points that pass the test for x.  The result equals an exhaustive scan.
 //
+// SPARSE form.  The dense block array and its build scratch grow with the bounding-box VOLUME (8 bytes of
+// scratch per cell).  A scene whose box is mostly empty -- a whole room at delta = 5 mm -- takes the sparse
+// form instead: the same 4 x 4 x 2 blocks, but only those that hold a candidate, in an open-addressing table
+// (uint4 {key, bits, base, slot}, load factor <= 1/8, multiplicative hash, linear probing).  A query reads
+// one 16-byte entry where the dense form reads one 8-byte word; scratch and table scale with the occupied
+// blocks, the cell edge stays 0.85 delta up to 16 384 cells per axis (70 m at delta = 5 mm).
+//
 // HBM layout: 28 copies of each point on average (h = 0.85 delta, two dilation rings) = 22.6 MB at
 // |P| = 50 k; the index trades capacity (288 GB) for one-run locality.
 
@@ -33,8 +40,9 @@ namespace pgp {
 
 namespace {
 
-constexpr int kMaxDim = 1024;                  // cells per axis
-constexpr long long kMaxCells = 1LL << 28;     // 268 M cells (1 GiB of offsets) hard cap
+constexpr int kMaxDim = 1024;                  // cells per axis, dense form (the flat scoring kernel's bit fields)
+constexpr long long kMaxCells = 1LL << 26;     // dense form: 67 M cells (2 x 256 MiB of build scratch); beyond, sparse
+constexpr int kMaxDimSparse = 16384;           // cells per axis, sparse form
 
 __device__ __forceinline__ float box_dist2(float px, float lo, float h) {
   // squared distance from coordinate px to the interval [lo, lo+h]
@@ -44,16 +52,9 @@ __device__ __forceinline__ float box_dist2(float px, float lo, float h) {
   return d * d;
 }
 
-// One thread per scene point: visit the (2r+1)^3 cells around its own cell; for each whose box
-// is within `reach`, either count it (FILL=false) or append the point to the cell's list.
-template <bool FILL>
-__global__ __launch_bounds__(256) void scatter_points(GridDesc g, int r, const float4* __restrict__ P,
-                                                      int nP, uint32_t* __restrict__ cell_ctr,
-                                                      const uint32_t* __restrict__ cell_start,
-                                                      float4* __restrict__ cand) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nP) return;
-  float4 p = P[i];
+// Every cell whose box is within `reach` of point p (the (2r+1)^3 cells around its own): f(x, y, z).
+template <class F>
+__device__ __forceinline__ void for_cells_in_reach(const GridDesc& g, int r, float4 p, F f) {
   float fx = (p.x - g.ox) * g.inv_h, fy = (p.y - g.oy) * g.inv_h, fz = (p.z - g.oz) * g.inv_h;
   if (!(fx >= 0.f && fx < (float)g.nx && fy >= 0.f && fy < (float)g.ny && fz >= 0.f && fz < (float)g.nz))
     return;  // NaN / inf points can never be inliers (d2 <= eps is false for NaN)
@@ -72,12 +73,99 @@ __global__ __launch_bounds__(256) void scatter_points(GridDesc g, int r, const f
         if (x < 0 || x >= g.nx) continue;
         float ex = box_dist2(p.x, g.ox + (float)x * g.h, g.h);
         if (ex + ey + ez > reach2) continue;
-        size_t c = (size_t)grid_word(g, x, y, z) * 32 + grid_bit(x, y, z);
-        uint32_t slot = atomicAdd(&cell_ctr[c], 1u);
-        if (FILL) cand[cell_start[c] + slot] = p;
+        f(x, y, z);
       }
     }
   }
+}
+
+// slot of an existing block of the sparse table (build time: every block asked for was inserted)
+__device__ __forceinline__ uint32_t block_slot(const GridDesc& g, const uint4* __restrict__ tab, int x, int y, int z) {
+  const uint32_t key = block_key(g, (uint32_t)x >> 2, (uint32_t)y >> 2, (uint32_t)z >> 1);
+  uint32_t i = block_hash(g, key);
+  for (uint32_t probe = 0; probe <= g.tab_mask; ++probe) {
+    const uint4 e = tab[i];
+    if (e.x == key) return e.w;
+    i = (i + 1u) & g.tab_mask;
+  }
+  return 0u;
+}
+
+// One thread per scene point: for each cell within `reach`, either count it (FILL=false) or append the
+// point to the cell's list.  SPARSE: the cell's number is (slot of its block) * 32 + bit.
+template <bool FILL, bool SPARSE>
+__global__ __launch_bounds__(256) void scatter_points(GridDesc g, int r, const float4* __restrict__ P,
+                                                      int nP, uint32_t* __restrict__ cell_ctr,
+                                                      const uint32_t* __restrict__ cell_start,
+                                                      float4* __restrict__ cand, const uint4* __restrict__ tab) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nP) return;
+  const float4 p = P[i];
+  for_cells_in_reach(g, r, p, [&](int x, int y, int z) {
+    const size_t w = SPARSE ? (size_t)block_slot(g, tab, x, y, z) : (size_t)grid_word(g, x, y, z);
+    const size_t c = w * 32 + grid_bit(x, y, z);
+    uint32_t slot = atomicAdd(&cell_ctr[c], 1u);
+    if (FILL) cand[cell_start[c] + slot] = p;
+  });
+}
+
+// Sparse form, pass 1: the distinct blocks that hold a cell within reach of some point, counted through a
+// scratch table of bare keys (capacity = a bound on the blocks all points can touch, load <= 1/2).
+__global__ __launch_bounds__(256) void blocks_count(GridDesc g, int r, const float4* __restrict__ P, int nP,
+                                                    uint32_t* __restrict__ keys, uint32_t mask, int shift,
+                                                    uint32_t* __restrict__ n_blocks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nP) return;
+  uint32_t last = kBlockEmpty, fresh = 0;
+  for_cells_in_reach(g, r, P[i], [&](int x, int y, int z) {
+    const uint32_t key = block_key(g, (uint32_t)x >> 2, (uint32_t)y >> 2, (uint32_t)z >> 1);
+    if (key == last) return;
+    last = key;
+    uint32_t j = (key * 2654435761u) >> shift;
+    for (;;) {
+      uint32_t k = keys[j];
+      if (k == kBlockEmpty) k = atomicCAS(&keys[j], kBlockEmpty, key);
+      if (k == kBlockEmpty) { ++fresh; break; }
+      if (k == key) break;
+      j = (j + 1u) & mask;
+    }
+  });
+  if (fresh) atomicAdd(n_blocks, fresh);
+}
+
+// pass 2: the same blocks into the final table (load <= 1/8); the inserting thread numbers the block
+__global__ __launch_bounds__(256) void blocks_insert(GridDesc g, int r, const float4* __restrict__ P, int nP,
+                                                     uint4* __restrict__ tab, uint32_t* __restrict__ n_blocks) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nP) return;
+  uint32_t last = kBlockEmpty;
+  uint32_t* tab32 = reinterpret_cast<uint32_t*>(tab);
+  for_cells_in_reach(g, r, P[i], [&](int x, int y, int z) {
+    const uint32_t key = block_key(g, (uint32_t)x >> 2, (uint32_t)y >> 2, (uint32_t)z >> 1);
+    if (key == last) return;
+    last = key;
+    uint32_t j = block_hash(g, key);
+    for (;;) {
+      uint32_t k = tab32[4 * (size_t)j];
+      if (k == kBlockEmpty) k = atomicCAS(&tab32[4 * (size_t)j], kBlockEmpty, key);
+      if (k == kBlockEmpty) { tab32[4 * (size_t)j + 3] = atomicAdd(n_blocks, 1u); break; }
+      if (k == key) break;
+      j = (j + 1u) & g.tab_mask;
+    }
+  });
+}
+
+// last pass: {occupancy bits, rank base} of each block from the per-slot words into its table entry
+__global__ __launch_bounds__(256) void blocks_finish(uint4* __restrict__ tab, uint32_t n_entries,
+                                                     const uint2* __restrict__ words) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_entries) return;
+  uint4 e = tab[i];
+  if (e.x == kBlockEmpty) return;
+  const uint2 w = words[e.w];
+  e.y = w.x;
+  e.z = w.y;
+  tab[i] = e;
 }
 
 // ---- exclusive scan over uint32 (3 passes) ----
@@ -194,7 +282,14 @@ __global__ __launch_bounds__(256) void fill_occupied(GridDesc g, const uint32_t*
   }
 }
 
-// Choose cell size, origin and dims for a bounding box and a radius.
+int ceil_log2(long long n) {
+  int b = 0;
+  while ((1LL << b) < n) ++b;
+  return b;
+}
+
+// Choose cell size, origin, dims and form (dense block array or sparse block table) for a bounding box
+// and a radius.
 int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, int* r_out) {
   float ext[3], maxext = 0.f, maxabs = 0.f;
   for (int k = 0; k < 3; ++k) {
@@ -207,67 +302,84 @@ int choose_grid(const float mn[3], const float mx[3], float delta, GridDesc* g, 
   // of a smaller box -- 1.5 M candidates instead of 1.0 M at C2, but 20 % fewer per query.  Measured
   // on the round-1 kernel (tools/tune.py, PGP_CELL_RATIO): 0.75-0.85 -> 85.5 us plain / 116 us
   // weighted, 1.02 -> 88.4 / 116.6, 0.6 -> 88 / 122, 0.45 -> 102 / 133, 1.3 -> 91 / 121.
-  // h grows further only to keep the grid within kMaxDim / kMaxCells.
+  // h grows further only when neither form can hold the grid (beyond kMaxDimSparse cells per axis).
   float h = delta * 0.85f;
   if (const char* v = getenv("PGP_CELL_RATIO")) {  // experiment knob: cell edge / delta
     float ratio = (float)atof(v);
     if (ratio > 0.05f && ratio < 64.f) h = delta * ratio;
   }
-  for (int iter = 0; iter < 200; ++iter) {
-    // margin: rounding of cell(x) is <= ~4 ulp of (x-origin)*inv_h (value up to kMaxDim) plus
-    // the ulp of the coordinates themselves; 0.4 % of a cell + 64 ulp(extent) covers it.
-    float margin = 0.004f * h + 1e-6f * (float)kMaxDim * h + 64.f * FLT_EPSILON * (maxabs + maxext);
-    float reach = delta * (1.f + 4.f * FLT_EPSILON) + margin;
-    int r = (int)ceilf(reach / h);
-    if (r < 1) r = 1;
-    // origin one dilation ring (+1 cell) outside the box so that every position within reach of
-    // a point has a valid cell; a position outside the grid is farther than delta from all of P.
-    float pad = (float)(r + 1) * h;
-    g->h = h;
-    g->inv_h = 1.0f / h;
-    g->reach = reach;
-    // origin ON the lattice of pitch 1 / inv_h (GridDesc): cell 0 is lattice cell k0, at most 1.5 cells
-    // below mn - pad.  The scoring kernel then finds a cell as round(x * inv_h) - k0 with one fused
-    // multiply-add; that and floor((x - origin) * inv_h) differ by the rounding of `origin`, of h vs
-    // 1 / inv_h and of the products -- a few ulp of the coordinate, far inside `margin`.
-    const double k0d[3] = {floor((double)(mn[0] - pad) * g->inv_h), floor((double)(mn[1] - pad) * g->inv_h),
-                           floor((double)(mn[2] - pad) * g->inv_h)};
-    g->magic_ok = 1;
-    for (int k = 0; k < 3; ++k)
-      if (!(fabs(k0d[k]) < (double)((1 << 22) - 4 * kMaxDim))) g->magic_ok = 0;
-    if (g->magic_ok) {
-      g->k0x = (int)k0d[0];
-      g->k0y = (int)k0d[1];
-      g->k0z = (int)k0d[2];
-      g->ox = ((float)g->k0x - 0.5f) * h;
-      g->oy = ((float)g->k0y - 0.5f) * h;
-      g->oz = ((float)g->k0z - 0.5f) * h;
-      // h and 1 / inv_h differ in the last place: with a large lattice number the product can land
-      // above mn - pad by that much; one more cell of padding restores the invariant
-      if (!(g->ox <= mn[0] - pad)) { g->k0x -= 1; g->ox = ((float)g->k0x - 0.5f) * h; }
-      if (!(g->oy <= mn[1] - pad)) { g->k0y -= 1; g->oy = ((float)g->k0y - 0.5f) * h; }
-      if (!(g->oz <= mn[2] - pad)) { g->k0z -= 1; g->oz = ((float)g->k0z - 0.5f) * h; }
-    } else {
-      g->k0x = g->k0y = g->k0z = 0;
-      g->ox = mn[0] - pad;
-      g->oy = mn[1] - pad;
-      g->oz = mn[2] - pad;
-    }
-    double nx = floor((double)(mx[0] - g->ox) / h) + r + 2;
-    double ny = floor((double)(mx[1] - g->oy) / h) + r + 2;
-    double nz = floor((double)(mx[2] - g->oz) / h) + r + 2;
-    const double padded = (floor((nx + 3) / 4) * 4) * (floor((ny + 3) / 4) * 4) * (floor((nz + 1) / 2) * 2);
-    if (nx <= kMaxDim && ny <= kMaxDim && nz <= kMaxDim && padded <= (double)kMaxCells) {
+  int only_form = -1;  // experiment / test knob: PGP_INDEX=dense|sparse
+  if (const char* v = getenv("PGP_INDEX")) only_form = (v[0] == 's') ? 1 : (v[0] == 'd') ? 0 : -1;
+  for (int iter = 0; iter < 200; ++iter, h *= 1.25f) {
+    for (int form = 0; form < 2; ++form) {  // 0: dense block array, 1: sparse block table
+      if (only_form >= 0 && form != only_form) continue;
+      const int dimcap = form ? kMaxDimSparse : kMaxDim;
+      // margin: rounding of cell(x) is <= ~4 ulp of (x-origin)*inv_h (value up to dimcap) plus
+      // the ulp of the coordinates themselves; 0.4 % of a cell + 64 ulp(extent) covers it.
+      float margin = 0.004f * h + 1e-6f * (float)dimcap * h + 64.f * FLT_EPSILON * (maxabs + maxext);
+      float reach = delta * (1.f + 4.f * FLT_EPSILON) + margin;
+      int r = (int)ceilf(reach / h);
+      if (r < 1) r = 1;
+      // origin one dilation ring (+1 cell) outside the box so that every position within reach of
+      // a point has a valid cell; a position outside the grid is farther than delta from all of P.
+      float pad = (float)(r + 1) * h;
+      g->h = h;
+      g->inv_h = 1.0f / h;
+      g->reach = reach;
+      g->sparse = form;
+      g->key_sy = g->key_sz = 0;
+      g->tab_mask = 0;
+      g->tab_shift = 0;
+      // origin ON the lattice of pitch 1 / inv_h (GridDesc): cell 0 is lattice cell k0, at most 1.5 cells
+      // below mn - pad.  The scoring kernel then finds a cell as round(x * inv_h) - k0 with one fused
+      // multiply-add; that and floor((x - origin) * inv_h) differ by the rounding of `origin`, of h vs
+      // 1 / inv_h and of the products -- a few ulp of the coordinate, far inside `margin`.
+      const double k0d[3] = {floor((double)(mn[0] - pad) * g->inv_h), floor((double)(mn[1] - pad) * g->inv_h),
+                             floor((double)(mn[2] - pad) * g->inv_h)};
+      g->magic_ok = 1;
+      for (int k = 0; k < 3; ++k)
+        if (!(fabs(k0d[k]) < (double)((1 << 22) - 4 * dimcap))) g->magic_ok = 0;
+      if (g->magic_ok) {
+        g->k0x = (int)k0d[0];
+        g->k0y = (int)k0d[1];
+        g->k0z = (int)k0d[2];
+        g->ox = ((float)g->k0x - 0.5f) * h;
+        g->oy = ((float)g->k0y - 0.5f) * h;
+        g->oz = ((float)g->k0z - 0.5f) * h;
+        // h and 1 / inv_h differ in the last place: with a large lattice number the product can land
+        // above mn - pad by that much; one more cell of padding restores the invariant
+        if (!(g->ox <= mn[0] - pad)) { g->k0x -= 1; g->ox = ((float)g->k0x - 0.5f) * h; }
+        if (!(g->oy <= mn[1] - pad)) { g->k0y -= 1; g->oy = ((float)g->k0y - 0.5f) * h; }
+        if (!(g->oz <= mn[2] - pad)) { g->k0z -= 1; g->oz = ((float)g->k0z - 0.5f) * h; }
+      } else {
+        g->k0x = g->k0y = g->k0z = 0;
+        g->ox = mn[0] - pad;
+        g->oy = mn[1] - pad;
+        g->oz = mn[2] - pad;
+      }
+      double nx = floor((double)(mx[0] - g->ox) / h) + r + 2;
+      double ny = floor((double)(mx[1] - g->oy) / h) + r + 2;
+      double nz = floor((double)(mx[2] - g->oz) / h) + r + 2;
+      if (!(nx <= dimcap && ny <= dimcap && nz <= dimcap)) continue;
+      const long long nbx = ((long long)nx + 3) / 4, nby = ((long long)ny + 3) / 4, nbz = ((long long)nz + 1) / 2;
+      if (form == 0) {
+        if (nbx * nby * nbz * 32 > kMaxCells) continue;
+      } else {
+        // block key = bx | by << sy | bz << sz in 31 bits (0xFFFFFFFF marks an empty table entry)
+        const int wx = ceil_log2(nbx), wy = ceil_log2(nby), wz = ceil_log2(nbz);
+        if (wx + wy + wz > 31) continue;
+        g->key_sy = wx;
+        g->key_sz = wx + wy;
+      }
       g->nx = (int)nx;
       g->ny = (int)ny;
       g->nz = (int)nz;
-      g->nbx = (g->nx + 3) / 4;
-      g->nby = (g->ny + 3) / 4;
-      g->nbz = (g->nz + 1) / 2;
+      g->nbx = (int)nbx;
+      g->nby = (int)nby;
+      g->nbz = (int)nbz;
       *r_out = r;
       return PGP_OK;
     }
-    h *= 1.25f;
   }
   set_error("scene extent %.3g m cannot be gridded for delta %.3g", maxext, delta);
   return PGP_EINVAL;
@@ -315,16 +427,6 @@ int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float d
   int r = 1;
   int rc = choose_grid(mn, mx, delta, &g, &r);
   if (rc != PGP_OK) return rc;
-  const size_t n_words = (size_t)g.nbx * g.nby * g.nbz;
-  const size_t n_cells = n_words * 32;  // blocked numbering, padded to whole 4 x 4 x 2 blocks
-  const size_t n_scan = n_cells + 1;
-  const int n_tiles = (int)((n_scan + kScanTile - 1) / kScanTile);
-
-  if ((rc = ctx->d_cell_start.ensure(n_scan * 4)) != PGP_OK) return rc;
-  if ((rc = ctx->d_cell_tmp.ensure(n_scan * 4)) != PGP_OK) return rc;
-  if ((rc = ctx->d_scan_tmp.ensure((size_t)n_tiles * 4 + 4)) != PGP_OK) return rc;
-  if ((rc = ctx->d_bitmap.ensure(n_words * 8)) != PGP_OK) return rc;
-
   struct EventPair {  // destroyed on every return path
     hipEvent_t a = nullptr, b = nullptr;
     ~EventPair() {
@@ -336,23 +438,83 @@ int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float d
   PGP_HIP(hipEventCreate(&ev.b));
   const hipEvent_t e0 = ev.a, e1 = ev.b;
   PGP_HIP(hipEventRecord(e0, st));
+  const int pb = (nP + 255) / 256;
+
+  size_t n_words = (size_t)g.nbx * g.nby * g.nbz;
+  uint32_t n_blk = 0;
+  if (g.sparse) {
+    // pass 1: count the distinct blocks (scratch key table sized by what nP points can touch at most)
+    const double per_pt = (double)((2 * r + 4) / 4 + 1) * ((2 * r + 4) / 4 + 1) * ((2 * r + 2) / 2 + 1);
+    const double bound = std::max(1.0, std::min((double)nP * per_pt, (double)n_words));
+    const int tmp_log = std::max(10, ceil_log2((long long)(2.0 * bound)));
+    if (tmp_log > 31) {
+      set_error("scene of %d points: block table scratch out of range", nP);
+      return PGP_EINVAL;
+    }
+    const size_t tmp_cap = (size_t)1 << tmp_log;
+    if ((rc = ctx->d_cell_tmp.ensure((tmp_cap + 1) * 4)) != PGP_OK) return rc;
+    uint32_t* keys = ctx->d_cell_tmp.as<uint32_t>();
+    PGP_HIP(hipMemsetAsync(keys, 0xFF, tmp_cap * 4, st));
+    PGP_HIP(hipMemsetAsync(keys + tmp_cap, 0, 4, st));
+    if (nP > 0)
+      hipLaunchKernelGGL(blocks_count, dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, keys,
+                         (uint32_t)(tmp_cap - 1), 32 - tmp_log, keys + tmp_cap);
+    PGP_HIP(hipMemcpyAsync(&n_blk, keys + tmp_cap, 4, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+    // pass 2: the table itself, at most one eighth full
+    // table entries per block (knob 2 .. 16): at C2 forced sparse 2 -> 29.6, 4 -> 38.5, 8 -> 40.9 M hyp/s weighted
+    // (tools/sparse_index_time.py; dense 46.2) -- the wave waits for the lane with the longest probe chain
+    long long slack = 8;
+    if (const char* v = getenv("PGP_TAB_SLACK")) slack = std::min(16, std::max(2, atoi(v)));
+    const int tab_log = std::max(10, ceil_log2(slack * (long long)n_blk));
+    const size_t tab_cap = (size_t)1 << tab_log;
+    g.tab_mask = (uint32_t)(tab_cap - 1);
+    g.tab_shift = 32 - tab_log;
+    if ((rc = ctx->d_blocktab.ensure(tab_cap * 16)) != PGP_OK) return rc;
+    keys = ctx->d_cell_tmp.as<uint32_t>();
+    PGP_HIP(hipMemsetAsync(ctx->d_blocktab.p, 0xFF, tab_cap * 16, st));
+    PGP_HIP(hipMemsetAsync(keys, 0, 4, st));
+    if (nP > 0)
+      hipLaunchKernelGGL(blocks_insert, dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP,
+                         ctx->d_blocktab.as<uint4>(), keys);
+    PGP_HIP(hipStreamSynchronize(st));  // d_cell_tmp is re-sized below
+    n_words = std::max<size_t>(n_blk, 1);  // words are per block SLOT from here on
+  }
+  const size_t n_cells = n_words * 32;  // blocked numbering, padded to whole 4 x 4 x 2 blocks
+  const size_t n_scan = n_cells + 1;
+  const int n_tiles = (int)((n_scan + kScanTile - 1) / kScanTile);
+
+  if ((rc = ctx->d_cell_start.ensure(n_scan * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cell_tmp.ensure(n_scan * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_scan_tmp.ensure((size_t)n_tiles * 4 + 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_bitmap.ensure(n_words * 8)) != PGP_OK) return rc;
+  const uint4* tab = g.sparse ? ctx->d_blocktab.as<uint4>() : nullptr;
 
   uint32_t* ctr = ctx->d_cell_tmp.as<uint32_t>();
   uint32_t* start = ctx->d_cell_start.as<uint32_t>();
   PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
-  const int pb = (nP + 255) / 256;
-  if (nP > 0)
-    hipLaunchKernelGGL(scatter_points<false>, dim3(pb), dim3(256), 0, st, g, r,
-                       ctx->d_P.as<float4>(), nP, ctr, (const uint32_t*)nullptr, (float4*)nullptr);
+  if (nP > 0) {
+    if (g.sparse)
+      hipLaunchKernelGGL((scatter_points<false, true>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP,
+                         ctr, (const uint32_t*)nullptr, (float4*)nullptr, tab);
+    else
+      hipLaunchKernelGGL((scatter_points<false, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP,
+                         ctr, (const uint32_t*)nullptr, (float4*)nullptr, tab);
+  }
   if ((rc = device_exclusive_scan(ctr, start, n_scan, ctx->d_scan_tmp.as<uint32_t>(), st)) != PGP_OK) return rc;
   uint32_t total = 0;
   PGP_HIP(hipMemcpyAsync(&total, start + n_cells, 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
   if ((rc = ctx->d_cand.ensure(((size_t)total + 1 + 256) * sizeof(float4))) != PGP_OK) return rc;
   PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
-  if (nP > 0)
-    hipLaunchKernelGGL(scatter_points<true>, dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(),
-                       nP, ctr, start, ctx->d_cand.as<float4>());
+  if (nP > 0) {
+    if (g.sparse)
+      hipLaunchKernelGGL((scatter_points<true, true>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+                         (const uint32_t*)start, ctx->d_cand.as<float4>(), tab);
+    else
+      hipLaunchKernelGGL((scatter_points<true, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+                         (const uint32_t*)start, ctx->d_cand.as<float4>(), tab);
+  }
   // two-level compaction: words {bits, rank base} + offsets of occupied cells only
   uint2* words = ctx->d_bitmap.as<uint2>();
   hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
@@ -365,6 +527,9 @@ int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float d
   hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
                      (const uint32_t*)start, (const uint32_t*)ctr, words,
                      ctx->d_occ_start.as<uint2>(), n_words, n_cells);
+  if (g.sparse)
+    hipLaunchKernelGGL(blocks_finish, dim3((g.tab_mask + 256) / 256), dim3(256), 0, st, ctx->d_blocktab.as<uint4>(),
+                       g.tab_mask + 1, (const uint2*)words);
   PGP_HIP(hipGetLastError());
   PGP_HIP(hipEventRecord(e1, st));
   PGP_HIP(hipStreamSynchronize(st));
@@ -373,6 +538,7 @@ int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float d
 
   ctx->grid = g;
   ctx->n_cells = (long long)n_cells;
+  ctx->n_blocks = (long long)n_blk;
   ctx->n_cand = (long long)total;
   ctx->delta = delta;
   ctx->has_index = true;

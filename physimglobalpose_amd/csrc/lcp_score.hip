@@ -188,6 +188,23 @@ __device__ __forceinline__ uint32_t cell_bits(float x, float inv_h_vgpr, float c
   return (uint32_t)b;
 }
 
+// Sparse form of the index (grid_index.hip): {occupancy bits, rank base} of block (bx, by, bz) from the
+// open-addressing table; a block that is not in the table holds no candidate.  The table is at most one
+// eighth full, so a look-up ends after 1.07 - 1.15 entries on average, hit or miss.
+__device__ __forceinline__ void block_probe(const GridDesc& g, const uint4* __restrict__ tab, uint32_t bx,
+                                            uint32_t by, uint32_t bz, unsigned* bits, unsigned* base) {
+  const uint32_t key = block_key(g, bx, by, bz);
+  uint32_t i = block_hash(g, key);
+  uint4 e = tab[i];
+  while (e.x != key && e.x != kBlockEmpty) {
+    i = (i + 1u) & g.tab_mask;
+    e = tab[i];
+  }
+  const bool hit = e.x == key;
+  *bits = hit ? e.y : 0u;
+  *base = hit ? e.z : 0u;
+}
+
 template <bool WAVE_SKIP = false>
 __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restrict__ words,
                                          const uint2* __restrict__ occ_run, float x, float y,
@@ -197,10 +214,17 @@ __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restr
   const int cy = clamp0(cvt_rz(fy), g.ny - 1);
   const int cz = clamp0(cvt_rz(fz), g.nz - 1);
   // blocked numbering (pgp_internal.h grid_word / grid_bit): word = 4 x 4 x 2 block, bit = cell in it
-  const uint32_t brow = mad24((uint32_t)cz >> 1, (uint32_t)g.nby, (uint32_t)cy >> 2);
-  const uint32_t wi = mad24(brow, (uint32_t)g.nbx, (uint32_t)cx >> 2);
-  const unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
-  const unsigned lo = (unsigned)(wv & 0xFFFFFFFFull), base = (unsigned)(wv >> 32);
+  unsigned lo, base;
+  if (g.sparse) {
+    block_probe(g, reinterpret_cast<const uint4*>(words), (uint32_t)cx >> 2, (uint32_t)cy >> 2, (uint32_t)cz >> 1,
+                &lo, &base);
+  } else {
+    const uint32_t brow = mad24((uint32_t)cz >> 1, (uint32_t)g.nby, (uint32_t)cy >> 2);
+    const uint32_t wi = mad24(brow, (uint32_t)g.nbx, (uint32_t)cx >> 2);
+    const unsigned long long wv = reinterpret_cast<const unsigned long long*>(words)[wi];
+    lo = (unsigned)(wv & 0xFFFFFFFFull);
+    base = (unsigned)(wv >> 32);
+  }
   const int bit = ((cz & 1) << 4) | ((cy & 3) << 2) | (cx & 3);
   const bool occ = live & (((lo >> bit) & 1u) != 0u);
   if (WAVE_SKIP && __ballot(occ) == 0ull) {  // wave-uniform: no lane has a candidate run
@@ -475,7 +499,7 @@ constexpr int kSumGroup = 4;
 // The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
 // with FOUR vector loads per hypothesis instead of scalar loads.
-template <int MODE, int NCW>   // NCW: widest batch (chunks of 64 slots) in weighted mode
+template <int MODE, int NCW, bool SPARSE>   // NCW: widest batch (chunks of 64 slots) in weighted mode
 __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float* __restrict__ Tm,
                                                 const uint2* __restrict__ words,
                                                 const uint2* __restrict__ occ_run,
@@ -549,6 +573,32 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     const uint32_t bx = cell_bits(x, inv_h_v, a.cell_c[0], cell_lo_v, a.cell_hi);
     const uint32_t by = cell_bits(y, inv_h_v, a.cell_c[1], cell_lo_v, a.cell_hi);
     const uint32_t bz = cell_bits(z, inv_h_v, a.cell_c[2], cell_lo_v, a.cell_hi);
+    uint32_t lo, base;
+    if (SPARSE) {
+      // sparse form: the block's entry of the hashed table (grid_index.hip).  A position outside the grid is
+      // clamped to the LARGEST axis only (cell_hi), so its key may be any 31-bit number: whatever block that
+      // names holds candidates far from the position, and the distance test below rejects them.
+      const uint32_t key = (__builtin_amdgcn_ubfe(bx, 2, 12) | (__builtin_amdgcn_ubfe(by, 2, 12) << a.g.key_sy) |
+                            (__builtin_amdgcn_ubfe(bz, 1, 13) << a.g.key_sz)) & 0x7FFFFFFFu;
+      const uint4* tab = reinterpret_cast<const uint4*>(words);
+      // two entries in flight at once: a second DEPENDENT load (the wave waits for its slowest lane) is then
+      // needed by ~1 % of the look-ups instead of ~10 % (table at most one eighth full): 32.7 -> 38.5 M hyp/s at
+      // C2 forced sparse with 4 entries per block, 40.9 M with 8 (tools/sparse_index_time.py)
+      uint32_t i = block_hash(a.g, key);
+      uint4 e = tab[i];
+      const uint4 e1 = tab[(i + 1u) & a.g.tab_mask];
+      if (e.x != key && e.x != kBlockEmpty) {
+        e = e1;
+        ++i;
+        while (e.x != key && e.x != kBlockEmpty) {
+          i = (i + 1u) & a.g.tab_mask;
+          e = tab[i];
+        }
+      }
+      const bool hit = e.x == key;
+      lo = hit ? e.y : 0u;
+      base = e.z;
+    } else {
     const uint32_t brow = mad24(__builtin_amdgcn_ubfe(bz, 1, 9), (uint32_t)a.g.nby, __builtin_amdgcn_ubfe(by, 2, 8));
     const uint32_t wi = min(mad24(brow, (uint32_t)a.g.nbx, __builtin_amdgcn_ubfe(bx, 2, 8)), a.last_word);
 #if defined(PGP_ABLATE) && (PGP_ABLATE == 4 || PGP_ABLATE == 7)
@@ -560,7 +610,9 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
 #else
     const unsigned long long wv = words64[wi];
 #endif
-    const uint32_t lo = (uint32_t)wv, base = (uint32_t)(wv >> 32);
+    lo = (uint32_t)wv;
+    base = (uint32_t)(wv >> 32);
+    }
     const uint32_t bit = (bx & 3u) | ((by & 3u) << 2) | ((bz & 1u) << 4);
     // lanes whose cell holds a candidate run; the second look-up runs for those lanes only
     const bool occ = __builtin_amdgcn_ubfe(lo, bit, 1) != 0u;
@@ -737,7 +789,15 @@ template <int MODE>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat(
     ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
     const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
-  score_flat_body<MODE, 3>(a, Tm, words, occ_run, cand, Pnw);
+  score_flat_body<MODE, 3, false>(a, Tm, words, occ_run, cand, Pnw);
+}
+
+// the same kernel over the sparse block table (grid_index.hip): `words` is the uint4 table
+template <int MODE>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat_sparse(
+    ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
+    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
+  score_flat_body<MODE, 3, true>(a, Tm, words, occ_run, cand, Pnw);
 }
 
 // One model point (Morton position i) under one transform: the scene id it registers to (after
@@ -1343,7 +1403,16 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
   // per-lane walk (U = 2) 125 / 170 us
   // (a scene so far from the origin that its lattice numbers leave the mantissa trick's range takes the
   // per-lane kernel, which finds cells by subtraction and truncation)
-  if (unroll <= 0 && a.g.magic_ok) {  // wave-flattened candidate phase
+  if (unroll <= 0 && a.g.magic_ok && a.g.sparse) {  // wave-flattened candidate phase over the sparse block table
+    if (mode == PGP_MODE_PLAIN)
+      hipExtLaunchKernelGGL(score_hypotheses_flat_sparse<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
+                            a.T, a.words, a.occ_run, a.cand, a.Pnw);
+    else
+      hipExtLaunchKernelGGL(score_hypotheses_flat_sparse<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0,
+                            a, a.T, a.words, a.occ_run, a.cand, a.Pnw);
+    return;
+  }
+  if (unroll <= 0 && a.g.magic_ok) {  // wave-flattened candidate phase (dense block array)
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T,
                             a.words, a.occ_run, a.cand, a.Pnw);
@@ -1387,7 +1456,7 @@ int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
   a->cell_c[2] = 12582912.0f - (float)ctx->grid.k0z;
   a->cell_hi = kMagicBits + std::max(ctx->grid.nx, std::max(ctx->grid.ny, ctx->grid.nz)) - 1;
   a->last_word = (uint32_t)ctx->grid.nbx * (uint32_t)ctx->grid.nby * (uint32_t)ctx->grid.nbz - 1u;
-  a->words = ctx->d_bitmap.as<uint2>();
+  a->words = ctx->grid.sparse ? ctx->d_blocktab.as<uint2>() : ctx->d_bitmap.as<uint2>();
   a->occ_run = ctx->d_occ_start.as<uint2>();
   a->cand = ctx->d_cand.as<float4>();
   a->Pnw = ctx->d_Pnw.as<float4>();
@@ -1607,7 +1676,7 @@ int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream
   }
   if (ctx->nP == 0) return PGP_OK;
   hipLaunchKernelGGL(count_neighbours, dim3((ctx->nP + 255) / 256), dim3(256), 0, stream, ctx->grid,
-                     ctx->d_bitmap.as<uint2>(), ctx->d_occ_start.as<uint2>(), ctx->d_cand.as<float4>(),
+                     ctx->grid.sparse ? ctx->d_blocktab.as<uint2>() : ctx->d_bitmap.as<uint2>(), ctx->d_occ_start.as<uint2>(), ctx->d_cand.as<float4>(),
                      ctx->d_P.as<float4>(), ctx->nP, radius * radius, d_counts);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
@@ -1629,7 +1698,7 @@ int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q,
   }
   ScoreArgs a{};
   a.g = ctx->grid;
-  a.words = ctx->d_bitmap.as<uint2>();
+  a.words = ctx->grid.sparse ? ctx->d_blocktab.as<uint2>() : ctx->d_bitmap.as<uint2>();
   a.occ_run = ctx->d_occ_start.as<uint2>();
   a.cand = ctx->d_cand.as<float4>();
   a.Pnw = ctx->d_Pnw.as<float4>();

@@ -176,7 +176,7 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
-                    &ctx->d_bitmap, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
+                    &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
@@ -1564,8 +1564,11 @@ int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info) {
     info->n_cells = ctx->n_cells;
     info->n_candidates = ctx->n_cand;
     info->n_occupied = ctx->n_occ;
-    info->bytes_index = (long long)((size_t)ctx->grid.nbx * ctx->grid.nby * ctx->grid.nbz * 8 +
-                                    (size_t)ctx->n_occ * 8 + (size_t)ctx->n_cand * 16);
+    const size_t table = ctx->grid.sparse ? ((size_t)ctx->grid.tab_mask + 1) * 16
+                                          : (size_t)ctx->grid.nbx * ctx->grid.nby * ctx->grid.nbz * 8;
+    info->bytes_index = (long long)(table + (size_t)ctx->n_occ * 8 + (size_t)ctx->n_cand * 16);
+    info->sparse = ctx->grid.sparse;
+    info->n_blocks = ctx->grid.sparse ? ctx->n_blocks : (long long)ctx->grid.nbx * ctx->grid.nby * ctx->grid.nbz;
     info->build_ms = ctx->build_ms;
   }
   return PGP_OK;

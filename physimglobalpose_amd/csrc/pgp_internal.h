@@ -38,7 +38,21 @@ struct GridDesc {
   // and neighbouring candidate runs -- the vector L1 counts distinct lines per instruction.
   int nbx, nby, nbz;  // blocks per axis = ceil(nx/4), ceil(ny/4), ceil(nz/2)
   float reach;        // delta + margin: a point is a candidate of every cell within `reach`
+  // SPARSE form (grid_index.hip, scenes whose bounding box is mostly empty): only the blocks that hold a
+  // candidate exist, in an open-addressing table of uint4 {key, occupancy bits, rank base, slot} keyed by
+  // bx | by << key_sy | bz << key_sz (block coordinates); `words` then points at that table.
+  int sparse;
+  int key_sy, key_sz;
+  uint32_t tab_mask;  // table entries - 1 (a power of two)
+  int tab_shift;      // 32 - log2(entries): slot = key * 2654435761 >> tab_shift
 };
+constexpr uint32_t kBlockEmpty = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t block_key(const GridDesc& g, uint32_t bx, uint32_t by, uint32_t bz) {
+  return bx | (by << g.key_sy) | (bz << g.key_sz);
+}
+__host__ __device__ inline uint32_t block_hash(const GridDesc& g, uint32_t key) {
+  return (key * 2654435761u) >> g.tab_shift;
+}
 
 // A growable device buffer (never shrinks; freed with the context).
 struct DevBuf {
@@ -71,7 +85,9 @@ struct pgp_ctx {
   pgp::DevBuf d_cell_start;  // uint32 [n_cells+1]  (build-time scratch: full-grid CSR)
   pgp::DevBuf d_cell_tmp;    // uint32 [n_cells+1]  (counts, then fill cursors)
   pgp::DevBuf d_scan_tmp;    // uint32 block sums
-  pgp::DevBuf d_bitmap;      // uint2 {occupancy bits, rank base} [nbz*nby*nbx]
+  pgp::DevBuf d_bitmap;      // uint2 {occupancy bits, rank base} [nbz*nby*nbx]  (sparse: per block slot, build only)
+  pgp::DevBuf d_blocktab;    // sparse form: uint4 {key, bits, base, slot} [tab_mask + 1]
+  long long n_blocks = 0;    // sparse form: blocks that hold a candidate
   pgp::DevBuf d_occ_start;   // uint2 {start, count} per occupied cell [n_occ]
   long long n_occ = 0;
   pgp::DevBuf d_cand;        // float4 {x,y,z,bits(i)} [n_cand]

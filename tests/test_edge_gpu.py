@@ -78,9 +78,11 @@ def test_nonfinite_and_far_transforms_score_zero():
         assert bi == bio
 
 
-def test_large_coordinates_and_large_extent():
-    """Scene far from the origin and wider than 1024 cells per axis (cell size grows above
-    delta): the dilated lists must still contain every inlier -> counts equal the oracle's."""
+@pytest.mark.parametrize("form", ["auto", "dense"])
+def test_large_coordinates_and_large_extent(form, monkeypatch):
+    """Scene far from the origin and wider than 1024 cells per axis.  By default the index takes its sparse
+    form and keeps the 0.85 delta cell; held to the dense block array (PGP_INDEX=dense) the cell grows above
+    delta.  Either way the dilated lists must still contain every inlier -> counts equal the oracle's."""
     rng = np.random.default_rng(4)
     P = rng.uniform(0, 12.0, (20000, 3)).astype(np.float32) + np.float32(40.0)
     Q = P[rng.integers(0, len(P), 500)] + rng.normal(0, 0.002, (500, 3)).astype(np.float32)
@@ -88,10 +90,16 @@ def test_large_coordinates_and_large_extent():
     Qn = synth._unit(rng.standard_normal(Q.shape)).astype(np.float32)
     T = np.stack([I16] + [synth.colmajor16(synth._se3(synth._random_rot(rng, 0.002),
                                                       0.003 * rng.standard_normal(3))) for _ in range(7)])
+    if form == "dense":
+        monkeypatch.setenv("PGP_INDEX", "dense")
     sc = LcpScorer()
     sc.init(P, Pn, None, Q, Qn, 0.005)
     info = sc.index_info()
-    assert info["cell_size"] > 0.0055 and max(info["grid_nx"], info["grid_ny"], info["grid_nz"]) <= 1024
+    if form == "dense":
+        assert info["sparse"] == 0 and info["cell_size"] > 0.0055
+        assert max(info["grid_nx"], info["grid_ny"], info["grid_nz"]) <= 1024
+    else:
+        assert info["sparse"] == 1 and abs(info["cell_size"] - 0.00425) < 1e-6 and info["grid_nx"] > 2800
     orc = Oracle(P, Pn, np.ones(len(P), np.float32), Q, Qn)
     s, c, bi, _ = sc.score(T)
     so, bio, _ = orc.score_batch(T, 0.005, mode=0)
