@@ -76,6 +76,9 @@ int pgp_weights_from_image(const float* P_xyz, int n, const float centroid_P[3],
  * 327-340): uploads the (centred) scene cloud and builds the device spatial index for inlier
  * radius `delta` (options_.delta, S4/super4pcs_test.cc:20).  nrm and weight may be NULL
  * (weights default to 1; PGP_MODE_WEIGHTED then needs normals and fails without them).
+ * The index is a uniform grid of cell 0.85 delta with dilated candidate lists; its block table is a dense array
+ * for scenes within 1024 cells per axis and 2^26 cells, a hashed table of the occupied blocks beyond (up to
+ * 16 384 cells per axis at that cell size; pgp_index_info.sparse says which).  Answers are identical.
  * Host pointers, synchronous. */
 int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float* weight, int n,
                   float delta);
