@@ -496,6 +496,17 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
 // would halve that again, but their 8 KB push the workgroup past 20 KB of LDS = 7 workgroups per CU.)
 constexpr int kSumGroup = 4;
 
+// Build knobs of the flat kernel (A/B through `make variant`, tools/ab_step.sh):
+//   PGP_SHORTRUN  longest run a wave's owner lanes test by themselves (0: every trip takes the flat path)
+//   PGP_PLAIN_NC  widest batch in plain mode, in chunks of 64 slots.  Four chunks used all 64 VGPRs: with the
+//                 short-trip path they spill (plain 84 -> 104 us per step); three leave 60.
+#ifndef PGP_SHORTRUN
+#define PGP_SHORTRUN 1
+#endif
+#ifndef PGP_PLAIN_NC
+#define PGP_PLAIN_NC 3
+#endif
+
 // The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
 // with FOUR vector loads per hypothesis instead of scalar loads.
@@ -627,6 +638,34 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       s = (uint32_t)rv;
       len = (uint32_t)(rv >> 32);
     }
+    uint32_t rlo = kW ? 0xFFFFFFFFu : 0u;
+    // Short trips (round 3, profiles/r03_ab/shortrun.log): when every run of the wave holds at most
+    // PGP_SHORTRUN candidates, each owner lane tests its own -- no slot scan, no owner table, no LDS round
+    // trips.  With 1: weighted 101.7 -> 99.2 us per step, plain 84.5 -> 83.6 (with three-chunk batches, below);
+    // 2: 100.4 / 84.2; 3: 101.8; 4: 109 -- testing N candidates in every owner lane soon costs more than the
+    // trips it takes off the flat path.  (Not in the weighted kernel over the sparse table: it would spill.)
+    constexpr int kShort = (SPARSE && kW) ? 0 : PGP_SHORTRUN;
+    const bool short_trip = kShort > 0 && __ballot(len > (uint32_t)kShort) == 0ull;
+    if (short_trip) {
+      if (occ) {
+        const uint32_t last = s + len - 1u;
+        float4 pc[kShort > 0 ? kShort : 1];
+#pragma unroll
+        for (int k = 0; k < kShort; ++k) pc[k] = cand[min(s + (uint32_t)k, last)];
+        unsigned long long best = ~0ull;
+#pragma unroll
+        for (int k = 0; k < kShort; ++k) {
+          const float d2 = sqdist(x, y, z, pc[k]);
+          if (!kW) {
+            if (d2 <= a.sq_eps) rlo = 1u;
+          } else {
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(pc[k].w);
+            if (d2 <= a.sq_eps && key < best) best = key;
+          }
+        }
+        if (kW) rlo = (uint32_t)best;
+      }
+    } else {
     // slot allocation in the concatenated run of the wave, in LANE order: an inclusive DPP scan of
     // the run lengths (no LDS); the total lands in an SGPR, so everything below branches scalar.
     const uint32_t incl = wave_inclusive_scan(len);
@@ -634,9 +673,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     const uint32_t pre = incl - len;
     PGP_STAMP(t_c);   // run descriptors + scan
     PGP_PHASE(1, t_b, t_c);
-    // result of the candidate phase per owner lane: plain 0 / 1, weighted the scene id of the nearest
+    // result of the candidate phase per owner lane (rlo): plain 0 / 1, weighted the scene id of the nearest
     // candidate within delta (all ones = -1: none)
-    uint32_t rlo = kW ? 0xFFFFFFFFu : 0u;
     if (W <= (uint32_t)kFlatCap) {
       // owners are numbered in lane order = start order: # owning lanes below this one (v_mbcnt)
       const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
@@ -655,10 +693,13 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       // batch width follows what is left instead of always issuing four chunks.
       for (uint32_t w0 = 0; w0 < W;) {
         const uint32_t left = W - w0;
+#if PGP_PLAIN_NC >= 4
         if (!kW && left > 128) {
           flat_batch<MODE, 4>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 256;
-        } else if (kW && NCW >= 3 && left > 128) {
+        } else
+#endif
+        if ((kW || PGP_PLAIN_NC == 3) && NCW >= 3 && left > 128) {
           flat_batch<MODE, 3>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
           w0 += 192;
         } else if (left > 64) {
@@ -679,6 +720,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       // oversized wave-iteration (very dense scene): per-lane walk
       if (!kW) rlo = any_in_run(cand, s, s + len, x, y, z, a.sq_eps) ? 1u : 0u;
       else rlo = (uint32_t)nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
+    }
     }
     PGP_STAMP(t_f);   // results read back
     unsigned long long hm;   // lanes whose model point registers under this hypothesis
