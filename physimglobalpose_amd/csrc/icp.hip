@@ -137,6 +137,13 @@ struct IcpArgs {
   const unsigned char* nn_image; // the LDS image of the index, in HBM: points | start16 | rep16 | mask
   int* ws_pos;                   // [n][n_src] position (in the image's point order) of the last correspondence
   int nn_image_in_lds;           // 1: a workgroup copies the image into LDS; 0: it is read where it lies (L2)
+  // several workgroups per pose (icp_persist_index, few poses): each searches its share of the source points,
+  // the shares meet in HBM once per iteration
+  int wgs_per_pose;              // 1, 2 or 4
+  unsigned long long* x_buf;     // [2][n][n_src] (d2 bits << 32) | position, ping-pong by iteration parity
+  unsigned* x_ctr;               // [n] arrivals of the pose's workgroups (monotone; zeroed before the launch)
+  int slot_budget;               // A/B knob (PGP_ICP_SLOTS): lane slots up to which queries get more lanes; 0 = one pass
+  int dbg_pose;                  // diagnostic builds (PGP_ICP_STAMPS): the pose whose phases are timed (PGP_ICP_DBG_POSE)
 };
 
 __device__ __forceinline__ float row_xf(float a, float b, float c, float t, float x, float y, float z) {
@@ -1151,8 +1158,8 @@ __device__ __forceinline__ float4 nn_src(const IcpArgs& a, const NnLds&, int q_b
 // Needs R >= ceil(n_q / NT).  In: t.pos[q] = previous correspondence (0xFFFF none).
 // Out: t.d2[q], t.pos[q].  Ends with a barrier.
 constexpr int kNnBaseClass = 6;   // <= 127 cost units: one lane
-__device__ __forceinline__ int nn_class_lanes_log2(int c) {
-  const int l = c - kNnBaseClass;
+__device__ __forceinline__ int nn_class_lanes_log2(int c, int base = kNnBaseClass) {
+  const int l = c - base;
   return l < 0 ? 0 : (l > 6 ? 6 : l);
 }
 struct NnSched {
@@ -1160,10 +1167,13 @@ struct NnSched {
   unsigned slot_end[kNnClasses];   // end of the class's lane slots
   unsigned n_slots;
   unsigned wave_sum[16];
+  int base;                        // classes above it get 2^(class - base) lanes (kNnBaseClass, lower when lanes would idle)
 };
+// The caller may hand over a SHARE of the queries: local query j is query first + j * stride, n_q counts the
+// share (t.d2 / t.pos / t.order are indexed by the query itself, so shares of several workgroups interleave).
 template <int NT, int R>
 __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
-                                               NnSched* sch /* LDS */, int tid) {
+                                               NnSched* sch /* LDS */, int tid, int first = 0, int stride = 1) {
   const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
               g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
   static_assert(kNnBins / 2 == 4 * NT, "four counter words per thread");
@@ -1187,9 +1197,9 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   unsigned tag[R];   // key << 16 | rank inside the bin
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int q = r * NT + tid;
+    const int j = r * NT + tid, q = first + j * stride;
     tag[r] = 0;
-    if (q < n_q) {
+    if (j < n_q) {
       const float4 s = nn_src(a, t, q_base, q);
       const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
                   z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
@@ -1237,18 +1247,40 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   }
   __syncthreads();
   if (tid == 0) {   // the lane slots of the classes, dearest first
+    // With few queries (a share of a pose's points, a short cloud) one lane per query leaves most of the
+    // workgroup idle while the wave that holds the dearest class works alone (measured: 35 us of a 40 us search
+    // with 625 queries on 1024 lanes): lower the class from which queries get 2, 4, ... lanes for as long as
+    // everything still fits ONE pass of the workgroup.
+    unsigned members[kNnClasses];   // queries per class (registers: the loops below are unrolled)
+#pragma unroll
+    for (int c = 0; c < kNnClasses; ++c) members[c] = (c == 0 ? (unsigned)n_q : sch->cnt[c - 1]) - sch->cnt[c];
+    auto count_slots = [&](int bs) {
+      unsigned sl = 0;
+#pragma unroll
+      for (int c = 0; c < kNnClasses; ++c) sl += members[c] << nn_class_lanes_log2(c, bs);
+      return sl;
+    };
+    int base = kNnBaseClass;
+    unsigned total = count_slots(base);
+    while (base > 0) {
+      const unsigned wider = count_slots(base - 1);
+      if (wider > (unsigned)(a.slot_budget > 0 ? a.slot_budget : NT)) break;
+      --base;
+      total = wider;
+    }
+    sch->n_slots = total;
+    sch->base = base;
     unsigned slots = 0;
+#pragma unroll
     for (int c = kNnClasses - 1; c >= 0; --c) {
-      const unsigned first = sch->cnt[c], next = c == 0 ? (unsigned)n_q : sch->cnt[c - 1];
-      slots += (next - first) << nn_class_lanes_log2(c);
+      slots += members[c] << nn_class_lanes_log2(c, base);
       sch->slot_end[c] = slots;
     }
-    sch->n_slots = slots;
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int q = r * NT + tid;
-    if (q < n_q) {
+    const int j = r * NT + tid, q = first + j * stride;
+    if (j < n_q) {
       const unsigned key = tag[r] >> 16;
       const unsigned off = (key & 1u) ? (t.bins[key >> 1] >> 16) : (t.bins[key >> 1] & 0xFFFFu);
       t.order[off + (tag[r] & 0xFFFFu)] = (uint16_t)q;
@@ -1257,6 +1289,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   __syncthreads();
   PGP_NN_STAMP(6);
   const unsigned n_slots = sch->n_slots;
+  const int lane_base = sch->base;
   int c = kNnClasses - 1;   // class of the current slot: slots only grow
   // a slot's query and its source point (an L2 read behind an LDS read) are fetched one trip ahead
   int nq = 0, nlg = 0, nsub = 0;
@@ -1264,7 +1297,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   auto fetch = [&](unsigned sl) {
     if (sl < n_slots) {
       while (sl >= sch->slot_end[c]) --c;
-      nlg = nn_class_lanes_log2(c);
+      nlg = nn_class_lanes_log2(c, lane_base);
       const unsigned first = c == kNnClasses - 1 ? 0u : sch->slot_end[c + 1];
       const unsigned rel = sl - first;
       nsub = (int)(rel & ((1u << nlg) - 1u));
@@ -1380,9 +1413,19 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ float s_G_old[16];
   __shared__ NnSched s_sch;
 
-  const int pose = blockIdx.x;
+  // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
+  // searches the source points part, part + P, ...; the shares meet in HBM (x_buf) once per iteration, everything
+  // after the search runs in every workgroup of the pose on the same data -- same bits, same decisions
+  const int P = a.wgs_per_pose;
+  const int pose = (int)blockIdx.x / P, part = (int)blockIdx.x - pose * P;
+  const int n_share = (a.n_src - part + P - 1) / P;
+  __shared__ int s_lost;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* Tg = a.T + 16 * (size_t)pose;
+  if (tid == 0) s_lost = 0;
+#if defined(PGP_ICP_STAMPS)
+  const unsigned long long k_start = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef PGP_ICP_STAMPS
   __shared__ unsigned s_dbg[8];
   if (tid < 8) s_dbg[tid] = 0;
@@ -1403,7 +1446,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 #ifdef PGP_ICP_STAMPS   // diagnostic build only (tools/icp_phases.py): thread 0 of pose 0 times the phases (cycles, summed
   // over the iterations) and reports them in energy[1..5] (poses 1..7 leave their energies alone)
   unsigned long long st_prev = 0, st_acc[6] = {0, 0, 0, 0, 0, 0};
-#define PGP_STAMP(k) do { if (pose == 0 && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
+#define PGP_STAMP(k) do { if (pose == a.dbg_pose && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
     if ((k) > 0) st_acc[k] += now - st_prev; st_prev = now; } } while (0)
 #else
 #define PGP_STAMP(k) do { } while (0)
@@ -1411,7 +1454,42 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   for (;;) {
     PGP_STAMP(0);
     // ---- 1. correspondences ---------------------------------------------------------------------
-    nn_all_queries<kIcpThreads, kPiR>(a, t, s_G, 0, a.n_src, &s_sch, tid);
+    nn_all_queries<kIcpThreads, kPiR>(a, t, s_G, 0, n_share, &s_sch, tid, part, P);
+    if (P > 1) {
+      // publish this share (write-through, agent scope: the partners may sit on other XCDs), meet, read theirs
+      unsigned long long* xb = a.x_buf + ((size_t)(it & 1) * a.n + pose) * a.n_src;
+      for (int q = part + tid * P; q < a.n_src; q += kIcpThreads * P)
+        __hip_atomic_store(&xb[q], ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned long long)t.pos[q],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_s_waitcnt(0);   // the stores have left before the arrival below is counted
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned target = (unsigned)P * (unsigned)(it + 1);
+        // relaxed on both sides: the shares are written through and waited for above and are read with
+        // agent-scope loads below, so no cache has to be written back or invalidated here (an acquire in the
+        // polling loop invalidated the XCD's L2 for every workgroup on it: selection + sums 10.7 -> 13.4 us)
+        __hip_atomic_fetch_add(&a.x_ctr[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // All workgroups of the launch are resident (cooperative launch, one per CU), so the partners arrive;
+        // the clock bound only turns a broken assumption into an error code instead of a hang.
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__hip_atomic_load(&a.x_ctr[pose], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+          __builtin_amdgcn_s_sleep(1);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz
+            s_lost = 1;
+            break;
+          }
+        }
+      }
+      __syncthreads();
+      if (s_lost) break;
+      for (int q = tid; q < a.n_src; q += kIcpThreads) {
+        if (q % P == part) continue;
+        const unsigned long long v = __hip_atomic_load(&xb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t.d2[q] = __uint_as_float((unsigned)(v >> 32));
+        t.pos[q] = (uint16_t)(v & 0xFFFFull);
+      }
+      __syncthreads();
+    }
     PGP_STAMP(1);
 
     // ---- 2. selection threshold: k-th smallest d2 by radix select on the float bits ---------
@@ -1598,14 +1676,28 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     ++it;
     if (!s_continue) break;
   }
+  if (s_lost) {   // a partner never arrived: mark the pose (iterations -1), leave its transform alone
+    if (tid == 0 && a.iters) a.iters[pose] = -1;
+    return;
+  }
+  if (part != 0) return;
   if (tid < 16) Tg[tid] = s_G[tid];
   if (tid == 0) {
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 4
+    // level 4: every pose reports its whole time in the kernel (ticks) instead of its energy
+    if (a.energy) a.energy[pose] = (float)(__builtin_amdgcn_s_memrealtime() - k_start);
+    if (a.iters) a.iters[pose] = it;
+    return;
+#endif
 #ifdef PGP_ICP_STAMPS
-    if (pose == 0 && a.energy && a.n >= 16) {
+    if (pose == a.dbg_pose && a.energy && a.n >= 16) {
       for (int k = 1; k < 6; ++k) a.energy[k] = (float)st_acc[k];
       for (int k = 0; k < 8; ++k) a.energy[8 + k] = (float)s_dbg[k];
     }
-    if (a.energy && (pose == 0 || pose >= 16 || a.n < 16)) a.energy[pose] = (float)s_energy;
+    // poses 16.. report their whole time in the kernel (ticks) instead of their energy: tools/icp_phases.py picks
+    // the slowest of them for a second run
+    if (a.energy && pose >= 16) a.energy[pose] = (float)(__builtin_amdgcn_s_memrealtime() - k_start);
+    else if (a.energy && (pose == a.dbg_pose || a.n < 16)) a.energy[pose] = (float)s_energy;
 #else
     if (a.energy) a.energy[pose] = (float)s_energy;
 #endif
@@ -1847,13 +1939,41 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     }
     const bool il = a.nn_image_in_lds != 0;
     const size_t plds = nn_lds_bytes(a.nn.bytes, n_src, il);
-    if (a.metric == 1) {
-      if (il) hipLaunchKernelGGL((icp_persist_index<1, true>), dim3(n), dim3(kIcpThreads), plds, stream, a);
-      else hipLaunchKernelGGL((icp_persist_index<1, false>), dim3(n), dim3(kIcpThreads), plds, stream, a);
-    } else {
-      if (il) hipLaunchKernelGGL((icp_persist_index<0, true>), dim3(n), dim3(kIcpThreads), plds, stream, a);
-      else hipLaunchKernelGGL((icp_persist_index<0, false>), dim3(n), dim3(kIcpThreads), plds, stream, a);
+    const void* fn = a.metric == 1 ? (il ? reinterpret_cast<const void*>(icp_persist_index<1, true>)
+                                         : reinterpret_cast<const void*>(icp_persist_index<1, false>))
+                                   : (il ? reinterpret_cast<const void*>(icp_persist_index<0, true>)
+                                         : reinterpret_cast<const void*>(icp_persist_index<0, false>));
+    // Few poses: 2 or 4 workgroups per pose share the search (64 poses alone would use 64 of the 256 CUs).  They
+    // meet once per iteration, so all of them must be resident at once: a COOPERATIVE launch (the runtime checks
+    // that the grid fits and keeps such launches from interleaving), one workgroup per CU.  Not while the stream
+    // is being captured (a graph cannot hold the launch) and not with the pointmatcher history.
+    a.wgs_per_pose = 1;
+    if (const char* v = getenv("PGP_ICP_DBG_POSE")) a.dbg_pose = atoi(v);
+    if (const char* v = getenv("PGP_ICP_SLOTS")) a.slot_budget = atoi(v);
+    int want_wgs = n * 4 <= ctx->n_cus ? 4 : (n * 2 <= ctx->n_cus ? 2 : 1);
+    if (const char* v = getenv("PGP_ICP_WGS")) want_wgs = atoi(v) == 4 ? 4 : (atoi(v) == 2 ? 2 : 1);   // A/B knob
+    if (want_wgs > 1 && a.smooth == 0 && n * want_wgs <= ctx->n_cus && n_src >= 64 * want_wgs) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
+      if (cap == hipStreamCaptureStatusNone) a.wgs_per_pose = want_wgs;
     }
+    if (getenv("PGP_ICP_DEBUG")) fprintf(stderr, "icp: n_cus %d want %d -> %d\n", ctx->n_cus, want_wgs, a.wgs_per_pose);
+    if (a.wgs_per_pose > 1) {
+      const size_t xbytes = 2 * need * 8;
+      if ((rc = ctx->d_icp_x.ensure(xbytes + (size_t)n * 4 + 64)) != PGP_OK) return rc;
+      a.x_buf = ctx->d_icp_x.as<unsigned long long>();
+      a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
+      PGP_HIP(hipMemsetAsync(a.x_ctr, 0, (size_t)n * 4, stream));
+      void* params[] = {&a};
+      hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
+      if (getenv("PGP_ICP_DEBUG"))
+        fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
+      if (e == hipSuccess) return PGP_OK;
+      (void)hipGetLastError();   // the grid does not fit as a cooperative launch here: one workgroup per pose
+      a.wgs_per_pose = 1;
+    }
+    void* params[] = {&a};
+    PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), params, plds, stream));
     PGP_HIP(hipGetLastError());
     return PGP_OK;
   }

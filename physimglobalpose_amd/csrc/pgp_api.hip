@@ -147,6 +147,12 @@ int pgp_create(pgp_ctx** out, int device_id) {
   }
   pgp_ctx* ctx = new pgp_ctx();
   ctx->device = device_id;
+  {
+    int cus = 0, coop = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0 &&
+        hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device_id) == hipSuccess && coop)
+      ctx->n_cus = cus;   // 0: no cooperative launches on this device (the clustered ICP then stays off)
+  }
   if (const char* v = getenv("PGP_UNROLL")) ctx->unroll = atoi(v);
   if (const char* v = getenv("PGP_HPB")) ctx->hpb_override = atoi(v);
   if (const char* v = getenv("PGP_REFINE")) ctx->refine_best = atoi(v) != 0;
@@ -178,7 +184,7 @@ int pgp_destroy(pgp_ctx* ctx) {
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
                     &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
-                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
+                    &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_icp_x, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
@@ -1036,6 +1042,14 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  {   // clustered launch (several workgroups per pose): a pose whose workgroups lost each other reports -1
+    const int* it_host = reinterpret_cast<const int*>(pin + off_i);
+    for (int i = 0; i < n; ++i)
+      if (it_host[i] < 0) {
+        set_error("icp: the workgroups of pose %d did not meet (cooperative launch not honoured); set PGP_ICP_WGS=1", i);
+        return PGP_EHIP;
+      }
+  }
   std::memcpy(T, pin + off_T, (size_t)n * 64);
   if (energy) std::memcpy(energy, pin + off_e, (size_t)n * 4);
   if (iters) std::memcpy(iters, pin + off_i, (size_t)n * 4);

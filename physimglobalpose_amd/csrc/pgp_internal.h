@@ -141,6 +141,8 @@ struct pgp_ctx {
 
   // ICP (host API staging + per-pose correspondence workspace)
   pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_tgt_n, d_icp_T, d_icp_out, d_icp_ws, d_icp_grid;
+  pgp::DevBuf d_icp_x;       // clustered ICP: the workgroups' shares of (d2, correspondence), ping-pong + arrival counters
+  int n_cus = 0;             // compute units of the device if it takes cooperative launches, else 0
   bool icp_attr_set = false;   // dynamic-LDS limit of the ICP kernels raised on this device
   // the exact index of the ICP target (icp.hip build_nn_index) stays valid across calls while the caller
   // vouches for the target: token != 0 and the same (pointer, size, token) = the same points

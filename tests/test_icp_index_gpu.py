@@ -162,3 +162,33 @@ def test_resident_index_is_reused_and_never_stale(monkeypatch):
         for ref, args in ((ref1, (S, M, G)), (ref1, (S, M, G)), (ref2, (S2, M2, G2)), (ref3, (S, Me, G)), (ref1, (S, M, G))):
             got = sc.icp_refine_ex(*args, **kw)
             assert all(np.array_equal(x, y) for x, y in zip(ref, got))
+
+
+@pytest.mark.parametrize("form", ["trimmed", "capped", "plane", "all_points"])
+def test_several_workgroups_per_pose_give_the_same_bits(form, monkeypatch):
+    """Few poses: 2 or 4 workgroups share a pose's search and meet once per iteration (icp_persist_index,
+    cooperative launch).  Every workgroup then holds the same distances and correspondences, so transforms,
+    energies and iteration counts equal the one-workgroup run bit for bit -- also when poses stop at different
+    iterations, with 65 poses (two workgroups each) and with a source too short to share."""
+    S, M, N, G = _problem(32, 3000, 1900, 9, rot_deg=7.0, trans=0.008, outliers=0.05)
+    sc = LcpScorer()
+    runs = {}
+    for wgs in ("1", "2", "4"):
+        monkeypatch.setenv("PGP_ICP_WGS", wgs)
+        runs[wgs] = sc.icp_refine_ex(S, M, G, tgt_nrm=N, **FORMS[form])
+    for wgs in ("2", "4"):
+        for x, y, what in zip(runs["1"], runs[wgs], ("T", "energy", "iters")):
+            assert np.array_equal(x, y), (wgs, what)
+    assert len(set(runs["1"][2].tolist())) > 1 or form != "trimmed"      # the poses do not stop together
+    monkeypatch.delenv("PGP_ICP_WGS")
+    if form == "trimmed":
+        G65 = np.concatenate([G] * 8)[:65]
+        auto = sc.icp_refine_ex(S, M, G65, **FORMS[form])                  # 65 poses: two workgroups each by default
+        monkeypatch.setenv("PGP_ICP_WGS", "1")
+        one = sc.icp_refine_ex(S, M, G65, **FORMS[form])
+        short = sc.icp_refine_ex(S[:100], M, G[:2], **FORMS[form])          # 100 points: one workgroup
+        monkeypatch.setenv("PGP_ICP_WGS", "4")
+        short4 = sc.icp_refine_ex(S[:100], M, G[:2], **FORMS[form])
+        for x, y in zip(auto + short, one + short4):
+            assert np.array_equal(x, y)
+        assert np.array_equal(auto[0][:9], runs["1"][0])
