@@ -286,7 +286,7 @@ def other_rows(sc, w, torch, mode_name, d_batches):
                   "pose_iterations_per_s": icp["64"]["pose_iterations_per_s"], "ms_per_call": icp["64"]["ms_per_call"],
                   "algorithmic_GBps": icp["64"]["pose_iterations_per_s"] * (12 * 2500 + 12 * len(w.Q_xyz) + 112) / 1e9,
                   "by_poses": icp,
-                  "search": "exact index of the static target in LDS, one persistent workgroup per pose (csrc/icp.hip)"}
+                  "search": "exact index of the static target in LDS, persistent workgroups: one per pose, 2 or 4 while few poses are in flight (csrc/icp.hip)"}
     # congruent sets on a 1000-pt search model
     w2 = synth.make_workload(4000, 2000, 4, config_id=3, n_search=1000)
     sc.set_search_model(w2.Qs_xyz)

@@ -142,6 +142,8 @@ struct IcpArgs {
   int wgs_per_pose;              // 1, 2 or 4
   unsigned long long* x_buf;     // [2][n][n_src] (d2 bits << 32) | position, ping-pong by iteration parity
   unsigned* x_ctr;               // [n] arrivals of the pose's workgroups (monotone; zeroed before the launch)
+  unsigned* x_ticks;             // [2][n][4] search time of every share, published with it
+  unsigned solo_ticks;           // every share searched faster than this: the pose goes on in ONE workgroup
   int slot_budget;               // A/B knob (PGP_ICP_SLOTS): lane slots up to which queries get more lanes; 0 = one pass
   int dbg_pose;                  // diagnostic builds (PGP_ICP_STAMPS): the pose whose phases are timed (PGP_ICP_DBG_POSE)
 };
@@ -1167,6 +1169,7 @@ struct NnSched {
   unsigned slot_end[kNnClasses];   // end of the class's lane slots
   unsigned n_slots;
   unsigned wave_sum[16];
+  unsigned search_ticks;           // time of the search loop below as thread 0 saw it (100 MHz ticks)
   int base;                        // classes above it get 2^(class - base) lanes (kNnBaseClass, lower when lanes would idle)
 };
 // The caller may hand over a SHARE of the queries: local query j is query first + j * stride, n_q counts the
@@ -1306,6 +1309,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     }
   };
   fetch((unsigned)tid);
+  const unsigned long long search_t0 = __builtin_amdgcn_s_memrealtime();
 #if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS >= 3
   const unsigned long long wv0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1358,6 +1362,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   }
 #endif
   __syncthreads();
+  if (tid == 0) sch->search_ticks = (unsigned)(__builtin_amdgcn_s_memrealtime() - search_t0);
   PGP_NN_STAMP(7);
 #undef PGP_NN_STAMP
 }
@@ -1416,13 +1421,19 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
   // searches the source points part, part + P, ...; the shares meet in HBM (x_buf) once per iteration, everything
   // after the search runs in every workgroup of the pose on the same data -- same bits, same decisions
-  const int P = a.wgs_per_pose;
-  const int pose = (int)blockIdx.x / P, part = (int)blockIdx.x - pose * P;
-  const int n_share = (a.n_src - part + P - 1) / P;
-  __shared__ int s_lost;
+  // Sharing pays while the search is long (poses centimetres off: 60 -> 24 us per iteration); once every share is
+  // searched in ~10 us the meeting (~10 us) costs more than it saves, so the pose goes on in workgroup 0 alone
+  // and the others leave.  The switch follows measured time -- the results do not depend on it.
+  int P = a.wgs_per_pose;
+  // block b = part * n + pose: workgroup 0 of every pose (the one that may finish the pose alone) comes from the
+  // first n blocks, which the dispatcher deals round-robin over the 8 XCDs (b = pose * P + part put all of them
+  // on XCDs 0 and 4: +10 % on a call whose poses soon go solo)
+  const int part = (int)blockIdx.x / a.n, pose = (int)blockIdx.x - part * a.n;
+  int n_share = (a.n_src - part + P - 1) / P;
+  __shared__ int s_lost, s_solo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* Tg = a.T + 16 * (size_t)pose;
-  if (tid == 0) s_lost = 0;
+  if (tid == 0) s_lost = s_solo = 0;
 #if defined(PGP_ICP_STAMPS)
   const unsigned long long k_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -1461,6 +1472,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       for (int q = part + tid * P; q < a.n_src; q += kIcpThreads * P)
         __hip_atomic_store(&xb[q], ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned long long)t.pos[q],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned* xt = a.x_ticks + ((size_t)(it & 1) * a.n + pose) * 4;
+      if (tid == 0) __hip_atomic_store(&xt[part], s_sch.search_ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_s_waitcnt(0);   // the stores have left before the arrival below is counted
       __syncthreads();
       if (tid == 0) {
@@ -1479,9 +1492,14 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
             break;
           }
         }
+        unsigned slowest = 0;
+        for (int k = 0; k < P; ++k)
+          slowest = max(slowest, __hip_atomic_load(&xt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s_solo = slowest < a.solo_ticks ? 1 : 0;   // the same P numbers in every workgroup: the same decision
       }
       __syncthreads();
       if (s_lost) break;
+      if (s_solo && part != 0) return;   // this share is published; workgroup 0 finishes the pose
       for (int q = tid; q < a.n_src; q += kIcpThreads) {
         if (q % P == part) continue;
         const unsigned long long v = __hip_atomic_load(&xb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1489,6 +1507,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
         t.pos[q] = (uint16_t)(v & 0xFFFFull);
       }
       __syncthreads();
+      if (s_solo) {   // from the next iteration on: every query here, nobody to meet
+        P = 1;
+        n_share = a.n_src;
+      }
     }
     PGP_STAMP(1);
 
@@ -1960,9 +1982,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     if (getenv("PGP_ICP_DEBUG")) fprintf(stderr, "icp: n_cus %d want %d -> %d\n", ctx->n_cus, want_wgs, a.wgs_per_pose);
     if (a.wgs_per_pose > 1) {
       const size_t xbytes = 2 * need * 8;
-      if ((rc = ctx->d_icp_x.ensure(xbytes + (size_t)n * 4 + 64)) != PGP_OK) return rc;
+      if ((rc = ctx->d_icp_x.ensure(xbytes + (size_t)n * (4 + 32) + 64)) != PGP_OK) return rc;
       a.x_buf = ctx->d_icp_x.as<unsigned long long>();
       a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
+      a.x_ticks = a.x_ctr + n;
+      a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
+      if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
       PGP_HIP(hipMemsetAsync(a.x_ctr, 0, (size_t)n * 4, stream));
       void* params[] = {&a};
       hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
