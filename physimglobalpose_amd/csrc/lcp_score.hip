@@ -506,9 +506,6 @@ constexpr int kSumGroup = 4;
 #ifndef PGP_PLAIN_NC
 #define PGP_PLAIN_NC 3
 #endif
-#ifndef PGP_QUEUE_NC
-#define PGP_QUEUE_NC 2   // widest batch of the queue kernel (3 spills five registers in weighted mode)
-#endif
 
 // The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
@@ -843,270 +840,6 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
     ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
     const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
   score_flat_body<MODE, 3, true>(a, Tm, words, occ_run, cand, Pnw);
-}
-
-// ---- deferred candidate phase (round 3) -------------------------------------------------------------------------
-// The flat kernel above runs its candidate machinery (slot scan, owner table, batches of 64 slots, result
-// read-back, normal gate) once per (wave, hypothesis) with a neighbour cell -- for a median of 6 candidate slots
-// and 2-3 owner lanes on 64 lanes.  Here a wave only LOOKS UP its 64 model points under each hypothesis of a
-// group of kSumGroup and queues the lanes that found a candidate run {x', y', z', run start | run length,
-// hypothesis, lane} in LDS; the candidate machinery then runs ONCE per group over the queue (the same
-// flat_batch, the owners being queue entries instead of lanes), the gate runs once on the queue entries with a
-// neighbour, and the registered weights are scattered to the (hypothesis, lane) cells the group's reduction reads.
-// Every (hypothesis, model point) sees the same candidates, the same tests and the same tie rule, and the sums
-// are formed from the same cells in the same order: the scores equal the flat kernel's bit for bit.
-template <int MODE, bool SPARSE>
-__device__ __forceinline__ void score_queue_body(const ScoreArgs& a, const float* __restrict__ Tm,
-                                                 const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
-                                                 const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
-  constexpr bool kW = MODE == PGP_MODE_WEIGHTED;
-  __shared__ int s_cnt[kTile / 64][kMaxHpb];
-  __shared__ float s_sum[kTile / 64][kMaxHpb];
-  __shared__ float4 s_ent[kTile / 64][64];                 // queue: {x', y', z', bits(run start)}, later (start - prefix)
-  __shared__ uint2 s_meta[kTile / 64][64];                 // queue: {run length, hypothesis slot << 6 | lane}
-  __shared__ unsigned long long s_res[kTile / 64][64];     // plain: 0/1 ; weighted: min key
-  __shared__ unsigned long long s_marks[kTile / 64][kFlatCap / 64 + 4];
-  __shared__ float s_w[kW ? kTile / 64 : 1][kW ? kSumGroup : 1][64];   // registered weight per (hypothesis, lane); 0 = none
-  __shared__ float4 s_qn[kW ? kTile : 1];
-
-  const int L = blockIdx.x;
-  const int xcd = L & 7, seq = L >> 3;
-  const int chunk = (seq / a.n_tiles) * 8 + xcd;
-  const int tile = seq % a.n_tiles;
-  if (chunk >= a.n_chunks) return;
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int qi = tile * kTile + threadIdx.x;
-  const bool live = qi < a.nQ;
-  const float qnan = __int_as_float(0x7FC00000);
-  float4 q = live ? a.Q[qi] : make_float4(qnan, qnan, qnan, 0.f);
-  if (kW) s_qn[threadIdx.x] = live ? a.Qn[qi] : make_float4(0.f, 0.f, 0.f, 0.f);
-  float4* ent = s_ent[wave];
-  uint2* meta = s_meta[wave];
-  unsigned long long* res = s_res[wave];
-  unsigned long long* marks = s_marks[wave];
-  if (lane < kFlatCap / 64 + 4) marks[lane] = 0ull;
-  if (kW) {
-#pragma unroll
-    for (int k = 0; k < kSumGroup; ++k) s_w[wave][k][lane] = 0.0f;
-  }
-  const unsigned long long le_mask = (2ull << lane) - 1ull;
-  const uint32_t le_lo = (uint32_t)le_mask, le_hi = (uint32_t)(le_mask >> 32);
-  const unsigned long long* words64 = reinterpret_cast<const unsigned long long*>(words);
-  const unsigned long long* run64 = reinterpret_cast<const unsigned long long*>(occ_run);
-  const float inv_h_v = a.g.inv_h;
-  const int cell_lo_v = kMagicBits;
-
-  int h0, h1;
-  chunk_range(a, chunk, &h0, &h1);
-  unsigned long long cnt_pack = 0ull;   // the wave's registered counts of the group, one byte per hypothesis
-  uint32_t wrote = 0u;                  // some weight of the group was parked in s_w
-  uint32_t n_own = 0u;                  // queue length (wave-uniform)
-
-  // the candidate phase over the queue, the gate, the counts; empties the queue
-  auto flush = [&]() {
-    if (n_own == 0u) return;
-    __builtin_amdgcn_wave_barrier();
-    const bool mine = (uint32_t)lane < n_own;
-    const uint2 mt = mine ? meta[lane] : make_uint2(0u, 0u);
-    const uint32_t len = mt.x;
-    const uint32_t incl = wave_inclusive_scan(len);
-    const uint32_t W = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);   // >= 1
-    const uint32_t pre = incl - len;
-    uint32_t rlo = kW ? 0xFFFFFFFFu : 0u;
-    if (W <= (uint32_t)kFlatCap) {
-      if (mine) {
-        float* ew = reinterpret_cast<float*>(&ent[lane]) + 3;
-        *ew = __uint_as_float(__float_as_uint(*ew) - pre);   // slot w of this owner is candidate (start - prefix) + w
-        res[lane] = kW ? ~0ull : 0ull;
-        atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
-      }
-      __builtin_amdgcn_wave_barrier();
-      const uint32_t start_key = mine ? pre : 0xFFFFFFFFu;
-      for (uint32_t w0 = 0; w0 < W;) {
-        const uint32_t left = W - w0;
-#if PGP_QUEUE_NC >= 3
-        if (left > 128) {
-          flat_batch<MODE, 3>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
-          w0 += 192;
-        } else
-#endif
-        if (left > 64) {
-          flat_batch<MODE, 2>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
-          w0 += 128;
-        } else {
-          flat_batch<MODE, 1>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
-          w0 += 64;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      if ((uint32_t)lane < ((W + 63u) >> 6)) marks[lane] = 0ull;
-      if (mine) rlo = reinterpret_cast<const uint32_t*>(res)[2 * lane];
-    } else if (mine) {
-      // oversized queue (very dense scene): every entry walks its own run
-      const float4 e = ent[lane];
-      const uint32_t s0 = __float_as_uint(e.w);
-      if (!kW) rlo = any_in_run(cand, s0, s0 + len, e.x, e.y, e.z, a.sq_eps) ? 1u : 0u;
-      else rlo = (uint32_t)nearest_in_run(cand, s0, s0 + len, e.x, e.y, e.z, a.sq_eps);
-    }
-    const uint32_t tag = mt.y;
-    const uint32_t gs = (tag >> 6) & (uint32_t)(kSumGroup - 1);
-    bool reg;
-    if (!kW) {
-      reg = rlo != 0u;
-    } else {
-      const int nn_id = (int)rlo;
-      reg = false;
-      if (__ballot(nn_id >= 0) != 0ull) {
-        float dot = 2.0f, pw = 0.0f;   // dot = 2 fails the gate
-        if (nn_id >= 0) {
-          const float4 pn = Pnw[nn_id];
-          const float4 qn = s_qn[wave * 64 + (int)(tag & 63u)];
-          const float4* c = reinterpret_cast<const float4*>(Tm + 16u * ((uint32_t)h0 + (tag >> 6)));   // column-major 4x4
-          const float4 c0 = c[0], c1 = c[1], c2 = c[2];
-          const float nx = rot_row(c0.x, c1.x, c2.x, qn.x, qn.y, qn.z);
-          const float ny = rot_row(c0.y, c1.y, c2.y, qn.x, qn.y, qn.z);
-          const float nz = rot_row(c0.z, c1.z, c2.z, qn.x, qn.y, qn.z);
-          dot = __fadd_rn(__fmul_rn(pn.x, nx), __fadd_rn(__fmul_rn(pn.y, ny), __fmul_rn(pn.z, nz)));
-          pw = pn.w;
-        }
-        reg = gate_ok(dot, a.gate_lo, a.gate_hi);
-        if (reg) s_w[wave][gs][tag & 63u] = pw;
-        wrote |= __ballot(reg) != 0ull ? 1u : 0u;
-      }
-    }
-#pragma unroll
-    for (int g = 0; g < kSumGroup; ++g)
-      cnt_pack += (unsigned long long)(uint32_t)__popcll(__ballot(reg && gs == (uint32_t)g)) << (8 * g);
-    n_own = 0u;
-  };
-
-  // one hypothesis (slot hs of the chunk): look the 64 model points up, queue the lanes with a candidate run.
-  // Returns false when the queue cannot take them: the caller empties it and looks up AGAIN (nothing of the
-  // look-up stays live across the candidate phase; a half-full queue is emptied before a look-up anyway).
-  auto lookup = [&](const int hs, const Xf& m) -> bool {
-    const float x = xf_row(m.m00, m.m01, m.m02, m.m03, q.x, q.y, q.z);
-    const float y = xf_row(m.m10, m.m11, m.m12, m.m13, q.x, q.y, q.z);
-    const float z = xf_row(m.m20, m.m21, m.m22, m.m23, q.x, q.y, q.z);
-    const uint32_t bx = cell_bits(x, inv_h_v, a.cell_c[0], cell_lo_v, a.cell_hi);
-    const uint32_t by = cell_bits(y, inv_h_v, a.cell_c[1], cell_lo_v, a.cell_hi);
-    const uint32_t bz = cell_bits(z, inv_h_v, a.cell_c[2], cell_lo_v, a.cell_hi);
-    uint32_t lo, base;
-    if (SPARSE) {
-      const uint32_t key = (__builtin_amdgcn_ubfe(bx, 2, 12) | (__builtin_amdgcn_ubfe(by, 2, 12) << a.g.key_sy) |
-                            (__builtin_amdgcn_ubfe(bz, 1, 13) << a.g.key_sz)) & 0x7FFFFFFFu;
-      const uint4* tab = reinterpret_cast<const uint4*>(words);
-      uint32_t i = block_hash(a.g, key);
-      uint4 e = tab[i];
-      const uint4 e1 = tab[(i + 1u) & a.g.tab_mask];
-      if (e.x != key && e.x != kBlockEmpty) {
-        e = e1;
-        ++i;
-        while (e.x != key && e.x != kBlockEmpty) {
-          i = (i + 1u) & a.g.tab_mask;
-          e = tab[i];
-        }
-      }
-      lo = e.x == key ? e.y : 0u;
-      base = e.z;
-    } else {
-      const uint32_t brow = mad24(__builtin_amdgcn_ubfe(bz, 1, 9), (uint32_t)a.g.nby, __builtin_amdgcn_ubfe(by, 2, 8));
-      const uint32_t wi = min(mad24(brow, (uint32_t)a.g.nbx, __builtin_amdgcn_ubfe(bx, 2, 8)), a.last_word);
-      const unsigned long long wv = words64[wi];
-      lo = (uint32_t)wv;
-      base = (uint32_t)(wv >> 32);
-    }
-    const uint32_t bit = (bx & 3u) | ((by & 3u) << 2) | ((bz & 1u) << 4);
-    const bool occ = __builtin_amdgcn_ubfe(lo, bit, 1) != 0u;
-    const unsigned long long am = __ballot(occ);
-    if (am == 0ull) return true;
-    const uint32_t n_new = (uint32_t)__popcll(am);
-    if (n_own + n_new > 64u) return false;
-    uint32_t s = 0u, len = 0u;
-    if (occ) {
-      const uint32_t k = base + __popc(__builtin_amdgcn_ubfe(lo, 0, bit));
-      const unsigned long long rv = run64[k];  // {start, count}, count >= 1
-      s = (uint32_t)rv;
-      len = (uint32_t)(rv >> 32);
-    }
-    const uint32_t r = n_own + __builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
-    if (occ) {
-      ent[r] = make_float4(x, y, z, __uint_as_float(s));
-      meta[r] = make_uint2(len, ((uint32_t)hs << 6) | (uint32_t)lane);
-    }
-    n_own += n_new;
-    return true;
-  };
-
-  // after the last hypothesis of a group (slots g0s .. g0s + n - 1 of the chunk): lane 16k publishes slot k
-  auto publish = [&](const int g0s, const int n) {
-    int pl = lane;
-    asm volatile("" : "+v"(pl));
-    const int k = pl >> 4;
-    const bool pub = (pl & 15) == 0 && k < n;
-    if (pub) s_cnt[wave][g0s + k] = (int)((cnt_pack >> (8 * k)) & 0xFFull);
-    if (kW) {
-      float t = 0.0f;
-      if (wrote != 0u) {
-        __builtin_amdgcn_wave_barrier();
-        float4* cell = reinterpret_cast<float4*>(&s_w[wave][k][(pl & 15) * 4]);
-        const float4 v0 = *cell;
-        *cell = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the rows are clean for the next group
-        t = __fadd_rn(__fadd_rn(__fadd_rn(v0.x, v0.y), v0.z), v0.w);
-        t = dpp_step<0xB1>(t);   // the same fixed association as the flat kernel's publish
-        t = dpp_step<0x4E>(t);
-        t = dpp_step<0x141>(t);
-        t = dpp_step<0x140>(t);
-        __builtin_amdgcn_wave_barrier();
-      }
-      if (pub) s_sum[wave][g0s + k] = t;
-    }
-    cnt_pack = 0ull;
-    wrote = 0u;
-  };
-
-  const int n_slots = h1 - h0;
-  Xf m_pre = load_xf(Tm, (uint32_t)h0);
-  for (int hs = 0; hs < n_slots; ++hs) {
-    const Xf m = m_pre;
-    m_pre = load_xf(Tm, (uint32_t)(h0 + min(hs + 1, n_slots - 1)));
-    if (n_own >= 32u) flush();
-    if (!lookup(hs, m)) {
-      flush();
-      lookup(hs, m);
-    }
-    if (((hs & (kSumGroup - 1)) == kSumGroup - 1) || hs == n_slots - 1) {
-      flush();
-      publish(hs & ~(kSumGroup - 1), (hs & (kSumGroup - 1)) + 1);
-    }
-  }
-  __syncthreads();
-  const int hh = threadIdx.x;
-  if (hh < h1 - h0) {
-    int c = 0;
-#pragma unroll
-    for (int w = 0; w < kTile / 64; ++w) c += s_cnt[w][hh];
-    float f = 0.f;
-    if (kW) {
-#pragma unroll
-      for (int w = 0; w < kTile / 64; ++w) f += s_sum[w][hh];
-    }
-    a.partial[(size_t)tile * a.n_h + h0 + hh] = make_uint2((uint32_t)c, __float_as_uint(f));
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_queue(
-    ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
-    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
-  score_queue_body<MODE, false>(a, Tm, words, occ_run, cand, Pnw);
-}
-
-template <int MODE>
-__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_queue_sparse(
-    ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
-    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
-  score_queue_body<MODE, true>(a, Tm, words, occ_run, cand, Pnw);
 }
 
 // One model point (Morton position i) under one transform: the scene id it registers to (after
@@ -1712,24 +1445,6 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
   // per-lane walk (U = 2) 125 / 170 us
   // (a scene so far from the origin that its lattice numbers leave the mantissa trick's range takes the
   // per-lane kernel, which finds cells by subtraction and truncation)
-  if (unroll == -1 && a.g.magic_ok) {  // A/B: deferred candidate phase (score_queue_body)
-    if (a.g.sparse) {
-      if (mode == PGP_MODE_PLAIN)
-        hipExtLaunchKernelGGL(score_hypotheses_queue_sparse<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
-                              a.T, a.words, a.occ_run, a.cand, a.Pnw);
-      else
-        hipExtLaunchKernelGGL(score_hypotheses_queue_sparse<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0,
-                              a, a.T, a.words, a.occ_run, a.cand, a.Pnw);
-    } else {
-      if (mode == PGP_MODE_PLAIN)
-        hipExtLaunchKernelGGL(score_hypotheses_queue<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T,
-                              a.words, a.occ_run, a.cand, a.Pnw);
-      else
-        hipExtLaunchKernelGGL(score_hypotheses_queue<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
-                              a.T, a.words, a.occ_run, a.cand, a.Pnw);
-    }
-    return;
-  }
   if (unroll <= 0 && a.g.magic_ok && a.g.sparse) {  // wave-flattened candidate phase over the sparse block table
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat_sparse<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
