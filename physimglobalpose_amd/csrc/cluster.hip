@@ -50,15 +50,22 @@ __global__ __launch_bounds__(256) void cluster_keys(const float* __restrict__ sc
                                                     int* __restrict__ m_out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   bool pass = false;
+  unsigned long long key = 0ull;
   if (i < n) {
     const float s = scores[i];
     pass = s > bar;  // HypothesisSelection.cpp:75
-    // ascending sort of (~score, index) = score descending, index ascending; pruned go last
-    const uint32_t hi = pass ? ~orderable(s) : 0xFFFFFFFFu;
-    keys[i] = ((unsigned long long)hi << 32) | (uint32_t)i;
+    // ascending sort of (~score, index) = score descending, index ascending
+    key = ((unsigned long long)~orderable(s) << 32) | (uint32_t)i;
   }
+  // only the poses above the bar are kept (compacted: the sort then handles m keys, not n); their order in
+  // `keys` is whatever the atomics made it -- the keys are unique, so the sorted list does not depend on it
   const unsigned long long b = __ballot(pass);
-  if ((threadIdx.x & 63) == 0 && b) atomicAdd(m_out, __popcll(b));
+  if (b == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(m_out, __popcll(b));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (pass) keys[base + __popcll(b & ((1ull << lane) - 1ull))] = key;
 }
 
 __device__ __forceinline__ float cof3(const float* a, int i, int j) {
@@ -131,9 +138,14 @@ __device__ __forceinline__ float fold(float e, float sym) {
   return v;
 }
 
-// getPoseError(test = candidate (inverse rotation iv, translation tc), gt = g / tg)
-__device__ __forceinline__ void pose_error(const float* iv, const float* tc, const float* g, const float* tg,
-                                           Sym sym, float* rot_err, float* trans_err) {
+// translation part of getPoseError (:545-547 pow(float, int) promotes to double): independent of the rotations
+__device__ __forceinline__ float pose_trans_error(const float* tc, const float* tg) {
+  const double dx = (double)sub(tg[0], tc[0]), dy = (double)sub(tg[1], tc[1]), dz = (double)sub(tg[2], tc[2]);
+  return (float)__dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+}
+
+// rotation part of getPoseError(test = candidate (inverse rotation iv), gt = g)
+__device__ __forceinline__ float pose_rot_error(const float* iv, const float* g, Sym sym) {
   float d[9];
 #pragma unroll
   for (int i = 0; i < 3; ++i)
@@ -179,10 +191,14 @@ __device__ __forceinline__ void pose_error(const float* iv, const float* tc, con
   const double siny = 2.0 * (double)add(mul(w, z), mul(x, y));
   const double cosy = 1.0 - 2.0 * (double)add(mul(y, y), mul(z, z));
   const float e2 = (float)atan2(siny, cosy);
-  *rot_err = fdiv(add(add(fold(e0, sym.x), fold(e1, sym.y)), fold(e2, sym.z)), 3.0f);
-  // :545-547 pow(float, int) promotes to double
-  const double dx = (double)sub(tg[0], tc[0]), dy = (double)sub(tg[1], tc[1]), dz = (double)sub(tg[2], tc[2]);
-  *trans_err = (float)__dsqrt_rn(__dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz)));
+  return fdiv(add(add(fold(e0, sym.x), fold(e1, sym.y)), fold(e2, sym.z)), 3.0f);
+}
+
+// getPoseError(test = candidate (inverse rotation iv, translation tc), gt = g / tg)
+__device__ __forceinline__ void pose_error(const float* iv, const float* tc, const float* g, const float* tg,
+                                           Sym sym, float* rot_err, float* trans_err) {
+  *rot_err = pose_rot_error(iv, g, sym);
+  *trans_err = pose_trans_error(tc, tg);
 }
 
 __global__ __launch_bounds__(256) void pose_error_pairs(const float* __restrict__ test, const float* __restrict__ gt,
@@ -226,17 +242,24 @@ __global__ __launch_bounds__(256) void cluster_pair_bits(const float* __restrict
   const int nw = (c + 63) >> 6;  // words holding some r < c
   for (int w = wave; w < nw; w += 4) {
     const int r = 64 * w + lane;
+    // The translation test first: it does not involve the rotations, and among scored hypotheses few pairs are
+    // within centimetres of each other -- a wave none of whose 64 pairs passes it skips the quaternion and the
+    // three double-precision inverse trigonometric functions of the rotation error altogether.
     bool hit = false;
     if (r < c) {
-      float g[9], tg[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) g[k] = rot_r[(size_t)k * m + r];
+      float tg[3];
       tg[0] = rot_r[(size_t)9 * m + r];
       tg[1] = rot_r[(size_t)10 * m + r];
       tg[2] = rot_r[(size_t)11 * m + r];
-      float re, te;
-      pose_error(iv, tc, g, tg, sym, &re, &te);
-      hit = re < rot_thresh && te < trans_thresh;  // HypothesisSelection.cpp:99
+      hit = pose_trans_error(tc, tg) < trans_thresh;
+    }
+    if (__ballot(hit) != 0ull) {
+      if (hit) {
+        float g[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) g[k] = rot_r[(size_t)k * m + r];
+        hit = pose_rot_error(iv, g, sym) < rot_thresh;  // HypothesisSelection.cpp:99: both below their thresholds
+      }
     }
     const unsigned long long b = __ballot(hit);
     if (lane == 0) bits[(size_t)c * W + w] = b;
@@ -438,12 +461,18 @@ __global__ __launch_bounds__(kGreedyThreads) void cluster_greedy_small(const uns
       const unsigned long long cannot = __ballot(my_pre >= 0 || c >= m);   // lanes that cannot become representatives
       const unsigned dlo = (unsigned)(diag & 0xFFFFFFFFull), dhi = (unsigned)(diag >> 32);
       unsigned long long kw = 0ull;
+      if (__ballot(((cannot >> lane) & 1ull) == 0ull && (diag & ~cannot) != 0ull) == 0ull) {
+        // no eligible candidate of the tile is adjacent to an eligible earlier one of the same tile (the usual case:
+        // adjacency is sparse): every eligible candidate becomes a representative, no walk
+        kw = ~cannot;
+      } else {
 #pragma unroll
-      for (int j = 0; j < 64; ++j) {
-        const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
-                                      (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
-        const unsigned long long bit = ~cannot & (1ull << j);
-        kw |= (dj & kw) ? 0ull : bit;
+        for (int j = 0; j < 64; ++j) {
+          const unsigned long long dj = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dhi, j) << 32) |
+                                        (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)dlo, j);
+          const unsigned long long bit = ~cannot & (1ull << j);
+          kw |= (dj & kw) ? 0ull : bit;
+        }
       }
       // assignments and representatives from the final kw (bits >= j of diag_j are zero)
       const unsigned long long dk = diag & kw;
@@ -469,6 +498,95 @@ __global__ __launch_bounds__(kGreedyThreads) void cluster_greedy_small(const uns
     if (t + 1 < n_tiles) iteration(t + 1, wB, wA, dB, dA);
   }
   if (tid == 0) *n_rep_out = n_rep_s;
+}
+
+// ---- few clusters: one round per representative ---------------------------------------------------------------
+// With the reference's pruning (scores above half the best) the survivors sit around a handful of poses: 3612
+// survivors in 3 clusters on the configs[2] workload, for which the bit matrix holds 6.5 M pair tests and the walk
+// 57 tiles.  The greedy pass is then cheaper ROUND BY ROUND: the first unassigned candidate in score order is the
+// next representative (every earlier one has joined an earlier representative), every unassigned later candidate is
+// tested against it alone and joins it if within the thresholds -- the lowest-positioned representative it is
+// adjacent to, as the reference's loop over the clusters in creation order finds it (HypothesisSelection.cpp:88-109).
+// One workgroup; a round costs the tests of the unassigned candidates (translation first) + one barrier pair.
+// Stops after `max_rounds` representatives with *done = 0: the caller then runs the bit-matrix pass instead.
+constexpr int kRoundThreads = 1024;
+constexpr int kRoundMaxM = 16 * kRoundThreads;   // one assigned-bit per candidate in a 16-bit mask per thread
+__global__ __launch_bounds__(kRoundThreads) void cluster_rounds(const float* __restrict__ inv_c, const float* __restrict__ rot_r,
+                                                                int m, Sym sym, float rot_thresh, float trans_thresh,
+                                                                const int* __restrict__ idx_sorted, int max_rounds,
+                                                                int* __restrict__ rep_out, int* __restrict__ assign,
+                                                                int* __restrict__ n_rep_out, int* __restrict__ done) {
+  __shared__ int s_left;
+  __shared__ int s_next[3];   // round k reduces into slot k % 3; slot (k + 2) % 3 is re-armed meanwhile
+  const int tid = threadIdx.x;
+  unsigned assigned = 0u;   // bit k: candidate tid + 1024 k has a representative (or does not exist)
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (tid + kRoundThreads * k >= m) assigned |= 1u << k;
+  if (tid < 3) s_next[tid] = 0x7FFFFFFF;
+  __syncthreads();
+  int r = 0, n_rep = 0;
+  for (;;) {
+    // candidate r is the next representative
+    const int rid = idx_sorted[r];
+    if (tid == (r & (kRoundThreads - 1))) {
+      assigned |= 1u << (r / kRoundThreads);
+      rep_out[n_rep] = rid;
+      assign[rid] = rid;
+    }
+    ++n_rep;
+    float g[9], tg[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) g[k] = rot_r[(size_t)k * m + r];
+    tg[0] = rot_r[(size_t)9 * m + r];
+    tg[1] = rot_r[(size_t)10 * m + r];
+    tg[2] = rot_r[(size_t)11 * m + r];
+    int first_left = 0x7FFFFFFF;
+    for (int k = 0; k < 16; ++k) {
+      if ((assigned >> k) & 1u) continue;
+      const int c = tid + kRoundThreads * k;   // c > r: every candidate before r is assigned
+      const float* cp = inv_c + (size_t)kPoseStride * c;
+      const float tc[3] = {cp[9], cp[10], cp[11]};
+      bool hit = pose_trans_error(tc, tg) < trans_thresh;
+      if (hit) {
+        float iv[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) iv[q] = cp[q];
+        hit = pose_rot_error(iv, g, sym) < rot_thresh;
+      }
+      if (hit) {
+        assigned |= 1u << k;
+        assign[idx_sorted[c]] = rid;
+      } else if (c < first_left) {
+        first_left = c;
+      }
+    }
+    // the first candidate nobody has taken yet
+    int* slot = &s_next[n_rep % 3];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) first_left = min(first_left, __shfl_xor(first_left, off, 64));
+    if ((tid & 63) == 0 && first_left != 0x7FFFFFFF) atomicMin(slot, first_left);
+    __syncthreads();
+    r = *slot;
+    // many clusters ahead (eight representatives have taken less than half of the candidates): leave early
+    if (n_rep == 8 && r != 0x7FFFFFFF) {
+      if (tid == 0) s_left = 0;
+      __syncthreads();
+      int left = __popc(~assigned & 0xFFFFu);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) left += __shfl_xor(left, off, 64);
+      if ((tid & 63) == 0) atomicAdd(&s_left, left);
+      __syncthreads();
+      if (s_left > m / 2) n_rep = max_rounds;   // reported as "not done" below
+    }
+    // the slot of the round after next: last read before this barrier, next written after the next one
+    if (tid == 0) s_next[(n_rep + 2) % 3] = 0x7FFFFFFF;
+    if (r == 0x7FFFFFFF || n_rep >= max_rounds) break;
+  }
+  if (tid == 0) {
+    *n_rep_out = n_rep;
+    *done = r == 0x7FFFFFFF ? 1 : 0;
+  }
 }
 
 }  // namespace
@@ -504,19 +622,21 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
   unsigned long long* keys_out = keys_in + n;
   int* d_cnt = reinterpret_cast<int*>(keys_out + n);  // {m, n_rep}
   void* sort_tmp = reinterpret_cast<unsigned char*>(d_cnt) + 256;
-  PGP_HIP(hipMemsetAsync(d_cnt, 0, 2 * sizeof(int), st));
+  PGP_HIP(hipMemsetAsync(d_cnt, 0, 4 * sizeof(int), st));
   PGP_HIP(hipMemsetAsync(d_assign, 0xFF, (size_t)n * sizeof(int), st));
   hipLaunchKernelGGL(cluster_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_scores, n, bar, keys_in, d_cnt);
-  he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)n, 0, 64, st);
-  if (he != hipSuccess) {
-    set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));
-    return PGP_EHIP;
-  }
   int m = 0;
   PGP_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
   *h_m = m;
   if (m == 0) return PGP_OK;
+  // the m survivors only (typically a tenth of the batch: one block sort instead of a dozen merge passes)
+  size_t sort_bytes_m = sort_bytes;
+  he = rocprim::radix_sort_keys(sort_tmp, sort_bytes_m, keys_in, keys_out, (size_t)m, 0, 64, st);
+  if (he != hipSuccess) {
+    set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));
+    return PGP_EHIP;
+  }
   const int W = (m + 63) / 64;
   if ((size_t)W * 8 > 60 * 1024) {  // keep[] lives in LDS
     set_error("pgp_cluster_poses: %d hypotheses pass the score bar; at most %d are supported", m, 60 * 1024 / 8 * 64);
@@ -533,6 +653,24 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
   hipLaunchKernelGGL(cluster_gather, dim3((m + 255) / 256), dim3(256), 0, st, keys_out, d_T, m, inv_c, rot_r,
                      idx_sorted);
   const Sym s = {sym[0], sym[1], sym[2]};
+  // few clusters (the usual outcome of the reference's pruning): one round per representative
+  int max_rounds = 64;
+  if (const char* v = getenv("PGP_CLUSTER_ROUNDS")) max_rounds = atoi(v);   // A/B knob; 0 = bit matrix only
+  if (m <= kRoundMaxM && max_rounds > 0) {
+    hipLaunchKernelGGL(cluster_rounds, dim3(1), dim3(kRoundThreads), 0, st, (const float*)inv_c, (const float*)rot_r, m, s,
+                       prm->rot_thresh_deg, prm->trans_thresh, (const int*)idx_sorted, max_rounds, d_rep, d_assign,
+                       d_cnt + 1, d_cnt + 2);
+    PGP_HIP(hipGetLastError());
+    int res[2] = {0, 0};
+    PGP_HIP(hipMemcpyAsync(res, d_cnt + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+    if (res[1]) {
+      *h_n_rep = res[0];
+      return PGP_OK;
+    }
+    // more clusters than rounds: start over with the bit matrix (it overwrites every assignment made so far)
+    PGP_HIP(hipMemsetAsync(d_assign, 0xFF, (size_t)n * sizeof(int), st));
+  }
   hipLaunchKernelGGL(cluster_pair_bits, dim3(m), dim3(256), 0, st, inv_c, rot_r, m, W, s, prm->rot_thresh_deg,
                      prm->trans_thresh, bits);
   if (m <= kSmallMax)

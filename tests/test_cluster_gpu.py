@@ -126,3 +126,24 @@ def test_scored_hypotheses_end_to_end(sc):
     assert np.array_equal(rep, rep_o) and np.array_equal(assign, assign_o)
     assert rep[0] == bi
     assert len(rep) < int((scores > 0.5 * bs).sum())
+
+
+def test_round_by_round_pass_equals_the_bit_matrix_pass(monkeypatch):
+    """csrc/cluster.hip has two forms of the greedy pass: one round per representative (few clusters: the usual outcome of
+    the reference's pruning, HypothesisSelection.cpp:70-77) and the pair-bit matrix + tile walk (many clusters).  Same
+    representatives in the same order and the same assignment, whatever the number of clusters -- including the hand-over
+    from the first form to the second (more than 64 clusters, or eight representatives that take less than half)."""
+    from physimglobalpose_amd import LcpScorer, PGP_MODE_WEIGHTED, synth
+    w = synth.make_workload(20000, 2000, 6000, config_id=77)
+    sc = LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    s, _, _, bs = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
+    seen = set()
+    for frac, rot, trans in ((0.5, 10.0, 0.02), (0.2, 10.0, 0.02), (0.05, 4.0, 0.01), (0.0, 10.0, 0.02), (0.0, 1.0, 0.002)):
+        monkeypatch.setenv("PGP_CLUSTER_ROUNDS", "0")
+        rep_m, asg_m = sc.cluster_poses(w.T, s, bs, accept_fraction=frac, rot_thresh_deg=rot, trans_thresh=trans)
+        monkeypatch.delenv("PGP_CLUSTER_ROUNDS")
+        rep_r, asg_r = sc.cluster_poses(w.T, s, bs, accept_fraction=frac, rot_thresh_deg=rot, trans_thresh=trans)
+        assert np.array_equal(rep_m, rep_r) and np.array_equal(asg_m, asg_r), (frac, len(rep_m), len(rep_r))
+        seen.add(len(rep_m) > 64)
+    assert seen == {True, False}          # both sides of the hand-over were exercised
