@@ -1310,7 +1310,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   };
   fetch((unsigned)tid);
   const unsigned long long search_t0 = __builtin_amdgcn_s_memrealtime();
-#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS >= 3
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 3
   const unsigned long long wv0 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (unsigned s0 = 0; s0 < n_slots; s0 += NT) {   // uniform trip count: the exchanges below need whole waves
@@ -1352,7 +1352,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
     }
   }
-#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS >= 3
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 3
   if ((tid & 63) == 0 && t.dbg) {   // per-wave time in the search loop: sum over waves, maximum, wave 0's
     const unsigned dtw = (unsigned)(__builtin_amdgcn_s_memrealtime() - wv0);
     atomicAdd(&t.dbg[0], dtw);
@@ -1408,13 +1408,12 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ float s_G[16];
   __shared__ unsigned s_hist[256];
   __shared__ unsigned s_scan[kIcpThreads / 64];
-  __shared__ unsigned s_prefix, s_kleft;
+  __shared__ unsigned s_sel_prefix[2], s_sel_kleft[2];
   __shared__ unsigned s_tie[kPiR * (kIcpThreads / 64)];
   static_assert(kPiR * (kIcpThreads / 64) == 64, "one wave scans the tie counts");
   __shared__ double s_energy, s_energy_old;
   __shared__ int s_continue;
   __shared__ double s_sum[kRedPlane + 1];
-  __shared__ unsigned s_sel_bin, s_sel_acc;
   __shared__ float s_G_old[16];
   __shared__ NnSched s_sch;
 
@@ -1461,6 +1460,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     if ((k) > 0) st_acc[k] += now - st_prev; st_prev = now; } } while (0)
 #else
 #define PGP_STAMP(k) do { } while (0)
+#endif
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 5   // level 5: the parts of phase 3 (sums) in s_dbg[0..3]
+  unsigned long long sub_prev = 0;
+#define PGP_SUB(k) do { if (pose == a.dbg_pose && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
+    if ((k) >= 0) s_dbg[(k) < 0 ? 0 : (k)] += (unsigned)(now - sub_prev); sub_prev = now; } } while (0)
+#else
+#define PGP_SUB(k) do { } while (0)
 #endif
   for (;;) {
     PGP_STAMP(0);
@@ -1517,16 +1523,22 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     // ---- 2. selection threshold: k-th smallest d2 by radix select on the float bits ---------
     unsigned thr_key = 0xFFFFFFFFu, ties_to_take = 0xFFFFFFFFu;  // default: take everything
     if (a.max_corr2 < 0.f && a.k_trim < a.n_src) {
+      // Three barriers per pass: count | scan inside the waves | pick the bin.  The thread that owns the bin
+      // writes the next pass's prefix and rank itself (ping-pong slots: its neighbours still read this pass's),
+      // and every bin is zeroed by its owner on the way out.  (Five barriers per pass before: 20 -> 13 per
+      // iteration; same arithmetic, same result.)
       if (tid == 0) {
-        s_prefix = 0;
-        s_kleft = (unsigned)a.k_trim;
+        s_sel_prefix[0] = 0;
+        s_sel_kleft[0] = (unsigned)a.k_trim;
       }
+      if (tid < 256) s_hist[tid] = 0;
+      __syncthreads();
       for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        if (tid < 256) s_hist[tid] = 0;
-        __syncthreads();
-        const unsigned prefix = s_prefix;
+        const unsigned prefix = s_sel_prefix[pass & 1], kleft = s_sel_kleft[pass & 1];
         const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        // (counting up to four bins per wave with one atomic each -- the keys of a pass share few bins -- was
+        //  slower: select 7.3 -> 10.2 us; same-address LDS atomics are not the cost here)
         for (int i = tid; i < a.n_src; i += kIcpThreads) {
           const unsigned key = __float_as_uint(t.d2[i]);
           if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
@@ -1543,35 +1555,29 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
           }
           if (lane == 63) s_scan[wave] = incl;
         }
-        if (tid == 0) {
-          s_sel_bin = 255u;
-          s_sel_acc = 0xFFFFFFFFu;
-        }
         __syncthreads();
         if (tid < 256) {
           unsigned woff = 0;
           for (int w = 0; w < wave; ++w) woff += s_scan[w];
           incl += woff;
-          const unsigned excl = incl - hv, kleft = s_kleft;
-          if (excl < kleft && kleft <= incl) {
-            s_sel_bin = (unsigned)tid;
-            s_sel_acc = excl;
+          const unsigned excl = incl - hv;
+          if (excl < kleft && kleft <= incl) {          // the bin that holds the kleft-th key: exactly one thread
+            s_sel_kleft[(pass + 1) & 1] = kleft - excl;
+            s_sel_prefix[(pass + 1) & 1] = prefix | ((unsigned)tid << shift);
+          } else if (tid == 255 && kleft > incl) {      // fewer keys than the rank asks for (cannot happen: k <= n)
+            s_sel_kleft[(pass + 1) & 1] = kleft - incl;
+            s_sel_prefix[(pass + 1) & 1] = prefix | (255u << shift);
           }
-        }
-        __syncthreads();
-        if (tid == 0) {
-          unsigned acc = s_sel_acc;
-          if (acc == 0xFFFFFFFFu) acc = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3];
-          s_kleft = s_kleft - acc;
-          s_prefix = prefix | (s_sel_bin << shift);
+          s_hist[tid] = 0;
         }
         __syncthreads();
       }
-      thr_key = s_prefix;
-      ties_to_take = s_kleft;
+      thr_key = s_sel_prefix[0];
+      ties_to_take = s_sel_kleft[0];
     }
 
     PGP_STAMP(2);
+    PGP_SUB(-1);
     // ---- 3. f64 sums over the selected pairs (ordered tie handling), fixed-tree reduction ----
     constexpr int kNs = METRIC == 1 ? kRedPlane : 16;   // sums in use
     double acc[kNs];
@@ -1604,6 +1610,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       }
       __syncthreads();
     }
+    PGP_SUB(0);
 #pragma unroll
     for (int r = 0; r < kPiR; ++r) {
       const int i = r * kIcpThreads + tid;
@@ -1658,11 +1665,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
         e_acc += (double)d2;
       }
     }
+    PGP_SUB(1);
 #pragma unroll
     for (int k = 0; k < kNs; ++k)
       acc[k] = wave_sum_f64(acc[k]);
     e_acc = wave_sum_f64(e_acc);
-    __syncthreads();
+    PGP_SUB(2);
+    // (no barrier here: s_red was last read before the previous iteration's closing barriers)
     if (lane == 0) {
 #pragma unroll
       for (int k = 0; k < kRedPlane; ++k) s_red[wave * (kRedPlane + 1) + k] = k < kNs ? acc[k < kNs ? k : 0] : 0.0;
@@ -1676,6 +1685,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       s_sum[tid] = v;
     }
     __syncthreads();
+    PGP_SUB(3);
     PGP_STAMP(3);
     if (tid == 0) {
       const double* red = s_sum;

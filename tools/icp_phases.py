@@ -23,6 +23,8 @@ def report(n, G, iters, dp):
     dbg = e[8:16].astype(np.float64); nq = max(dbg[4], 1)
     if dbg[4] > 0:
         print(f"    per query: rows {dbg[0]/nq:7.1f}  live rows {dbg[1]/nq:7.1f}  points {dbg[2]/nq:7.1f}  lanes {dbg[3]/nq:5.2f}   (queries {nq/ni:.0f} per iteration)")
+    if os.environ.get("ICP_SUMS"):   # level-5 library: the parts of the sums phase
+        print(f"    sums: tie ranking {dbg[0]/100/ni:5.1f}  accumulate {dbg[1]/100/ni:5.1f}  wave sums {dbg[2]/100/ni:5.1f}  barriers + final {dbg[3]/100/ni:5.1f} us per iteration")
     if os.environ.get("ICP_WAVES"):
         print(f"    search loop per wave (sum over iterations, us): mean {dbg[0]/100/16:.1f}  wave0 {dbg[2]/100:.1f}  last wave {dbg[3]/100:.1f}  (max single {dbg[1]/100:.1f})")
     print(f"    nn split: bounds {dbg[5]/100/ni:6.1f}  sort {dbg[6]/100/ni:6.1f}  search {dbg[7]/100/ni:6.1f} us per iteration")
