@@ -120,4 +120,14 @@ models = [w.Q_xyz, w.Q_xyz[:1500]]
 poses = np.stack([w.T_gt, w.T[7]])
 for _ in range(REPS):
     sc.unexplained_segment(w.P_xyz[:3000], models, poses, 0.008)
+# round 3, second half: sparse form of the scene index (forced on the C2 scene), the round-by-round clustering pass
+os.environ["PGP_INDEX"] = "sparse"
+sp = LcpScorer(0)
+sp.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+os.environ.pop("PGP_INDEX")
+for _ in range(REPS):
+    sp.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
+    sp.score(w.T, 0)
+for _ in range(REPS):
+    sc.cluster_poses(w.T, sw, bs)                      # accept_fraction 0.5: few clusters -> cluster_rounds
 print("profile_rows done")
