@@ -60,6 +60,7 @@
 #include <cfloat>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 namespace pgp {
@@ -1849,6 +1850,20 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
   return PGP_OK;
 }
 
+// Clustered launches (several workgroups per pose that meet every iteration) must not interleave with each other on
+// a device: two of them, each half resident, would wait for partners that cannot be scheduled.  The runtime serialises
+// cooperative launches as far as it is documented; this chain makes it certain for every stream of THIS process: each
+// clustered launch waits for the previous one's completion event (no host synchronisation).
+namespace {
+struct CoopChain {
+  std::mutex mu;
+  hipEvent_t last[64] = {};
+};
+CoopChain g_coop;
+thread_local bool t_icp_single = false;   // the calling thread wants one workgroup per pose (retry after a lost meeting)
+}  // namespace
+void icp_force_single_workgroup(bool on) { t_icp_single = on; }
+
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
                unsigned long long tgt_token) {
@@ -1984,6 +1999,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     if (const char* v = getenv("PGP_ICP_SLOTS")) a.slot_budget = atoi(v);
     int want_wgs = n * 4 <= ctx->n_cus ? 4 : (n * 2 <= ctx->n_cus ? 2 : 1);
     if (const char* v = getenv("PGP_ICP_WGS")) want_wgs = atoi(v) == 4 ? 4 : (atoi(v) == 2 ? 2 : 1);   // A/B knob
+    if (t_icp_single) want_wgs = 1;
     if (want_wgs > 1 && a.smooth == 0 && n * want_wgs <= ctx->n_cus && n_src >= 64 * want_wgs) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
@@ -2000,7 +2016,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
       PGP_HIP(hipMemsetAsync(a.x_ctr, 0, (size_t)n * 4, stream));
       void* params[] = {&a};
+      const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+      std::lock_guard<std::mutex> chain(g_coop.mu);
+      if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
+      else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
       hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
+      if (e == hipSuccess) PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
       if (getenv("PGP_ICP_DEBUG"))
         fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
       if (e == hipSuccess) return PGP_OK;

@@ -114,6 +114,11 @@ inline uint32_t spread10(uint32_t v) {
 
 using namespace pgp;
 
+namespace pgp {
+// icp.hip: the calling thread's next launch_icp takes one workgroup per pose (no cooperative launch)
+void icp_force_single_workgroup(bool on);
+}  // namespace pgp
+
 extern "C" {
 
 int pgp_version(void) { return 200; }
@@ -1042,13 +1047,23 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
-  {   // clustered launch (several workgroups per pose): a pose whose workgroups lost each other reports -1
+  {   // clustered launch (several workgroups per pose): a pose whose workgroups lost each other reports -1 and keeps
+      // its transform.  That needs another process spinning on the same GPU; the call then runs again from the
+      // caller's transforms with one workgroup per pose.
     const int* it_host = reinterpret_cast<const int*>(pin + off_i);
-    for (int i = 0; i < n; ++i)
-      if (it_host[i] < 0) {
-        set_error("icp: the workgroups of pose %d did not meet (cooperative launch not honoured); set PGP_ICP_WGS=1", i);
-        return PGP_EHIP;
-      }
+    bool lost = false;
+    for (int i = 0; i < n; ++i) lost = lost || it_host[i] < 0;
+    if (lost) {
+      std::memcpy(pin + off_T, T, (size_t)n * 64);
+      PGP_HIP(hipMemcpyAsync(dev + off_T, pin + off_T, (size_t)n * 64, hipMemcpyHostToDevice, st));
+      icp_force_single_workgroup(true);
+      rc = launch_icp(ctx, reinterpret_cast<const float4*>(dev), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt, d_T, n, opt,
+                      d_energy, d_iters, st, tok);
+      icp_force_single_workgroup(false);
+      if (rc != PGP_OK) return rc;
+      PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
+      PGP_HIP(hipStreamSynchronize(st));
+    }
   }
   std::memcpy(T, pin + off_T, (size_t)n * 64);
   if (energy) std::memcpy(energy, pin + off_e, (size_t)n * 4);
