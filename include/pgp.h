@@ -320,8 +320,9 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * stream every four iterations to test for convergence.  While few poses are in flight (n x 4 or
  * n x 2 <= the device's compute units) that ONE launch is cooperative, with 4 or 2 workgroups per pose
  * sharing the search (not on a stream that is being captured; PGP_ICP_WGS=1 switches it off); should
- * the workgroups of a pose ever fail to meet, its iters entry reads -1 and its transform is unchanged
- * (the host-pointer call returns PGP_EHIP).  Checker paths, same results:
+ * the workgroups of a pose ever fail to meet (another process spinning on the same GPU), its iters entry
+ * reads -1 and its transform is unchanged; the host-pointer call then runs once more with one workgroup
+ * per pose.  Clustered launches of one process never overlap on a device.  Checker paths, same results:
  * PGP_ICP_NN=scan (exhaustive search), PGP_ICP_PERSIST=0 (index, host-driven iterations),
  * PGP_ICP_SPLIT=0/1 (the exhaustive persistent / host-driven kernels). */
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
