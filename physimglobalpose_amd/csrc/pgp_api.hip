@@ -114,11 +114,6 @@ inline uint32_t spread10(uint32_t v) {
 
 using namespace pgp;
 
-namespace pgp {
-// icp.hip: the calling thread's next launch_icp takes one workgroup per pose (no cooperative launch)
-void icp_force_single_workgroup(bool on);
-}  // namespace pgp
-
 extern "C" {
 
 int pgp_version(void) { return 200; }

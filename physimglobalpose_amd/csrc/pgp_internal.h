@@ -236,6 +236,8 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
 int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream_t stream);
 
 // icp.hip
+// the calling thread's next launch_icp takes one workgroup per pose (no cooperative launch): the retry of a lost meeting
+void icp_force_single_workgroup(bool on);
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
                unsigned long long tgt_token = 0);
