@@ -1409,7 +1409,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ float s_G[16];
   __shared__ unsigned s_hist[256];
   __shared__ unsigned s_scan[kIcpThreads / 64];
-  __shared__ unsigned s_sel_prefix[2], s_sel_kleft[2];
+  __shared__ unsigned s_sel_prefix[2], s_sel_kleft[2], s_sel_nties;
   __shared__ unsigned s_tie[kPiR * (kIcpThreads / 64)];
   static_assert(kPiR * (kIcpThreads / 64) == 64, "one wave scans the tie counts");
   __shared__ double s_energy, s_energy_old;
@@ -1565,9 +1565,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
           if (excl < kleft && kleft <= incl) {          // the bin that holds the kleft-th key: exactly one thread
             s_sel_kleft[(pass + 1) & 1] = kleft - excl;
             s_sel_prefix[(pass + 1) & 1] = prefix | ((unsigned)tid << shift);
+            s_sel_nties = hv;                           // after the last pass: the keys EQUAL to the threshold
           } else if (tid == 255 && kleft > incl) {      // fewer keys than the rank asks for (cannot happen: k <= n)
             s_sel_kleft[(pass + 1) & 1] = kleft - incl;
             s_sel_prefix[(pass + 1) & 1] = prefix | (255u << shift);
+            s_sel_nties = 0xFFFFFFFFu;
           }
           s_hist[tid] = 0;
         }
@@ -1588,8 +1590,12 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     // ties at the threshold are taken in index order (as icp_refine does, there with an ordered scan per
     // sweep of the cloud): one ballot per sweep, the per-(sweep, wave) counts scanned once by wave 0
     const bool ranked = a.max_corr2 < 0.f && thr_key != 0xFFFFFFFFu;
+    // the usual case: every key equal to the threshold is taken (one such key, the k-th itself) -- no ranking
+    const bool all_ties = ranked && ties_to_take >= s_sel_nties;
     unsigned before[kPiR];
-    if (ranked) {
+#pragma unroll
+    for (int r = 0; r < kPiR; ++r) before[r] = 0u;
+    if (ranked && !all_ties) {
 #pragma unroll
       for (int r = 0; r < kPiR; ++r) {
         const int i = r * kIcpThreads + tid;
@@ -1629,7 +1635,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
         sel = i < a.n_src;
       } else {
         const bool tie = i < a.n_src && key == thr_key;
-        sel = i < a.n_src && (key < thr_key || (tie && s_tie[r * (kIcpThreads / 64) + wave] + before[r] < ties_to_take));
+        sel = i < a.n_src && (key < thr_key ||
+                              (tie && (all_ties || s_tie[r * (kIcpThreads / 64) + wave] + before[r] < ties_to_take)));
       }
       const unsigned pm = i < a.n_src ? (unsigned)t.pos[i] : 0xFFFFu;   // 0xFFFF: a non-finite point has no neighbour
       if constexpr (METRIC == 1) {
