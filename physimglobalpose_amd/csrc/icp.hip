@@ -1708,7 +1708,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       bool go = it + 1 < a.max_iter;
       if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;
       if (red[0] < 1.0) go = false;
-      if (converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old)) go = false;
+      // (the TrimmedICP form has none of the extra rules: no call, no spills around it)
+      if ((a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0) &&
+          converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old))
+        go = false;
       s_continue = go ? 1 : 0;
       PGP_STAMP(5);
     }
