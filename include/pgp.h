@@ -168,6 +168,18 @@ int pgp_verify_early_out_device(pgp_ctx* ctx, const float* d_T, int n_h, float* 
  * pgp_settle_records_device does the same for a score vector assembled elsewhere (the slices of several
  * devices), like pgp_settle_best_device. */
 int pgp_set_exact_records(pgp_ctx* ctx, int on);
+
+/* Exact distance ties.  KdTree::doQueryRestrictedClosestIndex accepts a candidate when `sqdist <= cl_dist`
+ * (kdtree.h:424): of several scene points at exactly the same float distance from a query it returns the one its
+ * descent visits last (the query's side of every split plane first, points of a leaf in the order the build left
+ * them).  This library's index breaks such a tie by the lowest scene index instead -- the registered point, hence
+ * the normal gate and the weight of that model point, can then differ from the reference's (about one query in
+ * 10^7 with two neighbours on real clouds; every query near a DUPLICATED scene point).  With on != 0, every later
+ * pgp_set_scene / pgp_set_scene_device also builds the reference's tree on the host (its own splits, partition
+ * and leaf sizes, kdtree.h:522-641; ~5 ms per 50 000 points) and the scoring paths ask it whenever two different
+ * candidates share the minimal distance: scores, registered points and records then follow the reference on ties
+ * as well.  Default off.  Takes effect at the next scene set-up. */
+int pgp_set_exact_ties(pgp_ctx* ctx, int on);
 int pgp_settle_records_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                               void* stream);
 

@@ -107,6 +107,7 @@ SIGNATURES = {
     "pgp_mls_normals_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_int, _i, C.c_void_p]),
     "pgp_set_exact_records": (C.c_int, [C.c_void_p, C.c_int]),
+    "pgp_set_exact_ties": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_set_verify_early_out": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_verify_early_out_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_settle_records_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]),

@@ -241,9 +241,12 @@ __device__ __forceinline__ void cell_run(const GridDesc& g, const uint2* __restr
 
 // Nearest candidate with d2 <= sq_eps; ties -> lowest scene index (the reference's tie rule
 // depends on kd-tree leaf order, kdtree.h:424; ties are measure-zero on real data).
-__device__ __forceinline__ void nn_update(float4 p, float x, float y, float z, float* best, int* bid) {
+__device__ __forceinline__ void nn_update(float4 p, float x, float y, float z, float* best, int* bid, bool* tie) {
   float d2 = sqdist(x, y, z, p);
   int id = __float_as_int(p.w);
+  // two DIFFERENT scene points at the running minimum (a later, smaller distance makes the flag a false alarm:
+  // harmless, the tree is only asked more often than needed)
+  *tie = *tie || (d2 == *best && *bid >= 0 && id != *bid);
   if (d2 < *best || (d2 == *best && (*bid < 0 || id < *bid))) {
     *best = d2;
     *bid = id;
@@ -254,17 +257,19 @@ __device__ __forceinline__ void nn_update(float4 p, float x, float y, float z, f
 // tests (the run is contiguous; indices past the end are clamped to the last element, which is
 // harmless for "exists" and for arg-min with the lowest-index tie rule).
 __device__ __forceinline__ int nearest_in_run(const float4* __restrict__ cand, uint32_t s, uint32_t e,
-                                              float x, float y, float z, float sq_eps) {
+                                              float x, float y, float z, float sq_eps, bool* tied = nullptr) {
   float best = sq_eps;
   int bid = -1;
+  bool tie = false;
   for (uint32_t j = s; j < e; j += 4) {
     uint32_t last = e - 1;
     float4 p0 = cand[j], p1 = cand[min(j + 1, last)], p2 = cand[min(j + 2, last)], p3 = cand[min(j + 3, last)];
-    nn_update(p0, x, y, z, &best, &bid);
-    nn_update(p1, x, y, z, &best, &bid);
-    nn_update(p2, x, y, z, &best, &bid);
-    nn_update(p3, x, y, z, &best, &bid);
+    nn_update(p0, x, y, z, &best, &bid, &tie);
+    nn_update(p1, x, y, z, &best, &bid, &tie);
+    nn_update(p2, x, y, z, &best, &bid, &tie);
+    nn_update(p3, x, y, z, &best, &bid, &tie);
   }
+  if (tied) *tied = tie;
   return bid;
 }
 
@@ -304,7 +309,67 @@ struct ScoreArgs {
   int cell_hi;          // kMagicBits + (cells of the longest axis) - 1
   uint2* partial;       // [n_tiles][n_h] {inlier count, bits of the weight sum (weighted only)}: ONE 8-byte
                         // load per (tile, hypothesis) in finalize_scores
+  // pgp_set_exact_ties: the reference's kd-tree over the scene (kd_ties.hip), asked only when two different
+  // candidates share the minimal distance; null = ties go to the lowest scene index
+  const int4* kd_nodes;
+  const float4* kd_pts;
 };
+
+// KdTree::doQueryRestrictedClosestIndex (kdtree.h:394-459) on the uploaded tree: the same descent (the query's side
+// of a split first, the other side only while its plane is closer than the best so far, strictly), the same
+// inclusive test inside a leaf, so that among equal distances the point the reference visits last is returned.
+__device__ __attribute__((noinline)) int kd_restricted_nn(const int4* __restrict__ nodes, const float4* __restrict__ pts,
+                                                          float x, float y, float z, float sq_eps) {
+  int st_node[64];
+  float st_sq[64];
+  int cl_id = -1;
+  float cl_dist = sq_eps;
+  st_node[0] = 0;
+  st_sq[0] = 0.f;
+  int count = 1;
+  while (count) {
+    const int top = count - 1;
+    const int4 nd = nodes[st_node[top]];
+    if (st_sq[top] < cl_dist) {
+      if (nd.w) {   // leaf {start, size}
+        --count;
+        for (int i = nd.x; i < nd.x + nd.y; ++i) {
+          const float4 p = pts[i];
+          const float d2 = sqdist(x, y, z, p);
+          if (d2 <= cl_dist) {
+            cl_dist = d2;
+            cl_id = __float_as_int(p.w);
+          }
+        }
+      } else {      // inner {bits(split), first child, dim}
+        const float q = nd.z == 0 ? x : (nd.z == 1 ? y : z);
+        const float new_off = __fsub_rn(q, __int_as_float(nd.x));
+        if (new_off < 0.f) {
+          st_node[count] = nd.y;
+          st_node[top] = nd.y + 1;
+        } else {
+          st_node[count] = nd.y + 1;
+          st_node[top] = nd.y;
+        }
+        st_sq[count] = st_sq[top];
+        st_sq[top] = __fmul_rn(new_off, new_off);
+        ++count;
+      }
+    } else {
+      --count;
+    }
+  }
+  return cl_id;
+}
+
+// nearest candidate of a run by the rule in force: lowest scene index on exact ties, or the reference's
+// (kd_restricted_nn) when its tree is there
+__device__ __forceinline__ int nearest_by_rule(const ScoreArgs& a, uint32_t s, uint32_t e, float x, float y, float z) {
+  bool tied = false;
+  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps, &tied);
+  if (tied && a.kd_nodes) id = kd_restricted_nn(a.kd_nodes, a.kd_pts, x, y, z, a.sq_eps);
+  return id;
+}
 
 // Hypothesis range of a chunk.  The last chunks are smaller: workgroups are dispatched in block
 // order, so the batch ends on short workgroups and the idle tail of the launch shrinks.
@@ -361,7 +426,7 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
       if (MODE == PGP_MODE_PLAIN) {
         hit = any_in_run(a.cand, s[u], e[u], x[u], y[u], z[u], a.sq_eps);
       } else {
-        int id = nearest_in_run(a.cand, s[u], e[u], x[u], y[u], z[u], a.sq_eps);
+        int id = nearest_by_rule(a, s[u], e[u], x[u], y[u], z[u]);
         if (id >= 0) {
           float nx = rot_row(m[u].m00, m[u].m01, m[u].m02, qn.x, qn.y, qn.z);
           float ny = rot_row(m[u].m10, m[u].m11, m[u].m12, qn.x, qn.y, qn.z);
@@ -436,11 +501,12 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
 // (marks[w >> 6] bit w & 63) and owners are numbered in start order, so the owner of slot w is
 //   (#owners starting before the chunk) + popcount(marks word of the chunk & bits <= lane) - 1:
 // one uniform LDS read, a ballot and four VALU per chunk -- no per-slot owner table to fill.
-template <int MODE, int NC>
+template <int MODE, int NC, bool TIES = false>
 __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __restrict__ cand,
                                            const float4* ent, unsigned long long* res,
                                            const unsigned long long* marks, uint32_t start_key, uint32_t W,
-                                           uint32_t w0, int lane, uint32_t le_lo, uint32_t le_hi) {
+                                           uint32_t w0, int lane, uint32_t le_lo, uint32_t le_hi,
+                                           uint32_t* tieflag = nullptr) {
   // a lane past the last slot resolves to the LAST owner and repeats its last candidate (valid owner, valid
   // candidate, the SAME cache line); it is masked out of the result: no exec-mask branches in the batch.
   // (Letting those lanes read on past the run saved the clamp and cost 33 % more HBM traffic: a wave-
@@ -483,8 +549,14 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
 #endif
       if (MODE == PGP_MODE_PLAIN) {
         res[o[c]] = 1ull;  // benign race: every writer stores the same value
-      } else {
+      } else if (!TIES) {
         atomicMin(&res[o[c]], ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
+      } else {
+        // pgp_set_exact_ties: the key that was there holds the same distance and another scene point -> the owner
+        // asks the reference's tree (kd_restricted_nn) which of the tied points it returns
+        const unsigned long long old =
+            atomicMin(&res[o[c]], ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
+        if ((uint32_t)(old >> 32) == __float_as_uint(d2) && (uint32_t)old != (uint32_t)__float_as_int(p[c].w)) tieflag[o[c]] = 1u;
       }
     }
   }
@@ -510,7 +582,7 @@ constexpr int kSumGroup = 4;
 // The read-only arrays are separate __restrict__ kernel parameters: inside the by-value struct
 // hipcc could not prove them invariant next to the LDS atomics and fetched the wave-uniform 4x4
 // with FOUR vector loads per hypothesis instead of scalar loads.
-template <int MODE, int NCW, bool SPARSE>   // NCW: widest batch (chunks of 64 slots) in weighted mode
+template <int MODE, int NCW, bool SPARSE, bool TIES = false>   // NCW: widest batch (chunks of 64 slots) in weighted mode
 __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float* __restrict__ Tm,
                                                 const uint2* __restrict__ words,
                                                 const uint2* __restrict__ occ_run,
@@ -526,6 +598,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
   __shared__ unsigned long long s_marks[kTile / 64][kFlatCap / 64 + 4];
   __shared__ float s_w[kW ? kTile / 64 : 1][kW ? kSumGroup : 1][64];   // registered weight per (hypothesis, lane)
   __shared__ float4 s_qn[kW ? kTile : 1];                                 // model normals of the tile
+  __shared__ uint32_t s_tieflag[TIES ? kTile / 64 : 1][TIES ? 64 : 1];    // pgp_set_exact_ties: owners with tied candidates
+  uint32_t* tieflag = s_tieflag[TIES ? (threadIdx.x >> 6) : 0];
 
   const int L = blockIdx.x;
   const int xcd = L & 7, seq = L >> 3;
@@ -682,6 +756,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
         ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
         res[r] = kW ? ~0ull : 0ull;
+        if (TIES) tieflag[r] = 0u;
         atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
       }
       __builtin_amdgcn_wave_barrier();
@@ -695,18 +770,18 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         const uint32_t left = W - w0;
 #if PGP_PLAIN_NC >= 4
         if (!kW && left > 128) {
-          flat_batch<MODE, 4>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
+          flat_batch<MODE, 4, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
           w0 += 256;
         } else
 #endif
         if ((kW || PGP_PLAIN_NC == 3) && NCW >= 3 && left > 128) {
-          flat_batch<MODE, 3>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
+          flat_batch<MODE, 3, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
           w0 += 192;
         } else if (left > 64) {
-          flat_batch<MODE, 2>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
+          flat_batch<MODE, 2, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
           w0 += 128;
         } else {
-          flat_batch<MODE, 1>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi);
+          flat_batch<MODE, 1, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
           w0 += 64;
         }
       }
@@ -716,10 +791,13 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       if ((uint32_t)lane < ((W + 63u) >> 6)) marks[lane] = 0ull;  // clear the bits for the next iteration
       // the low word of the owner's result: plain 0 / 1; weighted the id of the minimum key, -1 if none
       if (occ) rlo = reinterpret_cast<const uint32_t*>(res)[2 * r];
+      if (TIES && kW) {   // tied candidates at the minimum: the reference's tree decides (rare)
+        if (occ && tieflag[r] != 0u) rlo = (uint32_t)kd_restricted_nn(a.kd_nodes, a.kd_pts, x, y, z, a.sq_eps);
+      }
     } else {
       // oversized wave-iteration (very dense scene): per-lane walk
       if (!kW) rlo = any_in_run(cand, s, s + len, x, y, z, a.sq_eps) ? 1u : 0u;
-      else rlo = (uint32_t)nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
+      else rlo = TIES ? (uint32_t)nearest_by_rule(a, s, s + len, x, y, z) : (uint32_t)nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
     }
     }
     PGP_STAMP(t_f);   // results read back
@@ -834,6 +912,14 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
   score_flat_body<MODE, 3, false>(a, Tm, words, occ_run, cand, Pnw);
 }
 
+// pgp_set_exact_ties, weighted mode: the same kernel with the tie flags and the reference's tree for tied candidates
+template <bool SPARSE>
+__global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat_ties(
+    ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
+    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
+  score_flat_body<PGP_MODE_WEIGHTED, 3, SPARSE, true>(a, Tm, words, occ_run, cand, Pnw);
+}
+
 // the same kernel over the sparse block table (grid_index.hip): `words` is the uint4 table
 template <int MODE>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat_sparse(
@@ -853,7 +939,7 @@ __device__ __forceinline__ int point_hit(const ScoreArgs& a, const Xf& m, int i)
   uint32_t s, e;
   cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
   e += s;
-  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+  int id = nearest_by_rule(a, s, e, x, y, z);
   if (MODE == PGP_MODE_WEIGHTED && id >= 0) {
     const float4 qn = a.Qn[i];
     const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
@@ -893,7 +979,7 @@ __global__ __launch_bounds__(256) void registered_model(ScoreArgs a, const float
   uint32_t s, e;
   cell_run(a.g, a.words, a.occ_run, x, y, z, &s, &e, true);
   e += s;
-  int id = nearest_in_run(a.cand, s, e, x, y, z, a.sq_eps);
+  int id = nearest_by_rule(a, s, e, x, y, z);
   if (id >= 0) {
     const float4 qn = q_nrm[i];
     const float nx = rot_row(m.m00, m.m01, m.m02, qn.x, qn.y, qn.z);
@@ -1445,6 +1531,15 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
   // per-lane walk (U = 2) 125 / 170 us
   // (a scene so far from the origin that its lattice numbers leave the mantissa trick's range takes the
   // per-lane kernel, which finds cells by subtraction and truncation)
+  if (unroll <= 0 && a.g.magic_ok && a.kd_nodes && mode == PGP_MODE_WEIGHTED) {   // exact ties (pgp_set_exact_ties)
+    if (a.g.sparse)
+      hipExtLaunchKernelGGL(score_hypotheses_flat_ties<true>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T, a.words,
+                            a.occ_run, a.cand, a.Pnw);
+    else
+      hipExtLaunchKernelGGL(score_hypotheses_flat_ties<false>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T, a.words,
+                            a.occ_run, a.cand, a.Pnw);
+    return;
+  }
   if (unroll <= 0 && a.g.magic_ok && a.g.sparse) {  // wave-flattened candidate phase over the sparse block table
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat_sparse<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
@@ -1500,6 +1595,9 @@ int fill_args(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
   a->last_word = (uint32_t)ctx->grid.nbx * (uint32_t)ctx->grid.nby * (uint32_t)ctx->grid.nbz - 1u;
   a->words = ctx->grid.sparse ? ctx->d_blocktab.as<uint2>() : ctx->d_bitmap.as<uint2>();
   a->occ_run = ctx->d_occ_start.as<uint2>();
+  const bool ties = ctx->exact_ties && ctx->kd_valid;
+  a->kd_nodes = ties ? ctx->d_kd_nodes.as<int4>() : nullptr;
+  a->kd_pts = ties ? ctx->d_kd_pts.as<float4>() : nullptr;
   a->cand = ctx->d_cand.as<float4>();
   a->Pnw = ctx->d_Pnw.as<float4>();
   a->Q = ctx->d_Q.as<float4>();

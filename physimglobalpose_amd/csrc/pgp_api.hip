@@ -182,7 +182,7 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
-                    &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
+                    &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_kd_nodes, &ctx->d_kd_pts, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_icp_x, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
                     &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
@@ -292,6 +292,8 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
   PGP_HIP(hipMemcpyAsync(ctx->d_P.p, hp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipMemcpyAsync(ctx->d_Pnw.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
   PGP_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->kd_valid = false;
+  if (ctx->exact_ties && (rc = build_kd_ties(ctx, xyz, n)) != PGP_OK) return rc;
   return build_index(ctx, xyz, delta);
 }
 
@@ -412,6 +414,17 @@ int pgp_score_lcp_device(pgp_ctx* ctx, const float* d_T, int n_h, int mode, floa
                               static_cast<hipStream_t>(stream));
   note_device_work(ctx, static_cast<hipStream_t>(stream));
   return rc;
+}
+
+int pgp_set_exact_ties(pgp_ctx* ctx, int on) {
+  if (!ctx) {
+    set_error("pgp_set_exact_ties: ctx is NULL");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx);
+  ctx->exact_ties = on != 0;
+  if (!ctx->exact_ties) ctx->kd_valid = false;   // the next pgp_set_scene builds the tree again if asked to
+  return PGP_OK;
 }
 
 int pgp_set_exact_records(pgp_ctx* ctx, int on) {

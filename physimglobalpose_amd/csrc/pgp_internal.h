@@ -175,6 +175,11 @@ struct pgp_ctx {
   int unroll = 0;      // <= 0: wave-flattened candidate phase (default); > 0: per-lane walk
   int hpb_override = 0;
   bool refine_best = true;   // PGP_REFINE=0 switches the exact near-tie re-score off (timing A/B only)
+  bool exact_ties = false;      // pgp_set_exact_ties: exact distance ties go to the scene point the reference's kd-tree returns
+  bool kd_valid = false;        // d_kd_* hold the reference's tree over the current scene (kd_ties.hip)
+  int kd_n_nodes = 0;
+  pgp::DevBuf d_kd_nodes;       // int4 per node: inner {bits(split), first child, dim, 0}, leaf {start, size, 0, 1}
+  pgp::DevBuf d_kd_pts;         // float4 {x, y, z, bits(original index)} in the tree's order
   bool exact_records = false;   // pgp_set_exact_records: weighted scores exact at every running-best decision
   pgp::DevBuf d_rec_ws;         // its workspace: near-record list | count | weights [nQ][kRecordCap]
 
@@ -201,6 +206,8 @@ __host__ __device__ inline uint32_t grid_bit(int x, int y, int z) {
 
 // grid_index.hip
 int build_index(pgp_ctx* ctx, const float* h_xyz, float delta);
+// kd_ties.hip
+int build_kd_ties(pgp_ctx* ctx, const float* h_xyz, int n);
 int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float delta);
 int device_exclusive_scan(const uint32_t* in, uint32_t* out, size_t n, uint32_t* tmp, hipStream_t st);
 

@@ -411,6 +411,12 @@ int set_scene_device(pgp_ctx* ctx, const float* d_xyz, const float* d_nrm, const
   }
   // build_index works on ctx->stream; the packing above ran on `st`
   PGP_HIP(hipStreamSynchronize(st));
+  ctx->kd_valid = false;
+  if (ctx->exact_ties) {   // the reference's tree is built on the host: one copy of the cloud back
+    std::vector<float> h((size_t)3 * N);
+    if (n > 0) PGP_HIP(hipMemcpy(h.data(), d_xyz, (size_t)n * 12, hipMemcpyDeviceToHost));
+    if ((rc = build_kd_ties(ctx, h.data(), n)) != PGP_OK) return rc;
+  }
   return build_index_bbox(ctx, mn, mx, delta);
 }
 

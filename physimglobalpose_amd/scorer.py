@@ -546,6 +546,11 @@ class LcpScorer:
         _lib.check(self._lib.pgp_find_congruent_4pcs(*args, out.ctypes.data_as(_i), int(cap), C.byref(n)))
         return out[: min(n.value, cap)].copy()
 
+    def set_exact_ties(self, on=True):
+        """Exact distance ties go to the scene point the reference's kd-tree returns (pgp_set_exact_ties); call before
+        set_scene / init: the tree is built with the scene."""
+        _lib.check(self._lib.pgp_set_exact_ties(self._h, int(bool(on))))
+
     def set_exact_records(self, on=True):
         """Weighted scoring calls also settle every near-record of the running-best walk exactly
         (pgp_set_exact_records): running_best(scores) is then the reference's list."""
