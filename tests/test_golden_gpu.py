@@ -26,7 +26,8 @@ def test_hip_matches_golden(name):
     assert np.array_equal(s, g["scores"])
     assert bi == int(g["best_plain"]) and np.float32(bs) == g["scores"][bi]
     assert np.array_equal(LcpScorer.running_best(s), g["sel_plain"])
-    ties = name == "duplicates"   # exact distance ties: NN id follows our lowest-index rule
+    ties = name == "duplicates"   # exact distance ties: NN id follows our lowest-index rule by default
+    #                               (test_exact_ties_gpu.py runs this fixture in full under pgp_set_exact_ties)
     for h, T in enumerate(g["T"]):
         hits = g["hits"][h]
         got = sc.registered(T, PGP_MODE_PLAIN)
