@@ -577,16 +577,22 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   ShimState local_state;
   ShimState& st = getenv("PGP_SHIM_NO_CACHE") ? local_state : shim_state();
   const int n_dev = shim_device_count();   // PGP_SHIM_DEVICES: 1 (default) | n | all
+  // PGP_SHIM_EXACT_TIES=1: exact distance ties (duplicated segment points) go to the point the reference's kd-tree
+  // returns (pgp_set_exact_ties: its tree is then built with every scene, +2-3 ms per object)
+  const bool exact_ties = getenv("PGP_SHIM_EXACT_TIES") != nullptr && atoi(getenv("PGP_SHIM_EXACT_TIES")) != 0;
   if (n_dev != 1) {
     // hypotheses sharded over the devices of the node (pgp_multi_*: RCCL all-reduce of the scores);
     // device 0's context of the group also serves the single-device steps
     if (!st.group) SHIM_PGP(pgp_multi_create(&st.group, nullptr, n_dev));
     ctx = pgp_multi_context(st.group, 0);
+    if (exact_ties)
+      for (int d = 0; pgp_multi_context(st.group, d); ++d) SHIM_PGP(pgp_set_exact_ties(pgp_multi_context(st.group, d), 1));
     SHIM_PGP(pgp_multi_set_scene(st.group, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_multi_set_model(st.group, qval.xyz.data(), qval.nrm.data(), qval.n));
   } else {
     if (!st.ctx) SHIM_PGP(pgp_create(&st.ctx, -1));
     ctx = st.ctx;
+    if (exact_ties) SHIM_PGP(pgp_set_exact_ties(ctx, 1));
     SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
   }
