@@ -458,6 +458,35 @@ bool super4pcs_shim_read_png16(const std::string& path, std::vector<unsigned sho
   return true;
 }
 
+// true when two of the n points coincide exactly (as floats: -0 == +0; a NaN point equals nothing)
+static bool has_duplicate_points(const float* xyz, int n) {
+  if (n < 2) return false;
+  size_t cap = 1;
+  while (cap < 2 * (size_t)n) cap <<= 1;
+  std::vector<int> slot(cap, -1);
+  for (int i = 0; i < n; ++i) {
+    const float* p = xyz + 3 * (size_t)i;
+    if (p[0] != p[0] || p[1] != p[1] || p[2] != p[2]) continue;
+    uint32_t b[3];
+    for (int k = 0; k < 3; ++k) {
+      const float v = p[k] == 0.f ? 0.f : p[k];   // -0 -> +0
+      std::memcpy(&b[k], &v, 4);
+    }
+    size_t h = ((size_t)b[0] * 0x9E3779B1u) ^ ((size_t)b[1] * 0x85EBCA77u) ^ ((size_t)b[2] * 0xC2B2AE3Du);
+    h = (h ^ (h >> 15)) & (cap - 1);
+    for (;; h = (h + 1) & (cap - 1)) {
+      const int j = slot[h];
+      if (j < 0) {
+        slot[h] = i;
+        break;
+      }
+      const float* q = xyz + 3 * (size_t)j;
+      if (q[0] == p[0] && q[1] == p[1] && q[2] == p[2]) return true;
+    }
+  }
+  return false;
+}
+
 static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
                        const Super4PCSCloudView& model_search,
                        const std::function<const unsigned short*(int*, int*)>& image,
@@ -577,22 +606,27 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   ShimState local_state;
   ShimState& st = getenv("PGP_SHIM_NO_CACHE") ? local_state : shim_state();
   const int n_dev = shim_device_count();   // PGP_SHIM_DEVICES: 1 (default) | n | all
-  // PGP_SHIM_EXACT_TIES=1: exact distance ties (duplicated segment points) go to the point the reference's kd-tree
-  // returns (pgp_set_exact_ties: its tree is then built with every scene, +2-3 ms per object)
-  const bool exact_ties = getenv("PGP_SHIM_EXACT_TIES") != nullptr && atoi(getenv("PGP_SHIM_EXACT_TIES")) != 0;
+  // Exact distance ties go to the point the reference's kd-tree returns (pgp_set_exact_ties: its tree is then built
+  // with the scene, +2-3 ms) -- by default only for a segment that HOLDS DUPLICATED POINTS, the one case in which
+  // ties are not a one-in-10^7 event (a voxel-gridded or back-projected segment has none: ~10 us to find out).
+  // PGP_SHIM_EXACT_TIES=1 / 0: always / never.
+  bool exact_ties;
+  if (const char* v = getenv("PGP_SHIM_EXACT_TIES")) exact_ties = atoi(v) != 0;
+  else exact_ties = has_duplicate_points(seg.xyz.data(), seg.n);
+  if (getenv("PGP_SHIM_VERBOSE"))
+    std::cerr << "[libsuper4pcs shim] exact ties: " << (exact_ties ? "on" : "off") << std::endl;
   if (n_dev != 1) {
     // hypotheses sharded over the devices of the node (pgp_multi_*: RCCL all-reduce of the scores);
     // device 0's context of the group also serves the single-device steps
     if (!st.group) SHIM_PGP(pgp_multi_create(&st.group, nullptr, n_dev));
     ctx = pgp_multi_context(st.group, 0);
-    if (exact_ties)
-      for (int d = 0; pgp_multi_context(st.group, d); ++d) SHIM_PGP(pgp_set_exact_ties(pgp_multi_context(st.group, d), 1));
+    for (int d = 0; pgp_multi_context(st.group, d); ++d) SHIM_PGP(pgp_set_exact_ties(pgp_multi_context(st.group, d), exact_ties ? 1 : 0));
     SHIM_PGP(pgp_multi_set_scene(st.group, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_multi_set_model(st.group, qval.xyz.data(), qval.nrm.data(), qval.n));
   } else {
     if (!st.ctx) SHIM_PGP(pgp_create(&st.ctx, -1));
     ctx = st.ctx;
-    if (exact_ties) SHIM_PGP(pgp_set_exact_ties(ctx, 1));
+    SHIM_PGP(pgp_set_exact_ties(ctx, exact_ties ? 1 : 0));
     SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
   }

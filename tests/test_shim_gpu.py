@@ -62,3 +62,34 @@ def test_drop_in_symbol_recovers_the_pose(tmp_path, binary):
     assert abs(s_found - score) < 1e-4          # the returned pose really has the returned score
     assert score > 0.6 * s_gt
     assert ang < 10.0 and np.linalg.norm(pose[:3, 3] - G[:3, 3]) < 0.02, (ang, pose[:3, 3] - G[:3, 3], score)
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
+def test_drop_in_takes_the_reference_tie_rule_for_a_segment_with_duplicated_points(tmp_path):
+    """A segment that holds duplicated points makes exact distance ties an every-query event; the drop-in notices
+    (a hash of the coordinates) and switches pgp_set_exact_ties on for that object: same output as forcing it, and a
+    verbose line says so.  A duplicate-free segment keeps the default."""
+    argv, case = make_dropin_case(tmp_path, False)
+    seg, val, search, png, ppf, fx, fy, cx, cy = argv
+    # rewrite the segment with a tenth of its points twice (pcl::io::savePLYFile layout: write_ply)
+    P, w = case["P"], case["w"]
+    rng = np.random.default_rng(5)
+    extra = rng.choice(len(P), len(P) // 10, replace=False)
+    Pd = np.concatenate([P, P[extra]])
+    Nd = np.concatenate([w.P_nrm, synth._unit(rng.standard_normal((len(extra), 3))).astype(np.float32)])
+    seg_dup = os.path.join(str(tmp_path), "segment_dup.ply")
+    write_ply(seg_dup, Pd, Nd, False)
+    base_env = dict(os.environ, PGP_SHIM_SEED="777", PGP_SHIM_VERBOSE="1", SHIM_TEST_REPEAT="1")
+    base_env.pop("PGP_SHIM_EXACT_TIES", None)
+
+    def run(segment, **extra_env):
+        out = subprocess.run([BIN, segment, val, search, png, ppf, str(fx), str(fy), str(cx), str(cy)],
+                             env=dict(base_env, **extra_env), capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return [l for l in out.stdout.splitlines() if not l.startswith("ELAPSED_MS")], out.stderr
+
+    auto, err_auto = run(seg_dup)
+    forced, _ = run(seg_dup, PGP_SHIM_EXACT_TIES="1")
+    assert auto == forced and "exact ties: on" in err_auto
+    _, err_plain = run(seg)
+    assert "exact ties: off" in err_plain
