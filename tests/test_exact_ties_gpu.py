@@ -122,3 +122,26 @@ def test_exact_records_and_device_scene_with_ties(monkeypatch):
     sc.set_scene(P, Pn, Pw, delta)
     s2, _, _, _ = sc.score(T, PGP_MODE_WEIGHTED, 30.0)
     assert np.abs(s2 - so[:len(T)]).max() > 1e-4
+
+
+def test_golden_lattice_ties_from_the_reference_tree():
+    """tests/golden/lattice_ties.npz holds what the REFERENCE's kd-tree (oracle/_ref, built from the reference's own
+    kdtree.h) returned on a 2278-point lattice scene whose queries have 2-, 4- and 8-fold exact ties across leaves:
+    the per-point NN ids, the registered lists and the weighted scores must be reproduced."""
+    g = np.load(os.path.join(GOLD, "lattice_ties.npz"))
+    sc = _exact(g["P"], g["Pn"], g["Pw"], g["Q"], g["Qn"], float(g["delta"]))
+    s, c, bi, bs = sc.score(g["T"], PGP_MODE_PLAIN)
+    assert np.array_equal(c, g["counts"]) and np.array_equal(s, g["scores"])
+    s, c, bi, bs = sc.score(g["T"], PGP_MODE_WEIGHTED, 30.0)
+    assert np.allclose(s, g["wscores"], rtol=0, atol=2e-6)
+    assert np.array_equal(c, np.diff(g["reg_off"]).astype(np.int32))
+    n_diff = 0
+    base = LcpScorer()
+    base.init(g["P"], g["Pn"], g["Pw"], g["Q"], g["Qn"], float(g["delta"]))
+    for h, T in enumerate(g["T"]):
+        hits = g["hits"][h]
+        assert np.array_equal(sc.registered(T, PGP_MODE_PLAIN), hits[hits >= 0]), h
+        reg = g["reg_flat"][g["reg_off"][h]:g["reg_off"][h + 1]]
+        assert np.array_equal(sc.registered(T, PGP_MODE_WEIGHTED, 30.0), reg), h
+        n_diff += int(not np.array_equal(base.registered(T, PGP_MODE_PLAIN), hits[hits >= 0]))
+    assert n_diff >= 5          # the lowest-index rule answers differently on most of these transforms

@@ -95,3 +95,24 @@ def test_rigid_fit_oracle_matches_golden():
     ok = status == 1
     assert np.array_equal(T[ok], g["T"][ok]) and np.array_equal(rms[ok], g["rms"][ok])
     assert np.abs(pose[ok] - g["pose"][ok]).max() < 1e-6
+
+
+def test_kd_oracle_matches_the_lattice_tie_fixture():
+    """tests/golden/lattice_ties.npz (make_ties_golden.py): 2-, 4- and 8-fold exact ties across the leaves of a
+    2278-point lattice scene, answered by the reference's own tree.  The oracle's restatement of the tree (build,
+    partition, descent, kdtree.h:394-459,522-641) must return the same ids, registered lists and sums."""
+    g = load("lattice_ties")
+    orc = Oracle(g["P"], g["Pn"], g["Pw"], g["Q"], g["Qn"], use_kd=True)
+    delta = float(g["delta"])
+    n_tie_sensitive = 0
+    brute = Oracle(g["P"], g["Pn"], g["Pw"], g["Q"], g["Qn"], use_kd=False)
+    for h, T in enumerate(g["T"]):
+        s, cnt, hits = orc.verify(T, delta)
+        assert cnt == g["counts"][h] and np.float32(s) == g["scores"][h]
+        assert np.array_equal(hits, g["hits"][h])
+        ws, reg = orc.weighted_verify(T, delta)
+        assert np.float32(ws) == g["wscores"][h]
+        assert np.array_equal(reg, g["reg_flat"][g["reg_off"][h]:g["reg_off"][h + 1]])
+        _, _, hb = brute.verify(T, delta)
+        n_tie_sensitive += int(not np.array_equal(hb, hits))
+    assert n_tie_sensitive >= 5     # the fixture does exercise the tie rule
