@@ -506,7 +506,7 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
                                            const float4* ent, unsigned long long* res,
                                            const unsigned long long* marks, uint32_t start_key, uint32_t W,
                                            uint32_t w0, int lane, uint32_t le_lo, uint32_t le_hi,
-                                           uint32_t* tieflag = nullptr) {
+                                           unsigned long long* res_hi = nullptr) {
   // a lane past the last slot resolves to the LAST owner and repeats its last candidate (valid owner, valid
   // candidate, the SAME cache line); it is masked out of the result: no exec-mask branches in the batch.
   // (Letting those lanes read on past the run saved the clamp and cost 33 % more HBM traffic: a wave-
@@ -552,11 +552,14 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
       } else if (!TIES) {
         atomicMin(&res[o[c]], ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
       } else {
-        // pgp_set_exact_ties: the key that was there holds the same distance and another scene point -> the owner
-        // asks the reference's tree (kd_restricted_nn) which of the tied points it returns
-        const unsigned long long old =
-            atomicMin(&res[o[c]], ((unsigned long long)__float_as_uint(d2) << 32) | (unsigned)__float_as_int(p[c].w));
-        if ((uint32_t)(old >> 32) == __float_as_uint(d2) && (uint32_t)old != (uint32_t)__float_as_int(p[c].w)) tieflag[o[c]] = 1u;
+        // pgp_set_exact_ties: a second minimum with the scene index complemented keeps the HIGHEST index at the
+        // minimal distance; when it differs from the lowest, two scene points tie and the owner asks the reference's
+        // tree (kd_restricted_nn).  (A returning atomic + a flag store instead of the second minimum costs the same:
+        // weighted step 103 -> 124 us at C2 either way, tools/exact_ties_cost.py.)
+        const unsigned long long dk = (unsigned long long)__float_as_uint(d2) << 32;
+        const unsigned id = (unsigned)__float_as_int(p[c].w);
+        atomicMin(&res[o[c]], dk | id);
+        atomicMin(&res_hi[o[c]], dk | (unsigned)~id);
       }
     }
   }
@@ -598,8 +601,9 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
   __shared__ unsigned long long s_marks[kTile / 64][kFlatCap / 64 + 4];
   __shared__ float s_w[kW ? kTile / 64 : 1][kW ? kSumGroup : 1][64];   // registered weight per (hypothesis, lane)
   __shared__ float4 s_qn[kW ? kTile : 1];                                 // model normals of the tile
-  __shared__ uint32_t s_tieflag[TIES ? kTile / 64 : 1][TIES ? 64 : 1];    // pgp_set_exact_ties: owners with tied candidates
-  uint32_t* tieflag = s_tieflag[TIES ? (threadIdx.x >> 6) : 0];
+  // pgp_set_exact_ties: min key with the scene index complemented (= the highest index at the minimal distance)
+  __shared__ unsigned long long s_res_hi[TIES ? kTile / 64 : 1][TIES ? 64 : 1];
+  unsigned long long* res_hi = s_res_hi[TIES ? (threadIdx.x >> 6) : 0];
 
   const int L = blockIdx.x;
   const int xcd = L & 7, seq = L >> 3;
@@ -756,7 +760,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
         ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
         res[r] = kW ? ~0ull : 0ull;
-        if (TIES) tieflag[r] = 0u;
+        if (TIES) res_hi[r] = ~0ull;
         atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
       }
       __builtin_amdgcn_wave_barrier();
@@ -770,18 +774,18 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         const uint32_t left = W - w0;
 #if PGP_PLAIN_NC >= 4
         if (!kW && left > 128) {
-          flat_batch<MODE, 4, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
+          flat_batch<MODE, 4, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, res_hi);
           w0 += 256;
         } else
 #endif
         if ((kW || PGP_PLAIN_NC == 3) && NCW >= 3 && left > 128) {
-          flat_batch<MODE, 3, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
+          flat_batch<MODE, 3, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, res_hi);
           w0 += 192;
         } else if (left > 64) {
-          flat_batch<MODE, 2, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
+          flat_batch<MODE, 2, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, res_hi);
           w0 += 128;
         } else {
-          flat_batch<MODE, 1, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, tieflag);
+          flat_batch<MODE, 1, TIES>(a, cand, ent, res, marks, start_key, W, w0, lane, le_lo, le_hi, res_hi);
           w0 += 64;
         }
       }
@@ -792,7 +796,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       // the low word of the owner's result: plain 0 / 1; weighted the id of the minimum key, -1 if none
       if (occ) rlo = reinterpret_cast<const uint32_t*>(res)[2 * r];
       if (TIES && kW) {   // tied candidates at the minimum: the reference's tree decides (rare)
-        if (occ && tieflag[r] != 0u) rlo = (uint32_t)kd_restricted_nn(a.kd_nodes, a.kd_pts, x, y, z, a.sq_eps);
+        if (occ && rlo != 0xFFFFFFFFu && reinterpret_cast<const uint32_t*>(res_hi)[2 * r] != ~rlo)
+          rlo = (uint32_t)kd_restricted_nn(a.kd_nodes, a.kd_pts, x, y, z, a.sq_eps);
       }
     } else {
       // oversized wave-iteration (very dense scene): per-lane walk
