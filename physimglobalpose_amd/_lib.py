@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libpgp.so")
+# PGP_LIB: a diagnostic / A-B build of the same library (tools/ab/*.so), never a different implementation
+LIB_PATH = os.environ.get("PGP_LIB") or os.path.join(HERE, "libpgp.so")
 
 PGP_MODE_PLAIN = 0
 PGP_MODE_WEIGHTED = 1

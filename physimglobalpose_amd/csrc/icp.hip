@@ -146,6 +146,15 @@ struct IcpArgs {
   unsigned* x_ticks;             // [2][n][4] search time of every share, published with it
   unsigned solo_ticks;           // every share searched faster than this: the pose goes on in ONE workgroup
   int slot_budget;               // A/B knob (PGP_ICP_SLOTS): lane slots up to which queries get more lanes; 0 = one pass
+  // vicinity graph of the target (nnidx_vic_*): per image position the kVicK nearest other target points and a
+  // radius inside which no unlisted point lies -- resolves a query next to a known candidate without a search
+  const uint4* nn_vic;           // [n_tgt] or nullptr
+  // lost meetings (clustered launch): a workgroup whose partners did not arrive sets *x_lost; the follow-up launch
+  // (run_if = x_lost, one workgroup per pose, starting again from the transforms saved in T_save) repairs the call
+  unsigned* x_lost;              // [1] in the library's own workspace
+  float* T_save;                 // [n][16]: clustered launch: part 0 stores the pose's initial transform here
+  const float* T_in;             // where a pose's initial transform is read (T itself, or T_save in the repair launch)
+  const unsigned* run_if;        // non-null: the whole launch returns at once unless *run_if != 0
   int dbg_pose;                  // diagnostic builds (PGP_ICP_STAMPS): the pose whose phases are timed (PGP_ICP_DBG_POSE)
 };
 

@@ -1055,24 +1055,6 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
-  {   // clustered launch (several workgroups per pose): a pose whose workgroups lost each other reports -1 and keeps
-      // its transform.  That needs another process spinning on the same GPU; the call then runs again from the
-      // caller's transforms with one workgroup per pose.
-    const int* it_host = reinterpret_cast<const int*>(pin + off_i);
-    bool lost = false;
-    for (int i = 0; i < n; ++i) lost = lost || it_host[i] < 0;
-    if (lost) {
-      std::memcpy(pin + off_T, T, (size_t)n * 64);
-      PGP_HIP(hipMemcpyAsync(dev + off_T, pin + off_T, (size_t)n * 64, hipMemcpyHostToDevice, st));
-      icp_force_single_workgroup(true);
-      rc = launch_icp(ctx, reinterpret_cast<const float4*>(dev), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt, d_T, n, opt,
-                      d_energy, d_iters, st, tok);
-      icp_force_single_workgroup(false);
-      if (rc != PGP_OK) return rc;
-      PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
-      PGP_HIP(hipStreamSynchronize(st));
-    }
-  }
   std::memcpy(T, pin + off_T, (size_t)n * 64);
   if (energy) std::memcpy(energy, pin + off_e, (size_t)n * 4);
   if (iters) std::memcpy(iters, pin + off_i, (size_t)n * 4);

@@ -150,6 +150,7 @@ struct pgp_ctx {
   unsigned long long icp_idx_token = 0;
   const void* icp_idx_tgt = nullptr;
   int icp_idx_ntgt = 0, icp_idx_nq = 0;
+  size_t icp_idx_vic_off = 0;   // byte offset of the vicinity graph inside d_icp_grid (0: none)
   alignas(8) unsigned char icp_idx_geom[96] = {0};
   unsigned long long icp_user_token = 0;                    // pgp_icp_target_token: device-pointer calls
   unsigned long long icp_host_token = 0, icp_host_ntoken = 0;   // hash of the last uploaded host target / normals
@@ -243,8 +244,6 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
 int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream_t stream);
 
 // icp.hip
-// the calling thread's next launch_icp takes one workgroup per pose (no cooperative launch): the retry of a lost meeting
-void icp_force_single_workgroup(bool on);
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
                unsigned long long tgt_token = 0);

@@ -27,6 +27,7 @@ def report(n, G, iters, dp):
         print(f"    sums: tie ranking {dbg[0]/100/ni:5.1f}  accumulate {dbg[1]/100/ni:5.1f}  wave sums {dbg[2]/100/ni:5.1f}  barriers + final {dbg[3]/100/ni:5.1f} us per iteration")
     if os.environ.get("ICP_WAVES"):
         print(f"    search loop per wave (sum over iterations, us): mean {dbg[0]/100/16:.1f}  wave0 {dbg[2]/100:.1f}  last wave {dbg[3]/100:.1f}  (max single {dbg[1]/100:.1f})")
+    print(f"    queries left to the row search per iteration: {dbg[3]/ni:.0f}")
     print(f"    nn split: bounds {dbg[5]/100/ni:6.1f}  sort {dbg[6]/100/ni:6.1f}  search {dbg[7]/100/ni:6.1f} us per iteration")
     print(f"poses {n:4d} pose {dp:3d} iterations {ni:3d}: per iteration  nn {us[0]:7.1f}  select {us[1]:7.1f}  sums+reduce {us[2]:7.1f}  solve {us[3]:7.1f}  stop rules {us[4]:7.1f}  us  (total {us.sum():7.1f})")
     whole = e[16:].astype(np.float64) / 100.0
