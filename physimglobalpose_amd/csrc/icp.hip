@@ -971,6 +971,100 @@ __global__ __launch_bounds__(256) void nnidx_pack(NnGeom g, const uint32_t* __re
   }
 }
 
+// ---- the vicinity graph: per target point its kVicK nearest other target points + a clearance radius ---------
+// Why: once a pose is within a few millimetres, a query's nearest neighbour is the previous iteration's
+// correspondence p or a point next to it, and the row search below only CONFIRMS that (its cost, ~1000
+// instructions per query, is the price of exactness).  The triangle inequality confirms it for the price of
+// kVicK + 1 distance tests: let N(p) be the kVicK target points nearest to p and R(p) a lower bound on |p - p'|
+// for every target point p' outside C = {p} u N(p) (the distance to the (kVicK+1)-th nearest, rounded down).
+// With c the best candidate of C under the scan's rule, a = |x - p|, b = |x - c|:  every p' outside C has
+// |x - p'| >= R(p) - a, so  a + b < R(p)  proves that c is the exact answer (no outsider can even tie).  The
+// float test keeps a relative margin of 1e-4 on a and b and 1e-3 on R against the ~3e-7 rounding of the computed
+// squared distances, so a query that passes has the same (d2, lowest original index) as the exhaustive scan.
+// A query that fails goes through the row search as before, with the graph's best candidate as its bound
+// (tighter than the cell representative: fewer rows).  The centre p is the better of the query's previous
+// correspondence and its cell's representative.
+// Record (uint4): seven 16-bit image positions + the upper 16 bits of the float R (truncated = rounded down).
+constexpr int kVicK = 7;
+constexpr int kVicChunk = 1024;       // target points per block of the partial pass
+constexpr int kVicMaxTargets = 16384; // brute-force build: 2.7e8 tests at most
+
+__device__ __forceinline__ void vic_insert(float (&bd)[kVicK + 1], int (&bp)[kVicK + 1], float d2, int pos) {
+  if (d2 < bd[kVicK]) {   // false for NaN; +inf and FLT_MAX never enter (a non-finite point is nobody's neighbour)
+    bd[kVicK] = d2;
+    bp[kVicK] = pos;
+#pragma unroll
+    for (int i = kVicK; i > 0; --i) {
+      const bool sw = bd[i] < bd[i - 1];
+      const float lo = sw ? bd[i] : bd[i - 1], hi = sw ? bd[i - 1] : bd[i];
+      const int plo = sw ? bp[i] : bp[i - 1], phi = sw ? bp[i - 1] : bp[i];
+      bd[i - 1] = lo;
+      bd[i] = hi;
+      bp[i - 1] = plo;
+      bp[i] = phi;
+    }
+  }
+}
+
+// grid (points / 64, chunks): the kVicK + 1 nearest points of one chunk for every point (image order)
+__global__ __launch_bounds__(64) void nnidx_vic_partial(const float4* __restrict__ pts, int n_tgt, float2* __restrict__ part) {
+  __shared__ float4 s_t[kVicChunk];
+  const int c0 = blockIdx.y * kVicChunk, cn = min(kVicChunk, n_tgt - c0);
+  for (int k = threadIdx.x; k < cn; k += 64) s_t[k] = pts[c0 + k];
+  __syncthreads();
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_tgt) return;
+  const float4 me = pts[p];
+  float bd[kVicK + 1];
+  int bp[kVicK + 1];
+#pragma unroll
+  for (int i = 0; i <= kVicK; ++i) {
+    bd[i] = FLT_MAX;
+    bp[i] = p;
+  }
+  for (int k = 0; k < cn; ++k) {
+    const float4 m = s_t[k];
+    const float dx = me.x - m.x, dy = me.y - m.y, dz = me.z - m.z;
+    float d2 = dx * dx + (dy * dy + dz * dz);
+    if (c0 + k == p) d2 = FLT_MAX;   // not its own neighbour
+    vic_insert(bd, bp, d2, c0 + k);
+  }
+  float2* o = part + ((size_t)blockIdx.y * n_tgt + p) * (kVicK + 1);
+#pragma unroll
+  for (int i = 0; i <= kVicK; ++i) o[i] = make_float2(bd[i], __int_as_float(bp[i]));
+}
+
+__global__ __launch_bounds__(64) void nnidx_vic_merge(const float2* __restrict__ part, int n_tgt, int n_chunks,
+                                                      uint4* __restrict__ vic) {
+  const int p = blockIdx.x * 64 + threadIdx.x;
+  if (p >= n_tgt) return;
+  float bd[kVicK + 1];
+  int bp[kVicK + 1];
+#pragma unroll
+  for (int i = 0; i <= kVicK; ++i) {
+    bd[i] = FLT_MAX;
+    bp[i] = p;
+  }
+  for (int c = 0; c < n_chunks; ++c) {
+    const float2* o = part + ((size_t)c * n_tgt + p) * (kVicK + 1);
+#pragma unroll
+    for (int i = 0; i <= kVicK; ++i) {
+      const float2 v = o[i];
+      vic_insert(bd, bp, v.x, __float_as_int(v.y));
+    }
+  }
+  // fewer than kVicK + 1 other (finite) points: everything is listed, nothing lies outside -> R = +inf
+  const float R = bd[kVicK] < FLT_MAX ? __builtin_sqrtf(bd[kVicK]) * 0.999f : __int_as_float(0x7F800000);
+  const unsigned r16 = __float_as_uint(R) >> 16;   // truncation: never above R
+  uint4 rec;
+  rec.x = (unsigned)bp[0] | ((unsigned)bp[1] << 16);
+  rec.y = (unsigned)bp[2] | ((unsigned)bp[3] << 16);
+  rec.z = (unsigned)bp[4] | ((unsigned)bp[5] << 16);
+  rec.w = (unsigned)bp[6] | (r16 << 16);
+  vic[p] = rec;
+}
+static_assert(kVicK == 7, "the record holds seven positions and the radius");
+
 // ---- the exact index: query (all tables in LDS) ----------------------------------------------------
 struct NnLds {
   const float4* pts;
@@ -1025,22 +1119,33 @@ __device__ __forceinline__ NnBox nn_box(const NnGeom& g, float x, float y, float
   return b;
 }
 
-// Phase A for one query: the bound from the representative of its cell and from its previous
-// correspondence; returns the cost class of the search that remains (0 cheapest .. 15 = plain scan).
+// Phase A helpers.  nn_class: the cost class (0 cheapest .. 14) of the row search that starts from the bound d2.
 __device__ __forceinline__ int nn_cost(const NnBox& b) { return (b.y1 - b.y0 + 1) * (b.z1 - b.z0 + 1) * (((b.x1 - b.x0) >> 2) + 3); }
-__device__ __forceinline__ int nn_bound(const NnGeom& g, const NnLds& t, float x, float y, float z, int prev_pos,
-                                        unsigned long long& best, int& bpos, int& cell) {
-  best = kNnNone;
-  bpos = -1;
-  cell = nn_cell_of(g, x, y, z);
-  const int p = t.rep[cell];
-  nn_consider(x, y, z, t.pts[p], p, best, bpos);
-  if (prev_pos >= 0) nn_consider(x, y, z, t.pts[prev_pos], prev_pos, best, bpos);
-  if (bpos < 0) return kNnClasses - 1;   // no bound (a non-finite or astronomically far query): the plain scan
-  const NnBox b = nn_box(g, x, y, z, __uint_as_float((unsigned)(best >> 32)));
+__device__ __forceinline__ int nn_class(const NnGeom& g, float x, float y, float z, float bound_d2) {
+  const NnBox b = nn_box(g, x, y, z, bound_d2);
   const int cost = nn_cost(b);   // rows x (row overhead + cells)
   const int c = 31 - __clz(cost);   // cost >= 3
   return c < kNnClasses - 2 ? c : kNnClasses - 2;
+}
+// The check on the vicinity graph (see nnidx_vic_*): the seven neighbours of the centre p (record rec; best / bpos
+// hold p on entry) are considered; returns true when a + b < R(p): nothing outside {p} u N(p) comes closer than
+// best or ties with it, i.e. best / bpos are the exhaustive scan's answer.
+__device__ __forceinline__ bool nn_vic_check(const NnLds& t, const uint4 rec, float x, float y, float z,
+                                             unsigned long long& best, int& bpos) {
+  const float a2 = __uint_as_float((unsigned)(best >> 32));   // best IS p here: |x - p|^2
+  const int n0 = rec.x & 0xFFFFu, n1 = rec.x >> 16, n2 = rec.y & 0xFFFFu, n3 = rec.y >> 16, n4 = rec.z & 0xFFFFu,
+            n5 = rec.z >> 16, n6 = rec.w & 0xFFFFu;
+  const float4 m0 = t.pts[n0], m1 = t.pts[n1], m2 = t.pts[n2], m3 = t.pts[n3], m4 = t.pts[n4], m5 = t.pts[n5], m6 = t.pts[n6];
+  nn_consider(x, y, z, m0, n0, best, bpos);
+  nn_consider(x, y, z, m1, n1, best, bpos);
+  nn_consider(x, y, z, m2, n2, best, bpos);
+  nn_consider(x, y, z, m3, n3, best, bpos);
+  nn_consider(x, y, z, m4, n4, best, bpos);
+  nn_consider(x, y, z, m5, n5, best, bpos);
+  nn_consider(x, y, z, m6, n6, best, bpos);
+  const float R = __uint_as_float(rec.w & 0xFFFF0000u);
+  const float a = __builtin_sqrtf(a2), b = __builtin_sqrtf(__uint_as_float((unsigned)(best >> 32)));
+  return a * 1.0001f + b * 1.0001f < R;
 }
 
 // Phase B for one query, shared by a group of L lanes (a power of two, consecutive lanes of one wave):
@@ -1180,19 +1285,36 @@ struct NnSched {
   unsigned n_slots;
   unsigned wave_sum[16];
   unsigned search_ticks;           // time of the search loop below as thread 0 saw it (100 MHz ticks)
+  unsigned n_unres;                // queries the vicinity graph did not answer: phase B's population
   int base;                        // classes above it get 2^(class - base) lanes (kNnBaseClass, lower when lanes would idle)
 };
-// The caller may hand over a SHARE of the queries: local query j is query first + j * stride, n_q counts the
-// share (t.d2 / t.pos / t.order are indexed by the query itself, so shares of several workgroups interleave).
+// The caller may hand over a SHARE of the queries (several workgroups per pose): the cloud is dealt in blocks of
+// eight consecutive queries, block k to workgroup k % P -- eight 8-byte meeting records are one 64-byte line, so a
+// line of the meeting buffer is written by ONE workgroup (interleaving single queries made every 8-byte store a
+// partial line: 4.6 x the algorithmic write traffic).  Local query j of part `part` is nn_share_query(j, part, P);
+// t.d2 / t.pos / t.order are indexed by the query itself.
+__host__ __device__ __forceinline__ int nn_share_query(int j, int part, int P) {
+  return P == 1 ? j : (((j >> 3) * P + part) << 3) + (j & 7);
+}
+__host__ __device__ __forceinline__ int nn_share_count(int n, int part, int P) {
+  if (P == 1) return n;
+  const int nb = (n + 7) >> 3;                       // blocks of eight, the last one possibly short
+  if (part >= nb) return 0;
+  const int mine = (nb - part + P - 1) / P;
+  return mine * 8 - ((nb - 1) % P == part ? nb * 8 - n : 0);
+}
+__host__ __device__ __forceinline__ bool nn_share_owns(int q, int part, int P) { return P == 1 || ((q >> 3) % P) == part; }
+
 template <int NT, int R>
 __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
-                                               NnSched* sch /* LDS */, int tid, int first = 0, int stride = 1) {
+                                               NnSched* sch /* LDS */, int tid, int part = 0, int P = 1) {
   const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
               g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
   static_assert(kNnBins / 2 == 4 * NT, "four counter words per thread");
   {   // zero the sort's counters
     uint4* b4 = reinterpret_cast<uint4*>(t.bins);
     b4[tid] = make_uint4(0u, 0u, 0u, 0u);
+    if (tid == 0) sch->n_unres = 0;
   }
   __syncthreads();
 #ifdef PGP_ICP_STAMPS
@@ -1201,34 +1323,98 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
 #else
 #define PGP_NN_STAMP(k) do { } while (0)
 #endif
-  // Sort key = (15 - class) * 512 + strip: dearest class first (the lane groups of phase B need whole classes in
+  // Phase A: every query is bounded -- and, next to a known candidate, ANSWERED -- on the vicinity graph
+  // (nn_vic_check).  The unanswered ones are filed for phase B under
+  // sort key = (15 - class) * 512 + strip: dearest class first (the lane groups of phase B need whole classes in
   // a row), and inside a class the queries of one strip -- a run of neighbouring cells of the index -- side by
   // side: the 64 lanes of a wave then walk the SAME rows of the same points, which LDS serves as broadcasts
   // instead of 64-way gathers (phase B is bound by the LDS gather rate).  One counting-sort pass over 8192
   // 16-bit counters; the order inside a bin is whatever the atomics made it.
   const int strip_shift = a.nn.strip_shift;
-  unsigned tag[R];   // key << 16 | rank inside the bin
+  constexpr unsigned kNoTag = 0xFFFFFFFFu;
+  unsigned tag[R];   // key << 16 | rank inside the bin; kNoTag: not in the sort
+  // Memory round trips are what phase A costs when few queries are on the lanes (a share of a pose): the R source
+  // points of a thread and the graph records of their previous correspondences -- where the check of a nearly
+  // converged pose happens -- are requested at once; a query whose cell representative is the better start
+  // candidate (the first iteration; a correspondence gone stale) requests that record in a second round, again
+  // all R together.  (A walk downhill on the graph before the check -- up to four steps -- was measured: every
+  // step costs ~110 instructions per query and a dependent L2 read, more than the rows it saves: 2.45 vs 2.60 M
+  // pose-iterations/s at 256 poses; one step it is.)
+  const uint4* __restrict__ vic = a.nn_vic;
+  float qx[R], qy[R], qz[R];
+  unsigned long long best[R];
+  int bpos[R];
+  uint4 rec[R];
+  bool live[R];
+  {
+    float4 sp[R];
+    int pp[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int j = r * NT + tid;
+      live[r] = j < n_q;
+      const int q = live[r] ? nn_share_query(j, part, P) : 0;
+      sp[r] = nn_src(a, t, q_base, q);
+      const unsigned v = t.pos[q];
+      pp[r] = live[r] && v != 0xFFFFu ? (int)v : -1;
+      if (vic) rec[r] = vic[pp[r] < 0 ? 0 : pp[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      best[r] = kNnNone;
+      bpos[r] = -1;
+      if (live[r]) {
+        const float4 s = sp[r];
+        const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                    z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+        qx[r] = x;
+        qy[r] = y;
+        qz[r] = z;
+        // candidates: the representative of the query's cell and the previous correspondence
+        const int p0 = t.rep[nn_cell_of(a.nn, x, y, z)];
+        nn_consider(x, y, z, t.pts[p0], p0, best[r], bpos[r]);
+        if (pp[r] >= 0) nn_consider(x, y, z, t.pts[pp[r]], pp[r], best[r], bpos[r]);
+        if (vic && bpos[r] >= 0 && bpos[r] != pp[r]) rec[r] = vic[bpos[r]];
+      }
+    }
+  }
+  unsigned n_mine = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int j = r * NT + tid, q = first + j * stride;
-    tag[r] = 0;
-    if (j < n_q) {
-      const float4 s = nn_src(a, t, q_base, q);
-      const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
-                  z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
-      unsigned long long best;
-      int bpos, cell;
-      const unsigned pp = t.pos[q];
-      const int c = nn_bound(a.nn, t, x, y, z, pp == 0xFFFFu ? -1 : (int)pp, best, bpos, cell);
-      t.d2[q] = __uint_as_float((unsigned)(best >> 32));
-      t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
-      const unsigned key = (unsigned)(kNnClasses - 1 - c) * kNnStrips + (unsigned)min(cell >> strip_shift, kNnStrips - 1);
-      const unsigned old = atomicAdd(&t.bins[key >> 1], (key & 1u) ? 0x10000u : 1u);
-      tag[r] = (key << 16) | ((key & 1u) ? (old >> 16) : (old & 0xFFFFu));
+    tag[r] = kNoTag;
+    if (live[r]) {
+      const int q = nn_share_query(r * NT + tid, part, P);
+      const bool proven = vic && bpos[r] >= 0 && nn_vic_check(t, rec[r], qx[r], qy[r], qz[r], best[r], bpos[r]);
+      t.d2[q] = bpos[r] < 0 ? FLT_MAX : __uint_as_float((unsigned)(best[r] >> 32));
+      t.pos[q] = (uint16_t)(bpos[r] < 0 ? 0xFFFF : bpos[r]);
+      if (!proven) {
+        // no candidate at all (a non-finite or astronomically far query): the plain scan, class 15
+        const int c = bpos[r] < 0 ? kNnClasses - 1 : nn_class(a.nn, qx[r], qy[r], qz[r], __uint_as_float((unsigned)(best[r] >> 32)));
+        const int cell = nn_cell_of(a.nn, qx[r], qy[r], qz[r]);
+        const unsigned key = (unsigned)(kNnClasses - 1 - c) * kNnStrips + (unsigned)min(cell >> strip_shift, kNnStrips - 1);
+        const unsigned old = atomicAdd(&t.bins[key >> 1], (key & 1u) ? 0x10000u : 1u);
+        tag[r] = (key << 16) | ((key & 1u) ? (old >> 16) : (old & 0xFFFFu));
+        ++n_mine;
+      }
     }
+  }
+  {   // how many queries are left for phase B (one atomic per wave)
+    unsigned w = n_mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
+    if ((tid & 63) == 0 && w) atomicAdd(&sch->n_unres, w);
   }
   __syncthreads();
   PGP_NN_STAMP(5);
+  const unsigned n_unres = sch->n_unres;
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 1
+  if (tid == 0 && t.dbg) t.dbg[3] += n_unres;   // queries the graph left to the search, summed over the iterations
+#endif
+  if (n_unres == 0) {   // every query answered on the graph (the usual iteration of a converged pose)
+    if (tid == 0) sch->search_ticks = 0;
+    __syncthreads();    // n_unres is zeroed by the next call: everybody has read it
+    return;
+  }
   {   // exclusive scan of the 8192 counters, 8 per thread, in key order
     uint4* b4 = reinterpret_cast<uint4*>(t.bins);
     const uint4 w = b4[tid];
@@ -1260,13 +1446,13 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   }
   __syncthreads();
   if (tid == 0) {   // the lane slots of the classes, dearest first
-    // With few queries (a share of a pose's points, a short cloud) one lane per query leaves most of the
-    // workgroup idle while the wave that holds the dearest class works alone (measured: 35 us of a 40 us search
-    // with 625 queries on 1024 lanes): lower the class from which queries get 2, 4, ... lanes for as long as
-    // everything still fits ONE pass of the workgroup.
+    // With few queries (a share of a pose's points, a short cloud, what the graph left over) one lane per query
+    // leaves most of the workgroup idle while the wave that holds the dearest class works alone (measured: 35 us
+    // of a 40 us search with 625 queries on 1024 lanes): lower the class from which queries get 2, 4, ... lanes
+    // for as long as everything still fits ONE pass of the workgroup.
     unsigned members[kNnClasses];   // queries per class (registers: the loops below are unrolled)
 #pragma unroll
-    for (int c = 0; c < kNnClasses; ++c) members[c] = (c == 0 ? (unsigned)n_q : sch->cnt[c - 1]) - sch->cnt[c];
+    for (int c = 0; c < kNnClasses; ++c) members[c] = (c == 0 ? n_unres : sch->cnt[c - 1]) - sch->cnt[c];
     auto count_slots = [&](int bs) {
       unsigned sl = 0;
 #pragma unroll
@@ -1292,8 +1478,8 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    const int j = r * NT + tid, q = first + j * stride;
-    if (j < n_q) {
+    if (tag[r] != kNoTag) {
+      const int q = nn_share_query(r * NT + tid, part, P);
       const unsigned key = tag[r] >> 16;
       const unsigned off = (key & 1u) ? (t.bins[key >> 1] >> 16) : (t.bins[key >> 1] & 0xFFFFu);
       t.order[off + (tag[r] & 0xFFFFu)] = (uint16_t)q;
