@@ -1597,6 +1597,7 @@ __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
 // the closed-form update and the stop rules are those of icp_refine, operation for operation: the two
 // kernels (and the exhaustive searches) give bit-identical transforms, energies and iteration counts.
 constexpr int kPiR = 4;   // source points per thread: n_src <= 4096
+constexpr int kSelRank = 512;   // keys of the threshold's 12-bit bin that are ranked by comparison (else: 8-bit radix passes)
 template <int METRIC, bool IMG_LDS>
 __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1605,6 +1606,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ unsigned s_hist[256];
   __shared__ unsigned s_scan[kIcpThreads / 64];
   __shared__ unsigned s_sel_prefix[2], s_sel_kleft[2], s_sel_nties;
+  __shared__ unsigned s_sel_bin, s_sel_m, s_sel_cnt, s_sel_thr, s_sel_take;
   __shared__ unsigned s_tie[kPiR * (kIcpThreads / 64)];
   static_assert(kPiR * (kIcpThreads / 64) == 64, "one wave scans the tie counts");
   __shared__ double s_energy, s_energy_old;
@@ -1613,9 +1615,12 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ float s_G_old[16];
   __shared__ NnSched s_sch;
 
+  // the repair launch of a clustered call (launch_icp): nothing to do unless a meeting was lost
+  if (a.run_if && *a.run_if == 0u) return;
+
   // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
-  // searches the source points part, part + P, ...; the shares meet in HBM (x_buf) once per iteration, everything
-  // after the search runs in every workgroup of the pose on the same data -- same bits, same decisions
+  // searches its share of the source points (nn_share_query); the shares meet in HBM (x_buf) once per iteration,
+  // everything after the search runs in every workgroup of the pose on the same data -- same bits, same decisions
   // Sharing pays while the search is long (poses centimetres off: 60 -> 24 us per iteration); once every share is
   // searched in ~10 us the meeting (~10 us) costs more than it saves, so the pose goes on in workgroup 0 alone
   // and the others leave.  The switch follows measured time -- the results do not depend on it.
@@ -1624,7 +1629,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   // first n blocks, which the dispatcher deals round-robin over the 8 XCDs (b = pose * P + part put all of them
   // on XCDs 0 and 4: +10 % on a call whose poses soon go solo)
   const int part = (int)blockIdx.x / a.n, pose = (int)blockIdx.x - part * a.n;
-  int n_share = (a.n_src - part + P - 1) / P;
+  int n_share = nn_share_count(a.n_src, part, P);
   __shared__ int s_lost, s_solo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* Tg = a.T + 16 * (size_t)pose;
@@ -1641,7 +1646,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   const NnLds t = nn_load_image<IMG_LDS>(a, smem, a.n_src, tid, kIcpThreads);
 #endif
   for (int q = tid; q < a.n_src; q += kIcpThreads) t.pos[q] = 0xFFFF;   // no previous correspondence yet
-  if (tid < 16) s_G[tid] = Tg[tid];
+  if (tid < 16) {
+    const float v = (a.T_in ? a.T_in : a.T)[16 * (size_t)pose + tid];
+    s_G[tid] = v;
+    if (a.T_save && part == 0) a.T_save[16 * (size_t)pose + tid] = v;   // what a repair launch starts from
+  }
   if (tid == 0) {
     s_energy_old = (double)FLT_MAX;   // PCL: energy starts at numeric_limits<float>::max()
     s_energy = 0.0;
@@ -1657,23 +1666,19 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 #else
 #define PGP_STAMP(k) do { } while (0)
 #endif
-#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 5   // level 5: the parts of phase 3 (sums) in s_dbg[0..3]
-  unsigned long long sub_prev = 0;
-#define PGP_SUB(k) do { if (pose == a.dbg_pose && tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); \
-    if ((k) >= 0) s_dbg[(k) < 0 ? 0 : (k)] += (unsigned)(now - sub_prev); sub_prev = now; } } while (0)
-#else
-#define PGP_SUB(k) do { } while (0)
-#endif
   for (;;) {
     PGP_STAMP(0);
     // ---- 1. correspondences ---------------------------------------------------------------------
     nn_all_queries<kIcpThreads, kPiR>(a, t, s_G, 0, n_share, &s_sch, tid, part, P);
     if (P > 1) {
-      // publish this share (write-through, agent scope: the partners may sit on other XCDs), meet, read theirs
+      // publish this share (write-through, agent scope: the partners may sit on other XCDs), meet, read theirs.
+      // Consecutive lanes store consecutive records of a block of eight: whole 64-byte lines.
       unsigned long long* xb = a.x_buf + ((size_t)(it & 1) * a.n + pose) * a.n_src;
-      for (int q = part + tid * P; q < a.n_src; q += kIcpThreads * P)
+      for (int j = tid; j < n_share; j += kIcpThreads) {
+        const int q = nn_share_query(j, part, P);
         __hip_atomic_store(&xb[q], ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned long long)t.pos[q],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       unsigned* xt = a.x_ticks + ((size_t)(it & 1) * a.n + pose) * 4;
       if (tid == 0) __hip_atomic_store(&xt[part], s_sch.search_ticks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __builtin_amdgcn_s_waitcnt(0);   // the stores have left before the arrival below is counted
@@ -1685,7 +1690,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
         // polling loop invalidated the XCD's L2 for every workgroup on it: selection + sums 10.7 -> 13.4 us)
         __hip_atomic_fetch_add(&a.x_ctr[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // All workgroups of the launch are resident (cooperative launch, one per CU), so the partners arrive;
-        // the clock bound only turns a broken assumption into an error code instead of a hang.
+        // the clock bound only turns a broken assumption into a repair launch instead of a hang.
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&a.x_ctr[pose], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
@@ -1703,7 +1708,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       if (s_lost) break;
       if (s_solo && part != 0) return;   // this share is published; workgroup 0 finishes the pose
       for (int q = tid; q < a.n_src; q += kIcpThreads) {
-        if (q % P == part) continue;
+        if (nn_share_owns(q, part, P)) continue;
         const unsigned long long v = __hip_atomic_load(&xb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t.d2[q] = __uint_as_float((unsigned)(v >> 32));
         t.pos[q] = (uint16_t)(v & 0xFFFFull);
@@ -1716,66 +1721,139 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     }
     PGP_STAMP(1);
 
-    // ---- 2. selection threshold: k-th smallest d2 by radix select on the float bits ---------
+    // the source points of the sums (step 3): requested now, so that their L2 round trip passes under the selection
+    float4 sreg[kPiR];
+#pragma unroll
+    for (int r = 0; r < kPiR; ++r) sreg[r] = a.src[min(r * kIcpThreads + tid, a.n_src - 1)];
+
+    // ---- 2. selection threshold: the k-th smallest d2 (the keys are the float bits: d2 >= +0) ----------------
     unsigned thr_key = 0xFFFFFFFFu, ties_to_take = 0xFFFFFFFFu;  // default: take everything
     if (a.max_corr2 < 0.f && a.k_trim < a.n_src) {
-      // Three barriers per pass: count | scan inside the waves | pick the bin.  The thread that owns the bin
-      // writes the next pass's prefix and rank itself (ping-pong slots: its neighbours still read this pass's),
-      // and every bin is zeroed by its owner on the way out.  (Five barriers per pass before: 20 -> 13 per
-      // iteration; same arithmetic, same result.)
-      if (tid == 0) {
-        s_sel_prefix[0] = 0;
-        s_sel_kleft[0] = (unsigned)a.k_trim;
-      }
-      if (tid < 256) s_hist[tid] = 0;
+      // One histogram over the upper 12 key bits (sign, exponent, four mantissa bits: 4096 counters in the
+      // search's sort bins, free by now) finds the bin of the k-th key; the keys of that bin -- a few dozen of
+      // 2500 -- are compacted and RANKED by comparison, each by its own thread.  Six barriers instead of the
+      // thirteen of four 8-bit radix passes; same threshold, same tie count.  A bin with more than kSelRank
+      // keys (a cloud of coincident points: hundreds of d2 = 0) takes the radix passes below.
+      uint32_t* hist = t.bins;
+      reinterpret_cast<uint4*>(hist)[tid] = make_uint4(0u, 0u, 0u, 0u);
+      if (tid == 0) s_sel_cnt = 0;
       __syncthreads();
-      for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        const unsigned prefix = s_sel_prefix[pass & 1], kleft = s_sel_kleft[pass & 1];
-        const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
-        // (counting up to four bins per wave with one atomic each -- the keys of a pass share few bins -- was
-        //  slower: select 7.3 -> 10.2 us; same-address LDS atomics are not the cost here)
-        for (int i = tid; i < a.n_src; i += kIcpThreads) {
-          const unsigned key = __float_as_uint(t.d2[i]);
-          if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        unsigned hv = 0, incl = 0;
-        if (tid < 256) {
-          hv = s_hist[tid];
-          incl = hv;
 #pragma unroll
-          for (int off = 1; off < 64; off <<= 1) {
-            const unsigned tt = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += tt;
-          }
-          if (lane == 63) s_scan[wave] = incl;
-        }
-        __syncthreads();
-        if (tid < 256) {
-          unsigned woff = 0;
-          for (int w = 0; w < wave; ++w) woff += s_scan[w];
-          incl += woff;
-          const unsigned excl = incl - hv;
-          if (excl < kleft && kleft <= incl) {          // the bin that holds the kleft-th key: exactly one thread
-            s_sel_kleft[(pass + 1) & 1] = kleft - excl;
-            s_sel_prefix[(pass + 1) & 1] = prefix | ((unsigned)tid << shift);
-            s_sel_nties = hv;                           // after the last pass: the keys EQUAL to the threshold
-          } else if (tid == 255 && kleft > incl) {      // fewer keys than the rank asks for (cannot happen: k <= n)
-            s_sel_kleft[(pass + 1) & 1] = kleft - incl;
-            s_sel_prefix[(pass + 1) & 1] = prefix | (255u << shift);
-            s_sel_nties = 0xFFFFFFFFu;
-          }
-          s_hist[tid] = 0;
-        }
-        __syncthreads();
+      for (int r = 0; r < kPiR; ++r) {
+        const int i = r * kIcpThreads + tid;
+        if (i < a.n_src) atomicAdd(&hist[__float_as_uint(t.d2[i]) >> 19], 1u);
       }
-      thr_key = s_sel_prefix[0];
-      ties_to_take = s_sel_kleft[0];
+      __syncthreads();
+      const uint4 hv = reinterpret_cast<const uint4*>(hist)[tid];
+      const unsigned mine = hv.x + hv.y + hv.z + hv.w;
+      unsigned incl = mine;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const unsigned tt = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += tt;
+      }
+      if (lane == 63) s_scan[wave] = incl;
+      __syncthreads();
+      {
+        unsigned woff = 0;
+        for (int w = 0; w < wave; ++w) woff += s_scan[w];
+        unsigned excl = woff + incl - mine;
+        const unsigned kk = (unsigned)a.k_trim;
+        if (excl < kk && kk <= excl + mine) {   // exactly one thread: its four bins hold the k-th key
+          unsigned b = 4u * (unsigned)tid, m = hv.x;
+          if (kk > excl + m) { excl += m; m = hv.y; ++b;
+            if (kk > excl + m) { excl += m; m = hv.z; ++b;
+              if (kk > excl + m) { excl += m; m = hv.w; ++b; } } }
+          s_sel_bin = b;
+          s_sel_m = m;
+          s_sel_kleft[0] = kk - excl;   // rank of the key inside its bin (1-based)
+        }
+      }
+      __syncthreads();
+      const unsigned sel_bin = s_sel_bin, sel_m = s_sel_m, kleft = s_sel_kleft[0];
+      if (sel_m <= (unsigned)kSelRank) {
+        uint32_t* cand = hist;   // the histogram is dead: every thread read its counters before the last barrier
+#pragma unroll
+        for (int r = 0; r < kPiR; ++r) {
+          const int i = r * kIcpThreads + tid;
+          if (i < a.n_src) {
+            const unsigned key = __float_as_uint(t.d2[i]);
+            if ((key >> 19) == sel_bin) cand[atomicAdd(&s_sel_cnt, 1u)] = key;
+          }
+        }
+        __syncthreads();
+        if ((unsigned)tid < sel_m) {
+          const unsigned c = cand[tid];
+          unsigned lt = 0, le = 0;
+          for (unsigned j = 0; j < sel_m; ++j) {   // broadcast reads
+            const unsigned v = cand[j];
+            lt += v < c ? 1u : 0u;
+            le += v <= c ? 1u : 0u;
+          }
+          if (lt < kleft && kleft <= le) {   // c is the k-th key (every thread that holds a copy of it writes the same)
+            s_sel_thr = c;
+            s_sel_take = kleft - lt;         // how many keys equal to it belong to the k smallest
+            s_sel_nties = le - lt;           // the keys EQUAL to the threshold
+          }
+        }
+        __syncthreads();
+        thr_key = s_sel_thr;
+        ties_to_take = s_sel_take;
+      } else {
+        // Three barriers per pass: count | scan inside the waves | pick the bin.  The thread that owns the bin
+        // writes the next pass's prefix and rank itself (ping-pong slots: its neighbours still read this pass's),
+        // and every bin is zeroed by its owner on the way out.
+        if (tid == 0) {
+          s_sel_prefix[0] = 0;
+          s_sel_kleft[0] = (unsigned)a.k_trim;
+        }
+        if (tid < 256) s_hist[tid] = 0;
+        __syncthreads();
+        for (int pass = 0; pass < 4; ++pass) {
+          const int shift = 24 - 8 * pass;
+          const unsigned prefix = s_sel_prefix[pass & 1], kl = s_sel_kleft[pass & 1];
+          const unsigned mask = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+          for (int i = tid; i < a.n_src; i += kIcpThreads) {
+            const unsigned key = __float_as_uint(t.d2[i]);
+            if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+          }
+          __syncthreads();
+          unsigned h8 = 0, inc8 = 0;
+          if (tid < 256) {
+            h8 = s_hist[tid];
+            inc8 = h8;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+              const unsigned tt = __shfl_up(inc8, off, 64);
+              if (lane >= off) inc8 += tt;
+            }
+            if (lane == 63) s_scan[wave] = inc8;
+          }
+          __syncthreads();
+          if (tid < 256) {
+            unsigned woff = 0;
+            for (int w = 0; w < wave; ++w) woff += s_scan[w];
+            inc8 += woff;
+            const unsigned excl = inc8 - h8;
+            if (excl < kl && kl <= inc8) {          // the bin that holds the kl-th key: exactly one thread
+              s_sel_kleft[(pass + 1) & 1] = kl - excl;
+              s_sel_prefix[(pass + 1) & 1] = prefix | ((unsigned)tid << shift);
+              s_sel_nties = h8;                           // after the last pass: the keys EQUAL to the threshold
+            } else if (tid == 255 && kl > inc8) {      // fewer keys than the rank asks for (cannot happen: k <= n)
+              s_sel_kleft[(pass + 1) & 1] = kl - inc8;
+              s_sel_prefix[(pass + 1) & 1] = prefix | (255u << shift);
+              s_sel_nties = 0xFFFFFFFFu;
+            }
+            s_hist[tid] = 0;
+          }
+          __syncthreads();
+        }
+        thr_key = s_sel_prefix[0];
+        ties_to_take = s_sel_kleft[0];
+      }
     }
 
     PGP_STAMP(2);
-    PGP_SUB(-1);
     // ---- 3. f64 sums over the selected pairs (ordered tie handling), fixed-tree reduction ----
     constexpr int kNs = METRIC == 1 ? kRedPlane : 16;   // sums in use
     double acc[kNs];
@@ -1812,7 +1890,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       }
       __syncthreads();
     }
-    PGP_SUB(0);
 #pragma unroll
     for (int r = 0; r < kPiR; ++r) {
       const int i = r * kIcpThreads + tid;
@@ -1836,7 +1913,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       const unsigned pm = i < a.n_src ? (unsigned)t.pos[i] : 0xFFFFu;   // 0xFFFF: a non-finite point has no neighbour
       if constexpr (METRIC == 1) {
         if (sel && pm != 0xFFFFu) {
-          const float4 s = nn_src(a, t, 0, i);
+          const float4 s = sreg[r];
           const float4 m = t.pts[pm];
           const float4 nn = a.tgt_n[__float_as_int(m.w)];
           const double px = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
@@ -1856,7 +1933,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
           e_acc += (double)d2;
         }
       } else if (sel && pm != 0xFFFFu) {
-        const float4 s = nn_src(a, t, 0, i);
+        const float4 s = sreg[r];
         const float4 m = t.pts[pm];
         const float s0 = s.x, s1 = s.y, s2 = s.z;
         acc[0] += 1.0;
@@ -1868,12 +1945,10 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
         e_acc += (double)d2;
       }
     }
-    PGP_SUB(1);
 #pragma unroll
     for (int k = 0; k < kNs; ++k)
       acc[k] = wave_sum_f64(acc[k]);
     e_acc = wave_sum_f64(e_acc);
-    PGP_SUB(2);
     // (no barrier here: s_red was last read before the previous iteration's closing barriers)
     if (lane == 0) {
 #pragma unroll
@@ -1888,7 +1963,6 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       s_sum[tid] = v;
     }
     __syncthreads();
-    PGP_SUB(3);
     PGP_STAMP(3);
     if (tid == 0) {
       const double* red = s_sum;
@@ -1914,8 +1988,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     ++it;
     if (!s_continue) break;
   }
-  if (s_lost) {   // a partner never arrived: mark the pose (iterations -1), leave its transform alone
-    if (tid == 0 && a.iters) a.iters[pose] = -1;
+  if (s_lost) {
+    // a partner never arrived (another process holding the GPU's CUs): this call's transforms are not to be
+    // trusted.  The flag lives in the library's workspace; the repair launch that follows every clustered launch
+    // sees it and runs all poses again from their saved initial transforms, one workgroup per pose.
+    if (tid == 0) __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
   if (part != 0) return;
