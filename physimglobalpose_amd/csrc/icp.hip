@@ -2040,6 +2040,7 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
       a->nn = g;
       a->nn_image = ctx->d_icp_grid.as<unsigned char>();
       a->nn_image_in_lds = in_lds ? 1 : 0;
+      a->nn_vic = ctx->icp_idx_vic_off ? reinterpret_cast<const uint4*>(a->nn_image + ctx->icp_idx_vic_off) : nullptr;
       *fits = true;
       return PGP_OK;
     }
@@ -2098,8 +2099,13 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
   if (in_lds && (long long)nn_lds_bytes(g.bytes, n_q) + kScratch > kLdsBytes) in_lds = false;
   const size_t nc1 = (size_t)g.n_cells + 1;
   const size_t off_ctr = ((size_t)g.bytes + 255) & ~(size_t)255, off_st = off_ctr + ((nc1 * 4 + 255) & ~(size_t)255),
-               off_key = off_st + ((nc1 * 4 + 255) & ~(size_t)255);
-  if ((rc = ctx->d_icp_grid.ensure(off_key + (size_t)g.n_cells * 8 + 256)) != PGP_OK) return rc;
+               off_key = off_st + ((nc1 * 4 + 255) & ~(size_t)255),
+               off_vic = (off_key + (size_t)g.n_cells * 8 + 255) & ~(size_t)255;
+  bool want_vic = n_tgt <= kVicMaxTargets;
+  if (const char* v = getenv("PGP_ICP_VIC")) want_vic = want_vic && atoi(v) != 0;   // A/B knob: 0 = searches only
+  const int vic_chunks = (n_tgt + kVicChunk - 1) / kVicChunk;
+  if ((rc = ctx->d_icp_grid.ensure(off_vic + (want_vic ? (size_t)n_tgt * 16 : 0) + 256)) != PGP_OK) return rc;
+  if (want_vic && (rc = ctx->d_icp_ws.ensure((size_t)vic_chunks * n_tgt * (kVicK + 1) * 8 + 64)) != PGP_OK) return rc;
   if ((rc = ctx->d_scan_tmp.ensure((nc1 / 2048 + 2) * 4)) != PGP_OK) return rc;
   unsigned char* image = ctx->d_icp_grid.as<unsigned char>();
   uint32_t* ctr = reinterpret_cast<uint32_t*>(image + off_ctr);
@@ -2118,10 +2124,19 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
                      reinterpret_cast<const float4*>(image), n_tgt, g, key);
   hipLaunchKernelGGL(nnidx_pack, dim3((g.n_cells + 1 + 255) / 256), dim3(256), 0, stream, g, (const uint32_t*)start,
                      (const unsigned long long*)key, image);
+  if (want_vic) {   // the vicinity graph over the points in image order
+    float2* part = ctx->d_icp_ws.as<float2>();
+    uint4* vic = reinterpret_cast<uint4*>(image + off_vic);
+    hipLaunchKernelGGL(nnidx_vic_partial, dim3((n_tgt + 63) / 64, vic_chunks), dim3(64), 0, stream,
+                       reinterpret_cast<const float4*>(image), n_tgt, part);
+    hipLaunchKernelGGL(nnidx_vic_merge, dim3((n_tgt + 63) / 64), dim3(64), 0, stream, (const float2*)part, n_tgt, vic_chunks, vic);
+  }
   PGP_HIP(hipGetLastError());
   a->nn = g;
   a->nn_image = image;
   a->nn_image_in_lds = in_lds ? 1 : 0;
+  a->nn_vic = want_vic ? reinterpret_cast<const uint4*>(image + off_vic) : nullptr;
+  ctx->icp_idx_vic_off = want_vic ? off_vic : 0;
   *fits = true;
   memcpy(ctx->icp_idx_geom, &g, sizeof g);
   ctx->icp_idx_valid = token != 0;
@@ -2142,9 +2157,7 @@ struct CoopChain {
   hipEvent_t last[64] = {};
 };
 CoopChain g_coop;
-thread_local bool t_icp_single = false;   // the calling thread wants one workgroup per pose (retry after a lost meeting)
 }  // namespace
-void icp_force_single_workgroup(bool on) { t_icp_single = on; }
 
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
@@ -2243,10 +2256,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   }
   if (use_grid || a.smooth > 0 || use_index) split = true;   // all live on the host-driven path
   const size_t hist_bytes = a.smooth > 0 ? (size_t)n * (kMaxSmooth + 1) * 7 * 8 : 0;
-  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 + (use_index ? need * 4 + 64 : 0) : 0;
-  if ((rc = ctx->d_icp_ws.ensure(need * 8 + state_bytes + 64)) != PGP_OK) return rc;
-  a.ws_d2 = ctx->d_icp_ws.as<float>();
-  a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
   a.energy = d_energy;
   a.iters = d_iters;
   const size_t lds = (size_t)kTgtTile * sizeof(float4);
@@ -2262,8 +2271,10 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     ctx->icp_attr_set = true;
   }
   if (persist_index) {
+    // everything of an iteration lives in LDS: the workspace holds the pointmatcher history only
     if (a.smooth > 0) {
-      a.st_hist = reinterpret_cast<double*>(((uintptr_t)(a.ws_j + need) + 15) & ~(uintptr_t)15);
+      if ((rc = ctx->d_icp_ws.ensure(hist_bytes + 64)) != PGP_OK) return rc;
+      a.st_hist = ctx->d_icp_ws.as<double>();
       PGP_HIP(hipMemsetAsync(a.st_hist, 0, hist_bytes, stream));
     }
     const bool il = a.nn_image_in_lds != 0;
@@ -2281,7 +2292,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     if (const char* v = getenv("PGP_ICP_SLOTS")) a.slot_budget = atoi(v);
     int want_wgs = n * 4 <= ctx->n_cus ? 4 : (n * 2 <= ctx->n_cus ? 2 : 1);
     if (const char* v = getenv("PGP_ICP_WGS")) want_wgs = atoi(v) == 4 ? 4 : (atoi(v) == 2 ? 2 : 1);   // A/B knob
-    if (t_icp_single) want_wgs = 1;
     if (want_wgs > 1 && a.smooth == 0 && n * want_wgs <= ctx->n_cus && n_src >= 64 * want_wgs) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
@@ -2289,32 +2299,56 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     }
     if (getenv("PGP_ICP_DEBUG")) fprintf(stderr, "icp: n_cus %d want %d -> %d\n", ctx->n_cus, want_wgs, a.wgs_per_pose);
     if (a.wgs_per_pose > 1) {
-      const size_t xbytes = 2 * need * 8;
-      if ((rc = ctx->d_icp_x.ensure(xbytes + (size_t)n * (4 + 32) + 64)) != PGP_OK) return rc;
-      a.x_buf = ctx->d_icp_x.as<unsigned long long>();
-      a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
-      a.x_ticks = a.x_ctr + n;
-      a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
-      if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
-      PGP_HIP(hipMemsetAsync(a.x_ctr, 0, (size_t)n * 4, stream));
-      void* params[] = {&a};
       const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+      // The chain first: the previous clustered launch of this device (any stream of this process) has finished
+      // before this one's buffers are (re)allocated, its counters zeroed and its workgroups started.
       std::lock_guard<std::mutex> chain(g_coop.mu);
       if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
       else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
+      // meeting buffers | arrival counters | lost flag | search ticks | saved transforms
+      const size_t xbytes = 2 * need * 8, ctr_words = (size_t)n + 4;
+      if ((rc = ctx->d_icp_x.ensure(xbytes + ctr_words * 4 + (size_t)n * 32 + (size_t)n * 64 + 64)) != PGP_OK) return rc;
+      a.x_buf = ctx->d_icp_x.as<unsigned long long>();
+      a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
+      a.x_lost = a.x_ctr + n;
+      a.x_ticks = a.x_ctr + ctr_words;
+      a.T_save = reinterpret_cast<float*>(a.x_ticks + (size_t)n * 8);
+      a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
+      if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
+      PGP_HIP(hipMemsetAsync(a.x_ctr, 0, ctr_words * 4, stream));
+      void* params[] = {&a};
       hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
-      if (e == hipSuccess) PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
       if (getenv("PGP_ICP_DEBUG"))
         fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
-      if (e == hipSuccess) return PGP_OK;
+      if (e == hipSuccess) {
+        // The repair launch: one workgroup per pose, an ordinary launch; every workgroup returns at once unless a
+        // meeting of the clustered launch was lost (another process spinning on the CUs), in which case all poses
+        // run again from their saved initial transforms.  The caller -- host-pointer or device-pointer API, with
+        // or without d_iters -- always gets refined transforms; nothing is reported through iters any more.
+        IcpArgs fix = a;
+        fix.wgs_per_pose = 1;
+        fix.run_if = a.x_lost;
+        fix.T_in = a.T_save;
+        fix.T_save = nullptr;
+        void* fparams[] = {&fix};
+        PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), fparams, plds, stream));
+        PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
+        PGP_HIP(hipGetLastError());
+        return PGP_OK;
+      }
       (void)hipGetLastError();   // the grid does not fit as a cooperative launch here: one workgroup per pose
       a.wgs_per_pose = 1;
+      a.T_save = nullptr;
     }
     void* params[] = {&a};
     PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), params, plds, stream));
     PGP_HIP(hipGetLastError());
     return PGP_OK;
   }
+  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 + (use_index ? need * 4 + 64 : 0) : 0;
+  if ((rc = ctx->d_icp_ws.ensure(need * 8 + state_bytes + 64)) != PGP_OK) return rc;
+  a.ws_d2 = ctx->d_icp_ws.as<float>();
+  a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
   if (!split) {
     hipLaunchKernelGGL(icp_refine<false>, dim3(n), dim3(kIcpThreads), lds, stream, a);
     PGP_HIP(hipGetLastError());
