@@ -1279,6 +1279,7 @@ __device__ __forceinline__ int nn_class_lanes_log2(int c, int base = kNnBaseClas
   const int l = c - base;
   return l < 0 ? 0 : (l > 6 ? 6 : l);
 }
+constexpr int kNnFew = 64;        // up to this many unanswered queries skip the sort: 16 lanes each, one pass
 struct NnSched {
   unsigned cnt[kNnClasses + 1];    // offset of every class in `order` (dearest class first); [kNnClasses] = n_q
   unsigned slot_end[kNnClasses];   // end of the class's lane slots
@@ -1286,6 +1287,7 @@ struct NnSched {
   unsigned wave_sum[16];
   unsigned search_ticks;           // time of the search loop below as thread 0 saw it (100 MHz ticks)
   unsigned n_unres;                // queries the vicinity graph did not answer: phase B's population
+  uint16_t few[kNnFew];            // the first of them, in arrival order: the short path of phase B
   int base;                        // classes above it get 2^(class - base) lanes (kNnBaseClass, lower when lanes would idle)
 };
 // The caller may hand over a SHARE of the queries (several workgroups per pose): the cloud is dealt in blocks of
@@ -1378,31 +1380,34 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       }
     }
   }
-  unsigned n_mine = 0;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     tag[r] = kNoTag;
+    bool unres = false;
+    const int q = nn_share_query(r * NT + tid, part, P);
     if (live[r]) {
-      const int q = nn_share_query(r * NT + tid, part, P);
       const bool proven = vic && bpos[r] >= 0 && nn_vic_check(t, rec[r], qx[r], qy[r], qz[r], best[r], bpos[r]);
       t.d2[q] = bpos[r] < 0 ? FLT_MAX : __uint_as_float((unsigned)(best[r] >> 32));
       t.pos[q] = (uint16_t)(bpos[r] < 0 ? 0xFFFF : bpos[r]);
       if (!proven) {
+        unres = true;
         // no candidate at all (a non-finite or astronomically far query): the plain scan, class 15
         const int c = bpos[r] < 0 ? kNnClasses - 1 : nn_class(a.nn, qx[r], qy[r], qz[r], __uint_as_float((unsigned)(best[r] >> 32)));
         const int cell = nn_cell_of(a.nn, qx[r], qy[r], qz[r]);
         const unsigned key = (unsigned)(kNnClasses - 1 - c) * kNnStrips + (unsigned)min(cell >> strip_shift, kNnStrips - 1);
         const unsigned old = atomicAdd(&t.bins[key >> 1], (key & 1u) ? 0x10000u : 1u);
         tag[r] = (key << 16) | ((key & 1u) ? (old >> 16) : (old & 0xFFFFu));
-        ++n_mine;
       }
     }
-  }
-  {   // how many queries are left for phase B (one atomic per wave)
-    unsigned w = n_mine;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) w += __shfl_xor(w, off, 64);
-    if ((tid & 63) == 0 && w) atomicAdd(&sch->n_unres, w);
+    // count the queries left for phase B (one atomic per wave and sweep) and list the first kNnFew of them
+    const unsigned long long um = __ballot(unres);
+    if (um) {
+      unsigned base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(&sch->n_unres, (unsigned)__popcll(um));
+      base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+      const unsigned slot = base + (unsigned)__popcll(um & ((1ull << (tid & 63)) - 1ull));
+      if (unres && slot < (unsigned)kNnFew) sch->few[slot] = (uint16_t)q;
+    }
   }
   __syncthreads();
   PGP_NN_STAMP(5);
@@ -1413,6 +1418,41 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   if (n_unres == 0) {   // every query answered on the graph (the usual iteration of a converged pose)
     if (tid == 0) sch->search_ticks = 0;
     __syncthreads();    // n_unres is zeroed by the next call: everybody has read it
+    return;
+  }
+  if (NT == 16 * kNnFew && n_unres <= (unsigned)kNnFew) {
+    // A handful of stragglers (the graph answers all but ~30 of 1800 queries of a pose that is millimetres off):
+    // no sort, no slot table -- query i takes lanes 16 i .. 16 i + 15, which share its rows; one pass, one barrier.
+    const int grp = tid >> 4, sub = tid & 15;
+    unsigned long long best = kNnNone;
+    int bpos = -1, q = 0;
+    const bool valid = (unsigned)grp < n_unres;
+    if (valid) {
+      q = sch->few[grp];
+      const float4 s = nn_src(a, t, q_base, q);
+      const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                  z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+      const unsigned pp = t.pos[q];
+      bpos = pp == 0xFFFFu ? -1 : (int)pp;
+      if (bpos >= 0) best = ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned)__float_as_int(t.pts[bpos].w);
+      nn_search(a.nn, t, a.n_tgt, x, y, z, sub, 16, best, bpos);
+    }
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {   // the 16 lanes of a group are aligned: partners lane ^ off
+      const unsigned lo = __shfl_xor((unsigned)best, off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+      const int pp = __shfl_xor(bpos, off, 64);
+      const unsigned long long pk = ((unsigned long long)hi << 32) | lo;
+      if (pk < best) {
+        best = pk;
+        bpos = pp;
+      }
+    }
+    if (valid && sub == 0) {
+      t.d2[q] = bpos < 0 ? FLT_MAX : __uint_as_float((unsigned)(best >> 32));
+      t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
+    }
+    if (tid == 0) sch->search_ticks = 1;
+    __syncthreads();
     return;
   }
   {   // exclusive scan of the 8192 counters, 8 per thread, in key order

@@ -493,6 +493,27 @@ class LcpScorer:
                                                C.byref(o), _fp(energy), iters.ctypes.data_as(_i)))
         return T, energy, iters
 
+    def icp_refine_device(self, d_src4, d_tgt4, d_T, d_energy=None, d_iters=None, trim=1.0, max_iterations=100,
+                          max_corr_dist=0.0, energy_ratio=1.0, target_token=None, stream=None):
+        """pgp_icp_refine_device: d_src4 / d_tgt4 cuda float32 (n,4) {x,y,z,-}; d_T cuda float32 (n_poses,16), refined
+        in place; d_energy float32 / d_iters int32 (n_poses,) or None.  target_token (non-zero int) vouches that the
+        target is the one of the previous call with the same token (the index stays resident).  Enqueued, no sync."""
+        import torch
+        for x in (d_src4, d_tgt4, d_T):
+            assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(d_T.device).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        if target_token is not None:
+            _lib.check(self._lib.pgp_icp_target_token(self._h, C.c_ulonglong(int(target_token))))
+        prm = _lib.IcpParams(int(max_iterations), float(trim), float(max_corr_dist), float(energy_ratio))
+        _lib.check(self._lib.pgp_icp_refine_device(
+            self._h, C.c_void_p(d_src4.data_ptr()), int(d_src4.shape[0]), C.c_void_p(d_tgt4.data_ptr()),
+            int(d_tgt4.shape[0]), C.c_void_p(d_T.data_ptr()), int(d_T.shape[0]), C.byref(prm),
+            C.c_void_p(d_energy.data_ptr()) if d_energy is not None else None,
+            C.c_void_p(d_iters.data_ptr()) if d_iters is not None else None, C.c_void_p(stream)))
+
     # ---- verification loop -----------------------------------------------------------------------
     def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         """T: (n_h,16) column-major float transforms.  Returns (scores, counts, best_index, best_score)."""
