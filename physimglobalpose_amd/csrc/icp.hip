@@ -1638,7 +1638,13 @@ __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
 // kernels (and the exhaustive searches) give bit-identical transforms, energies and iteration counts.
 constexpr int kPiR = 4;   // source points per thread: n_src <= 4096
 constexpr int kSelRank = 512;   // keys of the threshold's 12-bit bin that are ranked by comparison (else: 8-bit radix passes)
-template <int METRIC, bool IMG_LDS>
+// CLUSTER = false: one workgroup per pose, the meeting code (and its arguments) compiled out -- the kernel is at its
+// 128-register ceiling, and every value less to keep is a spill less per iteration.
+// TRIM_ONLY = true: the TrimmedICP form (UCTState.cpp:137-139: trimming, energy ratio, no correspondence cap and none
+// of the extra stop rules) -- the hot form; its branches on the other forms' options are gone at compile time.
+// PIR: source points per thread (n_src <= PIR x 1024): every per-thread array of the search's phase A, of the
+// selection and of the sums has PIR entries -- a 1756-point segment takes PIR = 2 and half the registers of PIR = 4.
+template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR>
 __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_red[(kIcpThreads / 64) * (kRedPlane + 1)];
@@ -1647,8 +1653,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ unsigned s_scan[kIcpThreads / 64];
   __shared__ unsigned s_sel_prefix[2], s_sel_kleft[2], s_sel_nties;
   __shared__ unsigned s_sel_bin, s_sel_m, s_sel_cnt, s_sel_thr, s_sel_take;
-  __shared__ unsigned s_tie[kPiR * (kIcpThreads / 64)];
-  static_assert(kPiR * (kIcpThreads / 64) == 64, "one wave scans the tie counts");
+  __shared__ unsigned s_tie[64];
+  static_assert(PIR >= 1 && PIR * (kIcpThreads / 64) <= 64, "one wave scans the tie counts");
   __shared__ double s_energy, s_energy_old;
   __shared__ int s_continue;
   __shared__ double s_sum[kRedPlane + 1];
@@ -1656,7 +1662,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   __shared__ NnSched s_sch;
 
   // the repair launch of a clustered call (launch_icp): nothing to do unless a meeting was lost
-  if (a.run_if && *a.run_if == 0u) return;
+  if (!CLUSTER && a.run_if && *a.run_if == 0u) return;   // (the repair launch is a one-workgroup-per-pose launch)
 
   // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
   // searches its share of the source points (nn_share_query); the shares meet in HBM (x_buf) once per iteration,
@@ -1664,11 +1670,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   // Sharing pays while the search is long (poses centimetres off: 60 -> 24 us per iteration); once every share is
   // searched in ~10 us the meeting (~10 us) costs more than it saves, so the pose goes on in workgroup 0 alone
   // and the others leave.  The switch follows measured time -- the results do not depend on it.
-  int P = a.wgs_per_pose;
+  int P = CLUSTER ? a.wgs_per_pose : 1;
   // block b = part * n + pose: workgroup 0 of every pose (the one that may finish the pose alone) comes from the
   // first n blocks, which the dispatcher deals round-robin over the 8 XCDs (b = pose * P + part put all of them
   // on XCDs 0 and 4: +10 % on a call whose poses soon go solo)
-  const int part = (int)blockIdx.x / a.n, pose = (int)blockIdx.x - part * a.n;
+  const int part = CLUSTER ? (int)blockIdx.x / a.n : 0, pose = (int)blockIdx.x - part * a.n;
   int n_share = nn_share_count(a.n_src, part, P);
   __shared__ int s_lost, s_solo;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1687,9 +1693,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 #endif
   for (int q = tid; q < a.n_src; q += kIcpThreads) t.pos[q] = 0xFFFF;   // no previous correspondence yet
   if (tid < 16) {
-    const float v = (a.T_in ? a.T_in : a.T)[16 * (size_t)pose + tid];
+    const float v = (!CLUSTER && a.T_in ? a.T_in : a.T)[16 * (size_t)pose + tid];
     s_G[tid] = v;
-    if (a.T_save && part == 0) a.T_save[16 * (size_t)pose + tid] = v;   // what a repair launch starts from
+    if (CLUSTER && a.T_save && part == 0) a.T_save[16 * (size_t)pose + tid] = v;   // what a repair launch starts from
   }
   if (tid == 0) {
     s_energy_old = (double)FLT_MAX;   // PCL: energy starts at numeric_limits<float>::max()
@@ -1709,8 +1715,8 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   for (;;) {
     PGP_STAMP(0);
     // ---- 1. correspondences ---------------------------------------------------------------------
-    nn_all_queries<kIcpThreads, kPiR>(a, t, s_G, 0, n_share, &s_sch, tid, part, P);
-    if (P > 1) {
+    nn_all_queries<kIcpThreads, PIR>(a, t, s_G, 0, n_share, &s_sch, tid, part, P);
+    if (CLUSTER && P > 1) {
       // publish this share (write-through, agent scope: the partners may sit on other XCDs), meet, read theirs.
       // Consecutive lanes store consecutive records of a block of eight: whole 64-byte lines.
       unsigned long long* xb = a.x_buf + ((size_t)(it & 1) * a.n + pose) * a.n_src;
@@ -1762,13 +1768,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     PGP_STAMP(1);
 
     // the source points of the sums (step 3): requested now, so that their L2 round trip passes under the selection
-    float4 sreg[kPiR];
+    float4 sreg[PIR];
 #pragma unroll
-    for (int r = 0; r < kPiR; ++r) sreg[r] = a.src[min(r * kIcpThreads + tid, a.n_src - 1)];
+    for (int r = 0; r < PIR; ++r) sreg[r] = a.src[min(r * kIcpThreads + tid, a.n_src - 1)];
 
     // ---- 2. selection threshold: the k-th smallest d2 (the keys are the float bits: d2 >= +0) ----------------
     unsigned thr_key = 0xFFFFFFFFu, ties_to_take = 0xFFFFFFFFu;  // default: take everything
-    if (a.max_corr2 < 0.f && a.k_trim < a.n_src) {
+    if ((TRIM_ONLY || a.max_corr2 < 0.f) && a.k_trim < a.n_src) {
       // One histogram over the upper 12 key bits (sign, exponent, four mantissa bits: 4096 counters in the
       // search's sort bins, free by now) finds the bin of the k-th key; the keys of that bin -- a few dozen of
       // 2500 -- are compacted and RANKED by comparison, each by its own thread.  Six barriers instead of the
@@ -1779,7 +1785,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       if (tid == 0) s_sel_cnt = 0;
       __syncthreads();
 #pragma unroll
-      for (int r = 0; r < kPiR; ++r) {
+      for (int r = 0; r < PIR; ++r) {
         const int i = r * kIcpThreads + tid;
         if (i < a.n_src) atomicAdd(&hist[__float_as_uint(t.d2[i]) >> 19], 1u);
       }
@@ -1814,7 +1820,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       if (sel_m <= (unsigned)kSelRank) {
         uint32_t* cand = hist;   // the histogram is dead: every thread read its counters before the last barrier
 #pragma unroll
-        for (int r = 0; r < kPiR; ++r) {
+        for (int r = 0; r < PIR; ++r) {
           const int i = r * kIcpThreads + tid;
           if (i < a.n_src) {
             const unsigned key = __float_as_uint(t.d2[i]);
@@ -1902,15 +1908,15 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     double e_acc = 0.0;
     // ties at the threshold are taken in index order (as icp_refine does, there with an ordered scan per
     // sweep of the cloud): one ballot per sweep, the per-(sweep, wave) counts scanned once by wave 0
-    const bool ranked = a.max_corr2 < 0.f && thr_key != 0xFFFFFFFFu;
+    const bool ranked = (TRIM_ONLY || a.max_corr2 < 0.f) && thr_key != 0xFFFFFFFFu;
     // the usual case: every key equal to the threshold is taken (one such key, the k-th itself) -- no ranking
     const bool all_ties = ranked && ties_to_take >= s_sel_nties;
-    unsigned before[kPiR];
+    unsigned before[PIR];
 #pragma unroll
-    for (int r = 0; r < kPiR; ++r) before[r] = 0u;
+    for (int r = 0; r < PIR; ++r) before[r] = 0u;
     if (ranked && !all_ties) {
 #pragma unroll
-      for (int r = 0; r < kPiR; ++r) {
+      for (int r = 0; r < PIR; ++r) {
         const int i = r * kIcpThreads + tid;
         const bool tie = i < a.n_src && __float_as_uint(t.d2[i]) == thr_key;
         const unsigned long long bm = __ballot(tie);
@@ -1919,7 +1925,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       }
       __syncthreads();
       if (wave == 0) {   // exclusive scan of the 64 counts in (sweep, wave) order = index order
-        const unsigned v = s_tie[lane];
+        const unsigned v = lane < PIR * (kIcpThreads / 64) ? s_tie[lane] : 0u;
         unsigned incl = v;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -1931,7 +1937,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       __syncthreads();
     }
 #pragma unroll
-    for (int r = 0; r < kPiR; ++r) {
+    for (int r = 0; r < PIR; ++r) {
       const int i = r * kIcpThreads + tid;
       if (r * kIcpThreads >= a.n_src) break;
       unsigned key = 0xFFFFFFFFu;
@@ -1941,7 +1947,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
         key = __float_as_uint(d2);
       }
       bool sel;
-      if (a.max_corr2 >= 0.f) {
+      if (!TRIM_ONLY && a.max_corr2 >= 0.f) {
         sel = i < a.n_src && d2 <= a.max_corr2;
       } else if (!ranked) {
         sel = i < a.n_src;
@@ -2018,7 +2024,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;
       if (red[0] < 1.0) go = false;
       // (the TrimmedICP form has none of the extra rules: no call, no spills around it)
-      if ((a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0) &&
+      if (!TRIM_ONLY && (a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0) &&
           converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old))
         go = false;
       s_continue = go ? 1 : 0;
@@ -2028,14 +2034,14 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
     ++it;
     if (!s_continue) break;
   }
-  if (s_lost) {
+  if (CLUSTER && s_lost) {
     // a partner never arrived (another process holding the GPU's CUs): this call's transforms are not to be
     // trusted.  The flag lives in the library's workspace; the repair launch that follows every clustered launch
     // sees it and runs all poses again from their saved initial transforms, one workgroup per pose.
     if (tid == 0) __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return;
   }
-  if (part != 0) return;
+  if (CLUSTER && part != 0) return;
   if (tid < 16) Tg[tid] = s_G[tid];
   if (tid == 0) {
 #if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 4
@@ -2061,6 +2067,32 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
 }
 
 }  // namespace
+
+// The instantiations of icp_persist_index.  Point-to-point with the image in LDS (the hot ones) exist per
+// (several workgroups per pose, TrimmedICP form, points per thread 2 / 3 / 4); point-to-plane and the image read
+// from L2 in the general form only.
+constexpr int kPersistKernels = 18;
+static const void* persist_kernel_at(int k) {
+#define PGP_PK(M, I, C, T, R) reinterpret_cast<const void*>(icp_persist_index<M, I, C, T, R>)
+  static const void* const tab[kPersistKernels] = {
+      PGP_PK(0, true, false, false, 2), PGP_PK(0, true, false, false, 3), PGP_PK(0, true, false, false, 4),
+      PGP_PK(0, true, false, true, 2),  PGP_PK(0, true, false, true, 3),  PGP_PK(0, true, false, true, 4),
+      PGP_PK(0, true, true, false, 2),  PGP_PK(0, true, true, false, 3),  PGP_PK(0, true, true, false, 4),
+      PGP_PK(0, true, true, true, 2),   PGP_PK(0, true, true, true, 3),   PGP_PK(0, true, true, true, 4),
+      PGP_PK(1, true, false, false, 4), PGP_PK(1, true, true, false, 4),
+      PGP_PK(0, false, false, false, 4), PGP_PK(0, false, true, false, 4),
+      PGP_PK(1, false, false, false, 4), PGP_PK(1, false, true, false, 4)};
+#undef PGP_PK
+  return tab[k];
+}
+static const void* persist_kernel(int metric, bool img_lds, bool cluster, bool trim_only, int n_src) {
+  if (metric != 1 && img_lds) {
+    const int r = n_src <= 2 * kIcpThreads ? 0 : (n_src <= 3 * kIcpThreads ? 1 : 2);
+    return persist_kernel_at((cluster ? 6 : 0) + (trim_only ? 3 : 0) + r);
+  }
+  if (metric == 1 && img_lds) return persist_kernel_at(cluster ? 13 : 12);
+  return persist_kernel_at(14 + (metric == 1 ? 2 : 0) + (cluster ? 1 : 0));
+}
 
 // Builds the exact index of the target in ctx->d_icp_grid (image | counters | starts | keys) when its
 // image fits one workgroup's LDS.  *fits = false (and PGP_OK): the caller keeps the exhaustive search.
@@ -2304,10 +2336,10 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const void* big[] = {reinterpret_cast<const void*>(icp_nn_index<true>), reinterpret_cast<const void*>(icp_nn_index<false>),
-                         reinterpret_cast<const void*>(icp_persist_index<0, true>), reinterpret_cast<const void*>(icp_persist_index<1, true>),
-                         reinterpret_cast<const void*>(icp_persist_index<0, false>), reinterpret_cast<const void*>(icp_persist_index<1, false>)};
+    const void* big[] = {reinterpret_cast<const void*>(icp_nn_index<true>), reinterpret_cast<const void*>(icp_nn_index<false>)};
     for (const void* f : big) PGP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    for (int v = 0; v < kPersistKernels; ++v)
+      PGP_HIP(hipFuncSetAttribute(persist_kernel_at(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
     ctx->icp_attr_set = true;
   }
   if (persist_index) {
@@ -2319,10 +2351,9 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     }
     const bool il = a.nn_image_in_lds != 0;
     const size_t plds = nn_lds_bytes(a.nn.bytes, n_src, il);
-    const void* fn = a.metric == 1 ? (il ? reinterpret_cast<const void*>(icp_persist_index<1, true>)
-                                         : reinterpret_cast<const void*>(icp_persist_index<1, false>))
-                                   : (il ? reinterpret_cast<const void*>(icp_persist_index<0, true>)
-                                         : reinterpret_cast<const void*>(icp_persist_index<0, false>));
+    const bool trim_only = !(a.max_corr2 >= 0.f) && !(a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0);
+    const void* fn = persist_kernel(a.metric, il, false, trim_only, n_src);
+    const void* fn_cluster = persist_kernel(a.metric, il, true, trim_only, n_src);
     // Few poses: 2 or 4 workgroups per pose share the search (64 poses alone would use 64 of the 256 CUs).  They
     // meet once per iteration, so all of them must be resident at once: a COOPERATIVE launch (the runtime checks
     // that the grid fits and keeps such launches from interleaving), one workgroup per CU.  Not while the stream
@@ -2357,7 +2388,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
       PGP_HIP(hipMemsetAsync(a.x_ctr, 0, ctr_words * 4, stream));
       void* params[] = {&a};
-      hipError_t e = hipLaunchCooperativeKernel(fn, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
+      hipError_t e = hipLaunchCooperativeKernel(fn_cluster, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG"))
         fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
       if (e == hipSuccess) {
