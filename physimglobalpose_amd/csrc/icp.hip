@@ -462,6 +462,20 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
   return ((r0 + r1) + r2) + r3;
 }
 
+// Inclusive prefix sum over the 64 lanes on the DPP path: four row_shr steps inside the rows of 16, then the row
+// totals are carried by row_bcast15 (rows 1, 3) and row_bcast31 (rows 2, 3) -- six additions, no LDS.  (__shfl_up
+// is a ds_bpermute round trip per step; the scans of the query sort and of the selection sit between barriers
+// where nothing hides it.)
+__device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast15 into rows 1 and 3
+  v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast31 into rows 2 and 3
+  return v;
+}
+
 // SPLIT = false: persistent kernel, all iterations of one pose in one workgroup (many poses).
 // SPLIT = true : one iteration's selection + update for one pose; the correspondences were
 //                produced by icp_nn_split over many workgroups (few poses: a single pose would
@@ -1461,12 +1475,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     const unsigned c0 = w.x & 0xFFFFu, c1 = w.x >> 16, c2 = w.y & 0xFFFFu, c3 = w.y >> 16, c4 = w.z & 0xFFFFu, c5 = w.z >> 16,
                    c6 = w.w & 0xFFFFu, c7 = w.w >> 16;
     const unsigned mine = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
-    unsigned incl = mine;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const unsigned o = __shfl_up(incl, off, 64);
-      if ((tid & 63) >= off) incl += o;
-    }
+    const unsigned incl = wave_scan_incl_u32(mine);
     if ((tid & 63) == 63) sch->wave_sum[tid >> 6] = incl;
     __syncthreads();
     unsigned base = 0;
@@ -1792,12 +1801,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
       __syncthreads();
       const uint4 hv = reinterpret_cast<const uint4*>(hist)[tid];
       const unsigned mine = hv.x + hv.y + hv.z + hv.w;
-      unsigned incl = mine;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const unsigned tt = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += tt;
-      }
+      const unsigned incl = wave_scan_incl_u32(mine);
       if (lane == 63) s_scan[wave] = incl;
       __syncthreads();
       {
