@@ -68,12 +68,16 @@ def algorithmic_bytes_per_hypothesis(n_scene, n_model, mode):
 
 
 def kernel_source_id():
-    """sha256[:16] over the sources that define the scoring kernel and its index: the PMC counters
+    """sha256[:16] over the sources that define the scoring kernel and its index AND their compiler flags: the PMC counters
     in profiles/pmc_current.json are only used when they were collected on this very code."""
     import hashlib
     h = hashlib.sha256()
     for f in ("lcp_score.hip", "grid_index.hip", "pgp_internal.h"):
         h.update(open(os.path.join(ROOT, "physimglobalpose_amd", "csrc", f), "rb").read())
+    # ... and the flags they are compiled with (the FLAGS line of the Makefile: -O level, -ffp-contract, arch)
+    for line in open(os.path.join(ROOT, "physimglobalpose_amd", "csrc", "Makefile")):
+        if line.startswith("FLAGS") or line.startswith("ARCH"):
+            h.update(line.strip().encode())
     return h.hexdigest()[:16]
 
 

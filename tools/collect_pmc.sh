@@ -53,6 +53,9 @@ for k, d in agg.items():
 h = hashlib.sha256()
 for f in ("lcp_score.hip", "grid_index.hip", "pgp_internal.h"):
     h.update(open(os.path.join(repo, "physimglobalpose_amd", "csrc", f), "rb").read())
+for line in open(os.path.join(repo, "physimglobalpose_amd", "csrc", "Makefile")):   # same rule as bench.py kernel_source_id()
+    if line.startswith("FLAGS") or line.startswith("ARCH"):
+        h.update(line.strip().encode())
 try:
     import valu_mix
     text = open(out + "/lcp_score.s").read()
