@@ -2,8 +2,8 @@
 //
 // north_star / SURVEY 8(e): hypotheses are independent, so the batch is block-partitioned over the
 // devices (clouds + index replicated on each), every device scores its contiguous slice into a
-// zero-initialised full-length vector, ONE RCCL all-reduce(sum) over xGMI leaves every device with
-// all scores (and counts), and the arg-max -- with the exact near-tie settlement of lcp_score.hip --
+// zero-initialised full-length vector, ONE RCCL all-reduce(integer sum over {scores | counts}) over xGMI leaves
+// every device with all scores and counts, and the arg-max -- with the exact near-tie settlement of lcp_score.hip --
 // is taken on device 0.  The consumers are the per-object loops of the node
 // (PPE/data_layer/SceneCfg.cpp:376-406 -> ObjectPoseCandidateSet.cpp:66-68) and the score readers of
 // the search (PPE/hypothesis_verification/HypothesisSelection.cpp:248-257): they get the same
@@ -159,21 +159,16 @@ struct pgp_multi {
 
 namespace {
 
-// out[i] = sum over members of in[k][i]: floats for the scores, ints for the counts (every element is
-// non-zero in at most one member, so the order of the additions cannot matter -- as in the RCCL sum)
+// out[i] = sum over members of in[k][i] over the 2 n_h 32-bit words {scores | counts}, as INTEGERS -- what the one
+// RCCL all-reduce of the production path computes (every element is non-zero in at most one member, so the sum of
+// the bit patterns is that member's pattern, for the float scores too)
 __global__ __launch_bounds__(256) void emulate_sum(const float* const* __restrict__ in, int n_members, int n_h,
                                                    float* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * n_h) return;
-  if (i < n_h) {
-    float s = 0.f;
-    for (int k = 0; k < n_members; ++k) s += in[k][i];
-    out[i] = s;
-  } else {
-    int s = 0;
-    for (int k = 0; k < n_members; ++k) s += reinterpret_cast<const int*>(in[k])[i];
-    reinterpret_cast<int*>(out)[i] = s;
-  }
+  int s = 0;
+  for (int k = 0; k < n_members; ++k) s += reinterpret_cast<const int*>(in[k])[i];
+  reinterpret_cast<int*>(out)[i] = s;
 }
 
 int run_all(pgp_multi* m, const std::function<int(int)>& fn) {
@@ -459,12 +454,14 @@ int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scor
     });
     if (rc != PGP_OK) return rc;
   } else if (m->use_coll && n_h > 0) {
+    // ONE all-reduce per call over the 8 n_h bytes {scores | counts}, summed as 32-bit integers: every element is
+    // non-zero on exactly one member (its owner) and all-zero bits elsewhere, and x + 0 + ... + 0 over the BIT
+    // PATTERNS returns x's pattern -- exact for the float scores too (scores are >= +0: no -0, no NaN).  At 4096
+    // hypotheses the exchange is latency-bound (32 KB per member), so two collectives cost twice what one does.
     ncclResult_t nr = m->rccl.GroupStart();
     for (int k = 0; k < m->n && nr == ncclSuccess; ++k) {
       float* d_s = m->d_all[k].as<float>();
-      nr = m->rccl.AllReduce(d_s, d_s, (size_t)n_h, ncclFloat32, ncclSum, m->comm[k], m->stream[k]);
-      if (nr == ncclSuccess)
-        nr = m->rccl.AllReduce(d_s + n_h, d_s + n_h, (size_t)n_h, ncclInt32, ncclSum, m->comm[k], m->stream[k]);
+      nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)n_h, ncclInt32, ncclSum, m->comm[k], m->stream[k]);
     }
     ncclResult_t ge = m->rccl.GroupEnd();
     if (nr == ncclSuccess) nr = ge;

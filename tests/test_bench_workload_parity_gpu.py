@@ -4,9 +4,13 @@ distinct batches in rotation) and, for the configs[2] row, make_workload(50 000,
 hypothesis of both is scored by the C oracle (OpenMP, the restatement of base.cc:1699-1766 pinned on the reference's kd-tree)
 and compared with the HIP path through the C ABI:
   plain    Verify          : scores bit-exact, best index per batch identical
-  weighted WeightedVerify  : scores within 2e-6 (bar of north_star: 1e-4), best index per batch identical under the
-                             reference's strict `>` walk (base.cc:1891-1901), and the
-                             registered scene ids of each batch's winner identical."""
+  weighted WeightedVerify  : with pgp_set_exact_ties (the reference's kd-tree rule on EXACT float distance ties,
+                             kdtree.h:424) every score within 2e-6 (bar of north_star: 1e-4), best index per batch
+                             identical under the reference's strict `>` walk (base.cc:1891-1901), the registered scene
+                             ids of each batch's winner identical; with the default rule (lowest scene index) the
+                             same except for the hypotheses in which such a tie occurs -- ONE of the 32 768 of the
+                             bench batches (batch 3, hypothesis 272: model point 3584 is 1.3374e-05 m^2 from scene
+                             points 29369 and 41995 alike), moved by one point's weight / |Q| = 1.5e-4."""
 import os
 
 import numpy as np
@@ -20,38 +24,63 @@ THREADS = max(1, min(16, os.cpu_count() or 1))
 
 
 def _full_parity(w, batch):
-    sc = LcpScorer()
-    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    """Returns (largest weighted deviation with exact ties on, hypotheses the DEFAULT tie rule moves)."""
     orc = Oracle(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm)
     n = len(w.T)
     assert n % batch == 0
-    worst = 0.0
+    # the oracle once (the C restatement on the box's host cores: ~2 s per mode for 32 768 hypotheses)
+    ref = []
     for b in range(n // batch):
         T = w.T[b * batch:(b + 1) * batch]
-        # plain
-        s, c, bi, bs = sc.score(T, PGP_MODE_PLAIN)
         so, bio, _ = orc.score_batch(T, w.delta, mode=0, threads=THREADS)
-        assert np.array_equal(s, so), (b, int((s != so).sum()))
-        assert bi == bio and bs == so[bio]
-        assert np.array_equal(c, np.rint(so.astype(np.float64) * len(w.Q_xyz)).astype(np.int32))
-        # weighted
-        sw, cw, biw, bsw = sc.score(T, PGP_MODE_WEIGHTED, w.gate_deg)
         swo, biwo, _ = orc.score_batch(T, w.delta, mode=1, gate_deg=w.gate_deg, threads=THREADS)
-        err = float(np.abs(sw.astype(np.float64) - swo).max())
-        worst = max(worst, err)
-        assert err <= 2e-6, (b, err)
-        assert biw == biwo, (b, biw, biwo, sw[biw], swo[biwo])
-        assert abs(float(bsw) - float(swo[biwo])) <= 2e-6   # (bit-exact when a runner-up forced the settlement)
-        ws, reg = orc.weighted_verify(T[biw], w.delta, w.gate_deg)
-        assert np.array_equal(sc.registered(T[biw], PGP_MODE_WEIGHTED, w.gate_deg), reg) and cw[biw] == len(reg)
-    return worst
+        ref.append((so, bio, swo, biwo))
+    worst, moved = 0.0, []
+    for exact_ties in (False, True):
+        sc = LcpScorer()
+        sc.set_exact_ties(exact_ties)
+        sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+        for b in range(n // batch):
+            T = w.T[b * batch:(b + 1) * batch]
+            so, bio, swo, biwo = ref[b]
+            # plain: an inlier is an inlier whichever of two equidistant scene points registers it
+            s, c, bi, bs = sc.score(T, PGP_MODE_PLAIN)
+            assert np.array_equal(s, so), (b, int((s != so).sum()))
+            assert bi == bio and bs == so[bio]
+            assert np.array_equal(c, np.rint(so.astype(np.float64) * len(w.Q_xyz)).astype(np.int32))
+            # weighted
+            sw, cw, biw, bsw = sc.score(T, PGP_MODE_WEIGHTED, w.gate_deg)
+            err = np.abs(sw.astype(np.float64) - swo)
+            off = np.flatnonzero(err > 2e-6)
+            if exact_ties:
+                # the reference's kd-tree tie rule reproduced: every hypothesis within the summation-order bound
+                assert len(off) == 0, (b, off[:8], err[off[:8]])
+                worst = max(worst, float(err.max()))
+                assert biw == biwo, (b, biw, biwo, sw[biw], swo[biwo])
+            else:
+                # default rule (lowest scene index on EXACT float distance ties, DESIGN section 2 divergence (i)): a tie
+                # hands one model point to another scene point -- at most one point's weight per tied point
+                assert (err[off] <= 2.0 / len(w.Q_xyz)).all(), (b, off, err[off])
+                moved += [(b, int(i)) for i in off]
+                if biw != biwo:
+                    assert biwo in off or biw in off, (b, biw, biwo)      # only a tie may move the winner
+            if biw == biwo:
+                assert abs(float(bsw) - float(swo[biwo])) <= (2e-6 if exact_ties or biw not in off else 2.0 / len(w.Q_xyz))
+                ws, reg = orc.weighted_verify(T[biw], w.delta, w.gate_deg)
+                mine = sc.registered(T[biw], PGP_MODE_WEIGHTED, w.gate_deg)
+                if exact_ties or biw not in off:
+                    assert np.array_equal(mine, reg) and cw[biw] == len(reg)
+    # exact float ties are a one-in-2^24 event per (hypothesis, model point with two scene points within delta)
+    assert len(moved) <= max(4, n // 4096)
+    return worst, moved
 
 
 def test_every_hypothesis_of_the_bench_batches():
     """8 x 4096 hypotheses = what `python bench.py` rotates through at N = 1."""
     w = synth.make_workload(50000, 5000, 4096 * 8, config_id=2)
-    worst = _full_parity(w, 4096)
-    print(f"weighted: largest |gpu - oracle| over 32 768 hypotheses = {worst:.3e}")
+    worst, moved = _full_parity(w, 4096)
+    print(f"weighted: largest |gpu - oracle| over 32 768 hypotheses with pgp_set_exact_ties = {worst:.3e}; "
+          f"hypotheses the default tie rule moves: {moved}")
 
 
 def test_every_hypothesis_of_the_config2_object_batch():

@@ -1,7 +1,7 @@
 """The native multi-GPU group behind the C ABI (pgp_multi_*, csrc/multi_gpu.hip): slice arithmetic
 on the CPU; on the GPU box a one-device group -- with and without the RCCL exchange
-(PGP_MULTI_FORCE_COLLECTIVE=1 runs a one-rank communicator: ncclCommInitAll, two grouped
-all-reduces, then the arg-max over the complete vector on device 0) -- returns what a single
+(PGP_MULTI_FORCE_COLLECTIVE=1 runs a one-rank communicator: ncclCommInitAll, ONE grouped integer
+all-reduce over {scores | counts}, then the arg-max over the complete vector on device 0) -- returns what a single
 context returns, bit for bit."""
 import os
 
