@@ -331,15 +331,45 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * iterations are driven from the host (many workgroups per pose) and the call synchronises the
  * stream every four iterations to test for convergence.  While few poses are in flight (n x 4 or
  * n x 2 <= the device's compute units) that ONE launch is cooperative, with 4 or 2 workgroups per pose
- * sharing the search (not on a stream that is being captured; PGP_ICP_WGS=1 switches it off); should
- * the workgroups of a pose ever fail to meet (another process spinning on the same GPU), its iters entry
- * reads -1 and its transform is unchanged; the host-pointer call then runs once more with one workgroup
- * per pose.  Clustered launches of one process never overlap on a device.  Checker paths, same results:
+ * sharing the search (not on a stream that is being captured; PGP_ICP_WGS=1 switches it off), followed by a
+ * repair launch that does nothing unless the workgroups of a pose failed to meet (another process spinning on
+ * the same GPU): it then refines every pose again from its initial transform, one workgroup per pose -- the
+ * caller always receives refined transforms, with or without d_iters.  Clustered launches of one process never
+ * overlap on a device.  Checker paths, same results:
  * PGP_ICP_NN=scan (exhaustive search), PGP_ICP_PERSIST=0 (index, host-driven iterations),
  * PGP_ICP_SPLIT=0/1 (the exhaustive persistent / host-driven kernels). */
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,
                           float* d_T, int n, const pgp_icp_params* params, float* d_energy,
                           int* d_iters, void* stream);
+
+/* SEVERAL (segment, target) pairs refined by ONE launch: the children of an MCTS expansion belong to different objects
+ * (PPE/hypothesis_verification/mcts/UCTSearch.cpp:200-266 -> UCTState.cpp:121-204) and the node's object loop
+ * (PPE/data_layer/SceneCfg.cpp:379-402) refines the candidates of every object of a frame -- through
+ * pgp_icp_refine_device that is one launch per object, each wanting the whole chip.  Every job names the context
+ * that keeps its target's index (pgp_icp_target_token applies per context), its clouds and its own transform /
+ * energy / iteration arrays; all contexts on one device.  Results are bit-identical to one pgp_icp_refine_device
+ * call per job -- which is also what happens when the single launch cannot serve the jobs (more than 8 of them, a
+ * target whose index does not fit a compute unit's LDS, a segment beyond 4096 points).  Enqueued on `stream`. */
+typedef struct {
+  pgp_ctx* ctx;
+  const float* d_src4;   /* float4 {x,y,z,-} [n_src] */
+  int n_src;
+  const float* d_tgt4;   /* float4 {x,y,z,-} [n_tgt] */
+  int n_tgt;
+  float* d_T;            /* [n][16] in/out */
+  int n;
+  float* d_energy;       /* [n], nullable */
+  int* d_iters;          /* [n], nullable */
+} pgp_icp_job;
+int pgp_icp_refine_multi_device(const pgp_icp_job* jobs, int n_jobs, const pgp_icp_params* params, void* stream);
+
+/* The k best-scoring hypotheses of a scored batch, in HBM: d_T_out[k][16] = their transforms in descending score
+ * order (equal scores: lower index first -- a stable argsort of -score), inverted as rigid transforms {R^T, -R^T t}
+ * when invert != 0 (UCTState.cpp:184-185 hands `pose.inverse()` to ICP); d_index_out[k] (nullable) = their indices,
+ * *d_n_out = how many of the k have a score > 0 (the rest: index -1, identity).  The hand-off
+ * HypothesisSelection.cpp:248-257 -> UCTState::performTrICP without a trip to the host.  Enqueued on `stream`. */
+int pgp_select_top_device(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n, int k, int invert,
+                          float* d_T_out, int* d_index_out, int* d_n_out, void* stream);
 
 /* The index over the target is built per call unless the caller vouches that the target has not
  * changed: after pgp_icp_target_token(ctx, token != 0), *_device calls with the same (d_tgt pointer,

@@ -37,6 +37,11 @@ class IcpOptions(C.Structure):
                 ("min_diff_trans", C.c_float), ("smooth_length", C.c_int), ("nn_search", C.c_int)]
 
 
+class IcpJob(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("d_src4", C.c_void_p), ("n_src", C.c_int), ("d_tgt4", C.c_void_p), ("n_tgt", C.c_int),
+                ("d_T", C.c_void_p), ("n", C.c_int), ("d_energy", C.c_void_p), ("d_iters", C.c_void_p)]
+
+
 class Camera(C.Structure):
     _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
                 ("cy", C.c_float), ("z_near", C.c_float), ("z_max", C.c_float)]
@@ -90,6 +95,9 @@ SIGNATURES = {
                                         C.c_int, C.POINTER(IcpParams), C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_icp_default_options": (C.c_int, [C.POINTER(IcpOptions)]),
     "pgp_icp_target_token": (C.c_int, [C.c_void_p, C.c_ulonglong]),
+    "pgp_icp_refine_multi_device": (C.c_int, [C.POINTER(IcpJob), C.c_int, C.POINTER(IcpParams), C.c_void_p]),
+    "pgp_select_top_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "pgp_set_scene_weights": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_unexplained_segment": (C.c_int, [C.c_void_p, _f, C.c_int, _f, _i, _f, C.c_int, C.c_float, C.c_char_p, _i]),
     "pgp_multi_set_scene_weights": (C.c_int, [C.c_void_p, _f, C.c_int]),

@@ -1654,7 +1654,7 @@ constexpr int kSelRank = 512;   // keys of the threshold's 12-bit bin that are r
 // PIR: source points per thread (n_src <= PIR x 1024): every per-thread array of the search's phase A, of the
 // selection and of the sums has PIR entries -- a 1756-point segment takes PIR = 2 and half the registers of PIR = 4.
 template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR>
-__global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
+__device__ __forceinline__ void icp_persist_body(const IcpArgs& a) {
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_red[(kIcpThreads / 64) * (kRedPlane + 1)];
   __shared__ float s_G[16];
@@ -2070,6 +2070,53 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   }
 }
 
+template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR>
+__global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
+  icp_persist_body<METRIC, IMG_LDS, CLUSTER, TRIM_ONLY, PIR>(a);
+}
+
+// SEVERAL (source, target) pairs in ONE launch: the children of an MCTS expansion belong to different objects
+// (UCTSearch.cpp:200-266 -> UCTState.cpp:121-204), and the node's per-object loop (SceneCfg.cpp:379-402) refines
+// the candidates of every object of a frame -- 3 x 64 poses are three cooperative launches one after the other
+// through the single-target entry, or 192 workgroups of one launch here.  Workgroup = one pose; its target (index
+// image, geometry, vicinity graph), its segment and its slice of the transform / energy / iteration arrays come
+// from the descriptor of the pose's job -- a table that travels in the kernel arguments (no upload, no sync).
+constexpr int kIcpMultiMax = 8;
+struct IcpTarget {
+  const float4* src;
+  const unsigned char* nn_image;
+  const uint4* nn_vic;
+  float* T;              // the job's arrays, offset so that the launch-wide pose number indexes them
+  float* energy;
+  int* iters;
+  NnGeom nn;
+  int n_src, n_tgt, k_trim, pad;
+};
+struct IcpMulti {
+  int n_jobs;
+  int first[kIcpMultiMax + 1];   // poses [first[j], first[j + 1]) belong to job j
+  IcpTarget tg[kIcpMultiMax];
+};
+template <bool TRIM_ONLY, int PIR>
+__global__ __launch_bounds__(kIcpThreads) void icp_persist_multi(IcpArgs a, IcpMulti mt) {
+  const int pose = (int)blockIdx.x;
+  int j = 0;
+  for (int k = 1; k < mt.n_jobs; ++k) j = pose >= mt.first[k] ? k : j;   // uniform: scalar loads and compares
+  const IcpTarget& tg = mt.tg[j];
+  IcpArgs b = a;
+  b.src = tg.src;
+  b.nn_image = tg.nn_image;
+  b.nn_vic = tg.nn_vic;
+  b.T = tg.T;
+  b.energy = tg.energy;
+  b.iters = tg.iters;
+  b.nn = tg.nn;
+  b.n_src = tg.n_src;
+  b.n_tgt = tg.n_tgt;
+  b.k_trim = tg.k_trim;
+  icp_persist_body<0, true, false, TRIM_ONLY, PIR>(b);
+}
+
 }  // namespace
 
 // The instantiations of icp_persist_index.  Point-to-point with the image in LDS (the hot ones) exist per
@@ -2096,6 +2143,30 @@ static const void* persist_kernel(int metric, bool img_lds, bool cluster, bool t
   }
   if (metric == 1 && img_lds) return persist_kernel_at(cluster ? 13 : 12);
   return persist_kernel_at(14 + (metric == 1 ? 2 : 0) + (cluster ? 1 : 0));
+}
+
+static const void* multi_kernel(bool trim_only, int pir) {
+  static const void* const tab[6] = {
+      reinterpret_cast<const void*>(icp_persist_multi<false, 2>), reinterpret_cast<const void*>(icp_persist_multi<false, 3>),
+      reinterpret_cast<const void*>(icp_persist_multi<false, 4>), reinterpret_cast<const void*>(icp_persist_multi<true, 2>),
+      reinterpret_cast<const void*>(icp_persist_multi<true, 3>),  reinterpret_cast<const void*>(icp_persist_multi<true, 4>)};
+  return tab[(trim_only ? 3 : 0) + (pir <= 2 ? 0 : (pir == 3 ? 1 : 2))];
+}
+
+// dynamic-LDS limits of the ICP kernels: per context = per device (function attributes are per device)
+static int ensure_icp_attrs(pgp_ctx* ctx) {
+  if (ctx->icp_attr_set) return PGP_OK;
+  const size_t lds = (size_t)kTgtTile * sizeof(float4);
+  PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const void* big[] = {reinterpret_cast<const void*>(icp_nn_index<true>), reinterpret_cast<const void*>(icp_nn_index<false>)};
+  for (const void* f : big) PGP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+  for (int v = 0; v < kPersistKernels; ++v)
+    PGP_HIP(hipFuncSetAttribute(persist_kernel_at(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+  for (int v = 0; v < 6; ++v)
+    PGP_HIP(hipFuncSetAttribute(multi_kernel(v >= 3, 2 + v % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+  ctx->icp_attr_set = true;
+  return PGP_OK;
 }
 
 // Builds the exact index of the target in ctx->d_icp_grid (image | counters | starts | keys) when its
@@ -2235,6 +2306,35 @@ struct CoopChain {
 CoopChain g_coop;
 }  // namespace
 
+// the options of a call (pgp_icp_options) as kernel arguments; k_trim = the trimmed count of a cloud of n_src points
+static int icp_trim_count(const pgp_icp_options* prm, int n_src) {
+  float tf = prm->trim_fraction;
+  if (!(tf > 0.f) || tf > 1.f) tf = 1.f;
+  // float numPoints = trim * size; align(..., abs(numPoints), ...) -> int (UCTState.cpp:176,194)
+  int k = (int)fabsf(tf * (float)n_src);
+  if (k < 1) k = 1;
+  if (k > n_src) k = n_src;
+  return k;
+}
+static void icp_option_args(const pgp_icp_options* prm, int n_src, IcpArgs* a) {
+  a->max_iter = prm->max_iterations > 0 ? prm->max_iterations : 100;
+  a->k_trim = icp_trim_count(prm, n_src);
+  a->max_corr2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : -1.f;
+  a->ratio = prm->energy_ratio;            // <= 0: the energy-ratio test is off
+  a->metric = prm->error_metric;
+  a->t_eps = prm->transformation_epsilon;  // < 0: off
+  a->rel_mse = prm->relative_mse;
+  a->abs_mse = prm->absolute_mse;
+  a->diff_rot = prm->min_diff_rot;
+  a->diff_trans = prm->min_diff_trans;
+  a->smooth = (prm->min_diff_rot > 0.f && prm->min_diff_trans > 0.f)
+                  ? (prm->smooth_length < 1 ? 1 : (prm->smooth_length > kMaxSmooth ? kMaxSmooth : prm->smooth_length))
+                  : 0;
+}
+static bool icp_trim_only(const IcpArgs& a) {
+  return !(a.max_corr2 >= 0.f) && !(a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0);
+}
+
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
                unsigned long long tgt_token) {
@@ -2270,25 +2370,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.n_tgt = n_tgt;
   a.T = d_T;
   a.n = n;
-  a.max_iter = prm->max_iterations > 0 ? prm->max_iterations : 100;
-  float tf = prm->trim_fraction;
-  if (!(tf > 0.f) || tf > 1.f) tf = 1.f;
-  // float numPoints = trim * size; align(..., abs(numPoints), ...) -> int (UCTState.cpp:176,194)
-  int k = (int)fabsf(tf * (float)n_src);
-  if (k < 1) k = 1;
-  if (k > n_src) k = n_src;
-  a.k_trim = k;
-  a.max_corr2 = prm->max_corr_dist > 0.f ? prm->max_corr_dist * prm->max_corr_dist : -1.f;
-  a.ratio = prm->energy_ratio;            // <= 0: the energy-ratio test is off
-  a.metric = prm->error_metric;
-  a.t_eps = prm->transformation_epsilon;  // < 0: off
-  a.rel_mse = prm->relative_mse;
-  a.abs_mse = prm->absolute_mse;
-  a.diff_rot = prm->min_diff_rot;
-  a.diff_trans = prm->min_diff_trans;
-  a.smooth = (prm->min_diff_rot > 0.f && prm->min_diff_trans > 0.f)
-                 ? (prm->smooth_length < 1 ? 1 : (prm->smooth_length > kMaxSmooth ? kMaxSmooth : prm->smooth_length))
-                 : 0;
+  icp_option_args(prm, n_src, &a);
   int rc;
   size_t need = (size_t)n * n_src;
   // measured (tools/icp_time.py, 2500 x 5000, 10 iterations): the split path wins at every batch
@@ -2335,17 +2417,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.energy = d_energy;
   a.iters = d_iters;
   const size_t lds = (size_t)kTgtTile * sizeof(float4);
-  if (!ctx->icp_attr_set) {  // per context = per device (function attributes are per device)
-    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const void* big[] = {reinterpret_cast<const void*>(icp_nn_index<true>), reinterpret_cast<const void*>(icp_nn_index<false>)};
-    for (const void* f : big) PGP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    for (int v = 0; v < kPersistKernels; ++v)
-      PGP_HIP(hipFuncSetAttribute(persist_kernel_at(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-    ctx->icp_attr_set = true;
-  }
+  if ((rc = ensure_icp_attrs(ctx)) != PGP_OK) return rc;
   if (persist_index) {
     // everything of an iteration lives in LDS: the workspace holds the pointmatcher history only
     if (a.smooth > 0) {
@@ -2355,7 +2427,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     }
     const bool il = a.nn_image_in_lds != 0;
     const size_t plds = nn_lds_bytes(a.nn.bytes, n_src, il);
-    const bool trim_only = !(a.max_corr2 >= 0.f) && !(a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0);
+    const bool trim_only = icp_trim_only(a);
     const void* fn = persist_kernel(a.metric, il, false, trim_only, n_src);
     const void* fn_cluster = persist_kernel(a.metric, il, true, trim_only, n_src);
     // Few poses: 2 or 4 workgroups per pose share the search (64 poses alone would use 64 of the 256 CUs).  They
@@ -2517,6 +2589,86 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     }
   }
   PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+
+// Several (segment, target) jobs in ONE launch (icp_persist_multi).  Falls back to one launch_icp per job whenever
+// the single launch cannot serve them all: a target whose index does not fit LDS, a segment beyond 4096 points,
+// the point-to-plane metric, the pointmatcher history, more than kIcpMultiMax jobs.  Same results either way.
+int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm, hipStream_t stream) {
+  if (n_jobs <= 0) return PGP_OK;
+  for (int j = 0; j < n_jobs; ++j) {
+    const IcpJob& q = jobs[j];
+    if (!q.ctx || q.n < 0 || (q.n > 0 && (!q.d_src || !q.d_tgt || !q.d_T || q.n_src <= 0 || q.n_tgt <= 0))) {
+      set_error("icp (multi): bad job %d", j);
+      return PGP_EINVAL;
+    }
+    if (q.ctx->device != jobs[0].ctx->device) {
+      set_error("icp (multi): the jobs' contexts live on different devices (%d, %d)", jobs[0].ctx->device, q.ctx->device);
+      return PGP_EINVAL;
+    }
+  }
+  IcpArgs a{};
+  icp_option_args(prm, 1, &a);
+  bool one_launch = n_jobs >= 2 && n_jobs <= kIcpMultiMax && a.metric == 0 && a.smooth == 0 && prm->nn_search != 1 &&
+                    prm->nn_search != 2 && !getenv("PGP_ICP_NN") && !getenv("PGP_ICP_PERSIST") && !getenv("PGP_ICP_SPLIT");
+  if (const char* v = getenv("PGP_ICP_MULTI")) one_launch = one_launch && atoi(v) != 0;   // A/B knob: 0 = job by job
+  IcpMulti mt{};
+  int total = 0, max_src = 0, rc;
+  size_t lds = 0;
+  for (int j = 0; j < n_jobs && one_launch; ++j) {
+    const IcpJob& q = jobs[j];
+    mt.first[j] = total;
+    if (q.n == 0) continue;
+    if (q.n_src > kPiR * kIcpThreads) {
+      one_launch = false;
+      break;
+    }
+    IcpArgs aj{};
+    bool fits = false;
+    if ((rc = build_nn_index(q.ctx, q.d_tgt, q.n_tgt, q.n_src, &aj, &fits, stream, q.token)) != PGP_OK) return rc;
+    if (!fits || !aj.nn_image_in_lds) {
+      one_launch = false;
+      break;
+    }
+    IcpTarget& tg = mt.tg[j];
+    tg.src = q.d_src;
+    tg.nn_image = aj.nn_image;
+    tg.nn_vic = aj.nn_vic;
+    tg.T = q.d_T - 16 * (ptrdiff_t)total;
+    tg.energy = q.d_energy ? q.d_energy - total : nullptr;
+    tg.iters = q.d_iters ? q.d_iters - total : nullptr;
+    tg.nn = aj.nn;
+    tg.n_src = q.n_src;
+    tg.n_tgt = q.n_tgt;
+    tg.k_trim = icp_trim_count(prm, q.n_src);
+    total += q.n;
+    max_src = q.n_src > max_src ? q.n_src : max_src;
+    const size_t l = nn_lds_bytes(aj.nn.bytes, q.n_src, true);
+    lds = l > lds ? l : lds;
+  }
+  if (one_launch && total > 0 && total <= 32768) {
+    mt.n_jobs = n_jobs;
+    for (int j = n_jobs; j <= kIcpMultiMax; ++j) mt.first[j] = total;
+    // (jobs without poses keep first[j] = first[j + 1]: no workgroup ever selects them)
+    for (int j = n_jobs - 1; j >= 0; --j)
+      if (jobs[j].n == 0) mt.first[j] = mt.first[j + 1];
+    a.n = total;
+    a.wgs_per_pose = 1;
+    a.energy = nullptr;   // per job, through the descriptor
+    if ((rc = ensure_icp_attrs(jobs[0].ctx)) != PGP_OK) return rc;
+    const int pir = max_src <= 2 * kIcpThreads ? 2 : (max_src <= 3 * kIcpThreads ? 3 : 4);
+    void* params[] = {&a, &mt};
+    PGP_HIP(hipLaunchKernel(multi_kernel(icp_trim_only(a), pir), dim3(total), dim3(kIcpThreads), params, lds, stream));
+    PGP_HIP(hipGetLastError());
+    return PGP_OK;
+  }
+  for (int j = 0; j < n_jobs; ++j) {
+    const IcpJob& q = jobs[j];
+    if ((rc = launch_icp(q.ctx, q.d_src, q.n_src, q.d_tgt, nullptr, q.n_tgt, q.d_T, q.n, prm, q.d_energy, q.d_iters, stream,
+                         q.token)) != PGP_OK)
+      return rc;
+  }
   return PGP_OK;
 }
 

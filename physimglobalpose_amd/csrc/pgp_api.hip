@@ -941,6 +941,41 @@ int pgp_icp_refine_ex_device(pgp_ctx* ctx, const float* d_src4, int n_src, const
   return rc;
 }
 
+int pgp_select_top_device(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n, int k, int invert,
+                          float* d_T_out, int* d_index_out, int* d_n_out, void* stream) {
+  if (!ctx || n < 0 || k < 0 || (k > 0 && (!d_T_out || !d_n_out)) || (n > 0 && (!d_T || !d_scores))) {
+    set_error("pgp_select_top_device: bad argument");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx, false);
+  const int rc = launch_select_top(ctx, d_T, d_scores, n, k, invert, d_T_out, d_index_out, d_n_out, static_cast<hipStream_t>(stream));
+  note_device_work(ctx, static_cast<hipStream_t>(stream));
+  return rc;
+}
+
+int pgp_icp_refine_multi_device(const pgp_icp_job* jobs, int n_jobs, const pgp_icp_params* params, void* stream) {
+  if (n_jobs < 0 || (n_jobs > 0 && !jobs) || !params) {
+    set_error("pgp_icp_refine_multi_device: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n_jobs == 0) return PGP_OK;
+  std::vector<IcpJob> v((size_t)n_jobs);
+  for (int j = 0; j < n_jobs; ++j) {
+    const pgp_icp_job& q = jobs[j];
+    if (!q.ctx || q.n < 0 || q.n_src < 0 || q.n_tgt < 0 || (q.n > 0 && (!q.d_src4 || !q.d_tgt4 || !q.d_T))) {
+      set_error("pgp_icp_refine_multi_device: bad job %d", j);
+      return PGP_EINVAL;
+    }
+    v[j] = IcpJob{q.ctx, reinterpret_cast<const float4*>(q.d_src4), q.n_src, reinterpret_cast<const float4*>(q.d_tgt4), q.n_tgt,
+                  q.d_T, q.n, q.d_energy, q.d_iters, q.ctx->icp_user_token};
+  }
+  const pgp_icp_options o = options_of(params);
+  CtxGuard guard(jobs[0].ctx, false);
+  const int rc = launch_icp_multi(v.data(), n_jobs, &o, static_cast<hipStream_t>(stream));
+  for (int j = 0; j < n_jobs; ++j) note_device_work(jobs[j].ctx, static_cast<hipStream_t>(stream));
+  return rc;
+}
+
 int pgp_icp_target_token(pgp_ctx* ctx, unsigned long long token) {
   if (!ctx) {
     set_error("pgp_icp_target_token: ctx is NULL");

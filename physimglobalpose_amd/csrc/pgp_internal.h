@@ -141,6 +141,7 @@ struct pgp_ctx {
 
   // ICP (host API staging + per-pose correspondence workspace)
   pgp::DevBuf d_icp_src, d_icp_tgt, d_icp_tgt_n, d_icp_T, d_icp_out, d_icp_ws, d_icp_grid;
+  pgp::DevBuf d_top_ws;      // select.hip: sort keys / indices / rocprim scratch of pgp_select_top_device
   pgp::DevBuf d_icp_x;       // clustered ICP: the workgroups' shares of (d2, correspondence), ping-pong + arrival counters
   int n_cus = 0;             // compute units of the device if it takes cooperative launches, else 0
   bool icp_attr_set = false;   // dynamic-LDS limit of the ICP kernels raised on this device
@@ -244,6 +245,23 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max);
 int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream_t stream);
 
 // icp.hip
+// select.hip
+int launch_select_top(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n, int k, int invert, float* d_T_out,
+                      int* d_idx_out, int* d_n_out, hipStream_t st);
+// one (segment, target) pair of a multi-target ICP launch (pgp_icp_refine_multi_device)
+struct IcpJob {
+  pgp_ctx* ctx;            // holds the target's index between calls
+  const float4* d_src;
+  int n_src;
+  const float4* d_tgt;
+  int n_tgt;
+  float* d_T;
+  int n;
+  float* d_energy;         // nullable
+  int* d_iters;            // nullable
+  unsigned long long token;
+};
+int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm, hipStream_t stream);
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
                unsigned long long tgt_token = 0);

@@ -514,6 +514,56 @@ class LcpScorer:
             C.c_void_p(d_energy.data_ptr()) if d_energy is not None else None,
             C.c_void_p(d_iters.data_ptr()) if d_iters is not None else None, C.c_void_p(stream)))
 
+    def select_top_device(self, d_T, d_scores, k, invert=True, d_T_out=None, d_index_out=None, d_n_out=None, stream=None):
+        """pgp_select_top_device: the k best-scoring transforms (descending score, ties: lower index), rigidly inverted
+        when `invert`, written to d_T_out (k,16); returns (d_T_out, d_index_out, d_n_out) -- all on the device."""
+        import torch
+        assert d_T.is_cuda and d_T.dtype == torch.float32 and d_T.is_contiguous()
+        assert d_scores.is_cuda and d_scores.dtype == torch.float32 and d_scores.is_contiguous()
+        n = int(d_T.shape[0])
+        dev = d_T.device
+        if d_T_out is None:
+            d_T_out = torch.empty(k, 16, dtype=torch.float32, device=dev)
+        if d_index_out is None:
+            d_index_out = torch.empty(k, dtype=torch.int32, device=dev)
+        if d_n_out is None:
+            d_n_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        if stream is None:
+            stream = torch.cuda.current_stream(dev).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        _lib.check(self._lib.pgp_select_top_device(
+            self._h, C.c_void_p(d_T.data_ptr()), C.c_void_p(d_scores.data_ptr()), n, int(k), 1 if invert else 0,
+            C.c_void_p(d_T_out.data_ptr()), C.c_void_p(d_index_out.data_ptr()), C.c_void_p(d_n_out.data_ptr()),
+            C.c_void_p(stream)))
+        return d_T_out, d_index_out, d_n_out
+
+    @staticmethod
+    def icp_refine_multi_device(jobs, trim=1.0, max_iterations=100, max_corr_dist=0.0, energy_ratio=1.0, stream=None):
+        """pgp_icp_refine_multi_device.  jobs: list of dicts {scorer, d_src4, d_tgt4, d_T, d_energy (opt), d_iters (opt),
+        target_token (opt)}: every (segment, target) pair refined by ONE launch; each d_T refined in place."""
+        import torch
+        if not jobs:
+            return
+        lib = jobs[0]["scorer"]._lib
+        arr = (_lib.IcpJob * len(jobs))()
+        for j, q in enumerate(jobs):
+            sc = q["scorer"]
+            for x in (q["d_src4"], q["d_tgt4"], q["d_T"]):
+                assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()
+            if q.get("target_token") is not None:
+                _lib.check(lib.pgp_icp_target_token(sc._h, C.c_ulonglong(int(q["target_token"]))))
+            e, it = q.get("d_energy"), q.get("d_iters")
+            arr[j] = _lib.IcpJob(sc._h, q["d_src4"].data_ptr(), int(q["d_src4"].shape[0]), q["d_tgt4"].data_ptr(),
+                                 int(q["d_tgt4"].shape[0]), q["d_T"].data_ptr(), int(q["d_T"].shape[0]),
+                                 e.data_ptr() if e is not None else None, it.data_ptr() if it is not None else None)
+        if stream is None:
+            stream = torch.cuda.current_stream(jobs[0]["d_T"].device).cuda_stream
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        prm = _lib.IcpParams(int(max_iterations), float(trim), float(max_corr_dist), float(energy_ratio))
+        _lib.check(lib.pgp_icp_refine_multi_device(arr, len(jobs), C.byref(prm), C.c_void_p(stream)))
+
     # ---- verification loop -----------------------------------------------------------------------
     def score(self, T, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         """T: (n_h,16) column-major float transforms.  Returns (scores, counts, best_index, best_score)."""
