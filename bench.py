@@ -533,8 +533,8 @@ def config_rows(torch, timed):
 def drop_in_row():
     """End-to-end time of the drop-in boundary per object: shim/test_shim (prebuilt in the build
     container, it needs Eigen) calls getProbableTransformsSuper4PCS on a synthetic segment the way
-    ObjectPoseCandidateSet.cpp:53-68 does -- file hand-off and in-memory overload, 3 calls each in
-    one process, the first (context + code-object load) reported apart."""
+    ObjectPoseCandidateSet.cpp:53-68 does -- file hand-off (20 calls) and in-memory overload (200 calls) in
+    one process each, the first (context + code-object load) reported apart; median, p90, p99 and max of the rest."""
     import subprocess
     import tempfile
     exe = os.path.join(ROOT, "shim", "test_shim")
@@ -545,15 +545,18 @@ def drop_in_row():
     with tempfile.TemporaryDirectory() as d:
         args, case = make_dropin_case(d)
         out = {"case": case["info"]}
-        for name, extra in (("file_path", {}), ("in_memory", {"SHIM_TEST_INMEMORY": "1"})):
-            env = dict(os.environ, PGP_SHIM_SEED="12345", SHIM_TEST_REPEAT="3", **extra)
+        for name, extra, calls in (("file_path", {}, 20), ("in_memory", {"SHIM_TEST_INMEMORY": "1"}, 200)):
+            env = dict(os.environ, PGP_SHIM_SEED="12345", SHIM_TEST_REPEAT=str(calls), **extra)
             r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 out[name] = {"error": r.stderr[-300:]}
                 continue
             ms = [float(x) for l in r.stdout.splitlines() if l.startswith("ELAPSED_MS") for x in l.split()[1:]]
-            out[name] = {"first_call_ms": ms[0], "drop_in_ms_per_object": min(ms[1:]) if len(ms) > 1 else ms[0],
-                         "calls_ms": ms}
+            rest = np.array(ms[1:] if len(ms) > 1 else ms)
+            out[name] = {"first_call_ms": ms[0], "drop_in_ms_per_object": float(np.median(rest)), "calls": len(ms),
+                         "min_ms": float(rest.min()), "p90_ms": float(np.percentile(rest, 90)),
+                         "p99_ms": float(np.percentile(rest, 99)), "max_ms": float(rest.max()),
+                         "phases": "profiles/r04_dropin_phases.txt (tools/dropin_phases.py)"}
         return out
 
 

@@ -303,6 +303,17 @@ int pgp_congruent_batch_quads(pgp_ctx* ctx, const int* picks, int m, int* quads)
 int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
                             const float centroid_Q[3], float* T, double* pose, int* status, float* rms);
 
+/* pgp_congruent_batch_fit and the verification of its fits WITHOUT a round trip of the transforms: the fits stay in
+ * HBM, every pick is scored there ([Weighted]Verify, base.cc:1885-1901; a fit the reference does not push -- status
+ * != 1, base.cc:1467-1485 -- scores 0 and can therefore never enter the strict-`>` walk), and only scores[m],
+ * status[m] and the best {index, score} come back.  With pgp_set_exact_records the scores at the walk's decisions are
+ * the reference's own sums.  pgp_congruent_batch_fetch then returns the float transform and the double pose of the few
+ * picks the caller keeps (the running-best list, the best pose): index[k] -> T[k][16], pose[k][16], either nullable. */
+int pgp_congruent_batch_fit_score(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                                  const float centroid_Q[3], int mode, float gate_deg, float* scores, int* status,
+                                  int* best_index, float* best_score);
+int pgp_congruent_batch_fetch(pgp_ctx* ctx, const int* index, int k, float* T, double* pose);
+
 /* ICP refinement.  Replaces the inner loop behind pcl::recognition::TrimmedICP::align
  * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and
  * pcl::IterativeClosestPoint::align (utilities.cpp:697-703; PPE/data_layer/SceneCfg.cpp:101,135-141)

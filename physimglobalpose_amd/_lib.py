@@ -89,6 +89,8 @@ SIGNATURES = {
     "pgp_find_congruent_batch": (C.c_int, [C.c_void_p, _i, _f, _f, C.c_int, C.c_float, _i]),
     "pgp_congruent_batch_quads": (C.c_int, [C.c_void_p, _i, C.c_int, _i]),
     "pgp_congruent_batch_fit": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, _f, C.POINTER(C.c_double), _i, _f]),
+    "pgp_congruent_batch_fit_score": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, C.c_int, C.c_float, _f, _i, _i, _f]),
+    "pgp_congruent_batch_fetch": (C.c_int, [C.c_void_p, _i, C.c_int, _f, C.POINTER(C.c_double)]),
     "pgp_icp_refine": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _f, C.c_int,
                                  C.POINTER(IcpParams), _f, _i]),
     "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -896,6 +896,148 @@ int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids,
   return PGP_OK;
 }
 
+namespace {
+// a fit the reference does not push (status != 1: base.cc:1467-1485) is replaced by a transform that registers
+// nothing -- identity rotation, translation 1e6 -- so that it scores 0 and can never enter the running-best walk
+__global__ __launch_bounds__(256) void mask_failed_fits(const int* __restrict__ status, int m, float* __restrict__ T) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || status[i] == 1) return;
+  float* o = T + 16 * (size_t)i;
+  for (int q = 0; q < 16; ++q) o[q] = (q % 5 == 0) ? 1.f : 0.f;
+  o[12] = o[13] = o[14] = 1e6f;
+}
+// 16 lanes per kept fit: its float transform and its double pose into a contiguous staging block
+__global__ __launch_bounds__(64) void gather_fits(const int* __restrict__ index, int k, const float* __restrict__ T,
+                                                  const double* __restrict__ pose, float* __restrict__ T_out,
+                                                  double* __restrict__ pose_out) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 4), q = threadIdx.x & 15;
+  if (j >= k) return;
+  const size_t h = (size_t)index[j];
+  T_out[16 * (size_t)j + q] = T[16 * h + q];
+  pose_out[16 * (size_t)j + q] = pose[16 * h + q];
+}
+}  // namespace
+
+int pgp_congruent_batch_fit_score(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                                  const float centroid_Q[3], int mode, float gate_deg, float* scores, int* status,
+                                  int* best_index, float* best_score) {
+  if (!ctx || m < 0 || !centroid_P || !centroid_Q || (m > 0 && (!picks || !base_ids || !scores || !status))) {
+    set_error("pgp_congruent_batch_fit_score: bad argument");
+    return PGP_EINVAL;
+  }
+  if (best_index) *best_index = -1;
+  if (best_score) *best_score = 0.f;
+  if (m == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)m;
+  int rc;
+  if ((rc = pgp_reserve(ctx, m)) != PGP_OK) return rc;
+  if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_out.ensure(N * 8 + 8)) != PGP_OK) return rc;
+  // pinned staging: [bases of the picks | picks] in, [scores | status | best] out
+  const size_t in_bytes = N * 16, out_bytes = N * 8 + 8, pin_need = in_bytes + out_bytes + 128;
+  if (pin_need > ctx->h_pin_cap) {
+    if (ctx->h_pin) {
+      hipError_t e = hipHostFree(ctx->h_pin);
+      (void)e;
+      ctx->h_pin = nullptr;
+      ctx->h_pin_cap = 0;
+    }
+    const size_t want = pin_need + pin_need / 4;
+    PGP_HIP(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
+    ctx->h_pin_cap = want;
+  }
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
+  int* hb = reinterpret_cast<int*>(pin);
+  for (size_t k = 0; k < N; ++k) {
+    const int b = picks[2 * k];
+    if (b < 0 || b >= ctx->csb_nb) {
+      set_error("pgp_congruent_batch_fit_score: pick %zu names base %d of %d", k, b, ctx->csb_nb);
+      return PGP_EINVAL;
+    }
+    for (int j = 0; j < 4; ++j) hb[4 * k + j] = base_ids[4 * (size_t)b + j];
+  }
+  int* d_b = ctx->d_ids.as<int>();
+  int* d_q = d_b + 4 * N;
+  PGP_HIP(hipMemcpyAsync(d_b, hb, in_bytes, hipMemcpyHostToDevice, st));
+  rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st);
+  if (rc != PGP_OK) return rc;
+  double* d_pose = ctx->d_rig.as<double>();
+  float* d_T = reinterpret_cast<float*>(d_pose + 16 * N);
+  float* d_rms = d_T + 16 * N;
+  int* d_status = reinterpret_cast<int*>(d_rms + N);
+  rc = launch_rigid(ctx, d_b, d_q, m, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms, st);
+  if (rc != PGP_OK) return rc;
+  hipLaunchKernelGGL(mask_failed_fits, dim3((m + 255) / 256), dim3(256), 0, st, (const int*)d_status, m, d_T);
+  float* d_scores = ctx->d_out.as<float>();
+  int* d_best = reinterpret_cast<int*>(d_scores + 2 * N);
+  rc = launch_score(ctx, d_T, m, mode, gate_deg, d_scores, nullptr, d_best, st);
+  if (rc != PGP_OK) return rc;
+  unsigned char* pin_out = pin + ((in_bytes + 63) & ~(size_t)63);
+  PGP_HIP(hipMemcpyAsync(pin_out, d_scores, N * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemcpyAsync(pin_out + N * 4, d_status, N * 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemcpyAsync(pin_out + N * 8, d_best, 8, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  std::memcpy(scores, pin_out, N * 4);
+  std::memcpy(status, pin_out + N * 4, N * 4);
+  int best[2];
+  std::memcpy(best, pin_out + N * 8, sizeof best);
+  if (best_index) *best_index = best[0];
+  if (best_score) std::memcpy(best_score, &best[1], 4);
+  ctx->csb_fit_m = m;
+  return PGP_OK;
+}
+
+int pgp_congruent_batch_fetch(pgp_ctx* ctx, const int* index, int k, float* T, double* pose) {
+  if (!ctx || k < 0 || (k > 0 && !index)) {
+    set_error("pgp_congruent_batch_fetch: bad argument");
+    return PGP_EINVAL;
+  }
+  if (k == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  const size_t N = (size_t)ctx->csb_fit_m;
+  if (N == 0 || ctx->d_rig.cap < N * (128 + 64 + 4 + 4)) {
+    set_error("pgp_congruent_batch_fetch: no fits resident (pgp_congruent_batch_fit_score first)");
+    return PGP_ESTATE;
+  }
+  const double* d_pose = ctx->d_rig.as<double>();
+  const float* d_T = reinterpret_cast<const float*>(d_pose + 16 * N);
+  for (int j = 0; j < k; ++j)
+    if (index[j] < 0 || (size_t)index[j] >= N) {
+      set_error("pgp_congruent_batch_fetch: index %d of %zu", index[j], N);
+      return PGP_EINVAL;
+    }
+  // gathered on the device, ONE copy back through the pinned buffer (a 64-byte copy into pageable memory per
+  // entry cost 15 us each: 0.3 ms for the twenty entries of a running-best list)
+  const size_t K = (size_t)k, pin_need = K * (4 + 128 + 64) + 256;
+  int rc;
+  if ((rc = ctx->d_cs_out.ensure(K * (4 + 128 + 64) + 256)) != PGP_OK) return rc;
+  if (pin_need > ctx->h_pin_cap) {
+    if (ctx->h_pin) {
+      hipError_t e = hipHostFree(ctx->h_pin);
+      (void)e;
+      ctx->h_pin = nullptr;
+      ctx->h_pin_cap = 0;
+    }
+    PGP_HIP(hipHostMalloc(&ctx->h_pin, pin_need + pin_need / 4, hipHostMallocDefault));
+    ctx->h_pin_cap = pin_need + pin_need / 4;
+  }
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
+  unsigned char* dev = ctx->d_cs_out.as<unsigned char>();
+  const size_t off_pose = (K * 4 + 127) & ~(size_t)127, off_T = off_pose + K * 128;
+  std::memcpy(pin, index, K * 4);
+  PGP_HIP(hipMemcpyAsync(dev, pin, K * 4, hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(gather_fits, dim3((k + 3) / 4), dim3(64), 0, ctx->stream, reinterpret_cast<const int*>(dev), k, d_T, d_pose,
+                     reinterpret_cast<float*>(dev + off_T), reinterpret_cast<double*>(dev + off_pose));
+  PGP_HIP(hipMemcpyAsync(pin + off_pose, dev + off_pose, K * (128 + 64), hipMemcpyDeviceToHost, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  if (pose) std::memcpy(pose, pin + off_pose, K * 128);
+  if (T) std::memcpy(T, pin + off_T, K * 64);
+  return PGP_OK;
+}
+
 static pgp_icp_options options_of(const pgp_icp_params* p) {
   pgp_icp_options o;
   pgp_icp_default_options(&o);

@@ -124,6 +124,7 @@ struct pgp_ctx {
   pgp::DevBuf d_csb, d_csb_picks;       // batched congruent sets: bases | cones | per-base starts; staged picks
   int csb_nb = 0;                       // bases of the last pgp_find_congruent_batch (its keys are still resident);
                                         // 0 as soon as d_cs_keys / d_ppf_pairs / the search model are rewritten
+  int csb_fit_m = 0;                    // fits of the last pgp_congruent_batch_fit_score, resident in d_rig
   uint32_t csb_total = 0;
   std::vector<uint32_t> csb_starts;     // per-base starts in the sorted keys (nb + 1), host copy: picks are checked here
   pgp::DevBuf d_prob_cdf;               // double prefix sums of the scene weights (first draw)

@@ -581,6 +581,16 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   const int max_sampled_csets = 100;       // base.cc:1858
   pgp_ctx* ctx = nullptr;
   set_identity(bestHypothesis);
+  // PGP_SHIM_VERBOSE: where a call's time goes (one PHASES line per call: tools/dropin_phases.py aggregates them)
+  const bool verbose = getenv("PGP_SHIM_VERBOSE") != nullptr;
+  auto t_mark = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char*, double> > phases;
+  auto mark = [&](const char* name) {
+    if (!verbose) return;
+    const auto now = std::chrono::steady_clock::now();
+    phases.push_back(std::make_pair(name, std::chrono::duration<double, std::milli>(now - t_mark).count()));
+    t_mark = now;
+  };
   auto own = [](const Super4PCSCloudView& v) {   // the call centres and re-normalises: work on copies
     Cloud c;
     c.n = v.n > 0 && v.xyz ? v.n : 0;
@@ -593,10 +603,12 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   if (seg.n == 0 || qval.n == 0 || qsearch.n == 0) return;
   clean_normals(seg.nrm);
   clean_normals(qval.nrm);
+  mark("copy+normals");
 
   // ---- init(): centring (base.cc:242-268)
   float cP[3], cQ[3];
   if (pgp_center(seg.xyz.data(), seg.n, qsearch.xyz.data(), qsearch.n, qval.xyz.data(), qval.n, cP, cQ) != PGP_OK) return;
+  mark("centre");
 
   const auto t_start = std::chrono::steady_clock::now();
   auto ms_since = [](std::chrono::steady_clock::time_point t0) {
@@ -627,10 +639,14 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     if (!st.ctx) SHIM_PGP(pgp_create(&st.ctx, -1));
     ctx = st.ctx;
     SHIM_PGP(pgp_set_exact_ties(ctx, exact_ties ? 1 : 0));
+    mark("ties+context");
     SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
+    mark("set_scene");
     SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
+    mark("set_model");
   }
   SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
+  mark("set_search_model");
   unsigned long long print = 0x9E3779B97F4A7C15ull;
   if (!PPFMap.empty()) {
     auto mix = [&print](long long v) { print = (print ^ (unsigned long long)v) * 0x100000001B3ull + (print >> 31); };
@@ -664,6 +680,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     st.map_ctx = ctx;
   }
 
+  mark("ppf_map");
   // ---- per-point weights from the probability image (base.cc:317-340), once the image is there
   {
     int rows = 0, cols = 0;
@@ -678,6 +695,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
       else SHIM_PGP(pgp_set_scene_weights(ctx, prob.data(), seg.n));
     }
   }
+  mark("weights");
   const double ms_setup = ms_since(t_start);
   const auto t_bases = std::chrono::steady_clock::now();
   // ---- Step 1: base selection (base.cc:1831-1848): rounds of independent attempts, one launch each;
@@ -685,7 +703,8 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   unsigned seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
   if (const char* s = getenv("PGP_SHIM_SEED")) { seed = (unsigned)strtoul(s, nullptr, 10); srand(seed); }
   std::default_random_engine generator(seed);
-  const int attempts_per_round = 128;
+  const int attempts_per_round = 256;   // (the variates are drawn in attempt order, so the round size does not change which bases are taken;
+                                        //  256 workgroups are one wave of the 256 CUs and the reference's 100 bases come out of ONE round: 0.41 -> 0.2 ms)
   std::vector<int> base_ids;       // n_bases x 4 (scene ids, TryQuadrilateral's order)
   std::vector<float> base_inv;     // n_bases x 2
   {
@@ -704,6 +723,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   }
   const int n_bases = (int)(base_ids.size() / 4);
 
+  mark("base_selection");
   const double ms_bases = ms_since(t_bases);
   const auto t_cs = std::chrono::steady_clock::now();
   // ---- Step 2: congruent sets of every base in one pass (base.cc:1855-1874, 1929-1993), then the
@@ -727,9 +747,69 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
       for (int j : chosen) { picks.push_back(b); picks.push_back(j); }
     }
   }
+  mark("congruent_sets");
   const double ms_cs = ms_since(t_cs);
   const auto t_fit = std::chrono::steady_clock::now();
   const int n_pairs = (int)(picks.size() / 2);
+  if (!st.group) {
+    // ---- single device: the fits never leave HBM -- fitted, verified (Step 3, base.cc:1885-1901, operMode = 1 ->
+    // WeightedVerify) and walked there; scores and status come back, then the poses of the few hypotheses that are kept
+    std::vector<float> lcp_all(n_pairs > 0 ? n_pairs : 1);
+    std::vector<int> status(n_pairs > 0 ? n_pairs : 1);
+    int best_pick = -1;
+    float best_lcp = 0.f;
+    // hypothesisSet is the running-best list: its entries are decided on exact (reference-order) sums
+    SHIM_PGP(pgp_set_exact_records(ctx, 1));
+    if (n_pairs > 0)
+      SHIM_PGP(pgp_congruent_batch_fit_score(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, PGP_MODE_WEIGHTED, 30.f,
+                                             lcp_all.data(), status.data(), &best_pick, &best_lcp));
+    // allTransforms / allPose hold only the fits that were pushed (base.cc:1467-1485)
+    std::vector<int> kept;
+    std::vector<float> lcp;
+    for (int i = 0; i < n_pairs; ++i)
+      if (status[i] == 1) {
+        kept.push_back(i);
+        lcp.push_back(lcp_all[i]);
+      }
+    const int n_h = (int)kept.size();
+    mark("fit+score+records");
+    if (verbose)
+      std::cerr << "[libsuper4pcs shim] bases " << n_bases << ", congruent pairs " << n_pairs << ", transforms " << n_h
+                << "; ms: setup " << ms_setup << ", base selection " << ms_bases << ", congruent sets " << ms_cs << std::endl;
+    std::vector<int> selected(n_h > 0 ? n_h : 1);
+    int n_sel = 0;
+    pgp_running_best(lcp.data(), n_h, selected.data(), &n_sel);
+    std::vector<int> want;   // picks whose pose is needed: the running-best list, then the best
+    for (int k = 0; k < n_sel; ++k) want.push_back(kept[selected[k]]);
+    if (best_pick >= 0) want.push_back(best_pick);
+    std::vector<float> Tf(16 * want.size() + 16);
+    std::vector<double> posed(16 * want.size() + 16);
+    if (!want.empty()) SHIM_PGP(pgp_congruent_batch_fetch(ctx, want.data(), (int)want.size(), Tf.data(), posed.data()));
+    auto iso_of = [&posed](size_t k) {
+      Eigen::Isometry3d iso;
+      iso.matrix() = Eigen::Map<const Eigen::Matrix4d>(posed.data() + 16 * k);
+      return iso;
+    };
+    hypothesisSet.clear();   // the reference REPLACES the list by the running-best subsequence (allPose.clear(), base.cc:1903)
+    for (int k = 0; k < n_sel; ++k) hypothesisSet.push_back(std::make_pair(iso_of((size_t)k), lcp[selected[k]]));  // base.cc:1903-1908
+    if (best_pick >= 0) {
+      bestHypothesis = std::make_pair(iso_of(want.size() - 1), best_lcp);
+      registered_points.resize(qval.n);
+      int n_reg = 0;
+      SHIM_PGP(pgp_registered(ctx, Tf.data() + 16 * (want.size() - 1), PGP_MODE_WEIGHTED, 30.f, registered_points.data(), &n_reg));
+      registered_points.resize(n_reg);
+    } else {
+      std::cout << "returning identity" << std::endl;  // base.cc:1791-1794
+    }
+    mark("list+registered");
+    if (verbose) {
+      std::cerr << "[libsuper4pcs shim] PHASES";
+      for (const auto& ph : phases) std::cerr << " " << ph.first << "=" << ph.second;
+      std::cerr << " n_h=" << n_h << std::endl;
+    }
+    return;
+  }
+  // ---- several devices (PGP_SHIM_DEVICES): the fits come back and the group scores them
   std::vector<float> T((size_t)n_pairs * 16);
   std::vector<double> pose((size_t)n_pairs * 16);
   std::vector<int> status(n_pairs);
@@ -749,6 +829,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
 
   // ---- Step 3: verification (base.cc:1885-1901), operMode = 1 -> WeightedVerify
   const int n_h = (int)allPose.size();
+  mark("rigid_fits");
   const double ms_fit = ms_since(t_fit);
   if (getenv("PGP_SHIM_VERBOSE"))
     std::cerr << "[libsuper4pcs shim] bases " << n_bases << ", congruent pairs " << n_pairs
@@ -764,6 +845,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
                                  &best_lcp));
   else
     SHIM_PGP(pgp_score_lcp(ctx, allT.data(), n_h, PGP_MODE_WEIGHTED, 30.f, lcp.data(), nullptr, &best, &best_lcp));
+  mark("score+records");
   for (int i = 0; i < n_h; ++i) allPose[i].second = lcp[i];
   std::vector<int> selected(n_h > 0 ? n_h : 1);
   int n_sel = 0;
@@ -779,5 +861,11 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     registered_points.resize(n_reg);
   } else {
     std::cout << "returning identity" << std::endl;  // base.cc:1791-1794
+  }
+  mark("list+registered");
+  if (verbose) {
+    std::cerr << "[libsuper4pcs shim] PHASES";
+    for (const auto& ph : phases) std::cerr << " " << ph.first << "=" << ph.second;
+    std::cerr << " n_h=" << n_h << std::endl;
   }
 }
