@@ -62,42 +62,81 @@ def _edge(ax, ay, bx, by, px, py):
     return (bx - ax) * (py - ay) - (by - ay) * (px - ax)
 
 
-def raster(vertices, triangles, T16, cam, parent=None):
-    px, py, z, valid = project(vertices, T16, cam)
-    d = _start(cam, parent)
+def cam_points(vertices, T16):
+    v = np.asarray(vertices, F)
+    G = np.asarray(T16, F)
+    return (_row(G[0], G[4], G[8], G[12], v[:, 0], v[:, 1], v[:, 2]), _row(G[1], G[5], G[9], G[13], v[:, 0], v[:, 1], v[:, 2]),
+            _row(G[2], G[6], G[10], G[14], v[:, 0], v[:, 1], v[:, 2]))
+
+
+def _fill(d, cam, P0, P1, P2):
+    """one projected triangle {px, py, z} x 3 into d (inclusive edges, perspective-correct depth)"""
     rows, cols = cam["rows"], cam["cols"]
     zn, zm = F(max(cam["z_near"], 0.0)), _zmax(cam)
     half = F(0.5)
-    for i0, i1, i2 in np.asarray(triangles, np.int64).reshape(-1, 3):
-        if not (valid[i0] and valid[i1] and valid[i2]):
+    (x0, y0, z0), (x1, y1, z1), (x2, y2, z2) = P0, P1, P2
+    area = _edge(x0, y0, x1, y1, x2, y2)
+    if not (area != 0):
+        return
+    sgn = F(1.0) if area > 0 else F(-1.0)
+    minx, maxx = min(x0, x1, x2), max(x0, x1, x2)
+    miny, maxy = min(y0, y1, y2), max(y0, y1, y2)
+    if not (maxx >= 0 and maxy >= 0 and minx <= F(cols) and miny <= F(rows)):
+        return
+    xa = int(max(np.ceil(F(minx - half)), F(0))); xb = int(min(np.floor(F(maxx - half)), F(cols - 1)))
+    ya = int(max(np.ceil(F(miny - half)), F(0))); yb = int(min(np.floor(F(maxy - half)), F(rows - 1)))
+    if xa > xb or ya > yb:
+        return
+    cx = (np.arange(xa, xb + 1).astype(F) + half)[None, :]
+    cy = (np.arange(ya, yb + 1).astype(F) + half)[:, None]
+    e0 = sgn * _edge(x1, y1, x2, y2, cx, cy)
+    e1 = sgn * _edge(x2, y2, x0, y0, cx, cy)
+    e2 = sgn * _edge(x0, y0, x1, y1, cx, cy)
+    inside = (e0 >= 0) & (e1 >= 0) & (e2 >= 0)
+    with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+        den = ((e0 / z0) + (e1 / z1)) + (e2 / z2)
+        zz = ((sgn * area) / den).astype(F)
+    keep = inside & (zz > zn) & (zz <= zm)
+    sub = d[ya:yb + 1, xa:xb + 1]
+    sub[keep] = np.minimum(sub[keep], zz[keep])
+
+
+def raster(vertices, triangles, T16, cam, parent=None):
+    px, py, z, valid = project(vertices, T16, cam)
+    X, Y, Z = cam_points(vertices, T16)
+    d = _start(cam, parent)
+    zc = F(cam["z_near"]) if cam["z_near"] > 0 else F(1e-4)       # the clipping plane
+    fx, fy, cx0, cy0 = F(cam["fx"]), F(cam["fy"]), F(cam["cx"]), F(cam["cy"])
+
+    def clip(ia, ib):      # the point of the edge ia (in front) -> ib (behind) on the clipping plane, projected
+        with np.errstate(all="ignore"):
+            t = F(F(zc - Z[ia]) / F(Z[ib] - Z[ia]))
+            x = F(X[ia] + F(t * F(X[ib] - X[ia])))
+            y = F(Y[ia] + F(t * F(Y[ib] - Y[ia])))
+            return (F(F(F(fx * x) / zc) + cx0), F(F(F(fy * y) / zc) + cy0), zc)
+
+    for tri in np.asarray(triangles, np.int64).reshape(-1, 3):
+        idx = [int(k) for k in tri]
+        front = [bool(valid[k]) for k in idx]
+        P = [(px[k], py[k], z[k]) for k in idx]
+        if all(front):
+            _fill(d, cam, P[0], P[1], P[2])
             continue
-        x0, y0, z0 = px[i0], py[i0], z[i0]
-        x1, y1, z1 = px[i1], py[i1], z[i1]
-        x2, y2, z2 = px[i2], py[i2], z[i2]
-        area = _edge(x0, y0, x1, y1, x2, y2)
-        if not (area != 0):
+        if not any(front):
             continue
-        sgn = F(1.0) if area > 0 else F(-1.0)
-        minx, maxx = min(x0, x1, x2), max(x0, x1, x2)
-        miny, maxy = min(y0, y1, y2), max(y0, y1, y2)
-        if not (maxx >= 0 and maxy >= 0 and minx <= F(cols) and miny <= F(rows)):
+        for _ in range(2):      # rotate: the first vertex in front, the one before it (cyclically) behind
+            if front[0] and not front[2]:
+                break
+            idx, front, P = idx[1:] + idx[:1], front[1:] + front[:1], P[1:] + P[:1]
+        ia, ib, ic = idx
+        if np.isnan(Z[ia]) or np.isnan(Z[ib]) or np.isnan(Z[ic]):
             continue
-        xa = int(max(np.ceil(F(minx - half)), F(0))); xb = int(min(np.floor(F(maxx - half)), F(cols - 1)))
-        ya = int(max(np.ceil(F(miny - half)), F(0))); yb = int(min(np.floor(F(maxy - half)), F(rows - 1)))
-        if xa > xb or ya > yb:
-            continue
-        cx = (np.arange(xa, xb + 1).astype(F) + half)[None, :]
-        cy = (np.arange(ya, yb + 1).astype(F) + half)[:, None]
-        e0 = sgn * _edge(x1, y1, x2, y2, cx, cy)
-        e1 = sgn * _edge(x2, y2, x0, y0, cx, cy)
-        e2 = sgn * _edge(x0, y0, x1, y1, cx, cy)
-        inside = (e0 >= 0) & (e1 >= 0) & (e2 >= 0)
-        with np.errstate(divide="ignore", invalid="ignore"):
-            den = ((e0 / z0) + (e1 / z1)) + (e2 / z2)
-            zz = ((sgn * area) / den).astype(F)
-        keep = inside & (zz > zn) & (zz <= zm)
-        sub = d[ya:yb + 1, xa:xb + 1]
-        sub[keep] = np.minimum(sub[keep], zz[keep])
+        if sum(front) == 1:
+            _fill(d, cam, P[0], clip(ia, ib), clip(ia, ic))
+        else:
+            bc, ac = clip(ib, ic), clip(ia, ic)
+            _fill(d, cam, P[0], P[1], bc)
+            _fill(d, cam, P[0], bc, ac)
     return _finish(d)
 
 

@@ -95,6 +95,40 @@ def test_triangle_raster_is_the_restatement_bit_for_bit(level):
     assert np.median(drawn) < c and drawn.min() >= c - 0.07 - 1e-3 and drawn.max() <= c + 0.07
 
 
+def test_near_plane_clipping_and_view_filling_triangles():
+    """a table quad that fills the view and runs past the camera (OpenGL clips, renderScene.cpp:45-72): its
+    two triangles have vertices BEHIND the near plane and a pixel box of the whole image -- clipped against z_near
+    (csrc/render.hip clip_edge) and filled by a workgroup each (render_big); bit-equal to oracle/render_oracle.py."""
+    rng = np.random.default_rng(9)
+    sc = LcpScorer()
+    # a table: a 3 m x 3 m quad 0.25 m below the camera, tilted, reaching 1 m behind it; an object mesh on top
+    quad = np.array([[-1.5, 0.25, -1.0], [1.5, 0.25, -1.0], [1.5, 0.25, 2.0], [-1.5, 0.25, 2.0]], np.float32)
+    qf = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    ball, bf = icosphere(2, 0.06)
+    ball = ball + np.array([0.02, 0.15, 0.55], np.float32)
+    v = np.concatenate([quad, ball]).astype(np.float32)
+    f = np.concatenate([qf, bf + 4]).astype(np.int32)
+    T = np.stack([synth.colmajor16(synth._se3(synth._rot_axis_angle([1, 0.3, 0.1], a), [0.0, 0.02 * k, 0.0]))
+                  for k, a in enumerate((0.0, 0.15, -0.2, 0.35))])
+    for rows, cols, Kc in ((ROWS, COLS, K), (480, 640, np.array([[614.0, 0, 322.5], [0, 614.0, 239.7], [0, 0, 1]], np.float32))):
+        for z_near in (0.1, 0.0):
+            cam = LcpScorer.camera(Kc, rows, cols, z_near, 2.5)
+            camd = _cam_dict(z_near=z_near, z_max=2.5, K=Kc, rows=rows, cols=cols)
+            got = sc.render_depth(v, f, T, cam)
+            for k in range(len(T) if rows == ROWS else 2):
+                want = ro.raster(v, f, T[k], camd)
+                assert np.array_equal(got[k].view(np.uint32), want.view(np.uint32)), (rows, z_near, k, np.abs(got[k] - want).max())
+            # the table fills the lower part of the view; the ball is in front of it
+            assert (got[0] > 0).mean() > 0.3 and got[0][got[0] > 0].min() < 0.55
+    # every vertex order of a clipped triangle gives the same coverage
+    tri = np.array([[0, 1, 2]], np.int32)
+    cam = LcpScorer.camera(K, ROWS, COLS, 0.1, 2.5)
+    a = sc.render_depth(quad, tri, T[:1], cam)[0]
+    for perm in ([1, 2, 0], [2, 0, 1], [2, 1, 0]):
+        b = sc.render_depth(quad, tri[:, perm], T[:1], cam)[0]
+        assert np.array_equal(a > 0, b > 0) and np.allclose(a, b, atol=1e-6)
+
+
 def test_edge_cases():
     sc = LcpScorer()
     cam = LcpScorer.camera(K, ROWS, COLS, 0.1, 1.0)

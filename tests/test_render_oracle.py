@@ -58,3 +58,34 @@ def test_depth_cost_counts_like_compute_cost():
     # |d| > 0.01: pixels (0,1) both>0, (0,2) ren only, (1,0) obs only, (1,3) ren only
     c = ro.depth_cost(obs, ren, 0.01)
     assert c.tolist() == [[2, 3, 1]]            # obScore, renScore, intScore -> renderScore 4 (UCTState.cpp:115)
+
+
+def test_a_plane_that_runs_past_the_camera_is_clipped_not_dropped():
+    """a floor y = 0.2 from 1 m in front of the camera to 1 m BEHIND it (two triangles with vertices at z = -1): every
+    pixel whose ray meets the floor between z_near and z_max carries the floor's depth z = 0.2 fy / (v + 0.5 - cy)"""
+    cam = dict(rows=12, cols=10, fx=10.0, fy=10.0, cx=5.0, cy=4.0, z_near=0.1, z_max=1.0)
+    v = np.array([[-2.0, 0.2, -1.0], [2.0, 0.2, -1.0], [2.0, 0.2, 1.0], [-2.0, 0.2, 1.0]], np.float32)
+    d = ro.raster(v, np.array([[0, 1, 2], [0, 2, 3]]), I16, cam)
+    for row in range(12):
+        dy = row + 0.5 - 4.0
+        z = 0.2 * 10.0 / dy if dy > 0 else np.inf
+        if 0.1 < z <= 1.0 and z < 0.97:        # (the last row before z_max may be cut by the far edge of the quad)
+            assert np.allclose(d[row, 2:8], z, rtol=2e-5), (row, d[row], z)
+        elif z > 1.0 or dy <= 0:
+            assert not d[row].any(), row
+    assert (d > 0).sum() >= 40
+    # one vertex in front only (the apex of a fan in the middle of the view); vertex order and winding do not matter
+    v5 = np.concatenate([v, np.array([[0.0, 0.2, 1.0]], np.float32)])
+    t1 = ro.raster(v5, np.array([[0, 1, 4]]), I16, cam)
+    assert (t1 > 0).sum() > 10 and np.array_equal(t1, ro.raster(v5, np.array([[1, 4, 0]]), I16, cam))
+    assert np.array_equal(t1 > 0, ro.raster(v5, np.array([[4, 1, 0]]), I16, cam) > 0)
+    for row in range(6, 12):
+        z = 0.2 * 10.0 / (row + 0.5 - 4.0)
+        assert np.allclose(t1[row][t1[row] > 0], z, rtol=2e-5)
+    # two in front
+    t2 = ro.raster(v, np.array([[0, 2, 3]]), I16, cam)
+    assert (t2 > 0).sum() > 10 and np.array_equal(t2, ro.raster(v, np.array([[2, 3, 0]]), I16, cam))
+    # all behind: nothing; z_near = 0 clips at 1e-4 without producing NaN
+    assert not ro.raster(v[[0, 1, 0]] * np.float32(1.0), np.array([[0, 1, 2]]), I16, cam).any()
+    d0 = ro.raster(v, np.array([[0, 1, 2], [0, 2, 3]]), I16, dict(cam, z_near=0.0))
+    assert np.isfinite(d0).all() and (d0 > 0).sum() >= (d > 0).sum()
