@@ -307,7 +307,14 @@ int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n) {
     return PGP_ESTATE;
   }
   if (n == 0) return PGP_OK;
+  if (!ctx->has_index) {
+    set_error("pgp_set_scene_weights: no scene (pgp_set_scene first)");
+    return PGP_ESTATE;
+  }
   CtxGuard guard(ctx);
+  // a pgp_score_lcp_device / pgp_settle_records_device call still queued on the caller's stream reads these
+  // weights: wait for the device as pgp_set_scene does, before they are rewritten
+  PGP_HIP(hipDeviceSynchronize());
   int rc = ctx->d_pre_io.ensure((size_t)n * 4);
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, weight, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));

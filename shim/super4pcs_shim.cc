@@ -518,12 +518,29 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
     fn();
     ms_part[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
+  // A worker that throws (bad_alloc on a huge file) must not take the host node down through std::terminate: every
+  // worker body catches and reports failure through its flag, and the guard joins whatever is still joinable when
+  // this frame unwinds -- the reference would propagate the exception, and so does this function after the join.
+  struct JoinGuard {
+    std::thread& t;
+    ~JoinGuard() { if (t.joinable()) t.join(); }
+  };
+  auto guarded = [](bool* flag, const std::function<bool()>& body) {
+    try {
+      *flag = body();
+    } catch (...) {
+      *flag = false;
+    }
+  };
   // the PNG (inflate + unfilter: the longest of the four) keeps decoding while the clouds are centred,
   // uploaded and indexed; the match waits for it only where the weights are first needed
-  std::thread t4([&] { timed(3, [&] { have = read_png_gray(probImagePath, px, rows, cols); }); });
+  std::thread t4([&] { timed(3, [&] { guarded(&have, [&] { return read_png_gray(probImagePath, px, rows, cols); }); }); });
+  JoinGuard g4{t4};
   {
-    std::thread t2([&] { timed(1, [&] { ok2 = read_ply(input2, qval); }); });
-    std::thread t3([&] { timed(2, [&] { ok3 = read_ply(input3, qsearch); }); });
+    std::thread t2([&] { timed(1, [&] { guarded(&ok2, [&] { return read_ply(input2, qval); }); }); });
+    JoinGuard g2{t2};
+    std::thread t3([&] { timed(2, [&] { guarded(&ok3, [&] { return read_ply(input3, qsearch); }); }); });
+    JoinGuard g3{t3};
     timed(0, [&] { ok1 = read_ply(input1, seg); });
     t2.join();
     t3.join();
@@ -552,7 +569,7 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
     return have ? px.data() : nullptr;
   };
   match_impl(vs, vq, vqs, image, bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
-  if (!joined) t4.join();
+  if (!joined && t4.joinable()) t4.join();
 }
 
 void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,

@@ -68,6 +68,29 @@ def test_grid_search_equals_exhaustive_scan():
     assert np.array_equal(Ta, Tc) and np.array_equal(ia, ic)
 
 
+def test_table_icp_shape_target_beyond_16_bit_positions():
+    """SceneCfg.cpp:101,135-141: the segmented scene (30 000 points) aligned to table.ply (100 000 points: beyond the
+    16-bit positions of the LDS index), max correspondence distance 1 cm.  The capped search runs on the uniform grid
+    (32-bit cell starts, any target size); transforms, energies and iteration counts equal the exhaustive scan's."""
+    rng = np.random.default_rng(12)
+    # a table top with a rim: 100 000 points on a 1.2 m x 0.8 m plane + edge strips
+    top = np.c_[rng.uniform(-0.6, 0.6, 90000), rng.uniform(-0.4, 0.4, 90000), 0.0005 * rng.standard_normal(90000)]
+    rim = np.c_[rng.uniform(-0.6, 0.6, 10000), np.where(rng.random(10000) < 0.5, -0.4, 0.4), rng.uniform(-0.05, 0.0, 10000)]
+    tgt = np.concatenate([top, rim]).astype(np.float32)
+    assert len(tgt) > 65535
+    R = synth._random_rot(rng, np.deg2rad(1.0))
+    pick = rng.choice(len(tgt), 30000, replace=False)
+    src = (tgt[pick] @ R.T + np.array([0.004, -0.003, 0.002]) + 0.0008 * rng.standard_normal((30000, 3))).astype(np.float32)
+    src[:300] += rng.uniform(-0.2, 0.2, (300, 3)).astype(np.float32)     # objects standing on the table: beyond the cap
+    G0 = synth.colmajor16(np.eye(4))[None]
+    sc = LcpScorer()
+    kw = dict(max_iterations=8, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
+    Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, nn_search=1, **kw)       # exhaustive scan: 3e9 tests per iteration
+    Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, nn_search=0, **kw)       # default: the grid at this size
+    assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
+    assert Ea[0] < 4e-6 and ia[0] >= 2
+
+
 def test_old_entry_point_is_the_trimmed_form():
     g = np.load(GOLD)
     sc = LcpScorer()
