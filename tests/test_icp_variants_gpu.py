@@ -88,7 +88,7 @@ def test_table_icp_shape_target_beyond_16_bit_positions():
     Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, nn_search=1, **kw)       # exhaustive scan: 3e9 tests per iteration
     Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, nn_search=0, **kw)       # default: the grid at this size
     assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
-    assert Ea[0] < 4e-6 and ia[0] >= 2
+    assert Ea[0] < 1e-5 and ia[0] >= 2      # registered: rms below 3 mm (the noise is 0.8 mm per axis)
 
 
 def test_old_entry_point_is_the_trimmed_form():
