@@ -155,6 +155,14 @@ struct IcpArgs {
   float* T_save;                 // [n][16]: clustered launch: part 0 stores the pose's initial transform here
   const float* T_in;             // where a pose's initial transform is read (T itself, or T_save in the repair launch)
   const unsigned* run_if;        // non-null: the whole launch returns at once unless *run_if != 0
+  // helping (icp_persist_help: one workgroup per pose, all resident): a workgroup whose pose has finished takes
+  // search passes of poses that are still running -- see HelpPub
+  unsigned char* help;           // the poses' publication blocks, help_stride bytes each
+  size_t help_stride;
+  unsigned long long* help_ctl;  // [n] (iteration tag << 32) | next unclaimed slot; tag 0 = nothing to take
+  unsigned* help_nslots;         // [n] slots of the published iteration
+  unsigned* help_done;           // [n] passes completed
+  unsigned* help_finished;       // [1] poses that are through all their iterations
   int dbg_pose;                  // diagnostic builds (PGP_ICP_STAMPS): the pose whose phases are timed (PGP_ICP_DBG_POSE)
 };
 
@@ -1302,8 +1310,108 @@ struct NnSched {
   unsigned search_ticks;           // time of the search loop below as thread 0 saw it (100 MHz ticks)
   unsigned n_unres;                // queries the vicinity graph did not answer: phase B's population
   uint16_t few[kNnFew];            // the first of them, in arrival order: the short path of phase B
+  unsigned help_s0[2];             // helping: the pass this workgroup has claimed (ping-pong across turns)
+  unsigned help_avail;             // helping: some workgroup of the launch is through with its pose
   int base;                        // classes above it get 2^(class - base) lanes (kNnBaseClass, lower when lanes would idle)
 };
+// ---- helping: search passes of a slow pose taken by workgroups whose own pose has finished -----------------------
+// With one workgroup per pose a launch lasts as long as its slowest pose (256 poses from up to 6 cm off: 240 .. 1050 us,
+// mean 680: a third of the chip's time idle).  What makes a pose slow is its search -- 2000 queries still far from
+// the surface, three passes of 1024 lane slots at ~20 us each -- and the passes of one iteration are independent.
+// So the owner of such an iteration PUBLISHES it in HBM (the sorted slot table, the queries' bounds, the pose) and
+// takes passes off a counter; a workgroup that is through with its own pose polls the counters of the others and
+// takes passes too: it holds the same target image in LDS and needs nothing else.  Results come back through HBM,
+// the owner waits for the passes it did not run itself.  The answer of a query does not depend on who searched
+// for it (exact nearest neighbour), so results are the bits of the unhelped kernel.
+//   ctl[p] = (tag << 32) | next unclaimed slot, tag = iteration + 1 while open, 0 when closed: a helper claims a pass
+//   by compare-and-swap on the whole word, so a pass of iteration k + 1 is never taken with the tables of iteration k;
+//   done[p] counts completed passes.  Nobody waits for anybody except the owner for passes that were CLAIMED, and a
+//   claimed pass is always finished: no cycle of waits; every spin is bounded by a clock all the same (a lost pass
+//   sets the lost flag and the repair launch redoes the call, as for the clustered launch).
+struct HelpPub {                     // one per pose, in HBM (write-through stores, agent-scope loads)
+  unsigned n_unres, base, pad0, pad1;
+  unsigned cnt[kNnClasses + 1];
+  unsigned slot_end[kNnClasses];
+  float G[16];
+  // followed by: order[n_src] (u32) | bound[n_src] (u64, by query) | result[n_src] (u64, by query)
+};
+__host__ __device__ inline size_t help_off_order() { return (sizeof(HelpPub) + 255) & ~(size_t)255; }
+__host__ __device__ inline size_t help_off_bound(int n_src) { return help_off_order() + (((size_t)n_src * 4 + 255) & ~(size_t)255); }
+__host__ __device__ inline size_t help_off_result(int n_src) { return help_off_bound(n_src) + (((size_t)n_src * 8 + 255) & ~(size_t)255); }
+__host__ __device__ inline size_t help_bytes(int n_src) { return help_off_result(n_src) + (((size_t)n_src * 8 + 255) & ~(size_t)255); }
+
+template <class V>
+__device__ __forceinline__ void st_agent(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class V>
+__device__ __forceinline__ V ld_agent(const V* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// ONE pass of 1024 lane slots.  tab: the slot table in LDS (the owner's own, or a helper's copy); from_pub: the
+// queries' order and bounds are read from the publication (a helper) instead of this workgroup's LDS arrays (the
+// owner); to_pub: the results go to the publication (a published iteration) instead of the LDS arrays (an owner's
+// unpublished single pass).  ONE instance per kernel: the search it inlines is the bulk of the kernel's code.
+template <int NT>
+__device__ __forceinline__ void help_pass(const IcpArgs& a, const NnLds& t, const NnSched* tab, const float* G, unsigned char* pub,
+                                          unsigned s0, unsigned n_slots, int tid, bool from_pub, bool to_pub) {
+  const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
+              g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
+  const unsigned* p_order = reinterpret_cast<const unsigned*>(pub + help_off_order());
+  const unsigned long long* p_bound = reinterpret_cast<const unsigned long long*>(pub + help_off_bound(a.n_src));
+  unsigned long long* p_result = reinterpret_cast<unsigned long long*>(pub + help_off_result(a.n_src));
+  const unsigned sl = s0 + (unsigned)tid;
+  const bool valid = sl < n_slots;
+  unsigned long long best = kNnNone;
+  int bpos = -1, q = 0, lg = 0, sub = 0;
+  if (valid) {
+    int c = kNnClasses - 1;
+    while (sl >= tab->slot_end[c]) --c;
+    lg = nn_class_lanes_log2(c, tab->base);
+    const unsigned first = c == kNnClasses - 1 ? 0u : tab->slot_end[c + 1];
+    const unsigned rel = sl - first;
+    sub = (int)(rel & ((1u << lg) - 1u));
+    const unsigned at = tab->cnt[c] + (rel >> lg);
+    q = !from_pub ? (int)t.order[at] : (int)ld_agent(&p_order[at]);
+    const float4 s = a.src[q];
+    const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+    unsigned pp, d2b;
+    if (!from_pub) {
+      pp = t.pos[q];
+      d2b = __float_as_uint(t.d2[q]);
+    } else {
+      const unsigned long long b = ld_agent(&p_bound[q]);
+      pp = (unsigned)(b & 0xFFFFull);
+      d2b = (unsigned)(b >> 32);
+    }
+    bpos = pp == 0xFFFFu ? -1 : (int)pp;
+    if (bpos >= 0) best = ((unsigned long long)d2b << 32) | (unsigned)__float_as_int(t.pts[bpos].w);
+    nn_search(a.nn, t, a.n_tgt, x, y, z, sub, 1 << lg, best, bpos);
+  }
+  const bool b0 = __ballot(lg >= 1) != 0ull, b1 = __ballot(lg >= 2) != 0ull, b2 = __ballot(lg >= 3) != 0ull,
+             b3 = __ballot(lg >= 4) != 0ull, b4 = __ballot(lg >= 5) != 0ull, b5 = __ballot(lg >= 6) != 0ull;
+  const bool need[6] = {b0, b1, b2, b3, b4, b5};
+#pragma unroll
+  for (int st = 0; st < 6; ++st) {
+    if (!need[st]) break;   // wave-uniform
+    const int off = 1 << st;
+    const unsigned lo = __shfl_xor((unsigned)best, off, 64), hi = __shfl_xor((unsigned)(best >> 32), off, 64);
+    const int pp = __shfl_xor(bpos, off, 64);
+    const unsigned long long pk = ((unsigned long long)hi << 32) | lo;
+    if (off < (1 << lg) && pk < best) {
+      best = pk;
+      bpos = pp;
+    }
+  }
+  if (valid && sub == 0) {
+    if (to_pub) {   // {d2 bits, position}: what the owner copies into its LDS arrays after the last pass
+      st_agent(&p_result[q], ((unsigned long long)(bpos < 0 ? 0x7F7FFFFFu : (unsigned)(best >> 32)) << 32) |
+                                 (unsigned long long)(bpos < 0 ? 0xFFFFu : (unsigned)bpos));
+    } else {
+      t.d2[q] = bpos < 0 ? FLT_MAX : __uint_as_float((unsigned)(best >> 32));
+      t.pos[q] = (uint16_t)(bpos < 0 ? 0xFFFF : bpos);
+    }
+  }
+}
+
 // The caller may hand over a SHARE of the queries (several workgroups per pose): the cloud is dealt in blocks of
 // eight consecutive queries, block k to workgroup k % P -- eight 8-byte meeting records are one 64-byte line, so a
 // line of the meeting buffer is written by ONE workgroup (interleaving single queries made every 8-byte store a
@@ -1321,9 +1429,10 @@ __host__ __device__ __forceinline__ int nn_share_count(int n, int part, int P) {
 }
 __host__ __device__ __forceinline__ bool nn_share_owns(int q, int part, int P) { return P == 1 || ((q >> 3) % P) == part; }
 
-template <int NT, int R>
+template <int NT, int R, bool HELP = false>
 __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
-                                               NnSched* sch /* LDS */, int tid, int part = 0, int P = 1) {
+                                               NnSched* sch /* LDS */, int tid, int part = 0, int P = 1, int help_pose = 0,
+                                               unsigned help_tag = 0, int* lost = nullptr) {
   const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
               g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
   static_assert(kNnBins / 2 == 4 * NT, "four counter words per thread");
@@ -1434,7 +1543,24 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     __syncthreads();    // n_unres is zeroed by the next call: everybody has read it
     return;
   }
-  if (NT == 16 * kNnFew && n_unres <= (unsigned)kNnFew) {
+  if (HELP && NT == 16 * kNnFew && n_unres <= (unsigned)kNnFew) {
+    // (the helping kernel keeps ONE inlined copy of the search: the handful goes through help_pass as one class of
+    //  16-lane groups -- class 15 with base 11)
+    if (tid < kNnClasses) {
+      sch->cnt[tid] = 0;
+      sch->slot_end[tid] = tid == kNnClasses - 1 ? 16u * n_unres : 16u * n_unres;
+    }
+    if (tid == 0) {
+      sch->base = kNnClasses - 1 - 4;
+      sch->search_ticks = 1;
+    }
+    if ((unsigned)tid < n_unres) t.order[tid] = sch->few[tid];
+    __syncthreads();
+    help_pass<NT>(a, t, sch, G, nullptr, 0u, 16u * n_unres, tid, false, false);
+    __syncthreads();
+    return;
+  }
+  if (!HELP && NT == 16 * kNnFew && n_unres <= (unsigned)kNnFew) {
     // A handful of stragglers (the graph answers all but ~30 of 1800 queries of a pose that is millimetres off):
     // no sort, no slot table -- query i takes lanes 16 i .. 16 i + 15, which share its rows; one pass, one barrier.
     const int grp = tid >> 4, sub = tid & 15;
@@ -1518,6 +1644,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     }
     sch->n_slots = total;
     sch->base = base;
+    if (HELP) sch->help_avail = ld_agent(a.help_finished);   // nobody idle yet: nothing is published (no overhead)
     unsigned slots = 0;
 #pragma unroll
     for (int c = kNnClasses - 1; c >= 0; --c) {
@@ -1537,6 +1664,77 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   __syncthreads();
   PGP_NN_STAMP(6);
   const unsigned n_slots = sch->n_slots;
+  if (HELP && n_slots > (unsigned)NT && sch->help_avail != 0u) {
+    // ---- more than one pass: published, so that idle workgroups can take passes (see HelpPub)
+    unsigned char* pub = a.help + (size_t)help_pose * a.help_stride;
+    HelpPub* hp = reinterpret_cast<HelpPub*>(pub);
+    unsigned* p_order = reinterpret_cast<unsigned*>(pub + help_off_order());
+    unsigned long long* p_bound = reinterpret_cast<unsigned long long*>(pub + help_off_bound(a.n_src));
+    const unsigned long long* p_result = reinterpret_cast<const unsigned long long*>(pub + help_off_result(a.n_src));
+    for (unsigned i = (unsigned)tid; i < n_unres; i += NT) {
+      const unsigned q = t.order[i];
+      st_agent(&p_order[i], q);
+      st_agent(&p_bound[q], ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned long long)t.pos[q]);
+    }
+    if (tid < kNnClasses) {
+      st_agent(&hp->cnt[tid], sch->cnt[tid]);
+      st_agent(&hp->slot_end[tid], sch->slot_end[tid]);
+    }
+    if (tid < 16) st_agent(&hp->G[tid], G[tid]);
+    if (tid == 0) {
+      st_agent(&hp->base, (unsigned)sch->base);
+      st_agent(&hp->n_unres, n_unres);
+      st_agent(&a.help_nslots[help_pose], n_slots);
+      st_agent(&a.help_done[help_pose], 0u);
+    }
+    __builtin_amdgcn_s_waitcnt(0);   // everything above has left before the counter opens
+    __syncthreads();
+    if (tid == 0) {
+      st_agent(&a.help_ctl[help_pose], (unsigned long long)help_tag << 32);
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+    const unsigned long long search_t0 = __builtin_amdgcn_s_memrealtime();
+    for (int turn = 0;; ++turn) {
+      if (tid == 0)
+        sch->help_s0[turn & 1] = (unsigned)(__hip_atomic_fetch_add(&a.help_ctl[help_pose], (unsigned long long)NT, __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT) & 0xFFFFFFFFull);
+      __syncthreads();
+      const unsigned s0 = sch->help_s0[turn & 1];
+      if (s0 >= n_slots) break;
+      help_pass<NT>(a, t, sch, G, pub, s0, n_slots, tid, false, true);
+      __builtin_amdgcn_s_waitcnt(0);   // this pass's results have left
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(&a.help_done[help_pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {   // the passes others took: wait for them (claimed passes are always finished)
+      const unsigned n_passes = (n_slots + NT - 1) / NT;
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+      while (ld_agent(&a.help_done[help_pose]) < n_passes) {
+        __builtin_amdgcn_s_sleep(1);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz
+          if (lost) *lost = 1;
+          break;
+        }
+      }
+      st_agent(&a.help_ctl[help_pose], 0ull);   // closed
+      sch->search_ticks = (unsigned)(__builtin_amdgcn_s_memrealtime() - search_t0);
+    }
+    __syncthreads();
+    for (unsigned i = (unsigned)tid; i < n_unres; i += NT) {
+      const unsigned q = t.order[i];
+      const unsigned long long v = ld_agent(&p_result[q]);
+      t.d2[q] = __uint_as_float((unsigned)(v >> 32));
+      t.pos[q] = (uint16_t)(v & 0xFFFFull);
+    }
+    __syncthreads();
+    return;
+  }
+  if (HELP) {   // a single pass, or nobody there to help: this workgroup's own passes, results straight into LDS
+    for (unsigned s0 = 0; s0 < n_slots; s0 += NT) help_pass<NT>(a, t, sch, G, nullptr, s0, n_slots, tid, false, false);
+    if (tid == 0) sch->search_ticks = 1;
+    __syncthreads();
+    return;
+  }
   const int lane_base = sch->base;
   int c = kNnClasses - 1;   // class of the current slot: slots only grow
   // a slot's query and its source point (an L2 read behind an LDS read) are fetched one trip ahead
@@ -1653,8 +1851,8 @@ constexpr int kSelRank = 512;   // keys of the threshold's 12-bit bin that are r
 // of the extra stop rules) -- the hot form; its branches on the other forms' options are gone at compile time.
 // PIR: source points per thread (n_src <= PIR x 1024): every per-thread array of the search's phase A, of the
 // selection and of the sums has PIR entries -- a 1756-point segment takes PIR = 2 and half the registers of PIR = 4.
-template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR>
-__device__ __forceinline__ void icp_persist_body(const IcpArgs& a) {
+template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR, bool HELP = false>
+__device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALUE: a reference to the kernel argument costs 16 -> 83 spilled registers
   extern __shared__ __align__(16) unsigned char smem[];
   __shared__ double s_red[(kIcpThreads / 64) * (kRedPlane + 1)];
   __shared__ float s_G[16];
@@ -1704,7 +1902,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs& a) {
   if (tid < 16) {
     const float v = (!CLUSTER && a.T_in ? a.T_in : a.T)[16 * (size_t)pose + tid];
     s_G[tid] = v;
-    if (CLUSTER && a.T_save && part == 0) a.T_save[16 * (size_t)pose + tid] = v;   // what a repair launch starts from
+    if ((CLUSTER || HELP) && a.T_save && part == 0) a.T_save[16 * (size_t)pose + tid] = v;   // what a repair launch starts from
   }
   if (tid == 0) {
     s_energy_old = (double)FLT_MAX;   // PCL: energy starts at numeric_limits<float>::max()
@@ -1724,7 +1922,8 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs& a) {
   for (;;) {
     PGP_STAMP(0);
     // ---- 1. correspondences ---------------------------------------------------------------------
-    nn_all_queries<kIcpThreads, PIR>(a, t, s_G, 0, n_share, &s_sch, tid, part, P);
+    nn_all_queries<kIcpThreads, PIR, HELP>(a, t, s_G, 0, n_share, &s_sch, tid, part, P, pose, (unsigned)(it + 1), &s_lost);
+    if (HELP && s_lost) break;
     if (CLUSTER && P > 1) {
       // publish this share (write-through, agent scope: the partners may sit on other XCDs), meet, read theirs.
       // Consecutive lanes store consecutive records of a block of eight: whole 64-byte lines.
@@ -2038,6 +2237,83 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs& a) {
     ++it;
     if (!s_continue) break;
   }
+  if (HELP) {
+    if (!s_lost) {
+      if (tid < 16) Tg[tid] = s_G[tid];
+      if (tid == 0) {
+        if (a.energy) a.energy[pose] = (float)s_energy;
+        if (a.iters) a.iters[pose] = it;
+      }
+    } else if (tid == 0) {
+      __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- this pose is through: take search passes of the poses that are still running (see HelpPub)
+    __shared__ int h_pose;
+    __shared__ unsigned h_s0, h_ns;
+    __shared__ unsigned long long h_pick[kIcpThreads / 64];
+    if (tid == 0) {
+      __builtin_amdgcn_s_waitcnt(0);
+      __hip_atomic_fetch_add(a.help_finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const unsigned long long h_t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      // every thread looks at one pose's counter; the lowest open one is tried
+      unsigned long long c = 0;
+      unsigned ns = 0;
+      bool open = false;
+      if (tid < a.n && tid != pose) {
+        c = ld_agent(&a.help_ctl[tid]);
+        if ((c >> 32) != 0ull) {
+          ns = ld_agent(&a.help_nslots[tid]);
+          open = (unsigned)(c & 0xFFFFFFFFull) < ns;
+        }
+      }
+      const unsigned long long bm = __ballot(open);
+      if (lane == 0) h_pick[wave] = bm;
+      __syncthreads();
+      int cand = -1;
+      for (int w = 0; w < kIcpThreads / 64 && cand < 0; ++w)
+        if (h_pick[w]) cand = 64 * w + __builtin_ctzll(h_pick[w]);
+      if (tid == 0) h_pose = -1;
+      __syncthreads();
+      if (cand >= 0) {
+        if (tid == cand) {   // the thread that read this pose's counter claims a pass with it
+          unsigned long long expected = c;
+          if (__hip_atomic_compare_exchange_strong(&a.help_ctl[cand], &expected, c + (unsigned long long)kIcpThreads, __ATOMIC_RELAXED,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            h_pose = cand;
+            h_s0 = (unsigned)(c & 0xFFFFFFFFull);
+            h_ns = ns;
+          }
+        }
+        __syncthreads();
+        const int hp_pose = h_pose;
+        if (hp_pose >= 0) {
+          unsigned char* pub = a.help + (size_t)hp_pose * a.help_stride;
+          const HelpPub* hp = reinterpret_cast<const HelpPub*>(pub);
+          if (tid < kNnClasses) {
+            s_sch.cnt[tid] = ld_agent(&hp->cnt[tid]);
+            s_sch.slot_end[tid] = ld_agent(&hp->slot_end[tid]);
+          }
+          if (tid < 16) s_G[tid] = ld_agent(&hp->G[tid]);
+          if (tid == 0) s_sch.base = (int)ld_agent(&hp->base);
+          __syncthreads();
+          help_pass<kIcpThreads>(a, t, &s_sch, s_G, pub, h_s0, h_ns, tid, true, true);
+          __builtin_amdgcn_s_waitcnt(0);
+          __syncthreads();
+          if (tid == 0) __hip_atomic_fetch_add(&a.help_done[hp_pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        continue;   // (a lost race for the pass: look again at once)
+      }
+      // nothing open: done when every pose is through; never spin for ever
+      if (tid == 0)
+        h_pose = (ld_agent(a.help_finished) >= (unsigned)a.n || __builtin_amdgcn_s_memrealtime() - h_t0 > 200000000ull) ? -2 : -1;
+      __syncthreads();
+      if (h_pose == -2) break;
+      __builtin_amdgcn_s_sleep(127);   // ~3 us between looks: 255 idle workgroups must not crowd the counters
+    }
+    return;
+  }
   if (CLUSTER && s_lost) {
     // a partner never arrived (another process holding the GPU's CUs): this call's transforms are not to be
     // trusted.  The flag lives in the library's workspace; the repair launch that follows every clustered launch
@@ -2073,6 +2349,12 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs& a) {
 template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR>
 __global__ __launch_bounds__(kIcpThreads) void icp_persist_index(IcpArgs a) {
   icp_persist_body<METRIC, IMG_LDS, CLUSTER, TRIM_ONLY, PIR>(a);
+}
+
+// one workgroup per pose, all resident, finished workgroups helping the running ones (see HelpPub)
+template <bool TRIM_ONLY, int PIR>
+__global__ __launch_bounds__(kIcpThreads) void icp_persist_help(IcpArgs a) {
+  icp_persist_body<0, true, false, TRIM_ONLY, PIR, true>(a);
 }
 
 // SEVERAL (source, target) pairs in ONE launch: the children of an MCTS expansion belong to different objects
@@ -2145,6 +2427,13 @@ static const void* persist_kernel(int metric, bool img_lds, bool cluster, bool t
   return persist_kernel_at(14 + (metric == 1 ? 2 : 0) + (cluster ? 1 : 0));
 }
 
+static const void* help_kernel(bool trim_only, int pir) {
+  static const void* const tab[6] = {
+      reinterpret_cast<const void*>(icp_persist_help<false, 2>), reinterpret_cast<const void*>(icp_persist_help<false, 3>),
+      reinterpret_cast<const void*>(icp_persist_help<false, 4>), reinterpret_cast<const void*>(icp_persist_help<true, 2>),
+      reinterpret_cast<const void*>(icp_persist_help<true, 3>),  reinterpret_cast<const void*>(icp_persist_help<true, 4>)};
+  return tab[(trim_only ? 3 : 0) + (pir <= 2 ? 0 : (pir == 3 ? 1 : 2))];
+}
 static const void* multi_kernel(bool trim_only, int pir) {
   static const void* const tab[6] = {
       reinterpret_cast<const void*>(icp_persist_multi<false, 2>), reinterpret_cast<const void*>(icp_persist_multi<false, 3>),
@@ -2163,8 +2452,10 @@ static int ensure_icp_attrs(pgp_ctx* ctx) {
   for (const void* f : big) PGP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
   for (int v = 0; v < kPersistKernels; ++v)
     PGP_HIP(hipFuncSetAttribute(persist_kernel_at(v), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
-  for (int v = 0; v < 6; ++v)
+  for (int v = 0; v < 6; ++v) {
     PGP_HIP(hipFuncSetAttribute(multi_kernel(v >= 3, 2 + v % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+    PGP_HIP(hipFuncSetAttribute(help_kernel(v >= 3, 2 + v % 3), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
+  }
   ctx->icp_attr_set = true;
   return PGP_OK;
 }
@@ -2486,6 +2777,60 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       (void)hipGetLastError();   // the grid does not fit as a cooperative launch here: one workgroup per pose
       a.wgs_per_pose = 1;
       a.T_save = nullptr;
+    }
+    // One workgroup per pose and all of them resident at once (129 .. 256 poses on 256 compute units): a workgroup
+    // that is through with its pose takes search passes of the poses still running (HelpPub) -- the launch then
+    // lasts about as long as the MEAN pose, not the slowest.  Cooperative (co-residency checked by the runtime) and
+    // chained like the clustered launches; the same repair launch behind it.
+    // MEASURED SLOWER and therefore OFF unless PGP_ICP_HELP=1 (profiles/r04_ab/icp_helping.log: 256 poses from far
+    // 0.84 -> 1.00 ms, from near 0.25 -> 0.28 ms, same bits): the helped kernel's own passes lose the one-trip-ahead
+    // prefetch of the plain slot loop, a published iteration costs ~10 us of write-through traffic and waiting, and
+    // idle workgroups only exist once the fast poses are through -- when the slow ones have few far iterations left.
+    bool want_help = a.wgs_per_pose == 1 && n >= 2 && n <= ctx->n_cus && a.metric == 0 && il && a.smooth == 0;
+    {
+      const char* v = getenv("PGP_ICP_HELP");
+      want_help = want_help && v && atoi(v) != 0;
+    }
+    if (want_help) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) want_help = false;
+    }
+    if (want_help) {
+      const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+      std::lock_guard<std::mutex> chain(g_coop.mu);
+      if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
+      else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
+      // counters (claim words | slot counts | passes done | finished, lost) | saved transforms | publications
+      const size_t N = (size_t)n, hdr = (N * 16 + 8 + 255) & ~(size_t)255, save = (N * 64 + 255) & ~(size_t)255, hb = help_bytes(n_src);
+      if ((rc = ctx->d_icp_x.ensure(hdr + save + N * hb + 256)) != PGP_OK) return rc;
+      unsigned char* base = ctx->d_icp_x.as<unsigned char>();
+      IcpArgs h = a;
+      h.help_ctl = reinterpret_cast<unsigned long long*>(base);
+      h.help_nslots = reinterpret_cast<unsigned*>(base + N * 8);
+      h.help_done = h.help_nslots + N;
+      h.help_finished = h.help_done + N;
+      h.x_lost = h.help_finished + 1;
+      h.T_save = reinterpret_cast<float*>(base + hdr);
+      h.help = base + hdr + save;
+      h.help_stride = hb;
+      PGP_HIP(hipMemsetAsync(base, 0, hdr, stream));
+      void* hparams[] = {&h};
+      hipError_t e = hipLaunchCooperativeKernel(help_kernel(trim_only, n_src <= 2 * kIcpThreads ? 2 : (n_src <= 3 * kIcpThreads ? 3 : 4)),
+                                                dim3(n), dim3(kIcpThreads), hparams, (unsigned)plds, stream);
+      if (getenv("PGP_ICP_DEBUG")) fprintf(stderr, "icp: %d poses, helping launch: %s\n", n, hipGetErrorString(e));
+      if (e == hipSuccess) {
+        IcpArgs fix = a;
+        fix.wgs_per_pose = 1;
+        fix.run_if = h.x_lost;
+        fix.T_in = h.T_save;
+        fix.T_save = nullptr;
+        void* fparams[] = {&fix};
+        PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), fparams, plds, stream));
+        PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
+        PGP_HIP(hipGetLastError());
+        return PGP_OK;
+      }
+      (void)hipGetLastError();   // not launchable cooperatively here: the plain launch below
     }
     void* params[] = {&a};
     PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), params, plds, stream));

@@ -192,3 +192,18 @@ def test_several_workgroups_per_pose_give_the_same_bits(form, monkeypatch):
         for x, y in zip(auto + short, one + short4):
             assert np.array_equal(x, y)
         assert np.array_equal(auto[0][:9], runs["1"][0])
+
+
+def test_helping_launch_gives_the_bits_of_the_plain_launch(monkeypatch):
+    """PGP_ICP_HELP=1 (csrc/icp.hip HelpPub; off by default -- measured slower): workgroups that are through with their
+    pose take search passes of the poses still running; who searches for a query cannot change its answer."""
+    S, M, N, G = _problem(31, 4000, 2200, 140, rot_deg=7.0, trans=0.01, outliers=0.08)
+    sc = LcpScorer()
+    monkeypatch.setenv("PGP_ICP_HELP", "0")
+    ref = sc.icp_refine(S, M, G, trim=0.9, max_iterations=25)
+    monkeypatch.setenv("PGP_ICP_HELP", "1")
+    for _ in range(3):
+        got = sc.icp_refine(S, M, G, trim=0.9, max_iterations=25)
+        for x, y in zip(ref, got):
+            assert np.array_equal(x, y)
+    assert len(np.unique(ref[2])) > 3      # poses of very different length: there was something to help with
