@@ -48,7 +48,15 @@ def test_single_gpu_line():
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     assert len(lines) == 1
     d = _check(lines[0], 1)
-    assert "plain_lcp" in d["other_rows"] and "drop_in" in d["other_rows"]
+    o = d["other_rows"]
+    assert "plain_lcp" in o and "drop_in" in o
+    t3 = o["config2_three_objects"]                      # MEASURED: three contexts, one multi-target ICP launch
+    assert t3["same_transforms_as_serial"] is True and 0 < t3["step_ms"] < t3["serial_ms"]
+    assert "three_objects_ms" not in o["config2_object"]  # the extrapolation is gone
+    assert o["icp"]["by_poses_near_start"]["1024"]["pose_iterations_per_s"] > o["icp"]["by_poses"]["1024"]["pose_iterations_per_s"]
+    if "in_memory" in o["drop_in"] and "error" not in o["drop_in"]["in_memory"]:
+        im = o["drop_in"]["in_memory"]
+        assert im["calls"] == 200 and im["drop_in_ms_per_object"] <= im["p99_ms"] <= im["max_ms"]
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     if cb["kind"] == "reference":               # the prebuilt oracle/_ref travelled along
