@@ -23,3 +23,20 @@ def test_cpp_host_example(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK")
     print(out.stdout)
+
+
+@pytest.mark.skipif(not shutil.which("g++"), reason="no g++")
+def test_cpp_host_resident_chain_and_multi_target_icp(tmp_path):
+    """examples/refine_objects.cc: score -> top-k hand-off -> ONE multi-target ICP launch for three objects, all through the
+    C ABI with device pointers (HIP runtime API only), equal to per-object host-pointer calls bit for bit."""
+    exe = str(tmp_path / "refine_objects")
+    lib = os.path.join(ROOT, "physimglobalpose_amd")
+    r = subprocess.run(["g++", "-O2", "-std=c++11", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+                        "-I", "/opt/rocm/include", os.path.join(ROOT, "examples", "refine_objects.cc"), "-L", lib, "-lpgp",
+                        "-L", "/opt/rocm/lib", "-lamdhip64", f"-Wl,-rpath,{lib}", "-Wl,-rpath,/opt/rocm/lib", "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe, "1024"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK")
+    print(out.stdout)
