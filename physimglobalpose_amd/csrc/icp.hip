@@ -72,6 +72,7 @@ constexpr int kIcpR = 4;                 // source points per lane per sweep
 constexpr int kTgtTile = 4096;           // target points per LDS tile (64 KB)
 constexpr int kRedPlane = 28;            // point-to-plane: count + 21 (upper triangle of AtA) + 6 (Atb)
 constexpr int kMaxSmooth = 8;            // history length of the differential checker
+constexpr int kSumR = 4;                 // consecutive source points a thread sums per block of kSumR x kIcpThreads
 
 // ---- exact nearest-neighbour index over the STATIC target cloud ---------------------------------
 // The target (the object model: UCTState.cpp:137-139, utilities.cpp:666-676 build a TrimmedICP over it
@@ -642,29 +643,46 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     double e_acc = 0.0;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    for (int base = 0; base < a.n_src; base += kIcpThreads) {
-      const int i = base + tid;
-      unsigned key = 0xFFFFFFFFu;
-      float d2 = 0.f;
-      if (i < a.n_src) {
-        d2 = d2w[i];
-        key = __float_as_uint(d2);
+    // Thread t sums the points 4 t .. 4 t + 3 of every block of 4 x 1024 points, in index order (the persistent
+    // indexed kernel maps its points the same way, so both add the same numbers in the same order): a cloud of
+    // 1756 points then sits on 7 of the 16 waves, and only those pay the 17 wave-level f64 trees.
+    for (int b0 = 0; b0 < a.n_src; b0 += kSumR * kIcpThreads) {
+      unsigned key[kSumR];
+      float d2v[kSumR];
+      bool sel[kSumR];
+#pragma unroll
+      for (int r = 0; r < kSumR; ++r) {
+        const int i = b0 + kSumR * tid + r;
+        key[r] = 0xFFFFFFFFu;
+        d2v[r] = 0.f;
+        if (i < a.n_src) {
+          d2v[r] = d2w[i];
+          key[r] = __float_as_uint(d2v[r]);
+        }
       }
-      bool sel;
       if (a.max_corr2 >= 0.f) {
-        sel = i < a.n_src && d2 <= a.max_corr2;
+#pragma unroll
+        for (int r = 0; r < kSumR; ++r) sel[r] = b0 + kSumR * tid + r < a.n_src && d2v[r] <= a.max_corr2;
       } else if (thr_key == 0xFFFFFFFFu) {
-        sel = i < a.n_src;
+#pragma unroll
+        for (int r = 0; r < kSumR; ++r) sel[r] = b0 + kSumR * tid + r < a.n_src;
       } else {
-        // ties at the threshold are taken in index order: ordered exclusive scan of the flags
-        bool tie = i < a.n_src && key == thr_key;
-        unsigned long long bm = __ballot(tie);
-        unsigned before = __popcll(bm & ((1ull << lane) - 1ull));
-        if (lane == 0) s_scan[wave] = __popcll(bm);
+        // ties at the threshold are taken in index order: ordered exclusive scan of the per-thread tie counts
+        unsigned mine = 0;
+#pragma unroll
+        for (int r = 0; r < kSumR; ++r) mine += (b0 + kSumR * tid + r < a.n_src && key[r] == thr_key) ? 1u : 0u;
+        const unsigned incl = wave_scan_incl_u32(mine);
+        if (lane == 63) s_scan[wave] = incl;
         __syncthreads();
-        unsigned woff = s_carry;
-        for (int w = 0; w < wave; ++w) woff += s_scan[w];
-        sel = i < a.n_src && (key < thr_key || (tie && woff + before < ties_to_take));
+        unsigned rank = s_carry + incl - mine;
+        for (int w = 0; w < wave; ++w) rank += s_scan[w];
+#pragma unroll
+        for (int r = 0; r < kSumR; ++r) {
+          const bool in = b0 + kSumR * tid + r < a.n_src;
+          const bool tie = in && key[r] == thr_key;
+          sel[r] = in && (key[r] < thr_key || (tie && rank < ties_to_take));
+          rank += tie ? 1u : 0u;
+        }
         __syncthreads();
         if (tid == 0) {
           unsigned tot = 0;
@@ -673,8 +691,12 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
         }
         __syncthreads();
       }
+#pragma unroll
+      for (int r = 0; r < kSumR; ++r) {
+      const int i = b0 + kSumR * tid + r;
+      const float d2 = d2v[r];
       const int jm = i < a.n_src ? jw[i] : -1;
-      if (sel && jm >= 0 && a.metric == 1) {
+      if (sel[r] && jm >= 0 && a.metric == 1) {
         const float4 s = a.src[i];
         const float4 m = a.tgt[jm];
         const float4 nn = a.tgt_n[jm];
@@ -687,13 +709,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
         acc[0] += 1.0;
         int t = 1;
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+        for (int rr = 0; rr < 6; ++rr)
 #pragma unroll
-          for (int c = r; c < 6; ++c) acc[t++] += row[r] * row[c];
+          for (int c = rr; c < 6; ++c) acc[t++] += row[rr] * row[c];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) acc[22 + r] += row[r] * rhs;
+        for (int rr = 0; rr < 6; ++rr) acc[22 + rr] += row[rr] * rhs;
         e_acc += (double)d2;
-      } else if (sel && jm >= 0) {  // jm < 0: a non-finite transformed point has no neighbour
+      } else if (sel[r] && jm >= 0) {  // jm < 0: a non-finite transformed point has no neighbour
         float4 s = a.src[i];
         float4 m = a.tgt[jm];
         acc[0] += 1.0;
@@ -703,6 +725,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
         acc[10] += (double)s.y * m.x; acc[11] += (double)s.y * m.y; acc[12] += (double)s.y * m.z;
         acc[13] += (double)s.z * m.x; acc[14] += (double)s.z * m.y; acc[15] += (double)s.z * m.z;
         e_acc += (double)d2;
+      }
       }
     }
     // wave butterfly, then the 16 wave results through LDS (aliases the target tile: all reads of
@@ -1976,9 +1999,10 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
     PGP_STAMP(1);
 
     // the source points of the sums (step 3): requested now, so that their L2 round trip passes under the selection
-    float4 sreg[PIR];
+    // (thread t sums the points 4 t .. 4 t + 3, as icp_refine does: see there)
+    float4 sreg[kSumR];
 #pragma unroll
-    for (int r = 0; r < PIR; ++r) sreg[r] = a.src[min(r * kIcpThreads + tid, a.n_src - 1)];
+    for (int r = 0; r < kSumR; ++r) sreg[r] = a.src[min(kSumR * tid + r, a.n_src - 1)];
 
     // ---- 2. selection threshold: the k-th smallest d2 (the keys are the float bits: d2 >= +0) ----------------
     unsigned thr_key = 0xFFFFFFFFu, ties_to_take = 0xFFFFFFFFu;  // default: take everything
@@ -2109,40 +2133,30 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
 #pragma unroll
     for (int k = 0; k < kNs; ++k) acc[k] = 0.0;
     double e_acc = 0.0;
-    // ties at the threshold are taken in index order (as icp_refine does, there with an ordered scan per
-    // sweep of the cloud): one ballot per sweep, the per-(sweep, wave) counts scanned once by wave 0
+    // ties at the threshold are taken in index order (as icp_refine does): exclusive scan of the per-thread
+    // tie counts -- inside the waves on the DPP path, across them through LDS
     const bool ranked = (TRIM_ONLY || a.max_corr2 < 0.f) && thr_key != 0xFFFFFFFFu;
     // the usual case: every key equal to the threshold is taken (one such key, the k-th itself) -- no ranking
     const bool all_ties = ranked && ties_to_take >= s_sel_nties;
-    unsigned before[PIR];
-#pragma unroll
-    for (int r = 0; r < PIR; ++r) before[r] = 0u;
+    const bool wave_has_points = kSumR * 64 * wave < a.n_src;   // this wave's 256 consecutive points exist
+    unsigned rank = 0;
     if (ranked && !all_ties) {
+      unsigned mine = 0;
 #pragma unroll
-      for (int r = 0; r < PIR; ++r) {
-        const int i = r * kIcpThreads + tid;
-        const bool tie = i < a.n_src && __float_as_uint(t.d2[i]) == thr_key;
-        const unsigned long long bm = __ballot(tie);
-        before[r] = __popcll(bm & ((1ull << lane) - 1ull));
-        if (lane == 0) s_tie[r * (kIcpThreads / 64) + wave] = __popcll(bm);
+      for (int r = 0; r < kSumR; ++r) {
+        const int i = kSumR * tid + r;
+        mine += (i < a.n_src && __float_as_uint(t.d2[i]) == thr_key) ? 1u : 0u;
       }
+      const unsigned incl = wave_scan_incl_u32(mine);
+      if (lane == 63) s_tie[wave] = incl;
       __syncthreads();
-      if (wave == 0) {   // exclusive scan of the 64 counts in (sweep, wave) order = index order
-        const unsigned v = lane < PIR * (kIcpThreads / 64) ? s_tie[lane] : 0u;
-        unsigned incl = v;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-          const unsigned tt = __shfl_up(incl, off, 64);
-          if (lane >= off) incl += tt;
-        }
-        s_tie[lane] = incl - v;
-      }
-      __syncthreads();
+      rank = incl - mine;
+      for (int w = 0; w < wave; ++w) rank += s_tie[w];
     }
+    if (wave_has_points) {
 #pragma unroll
-    for (int r = 0; r < PIR; ++r) {
-      const int i = r * kIcpThreads + tid;
-      if (r * kIcpThreads >= a.n_src) break;
+    for (int r = 0; r < kSumR; ++r) {
+      const int i = kSumR * tid + r;
       unsigned key = 0xFFFFFFFFu;
       float d2 = 0.f;
       if (i < a.n_src) {
@@ -2156,8 +2170,8 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         sel = i < a.n_src;
       } else {
         const bool tie = i < a.n_src && key == thr_key;
-        sel = i < a.n_src && (key < thr_key ||
-                              (tie && (all_ties || s_tie[r * (kIcpThreads / 64) + wave] + before[r] < ties_to_take)));
+        sel = i < a.n_src && (key < thr_key || (tie && (all_ties || rank < ties_to_take)));
+        rank += tie ? 1u : 0u;
       }
       const unsigned pm = i < a.n_src ? (unsigned)t.pos[i] : 0xFFFFu;   // 0xFFFF: a non-finite point has no neighbour
       if constexpr (METRIC == 1) {
@@ -2194,10 +2208,12 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         e_acc += (double)d2;
       }
     }
+    // (a wave without points holds zeros: its trees would return the same zeros)
 #pragma unroll
     for (int k = 0; k < kNs; ++k)
       acc[k] = wave_sum_f64(acc[k]);
     e_acc = wave_sum_f64(e_acc);
+    }
     // (no barrier here: s_red was last read before the previous iteration's closing barriers)
     if (lane == 0) {
 #pragma unroll
