@@ -131,3 +131,51 @@ def test_set_model_after_queued_device_scoring_does_not_overwrite_under_the_kern
         side.synchronize()
         assert np.array_equal(ds.cpu().numpy(), want)
         sc.set_model(w.Q_xyz, w.Q_nrm)
+
+
+def test_round4_entry_points_on_empty_and_bad_arguments():
+    """pgp_select_top_device, pgp_icp_refine_multi_device, pgp_congruent_batch_fit_score / _fetch: empty inputs are
+    no-ops, bad arguments and missing state are error codes with a message, nothing is dereferenced."""
+    import ctypes as C
+    import torch
+    sc = LcpScorer()
+    L, h = sc._lib, sc._h
+    d_T = torch.zeros(4, 16, device="cuda")
+    d_s = torch.tensor([0.5, 0.0, 0.7, float("nan")], device="cuda")
+    # k = 0: nothing happens; n = 0 with k > 0: all slots marked empty
+    out, idx, n = sc.select_top_device(d_T, d_s, 3, invert=False)
+    torch.cuda.synchronize()
+    assert int(n[0]) == 2 and idx.cpu().numpy().tolist() == [2, 0, -1]
+    assert L.pgp_select_top_device(h, None, None, 0, 0, 1, None, None, None, None) == 0
+    empty_T, empty_s = torch.zeros(0, 16, device="cuda"), torch.zeros(0, device="cuda")
+    out, idx, n = sc.select_top_device(empty_T, empty_s, 2)
+    torch.cuda.synchronize()
+    assert int(n[0]) == 0 and idx.cpu().numpy().tolist() == [-1, -1]
+    assert L.pgp_select_top_device(h, None, None, 5, 2, 1, C.c_void_p(out.data_ptr()), None, C.c_void_p(n.data_ptr()), None) != 0
+    assert b"bad argument" in L.pgp_last_error()
+    # multi-target ICP: no jobs, a NULL context, a job without clouds
+    prm = _lib.IcpParams(10, 0.9, 0.0, 1.0)
+    assert L.pgp_icp_refine_multi_device(None, 0, C.byref(prm), None) == 0
+    jobs = (_lib.IcpJob * 1)()
+    jobs[0] = _lib.IcpJob(None, None, 0, None, 0, None, 1, None, None)
+    assert L.pgp_icp_refine_multi_device(jobs, 1, C.byref(prm), None) != 0
+    jobs[0] = _lib.IcpJob(h, None, 10, None, 10, d_T.data_ptr(), 4, None, None)
+    assert L.pgp_icp_refine_multi_device(jobs, 1, C.byref(prm), None) != 0 and b"bad job" in L.pgp_last_error()
+    LcpScorer.icp_refine_multi_device([])                                     # a no-op
+    # a job with poses but zero-size clouds is refused by the launcher, not run
+    z4 = torch.zeros(0, 4, device="cuda")
+    with pytest.raises(_lib.PgpError):
+        LcpScorer.icp_refine_multi_device([dict(scorer=sc, d_src4=z4, d_tgt4=z4, d_T=d_T.clone())])
+    # fused fit + verification: nothing to fit is fine; fetching before any fit is a state error
+    i4 = np.zeros(4, np.int32)
+    f3 = np.zeros(3, np.float32)
+    sco, st = np.zeros(1, np.float32), np.zeros(1, np.int32)
+    bi, bs = C.c_int(7), C.c_float(3.0)
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))      # noqa: E731
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))    # noqa: E731
+    assert L.pgp_congruent_batch_fit_score(h, ip(i4), ip(i4), 0, fp(f3), fp(f3), 1, C.c_float(30.0), fp(sco), ip(st),
+                                           C.byref(bi), C.byref(bs)) == 0
+    assert bi.value == -1 and bs.value == 0.0
+    assert L.pgp_congruent_batch_fetch(h, ip(i4), 1, None, None) != 0 and b"no fits resident" in L.pgp_last_error()
+    assert L.pgp_congruent_batch_fetch(h, ip(i4), 0, None, None) == 0
+    assert L.pgp_congruent_batch_fit_score(h, None, None, 3, fp(f3), fp(f3), 1, C.c_float(30.0), None, None, None, None) != 0
