@@ -150,6 +150,7 @@ struct IcpArgs {
   // vicinity graph of the target (nnidx_vic_*): per image position the kVicK nearest other target points and a
   // radius inside which no unlisted point lies -- resolves a query next to a known candidate without a search
   const uint4* nn_vic;           // [n_tgt] or nullptr
+  int first_walk;                // moves downhill on the graph in the FIRST iteration (no previous correspondence yet)
   // lost meetings (clustered launch): a workgroup whose partners did not arrive sets *x_lost; the follow-up launch
   // (run_if = x_lost, one workgroup per pose, starting again from the transforms saved in T_save) repairs the call
   unsigned* x_lost;              // [1] in the library's own workspace
@@ -1172,6 +1173,23 @@ __device__ __forceinline__ int nn_class(const NnGeom& g, float x, float y, float
   const int c = 31 - __clz(cost);   // cost >= 3
   return c < kNnClasses - 2 ? c : kNnClasses - 2;
 }
+// One move downhill on the vicinity graph: the seven neighbours of the centre (record rec; best / bpos hold it) are
+// considered; true when a neighbour is nearer (best / bpos then hold that neighbour, the next centre).
+__device__ __forceinline__ bool nn_vic_move(const NnLds& t, const uint4 rec, float x, float y, float z,
+                                            unsigned long long& best, int& bpos) {
+  const int p = bpos;
+  const int n0 = rec.x & 0xFFFFu, n1 = rec.x >> 16, n2 = rec.y & 0xFFFFu, n3 = rec.y >> 16, n4 = rec.z & 0xFFFFu,
+            n5 = rec.z >> 16, n6 = rec.w & 0xFFFFu;
+  nn_consider(x, y, z, t.pts[n0], n0, best, bpos);
+  nn_consider(x, y, z, t.pts[n1], n1, best, bpos);
+  nn_consider(x, y, z, t.pts[n2], n2, best, bpos);
+  nn_consider(x, y, z, t.pts[n3], n3, best, bpos);
+  nn_consider(x, y, z, t.pts[n4], n4, best, bpos);
+  nn_consider(x, y, z, t.pts[n5], n5, best, bpos);
+  nn_consider(x, y, z, t.pts[n6], n6, best, bpos);
+  return bpos != p;
+}
+
 // The check on the vicinity graph (see nnidx_vic_*): the seven neighbours of the centre p (record rec; best / bpos
 // hold p on entry) are considered; returns true when a + b < R(p): nothing outside {p} u N(p) comes closer than
 // best or ties with it, i.e. best / bpos are the exhaustive scan's answer.
@@ -1455,7 +1473,7 @@ __host__ __device__ __forceinline__ bool nn_share_owns(int q, int part, int P) {
 template <int NT, int R, bool HELP = false>
 __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
                                                NnSched* sch /* LDS */, int tid, int part = 0, int P = 1, int help_pose = 0,
-                                               unsigned help_tag = 0, int* lost = nullptr) {
+                                               unsigned help_tag = 0, int* lost = nullptr, int first_walk = 0) {
   const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
               g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
   static_assert(kNnBins / 2 == 4 * NT, "four counter words per thread");
@@ -1524,6 +1542,27 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
         if (pp[r] >= 0) nn_consider(x, y, z, t.pts[pp[r]], pp[r], best[r], bpos[r]);
         if (vic && bpos[r] >= 0 && bpos[r] != pp[r]) rec[r] = vic[bpos[r]];
       }
+    }
+  }
+  // The FIRST iteration has no previous correspondence: the only candidate is the representative of the query's
+  // cell.  There -- and only there: the walk lost when every iteration paid for it -- the candidate may first walk
+  // downhill on the graph (first_walk moves, the R queries of a thread together) before the check runs at the walk's
+  // end.  Measured (profiles/r04_ab/icp_first_walk_sweep.log): 0 .. 5 moves are within 1 % of each other on poses
+  // that start centimetres off (the representative's bound is not what makes their first search dear: the empty
+  // ball around a query 4 cm from the surface is) and one move is worth ~3 % on poses that start millimetres off.
+  if (vic && first_walk > 0) {
+    for (int hop = 0; hop < first_walk; ++hop) {
+      bool moved[R];
+      bool any = false;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        moved[r] = live[r] && bpos[r] >= 0 && nn_vic_move(t, rec[r], qx[r], qy[r], qz[r], best[r], bpos[r]);
+        any = any || moved[r];
+      }
+      if (!__any(any)) break;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (moved[r]) rec[r] = vic[bpos[r]];
     }
   }
 #pragma unroll
@@ -1945,7 +1984,8 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
   for (;;) {
     PGP_STAMP(0);
     // ---- 1. correspondences ---------------------------------------------------------------------
-    nn_all_queries<kIcpThreads, PIR, HELP>(a, t, s_G, 0, n_share, &s_sch, tid, part, P, pose, (unsigned)(it + 1), &s_lost);
+    nn_all_queries<kIcpThreads, PIR, HELP>(a, t, s_G, 0, n_share, &s_sch, tid, part, P, pose, (unsigned)(it + 1), &s_lost,
+                                            it == 0 ? a.first_walk : 0);
     if (HELP && s_lost) break;
     if (CLUSTER && P > 1) {
       // publish this share (write-through, agent scope: the partners may sit on other XCDs), meet, read theirs.
@@ -2678,6 +2718,8 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.T = d_T;
   a.n = n;
   icp_option_args(prm, n_src, &a);
+  a.first_walk = 1;
+  if (const char* v = getenv("PGP_ICP_FIRST_WALK")) a.first_walk = atoi(v) < 0 ? 0 : atoi(v);   // A/B knob
   int rc;
   size_t need = (size_t)n * n_src;
   // measured (tools/icp_time.py, 2500 x 5000, 10 iterations): the split path wins at every batch
@@ -2971,6 +3013,8 @@ int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm,
   }
   IcpArgs a{};
   icp_option_args(prm, 1, &a);
+  a.first_walk = 1;
+  if (const char* v = getenv("PGP_ICP_FIRST_WALK")) a.first_walk = atoi(v) < 0 ? 0 : atoi(v);
   bool one_launch = n_jobs >= 2 && n_jobs <= kIcpMultiMax && a.metric == 0 && a.smooth == 0 && prm->nn_search != 1 &&
                     prm->nn_search != 2 && !getenv("PGP_ICP_NN") && !getenv("PGP_ICP_PERSIST") && !getenv("PGP_ICP_SPLIT");
   if (const char* v = getenv("PGP_ICP_MULTI")) one_launch = one_launch && atoi(v) != 0;   // A/B knob: 0 = job by job
