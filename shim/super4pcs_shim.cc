@@ -353,18 +353,64 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
 // that rebuilds a map IN PLACE with the same size and the same two end entries would still be taken for the
 // old one: such callers set PGP_SHIM_NO_CACHE=1 (every call gets a fresh context and uploads its map).
 // ---------------------------------------------------------------------------------------------
-struct ShimState {
+// One context PER OBJECT (the node loops over the objects of a frame, ObjectPoseCandidateSet.cpp:53-68 per object,
+// SceneCfg.cpp:379-402): an object's pair-feature table (5 MB at 18 682 keys: milliseconds to flatten, upload and
+// hash), its validation model (Morton sort + upload) and its search model stay resident in ITS context from frame
+// to frame, so that alternating objects do not evict each other; what a call uploads is the segment.  An object is
+// recognised by its PPFMap (address, size, fingerprint of its end entries); the models are compared by a hash of
+// their (centred) coordinates and re-sent only when they changed.  At most kSlots objects, least recently used out.
+struct ObjectSlot {
   pgp_ctx* ctx = nullptr;
+  const void* map_addr = nullptr;
+  size_t map_size = 0;
+  unsigned long long map_print = 0;
+  bool map_loaded = false;
+  unsigned long long model_hash = 0, search_hash = 0;
+  unsigned long long stamp = 0;
+};
+struct ShimState {
+  static constexpr int kSlots = 8;
+  ObjectSlot slot[kSlots];
+  unsigned long long clock = 0;
+  pgp_ctx* ctx = nullptr;             // PGP_SHIM_NO_CACHE / several devices: the single context of older rounds
   pgp_multi* group = nullptr;
   const void* map_addr = nullptr;
   size_t map_size = 0;
   unsigned long long map_print = 0;   // fingerprint of the map's two end entries
   const void* map_ctx = nullptr;      // the context the table was uploaded to
+  ObjectSlot* find(const void* addr, size_t size, unsigned long long print) {
+    ObjectSlot* lru = &slot[0];
+    for (ObjectSlot& o : slot) {
+      if (o.ctx && o.map_addr == addr && o.map_size == size && o.map_print == print) {
+        o.stamp = ++clock;
+        return &o;
+      }
+      if (o.stamp < lru->stamp) lru = &o;
+    }
+    // the least recently used slot is re-used for the new object (its context keeps its allocations)
+    lru->map_addr = addr;
+    lru->map_size = size;
+    lru->map_print = print;
+    lru->map_loaded = false;
+    lru->model_hash = lru->search_hash = 0;
+    lru->stamp = ++clock;
+    return lru;
+  }
   ~ShimState() {
     if (group) pgp_multi_destroy(group);
     if (ctx) pgp_destroy(ctx);
+    for (ObjectSlot& o : slot)
+      if (o.ctx) pgp_destroy(o.ctx);
   }
 };
+static unsigned long long cloud_hash(const std::vector<float>& a, const std::vector<float>& b) {
+  unsigned long long h0 = 0x9E3779B97F4A7C15ull ^ (unsigned long long)a.size(), h1 = 0xC2B2AE3D27D4EB4Full ^ (unsigned long long)b.size();
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(a.data());
+  for (size_t i = 0; i < a.size(); ++i) h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
+  w = reinterpret_cast<const uint32_t*>(b.data());
+  for (size_t i = 0; i < b.size(); ++i) h1 = (h1 ^ w[i]) * 0x100000001B3ull + (h1 >> 31);
+  return (h0 ^ (h1 * 0x9E3779B97F4A7C15ull)) | 1ull;
+}
 
 ShimState& shim_state() {
   static thread_local ShimState st;
@@ -634,6 +680,20 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   // ---- device state: scene index, validation model, search model, pair-feature table
   ShimState local_state;
   ShimState& st = getenv("PGP_SHIM_NO_CACHE") ? local_state : shim_state();
+  ObjectSlot* obj = nullptr;
+  // fingerprint of the caller's PPFMap (its two end entries): with its address and size, what an object is known by
+  unsigned long long print = 0x9E3779B97F4A7C15ull;
+  if (!PPFMap.empty()) {
+    auto mix = [&print](long long v) { print = (print ^ (unsigned long long)v) * 0x100000001B3ull + (print >> 31); };
+    const auto& a = *PPFMap.begin();
+    const auto& b = *PPFMap.rbegin();
+    for (int v : a.first) mix(v);
+    mix((long long)a.second.size());
+    if (!a.second.empty()) { mix(a.second.front().first); mix(a.second.front().second); mix(a.second.back().first); mix(a.second.back().second); }
+    for (int v : b.first) mix(v);
+    mix((long long)b.second.size());
+    if (!b.second.empty()) { mix(b.second.front().first); mix(b.second.front().second); mix(b.second.back().first); mix(b.second.back().second); }
+  }
   const int n_dev = shim_device_count();   // PGP_SHIM_DEVICES: 1 (default) | n | all
   // Exact distance ties go to the point the reference's kd-tree returns (pgp_set_exact_ties: its tree is then built
   // with the scene, +2-3 ms) -- by default only for a segment that HOLDS DUPLICATED POINTS, the one case in which
@@ -652,7 +712,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     for (int d = 0; pgp_multi_context(st.group, d); ++d) SHIM_PGP(pgp_set_exact_ties(pgp_multi_context(st.group, d), exact_ties ? 1 : 0));
     SHIM_PGP(pgp_multi_set_scene(st.group, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     SHIM_PGP(pgp_multi_set_model(st.group, qval.xyz.data(), qval.nrm.data(), qval.n));
-  } else {
+  } else if (&st == &local_state) {
     if (!st.ctx) SHIM_PGP(pgp_create(&st.ctx, -1));
     ctx = st.ctx;
     SHIM_PGP(pgp_set_exact_ties(ctx, exact_ties ? 1 : 0));
@@ -661,23 +721,40 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     mark("set_scene");
     SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
     mark("set_model");
+  } else {
+    // the object's own context: models and pair-feature table stay resident in it
+    obj = st.find((const void*)&PPFMap, PPFMap.size(), print);
+    if (!obj->ctx) SHIM_PGP(pgp_create(&obj->ctx, -1));
+    ctx = obj->ctx;
+    SHIM_PGP(pgp_set_exact_ties(ctx, exact_ties ? 1 : 0));
+    mark("ties+context");
+    SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
+    mark("set_scene");
+    const unsigned long long mh = cloud_hash(qval.xyz, qval.nrm);
+    if (mh != obj->model_hash) {
+      obj->model_hash = 0;
+      SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
+      obj->model_hash = mh;
+    }
+    mark("set_model");
   }
-  SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
+  if (obj) {
+    static const std::vector<float> none;
+    const unsigned long long sh = cloud_hash(qsearch.xyz, none);
+    if (sh != obj->search_hash || !obj->map_loaded) {
+      obj->search_hash = 0;
+      obj->map_loaded = false;        // the table's pair lists index the search model: both go together
+      SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
+      obj->search_hash = sh;
+    }
+  } else {
+    SHIM_PGP(pgp_set_search_model(ctx, qsearch.xyz.data(), qsearch.n));
+  }
   mark("set_search_model");
-  unsigned long long print = 0x9E3779B97F4A7C15ull;
-  if (!PPFMap.empty()) {
-    auto mix = [&print](long long v) { print = (print ^ (unsigned long long)v) * 0x100000001B3ull + (print >> 31); };
-    const auto& a = *PPFMap.begin();
-    const auto& b = *PPFMap.rbegin();
-    for (int v : a.first) mix(v);
-    mix((long long)a.second.size());
-    if (!a.second.empty()) { mix(a.second.front().first); mix(a.second.front().second); mix(a.second.back().first); mix(a.second.back().second); }
-    for (int v : b.first) mix(v);
-    mix((long long)b.second.size());
-    if (!b.second.empty()) { mix(b.second.front().first); mix(b.second.front().second); mix(b.second.back().first); mix(b.second.back().second); }
-  }
-  if (st.map_addr != (const void*)&PPFMap || st.map_size != PPFMap.size() || st.map_print != print ||
-      st.map_ctx != (const void*)ctx) {
+  const bool map_stale = obj ? !obj->map_loaded
+                             : (st.map_addr != (const void*)&PPFMap || st.map_size != PPFMap.size() || st.map_print != print ||
+                                st.map_ctx != (const void*)ctx);
+  if (map_stale) {
     // std::map<std::vector<int>, std::vector<std::pair<int,int>>> -> keys | counts | pairs
     static_assert(sizeof(std::pair<int, int>) == 2 * sizeof(int), "pair<int,int> must be two packed ints");
     std::vector<int> keys, counts, pairs;
@@ -691,10 +768,14 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
       pairs.insert(pairs.end(), p, p + 2 * kv.second.size());
     }
     SHIM_PGP(pgp_set_ppf_map(ctx, keys.data(), counts.data(), pairs.data(), (int)counts.size()));
-    st.map_addr = &PPFMap;
-    st.map_size = PPFMap.size();
-    st.map_print = print;
-    st.map_ctx = ctx;
+    if (obj) {
+      obj->map_loaded = true;
+    } else {
+      st.map_addr = &PPFMap;
+      st.map_size = PPFMap.size();
+      st.map_print = print;
+      st.map_ctx = ctx;
+    }
   }
 
   mark("ppf_map");

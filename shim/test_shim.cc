@@ -56,7 +56,14 @@ int main(int argc, char** argv) {
   // pays context creation and the code-object load); every call starts from fresh output containers
   const int repeat = std::getenv("SHIM_TEST_REPEAT") ? std::max(1, std::atoi(std::getenv("SHIM_TEST_REPEAT"))) : 1;
   std::vector<double> elapsed;
+  // SHIM_TEST_TWO_OBJECTS=1: a second object with its own PPFMap (a copy: another address) alternates with the first,
+  // as the node's object loop does -- each keeps its table and models resident in its own context
+  std::map<std::vector<int>, std::vector<std::pair<int, int> > > PPFMap2;
+  const bool two = std::getenv("SHIM_TEST_TWO_OBJECTS") != nullptr;
+  if (two) PPFMap2 = PPFMap;
+  std::map<std::vector<int>, std::vector<std::pair<int, int> > >* maps[2] = {&PPFMap, two ? &PPFMap2 : &PPFMap};
   for (int rep = 0; rep < repeat; ++rep) {
+    std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMapCall = *maps[rep & 1];
     best.first.matrix().setIdentity();
     best.second = 0;
     hyps.clear();
@@ -74,10 +81,10 @@ int main(int argc, char** argv) {
       const Super4PCSCloudView v = {vx.data(), vn.data(), (int)(vx.size() / 3)};
       const Super4PCSCloudView q = {qx.data(), qn.data(), (int)(qx.size() / 3)};
       const auto t1 = std::chrono::steady_clock::now();   // the in-memory caller holds its clouds already
-      getProbableTransformsSuper4PCS(s, v, q, have ? px.data() : nullptr, rows, cols, best, hyps, PPFMap, K, registered);
+      getProbableTransformsSuper4PCS(s, v, q, have ? px.data() : nullptr, rows, cols, best, hyps, PPFMapCall, K, registered);
       elapsed.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     } else {
-      getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMap, 0, K, "synthetic_object",
+      getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], best, hyps, argv[4], PPFMapCall, 0, K, "synthetic_object",
                                      "./", registered);
       elapsed.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
