@@ -319,7 +319,7 @@ def other_rows(sc, w, torch, mode_name, d_batches):
     """Secondary measurements for the other rows of SURVEY section 8 (not the headline metric):
     weighted LCP, batched ICP, congruent-set extraction, rigid fits.  Device time via host wall
     clock around synchronous C-ABI calls, inputs staged per call (PCIe inclusive)."""
-    from physimglobalpose_amd import PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
+    from physimglobalpose_amd import LcpScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
     out = {}
     rng = np.random.default_rng(0)
 
@@ -353,6 +353,27 @@ def other_rows(sc, w, torch, mode_name, d_batches):
     sc.set_kernel_timing(False)
     out[o_name + "_lcp"] = {"hypotheses_per_s": N_HYP / dtw, "ms_per_step": dtw * 1e3, "gate_deg": float(w.gate_deg),
                             "roofline": roofline_block(o_name, N_HYP, kern_ms / max(launches, 1), launches)}
+    # the headline mode with the reference's rule on EXACT float distance ties (pgp_set_exact_ties: the kd-tree is rebuilt with
+    # the scene and descended for tied candidates; DESIGN section 2: one hypothesis in 32 768 of this very workload differs
+    # without it) -- what full parity costs on the same clock
+    try:
+        st = LcpScorer()
+        st.set_exact_ties(True)
+        st.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+        st.reserve(N_HYP)
+        for k in range(20):
+            st.score_device(d_batches[k % len(d_batches)], ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(200):
+            st.score_device(d_batches[k % len(d_batches)], ds, dc, db, mode=PGP_MODE_WEIGHTED, gate_deg=w.gate_deg)
+        torch.cuda.synchronize()
+        dte = (time.perf_counter() - t0) / 200
+        out["weighted_lcp_exact_ties"] = {"hypotheses_per_s": N_HYP / dte, "ms_per_step": dte * 1e3,
+                                          "note": "opt-in: pgp_set_exact_ties(ctx, 1); the headline runs the default rule (lowest scene index)"}
+        del st
+    except Exception as e:
+        out["weighted_lcp_exact_ties"] = {"error": repr(e)}
     # ICP (UCTState::performTrICP form, trim 0.9): 2500-pt segment vs the 5000-pt model, 10 iterations per pose.
     # Guesses = ground truth perturbed by <= 5 degrees about the CAMERA origin (0.7 m away: the segment starts up
     # to 6 cm off the model, the dear regime of the index) + 5 mm; "poses" = 64 is the round-1/2 point.
