@@ -30,7 +30,8 @@ constexpr int kMaxDepth = 32;             // KD_MAX_DEPTH, kdtree.h:60
 struct Builder {
   std::vector<float> pts;     // xyz, reordered in place
   std::vector<int> idx;       // original index of the point at each position
-  std::vector<int4> nodes;    // inner: {bits(split value), first child, dim, 0}; leaf: {start, size, 0, 1}
+  std::vector<int4> nodes;    // inner: {bits(split value), first child, dim, parent << 1}; leaf: {start, size, 0, parent << 1 | 1}
+  std::vector<int> parent;    // of every node (the root: itself): the device descent keeps no stack, it climbs
 
   void swap_pts(int a, int b) {
     for (int k = 0; k < 3; ++k) std::swap(pts[3 * (size_t)a + k], pts[3 * (size_t)b + k]);
@@ -50,7 +51,7 @@ struct Builder {
     return pts[3 * (size_t)l + dim] < v ? l + 1 : l;
   }
 
-  void leaf(int node, int start, int size) { nodes[node] = make_int4(start, size, 0, 1); }
+  void leaf(int node, int start, int size) { nodes[node] = make_int4(start, size, 0, (parent[node] << 1) | 1); }
 
   // kdtree.h:560-641: split the largest extent of the node's bounding box at its middle
   void create(int node, int start, int end, int level) {
@@ -71,7 +72,9 @@ struct Builder {
     const int first = (int)nodes.size();
     nodes.push_back(make_int4(0, 0, 0, 0));
     nodes.push_back(make_int4(0, 0, 0, 0));
-    nodes[node] = make_int4(__builtin_bit_cast(int, v), first, dim, 0);
+    parent.push_back(node);
+    parent.push_back(node);
+    nodes[node] = make_int4(__builtin_bit_cast(int, v), first, dim, parent[node] << 1);
     if ((unsigned)(mid - start) <= kPointsPerCell || level >= kMaxDepth) leaf(first, start, mid - start);
     else create(first, start, mid, level + 1);
     if ((unsigned)(end - mid) <= kPointsPerCell || level >= kMaxDepth) leaf(first + 1, mid, end - mid);
@@ -90,6 +93,7 @@ int build_kd_ties(pgp_ctx* ctx, const float* h_xyz, int n) {
   for (int i = 0; i < n; ++i) b.idx[i] = i;
   b.nodes.reserve(n > 0 ? 4 * (size_t)n / kPointsPerCell + 8 : 8);
   b.nodes.push_back(make_int4(0, 0, 0, 0));   // the root is an inner node even over an empty cloud (kdtree.h:362-367)
+  b.parent.push_back(0);
   b.create(0, 0, n, 1);
   std::vector<float4> hp((size_t)std::max(n, 1));
   for (int i = 0; i < n; ++i)

@@ -320,19 +320,20 @@ struct ScoreArgs {
 // inclusive test inside a leaf, so that among equal distances the point the reference visits last is returned.
 __device__ __attribute__((noinline)) int kd_restricted_nn(const int4* __restrict__ nodes, const float4* __restrict__ pts,
                                                           float x, float y, float z, float sq_eps) {
-  int st_node[64];
-  float st_sq[64];
+  // The reference keeps a stack of {node, squared plane distance}: the near child inherits its parent's entry (which has just
+  // passed the test, with the same best), so it is ALWAYS visited; the far child's entry is the squared offset to the parent's
+  // plane, tested against the best when the near subtree is done.  Both are functions of the parent alone, so the same order of
+  // visits is walked here WITHOUT a stack, climbing through parent links (node.w >> 1) -- a 512-byte stack per lane was the only
+  // scratch memory of every kernel that can meet a tie (finalize_scores among them, launched with every scoring call).
   int cl_id = -1;
   float cl_dist = sq_eps;
-  st_node[0] = 0;
-  st_sq[0] = 0.f;
-  int count = 1;
-  while (count) {
-    const int top = count - 1;
-    const int4 nd = nodes[st_node[top]];
-    if (st_sq[top] < cl_dist) {
-      if (nd.w) {   // leaf {start, size}
-        --count;
+  if (!(0.f < cl_dist)) return cl_id;   // the root's own entry {0, 0.f} fails the test
+  int node = 0, child = 0;
+  bool down = true;
+  for (;;) {
+    const int4 nd = nodes[node];
+    if (down) {
+      if (nd.w & 1) {   // leaf {start, size}
         for (int i = nd.x; i < nd.x + nd.y; ++i) {
           const float4 p = pts[i];
           const float d2 = sqdist(x, y, z, p);
@@ -341,22 +342,26 @@ __device__ __attribute__((noinline)) int kd_restricted_nn(const int4* __restrict
             cl_id = __float_as_int(p.w);
           }
         }
-      } else {      // inner {bits(split), first child, dim}
+        child = node;
+        node = nd.w >> 1;
+        down = false;
+      } else {          // inner {bits(split), first child, dim}: the query's side first
         const float q = nd.z == 0 ? x : (nd.z == 1 ? y : z);
         const float new_off = __fsub_rn(q, __int_as_float(nd.x));
-        if (new_off < 0.f) {
-          st_node[count] = nd.y;
-          st_node[top] = nd.y + 1;
-        } else {
-          st_node[count] = nd.y + 1;
-          st_node[top] = nd.y;
-        }
-        st_sq[count] = st_sq[top];
-        st_sq[top] = __fmul_rn(new_off, new_off);
-        ++count;
+        node = new_off < 0.f ? nd.y : nd.y + 1;
       }
-    } else {
-      --count;
+    } else {            // back in an inner node, from `child`
+      const float q = nd.z == 0 ? x : (nd.z == 1 ? y : z);
+      const float new_off = __fsub_rn(q, __int_as_float(nd.x));
+      const int near = new_off < 0.f ? nd.y : nd.y + 1;
+      if (child == near && __fmul_rn(new_off, new_off) < cl_dist) {
+        node = new_off < 0.f ? nd.y + 1 : nd.y;
+        down = true;
+        continue;
+      }
+      if (node == 0) break;
+      child = node;
+      node = nd.w >> 1;
     }
   }
   return cl_id;
@@ -1021,15 +1026,105 @@ __global__ __launch_bounds__(256) void registered_model(ScoreArgs a, const float
 constexpr int kRefineCap = 128;
 constexpr int kRefineGroup = 4;         // candidates settled together (one summation lane each)
 constexpr int kSeqChunk = 1024;         // floats per candidate staged through LDS per step
+constexpr int kSeqStride4 = kSeqChunk / 4 + 16;   // float4 per staged row: sixteen of padding (seq_sum_rows reads ahead)
 
 __device__ __forceinline__ float refine_tol(float best_score, int nQ) {
   const float rel = fmaxf(4.1f * 5.9604645e-8f * __fsqrt_rn((float)nQ), 4.8e-7f);
   return best_score * rel;
 }
 
+// Sequential float sums of G <= kRefineGroup rows of nQ4 floats (row g at seq + g * nQ4), lane g's return value = row g's sum
+// added in index order from +0.0f (base.cc:1737-1759).  All 256 threads of the block, wave g serving row g: the rows pass
+// through LDS in chunks of kSeqChunk floats with their ZEROS DROPPED in order (x + 0 == x for every x the sum can hold: it
+// starts at +0.0f and can not become -0.0f; a point that does not register contributes +0.0f, and that is most of them for
+// any pose but a very good one), the next chunk's global loads are in flight (registers) while lanes 0..G-1 add the current
+// one, and the LDS reads run eight 16-byte requests ahead of the adds -- the lane's time is then its chain of dependent adds
+// (~10 cycles each on this part) over the REGISTERED points only, not a load round trip per four model points (16 us per
+// 1500 points before, profiles/r04_dropin_kernels.txt).
+__device__ __forceinline__ float seq_sum_rows(const float* __restrict__ seq, int nQ4, int G, float4 (*s_stage)[kSeqStride4],
+                                              int* s_cnt) {
+  static_assert(kRefineGroup == 4 && kSeqChunk % 64 == 0, "one wave of the 256-thread block per row");
+  constexpr int kPer = kSeqChunk / 64;   // floats per lane and chunk
+  if (nQ4 <= 0) return 0.0f;
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const float* row = seq + (size_t)min(g, G - 1) * nQ4;
+  float regs[kPer];
+  auto fetch = [&](int c0) {   // every load issued, none behind a branch, none consumed before park()
+    const int len = min(kSeqChunk, nQ4 - c0);
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      const int i = k * 64 + lane;
+      regs[k] = row[i < len ? c0 + i : 0];
+    }
+  };
+  auto park = [&](int c0) {    // the chunk's non-zero values, in order, then zeros up to a whole group of the adding loop
+    const int len = min(kSeqChunk, nQ4 - c0);
+    float* dst = reinterpret_cast<float*>(s_stage[g]);
+    int n = 0;
+    if (g < G) {
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const bool nz = k * 64 + lane < len && regs[k] != 0.0f;   // (a NaN weight is kept and poisons the sum as it must)
+        const unsigned long long m = __ballot(nz);
+        if (nz) dst[n + __popcll(m & ((1ull << lane) - 1ull))] = regs[k];
+        n += __popcll(m);
+      }
+      dst[n + lane] = 0.0f;   // rows hold kSeqChunk + 64 floats
+      if (lane == 0) s_cnt[g] = n;
+    }
+  };
+  float S = 0.0f;
+  fetch(0);
+  park(0);
+  __syncthreads();
+  for (int c0 = 0; c0 < nQ4; c0 += kSeqChunk) {
+    const bool more = c0 + kSeqChunk < nQ4;
+    if (more) fetch(c0 + kSeqChunk);
+    if ((int)threadIdx.x < G) {
+      const float4* v = s_stage[threadIdx.x];
+      const int n4 = (s_cnt[threadIdx.x] + 63) / 64 * 16;   // whole groups of sixteen float4
+      float4 A[8], B[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) A[k] = v[k];
+      for (int i = 0; i < n4; i += 16) {
+        // B is requested before A's 32 dependent adds and A's next eight before B's (rows are padded by sixteen float4, so
+        // the last request needs no clamp)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) B[k] = v[i + 8 + k];
+        __builtin_amdgcn_sched_barrier(0);   // (the scheduler otherwise gathers all sixteen reads at the top and waits for them)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          S = __fadd_rn(S, A[k].x);
+          S = __fadd_rn(S, A[k].y);
+          S = __fadd_rn(S, A[k].z);
+          S = __fadd_rn(S, A[k].w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) A[k] = v[i + 16 + k];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          S = __fadd_rn(S, B[k].x);
+          S = __fadd_rn(S, B[k].y);
+          S = __fadd_rn(S, B[k].z);
+          S = __fadd_rn(S, B[k].w);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();
+    if (more) {
+      park(c0 + kSeqChunk);
+      __syncthreads();
+    }
+  }
+  return S;
+}
+
 // Exact scores of G <= kRefineGroup hypotheses hs[0..G) -> s_out[0..G).  All threads of the block.
 __device__ void refine_exact_group(const ScoreArgs& a, const int* hs, int G, float* __restrict__ seq,
-                                   float (*s_stage)[kSeqChunk], float* s_out) {
+                                   float4 (*s_stage)[kSeqStride4], int* s_cnt, float* s_out) {
   const int nQ4 = (a.nQ + 3) & ~3;
   // registered weights of every candidate, scattered to ORIGINAL model order: two model points per
   // thread and trip, so that their lookup chains overlap
@@ -1049,34 +1144,14 @@ __device__ void refine_exact_group(const ScoreArgs& a, const int* hs, int G, flo
     }
   }
   __syncthreads();
-  float S = 0.0f;   // lane g's running sum (base.cc:1737 `Scalar weighted_match = 0`)
-  for (int c0 = 0; c0 < nQ4; c0 += kSeqChunk) {
-    const int len = min(kSeqChunk, nQ4 - c0);   // a multiple of four
-    for (int g = 0; g < G; ++g)
-      for (int i = threadIdx.x; i < len; i += blockDim.x) s_stage[g][i] = seq[(size_t)g * nQ4 + c0 + i];
-    __syncthreads();
-    if ((int)threadIdx.x < G) {
-      const float4* v = reinterpret_cast<const float4*>(s_stage[threadIdx.x]);
-      const int n4 = len / 4;
-      float4 cur = v[0];
-      for (int i = 0; i < n4; ++i) {
-        const float4 nxt = v[min(i + 1, n4 - 1)];   // the next read is in flight under this trip's adds
-        S = __fadd_rn(S, cur.x);
-        S = __fadd_rn(S, cur.y);
-        S = __fadd_rn(S, cur.z);
-        S = __fadd_rn(S, cur.w);
-        cur = nxt;
-      }
-    }
-    __syncthreads();
-  }
+  const float S = seq_sum_rows(seq, nQ4, G, s_stage, s_cnt);
   if ((int)threadIdx.x < G) s_out[threadIdx.x] = __fdiv_rn(S, (float)a.nQ);   // base.cc:1765
   __syncthreads();
 }
 
 // Called by all 256 threads of ONE block with kk = the arg-max key over the (tree-summed) score
 // vector: publishes {best index, best score bits}, settling weighted near-ties exactly (above).
-__device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int mode, int refine, float* scores,
+__device__ __forceinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int mode, int refine, float* scores,
                                                 const unsigned long long kk, int* __restrict__ best,
                                                 float* __restrict__ seq, unsigned long long* s_key) {
   if (kk == 0) {
@@ -1090,7 +1165,8 @@ __device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int
   float bs = __uint_as_float((unsigned)(kk >> 32));
   if (mode == PGP_MODE_WEIGHTED && refine) {
     __shared__ int s_red[4];
-    __shared__ float s_stage[kRefineGroup][kSeqChunk];
+    __shared__ float4 s_stage[kRefineGroup][kSeqStride4];
+    __shared__ int s_seqcnt[kRefineGroup];
     __shared__ float s_exact[kRefineGroup];
     __shared__ int s_cand[kRefineGroup];
     const float thr = bs - refine_tol(bs, a.nQ);
@@ -1126,7 +1202,7 @@ __device__ __noinline__ void settle_and_publish(const ScoreArgs& a, int n_h, int
         }
         __syncthreads();
         if (G == 0) break;
-        refine_exact_group(a, s_cand, G, seq, s_stage, s_exact);
+        refine_exact_group(a, s_cand, G, seq, s_stage, s_seqcnt, s_exact);
         for (int g = 0; g < G; ++g) {
           const float e = s_exact[g];
           const int h = s_cand[g];
@@ -1276,7 +1352,9 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
+#if !(defined(PGP_ABLATE) && PGP_ABLATE == 11)   // 11: what the common launch would cost without the settlement in its code object
     settle_and_publish(a, n_h, mode, refine, scores, kk, best, seq, s_key);
+#endif
   } else if (threadIdx.x == 0) {
     if (kk == 0) {
       best[0] = -1;
@@ -1332,41 +1410,67 @@ constexpr int kRecordCap = 128;
 // 1. the near-records, in index order (one block)
 __global__ __launch_bounds__(256) void records_find(int n_h, int nQ, const float* __restrict__ scores,
                                                     int* __restrict__ list, int* __restrict__ count) {
-  __shared__ float s_cmax[256];
-  __shared__ int s_cnt[256];
-  const int tid = threadIdx.x;
-  const int per = (n_h + 255) / 256, lo = tid * per, hi = min(lo + per, n_h);
-  float m = 0.f;   // records are > 0 (best_LCP_ starts at 0)
-  for (int h = lo; h < hi; ++h) m = fmaxf(m, scores[h]);
-  s_cmax[tid] = m;
-  __syncthreads();
-  float run = 0.f;   // running maximum of the tree scores before this thread's chunk
-  for (int t = 0; t < tid; ++t) run = fmaxf(run, s_cmax[t]);
-  int cnt = 0;
-  {
-    float r = run;
-    for (int h = lo; h < hi; ++h) {
-      const float v = scores[h];
-      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), nQ)) ++cnt;
-      r = fmaxf(r, v);
+  // 4096 scores per pass, 16 consecutive ones per thread held in registers: ONE batch of loads, the running maximum in front of
+  // every thread's run by a prefix-max over the block, the positions of its near-records by a prefix sum (19 us as three
+  // passes of dependent loads with serial prefix loops, profiles/r04_dropin_kernels.txt)
+  constexpr int kPer = 16;
+  __shared__ float s_wmax[4];
+  __shared__ int s_wcnt[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float carry = 0.f;   // records are > 0 (best_LCP_ starts at 0)
+  int base = 0;
+  for (int s0 = 0; s0 < n_h; s0 += 256 * kPer) {
+    float v[kPer];
+    const int lo = s0 + tid * kPer;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) v[k] = lo + k < n_h ? scores[lo + k] : 0.f;
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) m = fmaxf(m, v[k]);
+    float inc = m;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc = fmaxf(inc, o);
     }
-  }
-  s_cnt[tid] = cnt;
-  __syncthreads();
-  int off = 0;
-  for (int t = 0; t < tid; ++t) off += s_cnt[t];
-  {
-    float r = run;
-    for (int h = lo; h < hi; ++h) {
-      const float v = scores[h];
-      if (v > 0.f && v >= r - 2.0f * refine_tol(fmaxf(r, v), nQ)) {
-        if (off < kRecordCap) list[off] = h;
-        ++off;
+    if (lane == 63) s_wmax[wave] = inc;
+    float run = __shfl_up(inc, 1, 64);   // running maximum of the tree scores before this thread's run
+    if (lane == 0) run = 0.f;
+    __syncthreads();
+    run = fmaxf(run, carry);
+    for (int w = 0; w < wave; ++w) run = fmaxf(run, s_wmax[w]);
+    carry = fmaxf(carry, fmaxf(fmaxf(s_wmax[0], s_wmax[1]), fmaxf(s_wmax[2], s_wmax[3])));
+    unsigned mask = 0;
+    {
+      float r = run;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        const float x = v[k];
+        if (x > 0.f && x >= r - 2.0f * refine_tol(fmaxf(r, x), nQ)) mask |= 1u << k;
+        r = fmaxf(r, x);
       }
-      r = fmaxf(r, v);
     }
+    const int cnt = __popc(mask);
+    int pre = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(pre, off, 64);
+      if (lane >= off) pre += o;
+    }
+    if (lane == 63) s_wcnt[wave] = pre;
+    __syncthreads();
+    int off = base + pre - cnt;
+    for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+    base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    while (mask) {
+      const int k = __ffs(mask) - 1;
+      mask &= mask - 1;
+      if (off < kRecordCap) list[off] = lo + k;
+      ++off;
+    }
+    __syncthreads();   // s_wmax / s_wcnt are rewritten by the next pass
   }
-  if (tid == 255) *count = min(off, kRecordCap);   // the last thread's running offset is the total
+  if (tid == 0) *count = min(base, kRecordCap);
 }
 
 // 2. the registered weight of every (near-record, model point), one row of nQ4 floats per near-record in
@@ -1394,33 +1498,14 @@ __global__ __launch_bounds__(256) void records_weights(ScoreArgs a, const int* _
 //    one row's 5000 dependent adds whatever the number of near-records.
 __global__ __launch_bounds__(256) void records_sum(int nQ, const int* __restrict__ list, const int* __restrict__ count,
                                                    const float* __restrict__ seq, float* __restrict__ scores) {
-  __shared__ float s_stage[kRefineGroup][kSeqChunk];
+  __shared__ float4 s_stage[kRefineGroup][kSeqStride4];
+  __shared__ int s_cnt[kRefineGroup];
   const int g0 = blockIdx.x * kRefineGroup;
   const int n = *count;
   if (g0 >= n) return;
   const int G = min(kRefineGroup, n - g0);
   const int nQ4 = (nQ + 3) & ~3;
-  float S = 0.0f;   // lane g's running sum (base.cc:1737 `Scalar weighted_match = 0`)
-  for (int c0 = 0; c0 < nQ4; c0 += kSeqChunk) {
-    const int len = min(kSeqChunk, nQ4 - c0);   // a multiple of four
-    for (int g = 0; g < G; ++g)
-      for (int i = threadIdx.x; i < len; i += blockDim.x) s_stage[g][i] = seq[(size_t)(g0 + g) * nQ4 + c0 + i];
-    __syncthreads();
-    if ((int)threadIdx.x < G) {
-      const float4* v = reinterpret_cast<const float4*>(s_stage[threadIdx.x]);
-      const int n4 = len / 4;
-      float4 cur = v[0];
-      for (int i = 0; i < n4; ++i) {
-        const float4 nxt = v[min(i + 1, n4 - 1)];   // the next read is in flight under this trip's adds
-        S = __fadd_rn(S, cur.x);
-        S = __fadd_rn(S, cur.y);
-        S = __fadd_rn(S, cur.z);
-        S = __fadd_rn(S, cur.w);
-        cur = nxt;
-      }
-    }
-    __syncthreads();
-  }
+  const float S = seq_sum_rows(seq + (size_t)g0 * nQ4, nQ4, G, s_stage, s_cnt);
   if ((int)threadIdx.x < G) scores[list[g0 + threadIdx.x]] = __fdiv_rn(S, (float)nQ);
 }
 
