@@ -801,8 +801,12 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       // the low word of the owner's result: plain 0 / 1; weighted the id of the minimum key, -1 if none
       if (occ) rlo = reinterpret_cast<const uint32_t*>(res)[2 * r];
       if (TIES && kW) {   // tied candidates at the minimum: the reference's tree decides (rare)
+#if defined(PGP_ABLATE) && PGP_ABLATE == 12   // ties seen (both minima kept) but never resolved: the cost of SEEING them alone
+        if (occ && rlo != 0xFFFFFFFFu && reinterpret_cast<const uint32_t*>(res_hi)[2 * r] != ~rlo) rlo = ~reinterpret_cast<const uint32_t*>(res_hi)[2 * r];
+#else
         if (occ && rlo != 0xFFFFFFFFu && reinterpret_cast<const uint32_t*>(res_hi)[2 * r] != ~rlo)
           rlo = (uint32_t)kd_restricted_nn(a.kd_nodes, a.kd_pts, x, y, z, a.sq_eps);
+#endif
       }
     } else {
       // oversized wave-iteration (very dense scene): per-lane walk
