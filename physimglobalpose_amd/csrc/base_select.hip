@@ -781,7 +781,7 @@ int launch_ppf_features(pgp_ctx* ctx, const int* h_pairs, int m, int* h_f, int* 
   PGP_HIP(hipMemcpyAsync(d_pairs, h_pairs, M * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(ppf_features, dim3((m + 255) / 256), dim3(256), 0, st, a, (const int2*)d_pairs, m, d_f, d_row);
   PGP_HIP(hipGetLastError());
-  PGP_HIP(hipMemcpyAsync(h_f, d_f, M * 16, hipMemcpyDeviceToHost, st));
+  if (h_f) PGP_HIP(hipMemcpyAsync(h_f, d_f, M * 16, hipMemcpyDeviceToHost, st));   // (null: the caller wants the rows only)
   if (h_row) PGP_HIP(hipMemcpyAsync(h_row, d_row, M * 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
   return PGP_OK;

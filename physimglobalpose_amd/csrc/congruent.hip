@@ -37,6 +37,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <chrono>
 #include <vector>
 
 namespace pgp {
@@ -301,10 +302,11 @@ struct CsBatchArgs {
   uint32_t* bucket_cnt;
   const uint32_t* bucket_start;
   int4* entries;              // {cell_lo, cell_hi, bin | base << 16, P-pair index}
-  uint32_t* q_cnt;
-  const uint32_t* q_start;
   unsigned long long* keys;   // base << 48 | P-pair << 24 | Q-pair
   uint32_t total_p, total_q;
+  uint32_t* n_keys;           // bq_match: matches appended so far (may pass key_cap: the host then grows and repeats)
+  uint32_t* base_cnt;         // [nb] matches per base
+  uint32_t key_cap;
 };
 
 __device__ __forceinline__ int base_of(const BatchBase* __restrict__ bases, int nb, uint32_t t, bool q_side) {
@@ -344,7 +346,10 @@ __global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
     a.entries[a.bucket_start[bk] + slot] = make_int4((int)(c & 0xFFFFFFFFll), (int)(c >> 32), bin | (b << 16), (int)i);
 }
 
-template <bool FILL>
+// ONE pass: a thread counts its matches, reserves that many key slots (one atomic per thread that found any, one more on
+// its base's counter) and walks its bucket a second time to write them -- the keys are sorted afterwards, so where a
+// thread's keys land does not matter, and the expensive part of a thread (the cone of <= 56 rotated samples) is done once.
+// (Before: a counting launch, a scan over all Q pairs and a second full launch; profiles/r04_dropin_kernels.txt.)
 __global__ __launch_bounds__(128) void bq_match(CsBatchArgs a) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.total_q) return;
@@ -354,7 +359,6 @@ __global__ __launch_bounds__(128) void bq_match(CsBatchArgs a) {
   const int2 qr = a.pairs[B.q_off + i];
   const float* cone = a.cones + (size_t)b * 168;
   uint32_t found = 0;
-  const uint32_t out0 = FILL ? a.q_start[t] : 0u;
   if ((unsigned)qr.x < (unsigned)a.nQs && (unsigned)qr.y < (unsigned)a.nQs) {
     V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
     long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
@@ -404,38 +408,73 @@ __global__ __launch_bounds__(128) void bq_match(CsBatchArgs a) {
           }
         }
         V3 queryQ = lerp_pt(ld3(a.Qw, qr.x), ld3(a.Qw, qr.y), B.inv2);
-        for (uint32_t k = s; k < e; ++k) {
-          int4 en = a.entries[k];
-          if (en.x != clo || en.y != chi || (en.z >> 16) != b) continue;
-          const int bin = en.z & 0xFFFF;
-          uint32_t word = 0;
+        // the first matches are kept in registers: a thread with at most kKeep of them (nearly all) walks its bucket once
+        constexpr int kKeep = 4;
+        uint32_t kept[kKeep];
+        uint32_t out0 = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+          uint32_t n = 0;
+          for (uint32_t k = s; k < e; ++k) {
+            int4 en = a.entries[k];
+            if (en.x != clo || en.y != chi || (en.z >> 16) != b) continue;
+            const int bin = en.z & 0xFFFF;
+            uint32_t word = 0;
 #pragma unroll
-          for (int w = 0; w < 11; ++w)
-            if (w == (bin >> 5)) word = colored[w];
-          if (!((word >> (bin & 31)) & 1u)) continue;
-          int2 pp = a.pairs[B.p_off + (uint32_t)en.w];
-          V3 w1 = ld3(a.Qw, pp.x), w2 = ld3(a.Qw, pp.y);
-          V3 dd = vsub(w2, w1);
-          V3 ip = {add(w1.x, mul(dd.x, B.inv1)), add(w1.y, mul(dd.y, B.inv1)), add(w1.z, mul(dd.z, B.inv1))};
-          if (sqnorm(vsub(queryQ, ip)) <= a.threshold) {
-            if (FILL)
-              a.keys[out0 + found] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)en.w << 24) |
+            for (int w = 0; w < 11; ++w)
+              if (w == (bin >> 5)) word = colored[w];
+            if (!((word >> (bin & 31)) & 1u)) continue;
+            int2 pp = a.pairs[B.p_off + (uint32_t)en.w];
+            V3 w1 = ld3(a.Qw, pp.x), w2 = ld3(a.Qw, pp.y);
+            V3 dd = vsub(w2, w1);
+            V3 ip = {add(w1.x, mul(dd.x, B.inv1)), add(w1.y, mul(dd.y, B.inv1)), add(w1.z, mul(dd.z, B.inv1))};
+            if (sqnorm(vsub(queryQ, ip)) <= a.threshold) {
+              if (pass == 0) {
+#pragma unroll
+                for (int q = 0; q < kKeep; ++q)
+                  if ((uint32_t)q == n) kept[q] = (uint32_t)en.w;
+              } else if (out0 + n < a.key_cap) {
+                a.keys[out0 + n] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)en.w << 24) |
+                                   (unsigned long long)i;
+              }
+              ++n;
+            }
+          }
+          if (pass == 0) {
+            found = n;
+            if (found == 0) break;
+            out0 = atomicAdd(a.n_keys, found);
+            atomicAdd(&a.base_cnt[b], found);
+            if (found <= (uint32_t)kKeep) {
+#pragma unroll
+              for (int q = 0; q < kKeep; ++q)
+                if ((uint32_t)q < found && out0 + q < a.key_cap)
+                  a.keys[out0 + q] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)kept[q] << 24) |
                                      (unsigned long long)i;
-            ++found;
+              break;
+            }
           }
         }
       }
     }
   }
-  if (!FILL) a.q_cnt[t] = found;
 }
 
-// matches per base = difference of the scanned counts at the base's Q range
-__global__ void batch_base_counts(const uint32_t* __restrict__ q_start, const BatchBase* __restrict__ bases, int nb,
-                                  uint32_t total_q, uint32_t* __restrict__ base_start) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b > nb) return;
-  base_start[b] = b == nb ? q_start[total_q] : q_start[bases[b].q_flat];
+// starts of the bases in the sorted keys = exclusive prefix sums of their match counts (one workgroup; nb is a few hundred)
+__global__ __launch_bounds__(256) void batch_base_starts(const uint32_t* __restrict__ base_cnt, int nb,
+                                                         uint32_t* __restrict__ base_start) {
+  __shared__ uint32_t s_sum[256];
+  const int per = (nb + 255) / 256, lo = min((int)threadIdx.x * per, nb), hi = min(lo + per, nb);
+  uint32_t sum = 0;
+  for (int b = lo; b < hi; ++b) sum += base_cnt[b];
+  s_sum[threadIdx.x] = sum;
+  __syncthreads();
+  uint32_t run = 0;
+  for (int t = 0; t < (int)threadIdx.x; ++t) run += s_sum[t];
+  for (int b = lo; b < hi; ++b) {
+    base_start[b] = run;
+    run += base_cnt[b];
+  }
+  if (threadIdx.x == 255) base_start[nb] = run;   // the last thread's running sum is the total
 }
 
 // picks (base, j) -> the j-th quad of that base in the reference's order
@@ -736,16 +775,27 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   }
   for (int b = 0; b < nb; ++b) h_n_quads[b] = 0;
   if (nb == 0) return PGP_OK;
+  // PGP_CS_TIMING=1: host time of the call's stages on stderr (each stage then ends with a stream synchronisation)
+  static const bool timing = getenv("PGP_CS_TIMING") && atoi(getenv("PGP_CS_TIMING")) != 0;
+  auto t_last = std::chrono::steady_clock::now();
+  auto stage = [&](const char* what) {
+    if (!timing) return;
+    (void)hipStreamSynchronize(st);
+    const auto now = std::chrono::steady_clock::now();
+    fprintf(stderr, "[congruent batch] %-28s %7.1f us\n", what, std::chrono::duration<double, std::micro>(now - t_last).count());
+    t_last = now;
+  };
   // ---- which rows of the table are pairs1 / pairs6 of every base: computePPF on the device
-  std::vector<int> edge_pairs((size_t)nb * 4), feat((size_t)nb * 8), rows((size_t)nb * 2);
+  std::vector<int> edge_pairs((size_t)nb * 4), rows((size_t)nb * 2);
   for (int b = 0; b < nb; ++b) {
     edge_pairs[4 * b] = h_base_ids[4 * b];       // computePPF(base_id1, base_id2)
     edge_pairs[4 * b + 1] = h_base_ids[4 * b + 1];
     edge_pairs[4 * b + 2] = h_base_ids[4 * b + 2];   // computePPF(base_id3, base_id4)
     edge_pairs[4 * b + 3] = h_base_ids[4 * b + 3];
   }
-  int rc = launch_ppf_features(ctx, edge_pairs.data(), 2 * nb, feat.data(), rows.data(), st);
+  int rc = launch_ppf_features(ctx, edge_pairs.data(), 2 * nb, nullptr, rows.data(), st);
   if (rc != PGP_OK) return rc;
+  stage("pair features of the bases");
   const float eps = threshold / ctx->cs_ratio;          // getNormalizedEpsilon
   const int gridDepth = (int)(-std::log2(eps));          // normalset.h:116
   if (!(eps > 0.f) || gridDepth < 0 || gridDepth > 20) {
@@ -786,6 +836,7 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     return PGP_EINVAL;
   }
   if (tp == 0 || tq == 0) return PGP_OK;
+  stage("rows + cones (host)");
   CsBatchArgs a{};
   a.eg = (int)std::pow(2, gridDepth);
   a.epsilon = 1.f / (float)a.eg;
@@ -793,7 +844,8 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   unsigned nbk = 1024;
   while (nbk < 2u * (unsigned)tp && nbk < (1u << 26)) nbk <<= 1;
   a.bmask = nbk - 1;
-  const size_t n_cnt = (size_t)nbk + 1 + (size_t)tq + 1;
+  // bucket counts | bucket starts | {matches appended, matches per base}
+  const size_t n_cnt = (size_t)nbk + 1 + (size_t)nb + 2;
   if ((rc = ctx->d_cs_cnt.ensure(n_cnt * 8 + 64)) != PGP_OK) return rc;
   if ((rc = ctx->d_cs_entries.ensure((size_t)tp * 16 + 16)) != PGP_OK) return rc;
   if ((rc = ctx->d_scan_tmp.ensure((n_cnt / 2048 + 2) * 4)) != PGP_OK) return rc;
@@ -804,12 +856,15 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   BatchBase* d_bases = reinterpret_cast<BatchBase*>(sb);
   float* d_cones = reinterpret_cast<float*>(sb + bb);
   uint32_t* d_base_start = reinterpret_cast<uint32_t*>(sb + bb + cb);
-  PGP_HIP(hipMemcpyAsync(d_bases, hb.data(), (size_t)nb * sizeof(BatchBase), hipMemcpyHostToDevice, st));
-  PGP_HIP(hipMemcpyAsync(d_cones, cones.data(), (size_t)nb * 168 * 4, hipMemcpyHostToDevice, st));
+  // bases and cones in ONE copy (a pageable copy costs the call ~10 us whatever its size); the staging vector lives until
+  // the stream is synchronised below
+  std::vector<unsigned char> stage_h(bb + cb, 0);
+  std::memcpy(stage_h.data(), hb.data(), (size_t)nb * sizeof(BatchBase));
+  std::memcpy(stage_h.data() + bb, cones.data(), (size_t)nb * 168 * 4);
+  PGP_HIP(hipMemcpyAsync(d_bases, stage_h.data(), bb + cb, hipMemcpyHostToDevice, st));
   uint32_t* bcnt = ctx->d_cs_cnt.as<uint32_t>();
   uint32_t* bstart = bcnt + (nbk + 1);
   uint32_t* qcnt = bstart + (nbk + 1);
-  uint32_t* qstart = qcnt + (tq + 1);
   a.Qw = ctx->d_Qs.as<float4>();
   a.Qu = ctx->d_Qs_unit.as<float4>();
   a.nQs = ctx->nQs;
@@ -821,8 +876,6 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   a.bucket_cnt = bcnt;
   a.bucket_start = bstart;
   a.entries = ctx->d_cs_entries.as<int4>();
-  a.q_cnt = qcnt;
-  a.q_start = qstart;
   a.total_p = (uint32_t)tp;
   a.total_q = (uint32_t)tq;
   uint32_t* scan_tmp = ctx->d_scan_tmp.as<uint32_t>();
@@ -832,15 +885,40 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   if ((rc = device_exclusive_scan(bcnt, bstart, (size_t)nbk + 1, scan_tmp, st)) != PGP_OK) return rc;
   PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
   hipLaunchKernelGGL(bp_entries<true>, gp, dim3(256), 0, st, a);
-  PGP_HIP(hipMemsetAsync(qcnt + tq, 0, 4, st));
-  hipLaunchKernelGGL(bq_match<false>, gq, dim3(128), 0, st, a);
-  if ((rc = device_exclusive_scan(qcnt, qstart, (size_t)tq + 1, scan_tmp, st)) != PGP_OK) return rc;
-  hipLaunchKernelGGL(batch_base_counts, dim3((nb + 1 + 255) / 256), dim3(256), 0, st, (const uint32_t*)qstart,
-                     (const BatchBase*)d_bases, nb, (uint32_t)tq, d_base_start);
+  stage("P entries into buckets");
+  // the matches: appended to a key array sized by a guess (twice the last batch's total, at least 64 k); a batch that
+  // outgrows it is matched again into a larger one
   std::vector<uint32_t> starts((size_t)nb + 1);
-  PGP_HIP(hipMemcpyAsync(starts.data(), d_base_start, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  const uint32_t total = starts[nb];
+  uint32_t total = 0;
+  uint32_t* d_nkeys = qcnt;            // [1] appended so far | [nb] per base (the Q counters of the two-pass form)
+  uint32_t* d_base_cnt = qcnt + 1;
+  size_t sort_bytes = 0;
+  for (size_t cap = std::max<size_t>((size_t)ctx->csb_cap_hint, (size_t)1 << 16);;) {
+    hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
+                                             (unsigned long long*)nullptr, cap, 0, 64, st);
+    if (he != hipSuccess) {
+      set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
+      return PGP_EHIP;
+    }
+    if ((rc = ctx->d_cs_keys.ensure(cap * 16 + sort_bytes + 256)) != PGP_OK) return rc;
+    a.keys = ctx->d_cs_keys.as<unsigned long long>();
+    a.key_cap = (uint32_t)cap;
+    a.n_keys = d_nkeys;
+    a.base_cnt = d_base_cnt;
+    PGP_HIP(hipMemsetAsync(d_nkeys, 0, ((size_t)nb + 1) * 4, st));
+    hipLaunchKernelGGL(bq_match, gq, dim3(128), 0, st, a);
+    hipLaunchKernelGGL(batch_base_starts, dim3(1), dim3(256), 0, st, (const uint32_t*)d_base_cnt, nb, d_base_start);
+    PGP_HIP(hipMemcpyAsync(starts.data(), d_base_start, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+    total = starts[nb];
+    if ((size_t)total <= cap) {
+      ctx->csb_keys_off = (uint32_t)cap;
+      break;
+    }
+    cap = (size_t)total + (size_t)total / 4;   // every key counted: this one fits
+  }
+  stage("Q matches");
+  ctx->csb_cap_hint = std::max<uint32_t>(2u * total, 1u << 16);
   for (int b = 0; b < nb; ++b) h_n_quads[b] = (int)(starts[b + 1] - starts[b]);
   if (total == 0) {   // a valid, empty batch: every pick is out of range
     ctx->csb_starts = starts;
@@ -848,25 +926,16 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     ctx->csb_total = 0;
     return PGP_OK;
   }
-  size_t sort_bytes = 0;
-  hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
-                                           (unsigned long long*)nullptr, (size_t)total, 0, 64, st);
-  if (he != hipSuccess) {
-    set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
-    return PGP_EHIP;
-  }
-  if ((rc = ctx->d_cs_keys.ensure((size_t)total * 16 + sort_bytes + 256)) != PGP_OK) return rc;
   unsigned long long* keys_in = ctx->d_cs_keys.as<unsigned long long>();
-  unsigned long long* keys_out = keys_in + total;
-  void* sort_tmp = keys_out + total;
-  a.keys = keys_in;
-  hipLaunchKernelGGL(bq_match<true>, gq, dim3(128), 0, st, a);
-  he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)total, 0, 64, st);
+  unsigned long long* keys_out = keys_in + ctx->csb_keys_off;
+  void* sort_tmp = keys_out + ctx->csb_keys_off;
+  hipError_t he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)total, 0, 64, st);
   if (he != hipSuccess) {
     set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));
     return PGP_EHIP;
   }
   PGP_HIP(hipGetLastError());
+  stage("sort");
   // only now do the sorted keys exist: the batch becomes visible to pgp_congruent_batch_quads / _fit
   ctx->csb_starts = starts;
   ctx->csb_nb = nb;
@@ -901,7 +970,7 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
   unsigned char* sb = ctx->d_csb.as<unsigned char>();
   const BatchBase* d_bases = reinterpret_cast<const BatchBase*>(sb);
   const uint32_t* d_base_start = reinterpret_cast<const uint32_t*>(sb + bb + cb);
-  const unsigned long long* keys_out = ctx->d_cs_keys.as<unsigned long long>() + ctx->csb_total;
+  const unsigned long long* keys_out = ctx->d_cs_keys.as<unsigned long long>() + ctx->csb_keys_off;
   hipLaunchKernelGGL(batch_gather, dim3((m + 255) / 256), dim3(256), 0, st, keys_out, d_base_start, d_bases,
                      (const int2*)ctx->d_ppf_pairs.as<int2>(), (const int2*)ctx->d_csb_picks.as<int2>(), m, d_quads);
   PGP_HIP(hipGetLastError());

@@ -418,15 +418,100 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   return build_index_bbox(ctx, mn, mx, delta);
 }
 
+int finish_index(pgp_ctx* ctx) {
+  if (!ctx->index_pending) return PGP_OK;
+  PGP_HIP(hipEventSynchronize(ctx->ev_index));
+  ctx->index_pending = false;
+  ctx->n_cand = (long long)ctx->h_build_counts[0];
+  ctx->n_occ = (long long)ctx->h_build_counts[1];
+  PGP_HIP(hipEventElapsedTime(&ctx->build_ms, ctx->ev_build0, ctx->ev_index));
+  return PGP_OK;
+}
+
+int await_index(pgp_ctx* ctx, hipStream_t stream) {
+  if (!ctx->index_pending) return PGP_OK;
+  if (hipEventQuery(ctx->ev_index) == hipSuccess) return finish_index(ctx);
+  (void)hipGetLastError();   // hipErrorNotReady is not an error
+  PGP_HIP(hipStreamWaitEvent(stream, ctx->ev_index, 0));
+  return PGP_OK;
+}
+
+// The dense index of a SMALL scene, queued on ctx->build_stream and left running (see pgp_ctx::build_stream): the
+// candidate array and the occupied-cell table are sized by what nP points can reach at most, so no count has to come
+// back before the next launch.  The points are already resident (pgp_set_scene synchronises its uploads).
+static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta) {
+  const int nP = ctx->nP;
+  int rc;
+  if (!ctx->build_stream) {
+    PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+    PGP_HIP(hipEventCreate(&ctx->ev_index));
+    PGP_HIP(hipEventCreate(&ctx->ev_build0));
+    PGP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_build_counts), 64, hipHostMallocDefault));
+  }
+  hipStream_t st = ctx->build_stream;
+  const size_t n_words = (size_t)g.nbx * g.nby * g.nbz;
+  const size_t n_cells = n_words * 32, n_scan = n_cells + 1;
+  const int n_tiles = (int)((n_scan + kScanTile - 1) / kScanTile);
+  const size_t reach = (size_t)(2 * r + 1) * (2 * r + 1) * (2 * r + 1);
+  const size_t cand_max = (size_t)nP * reach, occ_max = std::min(n_cells, cand_max);
+  if ((rc = ctx->d_cell_start.ensure(n_scan * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cell_tmp.ensure(n_scan * 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_build_scan.ensure((size_t)n_tiles * 4 + 4)) != PGP_OK) return rc;
+  if ((rc = ctx->d_bitmap.ensure(n_words * 8)) != PGP_OK) return rc;
+  if ((rc = ctx->d_cand.ensure((cand_max + 1 + 256) * sizeof(float4))) != PGP_OK) return rc;
+  if ((rc = ctx->d_occ_start.ensure((occ_max + 2) * 8)) != PGP_OK) return rc;
+  uint32_t* ctr = ctx->d_cell_tmp.as<uint32_t>();
+  uint32_t* start = ctx->d_cell_start.as<uint32_t>();
+  uint32_t* scan_tmp = ctx->d_build_scan.as<uint32_t>();
+  uint2* words = ctx->d_bitmap.as<uint2>();
+  const int pb = (nP + 255) / 256;
+  PGP_HIP(hipEventRecord(ctx->ev_build0, st));
+  PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
+  hipLaunchKernelGGL((scatter_points<false, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+                     (const uint32_t*)nullptr, (float4*)nullptr, (const uint4*)nullptr);
+  if ((rc = device_exclusive_scan(ctr, start, n_scan, scan_tmp, st)) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[0], start + n_cells, 4, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
+  hipLaunchKernelGGL((scatter_points<true, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+                     (const uint32_t*)start, ctx->d_cand.as<float4>(), (const uint4*)nullptr);
+  hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
+                     (const uint32_t*)start, words, ctr, n_words);
+  if ((rc = device_exclusive_scan(ctr, ctr, n_words + 1, scan_tmp, st)) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[1], ctr + n_words, 4, hipMemcpyDeviceToHost, st));
+  hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
+                     (const uint32_t*)start, (const uint32_t*)ctr, words, ctx->d_occ_start.as<uint2>(), n_words, n_cells);
+  PGP_HIP(hipGetLastError());
+  PGP_HIP(hipEventRecord(ctx->ev_index, st));
+  ctx->index_pending = true;
+  ctx->grid = g;
+  ctx->n_cells = (long long)n_cells;
+  ctx->n_blocks = 0;
+  ctx->n_cand = ctx->n_occ = 0;   // known when the build is through (finish_index)
+  ctx->build_ms = 0.f;
+  ctx->delta = delta;
+  ctx->has_index = true;
+  return PGP_OK;
+}
+
 // The index of the scene already resident in ctx->d_P, given the bounding box of its finite points.
 int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float delta) {
   const int nP = ctx->nP;
   hipStream_t st = ctx->stream;
   ctx->has_index = false;
+  int rc = finish_index(ctx);   // a build still running (its consumers are drained by the caller) owns these buffers
+  if (rc != PGP_OK) return rc;
   GridDesc g{};
   int r = 1;
-  int rc = choose_grid(mn, mx, delta, &g, &r);
+  rc = choose_grid(mn, mx, delta, &g, &r);
   if (rc != PGP_OK) return rc;
+  {
+    // PGP_ASYNC_BUILD=0: every scene takes the synchronous build below (A/B knob).  The bound on the candidate
+    // array (every point in every cell of its reach) keeps the side-stream build to scenes of a few thousand points.
+    static const bool async_on = !(getenv("PGP_ASYNC_BUILD") && atoi(getenv("PGP_ASYNC_BUILD")) == 0);
+    const size_t reach = (size_t)(2 * r + 1) * (2 * r + 1) * (2 * r + 1);
+    if (async_on && !g.sparse && nP > 0 && (size_t)nP * reach * sizeof(float4) <= ((size_t)32 << 20))
+      return build_index_async(ctx, g, r, delta);
+  }
   struct EventPair {  // destroyed on every return path
     hipEvent_t a = nullptr, b = nullptr;
     ~EventPair() {

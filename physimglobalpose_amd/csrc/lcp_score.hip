@@ -1747,7 +1747,8 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max) {
 int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
                  float* d_scores, int* d_counts, int* d_best, hipStream_t stream) {
   ScoreArgs a{};
-  int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
+  int rc = await_index(ctx, stream);
+  if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
   if (n_h > ctx->cap_h) {
     set_error("n_h %d exceeds reserved capacity %d (pgp_reserve)", n_h, ctx->cap_h);
@@ -1821,7 +1822,8 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
 int launch_verify_early_out(pgp_ctx* ctx, const float* d_T, int n_h, float* d_scores, int* d_counts, hipStream_t stream) {
   if (n_h <= 0) return PGP_OK;
   ScoreArgs a{};
-  int rc = fill_args(ctx, d_T, n_h, PGP_MODE_PLAIN, 30.f, &a);
+  int rc = await_index(ctx, stream);
+  if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, PGP_MODE_PLAIN, 30.f, &a);
   if (rc != PGP_OK) return rc;
   if (ctx->d_eo_ws.cap < (size_t)n_h * sizeof(int) || !ctx->d_Qpos.p) {
     set_error("verify early-out: workspace not reserved (pgp_reserve / pgp_set_model)");
@@ -1843,7 +1845,8 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
     return PGP_OK;
   }
   ScoreArgs a{};
-  int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
+  int rc = await_index(ctx, stream);
+  if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
   hipLaunchKernelGGL(settle_best_kernel, dim3(1), dim3(256), 0, stream, a, n_h, mode, ctx->refine_best ? 1 : 0,
                      d_scores, d_best, ctx->d_seq.as<float>());
@@ -1857,7 +1860,8 @@ int launch_settle_records(pgp_ctx* ctx, const float* d_T, int n_h, int mode, flo
                           hipStream_t stream) {
   if (n_h <= 0 || mode != PGP_MODE_WEIGHTED) return PGP_OK;   // plain counts are exact already
   ScoreArgs a{};
-  int rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
+  int rc = await_index(ctx, stream);
+  if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
   if (ctx->d_rec_ws.cap < (size_t)records_workspace_bytes(ctx->nQ)) {
     set_error("exact records: workspace not reserved (pgp_set_exact_records after pgp_set_model)");
@@ -1909,6 +1913,10 @@ int launch_count_neighbours(pgp_ctx* ctx, float radius, int* d_counts, hipStream
     return PGP_EINVAL;
   }
   if (ctx->nP == 0) return PGP_OK;
+  {
+    const int rc = await_index(ctx, stream);
+    if (rc != PGP_OK) return rc;
+  }
   hipLaunchKernelGGL(count_neighbours, dim3((ctx->nP + 255) / 256), dim3(256), 0, stream, ctx->grid,
                      ctx->grid.sparse ? ctx->d_blocktab.as<uint2>() : ctx->d_bitmap.as<uint2>(), ctx->d_occ_start.as<uint2>(), ctx->d_cand.as<float4>(),
                      ctx->d_P.as<float4>(), ctx->nP, radius * radius, d_counts);
@@ -1930,6 +1938,10 @@ int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q,
     gate_thresholds(gate_deg, &ctx->gate_lo, &ctx->gate_hi);
     ctx->gate_deg_cached = gate_deg;
   }
+  {
+    const int rc = await_index(ctx, stream);
+    if (rc != PGP_OK) return rc;
+  }
   ScoreArgs a{};
   a.g = ctx->grid;
   a.words = ctx->grid.sparse ? ctx->d_blocktab.as<uint2>() : ctx->d_bitmap.as<uint2>();
@@ -1950,7 +1962,8 @@ int launch_registered_model(pgp_ctx* ctx, const float* d_T16, const float4* d_q,
 int launch_registered(pgp_ctx* ctx, const float* d_T16, int mode, float gate_deg, int* d_hits,
                       hipStream_t stream) {
   ScoreArgs a{};
-  int rc = fill_args(ctx, d_T16, 1, mode, gate_deg, &a);
+  int rc = await_index(ctx, stream);
+  if (rc == PGP_OK) rc = fill_args(ctx, d_T16, 1, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
   if (ctx->nQ == 0) return PGP_OK;
   dim3 grid((ctx->nQ + 255) / 256);

@@ -181,7 +181,17 @@ int pgp_destroy(pgp_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)e;
   }
-  DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp,
+  if (ctx->build_stream) {
+    hipError_t e = hipStreamSynchronize(ctx->build_stream);
+    e = hipStreamDestroy(ctx->build_stream);
+    e = hipEventDestroy(ctx->ev_index);
+    e = hipEventDestroy(ctx->ev_build0);
+    e = hipHostFree(ctx->h_build_counts);
+    (void)e;
+    ctx->build_stream = nullptr;
+    ctx->index_pending = false;
+  }
+  DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp, &ctx->d_build_scan,
                     &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_kd_nodes, &ctx->d_kd_pts, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_icp_x, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
@@ -311,10 +321,11 @@ int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n) {
     set_error("pgp_set_scene_weights: no scene (pgp_set_scene first)");
     return PGP_ESTATE;
   }
+  // a pgp_score_lcp_device / pgp_settle_records_device call still queued on the caller's stream reads these weights:
+  // the guard drains the device when such a call has been noted (note_device_work).  Not unconditionally: an index
+  // build still running on the context's side stream (small scenes) reads the points only, and the caller's next
+  // steps -- base selection, congruent sets -- are meant to run beside it.
   CtxGuard guard(ctx);
-  // a pgp_score_lcp_device / pgp_settle_records_device call still queued on the caller's stream reads these
-  // weights: wait for the device as pgp_set_scene does, before they are rewritten
-  PGP_HIP(hipDeviceSynchronize());
   int rc = ctx->d_pre_io.ensure((size_t)n * 4);
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, weight, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
@@ -1759,6 +1770,9 @@ int pgp_get_index_info(pgp_ctx* ctx, pgp_index_info* info) {
   info->n_scene = ctx->nP;
   info->n_model = ctx->nQ;
   if (ctx->has_index) {
+    CtxGuard guard(ctx);
+    const int rc = finish_index(ctx);   // a build on the side stream: its counts are known when it is through
+    if (rc != PGP_OK) return rc;
     info->grid_nx = ctx->grid.nx;
     info->grid_ny = ctx->grid.ny;
     info->grid_nz = ctx->grid.nz;

@@ -92,6 +92,15 @@ struct pgp_ctx {
   long long n_occ = 0;
   pgp::DevBuf d_cand;        // float4 {x,y,z,bits(i)} [n_cand]
   float build_ms = 0.f;
+  // Small scenes (the drop-in's segments): the index is built on build_stream behind pgp_set_scene's uploads, with its
+  // buffers sized by upper bounds so that nothing is read back in between; whatever reads the index waits for ev_index
+  // on its own stream first (await_index, grid_index.hip) -- base selection and the congruent sets, which only read
+  // the points, run beside the build.
+  hipStream_t build_stream = nullptr;
+  hipEvent_t ev_index = nullptr, ev_build0 = nullptr;
+  bool index_pending = false;
+  uint32_t* h_build_counts = nullptr;   // pinned {candidates, occupied cells} of the pending build
+  pgp::DevBuf d_build_scan;             // the build's own scan scratch (d_scan_tmp serves the congruent sets meanwhile)
 
   // model
   int nQ = 0;
@@ -126,6 +135,8 @@ struct pgp_ctx {
                                         // 0 as soon as d_cs_keys / d_ppf_pairs / the search model are rewritten
   int csb_fit_m = 0;                    // fits of the last pgp_congruent_batch_fit_score, resident in d_rig
   uint32_t csb_total = 0;
+  uint32_t csb_keys_off = 0;            // the sorted keys start this many keys into d_cs_keys (the capacity of the unsorted ones)
+  uint32_t csb_cap_hint = 0;            // twice the last batch's total: the next batch's key capacity
   std::vector<uint32_t> csb_starts;     // per-base starts in the sorted keys (nb + 1), host copy: picks are checked here
   pgp::DevBuf d_prob_cdf;               // double prefix sums of the scene weights (first draw)
   bool prob_cdf_valid = false;
@@ -234,6 +245,10 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
                  float* d_scores, int* d_counts, int* d_best, hipStream_t stream);
 int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                        int* d_best, hipStream_t stream);
+// the launches that follow on `stream` read the scene's index: orders them behind a build still running on
+// ctx->build_stream (a no-op otherwise); finish_index() waits for it on the host and takes over its counts
+int await_index(pgp_ctx* ctx, hipStream_t stream);
+int finish_index(pgp_ctx* ctx);
 int launch_settle_records(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                           hipStream_t stream);
 int launch_verify_early_out(pgp_ctx* ctx, const float* d_T, int n_h, float* d_scores, int* d_counts, hipStream_t stream);
