@@ -198,9 +198,20 @@ __device__ float sequential_sum(const float* __restrict__ w, int n, float* s_bca
     for (int base = 0; base < n; base += 64) {
       const int i = base + (int)threadIdx.x;
       const float v = i < n ? w[i] : 0.f;
-      if (__ballot(v != 0.f) == 0ull) continue;
+      unsigned long long m = __ballot(v != 0.f);
+      if (m == 0ull) continue;
+      if (__popcll(m) > 40) {
 #pragma unroll
-      for (int k = 0; k < 64; ++k) S = __fadd_rn(S, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)));
+        for (int k = 0; k < 64; ++k) S = __fadd_rn(S, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)));
+      } else {
+        // few survivors of the stage's constraints (the usual case after stage 2): only the non-zero lanes, in lane order
+        // -- the chain of dependent adds is what this sum costs (~10 cycles each)
+        while (m) {
+          const int k = __builtin_ctzll(m);
+          m &= m - 1ull;
+          S = __fadd_rn(S, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k)));
+        }
+      }
     }
     if (threadIdx.x == 0) *s_bcast = S;
   }
@@ -213,16 +224,22 @@ __device__ float sequential_sum(const float* __restrict__ w, int n, float* s_bca
 // Inverse-CDF draw over w[0..n) (weights >= 0, at least one > 0): the first index with a positive
 // weight whose inclusive prefix sum (double, fixed block-wide association) reaches u * total.
 // All threads call.
+// 1024 threads per attempt: the stage weights of a ~2000-point segment are two trips per thread, not eight
+constexpr int kSelThreads = 1024;
+// The association is FIXED at kDrawT segments whatever the block size (threads beyond them only keep the barriers).
+constexpr int kDrawT = 256;
 __device__ int draw_index(const float* __restrict__ w, int n, double u, double* s_part, int* s_pick) {
-  const int T = blockDim.x;
+  constexpr int T = kDrawT;
   const int per = (n + T - 1) / T;
-  const int lo = min((int)threadIdx.x * per, n), hi = min(lo + per, n);
+  const bool mine = threadIdx.x < (unsigned)T;
+  const int lo = mine ? min((int)threadIdx.x * per, n) : n, hi = min(lo + per, n);
   double local = 0.0;
   for (int i = lo; i < hi; ++i) local += (double)w[i];
-  s_part[threadIdx.x] = local;
+  if (mine) s_part[threadIdx.x] = local;
   __syncthreads();
   if (threadIdx.x == 0) {
     double run = 0.0;
+#pragma unroll 8
     for (int t = 0; t < T; ++t) {   // exclusive offsets, in thread order
       const double v = s_part[t];
       s_part[t] = run;
@@ -233,7 +250,7 @@ __device__ int draw_index(const float* __restrict__ w, int n, double u, double* 
   }
   __syncthreads();
   const double target = u * s_part[T];
-  double run = s_part[threadIdx.x];
+  double run = mine ? s_part[threadIdx.x] : 0.0;
   int pick = 0x7FFFFFFF;
   for (int i = lo; i < hi; ++i) {
     const double wi = (double)w[i];
@@ -362,7 +379,7 @@ __device__ void try_quadrilateral(const float4* __restrict__ P, int ids[4], floa
   }
 }
 
-__global__ __launch_bounds__(256) void select_bases(SelectArgs a) {
+__global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
   __shared__ double s_part[257];
   __shared__ int s_pick;
   __shared__ float s_sum;
@@ -759,12 +776,15 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   a.ids = d_ids;
   a.inv = d_inv;
   a.status = d_status;
-  hipLaunchKernelGGL(select_bases, dim3(n_attempts), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(select_bases, dim3(n_attempts), dim3(kSelThreads), 0, st, a);
   PGP_HIP(hipGetLastError());
-  PGP_HIP(hipMemcpyAsync(h_ids, d_ids, A * 16, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(h_inv, d_inv, A * 8, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(h_status, d_status, A * 4, hipMemcpyDeviceToHost, st));
+  // ids | inv | status lie back to back in the workspace: ONE copy back (a pageable copy costs ~10 us whatever its size)
+  std::vector<unsigned char> out(A * 28);
+  PGP_HIP(hipMemcpyAsync(out.data(), d_ids, A * 28, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  std::memcpy(h_ids, out.data(), A * 16);
+  std::memcpy(h_inv, out.data() + A * 16, A * 8);
+  std::memcpy(h_status, out.data() + A * 24, A * 4);
   return PGP_OK;
 }
 

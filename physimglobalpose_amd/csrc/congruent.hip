@@ -350,9 +350,26 @@ __global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
 // its base's counter) and walks its bucket a second time to write them -- the keys are sorted afterwards, so where a
 // thread's keys land does not matter, and the expensive part of a thread (the cone of <= 56 rotated samples) is done once.
 // (Before: a counting launch, a scan over all Q pairs and a second full launch; profiles/r04_dropin_kernels.txt.)
-__global__ __launch_bounds__(128) void bq_match(CsBatchArgs a) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= a.total_q) return;
+// does Q pair t fall into a cell that holds a P entry of its base?  (the cheap part of a match: two loads and a bucket walk)
+__device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t t) {
+  const int b = base_of(a.bases, a.nb, t, true);
+  const BatchBase B = a.bases[b];
+  const int2 qr = a.pairs[B.q_off + (t - B.q_flat)];
+  if ((unsigned)qr.x >= (unsigned)a.nQs || (unsigned)qr.y >= (unsigned)a.nQs) return false;
+  const V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
+  const long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
+  if (c < 0) return false;
+  const unsigned bk = bucket_of_b(c, b, a.bmask);
+  const uint32_t s = a.bucket_start[bk], e = a.bucket_start[bk + 1];
+  const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
+  for (uint32_t k = s; k < e; ++k) {
+    const int4 en = a.entries[k];
+    if (en.x == clo && en.y == chi && (en.z >> 16) == b) return true;
+  }
+  return false;
+}
+
+__device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32_t t) {
   const int b = base_of(a.bases, a.nb, t, true);
   const BatchBase B = a.bases[b];
   const uint32_t i = t - B.q_flat;
@@ -457,6 +474,25 @@ __global__ __launch_bounds__(128) void bq_match(CsBatchArgs a) {
       }
     }
   }
+}
+
+// The Q pairs of a workgroup that have a cell at all are gathered first, so that the cone (<= 56 rotated samples, the
+// expensive part) runs on full waves: about one Q pair in four has one, scattered over the waves.
+__global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
+  __shared__ uint32_t s_items[256];
+  __shared__ uint32_t s_wcnt[4];
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool any = t < a.total_q && bq_has_cell(a, t);
+  const unsigned long long m = __ballot(any);
+  if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
+  __syncthreads();
+  uint32_t off = 0;
+  for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+  const uint32_t n_any = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+  if (any) s_items[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
+  __syncthreads();
+  if (threadIdx.x < n_any) bq_match_item(a, s_items[threadIdx.x]);
 }
 
 // starts of the bases in the sorted keys = exclusive prefix sums of their match counts (one workgroup; nb is a few hundred)
@@ -879,7 +915,7 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   a.total_p = (uint32_t)tp;
   a.total_q = (uint32_t)tq;
   uint32_t* scan_tmp = ctx->d_scan_tmp.as<uint32_t>();
-  const dim3 gp((unsigned)((tp + 255) / 256)), gq((unsigned)((tq + 127) / 128));
+  const dim3 gp((unsigned)((tp + 255) / 256)), gq((unsigned)((tq + 255) / 256));
   PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
   hipLaunchKernelGGL(bp_entries<false>, gp, dim3(256), 0, st, a);
   if ((rc = device_exclusive_scan(bcnt, bstart, (size_t)nbk + 1, scan_tmp, st)) != PGP_OK) return rc;
@@ -906,7 +942,7 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     a.n_keys = d_nkeys;
     a.base_cnt = d_base_cnt;
     PGP_HIP(hipMemsetAsync(d_nkeys, 0, ((size_t)nb + 1) * 4, st));
-    hipLaunchKernelGGL(bq_match, gq, dim3(128), 0, st, a);
+    hipLaunchKernelGGL(bq_match, gq, dim3(256), 0, st, a);
     hipLaunchKernelGGL(batch_base_starts, dim3(1), dim3(256), 0, st, (const uint32_t*)d_base_cnt, nb, d_base_start);
     PGP_HIP(hipMemcpyAsync(starts.data(), d_base_start, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
     PGP_HIP(hipStreamSynchronize(st));
@@ -918,6 +954,8 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     cap = (size_t)total + (size_t)total / 4;   // every key counted: this one fits
   }
   stage("Q matches");
+  if (timing) fprintf(stderr, "[congruent batch] %d bases, %llu P pairs, %llu Q pairs, %u buckets, %u matches\n", nb,
+                      (unsigned long long)tp, (unsigned long long)tq, nbk, total);
   ctx->csb_cap_hint = std::max<uint32_t>(2u * total, 1u << 16);
   for (int b = 0; b < nb; ++b) h_n_quads[b] = (int)(starts[b + 1] - starts[b]);
   if (total == 0) {   // a valid, empty batch: every pick is out of range

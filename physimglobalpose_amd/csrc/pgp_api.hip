@@ -330,8 +330,19 @@ int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n) {
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, weight, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
   if ((rc = launch_scene_weights(ctx, ctx->d_pre_io.as<float>(), n, ctx->stream)) != PGP_OK) return rc;
-  PGP_HIP(hipStreamSynchronize(ctx->stream));   // `weight` is the caller's
-  ctx->prob_cdf_valid = false;                  // base selection draws from these weights
+  // base selection draws its first point from these weights: their double prefix sums (the sequence launch_select_bases
+  // would otherwise read back and add up on its first call) go up with them
+  ctx->prob_cdf_valid = false;
+  std::vector<double> cdf((size_t)n);
+  double run = 0.0;
+  for (int i = 0; i < n; ++i) {
+    run += (double)weight[i];
+    cdf[i] = run;
+  }
+  if ((rc = ctx->d_prob_cdf.ensure((size_t)n * 8)) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_prob_cdf.p, cdf.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipStreamSynchronize(ctx->stream));   // `weight` is the caller's, `cdf` this call's
+  ctx->prob_cdf_valid = true;
   return PGP_OK;
 }
 
