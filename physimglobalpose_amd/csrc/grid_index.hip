@@ -430,6 +430,14 @@ int finish_index(pgp_ctx* ctx) {
 
 int await_index(pgp_ctx* ctx, hipStream_t stream) {
   if (!ctx->index_pending) return PGP_OK;
+  {
+    // a stream that is being captured into a graph can neither query nor wait for an event recorded outside the capture
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      set_error("the scene's index is still being built: call pgp_get_index_info (or any scoring call) once before capturing a graph");
+      return PGP_ESTATE;
+    }
+  }
   if (hipEventQuery(ctx->ev_index) == hipSuccess) return finish_index(ctx);
   (void)hipGetLastError();   // hipErrorNotReady is not an error
   PGP_HIP(hipStreamWaitEvent(stream, ctx->ev_index, 0));
