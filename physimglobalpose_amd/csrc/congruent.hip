@@ -351,8 +351,7 @@ __global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
 // thread's keys land does not matter, and the expensive part of a thread (the cone of <= 56 rotated samples) is done once.
 // (Before: a counting launch, a scan over all Q pairs and a second full launch; profiles/r04_dropin_kernels.txt.)
 // does Q pair t fall into a cell that holds a P entry of its base?  (the cheap part of a match: two loads and a bucket walk)
-__device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t t) {
-  const int b = base_of(a.bases, a.nb, t, true);
+__device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t t, const int b, uint32_t* first, uint32_t* end) {
   const BatchBase B = a.bases[b];
   const int2 qr = a.pairs[B.q_off + (t - B.q_flat)];
   if ((unsigned)qr.x >= (unsigned)a.nQs || (unsigned)qr.y >= (unsigned)a.nQs) return false;
@@ -364,30 +363,27 @@ __device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t
   const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
   for (uint32_t k = s; k < e; ++k) {
     const int4 en = a.entries[k];
-    if (en.x == clo && en.y == chi && (en.z >> 16) == b) return true;
+    if (en.x == clo && en.y == chi && (en.z >> 16) == b) {
+      *first = k;   // the walks of the match start at the first entry of the cell
+      *end = e;
+      return true;
+    }
   }
   return false;
 }
 
-__device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32_t t) {
-  const int b = base_of(a.bases, a.nb, t, true);
+__device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32_t t, const int b, const uint32_t s, const uint32_t e) {
   const BatchBase B = a.bases[b];
   const uint32_t i = t - B.q_flat;
   const int2 qr = a.pairs[B.q_off + i];
   const float* cone = a.cones + (size_t)b * 168;
   uint32_t found = 0;
-  if ((unsigned)qr.x < (unsigned)a.nQs && (unsigned)qr.y < (unsigned)a.nQs) {
+  {
     V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
     long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
-    if (c >= 0) {
-      unsigned bk = bucket_of_b(c, b, a.bmask);
-      uint32_t s = a.bucket_start[bk], e = a.bucket_start[bk + 1];
+    {
       const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
-      bool any = false;
-      for (uint32_t k = s; k < e && !any; ++k) {
-        int4 en = a.entries[k];
-        any = en.x == clo && en.y == chi && (en.z >> 16) == b;
-      }
+      const bool any = true;   // bq_has_cell said so
       if (any) {
         V3 queryn = normalized(vsub(p2, p1));
         V3 v1 = normalized(queryn);
@@ -480,19 +476,39 @@ __device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32
 // expensive part) runs on full waves: about one Q pair in four has one, scattered over the waves.
 __global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
   __shared__ uint32_t s_items[256];
+  __shared__ uint2 s_range[256];
+  __shared__ unsigned short s_base[256];
   __shared__ uint32_t s_wcnt[4];
+  __shared__ int s_b0, s_b1;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool any = t < a.total_q && bq_has_cell(a, t);
+  // the bases of the workgroup's first and last Q pair: nearly always the same one (a base has ~1000 Q pairs), so a thread
+  // searches a range of one
+  if (threadIdx.x == 0) s_b0 = base_of(a.bases, a.nb, blockIdx.x * blockDim.x, true);
+  if (threadIdx.x == 64) s_b1 = base_of(a.bases, a.nb, min(blockIdx.x * blockDim.x + blockDim.x - 1u, a.total_q - 1u), true);
+  __syncthreads();
+  int b = s_b0;
+  if (t < a.total_q)
+    for (const int b1 = s_b1; b < b1 && a.bases[b + 1].q_flat <= t;) ++b;   // last base whose first flat index is <= t
+  uint32_t first = 0, end = 0;
+  const bool any = t < a.total_q && bq_has_cell(a, t, b, &first, &end);
   const unsigned long long m = __ballot(any);
   if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
   __syncthreads();
   uint32_t off = 0;
   for (int w = 0; w < wave; ++w) off += s_wcnt[w];
   const uint32_t n_any = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-  if (any) s_items[off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = t;
+  if (any) {
+    const uint32_t slot = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+    s_items[slot] = t;
+    s_range[slot] = make_uint2(first, end);
+    s_base[slot] = (unsigned short)b;   // at most 65535 bases per call
+  }
   __syncthreads();
-  if (threadIdx.x < n_any) bq_match_item(a, s_items[threadIdx.x]);
+  if (threadIdx.x < n_any) {
+    const uint2 r = s_range[threadIdx.x];
+    bq_match_item(a, s_items[threadIdx.x], (int)s_base[threadIdx.x], r.x, r.y);
+  }
 }
 
 // starts of the bases in the sorted keys = exclusive prefix sums of their match counts (one workgroup; nb is a few hundred)
