@@ -72,6 +72,13 @@ int pgp_center(float* P_xyz, int nP, float* Qs_xyz, int nQs, float* Qv_xyz, int 
 int pgp_weights_from_image(const float* P_xyz, int n, const float centroid_P[3], const float K[9],
                            const unsigned short* img, int rows, int cols, float* weights);
 
+/* The image rows pgp_weights_from_image reads for these points (the same arithmetic, so the answer is exact):
+ * *row_min / *row_max over the points that fall inside a rows x cols image, -1 / -1 when none does.  A caller
+ * that decodes the probability image while the clouds are being set up (the drop-in's file hand-off, base.cc:317)
+ * can stop decoding after row_max.  Pure host helper. */
+int pgp_image_rows_needed(const float* P_xyz, int n, const float centroid_P[3], const float K[9], int rows,
+                          int cols, int* row_min, int* row_max);
+
 /* Replaces `sampled_P_3D_ = P` + initKdTree() + orig_probabilities_ (base.cc:235,270,1046-1056,
  * 327-340): uploads the (centred) scene cloud and builds the device spatial index for inlier
  * radius `delta` (options_.delta, S4/super4pcs_test.cc:20).  nrm and weight may be NULL

@@ -59,6 +59,7 @@ SIGNATURES = {
     "pgp_destroy": (C.c_int, [C.c_void_p]),
     "pgp_center": (C.c_int, [_f, C.c_int, _f, C.c_int, _f, C.c_int, _f, _f]),
     "pgp_weights_from_image": (C.c_int, [_f, C.c_int, _f, _f, C.POINTER(C.c_ushort), C.c_int, C.c_int, _f]),
+    "pgp_image_rows_needed": (C.c_int, [_f, C.c_int, _f, _f, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pgp_set_scene": (C.c_int, [C.c_void_p, _f, _f, _f, C.c_int, C.c_float]),
     "pgp_set_model": (C.c_int, [C.c_void_p, _f, _f, C.c_int]),
     "pgp_score_lcp": (C.c_int, [C.c_void_p, _f, C.c_int, C.c_int, C.c_float, _f, _i, _i, _f]),

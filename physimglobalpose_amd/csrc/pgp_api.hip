@@ -244,6 +244,28 @@ int pgp_center(float* P, int nP, float* Qs, int nQs, float* Qv, int nQv, float c
   return PGP_OK;
 }
 
+namespace {
+// the pixel of one scene point as Match4PCSBase::init computes it (base.cc:317-340); false = outside the image
+inline bool image_pixel(const float* p, const float cP[3], const float K[9], int rows, int cols, int* row, int* col) {
+  // b_ii.pos() += centroid_P_ (float), then double x1,y1,z1 -> Eigen::Vector3f(x1,y1,z1) (back to float)
+  const float x = p[0] + cP[0], y = p[1] + cP[1], z = p[2] + cP[2];
+  // camIntrinsic * v: Eigen evaluates a 3x3 * 3x1 float product as k0*x + (k1*y + k2*z) per row
+  float u[3];
+  for (int r = 0; r < 3; ++r) {
+    float a = K[3 * r] * x, b = K[3 * r + 1] * y, c = K[3 * r + 2] * z;
+    float bc = b + c;
+    u[r] = a + bc;
+  }
+  const float fc = u[0] / u[2], fr = u[1] / u[2];
+  // int col = point2D[0]/point2D[2]: truncation toward zero; guard what the reference leaves undefined
+  const bool ok = fc == fc && fr == fr && fc > -1.f && fr > -1.f && fc < (float)cols && fr < (float)rows;
+  if (!ok) return false;
+  *col = (int)fc;
+  *row = (int)fr;
+  return *col >= 0 && *row >= 0 && *col < cols && *row < rows;
+}
+}  // namespace
+
 int pgp_weights_from_image(const float* P, int n, const float cP[3], const float K[9],
                            const unsigned short* img, int rows, int cols, float* weights) {
   if (n < 0 || rows < 0 || cols < 0 || (n > 0 && (!P || !weights)) || !cP || !K || (rows * cols > 0 && !img)) {
@@ -251,25 +273,27 @@ int pgp_weights_from_image(const float* P, int n, const float cP[3], const float
     return PGP_EINVAL;
   }
   for (int i = 0; i < n; ++i) {
-    // b_ii.pos() += centroid_P_ (float), then double x1,y1,z1 -> Eigen::Vector3f(x1,y1,z1) (back to float)
-    const float x = P[3 * (size_t)i] + cP[0], y = P[3 * (size_t)i + 1] + cP[1], z = P[3 * (size_t)i + 2] + cP[2];
-    // camIntrinsic * v: Eigen evaluates a 3x3 * 3x1 float product as k0*x + (k1*y + k2*z) per row
-    float u[3];
-    for (int r = 0; r < 3; ++r) {
-      float a = K[3 * r] * x, b = K[3 * r + 1] * y, c = K[3 * r + 2] * z;
-      float bc = b + c;
-      u[r] = a + bc;
-    }
-    const float fc = u[0] / u[2], fr = u[1] / u[2];
-    // int col = point2D[0]/point2D[2]: truncation toward zero; guard what the reference leaves undefined
-    const bool ok = fc == fc && fr == fr && fc > -1.f && fr > -1.f && fc < (float)cols && fr < (float)rows;
-    float w = 0.f;
-    if (ok) {
-      const int col = (int)fc, row = (int)fr;
-      if (col >= 0 && row >= 0 && col < cols && row < rows) w = (float)img[(size_t)row * cols + col] / 10000;
-    }
-    weights[i] = w;
+    int row = 0, col = 0;
+    weights[i] = image_pixel(P + 3 * (size_t)i, cP, K, rows, cols, &row, &col) ? (float)img[(size_t)row * cols + col] / 10000 : 0.f;
   }
+  return PGP_OK;
+}
+
+int pgp_image_rows_needed(const float* P, int n, const float cP[3], const float K[9], int rows, int cols, int* row_min,
+                          int* row_max) {
+  if (n < 0 || rows < 0 || cols < 0 || (n > 0 && !P) || !cP || !K || !row_min || !row_max) {
+    set_error("pgp_image_rows_needed: bad argument");
+    return PGP_EINVAL;
+  }
+  int lo = -1, hi = -1;
+  for (int i = 0; i < n; ++i) {
+    int row = 0, col = 0;
+    if (!image_pixel(P + 3 * (size_t)i, cP, K, rows, cols, &row, &col)) continue;
+    lo = lo < 0 || row < lo ? row : lo;
+    hi = row > hi ? row : hi;
+  }
+  *row_min = lo;
+  *row_max = hi;
   return PGP_OK;
 }
 

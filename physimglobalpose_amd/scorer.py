@@ -69,6 +69,18 @@ class LcpScorer:
         return P, Qs, Qv, cP, cQ
 
     @staticmethod
+    def image_rows_needed(P_xyz, centroid_P, K, rows, cols):
+        """The image rows weights_from_image reads for these points: (row_min, row_max), (-1, -1) when no point
+        falls inside a rows x cols image (what lets the drop-in stop decoding the probability PNG early)."""
+        P = _f32(P_xyz, 3)
+        c = _f32(centroid_P).reshape(3)
+        Kf = _f32(K).reshape(9)
+        lo, hi = C.c_int(0), C.c_int(0)
+        _lib.check(_lib.load().pgp_image_rows_needed(_fp(P), len(P), _fp(c), _fp(Kf), int(rows), int(cols),
+                                                     C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    @staticmethod
     def weights_from_image(P_centred, centroid_P, K, img_u16):
         """base.cc:317-340: per-point weight = probability image (u16 / 10000) at the projection."""
         P = _f32(P_centred, 3)

@@ -30,6 +30,7 @@
 // PGP_SHIM_SEED fixes the RNG seed (the reference seeds from the clock).
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -271,7 +272,12 @@ bool read_ply(const std::string& path, Cloud& out) {
 // probability image read back at base.cc:317).  zlib inflates, the five scanline filters are
 // undone here.
 // ---------------------------------------------------------------------------------------------
-bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows, int& cols) {
+// `last_row` (optional): the decoder looks at it after every band of rows and stops once the rows up to it are
+// done -- the caller publishes the last image row its points fall on as soon as it knows it (pgp_image_rows_needed),
+// rows beyond stay zero and are never read.  The inflate of the whole 640 x 480 x 16 bit image is ~1 ms, the longest
+// single step of the file hand-off.
+bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows, int& cols,
+                   const std::atomic<int>* last_row = nullptr) {
   std::ifstream f(path.c_str(), std::ios::binary);
   if (!f) return false;
   std::vector<unsigned char> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
@@ -303,45 +309,65 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
   const int bpp = depth / 8;
   const size_t stride = (size_t)cols * bpp;
   std::vector<unsigned char> raw((stride + 1) * (size_t)rows);
-  uLongf raw_len = (uLongf)raw.size();
-  if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return false;
-  // undo the scanline filters IN PLACE, one specialised loop per row (the filter type is per row; a switch
-  // inside the per-byte loop made this the dearest part of the whole file hand-off: 1.7 ms of 2 at 640 x 480 x 16 bit)
   px.assign((size_t)rows * cols, 0);
   const std::vector<unsigned char> zero_row(stride, 0);
   const size_t B = (size_t)bpp;
-  for (int r = 0; r < rows; ++r) {
-    unsigned char* cur = raw.data() + (stride + 1) * (size_t)r + 1;
-    const unsigned char* prev = r > 0 ? cur - (stride + 1) : zero_row.data();
-    switch (cur[-1]) {
-      case 0: break;
-      case 1:
-        for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + cur[i - B]);
-        break;
-      case 2:
-        for (size_t i = 0; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]);
-        break;
-      case 3:
-        for (size_t i = 0; i < B && i < stride; ++i) cur[i] = (unsigned char)(cur[i] + (prev[i] >> 1));
-        for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
-        break;
-      case 4:
-        for (size_t i = 0; i < B && i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]);   // a = c = 0: predictor b
-        for (size_t i = B; i < stride; ++i) {
-          const int a = cur[i - B], b2 = prev[i], c = prev[i - B];
-          const int p = a + b2 - c, pa = std::abs(p - a), pb = std::abs(p - b2), pc = std::abs(p - c);
-          cur[i] = (unsigned char)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b2 : c)));
-        }
-        break;
-      default: return false;
+  z_stream zs;
+  std::memset(&zs, 0, sizeof zs);
+  if (inflateInit(&zs) != Z_OK) return false;
+  zs.next_in = idat.data();
+  zs.avail_in = (uInt)idat.size();
+  const int band = 32;   // rows per inflate call
+  bool ok = true;
+  for (int r0 = 0; r0 < rows && ok; r0 += band) {
+    const int r1 = std::min(rows, r0 + band);
+    zs.next_out = raw.data() + (stride + 1) * (size_t)r0;
+    zs.avail_out = (uInt)((stride + 1) * (size_t)(r1 - r0));
+    while (zs.avail_out > 0) {
+      const int rc = inflate(&zs, Z_NO_FLUSH);
+      if (rc == Z_STREAM_END) break;
+      if (rc != Z_OK) { ok = false; break; }
     }
-    uint16_t* out = px.data() + (size_t)r * cols;
-    if (depth == 16)
-      for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = (uint16_t)((cur[2 * cidx] << 8) | cur[2 * cidx + 1]);
-    else
-      for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = cur[cidx];
+    if (zs.avail_out > 0) ok = false;   // the stream ended before the image did
+    if (!ok) break;
+    // undo the scanline filters IN PLACE, one specialised loop per row (the filter type is per row; a switch inside
+    // the per-byte loop made this the dearest part of the whole file hand-off: 1.7 ms of 2 at 640 x 480 x 16 bit)
+    for (int r = r0; r < r1; ++r) {
+      unsigned char* cur = raw.data() + (stride + 1) * (size_t)r + 1;
+      const unsigned char* prev = r > 0 ? cur - (stride + 1) : zero_row.data();
+      switch (cur[-1]) {
+        case 0: break;
+        case 1:
+          for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + cur[i - B]);
+          break;
+        case 2:
+          for (size_t i = 0; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]);
+          break;
+        case 3:
+          for (size_t i = 0; i < B && i < stride; ++i) cur[i] = (unsigned char)(cur[i] + (prev[i] >> 1));
+          for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + ((cur[i - B] + prev[i]) >> 1));
+          break;
+        case 4:
+          for (size_t i = 0; i < B && i < stride; ++i) cur[i] = (unsigned char)(cur[i] + prev[i]);   // a = c = 0: predictor b
+          for (size_t i = B; i < stride; ++i) {
+            const int a = cur[i - B], b2 = prev[i], c = prev[i - B];
+            const int p = a + b2 - c, pa = std::abs(p - a), pb = std::abs(p - b2), pc = std::abs(p - c);
+            cur[i] = (unsigned char)(cur[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b2 : c)));
+          }
+          break;
+        default: ok = false;
+      }
+      if (!ok) break;
+      uint16_t* out = px.data() + (size_t)r * cols;
+      if (depth == 16)
+        for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = (uint16_t)((cur[2 * cidx] << 8) | cur[2 * cidx + 1]);
+      else
+        for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = cur[cidx];
+    }
+    if (ok && last_row && last_row->load(std::memory_order_acquire) < r1) break;   // every row anyone will read is done
   }
-  return true;
+  inflateEnd(&zs);
+  return ok;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,6 +515,20 @@ extern "C" int super4pcs_shim_read_png(const char* path, unsigned short* px, int
   return 0;
 }
 
+// the same with the decoder told (before it starts) that nothing beyond `last_row` will be read: rows up to
+// last_row are decoded, rows of later bands stay zero
+extern "C" int super4pcs_shim_read_png_rows(const char* path, int last_row, unsigned short* px, int cap, int* rows, int* cols) {
+  std::vector<uint16_t> v;
+  int r = 0, c = 0;
+  const std::atomic<int> last(last_row);
+  if (!read_png_gray(path, v, r, c, &last)) return -1;
+  *rows = r;
+  *cols = c;
+  if ((long long)r * c > cap) return -2;
+  std::copy(v.begin(), v.end(), px);
+  return 0;
+}
+
 bool super4pcs_shim_read_ply(const std::string& path, std::vector<float>& xyz, std::vector<float>& normals) {
   Cloud c;
   if (!read_ply(path, c)) return false;
@@ -535,7 +575,7 @@ static bool has_duplicate_points(const float* xyz, int n) {
 
 static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
                        const Super4PCSCloudView& model_search,
-                       const std::function<const unsigned short*(int*, int*)>& image,
+                       const std::function<const unsigned short*(int*, int*, int)>& image,
                        std::pair<Eigen::Isometry3d, float>& bestHypothesis,
                        std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
                        std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
@@ -580,7 +620,8 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
   };
   // the PNG (inflate + unfilter: the longest of the four) keeps decoding while the clouds are centred,
   // uploaded and indexed; the match waits for it only where the weights are first needed
-  std::thread t4([&] { timed(3, [&] { guarded(&have, [&] { return read_png_gray(probImagePath, px, rows, cols); }); }); });
+  std::atomic<int> last_row(1 << 30);   // until the match knows which rows its points fall on: all of them
+  std::thread t4([&] { timed(3, [&] { guarded(&have, [&] { return read_png_gray(probImagePath, px, rows, cols, &last_row); }); }); });
   JoinGuard g4{t4};
   {
     std::thread t2([&] { timed(1, [&] { guarded(&ok2, [&] { return read_ply(input2, qval); }); }); });
@@ -600,8 +641,9 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
   const Super4PCSCloudView vq = {qval.xyz.data(), qval.nrm.data(), qval.n};
   const Super4PCSCloudView vqs = {qsearch.xyz.data(), qsearch.nrm.data(), qsearch.n};
   bool joined = false;
-  auto image = [&](int* r, int* c) -> const unsigned short* {
+  auto image = [&](int* r, int* c, int last_needed) -> const unsigned short* {
     if (!joined) {
+      last_row.store(last_needed, std::memory_order_release);
       t4.join();
       joined = true;
       if (getenv("PGP_SHIM_VERBOSE"))
@@ -626,7 +668,7 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
                                     std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
                                     Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points) {
   match_impl(segment, model_validation, model_search,
-             [&](int* r, int* c) -> const unsigned short* { *r = rows; *c = cols; return prob_image; },
+             [&](int* r, int* c, int) -> const unsigned short* { *r = rows; *c = cols; return prob_image; },
              bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
 }
 
@@ -634,7 +676,7 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
 // decoding it on another thread while the clouds are uploaded and indexed)
 static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
                        const Super4PCSCloudView& model_search,
-                       const std::function<const unsigned short*(int*, int*)>& image,
+                       const std::function<const unsigned short*(int*, int*, int)>& image,
                        std::pair<Eigen::Isometry3d, float>& bestHypothesis,
                        std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
                        std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
@@ -782,12 +824,16 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   // ---- per-point weights from the probability image (base.cc:317-340), once the image is there
   {
     int rows = 0, cols = 0;
-    const unsigned short* prob_image = image(&rows, &cols);
+    float K[9];
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
+    // the last image row the segment's points fall on (whatever the image's size turns out to be): a decoder that
+    // is still running stops there
+    int row_lo = -1, row_hi = -1;
+    pgp_image_rows_needed(seg.xyz.data(), seg.n, cP, K, 1 << 24, 1 << 24, &row_lo, &row_hi);
+    const unsigned short* prob_image = image(&rows, &cols, row_hi);
     if (prob_image && rows > 0 && cols > 0) {
       std::vector<float> prob(seg.n, 1.f);
-      float K[9];
-      for (int r = 0; r < 3; ++r)
-        for (int c = 0; c < 3; ++c) K[3 * r + c] = camIntrinsic(r, c);
       pgp_weights_from_image(seg.xyz.data(), seg.n, cP, K, prob_image, rows, cols, prob.data());
       if (st.group) SHIM_PGP(pgp_multi_set_scene_weights(st.group, prob.data(), seg.n));
       else SHIM_PGP(pgp_set_scene_weights(ctx, prob.data(), seg.n));

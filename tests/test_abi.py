@@ -82,6 +82,26 @@ def test_weights_from_image_matches_golden():
     assert not LcpScorer.weights_from_image(far, g["centroid_P"], g["K"], g["img"]).any()
 
 
+def test_image_rows_needed_are_the_rows_the_weights_read():
+    """pgp_image_rows_needed (the drop-in stops decoding its probability PNG there): an image that encodes its own row
+    number gives the rows pgp_weights_from_image reads; their extremes are the helper's answer, for any image size."""
+    from physimglobalpose_amd import LcpScorer
+    g = np.load(os.path.join(ROOT, "tests", "golden", "weights.npz"))
+    P, c, K = g["P"], g["centroid_P"], g["K"]
+    small = LcpScorer.image_rows_needed(P, c, K, 480, 640)
+    for rows, cols in ((480, 640), (200, 640), (480, 100), (1 << 24, 1 << 24)):
+        lo, hi = LcpScorer.image_rows_needed(P, c, K, rows, cols)
+        if rows > 4000:      # too large to materialise: every point inside the small image is inside this one too
+            assert lo <= small[0] and hi >= small[1]
+            continue
+        img = np.repeat((np.arange(rows, dtype=np.uint16) + 1)[:, None], cols, axis=1)     # value = row + 1; 0 = outside
+        w = LcpScorer.weights_from_image(P, c, K, img)
+        read = np.rint(w[w > 0].astype(np.float64) * 10000).astype(int) - 1
+        assert (lo, hi) == ((int(read.min()), int(read.max())) if len(read) else (-1, -1))
+    far = P + np.array([1e6, 0, 0], np.float32)
+    assert LcpScorer.image_rows_needed(far, c, K, 480, 640) == (-1, -1)
+
+
 def test_running_best_rule():
     from physimglobalpose_amd import LcpScorer
     s = np.array([0.0, 0.2, 0.2, 0.1, 0.3, 0.3, 0.25, 0.31], np.float32)

@@ -114,6 +114,30 @@ def test_shim_png_decoder_matches_pil(tmp_path):
     assert L.super4pcs_shim_read_png(str(tmp_path / "missing.png").encode(), None, 0, C.byref(rows), C.byref(cols)) == -1
 
 
+def test_shim_png_decoder_stops_after_the_last_row_needed(tmp_path):
+    """The file hand-off publishes the last image row the segment's points fall on (pgp_image_rows_needed) and the
+    decoder stops after the band of rows that holds it: every row up to it equals PIL's, later bands stay zero."""
+    from PIL import Image
+    L = C.CDLL(SHIM)
+    L.super4pcs_shim_read_png_rows.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_ushort), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    yy, xx = np.mgrid[0:200, 0:150]
+    rng = np.random.default_rng(9)
+    for k, img in enumerate((((xx * 300 + yy * 91) % 65536).astype(np.uint16), rng.integers(1, 65536, (200, 150)).astype(np.uint16))):
+        p = str(tmp_path / f"rows_{k}.png")
+        Image.fromarray(img).save(p)
+        want = np.array(Image.open(p)).astype(np.uint16)
+        for last in (-1, 0, 31, 32, 100, 199, 5000):
+            out = np.zeros(img.size, np.uint16)
+            rows, cols = C.c_int(0), C.c_int(0)
+            rc = L.super4pcs_shim_read_png_rows(p.encode(), last, out.ctypes.data_as(C.POINTER(C.c_ushort)), out.size, C.byref(rows), C.byref(cols))
+            assert rc == 0 and (rows.value, cols.value) == img.shape
+            got = out.reshape(img.shape)
+            n = min(200, max(last, 0) + 1)
+            assert np.array_equal(got[:n], want[:n])
+            done = min(200, (max(last, 0) // 32 + 1) * 32)          # whole bands of 32 rows
+            assert np.array_equal(got[:done], want[:done]) and not got[done:].any()
+
+
 def test_number_parser_rounds_like_the_references_fscanf():
     """The reader's decimal path (<= 15 digits, |exponent| <= 22: one exact multiply / divide to a double, a cast
     to float unless the double sits at a float midpoint) and its strtof fallback against the C library's strtof
