@@ -55,6 +55,7 @@
 #include <Eigen/Geometry>
 
 #include "../include/pgp.h"
+#include "fast_inflate.h"
 #include "super4pcs_shim.h"
 
 namespace {
@@ -308,34 +309,68 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
   if (ctype != 0 || interlace != 0 || (depth != 8 && depth != 16) || rows <= 0 || cols <= 0) return false;
   const int bpp = depth / 8;
   const size_t stride = (size_t)cols * bpp;
-  std::vector<unsigned char> raw((stride + 1) * (size_t)rows);
+  std::vector<unsigned char> raw((stride + 1) * (size_t)rows);   // the inflated stream: filter byte + filtered row, per row
   px.assign((size_t)rows * cols, 0);
-  const std::vector<unsigned char> zero_row(stride, 0);
   const size_t B = (size_t)bpp;
+  // inflate: the decoder of fast_inflate.h, band by band (its history IS `raw`, which therefore stays as inflated: the
+  // rows are unfiltered into a pair of row buffers).  zlib's own inflate takes over from the start if the decoder ever
+  // refuses the stream, or if the Adler-32 of a completely decoded image does not match the stream's.
+  fastinf::Inflater fast(idat.data(), idat.size(), raw.data(), raw.size());
+  bool use_zlib = getenv("PGP_SHIM_ZLIB") != nullptr;   // A/B and test knob
   z_stream zs;
   std::memset(&zs, 0, sizeof zs);
-  if (inflateInit(&zs) != Z_OK) return false;
-  zs.next_in = idat.data();
-  zs.avail_in = (uInt)idat.size();
-  const int band = 32;   // rows per inflate call
-  bool ok = true;
-  for (int r0 = 0; r0 < rows && ok; r0 += band) {
-    const int r1 = std::min(rows, r0 + band);
-    zs.next_out = raw.data() + (stride + 1) * (size_t)r0;
-    zs.avail_out = (uInt)((stride + 1) * (size_t)(r1 - r0));
+  bool zs_open = false;
+  auto zlib_to = [&](size_t limit) -> bool {   // raw[0, limit) inflated by zlib afterwards
+    if (!zs_open) {
+      if (inflateInit(&zs) != Z_OK) return false;
+      zs_open = true;
+      zs.next_in = idat.data();
+      zs.avail_in = (uInt)idat.size();
+      zs.next_out = raw.data();
+    }
+    const size_t have = (size_t)(zs.next_out - raw.data());
+    if (limit <= have) return true;
+    zs.avail_out = (uInt)(limit - have);
     while (zs.avail_out > 0) {
       const int rc = inflate(&zs, Z_NO_FLUSH);
       if (rc == Z_STREAM_END) break;
-      if (rc != Z_OK) { ok = false; break; }
+      if (rc != Z_OK) return false;
     }
-    if (zs.avail_out > 0) ok = false;   // the stream ended before the image did
-    if (!ok) break;
-    // undo the scanline filters IN PLACE, one specialised loop per row (the filter type is per row; a switch inside
-    // the per-byte loop made this the dearest part of the whole file hand-off: 1.7 ms of 2 at 640 x 480 x 16 bit)
+    return zs.avail_out == 0;   // else the stream ended before the image did
+  };
+  std::vector<unsigned char> row_a(stride, 0), row_b(stride, 0);
+  unsigned char* prev = row_a.data();   // the row above, unfiltered (zeros above the first row)
+  unsigned char* cur = row_b.data();
+  const int band = 32;   // rows per inflate step
+  bool ok = true;
+  for (int r0 = 0; r0 < rows && ok; r0 += band) {
+    const int r1 = std::min(rows, r0 + band);
+    const size_t limit = (stride + 1) * (size_t)r1;
+    if (!use_zlib) {
+      bool good = fast.run(limit) && fast.produced() >= limit;
+      if (good && r1 == rows) {   // the whole image: the stream ends here and carries the checksum of what was decoded
+        uint32_t want = 0;
+        good = fast.finish() && fast.produced() == raw.size() && fast.trailer(&want) &&
+               (uint32_t)adler32(adler32(0L, Z_NULL, 0), raw.data(), (uInt)raw.size()) == want;
+      }
+      if (!good) {
+        use_zlib = true;     // zlib starts over, and so do the rows
+        std::fill(row_a.begin(), row_a.end(), 0);
+        prev = row_a.data();
+        cur = row_b.data();
+        r0 = -band;
+        continue;
+      }
+    } else if (!zlib_to(limit)) {
+      ok = false;
+      break;
+    }
+    // undo the scanline filters, one specialised loop per row (the filter type is per row; a switch inside the
+    // per-byte loop made this the dearest part of the whole file hand-off: 1.7 ms of 2 at 640 x 480 x 16 bit)
     for (int r = r0; r < r1; ++r) {
-      unsigned char* cur = raw.data() + (stride + 1) * (size_t)r + 1;
-      const unsigned char* prev = r > 0 ? cur - (stride + 1) : zero_row.data();
-      switch (cur[-1]) {
+      const unsigned char* in = raw.data() + (stride + 1) * (size_t)r;
+      std::memcpy(cur, in + 1, stride);
+      switch (in[0]) {
         case 0: break;
         case 1:
           for (size_t i = B; i < stride; ++i) cur[i] = (unsigned char)(cur[i] + cur[i - B]);
@@ -363,10 +398,11 @@ bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, int& rows
         for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = (uint16_t)((cur[2 * cidx] << 8) | cur[2 * cidx + 1]);
       else
         for (int cidx = 0; cidx < cols; ++cidx) out[cidx] = cur[cidx];
+      std::swap(prev, cur);
     }
     if (ok && last_row && last_row->load(std::memory_order_acquire) < r1) break;   // every row anyone will read is done
   }
-  inflateEnd(&zs);
+  if (zs_open) inflateEnd(&zs);
   return ok;
 }
 
@@ -513,6 +549,20 @@ extern "C" int super4pcs_shim_read_png(const char* path, unsigned short* px, int
   if ((long long)r * c > cap) return -2;
   std::copy(v.begin(), v.end(), px);
   return 0;
+}
+
+// C-linkage probe for the tests: the zlib-stream decoder of fast_inflate.h on its own, in steps of `step` output bytes
+// (0: one run); returns the number of bytes produced, -1 when it refuses the stream, -2 on a checksum mismatch
+extern "C" long long super4pcs_shim_inflate(const unsigned char* in, long long n_in, unsigned char* out, long long n_out, long long step) {
+  fastinf::Inflater f(in, (size_t)n_in, out, (size_t)n_out);
+  if (step > 0)
+    for (long long lim = step; lim < n_out; lim += step)
+      if (!f.run((size_t)lim)) return -1;
+  if (!f.run((size_t)n_out) || !f.finish()) return -1;
+  uint32_t want = 0;
+  if (!f.trailer(&want)) return -1;
+  if ((uint32_t)adler32(adler32(0L, Z_NULL, 0), out, (uInt)f.produced()) != want) return -2;
+  return (long long)f.produced();
 }
 
 // the same with the decoder told (before it starts) that nothing beyond `last_row` will be read: rows up to

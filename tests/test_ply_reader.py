@@ -183,3 +183,82 @@ def test_number_parser_rounds_like_the_references_fscanf():
     with np.errstate(over="ignore"):
         twice = np.array([np.float32(float(t)) for t in toks], np.float32)
     assert (twice.view(np.uint32) != want.view(np.uint32)).sum() > 0
+
+
+def test_shim_inflater_matches_zlib():
+    """shim/fast_inflate.h (the probability PNG's inflate): stored, fixed-Huffman and dynamic blocks, long and overlapping
+    matches, run lengths of 16-bit values, incompressible data, empty input -- byte for byte what zlib produces, in one
+    run and resumed every few hundred bytes; damaged streams are refused or fail the checksum, never crash."""
+    import zlib
+    L = C.CDLL(SHIM)
+    L.super4pcs_shim_inflate.restype = C.c_longlong
+    L.super4pcs_shim_inflate.argtypes = [C.c_char_p, C.c_longlong, C.POINTER(C.c_ubyte), C.c_longlong, C.c_longlong]
+    rng = np.random.default_rng(11)
+    yy, xx = np.mgrid[0:120, 0:160]
+    blob = (np.clip(10000 * np.exp(-((xx - 80) ** 2 + (yy - 60) ** 2) / 900.0), 0, 10000)).astype(">u2").tobytes()
+    datas = [
+        b"", b"a", b"abc" * 1000, bytes(70000), blob,
+        rng.integers(0, 256, 50000, dtype=np.uint8).tobytes(),                       # incompressible
+        rng.integers(0, 4, 80000, dtype=np.uint8).tobytes(),                         # short codes, many matches
+        np.repeat(rng.integers(0, 65536, 300).astype("<u2"), rng.integers(1, 700, 300)).tobytes(),   # runs of 16-bit values
+        bytes(rng.integers(0, 256, 7, dtype=np.uint8)) * 9000,                       # period 7: overlapping byte copies
+        (b"0123456789abcdef" * 4096) + rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(),
+        " ".join(str(v) for v in rng.normal(size=20000)).encode(),                   # text: long dynamic tables
+    ]
+
+    def streams(d):
+        for level in (0, 1, 6, 9):
+            yield zlib.compress(d, level)
+        for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+            c = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strategy)
+            yield c.compress(d) + c.flush()
+        c = zlib.compressobj(6, zlib.DEFLATED, 9)      # a small window
+        yield c.compress(d) + c.flush()
+        c = zlib.compressobj(6)                        # several blocks, an empty stored block between them
+        half = len(d) // 2
+        yield c.compress(d[:half]) + c.flush(zlib.Z_FULL_FLUSH) + c.compress(d[half:]) + c.flush()
+
+    n_streams = 0
+    for d in datas:
+        for z in streams(d):
+            assert zlib.decompress(z) == d
+            for step in (0, 1, 257, 4096):
+                out = np.zeros(max(len(d), 1) + 16, np.uint8)
+                n = L.super4pcs_shim_inflate(z, len(z), out.ctypes.data_as(C.POINTER(C.c_ubyte)), len(d), step)
+                assert n == len(d), (len(d), len(z), step, n)
+                assert out[:len(d)].tobytes() == d
+            n_streams += 1
+    assert n_streams == len(datas) * 10
+    # damage: every refusal is an error code (the reader then falls back to zlib), never a wrong answer accepted
+    z = zlib.compress(datas[4], 6)
+    out = np.zeros(len(datas[4]) + 16, np.uint8)
+    po = out.ctypes.data_as(C.POINTER(C.c_ubyte))
+    assert L.super4pcs_shim_inflate(z[:-5], len(z) - 5, po, len(datas[4]), 0) < 0                     # truncated
+    assert L.super4pcs_shim_inflate(z, len(z), po, len(datas[4]) - 1, 0) < 0                           # output too small
+    for k in rng.integers(2, len(z) - 4, 200):
+        bad = bytearray(z)
+        bad[k] ^= 1 << int(rng.integers(0, 8))
+        n = L.super4pcs_shim_inflate(bytes(bad), len(bad), po, len(datas[4]), 0)
+        assert n < 0 or out[:len(datas[4])].tobytes() == datas[4]       # (a flipped bit in unused header bits may be harmless)
+
+
+def test_shim_png_reader_takes_zlib_when_told(tmp_path, monkeypatch):
+    """PGP_SHIM_ZLIB=1 (the A/B knob, also the path a refused stream takes) decodes the same pixels."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 65536, (70, 90)).astype(np.uint16)
+    p = str(tmp_path / "z.png")
+    Image.fromarray(img).save(p)
+    import subprocess, sys
+    code = ("import ctypes as C, numpy as np, sys\n"
+            "L = C.CDLL(sys.argv[1]); out = np.zeros(6300, np.uint16); r = C.c_int(0); c = C.c_int(0)\n"
+            "L.super4pcs_shim_read_png.argtypes = [C.c_char_p, C.POINTER(C.c_ushort), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]\n"
+            "assert L.super4pcs_shim_read_png(sys.argv[2].encode(), out.ctypes.data_as(C.POINTER(C.c_ushort)), 6300, C.byref(r), C.byref(c)) == 0\n"
+            "sys.stdout.write(out.tobytes().hex())\n")
+    outs = []
+    for env in ({}, {"PGP_SHIM_ZLIB": "1"}):
+        r = subprocess.run([sys.executable, "-c", code, SHIM, p], env=dict(os.environ, **env), capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == img.tobytes().hex()
+
