@@ -438,6 +438,10 @@ __global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = __fdiv_rn(cur[i], sum);
   __syncthreads();
   const int b2 = draw_index(cur, n, u[1], s_part, &s_pick);
+#if defined(PGP_SEL_STOP) && PGP_SEL_STOP == 2   // timing experiment (wrong results): the kernel up to the second point
+  fail();
+  return;
+#endif
   // ---- point 3
   if (threadIdx.x == 0) s_present = 0;
   __syncthreads();
@@ -463,6 +467,10 @@ __global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = __fdiv_rn(cur[i], sum);
   __syncthreads();
   const int b3 = draw_index(cur, n, u[2], s_part, &s_pick);
+#if defined(PGP_SEL_STOP) && PGP_SEL_STOP == 3
+  fail();
+  return;
+#endif
   // ---- point 4
   if (threadIdx.x == 0) s_present = 0;
   __syncthreads();
@@ -488,6 +496,10 @@ __global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) cur[i] = __fdiv_rn(cur[i], sum);
   __syncthreads();
   const int b4 = draw_index(cur, n, u[3], s_part, &s_pick);
+#if defined(PGP_SEL_STOP) && PGP_SEL_STOP == 4
+  fail();
+  return;
+#endif
   // ---- pairing + invariants
   if (threadIdx.x < 64) {
     int ids[4] = {b1, b2, b3, b4};

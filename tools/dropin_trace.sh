@@ -13,6 +13,7 @@ args, case = make_dropin_case(d)
 open(os.path.join(sys.argv[1], "args.txt"), "w").write("\n".join(args))
 PY
 mapfile -t ARGS < $OUT/args.txt
+rm -rf $OUT/trace   # (an earlier run's summary must not be picked up below)
 cd /tmp && export TMPDIR=/tmp
 PGP_SHIM_SEED=12345 SHIM_TEST_REPEAT=50 SHIM_TEST_INMEMORY=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $REPO/shim/test_shim "${ARGS[@]}" > $OUT/out.txt 2> $OUT/err.txt
 cp $(find $OUT/trace -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
