@@ -450,12 +450,11 @@ int await_index(pgp_ctx* ctx, hipStream_t stream) {
 static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta) {
   const int nP = ctx->nP;
   int rc;
-  if (!ctx->build_stream) {
-    PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
-    PGP_HIP(hipEventCreate(&ctx->ev_index));
-    PGP_HIP(hipEventCreate(&ctx->ev_build0));
-    PGP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_build_counts), 64, hipHostMallocDefault));
-  }
+  // (each on its own: a failure half way leaves what exists, and the next call goes on from there)
+  if (!ctx->build_stream) PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+  if (!ctx->ev_index) PGP_HIP(hipEventCreate(&ctx->ev_index));
+  if (!ctx->ev_build0) PGP_HIP(hipEventCreate(&ctx->ev_build0));
+  if (!ctx->h_build_counts) PGP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_build_counts), 64, hipHostMallocDefault));
   hipStream_t st = ctx->build_stream;
   const size_t n_words = (size_t)g.nbx * g.nby * g.nbz;
   const size_t n_cells = n_words * 32, n_scan = n_cells + 1;

@@ -181,14 +181,19 @@ int pgp_destroy(pgp_ctx* ctx) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)e;
   }
-  if (ctx->build_stream) {
-    hipError_t e = hipStreamSynchronize(ctx->build_stream);
-    e = hipStreamDestroy(ctx->build_stream);
-    e = hipEventDestroy(ctx->ev_index);
-    e = hipEventDestroy(ctx->ev_build0);
-    e = hipHostFree(ctx->h_build_counts);
+  {
+    hipError_t e = hipSuccess;
+    if (ctx->build_stream) {
+      e = hipStreamSynchronize(ctx->build_stream);
+      e = hipStreamDestroy(ctx->build_stream);
+    }
+    if (ctx->ev_index) e = hipEventDestroy(ctx->ev_index);
+    if (ctx->ev_build0) e = hipEventDestroy(ctx->ev_build0);
+    if (ctx->h_build_counts) e = hipHostFree(ctx->h_build_counts);
     (void)e;
     ctx->build_stream = nullptr;
+    ctx->ev_index = ctx->ev_build0 = nullptr;
+    ctx->h_build_counts = nullptr;
     ctx->index_pending = false;
   }
   DevBuf* bufs[] = {&ctx->d_P, &ctx->d_Pnw, &ctx->d_cell_start, &ctx->d_cell_tmp, &ctx->d_scan_tmp, &ctx->d_build_scan,
