@@ -795,10 +795,15 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
 constexpr int kNnThreads = 128;   // 512 source points per workgroup: 2500 sources -> 5 workgroups, 98 % full
 constexpr int kNnTgt = 512;    // 8 KB of LDS per 2-wave workgroup: 8 waves per SIMD resident
 
-__global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
+// LIST: only the queries list[pose][0 .. cnt[pose]) (those the open grid search could not settle, icp_nn_grid_open)
+template <bool LIST>
+__global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a, const int* __restrict__ list, const int* __restrict__ cnt) {
   __shared__ float4 s_t[kNnTgt];
   const int pose = blockIdx.z;
   if (a.st_done[pose]) return;
+  const int n_q = LIST ? cnt[pose] : a.n_src;
+  if (LIST && (int)(blockIdx.x * kNnThreads * kIcpR) >= n_q) return;   // the grid is sized for every query unsettled
+  const int* qlist = LIST ? list + (size_t)pose * a.n_src : nullptr;
   const float* G = a.T + 16 * (size_t)pose;
   const float g00 = G[0], g10 = G[1], g20 = G[2], g01 = G[4], g11 = G[5], g21 = G[6], g02 = G[8], g12 = G[9],
               g22 = G[10], g03 = G[12], g13 = G[13], g23 = G[14];
@@ -821,10 +826,13 @@ __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
   float best[kIcpR];
   int bj[kIcpR];
   const int* jprev = a.ws_j + (size_t)pose * a.n_src;  // correspondences of the previous iteration (-1: none)
+  int qi[kIcpR];   // the query of slot r (-1: none)
 #pragma unroll
   for (int r = 0; r < kIcpR; ++r) {
-    int i = base + r * kNnThreads + tid;
-    float4 s = i < a.n_src ? a.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int slot = base + r * kNnThreads + tid;
+    int i = slot < n_q ? (LIST ? qlist[slot] : slot) : -1;
+    qi[r] = i;
+    float4 s = i >= 0 ? a.src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     const float sx = row_xf(g00, g01, g02, g03, s.x, s.y, s.z);
     const float sy = row_xf(g10, g11, g12, g13, s.x, s.y, s.z);
     const float sz = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
@@ -838,7 +846,7 @@ __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
     // and the workgroups of tiles that hold nothing closer write no key at all.
     best[r] = FLT_MAX;
     bj[r] = -1;
-    const int jp = i < a.n_src ? jprev[i] : -1;
+    const int jp = i >= 0 ? jprev[i] : -1;
     if (jp >= 0) {
       const float4 m = a.tgt[jp];
       const float dx = __fsub_rn(sx, m.x), dy = __fsub_rn(sy, m.y), dz = __fsub_rn(sz, m.z);
@@ -878,8 +886,8 @@ __global__ __launch_bounds__(kNnThreads) void icp_nn_split(IcpArgs a) {
   unsigned long long* kw = a.ws_key + (size_t)pose * a.n_src;
 #pragma unroll
   for (int r = 0; r < kIcpR; ++r) {
-    int i = base + r * kNnThreads + tid;
-    if (i < a.n_src && bj[r] >= 0)
+    const int i = qi[r];
+    if (i >= 0 && bj[r] >= 0)
       atomicMin(&kw[i], ((unsigned long long)__float_as_uint(best[r]) << 32) | (unsigned)bj[r]);
   }
 }
@@ -953,6 +961,56 @@ __global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
   }
   if (bj >= 0)
     a.ws_key[(size_t)pose * a.n_src + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj;
+}
+
+// The same search WITHOUT a correspondence cap, for targets beyond the exact index's 65 535 points (round 4): the 27
+// cells around a query hold every target point within r_safe of it, so a nearest neighbour found at d2 <= r2_safe is the
+// nearest of the whole target (same d2, same lowest-j rule as the scan) and is written as the query's key; a query whose
+// 27 cells hold nothing that close is appended to its pose's list and settled by the exhaustive scan over the listed
+// queries only (icp_nn_split<true>).  Which queries end on the list does not change any result.
+__global__ __launch_bounds__(256) void icp_nn_grid_open(IcpArgs a, float r2_safe, int* __restrict__ list, int* __restrict__ cnt) {
+  const int pose = blockIdx.y;
+  if (a.st_done[pose]) return;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n_src) return;
+  const float* G = a.T + 16 * (size_t)pose;
+  const float4 s = a.src[i];
+  const float x = row_xf(G[0], G[4], G[8], G[12], s.x, s.y, s.z);
+  const float y = row_xf(G[1], G[5], G[9], G[13], s.x, s.y, s.z);
+  const float z = row_xf(G[2], G[6], G[10], G[14], s.x, s.y, s.z);
+  float best = FLT_MAX;
+  int bj = -1;
+  int cx, cy, cz;
+  if (grid_cell_of(a, x, y, z, &cx, &cy, &cz)) {
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int zz = cz + dz;
+      if (zz < 0 || zz >= a.gnz) continue;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = cy + dy;
+        if (yy < 0 || yy >= a.gny) continue;
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, a.gnx - 1);
+        if (x0 > x1) continue;
+        const size_t c0 = ((size_t)zz * a.gny + yy) * a.gnx + x0;
+        const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
+        for (uint32_t k = b; k < e; ++k) {
+          const float4 m = a.gpts[k];
+          const float dx = __fsub_rn(x, m.x), dyy = __fsub_rn(y, m.y), dzz = __fsub_rn(z, m.z);
+          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
+          const int j = __float_as_int(m.w);
+          if (d2 < best || (d2 == best && j < bj)) {   // the scan's rule: smallest d2, then lowest j
+            best = d2;
+            bj = j;
+          }
+        }
+      }
+    }
+  }
+  if (bj >= 0 && best <= r2_safe) {
+    a.ws_key[(size_t)pose * a.n_src + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj;
+  } else if (x == x && y == y && z == z) {   // (a non-finite query has no neighbour in the scan either: no key)
+    const int slot = atomicAdd(&cnt[pose], 1);
+    list[(size_t)pose * a.n_src + slot] = i;
+  }
 }
 
 
@@ -2895,7 +2953,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     PGP_HIP(hipGetLastError());
     return PGP_OK;
   }
-  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 + (use_index ? need * 4 + 64 : 0) : 0;
+  // Targets beyond the exact index's 65 535 points, no correspondence cap: a uniform grid answers every query that has a
+  // neighbour within a safe radius, the exhaustive scan only the others (icp_nn_grid_open; PGP_ICP_OPEN_GRID=0: the scan alone)
+  bool open_grid = split && !use_grid && !use_index && a.max_corr2 < 0.f && n_tgt > 65535 && prm->nn_search != 1;
+  if (const char* v = getenv("PGP_ICP_OPEN_GRID")) open_grid = open_grid && atoi(v) != 0;
+  const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 + (use_index ? need * 4 + 64 : 0) +
+                                         (open_grid ? need * 4 + (size_t)n * 4 + 128 : 0) : 0;
   if ((rc = ctx->d_icp_ws.ensure(need * 8 + state_bytes + 64)) != PGP_OK) return rc;
   a.ws_d2 = ctx->d_icp_ws.as<float>();
   a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
@@ -2926,8 +2989,17 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     PGP_HIP(hipMemcpyAsync(a.st_E, e0.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream));
     PGP_HIP(hipStreamSynchronize(stream));  // e0 is a stack temporary
   }
-  if (use_grid) {
-    ctx->icp_idx_valid = false;   // d_icp_grid is about to hold the capped search's grid
+  int* open_list = nullptr;
+  int* open_cnt = nullptr;
+  float open_r2 = 0.f;
+  if (open_grid) {
+    unsigned char* q = reinterpret_cast<unsigned char*>(a.n_done + 1) + hist_bytes + 64;
+    q = reinterpret_cast<unsigned char*>(((uintptr_t)q + 15) & ~(uintptr_t)15);
+    open_list = reinterpret_cast<int*>(q);
+    open_cnt = open_list + need;
+  }
+  if (use_grid || open_grid) {
+    ctx->icp_idx_valid = false;   // d_icp_grid is about to hold the search's grid
     // ---- the target's grid: bounding box (device), cell edge >= max_corr (grown to keep <= 2^26 cells)
     float bb[6];
     if ((rc = device_bbox(ctx, reinterpret_cast<const float*>(d_tgt), n_tgt, 4, bb, bb + 3, stream)) != PGP_OK) return rc;
@@ -2936,7 +3008,21 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     for (int q = 0; q < 6; ++q) maxabs = fmaxf(maxabs, fabsf(bb[q]));
     // margin for the rounding of the cell coordinate: a point within max_corr of a query is at most
     // one cell away from the query's cell
-    float h = prm->max_corr_dist * 1.001f + 64.f * FLT_EPSILON * maxabs;
+    const float margin = 64.f * FLT_EPSILON * maxabs;
+    float h = prm->max_corr_dist * 1.001f + margin;
+    if (open_grid) {
+      // no cap to size the cells by: twice the spacing of n_tgt points spread over the bounding box's surface (a table,
+      // a room's walls), so that whatever lies within ~2 spacings of the target -- every query of a pose that is not far
+      // off -- is settled by the grid, from a few dozen candidates.  Measured (tools/icp_big_target.py, 30 000 x 100 000,
+      // 10 iterations): 1.5 / 2 / 3 / 4 / 6 spacings -> 2.63 / 2.32 / 2.94 / 3.84 / 6.67 ms from 4 mm off and 3.86 / 4.12 /
+      // 4.69 / 5.53 / 8.11 ms from 8 cm off, against 6.3 ms for the exhaustive scan alone.
+      const double ex = (double)bb[3] - bb[0], ey = (double)bb[4] - bb[1], ez = (double)bb[5] - bb[2];
+      const double area = 2.0 * (ex * ey + ey * ez + ez * ex);
+      double spacings = 2.0;
+      if (const char* v = getenv("PGP_ICP_OPEN_CELL")) spacings = atof(v) > 0.0 ? atof(v) : spacings;   // A/B knob
+      h = (float)(spacings * std::sqrt(std::max(area, 1e-12) / (double)n_tgt)) + margin;
+      if (!(h > 0.f) || !std::isfinite(h)) h = 1.f;
+    }
     for (;;) {
       // one spare cell per axis: the float cell coordinate of a point on the upper face may round up
       const double nx = floor((double)(bb[3] - bb[0]) / h) + 2, ny = floor((double)(bb[4] - bb[1]) / h) + 2,
@@ -2948,6 +3034,16 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
         break;
       }
       h *= 1.26f;
+    }
+    if (open_grid) {
+      // every target point within r of a query lies in the 27 cells around the query's: r = (h - margin) / 1.001, taken a
+      // little smaller still (the comparison is on squared distances as the kernels round them)
+      const double r = ((double)h - (double)margin) / 1.001;
+      open_r2 = (float)(r * r * (1.0 - 1e-5));
+      if (!(open_r2 > 0.f)) open_r2 = 0.f;
+      if (getenv("PGP_ICP_DEBUG"))
+        fprintf(stderr, "icp: open grid over %d target points: cell %.4g, %d x %d x %d cells, settles neighbours within %.4g\n", n_tgt,
+                (double)h, a.gnx, a.gny, a.gnz, r);
     }
     a.gox = bb[0];
     a.goy = bb[1];
@@ -2975,13 +3071,17 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   const dim3 ggrid((n_src + 255) / 256, n);
   for (int it = 0; it < a.max_iter; ++it) {
     if (use_grid) hipLaunchKernelGGL(icp_nn_grid, ggrid, dim3(256), 0, stream, a);
-    else if (use_index && a.nn_image_in_lds)
+    else if (open_grid) {
+      PGP_HIP(hipMemsetAsync(open_cnt, 0, (size_t)n * 4, stream));
+      hipLaunchKernelGGL(icp_nn_grid_open, ggrid, dim3(256), 0, stream, a, open_r2, open_list, open_cnt);
+      hipLaunchKernelGGL(icp_nn_split<true>, gnn, dim3(kNnThreads), 0, stream, a, (const int*)open_list, (const int*)open_cnt);
+    } else if (use_index && a.nn_image_in_lds)
       hipLaunchKernelGGL(icp_nn_index<true>, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
                          nn_lds_bytes(a.nn.bytes, kIdxThreads, true), stream, a);
     else if (use_index)
       hipLaunchKernelGGL(icp_nn_index<false>, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
                          nn_lds_bytes(a.nn.bytes, kIdxThreads, false), stream, a);
-    else hipLaunchKernelGGL(icp_nn_split, gnn, dim3(kNnThreads), 0, stream, a);
+    else hipLaunchKernelGGL(icp_nn_split<false>, gnn, dim3(kNnThreads), 0, stream, a, (const int*)nullptr, (const int*)nullptr);
     hipLaunchKernelGGL(icp_refine<true>, dim3(n), dim3(kIcpThreads), lds, stream, a);
     if (it == 0) PGP_HIP(hipGetLastError());   // a bad launch configuration shows on the first pair
     if ((it & 3) == 3) {  // every 4 iterations: has every pose stopped?

@@ -91,6 +91,32 @@ def test_table_icp_shape_target_beyond_16_bit_positions():
     assert Ea[0] < 1e-5 and ia[0] >= 2      # registered: rms below 3 mm (the noise is 0.8 mm per axis)
 
 
+@pytest.mark.parametrize("far", [False, True])
+def test_uncapped_icp_on_a_target_beyond_16_bit_positions(far):
+    """No correspondence cap and a 100 000-point target (beyond the exact index): the uniform grid settles every query
+    with a neighbour within its safe radius and the exhaustive scan only the others (icp_nn_grid_open +
+    icp_nn_split<true>, round 4).  Trimmed and plain forms, two poses, from close by (nearly every query settled by the
+    grid) and from 8 cm off (nearly none at first): transforms, energies and iteration counts equal the scan's, bit for bit."""
+    rng = np.random.default_rng(21)
+    top = np.c_[rng.uniform(-0.6, 0.6, 90000), rng.uniform(-0.4, 0.4, 90000), 0.0005 * rng.standard_normal(90000)]
+    rim = np.c_[rng.uniform(-0.6, 0.6, 10000), np.where(rng.random(10000) < 0.5, -0.4, 0.4), rng.uniform(-0.05, 0.0, 10000)]
+    tgt = np.concatenate([top, rim]).astype(np.float32)
+    R = synth._random_rot(rng, np.deg2rad(1.0))
+    pick = rng.choice(len(tgt), 6000, replace=False)
+    off = np.array([0.05, -0.04, 0.05]) if far else np.array([0.004, -0.003, 0.002])
+    src = (tgt[pick] @ R.T + off + 0.0008 * rng.standard_normal((6000, 3))).astype(np.float32)
+    src[:100] += rng.uniform(-0.3, 0.3, (100, 3)).astype(np.float32)     # clutter far from the table
+    src[7] = np.nan                                                      # a non-finite point has no neighbour either way
+    G0 = np.stack([synth.colmajor16(np.eye(4)), synth.colmajor16(synth._se3(synth._random_rot(rng, np.deg2rad(0.5)), [0.002, 0.0, -0.001]))])
+    sc = LcpScorer()
+    for kw in (dict(max_iterations=6, trim_fraction=0.9, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12),
+               dict(max_iterations=4, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)):
+        Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, nn_search=1, **kw)       # exhaustive scan
+        Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, nn_search=0, **kw)       # default: open grid + scan of the rest
+        assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
+        assert np.isfinite(Ta).all() and (ia >= 1).all()
+
+
 def test_old_entry_point_is_the_trimmed_form():
     g = np.load(GOLD)
     sc = LcpScorer()
