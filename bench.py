@@ -406,6 +406,24 @@ def other_rows(sc, w, torch, mode_name, d_batches):
                   "search": "exact index of the static target in LDS + vicinity graph (triangle-inequality proof for queries next to "
                             "their previous correspondence), persistent workgroups specialised per form: one per pose, 2 or 4 while few "
                             "poses are in flight (csrc/icp.hip)"}
+    # the reference's table alignment (SceneCfg.cpp:101,135-141): one pose, a 30 000-point scene against a 100 000-point
+    # table (beyond the LDS index: the capped search runs on the uniform grid), max correspondence distance 1 cm
+    try:
+        trng = np.random.default_rng(12)
+        top = np.c_[trng.uniform(-0.6, 0.6, 90000), trng.uniform(-0.4, 0.4, 90000), 0.0005 * trng.standard_normal(90000)]
+        rim = np.c_[trng.uniform(-0.6, 0.6, 10000), np.where(trng.random(10000) < 0.5, -0.4, 0.4), trng.uniform(-0.05, 0.0, 10000)]
+        t_tgt = np.concatenate([top, rim]).astype(np.float32)
+        Rt = synth._random_rot(trng, np.deg2rad(1.0))
+        t_src = (t_tgt[trng.choice(len(t_tgt), 30000, replace=False)] @ Rt.T + np.array([0.004, -0.003, 0.002])
+                 + 0.0008 * trng.standard_normal((30000, 3))).astype(np.float32)
+        G_id = synth.colmajor16(np.eye(4))[None]
+        dt, (_, e_t, it_t) = timed(lambda: sc.icp_refine_ex(t_src, t_tgt, G_id, max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0,
+                                                            transformation_epsilon=1e-9, absolute_mse=1e-12), reps=3)
+        out["icp_table_alignment"] = {"n_src": 30000, "n_tgt": 100000, "max_corr_dist": 0.01, "iterations": int(it_t[0]),
+                                      "ms_per_call": dt * 1e3, "us_per_iteration": dt * 1e6 / max(int(it_t[0]), 1),
+                                      "rms_mm": float(np.sqrt(e_t[0]) * 1e3)}
+    except Exception as e:
+        out["icp_table_alignment"] = {"error": repr(e)}
     # congruent sets on a 1000-pt search model
     w2 = synth.make_workload(4000, 2000, 4, config_id=3, n_search=1000)
     sc.set_search_model(w2.Qs_xyz)

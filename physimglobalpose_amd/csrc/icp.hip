@@ -525,11 +525,20 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     if (SPLIT) {
       // decode the keys left by icp_nn_split and re-arm them for the next iteration
       unsigned long long* kw = a.ws_key + (size_t)pose * a.n_src;
-      for (int i = tid; i < a.n_src; i += kIcpThreads) {
-        const unsigned long long k = kw[i];
-        kw[i] = ~0ull;
-        d2w[i] = k == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k >> 32));
-        jw[i] = k == ~0ull ? -1 : (int)(unsigned)(k & 0xFFFFFFFFull);
+      // four keys per trip, their loads issued together (a 30 000-point scene is 30 trips of a load-then-store chain
+      // otherwise: the reference's table alignment spent a third of this kernel here)
+      for (int i0 = tid; i0 < a.n_src; i0 += 4 * kIcpThreads) {
+        unsigned long long k[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) k[u] = i0 + u * kIcpThreads < a.n_src ? kw[i0 + u * kIcpThreads] : ~0ull;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * kIcpThreads;
+          if (i >= a.n_src) break;
+          kw[i] = ~0ull;
+          d2w[i] = k[u] == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(k[u] >> 32));
+          jw[i] = k[u] == ~0ull ? -1 : (int)(unsigned)(k[u] & 0xFFFFFFFFull);
+        }
       }
     } else {
     // ---- 1. correspondences: exhaustive NN of G*s_i in the target, tiled through LDS --------
@@ -921,46 +930,56 @@ __global__ __launch_bounds__(256) void grid_scatter(IcpArgs a, uint32_t* __restr
   if (FILL) pts[a.gcell_start[c] + slot] = make_float4(p.x, p.y, p.z, __int_as_float(j));
 }
 
+// Nearest target point of (x, y, z) among the 27 cells around its own, by the 16 lanes of a DPP row: lane r < 9 walks the
+// three x-neighbours of row (dz, dy) = (r / 3 - 1, r % 3 - 1) -- consecutive cells, one contiguous range of points --, then the
+// row's minimum key (d2 bits << 32 | j: smallest d2, then lowest j, the scan's rule; ~0: nothing) is formed by four
+// exchanges.  (One lane per query walked ~300 points through a chain of dependent loads: 73 us per iteration for the
+// reference's table alignment, 30 000 queries on 118 workgroups.)
+__device__ __forceinline__ unsigned long long grid_nn27(const IcpArgs& a, float x, float y, float z, int lane16) {
+  float best = FLT_MAX;
+  int bj = -1;
+  int cx, cy, cz;
+  if (lane16 < 9 && grid_cell_of(a, x, y, z, &cx, &cy, &cz)) {
+    const int zz = cz + lane16 / 3 - 1, yy = cy + lane16 % 3 - 1;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, a.gnx - 1);
+    if (zz >= 0 && zz < a.gnz && yy >= 0 && yy < a.gny && x0 <= x1) {
+      const size_t c0 = ((size_t)zz * a.gny + yy) * a.gnx + x0;
+      const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
+      for (uint32_t k = b; k < e; ++k) {
+        const float4 m = a.gpts[k];
+        const float dx = __fsub_rn(x, m.x), dyy = __fsub_rn(y, m.y), dzz = __fsub_rn(z, m.z);
+        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
+        const int j = __float_as_int(m.w);
+        if (d2 < best || (d2 == best && j < bj)) {   // the scan's rule: smallest d2, then lowest j
+          best = d2;
+          bj = j;
+        }
+      }
+    }
+  }
+  unsigned long long key = bj >= 0 ? ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj : ~0ull;   // d2 >= 0: bits order as values
+#pragma unroll
+  for (int off = 8; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off, 16);
+    key = o < key ? o : key;
+  }
+  return key;
+}
+
+constexpr int kGridLanes = 16;   // lanes per query in icp_nn_grid / icp_nn_grid_open
+
 __global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
   const int pose = blockIdx.y;
   if (a.st_done[pose]) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n_src) return;
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) / kGridLanes), lane16 = threadIdx.x & (kGridLanes - 1);
+  if (i >= a.n_src) return;   // whole rows: a row's lanes share i
   const float* G = a.T + 16 * (size_t)pose;
   const float4 s = a.src[i];
   const float x = row_xf(G[0], G[4], G[8], G[12], s.x, s.y, s.z);
   const float y = row_xf(G[1], G[5], G[9], G[13], s.x, s.y, s.z);
   const float z = row_xf(G[2], G[6], G[10], G[14], s.x, s.y, s.z);
-  float best = FLT_MAX;
-  int bj = -1;
-  int cx, cy, cz;
-  if (grid_cell_of(a, x, y, z, &cx, &cy, &cz)) {
-    for (int dz = -1; dz <= 1; ++dz) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= a.gnz) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= a.gny) continue;
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, a.gnx - 1);
-        if (x0 > x1) continue;
-        // the three x-neighbours are consecutive cells: one contiguous range of points
-        const size_t c0 = ((size_t)zz * a.gny + yy) * a.gnx + x0;
-        const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
-        for (uint32_t k = b; k < e; ++k) {
-          const float4 m = a.gpts[k];
-          const float dx = __fsub_rn(x, m.x), dyy = __fsub_rn(y, m.y), dzz = __fsub_rn(z, m.z);
-          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
-          const int j = __float_as_int(m.w);
-          if (d2 < best || (d2 == best && j < bj)) {   // the scan's rule: smallest d2, then lowest j
-            best = d2;
-            bj = j;
-          }
-        }
-      }
-    }
-  }
-  if (bj >= 0)
-    a.ws_key[(size_t)pose * a.n_src + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj;
+  const unsigned long long key = grid_nn27(a, x, y, z, lane16);
+  if (lane16 == 0 && key != ~0ull) a.ws_key[(size_t)pose * a.n_src + i] = key;
 }
 
 // The same search WITHOUT a correspondence cap, for targets beyond the exact index's 65 535 points (round 4): the 27
@@ -971,42 +990,17 @@ __global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
 __global__ __launch_bounds__(256) void icp_nn_grid_open(IcpArgs a, float r2_safe, int* __restrict__ list, int* __restrict__ cnt) {
   const int pose = blockIdx.y;
   if (a.st_done[pose]) return;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = (int)((blockIdx.x * blockDim.x + threadIdx.x) / kGridLanes), lane16 = threadIdx.x & (kGridLanes - 1);
   if (i >= a.n_src) return;
   const float* G = a.T + 16 * (size_t)pose;
   const float4 s = a.src[i];
   const float x = row_xf(G[0], G[4], G[8], G[12], s.x, s.y, s.z);
   const float y = row_xf(G[1], G[5], G[9], G[13], s.x, s.y, s.z);
   const float z = row_xf(G[2], G[6], G[10], G[14], s.x, s.y, s.z);
-  float best = FLT_MAX;
-  int bj = -1;
-  int cx, cy, cz;
-  if (grid_cell_of(a, x, y, z, &cx, &cy, &cz)) {
-    for (int dz = -1; dz <= 1; ++dz) {
-      const int zz = cz + dz;
-      if (zz < 0 || zz >= a.gnz) continue;
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int yy = cy + dy;
-        if (yy < 0 || yy >= a.gny) continue;
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, a.gnx - 1);
-        if (x0 > x1) continue;
-        const size_t c0 = ((size_t)zz * a.gny + yy) * a.gnx + x0;
-        const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
-        for (uint32_t k = b; k < e; ++k) {
-          const float4 m = a.gpts[k];
-          const float dx = __fsub_rn(x, m.x), dyy = __fsub_rn(y, m.y), dzz = __fsub_rn(z, m.z);
-          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
-          const int j = __float_as_int(m.w);
-          if (d2 < best || (d2 == best && j < bj)) {   // the scan's rule: smallest d2, then lowest j
-            best = d2;
-            bj = j;
-          }
-        }
-      }
-    }
-  }
-  if (bj >= 0 && best <= r2_safe) {
-    a.ws_key[(size_t)pose * a.n_src + i] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj;
+  const unsigned long long key = grid_nn27(a, x, y, z, lane16);
+  if (lane16 != 0) return;
+  if (key != ~0ull && __uint_as_float((unsigned)(key >> 32)) <= r2_safe) {
+    a.ws_key[(size_t)pose * a.n_src + i] = key;
   } else if (x == x && y == y && z == z) {   // (a non-finite query has no neighbour in the scan either: no key)
     const int slot = atomicAdd(&cnt[pose], 1);
     list[(size_t)pose * a.n_src + slot] = i;
@@ -3068,7 +3062,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     PGP_HIP(hipGetLastError());
   }
   const dim3 gnn((n_src + kNnThreads * kIcpR - 1) / (kNnThreads * kIcpR), (n_tgt + kNnTgt - 1) / kNnTgt, n);
-  const dim3 ggrid((n_src + 255) / 256, n);
+  const dim3 ggrid((unsigned)(((size_t)n_src * kGridLanes + 255) / 256), n);
   for (int it = 0; it < a.max_iter; ++it) {
     if (use_grid) hipLaunchKernelGGL(icp_nn_grid, ggrid, dim3(256), 0, stream, a);
     else if (open_grid) {
