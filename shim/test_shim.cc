@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -62,6 +63,10 @@ int main(int argc, char** argv) {
   const bool two = std::getenv("SHIM_TEST_TWO_OBJECTS") != nullptr;
   if (two) PPFMap2 = PPFMap;
   std::map<std::vector<int>, std::vector<std::pair<int, int> > >* maps[2] = {&PPFMap, two ? &PPFMap2 : &PPFMap};
+  // SHIM_TEST_CHECK_SAME=1 (with PGP_SHIM_SEED): every call must return what the first one did -- best score and pose,
+  // the list's scores, the registered points -- bit for bit (a soak for races between the calls' asynchronous parts)
+  int n_same = std::getenv("SHIM_TEST_CHECK_SAME") ? 0 : -1;
+  std::vector<double> first_sig;
   for (int rep = 0; rep < repeat; ++rep) {
     std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMapCall = *maps[rep & 1];
     best.first.matrix().setIdentity();
@@ -88,7 +93,19 @@ int main(int argc, char** argv) {
                                      "./", registered);
       elapsed.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     }
+    if (n_same >= 0) {
+      std::vector<double> sig;
+      sig.push_back(best.second);
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) sig.push_back(best.first.matrix()(r, c));
+      for (size_t i = 0; i < hyps.size(); ++i) sig.push_back(hyps[i].second);
+      sig.push_back((double)registered.size());
+      for (int v : registered) sig.push_back((double)v);
+      if (rep == 0) first_sig = sig;
+      if (sig.size() == first_sig.size() && std::memcmp(sig.data(), first_sig.data(), sig.size() * sizeof(double)) == 0) ++n_same;
+    }
   }
+  if (n_same >= 0) std::printf("SAME_AS_FIRST %d of %d\n", n_same, repeat);
   std::printf("ELAPSED_MS");
   for (double e : elapsed) std::printf(" %.3f", e);
   std::printf("\n");
