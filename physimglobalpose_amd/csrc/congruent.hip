@@ -945,7 +945,9 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   uint32_t* d_nkeys = qcnt;            // [1] appended so far | [nb] per base (the Q counters of the two-pass form)
   uint32_t* d_base_cnt = qcnt + 1;
   size_t sort_bytes = 0;
-  for (size_t cap = std::max<size_t>((size_t)ctx->csb_cap_hint, (size_t)1 << 16);;) {
+  // (PGP_CS_KEY_CAP=n: the first guess, for the test that makes a batch outgrow it)
+  static const size_t cap_env = getenv("PGP_CS_KEY_CAP") ? (size_t)std::max(1, atoi(getenv("PGP_CS_KEY_CAP"))) : 0;
+  for (size_t cap = cap_env ? cap_env : std::max<size_t>((size_t)ctx->csb_cap_hint, (size_t)1 << 16);;) {
     hipError_t he = rocprim::radix_sort_keys(nullptr, sort_bytes, (unsigned long long*)nullptr,
                                              (unsigned long long*)nullptr, cap, 0, 64, st);
     if (he != hipSuccess) {

@@ -116,3 +116,43 @@ def test_stale_batches_and_bad_picks_are_refused(case):
     sc.set_ppf_map(keys, counts, pairs)
     sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
     assert sc.congruent_batch_quads(np.array([[b, 0]], np.int32)).shape == (1, 4)
+
+
+def test_a_batch_that_outgrows_its_key_array_is_matched_again():
+    """The batch's single matching pass appends its keys to an array sized by a guess; PGP_CS_KEY_CAP=8 makes every batch
+    outgrow it, so the grow-and-repeat path runs: quad counts and quads equal the default run's."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import json, sys, tempfile, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from physimglobalpose_amd import LcpScorer
+from _dropin import make_dropin_case
+with tempfile.TemporaryDirectory() as d:
+    _, c = make_dropin_case(d, n_scene=6000, n_model=1200, n_search=400)
+w, table = c["w"], c["table"]
+keys = np.array(list(table.keys()), np.int32)
+counts = np.array([len(table[tuple(k)]) for k in keys.tolist()], np.int32)
+pairs = np.concatenate([np.array(table[tuple(k)], np.int32).reshape(-1, 2) for k in keys.tolist()])
+sc = LcpScorer()
+sc.set_scene(w.P_xyz, w.P_nrm, w.P_w, w.delta)
+sc.set_search_model(w.Qs_xyz)
+sc.set_ppf_map(keys, counts, pairs)
+ids, inv, status = sc.select_bases(np.random.default_rng(3).random((64, 4)))
+ok = status == 1
+ids, inv = ids[ok], inv[ok]
+out = []
+for rep in range(2):
+    n_quads = sc.find_congruent_batch(ids, w.P_xyz[ids], inv, w.delta)
+    picks = np.array([(b, j) for b in range(len(ids)) for j in range(n_quads[b])], np.int32).reshape(-1, 2)
+    out.append([n_quads.tolist(), sc.congruent_batch_quads(picks).tolist()])
+assert out[0] == out[1]
+print("RESULT " + json.dumps(out[0]))
+""" % (root, os.path.join(root, "tests"))
+    res = []
+    for env in ({}, {"PGP_CS_KEY_CAP": "8"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
+    assert res[0] == res[1] and sum(res[0][0]) > 8
+
