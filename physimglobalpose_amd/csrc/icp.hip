@@ -403,7 +403,18 @@ __device__ void quat_of(const float* G, double q[4]) {
 //   relative / absolute change of the mean squared correspondence distance;
 //   DifferentialTransformationChecker: mean over the last `smooth` iterations of the angular distance
 //   between consecutive absolute rotations and of the distance between consecutive translations.
-__device__ __attribute__((noinline)) bool converged_extra(const IcpArgs& a, int pose, int it_done, const float* G_old, const float* G_new,
+// what the extra stop rules read of IcpArgs, handed over BY VALUE: a reference to the kernel's argument struct made every
+// kernel that calls this keep a 440-byte copy of it in scratch memory (written by every thread at the start of the launch,
+// read back by lane 0 through memory round trips: 17.6 of the 88 us of icp_refine<true> on the reference's table alignment)
+struct StopRules {
+  float t_eps, rel_mse, abs_mse, diff_rot, diff_trans;
+  int smooth;
+  double* st_hist;
+};
+__device__ __forceinline__ StopRules stop_rules_of(const IcpArgs& a) {
+  return StopRules{a.t_eps, a.rel_mse, a.abs_mse, a.diff_rot, a.diff_trans, a.smooth, a.st_hist};
+}
+__device__ __attribute__((noinline)) bool converged_extra(const StopRules a, int pose, int it_done, const float* G_old, const float* G_new,
                                 double E, double E_old) {
   bool stop = false;
   if (a.t_eps >= 0.f) {
@@ -656,7 +667,11 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     // Thread t sums the points 4 t .. 4 t + 3 of every block of 4 x 1024 points, in index order (the persistent
     // indexed kernel maps its points the same way, so both add the same numbers in the same order): a cloud of
     // 1756 points then sits on 7 of the 16 waves, and only those pay the 17 wave-level f64 trees.
+#if defined(PGP_REFINE_ABLATE) && PGP_REFINE_ABLATE >= 4   // timing experiments (wrong results): 4 no sums loop
+    for (int b0 = 0; b0 < 0; b0 += kSumR * kIcpThreads) {
+#else
     for (int b0 = 0; b0 < a.n_src; b0 += kSumR * kIcpThreads) {
+#endif
       unsigned key[kSumR];
       float d2v[kSumR];
       bool sel[kSumR];
@@ -741,11 +756,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
     // wave butterfly, then the 16 wave results through LDS (aliases the target tile: all reads of
     // the tile finished before the barrier after step 1)
     // point-to-point uses the first 16 sums only (the branch is wave-uniform and folds away for k < 16)
+#if !(defined(PGP_REFINE_ABLATE) && PGP_REFINE_ABLATE >= 3)   // 3: no wave sums
 #pragma unroll
     for (int k = 0; k < kRedPlane; ++k)
       if (k < 16 || a.metric == 1)
         acc[k] = wave_sum_f64(acc[k]);
     e_acc = wave_sum_f64(e_acc);
+#endif
     __syncthreads();
     if (lane == 0) {
       for (int k = 0; k < kRedPlane; ++k) s_red[wave * (kRedPlane + 1) + k] = acc[k];
@@ -767,15 +784,19 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
       const double E = red[0] >= 1.0 ? red[kRedPlane] / red[0] : 0.0;
       // ---- 4. closed-form update, then the progress tests (PCL order: update first) ----------
       for (int k = 0; k < 16; ++k) s_G_old[k] = s_G[k];
+#if !(defined(PGP_REFINE_ABLATE) && PGP_REFINE_ABLATE >= 2)   // 2: no solve
       if (a.metric == 1) solve_plane(red, s_G);
       else solve_rigid(red, s_G);
+#endif
       const double E_old = s_energy_old;
       s_energy = E;
       s_energy_old = E;
       bool go = it + 1 < a.max_iter;
       if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;   // TrimmedICP's energy ratio
+#if !(defined(PGP_REFINE_ABLATE) && PGP_REFINE_ABLATE >= 1)   // 1: no stop rules (runs to max_iter)
       if (red[0] < 1.0) go = false;                                        // no correspondences left
-      if (converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old)) go = false;
+      if (converged_extra(stop_rules_of(a), pose, it + 1, s_G_old, s_G, E, E_old)) go = false;
+#endif
       s_continue = go ? 1 : 0;
     }
     __syncthreads();
@@ -2336,7 +2357,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
       if (red[0] < 1.0) go = false;
       // (the TrimmedICP form has none of the extra rules: no call, no spills around it)
       if (!TRIM_ONLY && (a.t_eps >= 0.f || a.rel_mse > 0.f || a.abs_mse >= 0.f || a.smooth > 0) &&
-          converged_extra(a, pose, it + 1, s_G_old, s_G, E, E_old))
+          converged_extra(stop_rules_of(a), pose, it + 1, s_G_old, s_G, E, E_old))
         go = false;
       s_continue = go ? 1 : 0;
       PGP_STAMP(5);
