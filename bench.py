@@ -406,6 +406,20 @@ def other_rows(sc, w, torch, mode_name, d_batches):
                   "search": "exact index of the static target in LDS + vicinity graph (triangle-inequality proof for queries next to "
                             "their previous correspondence), persistent workgroups specialised per form: one per pose, 2 or 4 while few "
                             "poses are in flight (csrc/icp.hip)"}
+    # the PCL form of the reference's calls (greedy_bfs/State.cpp:139-142: 50 iterations, 1 cm cap, transformation epsilon
+    # 1e-8, absolute MSE 1e-12) on the same segment / model, from 1 deg / 2 mm off: the persistent kernels with the extra stop rules
+    try:
+        pcl = {}
+        prng = np.random.default_rng(7)      # (its own generator: the rows below keep their draws)
+        for n_p in (1, 64, 256):
+            Gp = np.stack([synth.colmajor16(Tinv @ synth._se3(synth._random_rot(prng, np.deg2rad(1.0)), 0.002 * prng.standard_normal(3)))
+                           for _ in range(n_p)])
+            dt, (_, _, its) = timed(lambda: sc.icp_refine_ex(S, w.Q_xyz, Gp, max_iterations=50, max_corr_dist=0.01, energy_ratio=0.0,
+                                                             transformation_epsilon=1e-8, absolute_mse=1e-12), reps=5)
+            pcl[str(n_p)] = {"iterations_total": int(its.sum()), "ms_per_call": dt * 1e3, "pose_iterations_per_s": int(its.sum()) / dt}
+        out["icp_pcl_form"] = pcl
+    except Exception as e:
+        out["icp_pcl_form"] = {"error": repr(e)}
     # the reference's table alignment (SceneCfg.cpp:101,135-141): one pose, a 30 000-point scene against a 100 000-point
     # table (beyond the LDS index: the capped search runs on the uniform grid), max correspondence distance 1 cm
     try:
