@@ -117,6 +117,27 @@ def test_uncapped_icp_on_a_target_beyond_16_bit_positions(far):
         assert np.isfinite(Ta).all() and (ia >= 1).all()
 
 
+def test_uncapped_icp_big_target_point_to_plane_and_nothing_settled():
+    """The open grid on a 65 536-point target (the first size beyond the exact index): point-to-plane with normals, eight
+    poses; and a segment so far off that the grid settles NOTHING (every query goes to the listed scan) -- equal to the scan."""
+    rng = np.random.default_rng(33)
+    n = 65536
+    tgt = np.c_[rng.uniform(-0.5, 0.5, n), rng.uniform(-0.5, 0.5, n), 0.02 * np.sin(6 * rng.uniform(-0.5, 0.5, n))].astype(np.float32)
+    nrm = np.tile(np.array([0, 0, 1], np.float32), (n, 1))
+    src = (tgt[rng.choice(n, 3000, replace=False)] + np.array([0.003, 0.002, 0.004]) + 0.0005 * rng.standard_normal((3000, 3))).astype(np.float32)
+    G0 = np.stack([synth.colmajor16(synth._se3(synth._random_rot(rng, np.deg2rad(0.4)), 0.002 * rng.standard_normal(3))) for _ in range(8)])
+    sc = LcpScorer()
+    kw = dict(max_iterations=5, error_metric=1, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
+    Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, tgt_nrm=nrm, nn_search=1, **kw)
+    Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, tgt_nrm=nrm, nn_search=0, **kw)
+    assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
+    far = (src + np.array([0.0, 0.0, 0.6])).astype(np.float32)           # 60 cm above the sheet: no cell of the grid is near
+    kw = dict(max_iterations=3, trim_fraction=0.8, energy_ratio=0.0)
+    Ta, Ea, ia = sc.icp_refine_ex(far, tgt, G0[:2], nn_search=1, **kw)
+    Tb, Eb, ib = sc.icp_refine_ex(far, tgt, G0[:2], nn_search=0, **kw)
+    assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
+
+
 def test_old_entry_point_is_the_trimmed_form():
     g = np.load(GOLD)
     sc = LcpScorer()
