@@ -497,13 +497,18 @@ __device__ __forceinline__ unsigned wave_scan_incl_u32(unsigned v) {
   return v;
 }
 
+constexpr int kPartStride = 32;   // doubles per (pose, block) in the partial sums of icp_sums_partial (kRedPlane + 1 = 29 used)
+
 // SPLIT = false: persistent kernel, all iterations of one pose in one workgroup (many poses).
 // SPLIT = true : one iteration's selection + update for one pose; the correspondences were
 //                produced by icp_nn_split over many workgroups (few poses: a single pose would
 //                otherwise run its exhaustive search on one CU of 256).  Same arithmetic, same
 //                reduction tree: both paths give identical results.
-template <bool SPLIT>
-__global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
+// PART (host-driven path, scenes beyond 4096 points, no trimming): the sums of the iteration were formed by icp_sums_partial,
+// one workgroup per block of 4096 points, and are only added up here in block order (a single workgroup walking 30 000
+// points -- the reference's table alignment -- spent 52 of its 71 us in that walk, profiles/r04_ab/icp_refine_ablation.log)
+template <bool SPLIT, bool PART = false>
+__global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a, const double* __restrict__ part = nullptr, int n_blk = 0) {
   extern __shared__ __align__(16) unsigned char smem[];
   float4* s_tgt = reinterpret_cast<float4*>(smem);                         // kTgtTile float4
   double* s_red = reinterpret_cast<double*>(smem);                         // aliases the tile
@@ -533,7 +538,9 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
 
   int it = SPLIT ? a.st_it[pose] : 0;
   for (;;) {
-    if (SPLIT) {
+    if (SPLIT && PART) {
+      // (icp_sums_partial has decoded and re-armed the keys of its blocks)
+    } else if (SPLIT) {
       // decode the keys left by icp_nn_split and re-arm them for the next iteration
       unsigned long long* kw = a.ws_key + (size_t)pose * a.n_src;
       // four keys per trip, their loads issued together (a 30 000-point scene is 30 trips of a load-then-store chain
@@ -670,7 +677,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
 #if defined(PGP_REFINE_ABLATE) && PGP_REFINE_ABLATE >= 4   // timing experiments (wrong results): 4 no sums loop
     for (int b0 = 0; b0 < 0; b0 += kSumR * kIcpThreads) {
 #else
-    for (int b0 = 0; b0 < a.n_src; b0 += kSumR * kIcpThreads) {
+    for (int b0 = 0; b0 < (PART ? 0 : a.n_src); b0 += kSumR * kIcpThreads) {
 #endif
       unsigned key[kSumR];
       float d2v[kSumR];
@@ -769,7 +776,13 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
       s_red[wave * (kRedPlane + 1) + kRedPlane] = e_acc;
     }
     __syncthreads();
-    if (tid <= kRedPlane) {   // one thread per sum, waves added in order (as thread 0 did alone before)
+    if (PART) {
+      if (tid <= kRedPlane) {   // one thread per sum, the blocks' sums added in block order
+        double v = 0.0;
+        for (int b = 0; b < n_blk; ++b) v += part[((size_t)pose * n_blk + b) * kPartStride + tid];
+        s_sum[tid] = v;
+      }
+    } else if (tid <= kRedPlane) {   // one thread per sum, waves added in order (as thread 0 did alone before)
       double v = 0.0;
 #pragma unroll
       for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRedPlane + 1) + tid];
@@ -815,6 +828,100 @@ __global__ __launch_bounds__(kIcpThreads) void icp_refine(IcpArgs a) {
         atomicAdd(a.n_done, 1);
       }
     }
+  }
+}
+
+// One block of kSumR * kIcpThreads = 4096 points of one pose: decodes (and re-arms) the block's keys, selects (cap or
+// everything: this path is not taken when a trimming threshold has to be found first) and forms the block's f64 sums with the
+// accumulation and the reduction tree of icp_refine -- for a cloud of one block the numbers are icp_refine's own.
+__global__ __launch_bounds__(kIcpThreads) void icp_sums_partial(IcpArgs a, double* __restrict__ part, int n_blk) {
+  __shared__ double s_red[(kIcpThreads / 64) * (kRedPlane + 1)];
+  __shared__ float s_G[16];
+  const int pose = blockIdx.y, blk = blockIdx.x;
+  if (a.st_done[pose]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 16) s_G[tid] = a.T[16 * (size_t)pose + tid];
+  __syncthreads();
+  unsigned long long* kw = a.ws_key + (size_t)pose * a.n_src;
+  float* d2w = a.ws_d2 + (size_t)pose * a.n_src;
+  int* jw = a.ws_j + (size_t)pose * a.n_src;
+  const int b0 = blk * kSumR * kIcpThreads;
+  unsigned long long kv[kSumR];
+#pragma unroll
+  for (int r = 0; r < kSumR; ++r) {
+    const int i = b0 + kSumR * tid + r;
+    kv[r] = i < a.n_src ? kw[i] : ~0ull;
+  }
+  float d2v[kSumR];
+  int jmv[kSumR];
+  bool sel[kSumR];
+#pragma unroll
+  for (int r = 0; r < kSumR; ++r) {
+    const int i = b0 + kSumR * tid + r;
+    d2v[r] = kv[r] == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(kv[r] >> 32));
+    jmv[r] = kv[r] == ~0ull ? -1 : (int)(unsigned)(kv[r] & 0xFFFFFFFFull);
+    if (i < a.n_src) {
+      kw[i] = ~0ull;
+      d2w[i] = d2v[r];
+      jw[i] = jmv[r];
+    }
+    sel[r] = i < a.n_src && (a.max_corr2 >= 0.f ? d2v[r] <= a.max_corr2 : true);
+  }
+  double acc[kRedPlane];
+#pragma unroll
+  for (int k = 0; k < kRedPlane; ++k) acc[k] = 0.0;
+  double e_acc = 0.0;
+#pragma unroll
+  for (int r = 0; r < kSumR; ++r) {
+    const int i = b0 + kSumR * tid + r;
+    const float d2 = d2v[r];
+    const int jm = jmv[r];
+    if (sel[r] && jm >= 0 && a.metric == 1) {
+      const float4 s = a.src[i];
+      const float4 m = a.tgt[jm];
+      const float4 nn = a.tgt_n[jm];
+      const double sx = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
+      const double sy = row_xf(s_G[1], s_G[5], s_G[9], s_G[13], s.x, s.y, s.z);
+      const double sz = row_xf(s_G[2], s_G[6], s_G[10], s_G[14], s.x, s.y, s.z);
+      const double nx = nn.x, ny = nn.y, nz = nn.z;
+      const double row[6] = {nz * sy - ny * sz, nx * sz - nz * sx, ny * sx - nx * sy, nx, ny, nz};
+      const double rhs = nx * (double)m.x + ny * (double)m.y + nz * (double)m.z - nx * sx - ny * sy - nz * sz;
+      acc[0] += 1.0;
+      int t = 1;
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+        for (int c = rr; c < 6; ++c) acc[t++] += row[rr] * row[c];
+#pragma unroll
+      for (int rr = 0; rr < 6; ++rr) acc[22 + rr] += row[rr] * rhs;
+      e_acc += (double)d2;
+    } else if (sel[r] && jm >= 0) {
+      const float4 s = a.src[i];
+      const float4 m = a.tgt[jm];
+      acc[0] += 1.0;
+      acc[1] += s.x; acc[2] += s.y; acc[3] += s.z;
+      acc[4] += m.x; acc[5] += m.y; acc[6] += m.z;
+      acc[7] += (double)s.x * m.x; acc[8] += (double)s.x * m.y; acc[9] += (double)s.x * m.z;
+      acc[10] += (double)s.y * m.x; acc[11] += (double)s.y * m.y; acc[12] += (double)s.y * m.z;
+      acc[13] += (double)s.z * m.x; acc[14] += (double)s.z * m.y; acc[15] += (double)s.z * m.z;
+      e_acc += (double)d2;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < kRedPlane; ++k)
+    if (k < 16 || a.metric == 1)
+      acc[k] = wave_sum_f64(acc[k]);
+  e_acc = wave_sum_f64(e_acc);
+  if (lane == 0) {
+    for (int k = 0; k < kRedPlane; ++k) s_red[wave * (kRedPlane + 1) + k] = acc[k];
+    s_red[wave * (kRedPlane + 1) + kRedPlane] = e_acc;
+  }
+  __syncthreads();
+  if (tid <= kRedPlane) {   // one thread per sum, waves added in order
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < kIcpThreads / 64; ++w) v += s_red[w * (kRedPlane + 1) + tid];
+    part[((size_t)pose * n_blk + blk) * kPartStride + tid] = v;
   }
 }
 
@@ -2577,6 +2684,7 @@ static int ensure_icp_attrs(pgp_ctx* ctx) {
   const size_t lds = (size_t)kTgtTile * sizeof(float4);
   PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  PGP_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(icp_refine<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const void* big[] = {reinterpret_cast<const void*>(icp_nn_index<true>), reinterpret_cast<const void*>(icp_nn_index<false>)};
   for (const void* f : big) PGP_HIP(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024));
   for (int v = 0; v < kPersistKernels; ++v)
@@ -2972,8 +3080,14 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   // neighbour within a safe radius, the exhaustive scan only the others (icp_nn_grid_open; PGP_ICP_OPEN_GRID=0: the scan alone)
   bool open_grid = split && !use_grid && !use_index && a.max_corr2 < 0.f && n_tgt > 65535 && prm->nn_search != 1;
   if (const char* v = getenv("PGP_ICP_OPEN_GRID")) open_grid = open_grid && atoi(v) != 0;
+  // Scenes beyond one block of 4096 points, nothing to trim (a cap, or every pair kept): the iteration's sums are formed by one
+  // workgroup per block (icp_sums_partial) and icp_refine only adds them up (PGP_ICP_PART=0: one workgroup walks the scene)
+  const int n_blk = (n_src + kSumR * kIcpThreads - 1) / (kSumR * kIcpThreads);
+  bool part_sums = split && n_blk > 1 && !(a.max_corr2 < 0.f && a.k_trim < a.n_src);
+  if (const char* v = getenv("PGP_ICP_PART")) part_sums = part_sums && atoi(v) != 0;
+  const size_t part_bytes = part_sums ? (size_t)n * n_blk * kPartStride * 8 + 64 : 0;
   const size_t state_bytes = split ? need * 8 + (size_t)n * 16 + 64 + hist_bytes + 64 + (use_index ? need * 4 + 64 : 0) +
-                                         (open_grid ? need * 4 + (size_t)n * 4 + 128 : 0) : 0;
+                                         (open_grid ? need * 4 + (size_t)n * 4 + 128 : 0) + part_bytes : 0;
   if ((rc = ctx->d_icp_ws.ensure(need * 8 + state_bytes + 64)) != PGP_OK) return rc;
   a.ws_d2 = ctx->d_icp_ws.as<float>();
   a.ws_j = reinterpret_cast<int*>(a.ws_d2 + need);
@@ -3003,6 +3117,11 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     std::vector<double> e0((size_t)n, (double)FLT_MAX);
     PGP_HIP(hipMemcpyAsync(a.st_E, e0.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream));
     PGP_HIP(hipStreamSynchronize(stream));  // e0 is a stack temporary
+  }
+  double* d_part = nullptr;
+  if (part_sums) {   // the last part_bytes of the workspace
+    unsigned char* end = ctx->d_icp_ws.as<unsigned char>() + need * 8 + state_bytes + 64;
+    d_part = reinterpret_cast<double*>(((uintptr_t)(end - part_bytes) + 47) & ~(uintptr_t)15);
   }
   int* open_list = nullptr;
   int* open_cnt = nullptr;
@@ -3097,7 +3216,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       hipLaunchKernelGGL(icp_nn_index<false>, dim3((n_src + kIdxThreads - 1) / kIdxThreads, n), dim3(kIdxThreads),
                          nn_lds_bytes(a.nn.bytes, kIdxThreads, false), stream, a);
     else hipLaunchKernelGGL(icp_nn_split<false>, gnn, dim3(kNnThreads), 0, stream, a, (const int*)nullptr, (const int*)nullptr);
-    hipLaunchKernelGGL(icp_refine<true>, dim3(n), dim3(kIcpThreads), lds, stream, a);
+    if (part_sums) {
+      hipLaunchKernelGGL(icp_sums_partial, dim3(n_blk, n), dim3(kIcpThreads), 0, stream, a, d_part, n_blk);
+      hipLaunchKernelGGL((icp_refine<true, true>), dim3(n), dim3(kIcpThreads), lds, stream, a, (const double*)d_part, n_blk);
+    } else {
+      hipLaunchKernelGGL((icp_refine<true, false>), dim3(n), dim3(kIcpThreads), lds, stream, a, (const double*)nullptr, 0);
+    }
     if (it == 0) PGP_HIP(hipGetLastError());   // a bad launch configuration shows on the first pair
     if ((it & 3) == 3) {  // every 4 iterations: has every pose stopped?
       int done = 0;

@@ -138,6 +138,32 @@ def test_uncapped_icp_big_target_point_to_plane_and_nothing_settled():
     assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb) and np.array_equal(ia, ib)
 
 
+def test_scene_sized_source_sums_by_block_equal_the_single_workgroup_walk(monkeypatch):
+    """Scenes beyond 4096 points without trimming: the iteration's f64 sums are formed per block of 4096 points by a
+    workgroup each (icp_sums_partial) and added in block order; PGP_ICP_PART=0 keeps the one-workgroup walk.  The two
+    associate the sums differently beyond one block: same iteration counts, transforms within 1e-6, energies within 1e-6
+    relative -- and a cloud of at most one block is bit-equal (it IS the same tree)."""
+    rng = np.random.default_rng(5)
+    tgt = np.c_[rng.uniform(-0.5, 0.5, 40000), rng.uniform(-0.4, 0.4, 40000), 0.01 * rng.standard_normal(40000)].astype(np.float32)
+    sc = LcpScorer()
+    for n_src, exact in ((20000, False), (3000, True)):
+        R = synth._random_rot(rng, np.deg2rad(0.8))
+        src = (tgt[rng.choice(len(tgt), n_src, replace=False)] @ R.T + np.array([0.003, -0.002, 0.002])).astype(np.float32)
+        G0 = np.stack([synth.colmajor16(np.eye(4)), synth.colmajor16(synth._se3(synth._random_rot(rng, np.deg2rad(0.3)), [0.001, 0.0, 0.001]))])
+        for kw in (dict(max_iterations=12, max_corr_dist=0.02, energy_ratio=0.0, transformation_epsilon=1e-10, absolute_mse=1e-14, nn_search=2),
+                   dict(max_iterations=6, energy_ratio=0.0, nn_search=1)):
+            monkeypatch.setenv("PGP_ICP_PERSIST", "0")        # the host-driven path for both sizes
+            monkeypatch.delenv("PGP_ICP_PART", raising=False)
+            Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, **kw)
+            monkeypatch.setenv("PGP_ICP_PART", "0")
+            Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, **kw)
+            assert np.array_equal(ia, ib)
+            if exact:
+                assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb)
+            else:
+                assert np.abs(Ta - Tb).max() < 1e-6 and np.allclose(Ea, Eb, rtol=1e-6, atol=1e-14)
+
+
 def test_old_entry_point_is_the_trimmed_form():
     g = np.load(GOLD)
     sc = LcpScorer()
