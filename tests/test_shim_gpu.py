@@ -93,3 +93,21 @@ def test_drop_in_takes_the_reference_tie_rule_for_a_segment_with_duplicated_poin
     assert auto == forced and "exact ties: on" in err_auto
     _, err_plain = run(seg)
     assert "exact ties: off" in err_plain
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
+def test_drop_in_over_a_device_group_returns_the_single_device_result(tmp_path):
+    """PGP_SHIM_DEVICES=2 (hypotheses sharded over a native group, pgp_multi_*) with the group's N > 1 branches run on one
+    device (PGP_MULTI_EMULATE=2): best pose, score, list and registered count of the single-device call, for the same seed."""
+    argv, _ = make_dropin_case(tmp_path)
+    cmd = [BIN] + [str(a) for a in argv]
+    env = dict(os.environ, PGP_SHIM_SEED="4242", SHIM_TEST_INMEMORY="1", SHIM_TEST_REPEAT="2")
+    one = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    two = subprocess.run(cmd, env=dict(env, PGP_SHIM_DEVICES="2", PGP_MULTI_EMULATE="2"), capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0 and two.returncode == 0, one.stderr[-1000:] + two.stderr[-1000:]
+
+    def strip(t):
+        return [l for l in t.splitlines() if not l.startswith("ELAPSED_MS")]
+    assert strip(one.stdout) == strip(two.stdout)
+    assert any(l.startswith("BEST_SCORE") and float(l.split()[1]) > 0.1 for l in one.stdout.splitlines())
+
