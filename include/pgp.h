@@ -367,7 +367,9 @@ int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const fl
  * that keeps its target's index (pgp_icp_target_token applies per context), its clouds and its own transform /
  * energy / iteration arrays; all contexts on one device.  Results are bit-identical to one pgp_icp_refine_device
  * call per job -- which is also what happens when the single launch cannot serve the jobs (more than 8 of them, a
- * target whose index does not fit a compute unit's LDS, a segment beyond 4096 points).  Enqueued on `stream`. */
+ * target whose index does not fit a compute unit's LDS, a segment beyond 4096 points, or two jobs that name the SAME
+ * context: a context keeps one target index, so give every job of a launch its own context when the single launch
+ * matters).  Enqueued on `stream`. */
 typedef struct {
   pgp_ctx* ctx;
   const float* d_src4;   /* float4 {x,y,z,-} [n_src] */
@@ -604,7 +606,11 @@ int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, cons
  * pgp_score_lcp on one device, bit for bit (plain) / with the same summation tree (weighted).
  * device_ids NULL = devices 0 .. n_dev-1; n_dev <= 0 = every visible device.  RCCL (librccl.so.1)
  * is bound at run time and only when the group has more than one device (or
- * PGP_MULTI_FORCE_COLLECTIVE=1).  Calls on one pgp_multi must not overlap. */
+ * PGP_MULTI_FORCE_COLLECTIVE=1).  Every member's worker thread queues its slice, its own ncclAllReduce (one
+ * communicator per device) and, on member 0, the arg-max and the copy back: one rendezvous of the calling thread per
+ * call (PGP_MULTI_COLL=grouped issues the collective for all members from the calling thread inside one group instead).
+ * Member 0 holds all transforms (it settles near-ties across slices), the others copy their slice only.
+ * Calls on one pgp_multi must not overlap. */
 typedef struct pgp_multi pgp_multi;
 int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev);
 int pgp_multi_destroy(pgp_multi* m);
@@ -622,6 +628,69 @@ int pgp_multi_score_lcp(pgp_multi* m, const float* T, int n_h, int mode, float g
 int pgp_multi_upload(pgp_multi* m, const float* T, int n_h);
 int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts,
                              int* best_index, float* best_score);
+/* ---- a group that holds SEVERAL objects (BASELINE configs[3]: 6 objects, 64 k hypotheses over 8 GPUs) -----
+ * The node loops over the objects of a frame (PPE/data_layer/SceneCfg.cpp:376-406), each with its own segment (scene
+ * side), validation model and hypothesis list.  An OBJECT of a group is one such (scene, model) pair, replicated on
+ * every member; object 0 exists from pgp_multi_create on -- the single-object entry points above act on it --
+ * and pgp_multi_add_object appends one (returns its id >= 1, or a negative PGP_E* code).
+ * pgp_multi_score_objects flattens (object, hypothesis) into ONE index space (object after object), gives member k the
+ * contiguous share pgp_multi_slice(sum n_h, k, ...) of it -- pgp_multi_flat_slices lists that share as (object, lo, hi)
+ * pieces --, every member scores its pieces on the objects' contexts into a zeroed full-length vector, ONE all-reduce
+ * for the concatenated {scores | counts} of all objects, and member 0 takes every object's arg-max with the near-tie
+ * settlement of pgp_settle_best_device (pgp_set_exact_records / pgp_set_verify_early_out on
+ * pgp_multi_object_context(m, obj, 0) apply as for one object).
+ *   T[n_obj], n_h[n_obj]: every object's transform list (objects 0 .. n_obj-1 of the group; a count may be 0)
+ *   scores / counts (nullable): flat, sum(n_h) entries, object after object -- per object what pgp_score_lcp returns
+ *   best_index[n_obj] (nullable): per object, relative to the object's list; best_score[n_obj] (nullable). */
+int pgp_multi_add_object(pgp_multi* m);
+int pgp_multi_objects(const pgp_multi* m);
+pgp_ctx* pgp_multi_object_context(pgp_multi* m, int obj, int k);
+int pgp_multi_set_object_scene(pgp_multi* m, int obj, const float* xyz, const float* nrm, const float* weight, int n,
+                               float delta);
+int pgp_multi_set_object_scene_weights(pgp_multi* m, int obj, const float* weight, int n);
+int pgp_multi_set_object_model(pgp_multi* m, int obj, const float* xyz, const float* nrm, int n);
+int pgp_multi_set_object_search_model(pgp_multi* m, int obj, const float* xyz, int n);
+int pgp_multi_set_object_ppf_map(pgp_multi* m, int obj, const int* keys, const int* counts, const int* pairs, int n_keys);
+int pgp_multi_flat_slices(const int* n_h, int n_obj, int k, int n_dev, int* obj, int* lo, int* hi, int* n_pieces);
+int pgp_multi_score_objects(pgp_multi* m, const float* const* T, const int* n_h, int n_obj, int mode, float gate_deg,
+                            float* scores, int* counts, int* best_index, float* best_score);
+int pgp_multi_upload_objects(pgp_multi* m, const float* const* T, const int* n_h, int n_obj);
+int pgp_multi_score_objects_uploaded(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts, int* best_index,
+                                     float* best_score);
+
+/* ICP over the group: the poses to refine are sharded like the hypotheses ("shard poses-to-refine the same way;
+ * no collective except the final gather").  The jobs are the (segment, target) pairs of pgp_icp_refine -- the children of
+ * an MCTS expansion (PPE/hypothesis_verification/mcts/UCTSearch.cpp:200-266 -> UCTState.cpp:121-204), the objects of a
+ * frame -- with HOST pointers; the flat (job, pose) space is block-partitioned over the members
+ * (pgp_multi_flat_slices), every member refines its pieces in ONE launch (pgp_icp_refine_multi_device; the target of job
+ * j keeps its index on the member's j-th ICP context from call to call) and writes its poses' results straight into the
+ * caller's arrays.  Results are those of one pgp_icp_refine per job on one context, bit for bit. */
+typedef struct {
+  const float* src_xyz;  /* n_src x 3: the points that are moved (the segment) */
+  int n_src;
+  const float* tgt_xyz;  /* n_tgt x 3: the cloud searched for neighbours (the model) */
+  int n_tgt;
+  float* T;              /* [n][16] in/out */
+  int n;
+  float* energy;         /* [n], nullable */
+  int* iters;            /* [n], nullable */
+} pgp_multi_icp_job;
+int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs, const pgp_icp_params* params);
+
+/* Congruent sets over the group: the bases of an object are sharded ("shard by base (100 bases/object);
+ * gather variable-length transform lists on host"; the loop base.cc:1855-1874).  Member k runs pgp_find_congruent_batch
+ * for the bases pgp_multi_slice(n_bases, k, ...) on its context of object `obj` (which needs the object's scene, search
+ * model and pair-feature table: pgp_multi_set_object_*), n_quads[n_bases] is gathered, and the sorted quad lists stay on
+ * the member that owns the base.  pgp_multi_congruent_batch_quads / _fit route every pick (base, j) to that member and
+ * return the results in the caller's pick order -- what pgp_congruent_batch_quads / _fit return on one context
+ * (base_ids[n_bases][4] as there). */
+int pgp_multi_find_congruent_batch(pgp_multi* m, int obj, const int* base_ids, const float* base_xyz,
+                                   const float* invariants, int n_bases, float threshold, int* n_quads);
+int pgp_multi_congruent_batch_quads(pgp_multi* m, int obj, const int* picks, int cnt, int* quads);
+int pgp_multi_congruent_batch_fit(pgp_multi* m, int obj, const int* picks, const int* base_ids, int cnt,
+                                  const float centroid_P[3], const float centroid_Q[3], float* T, double* pose,
+                                  int* status, float* rms);
+
 /* Host wall clock of the last scoring call in ms: upload (pinned copy + H2D enqueue), enqueue
  * (kernels + collective issued on every device), total (until the results are back). */
 int pgp_multi_last_timing(pgp_multi* m, float* upload_ms, float* enqueue_ms, float* total_ms);

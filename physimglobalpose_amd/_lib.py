@@ -42,6 +42,11 @@ class IcpJob(C.Structure):
                 ("d_T", C.c_void_p), ("n", C.c_int), ("d_energy", C.c_void_p), ("d_iters", C.c_void_p)]
 
 
+class MultiIcpJob(C.Structure):
+    _fields_ = [("src_xyz", C.POINTER(C.c_float)), ("n_src", C.c_int), ("tgt_xyz", C.POINTER(C.c_float)), ("n_tgt", C.c_int),
+                ("T", C.POINTER(C.c_float)), ("n", C.c_int), ("energy", C.POINTER(C.c_float)), ("iters", C.POINTER(C.c_int))]
+
+
 class Camera(C.Structure):
     _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
                 ("cy", C.c_float), ("z_near", C.c_float), ("z_max", C.c_float)]
@@ -149,6 +154,22 @@ SIGNATURES = {
     "pgp_multi_upload": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_multi_score_uploaded": (C.c_int, [C.c_void_p, C.c_int, C.c_float, _f, _i, _i, _f]),
     "pgp_multi_last_timing": (C.c_int, [C.c_void_p, _f, _f, _f]),
+    "pgp_multi_add_object": (C.c_int, [C.c_void_p]),
+    "pgp_multi_objects": (C.c_int, [C.c_void_p]),
+    "pgp_multi_object_context": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "pgp_multi_set_object_scene": (C.c_int, [C.c_void_p, C.c_int, _f, _f, _f, C.c_int, C.c_float]),
+    "pgp_multi_set_object_scene_weights": (C.c_int, [C.c_void_p, C.c_int, _f, C.c_int]),
+    "pgp_multi_set_object_model": (C.c_int, [C.c_void_p, C.c_int, _f, _f, C.c_int]),
+    "pgp_multi_set_object_search_model": (C.c_int, [C.c_void_p, C.c_int, _f, C.c_int]),
+    "pgp_multi_set_object_ppf_map": (C.c_int, [C.c_void_p, C.c_int, _i, _i, _i, C.c_int]),
+    "pgp_multi_flat_slices": (C.c_int, [_i, C.c_int, C.c_int, C.c_int, _i, _i, _i, _i]),
+    "pgp_multi_score_objects": (C.c_int, [C.c_void_p, C.POINTER(_f), _i, C.c_int, C.c_int, C.c_float, _f, _i, _i, _f]),
+    "pgp_multi_upload_objects": (C.c_int, [C.c_void_p, C.POINTER(_f), _i, C.c_int]),
+    "pgp_multi_score_objects_uploaded": (C.c_int, [C.c_void_p, C.c_int, C.c_float, _f, _i, _i, _f]),
+    "pgp_multi_icp_refine": (C.c_int, [C.c_void_p, C.POINTER(MultiIcpJob), C.c_int, C.POINTER(IcpParams)]),
+    "pgp_multi_find_congruent_batch": (C.c_int, [C.c_void_p, C.c_int, _i, _f, _f, C.c_int, C.c_float, _i]),
+    "pgp_multi_congruent_batch_quads": (C.c_int, [C.c_void_p, C.c_int, _i, C.c_int, _i]),
+    "pgp_multi_congruent_batch_fit": (C.c_int, [C.c_void_p, C.c_int, _i, _i, C.c_int, _f, _f, _f, C.POINTER(C.c_double), _i, _f]),
     "pgp_set_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "pgp_get_kernel_timing": (C.c_int, [C.c_void_p, _i, _f, C.c_int]),
     "pgp_get_index_info": (C.c_int, [C.c_void_p, C.POINTER(IndexInfo)]),

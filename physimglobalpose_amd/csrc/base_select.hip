@@ -704,6 +704,7 @@ int fill_select_args(pgp_ctx* ctx, SelectArgs* a) {
 }  // namespace
 
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys) {
+  ctx->csb_fit_m = 0;
   ctx->csb_nb = 0;   // a resident congruent batch indexes the OLD pair lists
   int rc = ppf_thresholds(ctx->ppf_tpos, ctx->ppf_tneg);
   if (rc != PGP_OK) return rc;

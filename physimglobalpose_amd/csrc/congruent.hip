@@ -742,6 +742,7 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
     set_error("rocprim::radix_sort_keys (size query) failed: %s", hipGetErrorString(he));
     return PGP_EHIP;
   }
+  ctx->csb_fit_m = 0;
   ctx->csb_nb = 0;   // the batch's sorted keys (if any) are overwritten here
   if ((rc = ctx->d_cs_keys.ensure((size_t)total * 16 + sort_bytes + 256)) != PGP_OK) return rc;
   unsigned long long* keys_in = ctx->d_cs_keys.as<unsigned long long>();
@@ -812,6 +813,7 @@ int cone_for_base(const float base[12], float* cone /*[56][3]*/) {
 // Phase 1 + 2 for all bases: leaves the sorted match keys and the per-base starts in the context.
 int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
                                 int nb, float threshold, int* h_n_quads, hipStream_t st) {
+  ctx->csb_fit_m = 0;
   ctx->csb_nb = 0;
   if (ctx->nQs <= 0 || !ctx->d_Qs.p) {
     set_error("no search model: call pgp_set_search_model first");

@@ -472,23 +472,32 @@ static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta
   uint32_t* scan_tmp = ctx->d_build_scan.as<uint32_t>();
   uint2* words = ctx->d_bitmap.as<uint2>();
   const int pb = (nP + 255) / 256;
-  PGP_HIP(hipEventRecord(ctx->ev_build0, st));
-  PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
-  hipLaunchKernelGGL((scatter_points<false, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
-                     (const uint32_t*)nullptr, (float4*)nullptr, (const uint4*)nullptr);
-  if ((rc = device_exclusive_scan(ctr, start, n_scan, scan_tmp, st)) != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[0], start + n_cells, 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
-  hipLaunchKernelGGL((scatter_points<true, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
-                     (const uint32_t*)start, ctx->d_cand.as<float4>(), (const uint4*)nullptr);
-  hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
-                     (const uint32_t*)start, words, ctr, n_words);
-  if ((rc = device_exclusive_scan(ctr, ctr, n_words + 1, scan_tmp, st)) != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[1], ctr + n_words, 4, hipMemcpyDeviceToHost, st));
-  hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
-                     (const uint32_t*)start, (const uint32_t*)ctr, words, ctx->d_occ_start.as<uint2>(), n_words, n_cells);
-  PGP_HIP(hipGetLastError());
-  PGP_HIP(hipEventRecord(ctx->ev_index, st));
+  // everything from here on is queued on the non-blocking build stream over the context's index buffers: a step that
+  // fails half way must not leave that work running beside whatever reuses (or reallocates) the buffers next
+  auto enqueue = [&]() -> int {
+    PGP_HIP(hipEventRecord(ctx->ev_build0, st));
+    PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
+    hipLaunchKernelGGL((scatter_points<false, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+                       (const uint32_t*)nullptr, (float4*)nullptr, (const uint4*)nullptr);
+    if ((rc = device_exclusive_scan(ctr, start, n_scan, scan_tmp, st)) != PGP_OK) return rc;
+    PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[0], start + n_cells, 4, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
+    hipLaunchKernelGGL((scatter_points<true, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+                       (const uint32_t*)start, ctx->d_cand.as<float4>(), (const uint4*)nullptr);
+    hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
+                       (const uint32_t*)start, words, ctr, n_words);
+    if ((rc = device_exclusive_scan(ctr, ctr, n_words + 1, scan_tmp, st)) != PGP_OK) return rc;
+    PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[1], ctr + n_words, 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
+                       (const uint32_t*)start, (const uint32_t*)ctr, words, ctx->d_occ_start.as<uint2>(), n_words, n_cells);
+    PGP_HIP(hipGetLastError());
+    PGP_HIP(hipEventRecord(ctx->ev_index, st));
+    return PGP_OK;
+  };
+  if ((rc = enqueue()) != PGP_OK) {
+    (void)hipStreamSynchronize(st);
+    return rc;
+  }
   ctx->index_pending = true;
   ctx->grid = g;
   ctx->n_cells = (long long)n_cells;

@@ -3257,6 +3257,12 @@ int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm,
   bool one_launch = n_jobs >= 2 && n_jobs <= kIcpMultiMax && a.metric == 0 && a.smooth == 0 && prm->nn_search != 1 &&
                     prm->nn_search != 2 && !getenv("PGP_ICP_NN") && !getenv("PGP_ICP_PERSIST") && !getenv("PGP_ICP_SPLIT");
   if (const char* v = getenv("PGP_ICP_MULTI")) one_launch = one_launch && atoi(v) != 0;   // A/B knob: 0 = job by job
+  // a context keeps ONE target index (d_icp_grid): two jobs with poses on the same context would have the second build
+  // overwrite -- or reallocate -- the image the first job's descriptor points to.  Such jobs run one after the other
+  // (each launch_icp builds its index in stream order behind the previous job's kernel).
+  for (int j = 0; j < n_jobs && one_launch; ++j)
+    for (int i = 0; i < j && one_launch; ++i)
+      if (jobs[i].n > 0 && jobs[j].n > 0 && jobs[i].ctx == jobs[j].ctx) one_launch = false;
   IcpMulti mt{};
   int total = 0, max_src = 0, rc;
   size_t lds = 0;

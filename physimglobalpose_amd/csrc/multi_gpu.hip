@@ -140,21 +140,48 @@ using namespace pgp;
 struct pgp_multi {
   int n = 0;
   std::vector<int> dev;
-  std::vector<pgp_ctx*> ctx;
+  // [object][member]: an object = one (scene, model) pair -- a segment of the frame and the object model it is
+  // matched against (SceneCfg.cpp:376-406 loops over them) -- replicated on every member.  Object 0 exists from
+  // pgp_multi_create on (the single-object entry points act on it); pgp_multi_add_object appends.
+  std::vector<std::vector<pgp_ctx*>> octx;
   std::vector<hipStream_t> stream;
   std::vector<Worker*> worker;
   bool use_coll = false;
-  bool emulate = false;   // PGP_MULTI_EMULATE: members share one device, exchange = emulate_allreduce
+  bool grouped = false;   // PGP_MULTI_COLL=grouped: the collective is issued for all members by the calling thread
+  bool emulate = false;   // PGP_MULTI_EMULATE: members share one device, exchange = emulate_sum
   std::vector<hipEvent_t> ev;   // emulate: one event per member
   DevBuf d_sum;                 // emulate: the summed vector before it is handed to every member
   Rccl rccl;
   std::vector<ncclComm_t> comm;
-  // per device: the full transform list and the full-length {scores | counts} vector
+  // per device: the transform list (member 0: all of it; the others: their slice, in place) and the full-length
+  // {scores | counts} vector over the FLAT (object, hypothesis) space
   std::vector<DevBuf> d_T, d_all, d_best;
-  int n_h = 0;          // hypotheses currently uploaded
+  std::vector<int> off{0, 0};   // uploaded hypotheses: object o owns flat positions off[o] .. off[o + 1] - 1
   void* h_pin = nullptr;  // portable pinned staging: transforms in, scores | counts | best out
   size_t h_pin_cap = 0;
   float last_ms[3] = {0.f, 0.f, 0.f};  // host wall clock of the last call: upload, enqueue, total
+  // ICP pose shards: per member one context per job slot (a context keeps ONE target index, icp.hip)
+  std::vector<std::vector<pgp_ctx*>> ictx;
+  // congruent sets sharded by base: per object the base boundaries of the last pgp_multi_find_congruent_batch
+  std::vector<std::vector<int>> cs_lo;
+  // emulate: the members' worker threads meet here (the exchange kernel needs every slice queued)
+  std::mutex bar_mu;
+  std::condition_variable bar_cv;
+  int bar_count = 0, bar_gen = 0;
+
+  int total() const { return off.back(); }
+  int objects() const { return (int)octx.size(); }
+  void barrier() {
+    std::unique_lock<std::mutex> lk(bar_mu);
+    const int gen = bar_gen;
+    if (++bar_count == n) {
+      bar_count = 0;
+      ++bar_gen;
+      bar_cv.notify_all();
+    } else {
+      bar_cv.wait(lk, [&] { return bar_gen != gen; });
+    }
+  }
 };
 
 namespace {
@@ -197,6 +224,239 @@ int ensure_pin(pgp_multi* m, size_t bytes) {
   return PGP_OK;
 }
 
+bool bad_object(const pgp_multi* m, int obj, const char* who) {
+  if (!m) {
+    set_error("%s: handle is NULL", who);
+    return true;
+  }
+  if (obj < 0 || obj >= m->objects()) {
+    set_error("%s: object %d of %d", who, obj, m->objects());
+    return true;
+  }
+  return false;
+}
+
+void slice_of(int n_total, int k, int n_dev, int* lo, int* hi) {
+  // contiguous slices, sizes differ by at most one, earlier devices larger (sharding.shard_bounds)
+  const int base = n_total / n_dev, rem = n_total % n_dev;
+  *lo = k * base + (k < rem ? k : rem);
+  *hi = *lo + base + (k < rem ? 1 : 0);
+}
+
+// The scoring call over whatever pgp_multi_upload[_objects] left on the devices.  scores / counts: flat, object after
+// object; best_index / best_score: one entry per object.
+int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts, int* best_index, float* best_score) {
+  const int N = m->total(), n_obj = (int)m->off.size() - 1;
+  const double t0 = now_ms();
+  int rc = ensure_pin(m, (size_t)N * 72 + (size_t)n_obj * 8 + 256);   // nothing uploaded yet: an empty batch still returns {-1, 0}
+  if (rc != PGP_OK) return rc;
+  unsigned char* pin_out = static_cast<unsigned char*>(m->h_pin) + (((size_t)N * 64 + 63) & ~(size_t)63);
+  std::vector<int> fail((size_t)m->n, 0);   // emulate: a member that failed to queue its slice (the others still meet it)
+  double t_enq = t0;
+
+  // every member: its pieces of the flat space into a zeroed full-length vector (the sum over members is the gather)
+  auto score_slice = [&](int k) -> int {
+    int lo, hi;
+    slice_of(N, k, m->n, &lo, &hi);
+    float* d_s = m->d_all[k].as<float>();
+    int* d_c = reinterpret_cast<int*>(d_s + N);
+    if (N > 0 && m->n > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)N * 8, m->stream[k]));
+    for (int o = 0; o < n_obj; ++o) {
+      const int a = std::max(lo, m->off[o]), b = std::min(hi, m->off[o + 1]);
+      if (b <= a) continue;
+      pgp_ctx* c = m->octx[o][k];
+      // the exact-records pass (pgp_set_exact_records on member 0's context) belongs to the COMPLETE vector, below;
+      // Verify's early termination depends on ALL earlier hypotheses of the object: below as well
+      const bool records = c->exact_records, early = c->verify_early_out;
+      c->exact_records = false;
+      c->verify_early_out = false;
+      const int r = pgp_score_lcp_device(c, m->d_T[k].as<float>() + 16 * (size_t)a, b - a, mode, gate_deg, d_s + a, d_c + a,
+                                         nullptr, m->stream[k]);
+      c->exact_records = records;
+      c->verify_early_out = early;
+      if (r != PGP_OK) return r;
+    }
+    return PGP_OK;
+  };
+  // member 0: per object the arg-max over its complete vector (exact under weighted near-ties), one copy back
+  auto tail = [&]() -> int {
+    float* d_s = m->d_all[0].as<float>();
+    int* d_b = m->d_best[0].as<int>();
+    hipStream_t st = m->stream[0];
+    for (int o = 0; o < n_obj; ++o) {
+      pgp_ctx* c = m->octx[o][0];
+      const int a = m->off[o], cnt = m->off[o + 1] - a;
+      const float* d_To = m->d_T[0].as<float>() + 16 * (size_t)a;
+      int r = pgp_settle_best_device(c, d_To, cnt, mode, gate_deg, d_s + a, d_b + 2 * o, st);
+      if (r != PGP_OK) return r;
+      // pgp_set_exact_records / pgp_set_verify_early_out on member 0's context of the object cover the group's calls
+      if (c->exact_records && (r = pgp_settle_records_device(c, d_To, cnt, mode, gate_deg, d_s + a, st)) != PGP_OK) return r;
+      if (c->verify_early_out && mode == PGP_MODE_PLAIN && cnt > 0 &&
+          (r = pgp_verify_early_out_device(c, d_To, cnt, d_s + a, reinterpret_cast<int*>(d_s + N) + a, st)) != PGP_OK)
+        return r;
+    }
+    t_enq = now_ms();
+    if (N > 0) PGP_HIP(hipMemcpyAsync(pin_out, d_s, (size_t)N * 8, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipMemcpyAsync(pin_out + (size_t)N * 8, d_b, (size_t)n_obj * 8, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipStreamSynchronize(st));
+    return PGP_OK;
+  };
+  // the exchange on ONE device (PGP_MULTI_EMULATE): member 0's stream waits for every slice, sums the vectors and hands
+  // the sum to every member, whose streams then wait for it
+  auto emulate_exchange = [&](int k, int rc_mine) -> int {
+    if (rc_mine == PGP_OK && hipEventRecord(m->ev[k], m->stream[k]) != hipSuccess) rc_mine = PGP_EHIP;
+    fail[(size_t)k] = rc_mine != PGP_OK;
+    m->barrier();
+    bool any = false;
+    for (int f : fail) any = any || f;
+    int r = PGP_OK;
+    if (k == 0 && !any) {
+      r = [&]() -> int {
+        hipStream_t st = m->stream[0];
+        int q;
+        if ((q = m->d_sum.ensure((size_t)N * 8 + (size_t)m->n * sizeof(float*) + 64)) != PGP_OK) return q;
+        float* d_out = m->d_sum.as<float>();
+        const float** d_ptrs = reinterpret_cast<const float**>(m->d_sum.as<unsigned char>() + (((size_t)N * 8 + 15) & ~(size_t)15));
+        std::vector<const float*> ptrs((size_t)m->n);
+        for (int j = 0; j < m->n; ++j) {
+          ptrs[(size_t)j] = m->d_all[j].as<float>();
+          if (j > 0) PGP_HIP(hipStreamWaitEvent(st, m->ev[j], 0));
+        }
+        PGP_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), (size_t)m->n * sizeof(float*), hipMemcpyHostToDevice, st));
+        PGP_HIP(hipStreamSynchronize(st));   // ptrs is a stack temporary
+        hipLaunchKernelGGL(emulate_sum, dim3((2 * N + 255) / 256), dim3(256), 0, st, d_ptrs, m->n, N, d_out);
+        PGP_HIP(hipGetLastError());
+        for (int j = 0; j < m->n; ++j)
+          PGP_HIP(hipMemcpyAsync(m->d_all[j].p, d_out, (size_t)N * 8, hipMemcpyDeviceToDevice, st));
+        PGP_HIP(hipEventRecord(m->ev[0], st));
+        return PGP_OK;
+      }();
+      fail[0] = r != PGP_OK;
+    }
+    m->barrier();
+    if (rc_mine != PGP_OK) return rc_mine;
+    if (r != PGP_OK) return r;
+    if (any || fail[0]) {
+      set_error("another member of the group failed");
+      return PGP_EHIP;
+    }
+    if (k > 0) PGP_HIP(hipStreamWaitEvent(m->stream[k], m->ev[0], 0));
+    return PGP_OK;
+  };
+  // ONE all-reduce per call over the 8 N bytes {scores | counts}, summed as 32-bit integers: every element is non-zero
+  // on exactly one member (its owner) and all-zero bits elsewhere, and x + 0 + ... + 0 over the BIT PATTERNS returns
+  // x's pattern -- exact for the float scores too (scores are >= +0: no -0, no NaN).  At 4096 hypotheses the exchange is
+  // latency-bound (32 KB per member), so two collectives cost twice what one does.
+  auto own_allreduce = [&](int k) -> int {
+    float* d_s = m->d_all[k].as<float>();
+    const ncclResult_t nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)N, ncclInt32, ncclSum, m->comm[k], m->stream[k]);
+    if (nr != ncclSuccess) {
+      set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
+      return PGP_EHIP;
+    }
+    return PGP_OK;
+  };
+
+  const bool exchange = m->n > 1 || m->use_coll;
+  if (m->emulate && m->n > 1 && N > 0) {
+    rc = run_all(m, [&](int k) -> int {
+      int r = emulate_exchange(k, score_slice(k));
+      if (r == PGP_OK && k == 0) r = tail();
+      return r;
+    });
+  } else if (exchange && m->use_coll && !m->emulate && N > 0 && !m->grouped) {
+    // default: every member's worker thread queues its slice, its own all-reduce call (one communicator per device, the
+    // multi-thread form RCCL documents) and, on member 0, the tail -- ONE rendezvous of the calling thread per call.
+    // A member whose slice failed to queue still joins the collective: the others' streams would wait for it forever.
+    rc = run_all(m, [&](int k) -> int {
+      const int r1 = score_slice(k);
+      const int r2 = own_allreduce(k);
+      if (r1 != PGP_OK) return r1;
+      if (r2 != PGP_OK) return r2;
+      return k == 0 ? tail() : PGP_OK;
+    });
+  } else {
+    // PGP_MULTI_COLL=grouped (and the single-member group without a collective): slices, then the collective for all
+    // members from the calling thread inside one group, then the tail
+    rc = run_all(m, score_slice);
+    if (rc != PGP_OK) return rc;
+    if (m->use_coll && !m->emulate && N > 0) {
+      ncclResult_t nr = m->rccl.GroupStart();
+      for (int k = 0; k < m->n && nr == ncclSuccess; ++k) {
+        float* d_s = m->d_all[k].as<float>();
+        nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)N, ncclInt32, ncclSum, m->comm[k], m->stream[k]);
+      }
+      ncclResult_t ge = m->rccl.GroupEnd();
+      if (nr == ncclSuccess) nr = ge;
+      if (nr != ncclSuccess) {
+        set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
+        return PGP_EHIP;
+      }
+    }
+    Worker* w0 = m->worker[0];
+    w0->post(tail);
+    rc = w0->wait();
+    if (rc != PGP_OK) set_error("device %d: %s", m->dev[0], w0->err);
+  }
+  if (rc != PGP_OK) return rc;
+  if (N > 0) {
+    if (scores) std::memcpy(scores, pin_out, (size_t)N * 4);
+    if (counts) std::memcpy(counts, pin_out + (size_t)N * 4, (size_t)N * 4);
+  }
+  for (int o = 0; o < n_obj; ++o) {
+    int best[2];
+    std::memcpy(best, pin_out + (size_t)N * 8 + (size_t)o * 8, sizeof best);
+    if (best_index) best_index[o] = best[0];
+    if (best_score) std::memcpy(best_score + o, &best[1], 4);
+  }
+  m->last_ms[1] = (float)(t_enq - t0);
+  m->last_ms[2] = (float)(now_ms() - t0);
+  return PGP_OK;
+}
+
+// transforms of n_obj objects -> pinned image -> devices; sets m->off
+int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) {
+  std::vector<int> off((size_t)n_obj + 1, 0);
+  for (int o = 0; o < n_obj; ++o) {
+    if (n_h[o] < 0 || (n_h[o] > 0 && !T[o])) {
+      set_error("pgp_multi upload: bad hypothesis list of object %d", o);
+      return PGP_EINVAL;
+    }
+    if ((long long)off[o] + n_h[o] > 0x3FFFFFFF) {
+      set_error("pgp_multi upload: more than 2^30 hypotheses");
+      return PGP_EINVAL;
+    }
+    off[o + 1] = off[o] + n_h[o];
+  }
+  const int N = off[n_obj];
+  const size_t nT = (size_t)N * 64;
+  int rc = ensure_pin(m, nT + (size_t)N * 8 + (size_t)n_obj * 8 + 256);
+  if (rc != PGP_OK) return rc;
+  for (int o = 0; o < n_obj; ++o)
+    if (n_h[o]) std::memcpy(static_cast<unsigned char*>(m->h_pin) + (size_t)off[o] * 64, T[o], (size_t)n_h[o] * 64);
+  m->off = off;
+  return run_all(m, [m, nT, N, n_obj](int k) -> int {
+    int lo, hi, r;
+    slice_of(N, k, m->n, &lo, &hi);
+    if ((r = m->d_T[k].ensure(nT)) != PGP_OK) return r;
+    if ((r = m->d_all[k].ensure((size_t)N * 8)) != PGP_OK) return r;
+    if ((r = m->d_best[k].ensure((size_t)n_obj * 8 + 16)) != PGP_OK) return r;
+    for (int o = 0; o < n_obj; ++o) {
+      // member 0 also works on every object's complete vector (settlement, exact records, Verify's early termination)
+      const int a = std::max(lo, m->off[o]), b = std::min(hi, m->off[o + 1]);
+      const int need = k == 0 ? m->off[o + 1] - m->off[o] : std::max(b - a, 0);
+      if ((r = pgp_reserve(m->octx[o][k], need)) != PGP_OK) return r;
+    }
+    // member 0 holds ALL transforms (it settles near-ties across slices); the others copy their slice only, to the
+    // place it has in the flat list (64 B per hypothesis: 4 MB at 65 536 -- every device over its own PCIe link)
+    const size_t a = k == 0 ? 0 : (size_t)lo * 64, b = k == 0 ? nT : (size_t)hi * 64;
+    if (b > a)
+      PGP_HIP(hipMemcpyAsync(m->d_T[k].as<unsigned char>() + a, static_cast<unsigned char*>(m->h_pin) + a, b - a,
+                             hipMemcpyHostToDevice, m->stream[k]));
+    return PGP_OK;
+  });
+}
+
 }  // namespace
 
 extern "C" {
@@ -206,10 +466,40 @@ int pgp_multi_slice(int n_total, int k, int n_dev, int* lo, int* hi) {
     set_error("pgp_multi_slice: bad argument");
     return PGP_EINVAL;
   }
-  // contiguous slices, sizes differ by at most one, earlier devices larger (sharding.shard_bounds)
-  const int base = n_total / n_dev, rem = n_total % n_dev;
-  *lo = k * base + (k < rem ? k : rem);
-  *hi = *lo + base + (k < rem ? 1 : 0);
+  slice_of(n_total, k, n_dev, lo, hi);
+  return PGP_OK;
+}
+
+int pgp_multi_flat_slices(const int* n_h, int n_obj, int k, int n_dev, int* obj, int* lo, int* hi, int* n_pieces) {
+  if (n_obj < 0 || (n_obj > 0 && (!n_h || !obj || !lo || !hi)) || n_dev <= 0 || k < 0 || k >= n_dev || !n_pieces) {
+    set_error("pgp_multi_flat_slices: bad argument");
+    return PGP_EINVAL;
+  }
+  long long total = 0;
+  for (int o = 0; o < n_obj; ++o) {
+    if (n_h[o] < 0) {
+      set_error("pgp_multi_flat_slices: negative count");
+      return PGP_EINVAL;
+    }
+    total += n_h[o];
+  }
+  if (total > 0x3FFFFFFF) {
+    set_error("pgp_multi_flat_slices: more than 2^30 units");
+    return PGP_EINVAL;
+  }
+  int a, b, base = 0, np = 0;
+  slice_of((int)total, k, n_dev, &a, &b);
+  for (int o = 0; o < n_obj; ++o) {
+    const int x = std::max(a, base), y = std::min(b, base + n_h[o]);
+    if (y > x) {
+      obj[np] = o;
+      lo[np] = x - base;
+      hi[np] = y - base;
+      ++np;
+    }
+    base += n_h[o];
+  }
+  *n_pieces = np;
   return PGP_OK;
 }
 
@@ -248,7 +538,9 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
       }
     m->dev.push_back(d);
   }
-  m->ctx.assign(n_dev, nullptr);
+  m->octx.assign(1, std::vector<pgp_ctx*>((size_t)n_dev, nullptr));
+  m->cs_lo.assign(1, std::vector<int>());
+  m->ictx.assign((size_t)n_dev, std::vector<pgp_ctx*>());
   m->stream.assign(n_dev, nullptr);
   m->d_T.resize(n_dev);
   m->d_all.resize(n_dev);
@@ -261,13 +553,14 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
     m->worker.push_back(w);
   }
   rc = run_all(m, [m](int k) -> int {
-    int r = pgp_create(&m->ctx[k], m->dev[k]);
+    int r = pgp_create(&m->octx[0][k], m->dev[k]);
     if (r != PGP_OK) return r;
     PGP_HIP(hipStreamCreateWithFlags(&m->stream[k], hipStreamNonBlocking));
     return m->d_best[k].ensure(16);
   });
   const char* force = getenv("PGP_MULTI_FORCE_COLLECTIVE");
   m->use_coll = n_dev > 1 || (force && atoi(force) != 0);
+  if (const char* v = getenv("PGP_MULTI_COLL")) m->grouped = std::strcmp(v, "grouped") == 0;
   if (rc == PGP_OK && m->emulate) {
     m->ev.assign(n_dev, nullptr);
     rc = run_all(m, [m](int k) -> int {
@@ -301,7 +594,8 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
 
 int pgp_multi_destroy(pgp_multi* m) {
   if (!m) return PGP_OK;
-  if (!m->worker.empty() && (int)m->worker.size() == m->n) {
+  const bool workers = !m->worker.empty() && (int)m->worker.size() == m->n;
+  if (workers) {
     run_all(m, [m](int k) -> int {
       if (m->stream[k]) (void)hipStreamSynchronize(m->stream[k]);
       return PGP_OK;
@@ -309,7 +603,7 @@ int pgp_multi_destroy(pgp_multi* m) {
   }
   for (ncclComm_t c : m->comm)
     if (c) m->rccl.CommDestroy(c);
-  if (!m->worker.empty() && (int)m->worker.size() == m->n) {
+  if (workers) {
     run_all(m, [m](int k) -> int {
       m->d_T[k].release();
       m->d_all[k].release();
@@ -317,7 +611,10 @@ int pgp_multi_destroy(pgp_multi* m) {
       if (k < (int)m->ev.size() && m->ev[k]) (void)hipEventDestroy(m->ev[k]);
       if (k == 0) m->d_sum.release();
       if (m->stream[k]) (void)hipStreamDestroy(m->stream[k]);
-      if (m->ctx[k]) pgp_destroy(m->ctx[k]);
+      for (auto& per_obj : m->octx)
+        if (per_obj[(size_t)k]) pgp_destroy(per_obj[(size_t)k]);
+      for (pgp_ctx* c : m->ictx[(size_t)k])
+        if (c) pgp_destroy(c);
       return PGP_OK;
     });
   }
@@ -338,30 +635,73 @@ int pgp_multi_destroy(pgp_multi* m) {
 
 int pgp_multi_size(const pgp_multi* m) { return m ? m->n : 0; }
 
-pgp_ctx* pgp_multi_context(pgp_multi* m, int k) { return (m && k >= 0 && k < m->n) ? m->ctx[k] : nullptr; }
+pgp_ctx* pgp_multi_context(pgp_multi* m, int k) { return (m && k >= 0 && k < m->n) ? m->octx[0][(size_t)k] : nullptr; }
 
-int pgp_multi_set_scene(pgp_multi* m, const float* xyz, const float* nrm, const float* weight, int n, float delta) {
+int pgp_multi_add_object(pgp_multi* m) {
   if (!m) {
-    set_error("pgp_multi_set_scene: handle is NULL");
+    set_error("pgp_multi_add_object: handle is NULL");
     return PGP_EINVAL;
   }
-  return run_all(m, [=](int k) -> int { return pgp_set_scene(m->ctx[k], xyz, nrm, weight, n, delta); });
+  const int o = m->objects();
+  m->octx.emplace_back((size_t)m->n, nullptr);
+  m->cs_lo.emplace_back();
+  const int rc = run_all(m, [m, o](int k) -> int { return pgp_create(&m->octx[(size_t)o][(size_t)k], m->dev[k]); });
+  if (rc != PGP_OK) {
+    run_all(m, [m, o](int k) -> int {
+      if (m->octx[(size_t)o][(size_t)k]) pgp_destroy(m->octx[(size_t)o][(size_t)k]);
+      return PGP_OK;
+    });
+    m->octx.pop_back();
+    m->cs_lo.pop_back();
+    return rc;
+  }
+  return o;
+}
+
+int pgp_multi_objects(const pgp_multi* m) { return m ? m->objects() : 0; }
+
+pgp_ctx* pgp_multi_object_context(pgp_multi* m, int obj, int k) {
+  return (m && obj >= 0 && obj < m->objects() && k >= 0 && k < m->n) ? m->octx[(size_t)obj][(size_t)k] : nullptr;
+}
+
+int pgp_multi_set_object_scene(pgp_multi* m, int obj, const float* xyz, const float* nrm, const float* weight, int n,
+                               float delta) {
+  if (bad_object(m, obj, "pgp_multi_set_object_scene")) return PGP_EINVAL;
+  return run_all(m, [=](int k) -> int { return pgp_set_scene(m->octx[(size_t)obj][(size_t)k], xyz, nrm, weight, n, delta); });
+}
+
+int pgp_multi_set_object_scene_weights(pgp_multi* m, int obj, const float* weight, int n) {
+  if (bad_object(m, obj, "pgp_multi_set_object_scene_weights")) return PGP_EINVAL;
+  return run_all(m, [=](int k) -> int { return pgp_set_scene_weights(m->octx[(size_t)obj][(size_t)k], weight, n); });
+}
+
+int pgp_multi_set_object_model(pgp_multi* m, int obj, const float* xyz, const float* nrm, int n) {
+  if (bad_object(m, obj, "pgp_multi_set_object_model")) return PGP_EINVAL;
+  return run_all(m, [=](int k) -> int { return pgp_set_model(m->octx[(size_t)obj][(size_t)k], xyz, nrm, n); });
+}
+
+int pgp_multi_set_object_search_model(pgp_multi* m, int obj, const float* xyz, int n) {
+  if (bad_object(m, obj, "pgp_multi_set_object_search_model")) return PGP_EINVAL;
+  m->cs_lo[(size_t)obj].clear();
+  return run_all(m, [=](int k) -> int { return pgp_set_search_model(m->octx[(size_t)obj][(size_t)k], xyz, n); });
+}
+
+int pgp_multi_set_object_ppf_map(pgp_multi* m, int obj, const int* keys, const int* counts, const int* pairs, int n_keys) {
+  if (bad_object(m, obj, "pgp_multi_set_object_ppf_map")) return PGP_EINVAL;
+  m->cs_lo[(size_t)obj].clear();
+  return run_all(m, [=](int k) -> int { return pgp_set_ppf_map(m->octx[(size_t)obj][(size_t)k], keys, counts, pairs, n_keys); });
+}
+
+int pgp_multi_set_scene(pgp_multi* m, const float* xyz, const float* nrm, const float* weight, int n, float delta) {
+  return pgp_multi_set_object_scene(m, 0, xyz, nrm, weight, n, delta);
 }
 
 int pgp_multi_set_scene_weights(pgp_multi* m, const float* weight, int n) {
-  if (!m) {
-    set_error("pgp_multi_set_scene_weights: handle is NULL");
-    return PGP_EINVAL;
-  }
-  return run_all(m, [=](int k) -> int { return pgp_set_scene_weights(m->ctx[k], weight, n); });
+  return pgp_multi_set_object_scene_weights(m, 0, weight, n);
 }
 
 int pgp_multi_set_model(pgp_multi* m, const float* xyz, const float* nrm, int n) {
-  if (!m) {
-    set_error("pgp_multi_set_model: handle is NULL");
-    return PGP_EINVAL;
-  }
-  return run_all(m, [=](int k) -> int { return pgp_set_model(m->ctx[k], xyz, nrm, n); });
+  return pgp_multi_set_object_model(m, 0, xyz, nrm, n);
 }
 
 int pgp_multi_upload(pgp_multi* m, const float* T, int n_h) {
@@ -369,24 +709,15 @@ int pgp_multi_upload(pgp_multi* m, const float* T, int n_h) {
     set_error("pgp_multi_upload: bad argument");
     return PGP_EINVAL;
   }
-  const size_t nT = (size_t)n_h * 64;
-  int rc = ensure_pin(m, nT + (size_t)n_h * 8 + 64);
-  if (rc != PGP_OK) return rc;
-  if (nT) std::memcpy(m->h_pin, T, nT);
-  m->n_h = n_h;
-  return run_all(m, [m, nT, n_h](int k) -> int {
-    int lo, hi;
-    pgp_multi_slice(n_h, k, m->n, &lo, &hi);
-    int r;
-    if ((r = m->d_T[k].ensure(nT)) != PGP_OK) return r;
-    if ((r = m->d_all[k].ensure((size_t)n_h * 8)) != PGP_OK) return r;
-    // member 0 also works on the complete vector (settlement, exact records, Verify's early termination)
-    if ((r = pgp_reserve(m->ctx[k], k == 0 ? n_h : hi - lo)) != PGP_OK) return r;
-    // every device holds ALL transforms: device 0 needs them to settle near-ties across slices
-    // (64 B per hypothesis: 4 MB at 65 536 -- each device pulls its copy over its own PCIe link)
-    if (nT) PGP_HIP(hipMemcpyAsync(m->d_T[k].p, m->h_pin, nT, hipMemcpyHostToDevice, m->stream[k]));
-    return PGP_OK;
-  });
+  return upload_flat(m, &T, &n_h, 1);
+}
+
+int pgp_multi_upload_objects(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) {
+  if (!m || n_obj < 1 || n_obj > m->objects() || !T || !n_h) {
+    set_error("pgp_multi_upload_objects: bad argument (%d lists for %d objects)", n_obj, m ? m->objects() : 0);
+    return PGP_EINVAL;
+  }
+  return upload_flat(m, T, n_h, n_obj);
 }
 
 int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts,
@@ -395,122 +726,21 @@ int pgp_multi_score_uploaded(pgp_multi* m, int mode, float gate_deg, float* scor
     set_error("pgp_multi_score_uploaded: handle is NULL");
     return PGP_EINVAL;
   }
-  const int n_h = m->n_h;
-  const double t0 = now_ms();
-  int rc = ensure_pin(m, 64);   // nothing uploaded yet: the empty batch still returns {-1, 0}
-  if (rc != PGP_OK) return rc;
-  rc = run_all(m, [m, mode, gate_deg, n_h](int k) -> int {
-    int lo, hi;
-    pgp_multi_slice(n_h, k, m->n, &lo, &hi);
-    float* d_s = m->d_all[k].as<float>();
-    int* d_c = reinterpret_cast<int*>(d_s + n_h);
-    // every device fills only its slice of a zeroed vector: the sum over devices is the gather
-    if (n_h > 0 && m->n > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)n_h * 8, m->stream[k]));
-    // the exact-records pass (pgp_set_exact_records on member 0's context) belongs to the COMPLETE vector,
-    // below; running it on member 0's slice as well would only repeat three launches
-    const bool records = m->ctx[k]->exact_records, early = m->ctx[k]->verify_early_out;
-    m->ctx[k]->exact_records = false;
-    m->ctx[k]->verify_early_out = false;   // Verify's early termination depends on ALL earlier hypotheses: below
-    const int r = pgp_score_lcp_device(m->ctx[k], m->d_T[k].as<float>() + 16 * (size_t)lo, hi - lo, mode, gate_deg,
-                                       d_s + lo, d_c + lo, nullptr, m->stream[k]);
-    m->ctx[k]->exact_records = records;
-    m->ctx[k]->verify_early_out = early;
-    if (r == PGP_OK && m->emulate) PGP_HIP(hipEventRecord(m->ev[k], m->stream[k]));
-    return r;
-  });
-  if (rc != PGP_OK) return rc;
-  if (m->emulate && m->n > 1 && n_h > 0) {
-    // the all-reduce on one device: member 0's stream waits for every slice, sums the vectors, and hands
-    // the sum to every member (whose streams then wait for it)
-    Worker* w0 = m->worker[0];
-    w0->post([m, n_h]() -> int {
-      hipStream_t st = m->stream[0];
-      int r;
-      if ((r = m->d_sum.ensure((size_t)n_h * 8 + (size_t)m->n * sizeof(float*) + 64)) != PGP_OK) return r;
-      float* d_out = m->d_sum.as<float>();
-      const float** d_ptrs = reinterpret_cast<const float**>(m->d_sum.as<unsigned char>() + (((size_t)n_h * 8 + 15) & ~(size_t)15));
-      std::vector<const float*> ptrs(m->n);
-      for (int k = 0; k < m->n; ++k) {
-        ptrs[k] = m->d_all[k].as<float>();
-        if (k > 0) PGP_HIP(hipStreamWaitEvent(st, m->ev[k], 0));
-      }
-      PGP_HIP(hipMemcpyAsync(d_ptrs, ptrs.data(), (size_t)m->n * sizeof(float*), hipMemcpyHostToDevice, st));
-      PGP_HIP(hipStreamSynchronize(st));   // ptrs is a stack temporary
-      hipLaunchKernelGGL(emulate_sum, dim3((2 * n_h + 255) / 256), dim3(256), 0, st, d_ptrs, m->n, n_h, d_out);
-      PGP_HIP(hipGetLastError());
-      for (int k = 0; k < m->n; ++k)
-        PGP_HIP(hipMemcpyAsync(m->d_all[k].p, d_out, (size_t)n_h * 8, hipMemcpyDeviceToDevice, st));
-      PGP_HIP(hipEventRecord(m->ev[0], st));
-      return PGP_OK;
-    });
-    rc = w0->wait();
-    if (rc != PGP_OK) {
-      set_error("device %d: %s", m->dev[0], w0->err);
-      return rc;
-    }
-    rc = run_all(m, [m](int k) -> int {
-      if (k > 0) PGP_HIP(hipStreamWaitEvent(m->stream[k], m->ev[0], 0));
-      return PGP_OK;
-    });
-    if (rc != PGP_OK) return rc;
-  } else if (m->use_coll && n_h > 0) {
-    // ONE all-reduce per call over the 8 n_h bytes {scores | counts}, summed as 32-bit integers: every element is
-    // non-zero on exactly one member (its owner) and all-zero bits elsewhere, and x + 0 + ... + 0 over the BIT
-    // PATTERNS returns x's pattern -- exact for the float scores too (scores are >= +0: no -0, no NaN).  At 4096
-    // hypotheses the exchange is latency-bound (32 KB per member), so two collectives cost twice what one does.
-    ncclResult_t nr = m->rccl.GroupStart();
-    for (int k = 0; k < m->n && nr == ncclSuccess; ++k) {
-      float* d_s = m->d_all[k].as<float>();
-      nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)n_h, ncclInt32, ncclSum, m->comm[k], m->stream[k]);
-    }
-    ncclResult_t ge = m->rccl.GroupEnd();
-    if (nr == ncclSuccess) nr = ge;
-    if (nr != ncclSuccess) {
-      set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
-      return PGP_EHIP;
-    }
+  if (m->off.size() != 2) {
+    set_error("pgp_multi_score_uploaded: the resident batch belongs to %d objects (pgp_multi_score_objects_uploaded)",
+              (int)m->off.size() - 1);
+    return PGP_ESTATE;
   }
-  const double t1 = now_ms();
-  // device 0: arg-max over the complete vector (exact under weighted near-ties), one copy back
-  unsigned char* pin_out = static_cast<unsigned char*>(m->h_pin) + (((size_t)n_h * 64 + 63) & ~(size_t)63);
-  Worker* w0 = m->worker[0];
-  w0->post([m, mode, gate_deg, n_h, pin_out]() -> int {
-    float* d_s = m->d_all[0].as<float>();
-    int* d_b = m->d_best[0].as<int>();
-    hipStream_t st = m->stream[0];
-    int r = pgp_settle_best_device(m->ctx[0], m->d_T[0].as<float>(), n_h, mode, gate_deg, d_s, d_b, st);
-    if (r != PGP_OK) return r;
-    // pgp_set_exact_records on device 0's context (pgp_multi_context(m, 0)) covers the group's calls too
-    if (m->ctx[0]->exact_records) {
-      r = pgp_settle_records_device(m->ctx[0], m->d_T[0].as<float>(), n_h, mode, gate_deg, d_s, st);
-      if (r != PGP_OK) return r;
-    }
-    // pgp_set_verify_early_out on member 0's context: applied to the complete vector of true counts
-    if (m->ctx[0]->verify_early_out && mode == PGP_MODE_PLAIN && n_h > 0) {
-      r = pgp_verify_early_out_device(m->ctx[0], m->d_T[0].as<float>(), n_h, d_s, reinterpret_cast<int*>(d_s + n_h), st);
-      if (r != PGP_OK) return r;
-    }
-    if (n_h > 0) PGP_HIP(hipMemcpyAsync(pin_out, d_s, (size_t)n_h * 8, hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipMemcpyAsync(pin_out + (size_t)n_h * 8, d_b, 8, hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipStreamSynchronize(st));
-    return PGP_OK;
-  });
-  rc = w0->wait();
-  if (rc != PGP_OK) {
-    set_error("device %d: %s", m->dev[0], w0->err);
-    return rc;
+  return score_flat(m, mode, gate_deg, scores, counts, best_index, best_score);
+}
+
+int pgp_multi_score_objects_uploaded(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts, int* best_index,
+                                     float* best_score) {
+  if (!m) {
+    set_error("pgp_multi_score_objects_uploaded: handle is NULL");
+    return PGP_EINVAL;
   }
-  if (n_h > 0) {
-    if (scores) std::memcpy(scores, pin_out, (size_t)n_h * 4);
-    if (counts) std::memcpy(counts, pin_out + (size_t)n_h * 4, (size_t)n_h * 4);
-  }
-  int best[2];
-  std::memcpy(best, pin_out + (size_t)n_h * 8, sizeof best);
-  if (best_index) *best_index = best[0];
-  if (best_score) std::memcpy(best_score, &best[1], 4);
-  m->last_ms[1] = (float)(t1 - t0);
-  m->last_ms[2] = (float)(now_ms() - t0);
-  return PGP_OK;
+  return score_flat(m, mode, gate_deg, scores, counts, best_index, best_score);
 }
 
 int pgp_multi_score_lcp(pgp_multi* m, const float* T, int n_h, int mode, float gate_deg, float* scores,
@@ -528,6 +758,25 @@ int pgp_multi_score_lcp(pgp_multi* m, const float* T, int n_h, int mode, float g
   return rc;
 }
 
+int pgp_multi_score_objects(pgp_multi* m, const float* const* T, const int* n_h, int n_obj, int mode, float gate_deg,
+                            float* scores, int* counts, int* best_index, float* best_score) {
+  if (!m || n_obj < 1 || !T || !n_h) {
+    set_error("pgp_multi_score_objects: bad argument");
+    return PGP_EINVAL;
+  }
+  const double t0 = now_ms();
+  int rc = pgp_multi_upload_objects(m, T, n_h, n_obj);
+  if (rc != PGP_OK) return rc;
+  if (m->total() > 0 && !scores) {
+    set_error("pgp_multi_score_objects: scores is NULL");
+    return PGP_EINVAL;
+  }
+  const float up = (float)(now_ms() - t0);
+  rc = score_flat(m, mode, gate_deg, scores, counts, best_index, best_score);
+  m->last_ms[0] = up;
+  return rc;
+}
+
 int pgp_multi_last_timing(pgp_multi* m, float* upload_ms, float* enqueue_ms, float* total_ms) {
   if (!m) {
     set_error("pgp_multi_last_timing: handle is NULL");
@@ -537,6 +786,178 @@ int pgp_multi_last_timing(pgp_multi* m, float* upload_ms, float* enqueue_ms, flo
   if (enqueue_ms) *enqueue_ms = m->last_ms[1];
   if (total_ms) *total_ms = m->last_ms[2];
   return PGP_OK;
+}
+
+// ---- ICP: the poses to refine, sharded like the hypotheses (UCTSearch.cpp:200-266 -> UCTState.cpp:121-204) ----
+int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs, const pgp_icp_params* params) {
+  if (!m || n_jobs < 0 || (n_jobs > 0 && !jobs) || !params) {
+    set_error("pgp_multi_icp_refine: bad argument");
+    return PGP_EINVAL;
+  }
+  std::vector<int> cnt((size_t)n_jobs, 0);
+  for (int j = 0; j < n_jobs; ++j) {
+    const pgp_multi_icp_job& q = jobs[j];
+    if (q.n < 0 || q.n_src < 0 || q.n_tgt < 0 || (q.n > 0 && (!q.T || !q.src_xyz || !q.tgt_xyz || q.n_src == 0 || q.n_tgt == 0))) {
+      set_error("pgp_multi_icp_refine: bad job %d", j);
+      return PGP_EINVAL;
+    }
+    cnt[(size_t)j] = q.n;
+  }
+  if (n_jobs == 0) return PGP_OK;
+  const pgp_icp_options opt = icp_options_of(params);
+  return run_all(m, [&, m](int k) -> int {
+    // this member's share of the flat (job, pose) space: pieces (job, lo, hi)
+    std::vector<int> pj((size_t)n_jobs), plo((size_t)n_jobs), phi((size_t)n_jobs);
+    int np = 0, r;
+    if ((r = pgp_multi_flat_slices(cnt.data(), n_jobs, k, m->n, pj.data(), plo.data(), phi.data(), &np)) != PGP_OK) return r;
+    if (np == 0) return PGP_OK;
+    hipStream_t st = m->stream[k];
+    std::vector<pgp_ctx*>& pool = m->ictx[(size_t)k];
+    while ((int)pool.size() < n_jobs) {   // job j's target index lives in the member's context j, from call to call
+      pgp_ctx* c = nullptr;
+      if ((r = pgp_create(&c, m->dev[k])) != PGP_OK) return r;
+      pool.push_back(c);
+    }
+    std::vector<IcpHostStage> stage((size_t)np);
+    std::vector<IcpJob> dj((size_t)np);
+    for (int p = 0; p < np; ++p) {
+      const pgp_multi_icp_job& q = jobs[pj[(size_t)p]];
+      pgp_ctx* c = pool[(size_t)pj[(size_t)p]];
+      const int n = phi[(size_t)p] - plo[(size_t)p];
+      if ((r = icp_host_stage(c, q.src_xyz, q.n_src, q.tgt_xyz, q.n_tgt, q.T + 16 * (size_t)plo[(size_t)p], n, st, &stage[(size_t)p])) != PGP_OK)
+        return r;
+      const IcpHostStage& g = stage[(size_t)p];
+      dj[(size_t)p] = IcpJob{c, g.d_src, q.n_src, g.d_tgt, q.n_tgt, g.d_T, n, g.d_energy, g.d_iters, g.token};
+    }
+    // ONE launch for the member's pieces (pgp_icp_refine_multi_device; a single piece is the plain call)
+    if (np == 1)
+      r = launch_icp(dj[0].ctx, dj[0].d_src, dj[0].n_src, dj[0].d_tgt, nullptr, dj[0].n_tgt, dj[0].d_T, dj[0].n, &opt,
+                     dj[0].d_energy, dj[0].d_iters, st, dj[0].token);
+    else
+      r = launch_icp_multi(dj.data(), np, &opt, st);
+    if (r != PGP_OK) return r;
+    for (int p = 0; p < np; ++p)
+      if ((r = icp_host_collect_enqueue(dj[(size_t)p].ctx, stage[(size_t)p], st)) != PGP_OK) return r;
+    PGP_HIP(hipStreamSynchronize(st));
+    // the gather: every member writes its poses' results into the caller's arrays (disjoint ranges, no collective)
+    for (int p = 0; p < np; ++p) {
+      const pgp_multi_icp_job& q = jobs[pj[(size_t)p]];
+      const size_t lo = (size_t)plo[(size_t)p];
+      icp_host_collect(dj[(size_t)p].ctx, stage[(size_t)p], dj[(size_t)p].n, q.T + 16 * lo, q.energy ? q.energy + lo : nullptr,
+                       q.iters ? q.iters + lo : nullptr);
+    }
+    return PGP_OK;
+  });
+}
+
+// ---- congruent sets: the bases of an object sharded over the members (base.cc:1855-1874) ----
+int pgp_multi_find_congruent_batch(pgp_multi* m, int obj, const int* base_ids, const float* base_xyz, const float* invariants,
+                                   int n_bases, float threshold, int* n_quads) {
+  if (bad_object(m, obj, "pgp_multi_find_congruent_batch")) return PGP_EINVAL;
+  if (n_bases < 0 || (n_bases > 0 && (!base_ids || !base_xyz || !invariants || !n_quads))) {
+    set_error("pgp_multi_find_congruent_batch: bad argument");
+    return PGP_EINVAL;
+  }
+  std::vector<int>& lo = m->cs_lo[(size_t)obj];
+  lo.assign((size_t)m->n + 1, 0);
+  for (int k = 0; k < m->n; ++k) {
+    int a, b;
+    slice_of(n_bases, k, m->n, &a, &b);
+    lo[(size_t)k] = a;
+    lo[(size_t)k + 1] = b;
+  }
+  const int rc = run_all(m, [=, &lo](int k) -> int {
+    const int a = lo[(size_t)k], b = lo[(size_t)k + 1];
+    // (a member without bases still runs the call: it leaves an empty batch behind, as a single context would)
+    return pgp_find_congruent_batch(m->octx[(size_t)obj][(size_t)k], base_ids + 4 * (size_t)a, base_xyz + 12 * (size_t)a,
+                                    invariants + 2 * (size_t)a, b - a, threshold, n_quads + a);
+  });
+  if (rc != PGP_OK) lo.clear();
+  return rc;
+}
+
+namespace {
+// picks (base, j) -> the member that owns the base, with the base renumbered inside that member's batch
+int route_picks(pgp_multi* m, int obj, const int* picks, int cnt, const char* who, std::vector<std::vector<int>>* where,
+                std::vector<std::vector<int>>* local) {
+  const std::vector<int>& lo = m->cs_lo[(size_t)obj];
+  if (lo.size() != (size_t)m->n + 1) {
+    set_error("%s: no congruent batch resident for object %d (pgp_multi_find_congruent_batch)", who, obj);
+    return PGP_ESTATE;
+  }
+  where->assign((size_t)m->n, {});
+  local->assign((size_t)m->n, {});
+  for (int i = 0; i < cnt; ++i) {
+    const int b = picks[2 * (size_t)i];
+    if (b < 0 || b >= lo[(size_t)m->n]) {
+      set_error("%s: pick %d names base %d of %d", who, i, b, lo[(size_t)m->n]);
+      return PGP_EINVAL;
+    }
+    int k = 0;
+    while (b >= lo[(size_t)k + 1]) ++k;
+    (*where)[(size_t)k].push_back(i);
+    (*local)[(size_t)k].push_back(b - lo[(size_t)k]);
+    (*local)[(size_t)k].push_back(picks[2 * (size_t)i + 1]);
+  }
+  return PGP_OK;
+}
+}  // namespace
+
+int pgp_multi_congruent_batch_quads(pgp_multi* m, int obj, const int* picks, int cnt, int* quads) {
+  if (bad_object(m, obj, "pgp_multi_congruent_batch_quads")) return PGP_EINVAL;
+  if (cnt < 0 || (cnt > 0 && (!picks || !quads))) {
+    set_error("pgp_multi_congruent_batch_quads: bad argument");
+    return PGP_EINVAL;
+  }
+  if (cnt == 0) return PGP_OK;
+  std::vector<std::vector<int>> where, local;
+  int rc = route_picks(m, obj, picks, cnt, "pgp_multi_congruent_batch_quads", &where, &local);
+  if (rc != PGP_OK) return rc;
+  return run_all(m, [&, m, obj, quads](int k) -> int {
+    const int c = (int)where[(size_t)k].size();
+    if (c == 0) return PGP_OK;
+    std::vector<int> q((size_t)c * 4);
+    const int r = pgp_congruent_batch_quads(m->octx[(size_t)obj][(size_t)k], local[(size_t)k].data(), c, q.data());
+    if (r != PGP_OK) return r;
+    for (int i = 0; i < c; ++i) std::memcpy(quads + 4 * (size_t)where[(size_t)k][(size_t)i], &q[(size_t)i * 4], 16);
+    return PGP_OK;
+  });
+}
+
+int pgp_multi_congruent_batch_fit(pgp_multi* m, int obj, const int* picks, const int* base_ids, int cnt,
+                                  const float centroid_P[3], const float centroid_Q[3], float* T, double* pose, int* status,
+                                  float* rms) {
+  if (bad_object(m, obj, "pgp_multi_congruent_batch_fit")) return PGP_EINVAL;
+  if (cnt < 0 || (cnt > 0 && (!picks || !base_ids || !T || !status)) || !centroid_P || !centroid_Q) {
+    set_error("pgp_multi_congruent_batch_fit: bad argument");
+    return PGP_EINVAL;
+  }
+  if (cnt == 0) return PGP_OK;
+  std::vector<std::vector<int>> where, local;
+  int rc = route_picks(m, obj, picks, cnt, "pgp_multi_congruent_batch_fit", &where, &local);
+  if (rc != PGP_OK) return rc;
+  // the variable-length fit lists of the members, gathered on the host in the caller's pick order
+  return run_all(m, [&, m, obj](int k) -> int {
+    const std::vector<int>& w = where[(size_t)k];
+    const int c = (int)w.size();
+    if (c == 0) return PGP_OK;
+    std::vector<int> st((size_t)c);
+    std::vector<float> t((size_t)c * 16), e((size_t)c);
+    std::vector<double> ps(pose ? (size_t)c * 16 : 0);
+    // base_ids is indexed by base: the member's batch numbers its bases from its first one
+    const int* ids = base_ids + 4 * (size_t)m->cs_lo[(size_t)obj][(size_t)k];
+    const int r = pgp_congruent_batch_fit(m->octx[(size_t)obj][(size_t)k], local[(size_t)k].data(), ids, c, centroid_P,
+                                          centroid_Q, t.data(), pose ? ps.data() : nullptr, st.data(), rms ? e.data() : nullptr);
+    if (r != PGP_OK) return r;
+    for (int i = 0; i < c; ++i) {
+      const size_t d = (size_t)w[(size_t)i];
+      std::memcpy(T + 16 * d, &t[(size_t)i * 16], 64);
+      if (pose) std::memcpy(pose + 16 * d, &ps[(size_t)i * 16], 128);
+      status[d] = st[(size_t)i];
+      if (rms) rms[d] = e[(size_t)i];
+    }
+    return PGP_OK;
+  });
 }
 
 }  // extern "C"

@@ -100,6 +100,11 @@ inline void note_device_work(pgp_ctx* ctx, hipStream_t stream) {
   ctx->device_work_pending = true;
 }
 
+// after the host has synchronised a stream that was made to wait for the side-stream index build (await_index):
+// the build is through, so its flag is cleared and its counts are taken over here -- a *_device call that follows
+// (possibly on a capturing stream, which can neither query nor wait for the build's event) then finds nothing pending
+inline int index_settled(pgp_ctx* ctx) { return ctx->index_pending ? finish_index(ctx) : PGP_OK; }
+
 inline uint32_t spread10(uint32_t v) {
   v &= 1023u;
   v = (v | (v << 16)) & 0x030000FFu;
@@ -200,7 +205,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_kd_nodes, &ctx->d_kd_pts, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_icp_x, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp, &ctx->d_top_ws};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -447,8 +452,15 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
     return PGP_EINVAL;
   }
   CtxGuard guard(ctx);
+  if (ctx->index_pending && hipEventQuery(ctx->ev_index) == hipSuccess) {
+    const int rc = finish_index(ctx);   // a finished side-stream build: noticed without waiting
+    if (rc != PGP_OK) return rc;
+  } else if (ctx->index_pending) {
+    (void)hipGetLastError();   // hipErrorNotReady is not an error
+  }
   if (max_hypotheses <= ctx->cap_h) return PGP_OK;
   PGP_HIP(hipDeviceSynchronize());   // the workspaces replaced below may be in use by queued launches
+  if (int rc = index_settled(ctx)) return rc;
   int rc;
   size_t cap = (size_t)max_hypotheses;
   size_t tiles = (size_t)tiles_for(ctx->nQ);
@@ -595,6 +607,7 @@ int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_de
   if (rc != PGP_OK) return rc;
   PGP_HIP(hipMemcpyAsync(pin_out, d_scores, out_bytes, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   if (n_h > 0) {
     std::memcpy(scores, pin_out, (size_t)n_h * sizeof(float));
     if (counts) std::memcpy(counts, pin_out + (size_t)n_h * 4, (size_t)n_h * sizeof(int));
@@ -622,6 +635,7 @@ int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int
   if (ctx->nQ > 0)
     PGP_HIP(hipMemcpyAsync(hits.data(), ctx->d_hits.p, (size_t)ctx->nQ * sizeof(int), hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   int k = 0;
   for (int i = 0; i < ctx->nQ; ++i)
     if (hits[i] >= 0) ids[k++] = hits[i];  // model-point order, as push_back in base.cc:1760
@@ -661,6 +675,7 @@ int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, con
   std::vector<int> hits(N);
   PGP_HIP(hipMemcpyAsync(hits.data(), d_hits, N * 4, hipMemcpyDeviceToHost, st));
   PGP_HIP(hipStreamSynchronize(st));
+  if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   int k = 0;
   for (int i = 0; i < n; ++i)
     if (hits[i] >= 0) ids[k++] = hits[i];
@@ -720,6 +735,7 @@ int pgp_set_search_model(pgp_ctx* ctx, const float* xyz, int n) {
   }
   CtxGuard guard(ctx);
   PGP_HIP(hipDeviceSynchronize());   // see pgp_set_scene
+  ctx->csb_fit_m = 0;
   ctx->csb_nb = 0;   // a resident congruent batch belongs to the old search model
   std::vector<float4> hq((size_t)std::max(n, 1));
   for (int i = 0; i < n; ++i)
@@ -816,6 +832,7 @@ int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_
   int rc;
   if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
   // layout of the staged outputs: pose (double, first for alignment) | T | rms | status
+  ctx->csb_fit_m = 0;   // d_rig is rewritten below: the fits a pgp_congruent_batch_fetch could name are gone
   if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
   int* d_b = ctx->d_ids.as<int>();
   int* d_q = d_b + 4 * N;
@@ -924,6 +941,7 @@ int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids,
   const size_t N = (size_t)m;
   int rc;
   if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  ctx->csb_fit_m = 0;   // d_rig is rewritten below: the fits a pgp_congruent_batch_fetch could name are gone
   if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
   int* d_b = ctx->d_ids.as<int>();
   int* d_q = d_b + 4 * N;
@@ -992,6 +1010,7 @@ int pgp_congruent_batch_fit_score(pgp_ctx* ctx, const int* picks, const int* bas
   int rc;
   if ((rc = pgp_reserve(ctx, m)) != PGP_OK) return rc;
   if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  ctx->csb_fit_m = 0;   // d_rig is rewritten below: the fits a pgp_congruent_batch_fetch could name are gone
   if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
   if ((rc = ctx->d_out.ensure(N * 8 + 8)) != PGP_OK) return rc;
   // pinned staging: [bases of the picks | picks] in, [scores | status | best] out
@@ -1196,6 +1215,113 @@ int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const fl
   return pgp_icp_refine_ex_device(ctx, d_src4, n_src, d_tgt4, nullptr, n_tgt, d_T, n, &o, d_energy, d_iters, stream);
 }
 
+}  // extern "C"
+
+namespace pgp {
+
+pgp_icp_options icp_options_of(const pgp_icp_params* p) { return options_of(p); }
+
+namespace {
+std::vector<float4> pack4(const float* xyz, int m) {
+  std::vector<float4> v((size_t)std::max(m, 1));
+  for (int i = 0; i < m; ++i) v[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
+  return v;
+}
+// The target is the object's model, the same from call to call (TrimmedICP::init builds its search
+// structure once per model: UCTState.cpp:137-139): a hash of its coordinates tells whether the copy
+// and the index already resident on the device are this target's, and the upload + build are skipped.
+unsigned long long hash_of(const float* xyz, int m) {
+  // four independent multiply-xor chains over the 32-bit words (a single chain is latency-bound: 20 us at 5000 points)
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(xyz);
+  const size_t e = 3 * (size_t)m;
+  unsigned long long h0 = 0x9E3779B97F4A7C15ull ^ (unsigned long long)m, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull,
+                     h3 = 0x27D4EB2F165667C5ull;
+  size_t i = 0;
+  for (; i + 4 <= e; i += 4) {
+    h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
+    h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull + (h1 >> 31);
+    h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull + (h2 >> 27);
+    h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull + (h3 >> 30);
+  }
+  for (; i < e; ++i) h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
+  const unsigned long long hsh = h0 ^ (h1 * 0x9E3779B97F4A7C15ull) ^ (h2 << 17 | h2 >> 47) ^ (h3 * 0xC2B2AE3D27D4EB4Full);
+  return hsh | 1ull;   // never 0
+}
+}  // namespace
+
+// One host-pointer ICP job staged in the context's buffers on `st` (no launch yet): ONE device block
+// [src | T | energy | iters] and its pinned host image -- ONE copy in ([src | T]) and ONE copy out
+// ([T | energy | iters]): the caller's arrays are pageable, and five pageable copies cost more than ten
+// ICP iterations of one pose.  The target goes to d_icp_tgt unless its hash says it is resident.
+int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt, const float* T, int n,
+                   hipStream_t st, IcpHostStage* out) {
+  int rc;
+  IcpHostStage g{};
+  g.off_T = (size_t)std::max(n_src, 1) * 16;
+  g.off_e = g.off_T + (size_t)n * 64;
+  g.off_i = g.off_e + (size_t)n * 4;
+  g.total = g.off_i + (size_t)n * 4;
+  if ((rc = ctx->d_icp_src.ensure(g.total)) != PGP_OK) return rc;
+  if ((rc = ctx->d_icp_tgt.ensure((size_t)std::max(n_tgt, 1) * 16)) != PGP_OK) return rc;
+  if (g.total + 64 > ctx->h_pin_cap) {
+    if (ctx->h_pin) {
+      hipError_t e = hipHostFree(ctx->h_pin);
+      (void)e;
+      ctx->h_pin = nullptr;
+      ctx->h_pin_cap = 0;
+    }
+    const size_t want = g.total + g.total / 4 + 64;
+    PGP_HIP(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
+    ctx->h_pin_cap = want;
+  }
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
+  {
+    float4* ps = reinterpret_cast<float4*>(pin);
+    for (int i = 0; i < n_src; ++i)
+      ps[i] = make_float4(src_xyz[3 * (size_t)i], src_xyz[3 * (size_t)i + 1], src_xyz[3 * (size_t)i + 2], 0.f);
+    std::memcpy(pin + g.off_T, T, (size_t)n * 64);
+  }
+  const unsigned long long tok = hash_of(tgt_xyz, n_tgt);
+  if (!(tok == ctx->icp_host_token && n_tgt == ctx->icp_host_ntgt)) {
+    const std::vector<float4> ht = pack4(tgt_xyz, n_tgt);
+    ctx->icp_host_token = 0;
+    ctx->icp_idx_valid = false;
+    PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
+    PGP_HIP(hipStreamSynchronize(st));   // ht is a temporary
+    ctx->icp_host_token = tok;
+    ctx->icp_host_ntgt = n_tgt;
+  }
+  unsigned char* dev = ctx->d_icp_src.as<unsigned char>();
+  g.d_src = reinterpret_cast<const float4*>(dev);
+  g.d_tgt = ctx->d_icp_tgt.as<float4>();
+  g.d_T = reinterpret_cast<float*>(dev + g.off_T);
+  g.d_energy = reinterpret_cast<float*>(dev + g.off_e);
+  g.d_iters = reinterpret_cast<int*>(dev + g.off_i);
+  g.token = tok;
+  PGP_HIP(hipMemcpyAsync(dev, pin, g.off_e, hipMemcpyHostToDevice, st));
+  *out = g;
+  return PGP_OK;
+}
+
+// the results' way back: queued behind the job's kernels on `st` ...
+int icp_host_collect_enqueue(pgp_ctx* ctx, const IcpHostStage& g, hipStream_t st) {
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
+  unsigned char* dev = ctx->d_icp_src.as<unsigned char>();
+  PGP_HIP(hipMemcpyAsync(pin + g.off_T, dev + g.off_T, g.total - g.off_T, hipMemcpyDeviceToHost, st));
+  return PGP_OK;
+}
+// ... and, once `st` is synchronised, out of the pinned image into the caller's arrays
+void icp_host_collect(pgp_ctx* ctx, const IcpHostStage& g, int n, float* T, float* energy, int* iters) {
+  const unsigned char* pin = static_cast<const unsigned char*>(ctx->h_pin);
+  std::memcpy(T, pin + g.off_T, (size_t)n * 64);
+  if (energy) std::memcpy(energy, pin + g.off_e, (size_t)n * 4);
+  if (iters) std::memcpy(iters, pin + g.off_i, (size_t)n * 4);
+}
+
+}  // namespace pgp
+
+extern "C" {
+
 int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, const float* tgt_nrm,
                       int n_tgt, float* T, int n, const pgp_icp_options* opt, float* energy, int* iters) {
   if (!ctx || !opt || n < 0 || n_src < 0 || n_tgt < 0 ||
@@ -1206,73 +1332,15 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   if (n == 0) return PGP_OK;
   CtxGuard guard(ctx);
   hipStream_t st = ctx->stream;
-  auto pack = [](const float* xyz, int m) {
-    std::vector<float4> v((size_t)std::max(m, 1));
-    for (int i = 0; i < m; ++i) v[i] = make_float4(xyz[3 * (size_t)i], xyz[3 * (size_t)i + 1], xyz[3 * (size_t)i + 2], 0.f);
-    return v;
-  };
-  // The target is the object's model, the same from call to call (TrimmedICP::init builds its search
-  // structure once per model: UCTState.cpp:137-139): a hash of its coordinates tells whether the copy
-  // and the index already resident on the device are this target's, and the upload + build are skipped.
-  auto hash_of = [](const float* xyz, int m) {
-    // four independent multiply-xor chains over the 32-bit words (a single chain is latency-bound: 20 us at 5000 points)
-    const uint32_t* w = reinterpret_cast<const uint32_t*>(xyz);
-    const size_t e = 3 * (size_t)m;
-    unsigned long long h0 = 0x9E3779B97F4A7C15ull ^ (unsigned long long)m, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull,
-                       h3 = 0x27D4EB2F165667C5ull;
-    size_t i = 0;
-    for (; i + 4 <= e; i += 4) {
-      h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
-      h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull + (h1 >> 31);
-      h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull + (h2 >> 27);
-      h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull + (h3 >> 30);
-    }
-    for (; i < e; ++i) h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
-    const unsigned long long hsh = h0 ^ (h1 * 0x9E3779B97F4A7C15ull) ^ (h2 << 17 | h2 >> 47) ^ (h3 * 0xC2B2AE3D27D4EB4Full);
-    return hsh | 1ull;   // never 0
-  };
-  // One device block [src | T | energy | iters] and its pinned host image: ONE copy in ([src | T]) and ONE
-  // copy out ([T | energy | iters]) -- the caller's arrays are pageable, and five pageable copies cost
-  // more than ten ICP iterations of one pose.
   int rc;
-  const size_t off_T = (size_t)std::max(n_src, 1) * 16, off_e = off_T + (size_t)n * 64, off_i = off_e + (size_t)n * 4,
-               total = off_i + (size_t)n * 4;
-  if ((rc = ctx->d_icp_src.ensure(total)) != PGP_OK) return rc;
-  if ((rc = ctx->d_icp_tgt.ensure((size_t)std::max(n_tgt, 1) * 16)) != PGP_OK) return rc;
-  if (total + 64 > ctx->h_pin_cap) {
-    if (ctx->h_pin) {
-      hipError_t e = hipHostFree(ctx->h_pin);
-      (void)e;
-      ctx->h_pin = nullptr;
-      ctx->h_pin_cap = 0;
-    }
-    const size_t want = total + total / 4 + 64;
-    PGP_HIP(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
-    ctx->h_pin_cap = want;
-  }
-  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
-  {
-    float4* ps = reinterpret_cast<float4*>(pin);
-    for (int i = 0; i < n_src; ++i)
-      ps[i] = make_float4(src_xyz[3 * (size_t)i], src_xyz[3 * (size_t)i + 1], src_xyz[3 * (size_t)i + 2], 0.f);
-    std::memcpy(pin + off_T, T, (size_t)n * 64);
-  }
-  const unsigned long long tok = hash_of(tgt_xyz, n_tgt);
-  if (!(tok == ctx->icp_host_token && n_tgt == ctx->icp_host_ntgt)) {
-    const std::vector<float4> ht = pack(tgt_xyz, n_tgt);
-    ctx->icp_host_token = 0;
-    ctx->icp_idx_valid = false;
-    PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
-    PGP_HIP(hipStreamSynchronize(st));   // ht is a temporary
-    ctx->icp_host_token = tok;
-    ctx->icp_host_ntgt = n_tgt;
-  }
+  IcpHostStage g{};
+  if ((rc = icp_host_stage(ctx, src_xyz, n_src, tgt_xyz, n_tgt, T, n, st, &g)) != PGP_OK) return rc;
   const float4* d_n = nullptr;
   if (tgt_nrm) {
     const unsigned long long ntok = hash_of(tgt_nrm, n_tgt);
     if ((rc = ctx->d_icp_tgt_n.ensure((size_t)std::max(n_tgt, 1) * 16)) != PGP_OK) return rc;
     if (ntok != ctx->icp_host_ntoken) {
-      const std::vector<float4> hn = pack(tgt_nrm, n_tgt);
+      const std::vector<float4> hn = pack4(tgt_nrm, n_tgt);
       ctx->icp_host_ntoken = 0;
       PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt_n.p, hn.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
       PGP_HIP(hipStreamSynchronize(st));
@@ -1280,19 +1348,11 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
     }
     d_n = ctx->d_icp_tgt_n.as<float4>();
   }
-  unsigned char* dev = ctx->d_icp_src.as<unsigned char>();
-  float* d_T = reinterpret_cast<float*>(dev + off_T);
-  float* d_energy = reinterpret_cast<float*>(dev + off_e);
-  int* d_iters = reinterpret_cast<int*>(dev + off_i);
-  PGP_HIP(hipMemcpyAsync(dev, pin, off_e, hipMemcpyHostToDevice, st));
-  rc = launch_icp(ctx, reinterpret_cast<const float4*>(dev), n_src, ctx->d_icp_tgt.as<float4>(), d_n, n_tgt, d_T, n, opt,
-                  d_energy, d_iters, st, tok);
+  rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(pin + off_T, dev + off_T, total - off_T, hipMemcpyDeviceToHost, st));
+  if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
   PGP_HIP(hipStreamSynchronize(st));
-  std::memcpy(T, pin + off_T, (size_t)n * 64);
-  if (energy) std::memcpy(energy, pin + off_e, (size_t)n * 4);
-  if (iters) std::memcpy(iters, pin + off_i, (size_t)n * 4);
+  icp_host_collect(ctx, g, n, T, energy, iters);
   return PGP_OK;
 }
 

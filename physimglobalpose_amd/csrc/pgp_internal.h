@@ -282,6 +282,22 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
                unsigned long long tgt_token = 0);
 
+// pgp_api.hip: a host-pointer ICP job staged in a context's buffers (pgp_icp_refine_ex; the device group's pose shards)
+struct IcpHostStage {
+  const float4* d_src;
+  const float4* d_tgt;
+  float* d_T;
+  float* d_energy;
+  int* d_iters;
+  unsigned long long token;          // hash of the target's coordinates: the key of its resident index
+  size_t off_T, off_e, off_i, total; // byte offsets inside d_icp_src and its pinned image
+};
+int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt, const float* T, int n,
+                   hipStream_t st, IcpHostStage* out);
+int icp_host_collect_enqueue(pgp_ctx* ctx, const IcpHostStage& g, hipStream_t st);
+void icp_host_collect(pgp_ctx* ctx, const IcpHostStage& g, int n, float* T, float* energy, int* iters);
+pgp_icp_options icp_options_of(const pgp_icp_params* p);
+
 // base_select.hip
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);
 int ppf_thresholds(float tpos[9], float tneg[9]);

@@ -790,3 +790,128 @@ class MultiGpuScorer:
         a, b, c = C.c_float(0), C.c_float(0), C.c_float(0)
         _lib.check(self._lib.pgp_multi_last_timing(self._h, C.byref(a), C.byref(b), C.byref(c)))
         return {"upload_ms": a.value, "enqueue_ms": b.value, "total_ms": c.value}
+
+    # ---- several objects in one group (configs[3]; SceneCfg.cpp:376-406) ------------------------------
+    @property
+    def n_objects(self):
+        return int(self._lib.pgp_multi_objects(self._h))
+
+    def add_object(self):
+        """pgp_multi_add_object: a further (scene, model) pair replicated on every member; returns its id."""
+        o = int(self._lib.pgp_multi_add_object(self._h))
+        if o < 0:
+            _lib.check(o)
+        return o
+
+    def object_context(self, obj, k=0):
+        return C.c_void_p(self._lib.pgp_multi_object_context(self._h, int(obj), int(k)))
+
+    def init_object(self, obj, P_xyz, P_nrm, P_w, Q_xyz, Q_nrm, delta=0.005):
+        xyz, nrm, w = _f32(P_xyz, 3), _f32(P_nrm, 3), _f32(P_w)
+        _lib.check(self._lib.pgp_multi_set_object_scene(self._h, int(obj), _fp(xyz), _fp(nrm), _fp(w), len(xyz), C.c_float(delta)))
+        q, qn = _f32(Q_xyz, 3), _f32(Q_nrm, 3)
+        _lib.check(self._lib.pgp_multi_set_object_model(self._h, int(obj), _fp(q), _fp(qn), len(q)))
+
+    def set_object_search_model(self, obj, xyz):
+        q = _f32(xyz, 3)
+        _lib.check(self._lib.pgp_multi_set_object_search_model(self._h, int(obj), _fp(q), len(q)))
+
+    def set_object_ppf_map(self, obj, keys, counts=None, pairs=None):
+        k = np.ascontiguousarray(keys, np.int32).reshape(-1, 4)
+        c = None if counts is None else np.ascontiguousarray(counts, np.int32)
+        p = None if pairs is None else np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+        _lib.check(self._lib.pgp_multi_set_object_ppf_map(
+            self._h, int(obj), k.ctypes.data_as(_i), None if c is None else c.ctypes.data_as(_i),
+            None if p is None else p.ctypes.data_as(_i), len(k)))
+
+    @staticmethod
+    def flat_slices(counts, k, n_dev):
+        """pgp_multi_flat_slices: member k's share of the flat (object, unit) space as [(object, lo, hi), ...]."""
+        c = np.ascontiguousarray(counts, np.int32)
+        n = len(c)
+        o, lo, hi = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        m = C.c_int(0)
+        _lib.check(_lib.load().pgp_multi_flat_slices(c.ctypes.data_as(_i), n, int(k), int(n_dev), o.ctypes.data_as(_i),
+                                                     lo.ctypes.data_as(_i), hi.ctypes.data_as(_i), C.byref(m)))
+        return [(int(o[i]), int(lo[i]), int(hi[i])) for i in range(m.value)]
+
+    def _lists(self, T_per_object):
+        Ts = [_f32(T, 16) for T in T_per_object]
+        n = np.array([len(T) for T in Ts], np.int32)
+        ptrs = (_f * len(Ts))(*[_fp(T) for T in Ts])
+        return Ts, n, ptrs
+
+    def _flat_out(self, n, n_obj):
+        N = int(n.sum())
+        return (np.zeros(N, np.float32), np.zeros(N, np.int32), np.full(n_obj, -1, np.int32), np.zeros(n_obj, np.float32))
+
+    def _split(self, n, s, c, bi, bs):
+        off = np.concatenate([[0], np.cumsum(n)])
+        return [(s[off[o]:off[o + 1]], c[off[o]:off[o + 1]], int(bi[o]), float(bs[o])) for o in range(len(n))]
+
+    def score_objects(self, T_per_object, mode=PGP_MODE_PLAIN, gate_deg=30.0):
+        """pgp_multi_score_objects: per object (scores, counts, best_index, best_score), as LcpScorer.score returns them."""
+        Ts, n, ptrs = self._lists(T_per_object)
+        s, c, bi, bs = self._flat_out(n, len(Ts))
+        _lib.check(self._lib.pgp_multi_score_objects(self._h, ptrs, n.ctypes.data_as(_i), len(Ts), int(mode), C.c_float(gate_deg),
+                                                     _fp(s), c.ctypes.data_as(_i), bi.ctypes.data_as(_i), _fp(bs)))
+        return self._split(n, s, c, bi, bs)
+
+    def upload_objects(self, T_per_object):
+        Ts, n, ptrs = self._lists(T_per_object)
+        _lib.check(self._lib.pgp_multi_upload_objects(self._h, ptrs, n.ctypes.data_as(_i), len(Ts)))
+        self._n_up_obj = n
+
+    def score_objects_uploaded(self, mode=PGP_MODE_PLAIN, gate_deg=30.0):
+        n = self._n_up_obj
+        s, c, bi, bs = self._flat_out(n, len(n))
+        _lib.check(self._lib.pgp_multi_score_objects_uploaded(self._h, int(mode), C.c_float(gate_deg), _fp(s), c.ctypes.data_as(_i),
+                                                              bi.ctypes.data_as(_i), _fp(bs)))
+        return self._split(n, s, c, bi, bs)
+
+    # ---- ICP pose shards (UCTSearch.cpp:200-266 -> UCTState.cpp:121-204) ------------------------------
+    def icp_refine(self, jobs, trim=1.0, max_iterations=100, max_corr_dist=0.0, energy_ratio=1.0):
+        """pgp_multi_icp_refine.  jobs: [(src_xyz, tgt_xyz, T), ...]; returns per job (T, energy, iters) as
+        LcpScorer.icp_refine does."""
+        arr = (_lib.MultiIcpJob * max(len(jobs), 1))()
+        keep, out = [], []
+        for j, (src, tgt, T) in enumerate(jobs):
+            src, tgt = _f32(src, 3), _f32(tgt, 3)
+            T = _f32(T, 16).copy()
+            e, it = np.zeros(len(T), np.float32), np.zeros(len(T), np.int32)
+            keep.append((src, tgt))
+            out.append((T, e, it))
+            arr[j] = _lib.MultiIcpJob(_fp(src), len(src), _fp(tgt), len(tgt), _fp(T), len(T), _fp(e), it.ctypes.data_as(_i))
+        prm = _lib.IcpParams(int(max_iterations), float(trim), float(max_corr_dist), float(energy_ratio))
+        _lib.check(self._lib.pgp_multi_icp_refine(self._h, arr, len(jobs), C.byref(prm)))
+        return out
+
+    # ---- congruent sets sharded by base (base.cc:1855-1874) -------------------------------------------
+    def find_congruent_batch(self, obj, base_ids, base_xyz, invariants, threshold):
+        ids = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        xyz = _f32(np.asarray(base_xyz).reshape(-1, 12))
+        inv = _f32(invariants, 2)
+        nq = np.zeros(max(len(ids), 1), np.int32)
+        _lib.check(self._lib.pgp_multi_find_congruent_batch(self._h, int(obj), ids.ctypes.data_as(_i), _fp(xyz), _fp(inv), len(ids),
+                                                            C.c_float(threshold), nq.ctypes.data_as(_i)))
+        return nq[:len(ids)]
+
+    def congruent_batch_quads(self, obj, picks):
+        p = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)
+        q = np.zeros((max(len(p), 1), 4), np.int32)
+        _lib.check(self._lib.pgp_multi_congruent_batch_quads(self._h, int(obj), p.ctypes.data_as(_i), len(p), q.ctypes.data_as(_i)))
+        return q[:len(p)]
+
+    def congruent_batch_fit(self, obj, picks, base_ids, centroid_P, centroid_Q):
+        p = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)
+        ids = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        m = len(p)
+        T = np.zeros((max(m, 1), 16), np.float32)
+        pose = np.zeros((max(m, 1), 16), np.float64)
+        st = np.zeros(max(m, 1), np.int32)
+        rms = np.zeros(max(m, 1), np.float32)
+        cP, cQ = _f32(centroid_P), _f32(centroid_Q)
+        _lib.check(self._lib.pgp_multi_congruent_batch_fit(self._h, int(obj), p.ctypes.data_as(_i), ids.ctypes.data_as(_i), m, _fp(cP),
+                                                           _fp(cQ), _fp(T), pose.ctypes.data_as(C.POINTER(C.c_double)),
+                                                           st.ctypes.data_as(_i), _fp(rms)))
+        return T[:m], pose[:m], st[:m], rms[:m]

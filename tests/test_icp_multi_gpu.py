@@ -85,3 +85,25 @@ def test_select_top_matches_a_stable_argsort_and_the_rigid_inverse():
     torch.cuda.synchronize()
     assert int(d_n[0]) == 3 and d_idx.cpu().numpy().tolist() == [900, 5, 17, -1, -1, -1, -1, -1]
     assert np.array_equal(d_out[3:].cpu().numpy(), np.tile(np.eye(4, dtype=np.float32).reshape(16), (5, 1)))
+
+
+def test_two_jobs_on_one_context_run_one_after_the_other():
+    """A context keeps ONE target index: two jobs that name the same scorer (an object with two segments, two targets on
+    one context) must not share a launch whose second index build overwrites the first -- same bits as one
+    call per job."""
+    probs = [_problem(90, 3000, 1500, 12, rot_deg=4.0, trans=0.005, outliers=0.05),
+             _problem(91, 4200, 2100, 20, rot_deg=4.0, trans=0.005, outliers=0.05),
+             _problem(92, 2500, 1000, 7, rot_deg=4.0, trans=0.005, outliers=0.05)]
+    shared, own = LcpScorer(), LcpScorer()
+    scs = [shared, own, shared]                       # jobs 0 and 2: different targets, one context
+    jobs, ref = [], []
+    for (S, M, N, G), sc in zip(probs, scs):
+        checker = LcpScorer()
+        ref.append(checker.icp_refine(S, M, G, trim=0.9, max_iterations=30))
+        jobs.append(dict(scorer=sc, d_src4=_dev4(S), d_tgt4=_dev4(M), d_T=torch.from_numpy(G.copy()).cuda().reshape(-1, 16),
+                         d_energy=torch.zeros(len(G), device="cuda"), d_iters=torch.zeros(len(G), dtype=torch.int32, device="cuda")))
+    LcpScorer.icp_refine_multi_device(jobs, trim=0.9, max_iterations=30)
+    torch.cuda.synchronize()
+    for q, r in zip(jobs, ref):
+        assert np.array_equal(q["d_T"].cpu().numpy(), r[0]) and np.array_equal(q["d_energy"].cpu().numpy(), r[1])
+        assert np.array_equal(q["d_iters"].cpu().numpy(), r[2])

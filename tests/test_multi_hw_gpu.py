@@ -19,6 +19,7 @@ import torch
 
 from physimglobalpose_amd import LcpScorer, MultiGpuScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
 from _checkers import Oracle
+from test_multi_objects_gpu import congruent_case  # noqa: F401  (module-scoped fixture)
 
 N_DEV = torch.cuda.device_count()      # counting devices does not initialise the GPU
 pytestmark = [pytest.mark.gpu,
@@ -94,6 +95,35 @@ def test_exact_records_across_physical_slices():
     grp.set_exact_records(True)
     b = grp.score(T, PGP_MODE_WEIGHTED, w.gate_deg)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2:] == b[2:]
+    grp.close()
+
+
+@pytest.mark.parametrize("n", GROUPS)
+def test_objects_icp_shards_and_congruent_shards_over_physical_devices(n, congruent_case):
+    """row e-2 (SURVEY 8e line 4, configs[3]) over physical members: the cases of tests/test_multi_objects_gpu.py with
+    the real all-reduce -- several objects in one group, ICP pose shards, congruent sets sharded by base"""
+    from test_multi_objects_gpu import (check_congruent_shards_equal_single_context, check_icp_shards_equal_single_calls,
+                                        check_objects_equal_single_contexts)
+    shapes = [(9000, 1500, 700), (4000, 800, 0), (12000, 2000, 333), (3000, 500, 2), (6000, 1000, 1201)]
+    objs = [synth.make_workload(p, q, max(h, 1), config_id=500 + k) for k, (p, q, h) in enumerate(shapes)]
+    grp = MultiGpuScorer(list(range(n)))
+    for _ in range(len(objs) - 1):
+        grp.add_object()
+    check_objects_equal_single_contexts(grp, objs, [h for _, _, h in shapes])
+    check_icp_shards_equal_single_calls(grp)
+    check_congruent_shards_equal_single_context(grp, congruent_case, obj=1)
+    grp.close()
+
+
+def test_six_objects_64k_hypotheses_over_physical_devices():
+    """BASELINE.json configs[3] as the reference states it: 6 objects, 65 536 hypotheses, every visible device"""
+    from test_multi_objects_gpu import check_objects_equal_single_contexts
+    counts = [16384, 12288, 12288, 8192, 8192, 8192]
+    objs = [synth.make_workload(20000, 3000, c, config_id=300 + k) for k, c in enumerate(counts)]
+    grp = MultiGpuScorer(list(range(N_DEV)))
+    for _ in range(5):
+        grp.add_object()
+    check_objects_equal_single_contexts(grp, objs, counts, modes=(PGP_MODE_WEIGHTED,))
     grp.close()
 
 
