@@ -40,3 +40,21 @@ def test_cpp_host_resident_chain_and_multi_target_icp(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK")
     print(out.stdout)
+
+
+@pytest.mark.skipif(not shutil.which("g++"), reason="no g++")
+def test_cpp_host_six_objects_over_the_device_group(tmp_path):
+    """examples/six_objects.cc: BASELINE configs[3] from a C++ host -- six objects in one native group (eight logical
+    members on this one GPU), the flat (object, hypothesis) space scored with one exchange, the best poses of every object
+    refined with the poses sharded; equal to single-context calls bit for bit (the program checks)."""
+    exe = str(tmp_path / "six_objects")
+    lib = os.path.join(ROOT, "physimglobalpose_amd")
+    r = subprocess.run(["g++", "-O2", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "six_objects.cc"), "-L", lib, "-lpgp", f"-Wl,-rpath,{lib}",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    out = subprocess.run([exe, "65536", "32"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PGP_MULTI_EMULATE="8"))
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("OK")
+    print(out.stdout)

@@ -142,6 +142,8 @@ def test_bench_under_real_rccl(n):
     assert d["n_gpus"] == n and d["scaling"] == "weak" and d["value"] > 1e6
     pc = d["per_call"]
     assert pc["ms_per_step"] > 0 and pc["value"] > 0 and "error" not in pc
-    nm = d.get("native_multi")
+    nm = d["rows"].get("native_multi")
     assert nm is not None and "error" not in nm, nm
     assert nm["devices"] == n and nm["equals_single_device"] is True
+    for k in ("objects", "icp_shards", "congruent_shards"):      # row e-2 over the physical devices
+        assert nm[k]["equals_single_context"] is True and nm[k]["ms_per_call"] > 0, k
