@@ -155,8 +155,13 @@ def main():
     w = synth.make_workload(50000, 5000, args.hyp * n * n_b, config_id=2)
     grp.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
     batches = w.T.reshape(n_b, args.hyp * n, 16)
-    for b in range(3):
-        grp.score(batches[b], mode, w.gate_deg)
+    # pre-heat: a call is ~0.15 ms and this process starts on an idle chip -- 150 ms of calls first, and never fewer
+    # than 100 timed ones, whatever --steps says (bench.py passes the driver's 20)
+    args.steps = max(args.steps, 100)
+    t_heat = time.perf_counter()
+    while time.perf_counter() - t_heat < 0.15:
+        for b in range(n_b):
+            grp.score(batches[b], mode, w.gate_deg)
     t0 = time.perf_counter()
     for k in range(args.steps):
         s, c, bi, bs = grp.score(batches[k % n_b], mode, w.gate_deg)
