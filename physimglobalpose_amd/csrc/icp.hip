@@ -1073,14 +1073,21 @@ __device__ __forceinline__ unsigned long long grid_nn27(const IcpArgs& a, float 
     if (zz >= 0 && zz < a.gnz && yy >= 0 && yy < a.gny && x0 <= x1) {
       const size_t c0 = ((size_t)zz * a.gny + yy) * a.gnx + x0;
       const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
-      for (uint32_t k = b; k < e; ++k) {
-        const float4 m = a.gpts[k];
-        const float dx = __fsub_rn(x, m.x), dyy = __fsub_rn(y, m.y), dzz = __fsub_rn(z, m.z);
-        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
-        const int j = __float_as_int(m.w);
-        if (d2 < best || (d2 == best && j < bj)) {   // the scan's rule: smallest d2, then lowest j
-          best = d2;
-          bj = j;
+      // four points per trip, their loads issued together (one point per trip was a chain of ~30 dependent L2 round trips
+      // per lane); the comparisons stay in point order, so the winner is the one-by-one walk's
+      for (uint32_t k = b; k < e; k += 4) {
+        float4 m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) m[u] = a.gpts[min(k + (uint32_t)u, e - 1u)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float dx = __fsub_rn(x, m[u].x), dyy = __fsub_rn(y, m[u].y), dzz = __fsub_rn(z, m[u].z);
+          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
+          const int j = __float_as_int(m[u].w);
+          if (k + (uint32_t)u < e && (d2 < best || (d2 == best && j < bj))) {   // the scan's rule: smallest d2, then lowest j
+            best = d2;
+            bj = j;
+          }
         }
       }
     }
@@ -1135,6 +1142,270 @@ __global__ __launch_bounds__(256) void icp_nn_grid_open(IcpArgs a, float r2_safe
   }
 }
 
+
+// ---- the scene-sized capped ICP as ONE launch (round 5) --------------------------------------------------------------
+// The reference's one LIVE ICP call aligns the whole scene to the table model (SceneCfg.cpp:101,135-141: ~30 000 source
+// points, a 100 000-point target, correspondence cap 1 cm, <= 50 iterations).  Host-driven, an iteration was three launches
+// (icp_nn_grid, icp_sums_partial, icp_refine<true, true>) and every fourth a host synchronisation: 63 us of which 42 in
+// kernels.  Here ONE cooperative launch of resident workgroups runs every iteration, with the arithmetic of those three
+// kernels operation for operation (same grid search, same 4-points-per-lane accumulation, same wave tree, the same
+// order of the wave and block sums), so transforms, energies and iteration counts are theirs bit for bit:
+//   chunk  = 16 consecutive source points: one round of a 256-thread workgroup, 16 lanes per query (grid_nn27); keys go
+//            to memory write-through;
+//   unit   = 256 consecutive points = the 16 chunks whose keys one WAVE of icp_sums_partial would sum: the workgroup
+//            whose chunk arrives last at the unit's ticket forms that wave's sums (wave 0, lanes as icp_sums_partial's);
+//   pose   = the workgroup whose unit arrives last at the pose's ticket adds the unit sums in icp_sums_partial's wave
+//            order and icp_refine's block order, solves, applies the stop rules and publishes the next transform;
+// everybody else polls the pose's state word (iterations completed | done << 31).  Three tickets deep, no grid-wide
+// barrier, no host round trip.  A ticket is a returning agent-scope add behind the arriver's drained write-through
+// stores (MI355X_MICROARCH.md, handoff-flag); whoever draws the last number reads the others' data with agent-scope loads.
+struct SceneArgs {
+  unsigned long long* keys;   // [n][n_src] (d2 bits << 32) | j, ~0 = no neighbour in the 27 cells
+  double* W;                  // [n][n_units16][kPartStride]: the unit sums; units past the cloud stay zero
+  unsigned* unit_ctr;         // [n][n_units16] chunk arrivals, monotone over the iterations
+  unsigned* pose_ctr;         // [n] unit arrivals, monotone
+  unsigned* state;            // [n] iterations completed | done << 31
+  double* E_old;              // [n] mean squared distance of the previous iteration
+  unsigned* lost;             // [1] set when a wait ran into its clock bound
+  int n_chunks, n_units, n_units16, n_blk;
+  int poll_sleep;             // s_sleep argument between two polls of a pose's state word
+  int n_upd;                  // workgroups 0 .. n_upd-1 are updaters (pose p: updater p % n_upd), the rest workers
+};
+constexpr int kSceneThreads = 256;
+constexpr int kSceneQ = kSceneThreads / kGridLanes;   // queries per chunk
+
+template <class T>
+__device__ __forceinline__ T agent_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class T>
+__device__ __forceinline__ void agent_store(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+constexpr int kSceneRep = 32;       // copies of a pose's state word, one 128-byte line each: 1000 polling workgroups on ONE word
+constexpr int kSceneRepStride = 32; // (in words) queue behind each other at the memory side and hold up the updater's own traffic
+constexpr int kSceneUpdMax = 8;     // workgroups in the updater role
+
+// Two ROLES in one launch.  Workgroups 0 .. n_upd-1 are updaters: pose p belongs to updater p % n_upd, which waits for the
+// pose's unit counter, adds the unit sums in the reference order, solves, applies the stop rules and publishes the next
+// transform -- the code with the solvers' calls and ~120 registers.  All other workgroups are workers: search their
+// chunks, close units.  (One body for both had the compiler keep the solvers' calling-convention spills and 150-190
+// registers around the search loop: 3 waves per SIMD and scratch traffic in the hot path; measured 76 us per iteration
+// against 57 host-driven.)
+#ifdef PGP_SCENE_WAVES   // A/B knob (make variantf FILE=icp): force the register budget of N waves per SIMD
+#define PGP_SCENE_ATTR __attribute__((amdgpu_waves_per_eu(PGP_SCENE_WAVES, PGP_SCENE_WAVES)))
+#else
+#define PGP_SCENE_ATTR
+#endif
+template <int METRIC>
+__global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persist(IcpArgs a, SceneArgs z) {
+  __shared__ float s_G[16], s_G_old[16];
+  __shared__ int s_flag[2];
+  __shared__ double s_sum[kRedPlane + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(kSumR == 4 && kSceneQ * 16 == 256, "a unit is one wave of icp_sums_partial: 64 lanes x 4 consecutive points");
+  if ((int)blockIdx.x < z.n_upd) {
+    // ================= updater =================
+    if (wave != 0) return;
+    for (int it = 0;; ++it) {
+      bool any = false;
+      for (int pose = blockIdx.x; pose < a.n; pose += z.n_upd) {
+        unsigned st = agent_load(&z.state[(size_t)pose * kSceneRep * kSceneRepStride]);
+        if (st >> 31) continue;
+        any = true;
+        // ---- every unit of the pose has arrived (their sums are in memory: written through before the arrival)
+        const unsigned target = (unsigned)z.n_units * (unsigned)(it + 1);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        bool lost = false;
+        while (agent_load(&z.pose_ctr[pose]) < target) {
+          __builtin_amdgcn_s_sleep(4);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz: cannot happen with every workgroup resident
+            lost = true;
+            break;
+          }
+        }
+        if (lost) {
+          if (lane == 0) {
+            agent_store(z.lost, 1u);
+            if (a.iters) a.iters[pose] = -1;
+          }
+          if (lane < kSceneRep) agent_store(&z.state[((size_t)pose * kSceneRep + lane) * kSceneRepStride], 0x80000000u);
+          continue;
+        }
+        if (lane < 16) s_G[lane] = agent_load(&a.T[16 * (size_t)pose + lane]);
+        // ---- the pose's sums: icp_sums_partial adds its 16 waves in order from 0.0, icp_refine<true, true> the blocks in
+        // order from 0.0.  Lane k + 32 (b & 1) adds the waves of block b, two blocks per pass; lane k then adds the blocks.
+        {
+          const int k = lane & 31, half = lane >> 5;
+          double total = 0.0;
+          for (int bb = 0; bb < z.n_blk; bb += 2) {
+            const int b = bb + half;
+            double w16[16];
+#pragma unroll
+            for (int w = 0; w < 16; ++w)
+              w16[w] = (b < z.n_blk && k <= kRedPlane) ? agent_load(&z.W[((size_t)pose * z.n_units16 + 16 * b + w) * kPartStride + k]) : 0.0;
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) v += w16[w];
+            const double v_hi = __shfl(v, k + 32, 64);   // block bb + 1 (lanes 32..63)
+            if (half == 0) {
+              total += v;
+              if (bb + 1 < z.n_blk) total += v_hi;
+            }
+          }
+          if (lane <= kRedPlane) s_sum[lane] = total;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- closed-form update and the progress tests (icp_refine's, thread 0's)
+        int go_i = 0;
+        if (lane == 0) {
+          const double* red = s_sum;
+          const double E = red[0] >= 1.0 ? red[kRedPlane] / red[0] : 0.0;
+          for (int q = 0; q < 16; ++q) s_G_old[q] = s_G[q];
+          if constexpr (METRIC == 1) solve_plane(red, s_G);
+          else solve_rigid(red, s_G);
+          const double E_old = it == 0 ? (double)FLT_MAX : z.E_old[pose];   // PCL: energy starts at numeric_limits<float>::max()
+          bool go = it + 1 < a.max_iter;
+          if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;
+          if (red[0] < 1.0) go = false;
+          if (converged_extra(stop_rules_of(a), pose, it + 1, s_G_old, s_G, E, E_old)) go = false;
+          z.E_old[pose] = E;   // (this workgroup's own: nobody else reads it)
+          if (!go) {
+            if (a.energy) a.energy[pose] = (float)E;
+            if (a.iters) a.iters[pose] = it + 1;
+          }
+          go_i = go ? 1 : 0;
+        }
+        go_i = __builtin_amdgcn_readfirstlane(go_i);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (lane < 16) agent_store(&a.T[16 * (size_t)pose + lane], s_G[lane]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // every copy of the state word by ONE store instruction, a line each
+        if (lane < kSceneRep)
+          agent_store(&z.state[((size_t)pose * kSceneRep + lane) * kSceneRepStride], (unsigned)(it + 1) | (go_i ? 0u : 0x80000000u));
+      }
+      if (!any) break;
+    }
+    return;
+  }
+  // ================= worker =================
+  const int items = a.n * z.n_chunks, n_work = (int)gridDim.x - z.n_upd, me = (int)blockIdx.x - z.n_upd;
+  const unsigned* my_state = z.state + (size_t)(me % kSceneRep) * kSceneRepStride;
+  for (int it = 0;; ++it) {
+    bool any = false;
+    for (int item = me; item < items; item += n_work) {
+      const int pose = item / z.n_chunks, chunk = item - pose * z.n_chunks;
+      // ---- the pose's transform of this iteration: published by the updater when it closed the previous one
+      if (tid == 0) {
+        unsigned st = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        for (;;) {
+          st = agent_load(&my_state[(size_t)pose * kSceneRep * kSceneRepStride]);
+          if ((st >> 31) != 0u || (st & 0x7FFFFFFFu) >= (unsigned)it) break;
+          for (int q = 0; q < z.poll_sleep; ++q) __builtin_amdgcn_s_sleep(8);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s: the updater reports it (it has lost the units, too)
+            st = 0x80000000u;
+            break;
+          }
+        }
+        s_flag[0] = (int)(st >> 31);
+      }
+      __syncthreads();
+      const bool pose_done = s_flag[0] != 0;
+      if (!pose_done && tid < 16) s_G[tid] = agent_load(&a.T[16 * (size_t)pose + tid]);
+      __syncthreads();   // (also: everybody has read s_flag[0] before thread 0 writes it again)
+      if (pose_done) continue;
+      any = true;
+      // ---- 1. the chunk's correspondences (icp_nn_grid's arithmetic)
+      {
+        const int i = chunk * kSceneQ + (tid >> 4), lane16 = tid & (kGridLanes - 1);
+        if (i < a.n_src) {
+          const float4 s = a.src[i];
+          const float x = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
+          const float y = row_xf(s_G[1], s_G[5], s_G[9], s_G[13], s.x, s.y, s.z);
+          const float zq = row_xf(s_G[2], s_G[6], s_G[10], s_G[14], s.x, s.y, s.z);
+          const unsigned long long key = grid_nn27(a, x, y, zq, lane16);
+          if (lane16 == 0) agent_store(&z.keys[(size_t)pose * a.n_src + i], key);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's keys have left ...
+      __syncthreads();                                    // ... and so have every wave's, before the chunk's ticket
+      const int u = chunk >> 4;
+      if (tid == 0) {
+        const unsigned per = (unsigned)min(16, z.n_chunks - 16 * u);
+        const unsigned old = __hip_atomic_fetch_add(&z.unit_ctr[(size_t)pose * z.n_units16 + u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_flag[1] = old + 1u == per * (unsigned)(it + 1) ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_flag[1] || wave != 0) continue;   // (the other waves wait at the next item's barrier while wave 0 closes the unit)
+      // ---- 2. the unit's sums: lane l holds the points 256 u + 4 l .. + 3, as thread 64 w + l of icp_sums_partial does
+      const int b0 = 256 * u;
+      unsigned long long kv[kSumR];
+#pragma unroll
+      for (int r = 0; r < kSumR; ++r) {
+        const int i = b0 + kSumR * lane + r;
+        kv[r] = i < a.n_src ? agent_load(&z.keys[(size_t)pose * a.n_src + i]) : ~0ull;
+      }
+      constexpr int kNs = METRIC == 1 ? kRedPlane : 16;   // sums in use
+      double acc[kNs];
+#pragma unroll
+      for (int k = 0; k < kNs; ++k) acc[k] = 0.0;
+      double e_acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < kSumR; ++r) {
+        const int i = b0 + kSumR * lane + r;
+        const float d2 = kv[r] == ~0ull ? FLT_MAX : __uint_as_float((unsigned)(kv[r] >> 32));
+        const int jm = kv[r] == ~0ull ? -1 : (int)(unsigned)(kv[r] & 0xFFFFFFFFull);
+        const bool sel = i < a.n_src && (a.max_corr2 >= 0.f ? d2 <= a.max_corr2 : true);
+        if constexpr (METRIC == 1) {
+          if (sel && jm >= 0) {
+            const float4 s = a.src[i];
+            const float4 m = a.tgt[jm];
+            const float4 nn = a.tgt_n[jm];
+            const double sx = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
+            const double sy = row_xf(s_G[1], s_G[5], s_G[9], s_G[13], s.x, s.y, s.z);
+            const double sz = row_xf(s_G[2], s_G[6], s_G[10], s_G[14], s.x, s.y, s.z);
+            const double nx = nn.x, ny = nn.y, nz = nn.z;
+            const double row[6] = {nz * sy - ny * sz, nx * sz - nz * sx, ny * sx - nx * sy, nx, ny, nz};
+            const double rhs = nx * (double)m.x + ny * (double)m.y + nz * (double)m.z - nx * sx - ny * sy - nz * sz;
+            acc[0] += 1.0;
+            int t = 1;
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+              for (int c = rr; c < 6; ++c) acc[t++] += row[rr] * row[c];
+#pragma unroll
+            for (int rr = 0; rr < 6; ++rr) acc[22 + rr] += row[rr] * rhs;
+            e_acc += (double)d2;
+          }
+        } else if (sel && jm >= 0) {
+          const float4 s = a.src[i];
+          const float4 m = a.tgt[jm];
+          acc[0] += 1.0;
+          acc[1] += s.x; acc[2] += s.y; acc[3] += s.z;
+          acc[4] += m.x; acc[5] += m.y; acc[6] += m.z;
+          acc[7] += (double)s.x * m.x; acc[8] += (double)s.x * m.y; acc[9] += (double)s.x * m.z;
+          acc[10] += (double)s.y * m.x; acc[11] += (double)s.y * m.y; acc[12] += (double)s.y * m.z;
+          acc[13] += (double)s.z * m.x; acc[14] += (double)s.z * m.y; acc[15] += (double)s.z * m.z;
+          e_acc += (double)d2;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kNs; ++k) acc[k] = wave_sum_f64(acc[k]);
+      e_acc = wave_sum_f64(e_acc);
+      double* Wu = z.W + ((size_t)pose * z.n_units16 + u) * kPartStride;
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < kRedPlane; ++k) agent_store(&Wu[k], k < kNs ? acc[k < kNs ? k : 0] : 0.0);
+        agent_store(&Wu[kRedPlane], e_acc);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unit's sums have left before its arrival is counted
+      if (lane == 0) __hip_atomic_fetch_add(&z.pose_ctr[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!any) break;
+  }
+}
 
 // ---- the exact index: build ----------------------------------------------------------------------
 __device__ __forceinline__ int nn_axis(float v, float o, float inv_h, int n) {
@@ -2721,6 +2992,7 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
     }
   }
   ctx->icp_idx_valid = false;
+  ctx->icp_grid_valid = false;   // (d_icp_grid holds either the index image or the capped search's grid)
   if (n_tgt < 1 || n_tgt > 65535) return PGP_OK;                // 16-bit positions
   if ((long long)nn_lds_bytes(0, n_q, false) + kScratch > kLdsBytes) return PGP_OK;   // the per-query arrays alone do not fit
   // n_q = queries a workgroup keeps in LDS (8 B each).  When the image (16 B per point + 4 B per cell) fits beside
@@ -3105,19 +3377,27 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   a.st_done = a.st_it + n;
   a.n_done = a.st_done + n;
   a.st_hist = a.smooth > 0 ? reinterpret_cast<double*>(((uintptr_t)(a.n_done + 1) + 15) & ~(uintptr_t)15) : nullptr;
-  if (use_index) {
-    a.ws_pos = reinterpret_cast<int*>(((uintptr_t)(a.n_done + 1) + hist_bytes + 31) & ~(uintptr_t)15);
-    PGP_HIP(hipMemsetAsync(a.ws_pos, 0xFF, need * 4, stream));   // no previous correspondence yet
-  }
-  PGP_HIP(hipMemsetAsync(a.ws_key, 0xFF, need * 8, stream));
-  PGP_HIP(hipMemsetAsync(a.ws_j, 0xFF, need * 4, stream));  // no previous correspondence yet
-  PGP_HIP(hipMemsetAsync(a.st_it, 0, (size_t)n * 8 + 4, stream));
-  if (a.st_hist) PGP_HIP(hipMemsetAsync(a.st_hist, 0, hist_bytes, stream));
-  {
+  if (use_index) a.ws_pos = reinterpret_cast<int*>(((uintptr_t)(a.n_done + 1) + hist_bytes + 31) & ~(uintptr_t)15);
+  // the state of the host-driven iterations (not needed -- and its host synchronisation not paid -- by the one-launch form below)
+  auto init_split_state = [&]() -> int {
+    if (use_index) PGP_HIP(hipMemsetAsync(a.ws_pos, 0xFF, need * 4, stream));   // no previous correspondence yet
+    PGP_HIP(hipMemsetAsync(a.ws_key, 0xFF, need * 8, stream));
+    PGP_HIP(hipMemsetAsync(a.ws_j, 0xFF, need * 4, stream));  // no previous correspondence yet
+    PGP_HIP(hipMemsetAsync(a.st_it, 0, (size_t)n * 8 + 4, stream));
+    if (a.st_hist) PGP_HIP(hipMemsetAsync(a.st_hist, 0, hist_bytes, stream));
     std::vector<double> e0((size_t)n, (double)FLT_MAX);
     PGP_HIP(hipMemcpyAsync(a.st_E, e0.data(), (size_t)n * 8, hipMemcpyHostToDevice, stream));
     PGP_HIP(hipStreamSynchronize(stream));  // e0 is a stack temporary
+    return PGP_OK;
+  };
+  bool scene_persist = use_grid && n_blk > 1 && !(a.max_corr2 < 0.f && a.k_trim < a.n_src) && a.smooth == 0 && ctx->n_cus > 0;
+  if (const char* v = getenv("PGP_ICP_PART")) scene_persist = scene_persist && atoi(v) != 0;
+  if (const char* v = getenv("PGP_ICP_SCENE_PERSIST")) scene_persist = scene_persist && atoi(v) != 0;
+  if (scene_persist) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) scene_persist = false;
   }
+  if (!scene_persist && (rc = init_split_state()) != PGP_OK) return rc;
   double* d_part = nullptr;
   if (part_sums) {   // the last part_bytes of the workspace
     unsigned char* end = ctx->d_icp_ws.as<unsigned char>() + need * 8 + state_bytes + 64;
@@ -3132,7 +3412,27 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     open_list = reinterpret_cast<int*>(q);
     open_cnt = open_list + need;
   }
-  if (use_grid || open_grid) {
+  // The grid of the capped search stays valid across calls like the exact index does: same (target pointer, size, token
+  // != 0) and the same cap = the same cells (the reference aligns every frame's scene to the SAME table model with the same
+  // cap, SceneCfg.cpp:101,135-141: bounding box, two scatters and a scan -- ~0.15 ms and a host synchronisation -- per call).
+  const bool grid_cached = use_grid && !open_grid && tgt_token != 0 && ctx->icp_grid_valid && ctx->icp_grid_token == tgt_token &&
+                           ctx->icp_grid_tgt == (const void*)d_tgt && ctx->icp_grid_ntgt == n_tgt && ctx->icp_grid_cap == prm->max_corr_dist;
+  if (grid_cached) {
+    a.gox = ctx->icp_grid_geom[0];
+    a.goy = ctx->icp_grid_geom[1];
+    a.goz = ctx->icp_grid_geom[2];
+    a.ginv_h = ctx->icp_grid_geom[3];
+    a.gnx = ctx->icp_grid_n[0];
+    a.gny = ctx->icp_grid_n[1];
+    a.gnz = ctx->icp_grid_n[2];
+    const size_t cells = (size_t)a.gnx * a.gny * a.gnz;
+    const size_t off_pts = ((cells + 1) * 8 + 64 + 255) & ~(size_t)255;
+    unsigned char* gb = ctx->d_icp_grid.as<unsigned char>();
+    a.gcell_start = reinterpret_cast<uint32_t*>(gb + 64) + (cells + 1);
+    a.gpts = reinterpret_cast<float4*>(gb + off_pts);
+  }
+  if ((use_grid || open_grid) && !grid_cached) {
+    ctx->icp_grid_valid = false;
     ctx->icp_idx_valid = false;   // d_icp_grid is about to hold the search's grid
     // ---- the target's grid: bounding box (device), cell edge >= max_corr (grown to keep <= 2^26 cells)
     float bb[6];
@@ -3200,6 +3500,74 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     PGP_HIP(hipMemsetAsync(ctr, 0, (cells + 1) * 4, stream));
     hipLaunchKernelGGL(grid_scatter<true>, gt, dim3(256), 0, stream, a, ctr, pts);
     PGP_HIP(hipGetLastError());
+    if (use_grid && !open_grid && tgt_token != 0) {
+      ctx->icp_grid_valid = true;
+      ctx->icp_grid_token = tgt_token;
+      ctx->icp_grid_tgt = (const void*)d_tgt;
+      ctx->icp_grid_ntgt = n_tgt;
+      ctx->icp_grid_cap = prm->max_corr_dist;
+      ctx->icp_grid_geom[0] = a.gox;
+      ctx->icp_grid_geom[1] = a.goy;
+      ctx->icp_grid_geom[2] = a.goz;
+      ctx->icp_grid_geom[3] = a.ginv_h;
+      ctx->icp_grid_n[0] = a.gnx;
+      ctx->icp_grid_n[1] = a.gny;
+      ctx->icp_grid_n[2] = a.gnz;
+    }
+  }
+  // The capped grid search with sums by block -- the shape of the reference's table alignment -- as ONE cooperative launch
+  // (icp_scene_persist): every iteration on the device, no host round trip.  PGP_ICP_SCENE_PERSIST=0: the host-driven
+  // iterations below (the checker of that kernel: same bits); also taken while the stream is being captured, with the
+  // pointmatcher history, and where the device takes no cooperative launch.
+  {
+    if (scene_persist) {
+      SceneArgs z{};
+      z.n_chunks = (n_src + kSceneQ - 1) / kSceneQ;
+      z.n_units = (n_src + 255) / 256;
+      z.n_blk = n_blk;
+      z.n_units16 = n_blk * 16;
+      const size_t N = (size_t)n, w_bytes = N * z.n_units16 * kPartStride * 8, uc_bytes = (N * z.n_units16 * 4 + 63) & ~(size_t)63;
+      const size_t st_bytes = N * kSceneRep * kSceneRepStride * 4, pc_bytes = (N * 4 + 63) & ~(size_t)63, eo_bytes = (N * 8 + 63) & ~(size_t)63;
+      const size_t tail = pc_bytes + st_bytes + eo_bytes + 64;
+      const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+      std::lock_guard<std::mutex> chain(g_coop.mu);   // cooperative launches of one process never overlap on a device
+      if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
+      else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
+      if ((rc = ctx->d_icp_x.ensure(w_bytes + uc_bytes + tail + 256)) != PGP_OK) return rc;
+      unsigned char* xb = ctx->d_icp_x.as<unsigned char>();
+      z.W = reinterpret_cast<double*>(xb);
+      z.unit_ctr = reinterpret_cast<unsigned*>(xb + w_bytes);
+      z.pose_ctr = reinterpret_cast<unsigned*>(xb + w_bytes + uc_bytes);
+      z.state = reinterpret_cast<unsigned*>(xb + w_bytes + uc_bytes + pc_bytes);
+      z.E_old = reinterpret_cast<double*>(xb + w_bytes + uc_bytes + pc_bytes + st_bytes);
+      z.lost = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(z.E_old) + eo_bytes);
+      z.keys = a.ws_key;
+      PGP_HIP(hipMemsetAsync(xb, 0, w_bytes + uc_bytes + tail, stream));
+      int per_cu = 0;
+      const void* fn_scene = a.metric == 1 ? reinterpret_cast<const void*>(icp_scene_persist<1>) : reinterpret_cast<const void*>(icp_scene_persist<0>);
+      if (a.metric == 1) PGP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_scene_persist<1>, kSceneThreads, 0));
+      else PGP_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, icp_scene_persist<0>, kSceneThreads, 0));
+      const long long items = (long long)n * z.n_chunks, room = (long long)per_cu * ctx->n_cus;
+      z.n_upd = std::min(n, kSceneUpdMax);
+      unsigned grid = (unsigned)std::max<long long>(z.n_upd + 1, std::min(items + z.n_upd, room));
+      if (const char* v = getenv("PGP_ICP_SCENE_WGS")) grid = std::max((unsigned)z.n_upd + 1u, std::min(grid, (unsigned)atoi(v)));   // A/B knob
+      z.poll_sleep = 1;
+      if (const char* v = getenv("PGP_ICP_SCENE_SLEEP")) z.poll_sleep = atoi(v);
+      void* params[] = {&a, &z};
+      const hipError_t e = room > z.n_upd ? hipLaunchCooperativeKernel(fn_scene, dim3(grid), dim3(kSceneThreads),
+                                                                   params, 0, stream)
+                                      : hipErrorInvalidValue;
+      if (getenv("PGP_ICP_DEBUG"))
+        fprintf(stderr, "icp: scene-sized capped ICP in one launch: %d poses x %d chunks on %u workgroups (%d per CU): %s\n", n, z.n_chunks,
+                grid, per_cu, hipGetErrorString(e));
+      if (e == hipSuccess) {
+        PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
+        PGP_HIP(hipGetLastError());
+        return PGP_OK;
+      }
+      (void)hipGetLastError();   // not launchable cooperatively here: the host-driven iterations
+      if ((rc = init_split_state()) != PGP_OK) return rc;
+    }
   }
   const dim3 gnn((n_src + kNnThreads * kIcpR - 1) / (kNnThreads * kIcpR), (n_tgt + kNnTgt - 1) / kNnTgt, n);
   const dim3 ggrid((unsigned)(((size_t)n_src * kGridLanes + 255) / 256), n);

@@ -315,6 +315,34 @@ struct ScoreArgs {
   const float4* kd_pts;
 };
 
+// Fused finalisation (PGP_FUSED builds, launch_score): the (tile, hypothesis) partials are ADDED to per-hypothesis
+// accumulator words whose upper 16 bits count the tiles that have arrived -- data and ticket in ONE returning atomic --,
+// and whoever arrives last turns the total into the score; no second launch.  The LAST parameter of the flat kernels,
+// read through the kernel-argument pointer at the very end of a workgroup only (fuse_args): as members of ScoreArgs
+// these fields were fetched at the top of the kernel and sat in scalar registers through the whole scoring loop.
+struct FuseArgs {
+  unsigned long long* acc;        // [2][stride]: {arrivals << 48 | inlier count}, {arrivals << 48 | fixed-point weight sum}
+  float* scores;
+  int* counts;                    // nullable
+  unsigned long long* best_key;
+  unsigned long long* runner_key;
+  unsigned int* done;
+  int* best;
+  double fx_inv;                  // 2^-shift
+  float fx_scale;                 // 2^shift of the fixed-point weight sums
+  int acc_stride;
+};
+[[maybe_unused]] constexpr size_t kFuseArgsOffset = ((sizeof(ScoreArgs) + 7) & ~(size_t)7) + 5 * sizeof(void*);
+[[maybe_unused]] __device__ __forceinline__ FuseArgs fuse_args() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const unsigned char* kp = (const unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp));   // the loads below stay below
+  return *reinterpret_cast<const FuseArgs*>(kp + kFuseArgsOffset);
+#else
+  return FuseArgs{};
+#endif
+}
+
 // KdTree::doQueryRestrictedClosestIndex (kdtree.h:394-459) on the uploaded tree: the same descent (the query's side
 // of a split first, the other side only while its plane is closer than the best so far, strictly), the same
 // inclusive test inside a leaf, so that among equal distances the point the reference visits last is returned.
@@ -797,7 +825,13 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       __builtin_amdgcn_wave_barrier();
       PGP_STAMP(t_e);   // all batches done
       PGP_PHASE(3, t_d, t_e);
-      if ((uint32_t)lane < ((W + 63u) >> 6)) marks[lane] = 0ull;  // clear the bits for the next iteration
+      if ((uint32_t)lane < ((W + 63u) >> 6)) {   // clear the bits for the next iteration
+        // (the zero is made HERE: as an ordinary constant the compiler parked a 64-bit zero in two VGPRs for the whole
+        // scoring loop and, at the register ceiling, spilled it to scratch memory and reloaded it on every trip)
+        unsigned long long zero = 0ull;
+        asm volatile("" : "+v"(zero));
+        marks[lane] = zero;
+      }
       // the low word of the owner's result: plain 0 / 1; weighted the id of the minimum key, -1 if none
       if (occ) rlo = reinterpret_cast<const uint32_t*>(res)[2 * r];
       if (TIES && kW) {   // tied candidates at the minimum: the reference's tree decides (rare)
@@ -897,6 +931,93 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
 #endif
   __syncthreads();
   const int hh = threadIdx.x;
+#if defined(PGP_FUSED) && PGP_FUSED
+  if (threadIdx.x >= 64) return;   // the block's <= 64 hypotheses live in wave 0
+  {
+    const FuseArgs z = fuse_args();
+    unsigned long long key = 0;
+    bool fin = false;
+    if (hh < h1 - h0) {
+      int c = 0;
+#pragma unroll
+      for (int w = 0; w < kTile / 64; ++w) c += s_cnt[w][hh];
+      float f = 0.f;
+      if (kW) {
+#pragma unroll
+        for (int w = 0; w < kTile / 64; ++w) f += s_sum[w][hh];
+      }
+      const int h = h0 + hh;
+      const unsigned long long one = 1ull << 48, low = one - 1ull;
+      const unsigned long long last_mark = (unsigned long long)(a.n_tiles - 1);
+      // both adds are in flight together: ONE round trip to the memory side
+      unsigned long long oldB = 0, oldA = 0;
+      const unsigned long long fx = kW ? (unsigned long long)__float2ll_rn(__fmul_rn(f, z.fx_scale)) : 0ull;
+      if (kW) oldB = __hip_atomic_fetch_add(&z.acc[z.acc_stride + h], one | fx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const bool want_a = !kW || z.counts != nullptr;
+      if (want_a) oldA = __hip_atomic_fetch_add(&z.acc[h], one | (unsigned long long)(uint32_t)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float score = 0.f;
+      if (want_a && (oldA >> 48) == last_mark) {
+        const int total = (int)((oldA & low) + (unsigned long long)(uint32_t)c);
+        z.acc[h] = 0ull;   // re-armed for the next launch (nobody else touches it in this one)
+        if (z.counts) z.counts[h] = total;
+        if (!kW) {
+          score = __fdiv_rn((float)total, (float)a.nQ);
+          fin = true;
+        }
+      }
+      if (kW && (oldB >> 48) == last_mark) {
+        const unsigned long long sum = (oldB & low) + fx;
+        z.acc[z.acc_stride + h] = 0ull;
+        score = __fdiv_rn(__double2float_rn((double)sum * z.fx_inv), (float)a.nQ);
+        fin = true;
+      }
+      if (fin) {
+        __hip_atomic_store(&z.scores[h], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (score > 0.f) key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
+      }
+    }
+    const unsigned long long fm = __ballot(fin);
+    if (fm == 0ull) return;      // 19 of 20 blocks end here
+    // the hypotheses this block finalised: their top-2 keys, then the launch's (two atomics + the arrival count)
+    const unsigned long long mykey = key;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      unsigned long long o = __shfl_xor(key, off, 64);
+      key = o > key ? o : key;
+    }
+    unsigned long long key2 = mykey == key ? 0ull : mykey;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      unsigned long long o = __shfl_xor(key2, off, 64);
+      key2 = o > key2 ? o : key2;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through score stores of this wave are complete
+    if (threadIdx.x == 0) {
+      if (key) {
+        const unsigned long long old = atomicMax(z.best_key, key);
+        const unsigned long long push = old < key ? old : key;
+        if (push) atomicMax(z.runner_key, push);
+      }
+      if (key2) atomicMax(z.runner_key, key2);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned n_fin = (unsigned)__popcll(fm);
+      const bool last = atomicAdd(z.done, n_fin) + n_fin == (unsigned)a.n_h;
+      if (last) {
+        const unsigned long long kk = atomicExch(z.best_key, 0ull);
+        atomicExch(z.runner_key, 0ull);
+        atomicExch(z.done, 0u);
+        // (experiment: weighted near-ties are NOT settled here)
+        if (kk == 0) {
+          z.best[0] = -1;
+          z.best[1] = 0;
+        } else {
+          z.best[0] = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+          z.best[1] = (int)(unsigned)(kk >> 32);
+        }
+      }
+    }
+  }
+#else
   if (hh < h1 - h0) {
     int c = 0;
 #pragma unroll
@@ -908,6 +1029,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
     }
     a.partial[(size_t)tile * a.n_h + h0 + hh] = make_uint2((uint32_t)c, __float_as_uint(f));
   }
+#endif
 #if defined(PGP_ABLATE) && PGP_ABLATE == 9
   // timing experiment: what a per-block agent-scope release + ticket would cost (fused finalize)
   __threadfence();
@@ -922,7 +1044,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
 template <int MODE>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat(
     ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
-    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
+    const float4* __restrict__ cand, const float4* __restrict__ Pnw, FuseArgs) {
   score_flat_body<MODE, 3, false>(a, Tm, words, occ_run, cand, Pnw);
 }
 
@@ -930,7 +1052,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 template <bool SPARSE>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat_ties(
     ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
-    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
+    const float4* __restrict__ cand, const float4* __restrict__ Pnw, FuseArgs) {
   score_flat_body<PGP_MODE_WEIGHTED, 3, SPARSE, true>(a, Tm, words, occ_run, cand, Pnw);
 }
 
@@ -938,7 +1060,7 @@ __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) v
 template <int MODE>
 __global__ __launch_bounds__(kTile) __attribute__((amdgpu_waves_per_eu(8, 8))) void score_hypotheses_flat_sparse(
     ScoreArgs a, const float* __restrict__ Tm, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
-    const float4* __restrict__ cand, const float4* __restrict__ Pnw) {
+    const float4* __restrict__ cand, const float4* __restrict__ Pnw, FuseArgs) {
   score_flat_body<MODE, 3, true>(a, Tm, words, occ_run, cand, Pnw);
 }
 
@@ -1620,7 +1742,7 @@ float key2f(int32_t k) {
 // packets that hipEventRecord before and after the launch put on the stream (those cost the
 // C2 step 8 us, 7 % of its throughput, when per-kernel timing was on).
 void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a, hipEvent_t ev0,
-                    hipEvent_t ev1) {
+                    hipEvent_t ev1, const FuseArgs& fz = FuseArgs{}) {
   // default by measurement at C2 (tools/tune.py): wave-flattened 112 us plain / 157 us weighted vs
   // per-lane walk (U = 2) 125 / 170 us
   // (a scene so far from the origin that its lattice numbers leave the mantissa trick's range takes the
@@ -1628,28 +1750,28 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
   if (unroll <= 0 && a.g.magic_ok && a.kd_nodes && mode == PGP_MODE_WEIGHTED) {   // exact ties (pgp_set_exact_ties)
     if (a.g.sparse)
       hipExtLaunchKernelGGL(score_hypotheses_flat_ties<true>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T, a.words,
-                            a.occ_run, a.cand, a.Pnw);
+                            a.occ_run, a.cand, a.Pnw, fz);
     else
       hipExtLaunchKernelGGL(score_hypotheses_flat_ties<false>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T, a.words,
-                            a.occ_run, a.cand, a.Pnw);
+                            a.occ_run, a.cand, a.Pnw, fz);
     return;
   }
   if (unroll <= 0 && a.g.magic_ok && a.g.sparse) {  // wave-flattened candidate phase over the sparse block table
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat_sparse<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
-                            a.T, a.words, a.occ_run, a.cand, a.Pnw);
+                            a.T, a.words, a.occ_run, a.cand, a.Pnw, fz);
     else
       hipExtLaunchKernelGGL(score_hypotheses_flat_sparse<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0,
-                            a, a.T, a.words, a.occ_run, a.cand, a.Pnw);
+                            a, a.T, a.words, a.occ_run, a.cand, a.Pnw, fz);
     return;
   }
   if (unroll <= 0 && a.g.magic_ok) {  // wave-flattened candidate phase (dense block array)
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T,
-                            a.words, a.occ_run, a.cand, a.Pnw);
+                            a.words, a.occ_run, a.cand, a.Pnw, fz);
     else
       hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
-                            a.T, a.words, a.occ_run, a.cand, a.Pnw);
+                            a.T, a.words, a.occ_run, a.cand, a.Pnw, fz);
     return;
   }
 #define PGP_LAUNCH(M, UU) \
@@ -1800,7 +1922,29 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
       ev1 = ctx->ev[ctx->ev_used + 1];
       ctx->ev_used += 2;
     }
+#if defined(PGP_FUSED) && PGP_FUSED
+    const bool fused = ctx->unroll <= 0 && a.g.magic_ok;
+    FuseArgs fz{};
+    if (fused) {
+      fz.acc = ctx->d_acc.as<unsigned long long>();
+      fz.acc_stride = ctx->cap_h;
+      fz.scores = d_scores;
+      fz.counts = d_counts ? d_counts : (ctx->verify_early_out && mode == PGP_MODE_PLAIN ? ctx->d_counts.as<int>() : nullptr);
+      fz.best_key = key;
+      fz.runner_key = key + 3;
+      fz.done = ticket;
+      fz.best = d_best ? d_best : best_local;
+      // the weight sums in fixed point: nQ * w_max * 2^shift < 2^47 (w_max = 1: probabilities, base.cc:317-324)
+      int shift = 46 - std::ilogb((double)std::max(a.nQ, 1));
+      shift = shift > 40 ? 40 : shift;
+      fz.fx_scale = std::ldexp(1.0f, shift);
+      fz.fx_inv = std::ldexp(1.0, -shift);
+    }
+    launch_variant(mode, ctx->unroll, grid, stream, a, ev0, ev1, fz);
+    if (!fused)
+#else
     launch_variant(mode, ctx->unroll, grid, stream, a, ev0, ev1);
+#endif
     hipLaunchKernelGGL(finalize_scores, dim3((n_h + 255) / 256), dim3(256), 0, stream, a,
                        (const uint2*)a.partial, a.n_tiles, n_h, a.nQ,
                        mode, ctx->refine_best ? 1 : 0, d_scores,

@@ -205,7 +205,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_kd_nodes, &ctx->d_kd_pts, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_icp_x, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp, &ctx->d_top_ws};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp, &ctx->d_top_ws, &ctx->d_acc};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -469,6 +469,8 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
   if ((rc = ctx->d_scores.ensure(cap * sizeof(float))) != PGP_OK) return rc;
   if ((rc = ctx->d_counts.ensure(cap * sizeof(int))) != PGP_OK) return rc;
   if ((rc = ctx->d_eo_ws.ensure(cap * sizeof(int) + 64)) != PGP_OK) return rc;
+  if ((rc = ctx->d_acc.ensure(cap * 16)) != PGP_OK) return rc;
+  PGP_HIP(hipMemset(ctx->d_acc.p, 0, cap * 16));
   ctx->cap_h = max_hypotheses;
   return PGP_OK;
 }
@@ -1231,20 +1233,31 @@ std::vector<float4> pack4(const float* xyz, int m) {
 // structure once per model: UCTState.cpp:137-139): a hash of its coordinates tells whether the copy
 // and the index already resident on the device are this target's, and the upload + build are skipped.
 unsigned long long hash_of(const float* xyz, int m) {
-  // four independent multiply-xor chains over the 32-bit words (a single chain is latency-bound: 20 us at 5000 points)
-  const uint32_t* w = reinterpret_cast<const uint32_t*>(xyz);
-  const size_t e = 3 * (size_t)m;
-  unsigned long long h0 = 0x9E3779B97F4A7C15ull ^ (unsigned long long)m, h1 = 0xC2B2AE3D27D4EB4Full, h2 = 0x165667B19E3779F9ull,
-                     h3 = 0x27D4EB2F165667C5ull;
+  // eight independent multiply-xor chains over the 64-bit words (a single chain over 32-bit words is latency-bound: 20 us
+  // at 5000 points; four of them still took ~0.1 ms on the 100 000-point table of the scene alignment, SceneCfg.cpp:135-141)
+  const size_t e32 = 3 * (size_t)m, e = e32 / 2;
+  const unsigned char* bytes = reinterpret_cast<const unsigned char*>(xyz);
+  unsigned long long h[8] = {0x9E3779B97F4A7C15ull ^ (unsigned long long)m, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
+                             0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xFF51AFD7ED558CCDull, 0xC4CEB9FE1A85EC53ull};
   size_t i = 0;
-  for (; i + 4 <= e; i += 4) {
-    h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
-    h1 = (h1 ^ w[i + 1]) * 0x100000001B3ull + (h1 >> 31);
-    h2 = (h2 ^ w[i + 2]) * 0x100000001B3ull + (h2 >> 27);
-    h3 = (h3 ^ w[i + 3]) * 0x100000001B3ull + (h3 >> 30);
+  for (; i + 8 <= e; i += 8) {
+    unsigned long long w[8];
+    std::memcpy(w, bytes + 8 * i, 64);
+#pragma GCC unroll 8
+    for (int k = 0; k < 8; ++k) h[k] = (h[k] ^ w[k]) * 0x100000001B3ull + (h[k] >> (27 + k % 5));
   }
-  for (; i < e; ++i) h0 = (h0 ^ w[i]) * 0x100000001B3ull + (h0 >> 29);
-  const unsigned long long hsh = h0 ^ (h1 * 0x9E3779B97F4A7C15ull) ^ (h2 << 17 | h2 >> 47) ^ (h3 * 0xC2B2AE3D27D4EB4Full);
+  for (; i < e; ++i) {
+    unsigned long long w;
+    std::memcpy(&w, bytes + 8 * i, 8);
+    h[0] = (h[0] ^ w) * 0x100000001B3ull + (h[0] >> 29);
+  }
+  if (e32 & 1) {
+    uint32_t w;
+    std::memcpy(&w, bytes + 4 * (e32 - 1), 4);
+    h[1] = (h[1] ^ w) * 0x100000001B3ull + (h[1] >> 31);
+  }
+  unsigned long long hsh = h[0];
+  for (int k = 1; k < 8; ++k) hsh = (hsh ^ (h[k] << (7 * k) | h[k] >> (64 - 7 * k))) * 0x9E3779B97F4A7C15ull;
   return hsh | 1ull;   // never 0
 }
 }  // namespace
@@ -1286,6 +1299,7 @@ int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
     const std::vector<float4> ht = pack4(tgt_xyz, n_tgt);
     ctx->icp_host_token = 0;
     ctx->icp_idx_valid = false;
+    ctx->icp_grid_valid = false;
     PGP_HIP(hipMemcpyAsync(ctx->d_icp_tgt.p, ht.data(), (size_t)n_tgt * 16, hipMemcpyHostToDevice, st));
     PGP_HIP(hipStreamSynchronize(st));   // ht is a temporary
     ctx->icp_host_token = tok;

@@ -165,6 +165,14 @@ struct pgp_ctx {
   int icp_idx_ntgt = 0, icp_idx_nq = 0;
   size_t icp_idx_vic_off = 0;   // byte offset of the vicinity graph inside d_icp_grid (0: none)
   alignas(8) unsigned char icp_idx_geom[96] = {0};
+  // the uniform grid of the capped scene-sized search (icp.hip use_grid), kept across calls by the same rule
+  bool icp_grid_valid = false;
+  unsigned long long icp_grid_token = 0;
+  const void* icp_grid_tgt = nullptr;
+  int icp_grid_ntgt = 0;
+  float icp_grid_cap = 0.f;
+  float icp_grid_geom[4] = {0.f, 0.f, 0.f, 0.f};
+  int icp_grid_n[3] = {0, 0, 0};
   unsigned long long icp_user_token = 0;                    // pgp_icp_target_token: device-pointer calls
   unsigned long long icp_host_token = 0, icp_host_ntoken = 0;   // hash of the last uploaded host target / normals
   int icp_host_ntgt = 0;
@@ -173,6 +181,7 @@ struct pgp_ctx {
   int cap_h = 0;
   pgp::DevBuf d_T;        // staged transforms (host API)            [cap_h*16] float
   pgp::DevBuf d_partial;  // per (tile, hypothesis) partials          [n_tiles*cap_h] int2/float
+  pgp::DevBuf d_acc;      // fused finalisation (lcp_score.hip PGP_FUSED): 2 x cap_h accumulator words, zero between launches
   pgp::DevBuf d_scores;   // [cap_h] float
   pgp::DevBuf d_counts;   // [cap_h] int
   pgp::DevBuf d_best;     // 2 x uint64 packed argmax + {index, score bits}

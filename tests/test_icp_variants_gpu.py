@@ -179,3 +179,42 @@ def test_point_to_plane_needs_normals():
     sc = LcpScorer()
     with pytest.raises(PgpError):
         sc.icp_refine_ex(g["seg"], g["model"], synth.colmajor16(g["guesses"][0])[None], error_metric=1)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_scene_sized_capped_icp_in_one_launch_equals_the_host_driven_iterations(metric, monkeypatch):
+    """Round 5 (csrc/icp.hip icp_scene_persist): the scene-sized capped form -- the reference's one live ICP call,
+    SceneCfg.cpp:101,135-141 -- runs every iteration inside ONE cooperative launch (chunk / unit / pose tickets).
+    PGP_ICP_SCENE_PERSIST=0 keeps the host-driven iterations (icp_nn_grid + icp_sums_partial + icp_refine per
+    iteration): transforms, energies and iteration counts must be theirs bit for bit -- several poses that stop at
+    different iterations, a cloud that ends inside a unit and inside a block, point-to-point and point-to-plane."""
+    rng = np.random.default_rng(31 + metric)
+    n_tgt, n_src = 60000, 20011
+    tgt = np.c_[rng.uniform(-0.5, 0.5, n_tgt), rng.uniform(-0.4, 0.4, n_tgt), 0.004 * np.sin(7 * rng.uniform(-1, 1, n_tgt))]
+    tgt[:, 2] += 0.05 * tgt[:, 0] ** 2                                       # a gently curved sheet: the plane metric has something to hold
+    tgt = tgt.astype(np.float32)
+    nrm = np.c_[-0.1 * tgt[:, 0], np.zeros(n_tgt), np.ones(n_tgt)]
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    R = synth._random_rot(rng, np.deg2rad(0.8))
+    src = (tgt[rng.choice(n_tgt, n_src, replace=False)] @ R.T + np.array([0.003, -0.002, 0.002]) + 0.0005 * rng.standard_normal((n_src, 3))).astype(np.float32)
+    src[:200] += rng.uniform(-0.2, 0.2, (200, 3)).astype(np.float32)          # beyond the cap
+    src[11] = np.nan
+    G0 = np.stack([synth.colmajor16(np.eye(4)),
+                   synth.colmajor16(synth._se3(synth._random_rot(rng, np.deg2rad(0.4)), [0.002, 0.0, -0.001])),
+                   synth.colmajor16(synth._se3(R.T, -R.T @ np.array([0.003, -0.002, 0.002]))),     # starts at the answer: stops first
+                   synth.colmajor16(synth._se3(np.eye(3), [0.5, 0.5, 0.5]))])                       # nothing within the cap: no pairs
+    sc = LcpScorer()
+    for kw in (dict(max_iterations=25, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12),
+               dict(max_iterations=3, max_corr_dist=0.02, energy_ratio=0.0)):
+        kw = dict(kw, nn_search=2, error_metric=metric)
+        monkeypatch.setenv("PGP_ICP_SCENE_PERSIST", "0")
+        Ta, Ea, ia = sc.icp_refine_ex(src, tgt, G0, tgt_nrm=nrm if metric else None, **kw)
+        monkeypatch.delenv("PGP_ICP_SCENE_PERSIST")
+        Tb, Eb, ib = sc.icp_refine_ex(src, tgt, G0, tgt_nrm=nrm if metric else None, **kw)
+        assert np.array_equal(ia, ib), (ia, ib)
+        assert np.array_equal(Ta, Tb) and np.array_equal(Ea, Eb)
+        assert len(set(ia.tolist())) >= 2 or kw["max_iterations"] == 3        # the poses stop at different iterations
+    # one pose, the table's shape (the bench row)
+    Tc, Ec, ic = sc.icp_refine_ex(src, tgt, G0[:1], max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9,
+                                  absolute_mse=1e-12, error_metric=metric, tgt_nrm=nrm if metric else None)
+    assert ic[0] >= 1 and np.isfinite(Tc).all() and Ec[0] < 1e-4

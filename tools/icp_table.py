@@ -16,7 +16,7 @@ src = (tgt[pick] @ R.T + np.array([0.004, -0.003, 0.002]) + 0.0008 * rng.standar
 src[:300] += rng.uniform(-0.2, 0.2, (300, 3)).astype(np.float32)
 G0 = synth.colmajor16(np.eye(4))[None]
 sc = LcpScorer()
-kw = dict(max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
+kw = dict(max_iterations=int(os.environ.get("ICP_TABLE_ITERS", "30")), max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
 sc.icp_refine_ex(src, tgt, G0, **kw)
 t0 = time.perf_counter()
 n = 5
