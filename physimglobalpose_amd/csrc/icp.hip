@@ -1075,12 +1075,15 @@ __device__ __forceinline__ unsigned long long grid_nn27(const IcpArgs& a, float 
       const uint32_t b = a.gcell_start[c0], e = a.gcell_start[c0 + (x1 - x0) + 1];
       // four points per trip, their loads issued together (one point per trip was a chain of ~30 dependent L2 round trips
       // per lane); the comparisons stay in point order, so the winner is the one-by-one walk's
-      for (uint32_t k = b; k < e; k += 4) {
-        float4 m[4];
+#ifndef PGP_GRID_UNROLL
+#define PGP_GRID_UNROLL 4
+#endif
+      for (uint32_t k = b; k < e; k += PGP_GRID_UNROLL) {
+        float4 m[PGP_GRID_UNROLL];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) m[u] = a.gpts[min(k + (uint32_t)u, e - 1u)];
+        for (int u = 0; u < PGP_GRID_UNROLL; ++u) m[u] = a.gpts[min(k + (uint32_t)u, e - 1u)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PGP_GRID_UNROLL; ++u) {
           const float dx = __fsub_rn(x, m[u].x), dyy = __fsub_rn(y, m[u].y), dzz = __fsub_rn(z, m[u].z);
           const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
           const int j = __float_as_int(m[u].w);
@@ -1101,6 +1104,68 @@ __device__ __forceinline__ unsigned long long grid_nn27(const IcpArgs& a, float 
   return key;
 }
 
+// The same search with the candidates of the 27 cells FLATTENED over L lanes (round 5): the nine (dz, dy) rows are nine
+// contiguous ranges of points; lane l of the query's group tests the candidates l, l + L, l + 2 L ... of their concatenation.
+// With one lane per row, a planar target (a table top) kept three lanes busy with ~28 points each while six found their
+// rows empty; flattened, sixteen lanes take ~5 each and eight ~10.  The key minimum is a total order on (d2, j), so however
+// the candidates are dealt out the group's minimum is the row-wise walk's -- and the scan's -- key.
+template <int L, int U = 4>   // U: candidates per lane whose loads are in flight together
+__device__ __forceinline__ unsigned long long grid_nn27_flat(const IcpArgs& a, float x, float y, float z, int laneL) {
+  static_assert(L == 8 || L == 16, "a group is a power-of-two slice of a DPP row");
+  uint32_t rb[9], pre[10];
+  pre[0] = 0u;
+  int cx, cy, cz;
+  const bool in = grid_cell_of(a, x, y, z, &cx, &cy, &cz) != 0;
+  const int x0 = in ? max(cx - 1, 0) : 0, x1 = in ? min(cx + 1, a.gnx - 1) : -1;
+  uint32_t re[9];
+#pragma unroll
+  for (int r = 0; r < 9; ++r) {   // every lane of the group reads the same eighteen starts: one round trip, broadcast lines
+    const int zz = cz + r / 3 - 1, yy = cy + r % 3 - 1;
+    const bool ok = in && zz >= 0 && zz < a.gnz && yy >= 0 && yy < a.gny && x0 <= x1;
+    const size_t c0 = ok ? ((size_t)zz * a.gny + yy) * a.gnx + x0 : 0;
+    rb[r] = a.gcell_start[c0];
+    re[r] = ok ? a.gcell_start[c0 + (x1 - x0) + 1] : rb[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 9; ++r) pre[r + 1] = pre[r] + (re[r] - rb[r]);
+  const uint32_t T = pre[9];
+  float best = FLT_MAX;
+  int bj = -1;
+  for (uint32_t t0 = (uint32_t)laneL; t0 < T; t0 += (uint32_t)(U * L)) {
+    float4 m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t t = min(t0 + (uint32_t)(u * L), T - 1u);
+      // the row of candidate t: the last r with pre[r] <= t
+      uint32_t base = rb[0], p0 = 0u;
+#pragma unroll
+      for (int r = 1; r < 9; ++r) {
+        const bool ge = t >= pre[r];
+        base = ge ? rb[r] : base;
+        p0 = ge ? pre[r] : p0;
+      }
+      m[u] = a.gpts[base + (t - p0)];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float dx = __fsub_rn(x, m[u].x), dyy = __fsub_rn(y, m[u].y), dzz = __fsub_rn(z, m[u].z);
+      const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fadd_rn(__fmul_rn(dyy, dyy), __fmul_rn(dzz, dzz)));
+      const int j = __float_as_int(m[u].w);
+      if (t0 + (uint32_t)(u * L) < T && (d2 < best || (d2 == best && j < bj))) {   // the scan's rule: smallest d2, then lowest j
+        best = d2;
+        bj = j;
+      }
+    }
+  }
+  unsigned long long key = bj >= 0 ? ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bj : ~0ull;   // d2 >= 0: bits order as values
+#pragma unroll
+  for (int off = L / 2; off >= 1; off >>= 1) {
+    const unsigned long long o = __shfl_xor(key, off, L);
+    key = o < key ? o : key;
+  }
+  return key;
+}
+
 constexpr int kGridLanes = 16;   // lanes per query in icp_nn_grid / icp_nn_grid_open
 
 __global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
@@ -1113,7 +1178,7 @@ __global__ __launch_bounds__(256) void icp_nn_grid(IcpArgs a) {
   const float x = row_xf(G[0], G[4], G[8], G[12], s.x, s.y, s.z);
   const float y = row_xf(G[1], G[5], G[9], G[13], s.x, s.y, s.z);
   const float z = row_xf(G[2], G[6], G[10], G[14], s.x, s.y, s.z);
-  const unsigned long long key = grid_nn27(a, x, y, z, lane16);
+  const unsigned long long key = grid_nn27_flat<kGridLanes>(a, x, y, z, lane16);
   if (lane16 == 0 && key != ~0ull) a.ws_key[(size_t)pose * a.n_src + i] = key;
 }
 
@@ -1170,9 +1235,17 @@ struct SceneArgs {
   int n_chunks, n_units, n_units16, n_blk;
   int poll_sleep;             // s_sleep argument between two polls of a pose's state word
   int n_upd;                  // workgroups 0 .. n_upd-1 are updaters (pose p: updater p % n_upd), the rest workers
+  unsigned long long* dbg;    // PGP_SCENE_STAMPS builds: [64 iterations][16] clock stamps (100 MHz) of updater 0 and of three workers
 };
+#ifdef PGP_SCENE_STAMPS
+#define SCENE_STAMP(slot) do { if (it < 64) z.dbg[it * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SCENE_STAMP(slot) do { } while (0)
+#endif
 constexpr int kSceneThreads = 256;
-constexpr int kSceneQ = kSceneThreads / kGridLanes;   // queries per chunk
+constexpr int kSceneLanes = 8;                         // lanes per query (grid_nn27_flat)
+constexpr int kSceneQ = kSceneThreads / kSceneLanes;   // queries per chunk: 32
+constexpr int kSceneCpu = 256 / kSceneQ;               // chunks per unit: 8
 
 template <class T>
 __device__ __forceinline__ T agent_load(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1200,69 +1273,76 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
   __shared__ int s_flag[2];
   __shared__ double s_sum[kRedPlane + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  static_assert(kSumR == 4 && kSceneQ * 16 == 256, "a unit is one wave of icp_sums_partial: 64 lanes x 4 consecutive points");
+  static_assert(kSumR == 4 && kSceneQ * kSceneCpu == 256, "a unit is one wave of icp_sums_partial: 64 lanes x 4 consecutive points");
   if ((int)blockIdx.x < z.n_upd) {
     // ================= updater =================
-    if (wave != 0) return;
+    __shared__ double s_blk[8][kRedPlane + 1];   // the block sums of one pass (eight blocks), formed by four waves
+    __shared__ int s_upd[2];
     for (int it = 0;; ++it) {
       bool any = false;
       for (int pose = blockIdx.x; pose < a.n; pose += z.n_upd) {
+        // (this workgroup's own last publication: the same answer in every wave)
         unsigned st = agent_load(&z.state[(size_t)pose * kSceneRep * kSceneRepStride]);
         if (st >> 31) continue;
         any = true;
         // ---- every unit of the pose has arrived (their sums are in memory: written through before the arrival)
         const unsigned target = (unsigned)z.n_units * (unsigned)(it + 1);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        bool lost = false;
-        while (agent_load(&z.pose_ctr[pose]) < target) {
-          __builtin_amdgcn_s_sleep(4);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz: cannot happen with every workgroup resident
-            lost = true;
-            break;
+        if (tid == 0) {
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          int lost = 0;
+          while (agent_load(&z.pose_ctr[pose]) < target) {
+            __builtin_amdgcn_s_sleep(4);
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz: cannot happen with every workgroup resident
+              lost = 1;
+              break;
+            }
           }
+          s_upd[0] = lost;
         }
-        if (lost) {
-          if (lane == 0) {
+        __syncthreads();
+        if (s_upd[0]) {
+          if (tid == 0) {
             agent_store(z.lost, 1u);
             if (a.iters) a.iters[pose] = -1;
           }
-          if (lane < kSceneRep) agent_store(&z.state[((size_t)pose * kSceneRep + lane) * kSceneRepStride], 0x80000000u);
+          if (tid < kSceneRep) agent_store(&z.state[((size_t)pose * kSceneRep + tid) * kSceneRepStride], 0x80000000u);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();   // (every wave reads the state word at the top of the next pass)
           continue;
         }
-        if (lane < 16) s_G[lane] = agent_load(&a.T[16 * (size_t)pose + lane]);
+        if (tid == 0 && pose == 0) SCENE_STAMP(0);   // every unit has arrived
+        if (tid < 16) s_G[tid] = agent_load(&a.T[16 * (size_t)pose + tid]);
         // ---- the pose's sums: icp_sums_partial adds its 16 waves in order from 0.0, icp_refine<true, true> the blocks in
-        // order from 0.0.  Lane k + 32 (b & 1) adds the waves of block b, two blocks per pass; lane k then adds the blocks.
-        {
-          const int k = lane & 31, half = lane >> 5;
-          double total = 0.0;
-          for (int bb = 0; bb < z.n_blk; bb += 2) {
-            const int b = bb + half;
-            double w16[16];
+        // order from 0.0.  Eight blocks per pass: lane k + 32 (b & 1) of wave b / 2 adds the sixteen wave sums of block b
+        // (their loads in flight together); thread k then adds the pass's blocks in order.
+        double total = 0.0;
+        for (int bb = 0; bb < z.n_blk; bb += 8) {
+          const int k = lane & 31, b = bb + 2 * wave + (lane >> 5);
+          double w16[16];
 #pragma unroll
-            for (int w = 0; w < 16; ++w)
-              w16[w] = (b < z.n_blk && k <= kRedPlane) ? agent_load(&z.W[((size_t)pose * z.n_units16 + 16 * b + w) * kPartStride + k]) : 0.0;
-            double v = 0.0;
+          for (int w = 0; w < 16; ++w)
+            w16[w] = (b < z.n_blk && k <= kRedPlane) ? agent_load(&z.W[((size_t)pose * z.n_units16 + 16 * b + w) * kPartStride + k]) : 0.0;
+          double v = 0.0;
 #pragma unroll
-            for (int w = 0; w < 16; ++w) v += w16[w];
-            const double v_hi = __shfl(v, k + 32, 64);   // block bb + 1 (lanes 32..63)
-            if (half == 0) {
-              total += v;
-              if (bb + 1 < z.n_blk) total += v_hi;
-            }
-          }
-          if (lane <= kRedPlane) s_sum[lane] = total;
+          for (int w = 0; w < 16; ++w) v += w16[w];
+          if (k <= kRedPlane) s_blk[b - bb][k] = v;
+          __syncthreads();
+          if (tid <= kRedPlane)
+            for (int q = 0; q < 8 && bb + q < z.n_blk; ++q) total += s_blk[q][tid];
+          __syncthreads();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid <= kRedPlane) s_sum[tid] = total;
+        __syncthreads();
         // ---- closed-form update and the progress tests (icp_refine's, thread 0's)
         int go_i = 0;
-        if (lane == 0) {
+        if (tid == 0 && pose == 0) SCENE_STAMP(1);   // sums added
+        if (tid == 0) {
           const double* red = s_sum;
           const double E = red[0] >= 1.0 ? red[kRedPlane] / red[0] : 0.0;
           for (int q = 0; q < 16; ++q) s_G_old[q] = s_G[q];
           if constexpr (METRIC == 1) solve_plane(red, s_G);
           else solve_rigid(red, s_G);
+          if (pose == 0) SCENE_STAMP(2);   // solved
           const double E_old = it == 0 ? (double)FLT_MAX : z.E_old[pose];   // PCL: energy starts at numeric_limits<float>::max()
           bool go = it + 1 < a.max_iter;
           if (a.ratio > 0.f && !(E / E_old < (double)a.ratio)) go = false;
@@ -1274,16 +1354,18 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
             if (a.iters) a.iters[pose] = it + 1;
           }
           go_i = go ? 1 : 0;
+          s_upd[1] = go_i;
         }
-        go_i = __builtin_amdgcn_readfirstlane(go_i);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (lane < 16) agent_store(&a.T[16 * (size_t)pose + lane], s_G[lane]);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        go_i = s_upd[1];
+        if (tid < 16) agent_store(&a.T[16 * (size_t)pose + tid], s_G[tid]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (wave 0 holds both the transform's stores and the state's)
         // every copy of the state word by ONE store instruction, a line each
-        if (lane < kSceneRep)
-          agent_store(&z.state[((size_t)pose * kSceneRep + lane) * kSceneRepStride], (unsigned)(it + 1) | (go_i ? 0u : 0x80000000u));
+        if (tid < kSceneRep)
+          agent_store(&z.state[((size_t)pose * kSceneRep + tid) * kSceneRepStride], (unsigned)(it + 1) | (go_i ? 0u : 0x80000000u));
+        if (tid == 0 && pose == 0) SCENE_STAMP(3);   // published
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();   // (every wave reads the state word at the top of the next pass)
       }
       if (!any) break;
     }
@@ -1296,6 +1378,9 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
     bool any = false;
     for (int item = me; item < items; item += n_work) {
       const int pose = item / z.n_chunks, chunk = item - pose * z.n_chunks;
+      // (the chunk's source point does not depend on the transform: its round trip passes under the wait)
+      const int qi = chunk * kSceneQ + tid / kSceneLanes, laneL = tid & (kSceneLanes - 1);
+      const float4 sq = a.src[min(qi, a.n_src - 1)];
       // ---- the pose's transform of this iteration: published by the updater when it closed the previous one
       if (tid == 0) {
         unsigned st = 0;
@@ -1313,31 +1398,45 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
       }
       __syncthreads();
       const bool pose_done = s_flag[0] != 0;
+#ifdef PGP_SCENE_STAMPS
+      const int dslot = me == 0 ? (item == me ? 4 : 8) : -1;
+      if (tid == 0 && dslot >= 0) SCENE_STAMP(dslot);       // the state word said go
+      if (tid == 0 && it == 10 && me < 2048) z.dbg[1024 + me] = __builtin_amdgcn_s_memrealtime();   // every worker's go
+#endif
       if (!pose_done && tid < 16) s_G[tid] = agent_load(&a.T[16 * (size_t)pose + tid]);
       __syncthreads();   // (also: everybody has read s_flag[0] before thread 0 writes it again)
       if (pose_done) continue;
       any = true;
       // ---- 1. the chunk's correspondences (icp_nn_grid's arithmetic)
       {
-        const int i = chunk * kSceneQ + (tid >> 4), lane16 = tid & (kGridLanes - 1);
-        if (i < a.n_src) {
-          const float4 s = a.src[i];
+        const int i = qi;
+        if (i < a.n_src) {   // whole groups: a group's lanes share i
+          const float4 s = sq;
           const float x = row_xf(s_G[0], s_G[4], s_G[8], s_G[12], s.x, s.y, s.z);
           const float y = row_xf(s_G[1], s_G[5], s_G[9], s_G[13], s.x, s.y, s.z);
           const float zq = row_xf(s_G[2], s_G[6], s_G[10], s_G[14], s.x, s.y, s.z);
-          const unsigned long long key = grid_nn27(a, x, y, zq, lane16);
-          if (lane16 == 0) agent_store(&z.keys[(size_t)pose * a.n_src + i], key);
+          const unsigned long long key = grid_nn27_flat<kSceneLanes, 4>(a, x, y, zq, laneL);
+          if (laneL == 0) agent_store(&z.keys[(size_t)pose * a.n_src + i], key);
         }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's keys have left ...
       __syncthreads();                                    // ... and so have every wave's, before the chunk's ticket
-      const int u = chunk >> 4;
+#ifdef PGP_SCENE_STAMPS
+      if (tid == 0 && dslot >= 0) SCENE_STAMP(dslot + 1);   // searched, keys out
+      if (tid == 0 && it == 10 && me < 2048) z.dbg[1024 + 2048 + me] = __builtin_amdgcn_s_memrealtime();   // every worker's chunk searched
+#endif
+      const int u = chunk / kSceneCpu;
       if (tid == 0) {
-        const unsigned per = (unsigned)min(16, z.n_chunks - 16 * u);
+        const unsigned per = (unsigned)min(kSceneCpu, z.n_chunks - kSceneCpu * u);
         const unsigned old = __hip_atomic_fetch_add(&z.unit_ctr[(size_t)pose * z.n_units16 + u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_flag[1] = old + 1u == per * (unsigned)(it + 1) ? 1 : 0;
       }
       __syncthreads();
+#ifdef PGP_SCENE_STAMPS
+      if (tid == 0 && dslot >= 0) SCENE_STAMP(dslot + 2);   // ticket drawn
+#endif
+#ifdef PGP_SCENE_STAMPS
+#endif
       if (!s_flag[1] || wave != 0) continue;   // (the other waves wait at the next item's barrier while wave 0 closes the unit)
       // ---- 2. the unit's sums: lane l holds the points 256 u + 4 l .. + 3, as thread 64 w + l of icp_sums_partial does
       const int b0 = 256 * u;
@@ -1395,13 +1494,21 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
       for (int k = 0; k < kNs; ++k) acc[k] = wave_sum_f64(acc[k]);
       e_acc = wave_sum_f64(e_acc);
       double* Wu = z.W + ((size_t)pose * z.n_units16 + u) * kPartStride;
-      if (lane == 0) {
+      {
+        // every lane holds every sum (wave_sum_f64): lane k stores sum k -- ONE store instruction over three lines instead
+        // of 29 single-lane write-through stores, each a fabric write of its own
+        double mine = lane == kRedPlane ? e_acc : 0.0;
 #pragma unroll
-        for (int k = 0; k < kRedPlane; ++k) agent_store(&Wu[k], k < kNs ? acc[k < kNs ? k : 0] : 0.0);
-        agent_store(&Wu[kRedPlane], e_acc);
+        for (int k = 0; k < kNs; ++k) mine = lane == k ? acc[k] : mine;
+        if (lane <= kRedPlane) agent_store(&Wu[lane], mine);
       }
+#ifdef PGP_SCENE_STAMPS
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the unit's sums have left before its arrival is counted
       if (lane == 0) __hip_atomic_fetch_add(&z.pose_ctr[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef PGP_SCENE_STAMPS
+      if (lane == 0 && it < 64) atomicMax(&z.dbg[it * 16 + 12], __builtin_amdgcn_s_memrealtime());   // the LAST unit closed (any worker)
+#endif
     }
     if (!any) break;
   }
@@ -3542,6 +3649,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       z.E_old = reinterpret_cast<double*>(xb + w_bytes + uc_bytes + pc_bytes + st_bytes);
       z.lost = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(z.E_old) + eo_bytes);
       z.keys = a.ws_key;
+#ifdef PGP_SCENE_STAMPS
+      static unsigned long long* d_dbg = nullptr;
+      if (!d_dbg) PGP_HIP(hipMalloc(&d_dbg, (1024 + 4096) * 8));
+      PGP_HIP(hipMemsetAsync(d_dbg, 0, (1024 + 4096) * 8, stream));
+      z.dbg = d_dbg;
+#endif
       PGP_HIP(hipMemsetAsync(xb, 0, w_bytes + uc_bytes + tail, stream));
       int per_cu = 0;
       const void* fn_scene = a.metric == 1 ? reinterpret_cast<const void*>(icp_scene_persist<1>) : reinterpret_cast<const void*>(icp_scene_persist<0>);
@@ -3563,6 +3676,40 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (e == hipSuccess) {
         PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
         PGP_HIP(hipGetLastError());
+#ifdef PGP_SCENE_STAMPS
+        {
+          std::vector<unsigned long long> h(1024 + 4096);
+          PGP_HIP(hipStreamSynchronize(stream));
+          PGP_HIP(hipMemcpy(h.data(), d_dbg, (1024 + 4096) * 8, hipMemcpyDeviceToHost));
+          {   // iteration 10: every worker's go and searched times relative to the publication of iteration 9
+            const unsigned long long pub = h[9 * 16 + 3];
+            std::vector<double> go, se;
+            for (int w = 0; w < 2048; ++w)
+              if (h[1024 + w]) {
+                go.push_back((double)((long long)(h[1024 + w] - pub)) * 0.01);
+                se.push_back((double)((long long)(h[1024 + 2048 + w] - pub)) * 0.01);
+              }
+            if (!go.empty()) {
+              auto pct = [](std::vector<double> v, double p) { std::sort(v.begin(), v.end()); return v[(size_t)(p * (v.size() - 1))]; };
+              fprintf(stderr, "iteration 10, %zu workers: go min %.2f median %.2f p90 %.2f max %.2f | searched min %.2f median %.2f p90 %.2f p99 %.2f max %.2f us\n",
+                      go.size(), pct(go, 0), pct(go, 0.5), pct(go, 0.9), pct(go, 1), pct(se, 0), pct(se, 0.5), pct(se, 0.9), pct(se, 0.99), pct(se, 1));
+              int slow = 0;
+              for (size_t w = 0; w < se.size() && slow < 12; ++w)
+                if (se[w] > pct(se, 0.97)) { fprintf(stderr, "  worker %zu: go %.2f searched %.2f\n", w, go[w], se[w]); ++slow; }
+            }
+          }
+          // per iteration, in 10 ns ticks relative to the previous publication: worker 0's two chunks (go, searched, ticket),
+          // the last unit closed, the updater (units in, sums added, solved, published)
+          unsigned long long prev = h[4];
+          for (int it = 0; it < 64 && h[it * 16 + 3]; ++it) {
+            const unsigned long long* r = &h[it * 16];
+            auto d = [&](unsigned long long v) { return v ? (double)((long long)(v - prev)) * 0.01 : -1.0; };
+            fprintf(stderr, "it %2d  w0 chunk A: go %6.2f searched %6.2f ticket %6.2f | last unit closed %6.2f | updater: units in %6.2f summed %6.2f solved %6.2f "
+                            "published %6.2f us\n", it, d(r[4]), d(r[5]), d(r[6]), d(r[12]), d(r[0]), d(r[1]), d(r[2]), d(r[3]));
+            prev = r[3];
+          }
+        }
+#endif
         return PGP_OK;
       }
       (void)hipGetLastError();   // not launchable cooperatively here: the host-driven iterations
