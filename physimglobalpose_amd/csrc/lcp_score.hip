@@ -43,6 +43,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#if defined(PGP_CAND8) && PGP_CAND8
+#include <hip/hip_fp16.h>
+#include <map>
+#endif
 
 namespace pgp {
 
@@ -495,6 +499,45 @@ __global__ __launch_bounds__(kTile) void score_hypotheses(ScoreArgs a) {
   }
 }
 
+#if defined(PGP_CAND8) && PGP_CAND8
+// ---- the candidate FORMAT experiment (VERDICT r4 task 4; build knob PGP_CAND8, `make variantf FILE=lcp_score`) ----
+// 8-byte candidates instead of the 16-byte float4 {x, y, z, id}: three fp16 offsets from the CENTRE of the cell whose list the
+// candidate sits in + a 16-bit scene index -- half the candidate footprint (22.6 -> 11.3 MB at C2), so that finer cells fit the
+// footprint the 0.85-delta grid has today.  The query is expressed relative to the same centre (two VALU per axis and trip),
+// a candidate is decoded with three conversions and two shifts.  fp16 offsets carry ~4 um of error at these cell sizes:
+// inlier decisions next to the radius can differ from the exact kernel's, so this is a TIMING AND COUNTER experiment, not a
+// product path (a product would keep this test as a conservative reject and re-test survivors on the float4 array).
+// Scenes of at most 65 535 points, dense block array, flat kernels only.
+__device__ __forceinline__ float4 cand8_fetch(const float4* __restrict__ cand, uint32_t idx) {
+  const uint2 raw = reinterpret_cast<const uint2*>(cand)[idx];
+  const float hx = __half2float(__ushort_as_half((unsigned short)(raw.x & 0xFFFFu)));
+  const float hy = __half2float(__ushort_as_half((unsigned short)(raw.x >> 16)));
+  const float hz = __half2float(__ushort_as_half((unsigned short)(raw.y & 0xFFFFu)));
+  return make_float4(hx, hy, hz, __int_as_float((int)(raw.y >> 16)));
+}
+
+__global__ __launch_bounds__(256) void pack_cand8(GridDesc g, const uint2* __restrict__ words, const uint2* __restrict__ occ_run,
+                                                  const float4* __restrict__ cand, uint2* __restrict__ out, uint32_t n_words) {
+  const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t wi = tid >> 5, bit = tid & 31u;
+  if (wi >= n_words) return;
+  const uint2 w = words[wi];
+  if (!((w.x >> bit) & 1u)) return;
+  const uint2 run = occ_run[w.y + __popc(w.x & ((1u << bit) - 1u))];
+  const uint32_t bx = wi % (uint32_t)g.nbx, by = (wi / (uint32_t)g.nbx) % (uint32_t)g.nby, bz = wi / ((uint32_t)g.nbx * (uint32_t)g.nby);
+  // lattice numbers of the cell: round(p * inv_h) for the points inside it (grid_index.hip); the centre is L * h
+  const float Lx = (float)((int)(4u * bx + (bit & 3u)) + g.k0x), Ly = (float)((int)(4u * by + ((bit >> 2) & 3u)) + g.k0y),
+              Lz = (float)((int)(2u * bz + (bit >> 4)) + g.k0z);
+  const float cx = Lx * g.h, cy = Ly * g.h, cz = Lz * g.h;
+  for (uint32_t k = 0; k < run.y; ++k) {
+    const float4 p = cand[run.x + k];
+    const unsigned hx = __half_as_ushort(__float2half_rn(p.x - cx)), hy = __half_as_ushort(__float2half_rn(p.y - cy)),
+                   hz = __half_as_ushort(__float2half_rn(p.z - cz));
+    out[run.x + k] = make_uint2(hx | (hy << 16), hz | ((unsigned)__float_as_int(p.w) << 16));
+  }
+}
+#endif
+
 // ---- wave-flattened candidate phase --------------------------------------------------------------
 // What binds the per-lane kernel above (profiles/r01_c_*): the vector L1 is busy for the whole
 // kernel (TCP_GATE_EN ~ kernel duration) at ~25 busy cycles per vector-memory WAVE-INSTRUCTION,
@@ -561,6 +604,8 @@ __device__ __forceinline__ void flat_batch(const ScoreArgs& a, const float4* __r
   for (int c = 0; c < NC; ++c) {
 #if defined(PGP_ABLATE) && PGP_ABLATE == 1
     p[c] = cand[lane];            // timing experiment: one contiguous, always-cached 1 KB instead of the gather
+#elif defined(PGP_CAND8) && PGP_CAND8
+    p[c] = cand8_fetch(cand, __float_as_uint(en[c].w) + we[c]);   // the candidate FORMAT experiment (see cand8_fetch)
 #else
     p[c] = cand[__float_as_uint(en[c].w) + we[c]];
 #endif
@@ -749,6 +794,14 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       s = (uint32_t)rv;
       len = (uint32_t)(rv >> 32);
     }
+#if defined(PGP_CAND8) && PGP_CAND8
+    // the query relative to the centre of its cell: L = round(x * inv_h) sits in the clamped lattice word, centre = L * h
+    const float h_v = a.g.h;
+    const float xq = __fmaf_rn(-__fsub_rn(__uint_as_float(bx), a.cell_c[0]), h_v, x), yq = __fmaf_rn(-__fsub_rn(__uint_as_float(by), a.cell_c[1]), h_v, y),
+                zq = __fmaf_rn(-__fsub_rn(__uint_as_float(bz), a.cell_c[2]), h_v, z);
+#else
+    const float xq = x, yq = y, zq = z;
+#endif
     uint32_t rlo = kW ? 0xFFFFFFFFu : 0u;
     // Short trips (round 3, profiles/r03_ab/shortrun.log): when every run of the wave holds at most
     // PGP_SHORTRUN candidates, each owner lane tests its own -- no slot scan, no owner table, no LDS round
@@ -762,11 +815,15 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
         const uint32_t last = s + len - 1u;
         float4 pc[kShort > 0 ? kShort : 1];
 #pragma unroll
+#if defined(PGP_CAND8) && PGP_CAND8
+        for (int k = 0; k < kShort; ++k) pc[k] = cand8_fetch(cand, min(s + (uint32_t)k, last));
+#else
         for (int k = 0; k < kShort; ++k) pc[k] = cand[min(s + (uint32_t)k, last)];
+#endif
         unsigned long long best = ~0ull;
 #pragma unroll
         for (int k = 0; k < kShort; ++k) {
-          const float d2 = sqdist(x, y, z, pc[k]);
+          const float d2 = sqdist(xq, yq, zq, pc[k]);
           if (!kW) {
             if (d2 <= a.sq_eps) rlo = 1u;
           } else {
@@ -791,7 +848,7 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       const int r = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(am >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)am, 0u));
       if (occ) {
         // store (start - prefix) so that slot w maps to candidate (start - prefix) + w
-        ent[r] = make_float4(x, y, z, __uint_as_float(s - pre));
+        ent[r] = make_float4(xq, yq, zq, __uint_as_float(s - pre));
         res[r] = kW ? ~0ull : 0ull;
         if (TIES) res_hi[r] = ~0ull;
         atomicOr(&marks[pre >> 6], 1ull << (pre & 63u));
@@ -844,8 +901,8 @@ __device__ __forceinline__ void score_flat_body(const ScoreArgs& a, const float*
       }
     } else {
       // oversized wave-iteration (very dense scene): per-lane walk
-      if (!kW) rlo = any_in_run(cand, s, s + len, x, y, z, a.sq_eps) ? 1u : 0u;
-      else rlo = TIES ? (uint32_t)nearest_by_rule(a, s, s + len, x, y, z) : (uint32_t)nearest_in_run(cand, s, s + len, x, y, z, a.sq_eps);
+      if (!kW) rlo = any_in_run(a.cand, s, s + len, x, y, z, a.sq_eps) ? 1u : 0u;
+      else rlo = TIES ? (uint32_t)nearest_by_rule(a, s, s + len, x, y, z) : (uint32_t)nearest_in_run(a.cand, s, s + len, x, y, z, a.sq_eps);
     }
     }
     PGP_STAMP(t_f);   // results read back
@@ -1741,6 +1798,9 @@ float key2f(int32_t k) {
 // (hipExtLaunchKernelGGL) -- the kernel's own begin / end timestamps, without the two barrier
 // packets that hipEventRecord before and after the launch put on the stream (those cost the
 // C2 step 8 us, 7 % of its throughput, when per-kernel timing was on).
+#if defined(PGP_CAND8) && PGP_CAND8
+const float4* cand8_override = nullptr;   // experiment: the packed candidates of the context being launched
+#endif
 void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const ScoreArgs& a, hipEvent_t ev0,
                     hipEvent_t ev1, const FuseArgs& fz = FuseArgs{}) {
   // default by measurement at C2 (tools/tune.py): wave-flattened 112 us plain / 157 us weighted vs
@@ -1766,12 +1826,16 @@ void launch_variant(int mode, int unroll, dim3 grid, hipStream_t stream, const S
     return;
   }
   if (unroll <= 0 && a.g.magic_ok) {  // wave-flattened candidate phase (dense block array)
+    const float4* cand_arg = a.cand;
+#if defined(PGP_CAND8) && PGP_CAND8
+    cand_arg = cand8_override ? cand8_override : a.cand;
+#endif
     if (mode == PGP_MODE_PLAIN)
       hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_PLAIN>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a, a.T,
-                            a.words, a.occ_run, a.cand, a.Pnw, fz);
+                            a.words, a.occ_run, cand_arg, a.Pnw, fz);
     else
       hipExtLaunchKernelGGL(score_hypotheses_flat<PGP_MODE_WEIGHTED>, grid, dim3(kTile), 0, stream, ev0, ev1, 0, a,
-                            a.T, a.words, a.occ_run, a.cand, a.Pnw, fz);
+                            a.T, a.words, a.occ_run, cand_arg, a.Pnw, fz);
     return;
   }
 #define PGP_LAUNCH(M, UU) \
@@ -1909,6 +1973,30 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
     a.partial = ctx->d_partial.as<uint2>();
     int chunks_pad = (a.n_chunks + 7) / 8 * 8;
     dim3 grid((unsigned)(chunks_pad * a.n_tiles));
+#if defined(PGP_CAND8) && PGP_CAND8
+    {
+      // experiment only: the packed copy of this context's candidate lists, rebuilt when the index changed (recognised by
+      // its array, its size and the grid's origin); never freed
+      struct Packed { DevBuf buf; const void* cand = nullptr; long long n = -1; float ox = 0.f, h = 0.f; };
+      static std::map<pgp_ctx*, Packed> packed;
+      Packed& pk = packed[ctx];
+      cand8_override = nullptr;
+      if (!ctx->grid.sparse && ctx->grid.magic_ok && ctx->nP <= 65535 && !(ctx->exact_ties && ctx->kd_valid)) {
+        if (pk.cand != ctx->d_cand.p || pk.n != ctx->n_cand || pk.ox != ctx->grid.ox || pk.h != ctx->grid.h) {
+          if ((rc = finish_index(ctx)) != PGP_OK) return rc;
+          if ((rc = pk.buf.ensure(((size_t)ctx->n_cand + 256) * 8)) != PGP_OK) return rc;
+          const uint32_t n_words = (uint32_t)ctx->grid.nbx * (uint32_t)ctx->grid.nby * (uint32_t)ctx->grid.nbz;
+          hipLaunchKernelGGL(pack_cand8, dim3((unsigned)(((size_t)n_words * 32 + 255) / 256)), dim3(256), 0, stream, ctx->grid,
+                             (const uint2*)a.words, (const uint2*)a.occ_run, (const float4*)a.cand, pk.buf.as<uint2>(), n_words);
+          pk.cand = ctx->d_cand.p;
+          pk.n = ctx->n_cand;
+          pk.ox = ctx->grid.ox;
+          pk.h = ctx->grid.h;
+        }
+        cand8_override = reinterpret_cast<const float4*>(pk.buf.p);
+      }
+    }
+#endif
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing > 0 && (ctx->timing_seq++ % (unsigned)ctx->timing) == 0) {
       if (ctx->ev_used + 2 > ctx->ev.size()) {
