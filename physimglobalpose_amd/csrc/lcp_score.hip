@@ -1555,26 +1555,73 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
 __global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs a, int n_h, int mode, int refine,
                                                           float* scores, int* __restrict__ best,
                                                           float* __restrict__ seq) {
-  __shared__ unsigned long long s_key[4];
-  unsigned long long key = 0;
-  for (int h = threadIdx.x; h < n_h; h += blockDim.x) {
-    const float score = scores[h];
-    if (score > 0.f) {
-      const unsigned long long k = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
-      key = k > key ? k : key;
+  __shared__ unsigned long long s_key[4], s_key2[4];
+  unsigned long long key = 0, key2 = 0;   // this thread's best and second-best keys (keys > 0 are unique: they carry h)
+  // sixteen scores per thread in flight: ONE block walks the complete vector of a device group (65 536 scores at configs[3]),
+  // and one load per trip made that walk 256 dependent round trips -- ~60 us behind every exchange (round 5)
+  for (int h0 = threadIdx.x; h0 < n_h; h0 += 16 * (int)blockDim.x) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int h = h0 + u * (int)blockDim.x;
+      v[u] = h < n_h ? scores[h] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int h = h0 + u * (int)blockDim.x;
+      if (v[u] > 0.f) {   // (a slot past the end holds 0)
+        const unsigned long long k = ((unsigned long long)__float_as_uint(v[u]) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
+        if (k > key) {
+          key2 = key;
+          key = k;
+        } else if (k > key2) {
+          key2 = k;
+        }
+      }
     }
   }
+  // the block's top two: merge the lanes' pairs (the runner-up of a merge is the larger of the loser and the winner's second)
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {
-    unsigned long long o = __shfl_xor(key, off, 64);
-    key = o > key ? o : key;
+    const unsigned long long o = __shfl_xor(key, off, 64), o2 = __shfl_xor(key2, off, 64);
+    const unsigned long long hi = o > key ? o : key, lo = o > key ? key : o;
+    const unsigned long long s2 = o > key ? o2 : key2;   // the winner's own second
+    key = hi;
+    key2 = lo > s2 ? lo : s2;
   }
-  if ((threadIdx.x & 63) == 0) s_key[threadIdx.x >> 6] = key;
+  if ((threadIdx.x & 63) == 0) {
+    s_key[threadIdx.x >> 6] = key;
+    s_key2[threadIdx.x >> 6] = key2;
+  }
   __syncthreads();
-  key = s_key[0];
-  for (int w = 1; w < 4; ++w) key = s_key[w] > key ? s_key[w] : key;
+  key = 0;
+  key2 = 0;
+  for (int w = 0; w < 4; ++w) {
+    const unsigned long long a1 = s_key[w], a2 = s_key2[w];
+    if (a1 > key) {
+      key2 = key > a2 ? key : a2;
+      key = a1;
+    } else {
+      if (a1 > key2) key2 = a1;
+    }
+  }
   __syncthreads();
-  settle_and_publish(a, n_h, mode, refine, scores, key, best, seq, s_key);
+  // the walk of settle_and_publish over all scores (its count of the values within the tolerance of the maximum) only when the
+  // runner-up is within it -- the same decision finalize_scores takes from its two keys
+  const bool near_tie = mode == PGP_MODE_WEIGHTED && refine && key != 0ull && key2 != 0ull &&
+                        __uint_as_float((unsigned)(key2 >> 32)) >=
+                            __uint_as_float((unsigned)(key >> 32)) - refine_tol(__uint_as_float((unsigned)(key >> 32)), a.nQ);
+  if (near_tie) {
+    settle_and_publish(a, n_h, mode, refine, scores, key, best, seq, s_key);
+  } else if (threadIdx.x == 0) {
+    if (key == 0) {
+      best[0] = -1;
+      best[1] = 0;  // best_LCP_ = 0.0f
+    } else {
+      best[0] = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+      best[1] = (int)(unsigned)(key >> 32);
+    }
+  }
 }
 
 // ---- exact scores at every decision of the running-best walk (base.cc:1891-1908) ---------------------------

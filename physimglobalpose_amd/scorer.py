@@ -730,6 +730,8 @@ class MultiGpuScorer:
         self._h = h
         self.n_devices = int(self._lib.pgp_multi_size(h))
         self.nQ = 0
+        self._n_up = 0
+        self._n_up_obj = np.zeros(1, np.int32)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -770,6 +772,7 @@ class MultiGpuScorer:
         T = _f32(T, 16)
         _lib.check(self._lib.pgp_multi_upload(self._h, _fp(T), len(T)))
         self._n_up = len(T)
+        self._n_up_obj = np.array([len(T)], np.int32)
 
     def score_uploaded(self, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         s, c, bi, bs = self._out(self._n_up)
@@ -861,6 +864,7 @@ class MultiGpuScorer:
         Ts, n, ptrs = self._lists(T_per_object)
         _lib.check(self._lib.pgp_multi_upload_objects(self._h, ptrs, n.ctypes.data_as(_i), len(Ts)))
         self._n_up_obj = n
+        self._n_up = int(n.sum())
 
     def score_objects_uploaded(self, mode=PGP_MODE_PLAIN, gate_deg=30.0):
         n = self._n_up_obj

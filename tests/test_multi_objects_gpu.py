@@ -219,3 +219,46 @@ def test_congruent_sets_sharded_by_base(n, congruent_case, monkeypatch):
     with pytest.raises(PgpError):                      # object 0 holds no batch
         grp.congruent_batch_quads(0, np.array([[0, 0]], np.int32))
     grp.close()
+
+
+def test_error_paths_of_the_group_entry_points(monkeypatch):
+    """bad arguments and wrong states come back as error codes with a message (the node must never be taken down by a call)"""
+    import ctypes as C
+    from physimglobalpose_amd import _lib
+    from physimglobalpose_amd._lib import PgpError
+    L = _lib.load()
+    grp = _group(monkeypatch, 2, 2)
+    w = synth.make_workload(3000, 500, 40, config_id=81)
+    grp.init_object(0, w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    grp.init_object(1, w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    with pytest.raises(PgpError):                                   # more lists than objects
+        grp.score_objects([w.T, w.T, w.T], PGP_MODE_PLAIN)
+    with pytest.raises(PgpError):                                   # an object that does not exist
+        grp.init_object(7, w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    grp.upload_objects([w.T, w.T[:3]])
+    with pytest.raises(PgpError):                                   # the single-object call on a two-object batch
+        grp.score_uploaded(PGP_MODE_PLAIN)
+    a = grp.score_objects_uploaded(PGP_MODE_PLAIN)
+    assert len(a) == 2 and len(a[1][0]) == 3
+    grp.upload(w.T[:5])                                             # ... and back to one object
+    assert len(grp.score_uploaded(PGP_MODE_PLAIN)[0]) == 5
+    # an object without clouds: the scoring call says which member failed, and the group stays usable
+    grp.add_object()
+    with pytest.raises(PgpError):
+        grp.score_objects([w.T, w.T, w.T], PGP_MODE_PLAIN)
+    assert len(grp.score_objects([w.T, w.T], PGP_MODE_WEIGHTED, 30.0)) == 2
+    # ICP: nothing to do is not an error; a job with poses and no clouds is
+    assert grp.icp_refine([]) == []
+    arr = (_lib.MultiIcpJob * 1)()
+    arr[0] = _lib.MultiIcpJob(None, 0, None, 0, None, 3, None, None)
+    prm = _lib.IcpParams(10, 0.9, 0.0, 1.0)
+    assert L.pgp_multi_icp_refine(grp._h, arr, 1, C.byref(prm)) == -1 and b"bad job" in L.pgp_last_error()
+    # congruent sets: picks before a batch, a pick beyond the bases
+    with pytest.raises(PgpError):
+        grp.congruent_batch_quads(0, np.array([[0, 0]], np.int32))
+    lo, hi, n = (C.c_int * 4)(), (C.c_int * 4)(), C.c_int(0)
+    assert L.pgp_multi_flat_slices(None, 1, 0, 2, None, lo, hi, C.byref(n)) == -1
+    cnt = (C.c_int * 2)(5, -1)
+    ob = (C.c_int * 2)()
+    assert L.pgp_multi_flat_slices(cnt, 2, 0, 2, ob, lo, hi, C.byref(n)) == -1      # a negative count
+    grp.close()
