@@ -150,3 +150,33 @@ def test_bucketed_exchange_gathers_every_batch(bucket, n_batches):
         assert np.array_equal(vec, want), f"rank {rank}"
         j = b % bucket
         assert int(am[j]) == int(np.argmax(want))
+
+
+def test_native_flat_slices_equal_the_python_twin():
+    """pgp_multi_slice / pgp_multi_flat_slices (csrc/multi_gpu.hip: how the C-ABI group partitions the flat (object,
+    hypothesis), (job, pose) and base spaces) are pure host helpers: the same pieces as sharding.shard_bounds / flat_slices,
+    every unit covered exactly once, without a GPU."""
+    import ctypes as C
+    from physimglobalpose_amd import _lib
+    from physimglobalpose_amd.sharding import flat_slices, shard_bounds
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    cases = [[16384, 12288, 12288, 8192, 8192, 8192], [5, 0, 3], [0, 0], [1], [7, 1, 1, 1, 90]]
+    cases += [rng.integers(0, 50, rng.integers(1, 9)).tolist() for _ in range(40)]
+    for counts in cases:
+        n = len(counts)
+        arr = (C.c_int * n)(*counts)
+        for world in (1, 2, 3, 5, 8):
+            seen = []
+            for k in range(world):
+                lo, hi = C.c_int(), C.c_int()
+                assert L.pgp_multi_slice(sum(counts), k, world, C.byref(lo), C.byref(hi)) == 0
+                assert (lo.value, hi.value) == shard_bounds(sum(counts), k, world)
+                o, a, b = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+                m = C.c_int()
+                assert L.pgp_multi_flat_slices(arr, n, k, world, o, a, b, C.byref(m)) == 0
+                got = [(o[i], a[i], b[i]) for i in range(m.value)]
+                assert got == flat_slices(counts, k, world)
+                seen += [(obj, i) for obj, x, y in got for i in range(x, y)]
+            assert seen == [(obj, i) for obj, c in enumerate(counts) for i in range(c)]
+    assert L.pgp_multi_slice(10, 3, 3, C.byref(C.c_int()), C.byref(C.c_int())) == -1      # member index out of range
