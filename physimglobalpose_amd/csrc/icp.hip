@@ -3497,7 +3497,8 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     PGP_HIP(hipStreamSynchronize(stream));  // e0 is a stack temporary
     return PGP_OK;
   };
-  bool scene_persist = use_grid && n_blk > 1 && !(a.max_corr2 < 0.f && a.k_trim < a.n_src) && a.smooth == 0 && ctx->n_cus > 0;
+  // (up to 64 poses: the reference's call has one; the unit sums of many poses would be gigabytes)
+  bool scene_persist = use_grid && n_blk > 1 && !(a.max_corr2 < 0.f && a.k_trim < a.n_src) && a.smooth == 0 && ctx->n_cus > 0 && n <= 64;
   if (const char* v = getenv("PGP_ICP_PART")) scene_persist = scene_persist && atoi(v) != 0;
   if (const char* v = getenv("PGP_ICP_SCENE_PERSIST")) scene_persist = scene_persist && atoi(v) != 0;
   if (scene_persist) {

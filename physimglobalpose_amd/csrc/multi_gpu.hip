@@ -435,7 +435,7 @@ int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) 
   for (int o = 0; o < n_obj; ++o)
     if (n_h[o]) std::memcpy(static_cast<unsigned char*>(m->h_pin) + (size_t)off[o] * 64, T[o], (size_t)n_h[o] * 64);
   m->off = off;
-  return run_all(m, [m, nT, N, n_obj](int k) -> int {
+  rc = run_all(m, [m, nT, N, n_obj](int k) -> int {
     int lo, hi, r;
     slice_of(N, k, m->n, &lo, &hi);
     if ((r = m->d_T[k].ensure(nT)) != PGP_OK) return r;
@@ -455,6 +455,8 @@ int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) 
                              hipMemcpyHostToDevice, m->stream[k]));
     return PGP_OK;
   });
+  if (rc != PGP_OK) m->off.assign(2, 0);   // nothing usable is resident: a later *_uploaded call scores the empty batch
+  return rc;
 }
 
 }  // namespace
@@ -813,7 +815,13 @@ int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs
     if (np == 0) return PGP_OK;
     hipStream_t st = m->stream[k];
     std::vector<pgp_ctx*>& pool = m->ictx[(size_t)k];
-    while ((int)pool.size() < n_jobs) {   // job j's target index lives in the member's context j, from call to call
+    // Every piece needs a context of its own (a context stages ONE job and keeps ONE target index).  Up to kIcpSlots jobs,
+    // job j uses the member's context j, so that its target's index stays resident from call to call; beyond that the pieces
+    // take the contexts in order (a target is then recognised by its hash, and rebuilt when the slot held another one).
+    constexpr int kIcpSlots = 32;
+    const bool by_job = n_jobs <= kIcpSlots;
+    const int want = by_job ? n_jobs : std::min(np, n_jobs);
+    while ((int)pool.size() < want) {
       pgp_ctx* c = nullptr;
       if ((r = pgp_create(&c, m->dev[k])) != PGP_OK) return r;
       pool.push_back(c);
@@ -822,7 +830,7 @@ int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs
     std::vector<IcpJob> dj((size_t)np);
     for (int p = 0; p < np; ++p) {
       const pgp_multi_icp_job& q = jobs[pj[(size_t)p]];
-      pgp_ctx* c = pool[(size_t)pj[(size_t)p]];
+      pgp_ctx* c = pool[(size_t)(by_job ? pj[(size_t)p] : p)];
       const int n = phi[(size_t)p] - plo[(size_t)p];
       if ((r = icp_host_stage(c, q.src_xyz, q.n_src, q.tgt_xyz, q.n_tgt, q.T + 16 * (size_t)plo[(size_t)p], n, st, &stage[(size_t)p])) != PGP_OK)
         return r;

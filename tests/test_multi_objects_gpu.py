@@ -262,3 +262,22 @@ def test_error_paths_of_the_group_entry_points(monkeypatch):
     ob = (C.c_int * 2)()
     assert L.pgp_multi_flat_slices(cnt, 2, 0, 2, ob, lo, hi, C.byref(n)) == -1      # a negative count
     grp.close()
+
+
+def test_icp_pose_shards_with_more_jobs_than_context_slots(monkeypatch):
+    """beyond 32 jobs the members' ICP contexts are taken by piece, not by job: 40 small jobs, two targets alternating, so a
+    slot meets a different target from one piece to the next -- still the bits of one pgp_icp_refine per job"""
+    grp = _group(monkeypatch, 3)
+    base = [_problem(300 + k, 1200, 500, 3, rot_deg=3.0, trans=0.004) for k in range(2)]
+    rng = np.random.default_rng(9)
+    jobs = []
+    for j in range(40):
+        S, M, N, G = base[j % 2]
+        jobs.append((S, M, G[: 1 + j % 3] + np.float32(0)))
+    one = LcpScorer(0)
+    ref = [one.icp_refine(S, M, G, trim=0.9, max_iterations=20) for S, M, G in jobs]
+    for rep in range(2):
+        got = grp.icp_refine(jobs, trim=0.9, max_iterations=20)
+        for j, (r, q) in enumerate(zip(ref, got)):
+            assert all(np.array_equal(x, y) for x, y in zip(r, q)), (rep, j)
+    grp.close()
