@@ -1725,6 +1725,9 @@ __device__ __forceinline__ NnBox nn_box(const NnGeom& g, float x, float y, float
 
 // Phase A helpers.  nn_class: the cost class (0 cheapest .. 14) of the row search that starts from the bound d2.
 __device__ __forceinline__ int nn_cost(const NnBox& b) { return (b.y1 - b.y0 + 1) * (b.z1 - b.z0 + 1) * (((b.x1 - b.x0) >> 2) + 3); }
+// (round 5, tools/icp_lane_balance.py: the dearest lane of a wave-pass carries about twice the mean lane's work; ordering
+// the queries of a class by the next two bits of their cost did not change that -- neighbouring queries' costs differ by
+// their ROW lengths, which the box cost does not see -- and timed equal or slower: profiles/r05_ab/icp_lane_balance.log)
 __device__ __forceinline__ int nn_class(const NnGeom& g, float x, float y, float z, float bound_d2) {
   const NnBox b = nn_box(g, x, y, z, bound_d2);
   const int cost = nn_cost(b);   // rows x (row overhead + cells)
@@ -1773,11 +1776,12 @@ __device__ __forceinline__ bool nn_vic_check(const NnLds& t, const uint4 rec, fl
 // lane `sub` takes the rows sub, sub + L, ... of the search box (or, without a bound, every L-th target
 // point); the group's results are merged by the caller.  The row loop is the cost of a far query
 // (~(2U/h + 1)^2 pi/4 rows): everything in it works in CELL UNITS on values prepared once per query.
-__device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n_tgt, float x, float y, float z,
-                                          int sub, int L, unsigned long long& best, int& bpos) {
+// (returns the lane's work in instruction units -- ~45 per row, ~12 per point -- in PGP_ICP_STAMPS builds, 0 otherwise)
+__device__ __forceinline__ unsigned nn_search(const NnGeom& g, const NnLds& t, int n_tgt, float x, float y, float z,
+                                              int sub, int L, unsigned long long& best, int& bpos) {
   if (bpos < 0) {
     for (int k = sub; k < n_tgt; k += L) nn_consider(x, y, z, t.pts[k], k, best, bpos);
-    return;
+    return 0u;
   }
   const float bound = __uint_as_float((unsigned)(best >> 32));
   const NnBox b = nn_box(g, x, y, z, bound);
@@ -1846,6 +1850,11 @@ __device__ __forceinline__ void nn_search(const NnGeom& g, const NnLds& t, int n
     atomicAdd(&t.dbg[3], 1u);
     if (sub == 0) atomicAdd(&t.dbg[4], 1u);
   }
+#endif
+#ifdef PGP_ICP_STAMPS
+  return 45u * dbg_rows + 12u * dbg_pts;
+#else
+  return 0u;
 #endif
 }
 
@@ -2381,6 +2390,9 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     const bool valid = sl < n_slots;
     unsigned long long best = kNnNone;
     int bpos = -1;
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 6
+    unsigned lane_cost = 0;
+#endif
     const int q = nq, lg = valid ? nlg : 0, sub = nsub;
     const float4 s = ns;
     fetch(sl + NT);
@@ -2390,8 +2402,27 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       const unsigned pp = t.pos[q];
       bpos = pp == 0xFFFFu ? -1 : (int)pp;
       if (bpos >= 0) best = ((unsigned long long)__float_as_uint(t.d2[q]) << 32) | (unsigned)__float_as_int(t.pts[bpos].w);
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 6
+      lane_cost = nn_search(a.nn, t, a.n_tgt, x, y, z, sub, 1 << lg, best, bpos);
+#else
       nn_search(a.nn, t, a.n_tgt, x, y, z, sub, 1 << lg, best, bpos);
+#endif
     }
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 6
+    {   // how well a wave's lanes are balanced: the wave pays its dearest lane, 64 times
+      unsigned mx = lane_cost, sm = lane_cost;
+      for (int off = 32; off >= 1; off >>= 1) {
+        mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+        sm += (unsigned)__shfl_xor((int)sm, off, 64);
+      }
+      if ((tid & 63) == 0 && t.dbg && sm > 0) {
+        atomicAdd(&t.dbg[0], mx);          // critical path of the wave-pass (instruction units)
+        atomicAdd(&t.dbg[1], sm / 64u);    // what a perfectly balanced wave would pay
+        atomicAdd(&t.dbg[2], 1u);
+      }
+      lane_cost = 0;
+    }
+#endif
     // merge the lanes of a group: class regions start at multiples of their group size, so the partners
     // lane ^ off (off < L) work on the same query
     // (most waves hold single-lane queries only: no exchange at all)

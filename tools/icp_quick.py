@@ -1,6 +1,7 @@
 """Quick ICP timing of the default path only (tools/icp_time.py without the checker paths).
 usage: python tools/icp_quick.py [iterations] [reps]"""
-import sys, os, time
+import sys, os, time, gc
+gc.disable()   # a full collector pass (tens of ms, about every fifty calls) is not the library's time: tools/icp_hiccup_probe.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 from physimglobalpose_amd import LcpScorer, synth

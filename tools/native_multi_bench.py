@@ -26,11 +26,15 @@ def _group(args, n_objects=1):
 
 
 def _time(fn, reps):
+    import gc
     fn()
+    gc.disable()   # one full pass of the cycle collector is tens of milliseconds (tools/icp_hiccup_probe.py)
     t0 = time.perf_counter()
     for _ in range(reps):
         r = fn()
-    return (time.perf_counter() - t0) / reps, r
+    dt = (time.perf_counter() - t0) / reps
+    gc.enable()
+    return dt, r
 
 
 def objects_row(args, mode):
