@@ -67,7 +67,13 @@ namespace pgp {
 
 namespace {
 
-constexpr int kIcpThreads = 1024;
+#ifndef PGP_ICP_THREADS
+#define PGP_ICP_THREADS 1024   // A/B knob (round 5): 512 = 256 registers per lane, twice the points per thread (results' low bits differ:
+#endif                         // the sums' tree follows the thread count) -- profiles/r05_ab/icp_512_threads.log
+constexpr int kIcpThreads = PGP_ICP_THREADS;
+constexpr int kIcpBase = 1024;           // the points-per-thread classes below are in units of this many points
+constexpr int kPS = kIcpBase / kIcpThreads;
+static_assert(kIcpThreads == 1024 || kIcpThreads == 512, "workgroup shapes of the ICP kernels");
 constexpr int kIcpR = 4;                 // source points per lane per sweep
 constexpr int kTgtTile = 4096;           // target points per LDS tile (64 KB)
 constexpr int kRedPlane = 28;            // point-to-plane: count + 21 (upper triangle of AtA) + 6 (Atb)
@@ -1684,7 +1690,7 @@ struct NnLds {
 #endif
 };
 constexpr int kNnClasses = 16;
-constexpr int kNnStrips = 512;                       // runs of neighbouring cells a class is subdivided into
+constexpr int kNnStrips = 512 / kPS;                 // runs of neighbouring cells a class is subdivided into (8 counters per thread, 16 classes)
 constexpr int kNnBins = kNnClasses * kNnStrips;      // 16 KB of 16-bit counters
 
 // (d2, original index) as ONE unsigned 64-bit key: d2 >= +0, so the float bits order like the values,
@@ -1802,6 +1808,8 @@ __device__ __forceinline__ unsigned nn_search(const NnGeom& g, const NnLds& t, i
 #ifdef PGP_ICP_STAMPS
   unsigned dbg_rows = 0, dbg_live = 0, dbg_pts = 0;
 #endif
+  // (round 5: the same loop one row ahead -- the next row's chord cut with the bound before this row's points, its two `start`
+  // reads in flight beside this row's point reads -- timed equal on every row of tools/icp_quick.py: profiles/r05_ab/icp_lane_balance.log)
   while (cz <= b.z1) {
 #ifdef PGP_ICP_STAMPS
     ++dbg_rows;
@@ -2236,8 +2244,9 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     unsigned base = 0;
     for (int wv = 0; wv < (tid >> 6); ++wv) base += sch->wave_sum[wv];
     unsigned e = base + incl - mine;   // queries in front of this thread's first bin
-    // a class owns 512 bins = 64 threads = one wave: its first thread holds the class offset
-    if ((tid & 63) == 0) sch->cnt[kNnClasses - 1 - (tid >> 6)] = e;
+    // a class owns 512 bins = 64 threads = one wave (1024 threads): its first thread holds the class offset
+    constexpr int kTpc = kNnStrips / 8;
+    if ((tid & (kTpc - 1)) == 0) sch->cnt[kNnClasses - 1 - tid / kTpc] = e;
     uint4 o4;
     o4.x = e | ((e + c0) << 16);
     e += c0 + c1;
@@ -2463,7 +2472,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
 
 // Split-path correspondences through the index: grid (source chunks of 1024, poses); the workgroup
 // copies the image into LDS and answers its 1024 queries.  Same keys as icp_nn_split.
-constexpr int kIdxThreads = 1024;
+constexpr int kIdxThreads = kIcpThreads;   // (shares the sort of nn_all_queries, whose bins follow the thread count)
 template <bool IMG_LDS>
 __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2494,7 +2503,7 @@ __global__ __launch_bounds__(kIdxThreads) void icp_nn_index(IcpArgs a) {
 // (the target points of the sums are read from the image).  Selection, sums, their reduction tree,
 // the closed-form update and the stop rules are those of icp_refine, operation for operation: the two
 // kernels (and the exhaustive searches) give bit-identical transforms, energies and iteration counts.
-constexpr int kPiR = 4;   // source points per thread: n_src <= 4096
+constexpr int kPiR = 4 * kPS;   // source points per thread: n_src <= 4096
 constexpr int kSelRank = 512;   // keys of the threshold's 12-bit bin that are ranked by comparison (else: 8-bit radix passes)
 // CLUSTER = false: one workgroup per pose, the meeting code (and its arguments) compiled out -- the kernel is at its
 // 128-register ceiling, and every value less to keep is a spill less per iteration.
@@ -3051,7 +3060,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_multi(IcpArgs a, IcpM
 // from L2 in the general form only.
 constexpr int kPersistKernels = 18;
 static const void* persist_kernel_at(int k) {
-#define PGP_PK(M, I, C, T, R) reinterpret_cast<const void*>(icp_persist_index<M, I, C, T, R>)
+#define PGP_PK(M, I, C, T, R) reinterpret_cast<const void*>(icp_persist_index<M, I, C, T, (R) * kPS>)
   static const void* const tab[kPersistKernels] = {
       PGP_PK(0, true, false, false, 2), PGP_PK(0, true, false, false, 3), PGP_PK(0, true, false, false, 4),
       PGP_PK(0, true, false, true, 2),  PGP_PK(0, true, false, true, 3),  PGP_PK(0, true, false, true, 4),
@@ -3065,7 +3074,7 @@ static const void* persist_kernel_at(int k) {
 }
 static const void* persist_kernel(int metric, bool img_lds, bool cluster, bool trim_only, int n_src) {
   if (metric != 1 && img_lds) {
-    const int r = n_src <= 2 * kIcpThreads ? 0 : (n_src <= 3 * kIcpThreads ? 1 : 2);
+    const int r = n_src <= 2 * kIcpBase ? 0 : (n_src <= 3 * kIcpBase ? 1 : 2);
     return persist_kernel_at((cluster ? 6 : 0) + (trim_only ? 3 : 0) + r);
   }
   if (metric == 1 && img_lds) return persist_kernel_at(cluster ? 13 : 12);
@@ -3074,16 +3083,16 @@ static const void* persist_kernel(int metric, bool img_lds, bool cluster, bool t
 
 static const void* help_kernel(bool trim_only, int pir) {
   static const void* const tab[6] = {
-      reinterpret_cast<const void*>(icp_persist_help<false, 2>), reinterpret_cast<const void*>(icp_persist_help<false, 3>),
-      reinterpret_cast<const void*>(icp_persist_help<false, 4>), reinterpret_cast<const void*>(icp_persist_help<true, 2>),
-      reinterpret_cast<const void*>(icp_persist_help<true, 3>),  reinterpret_cast<const void*>(icp_persist_help<true, 4>)};
+      reinterpret_cast<const void*>(icp_persist_help<false, 2 * kPS>), reinterpret_cast<const void*>(icp_persist_help<false, 3 * kPS>),
+      reinterpret_cast<const void*>(icp_persist_help<false, 4 * kPS>), reinterpret_cast<const void*>(icp_persist_help<true, 2 * kPS>),
+      reinterpret_cast<const void*>(icp_persist_help<true, 3 * kPS>),  reinterpret_cast<const void*>(icp_persist_help<true, 4 * kPS>)};
   return tab[(trim_only ? 3 : 0) + (pir <= 2 ? 0 : (pir == 3 ? 1 : 2))];
 }
 static const void* multi_kernel(bool trim_only, int pir) {
   static const void* const tab[6] = {
-      reinterpret_cast<const void*>(icp_persist_multi<false, 2>), reinterpret_cast<const void*>(icp_persist_multi<false, 3>),
-      reinterpret_cast<const void*>(icp_persist_multi<false, 4>), reinterpret_cast<const void*>(icp_persist_multi<true, 2>),
-      reinterpret_cast<const void*>(icp_persist_multi<true, 3>),  reinterpret_cast<const void*>(icp_persist_multi<true, 4>)};
+      reinterpret_cast<const void*>(icp_persist_multi<false, 2 * kPS>), reinterpret_cast<const void*>(icp_persist_multi<false, 3 * kPS>),
+      reinterpret_cast<const void*>(icp_persist_multi<false, 4 * kPS>), reinterpret_cast<const void*>(icp_persist_multi<true, 2 * kPS>),
+      reinterpret_cast<const void*>(icp_persist_multi<true, 3 * kPS>),  reinterpret_cast<const void*>(icp_persist_multi<true, 4 * kPS>)};
   return tab[(trim_only ? 3 : 0) + (pir <= 2 ? 0 : (pir == 3 ? 1 : 2))];
 }
 
@@ -3464,7 +3473,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       h.help_stride = hb;
       PGP_HIP(hipMemsetAsync(base, 0, hdr, stream));
       void* hparams[] = {&h};
-      hipError_t e = hipLaunchCooperativeKernel(help_kernel(trim_only, n_src <= 2 * kIcpThreads ? 2 : (n_src <= 3 * kIcpThreads ? 3 : 4)),
+      hipError_t e = hipLaunchCooperativeKernel(help_kernel(trim_only, n_src <= 2 * kIcpBase ? 2 : (n_src <= 3 * kIcpBase ? 3 : 4)),
                                                 dim3(n), dim3(kIcpThreads), hparams, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG")) fprintf(stderr, "icp: %d poses, helping launch: %s\n", n, hipGetErrorString(e));
       if (e == hipSuccess) {
@@ -3854,7 +3863,7 @@ int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm,
     a.wgs_per_pose = 1;
     a.energy = nullptr;   // per job, through the descriptor
     if ((rc = ensure_icp_attrs(jobs[0].ctx)) != PGP_OK) return rc;
-    const int pir = max_src <= 2 * kIcpThreads ? 2 : (max_src <= 3 * kIcpThreads ? 3 : 4);
+    const int pir = max_src <= 2 * kIcpBase ? 2 : (max_src <= 3 * kIcpBase ? 3 : 4);
     void* params[] = {&a, &mt};
     PGP_HIP(hipLaunchKernel(multi_kernel(icp_trim_only(a), pir), dim3(total), dim3(kIcpThreads), params, lds, stream));
     PGP_HIP(hipGetLastError());
