@@ -791,13 +791,13 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   a.status = d_status;
   hipLaunchKernelGGL(select_bases, dim3(n_attempts), dim3(kSelThreads), 0, st, a);
   PGP_HIP(hipGetLastError());
-  // ids | inv | status lie back to back in the workspace: ONE copy back (a pageable copy costs ~10 us whatever its size)
-  std::vector<unsigned char> out(A * 28);
-  PGP_HIP(hipMemcpyAsync(out.data(), d_ids, A * 28, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  std::memcpy(h_ids, out.data(), A * 16);
-  std::memcpy(h_inv, out.data() + A * 16, A * 8);
-  std::memcpy(h_status, out.data() + A * 24, A * 4);
+  // ids | inv | status lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
+  HostOut out(ctx, st);
+  const unsigned char* got = nullptr;
+  if ((rc = out.fetch(&got, d_ids, A * 28)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+  std::memcpy(h_ids, got, A * 16);
+  std::memcpy(h_inv, got + A * 16, A * 8);
+  std::memcpy(h_status, got + A * 24, A * 4);
   return PGP_OK;
 }
 
@@ -814,10 +814,10 @@ int launch_ppf_features(pgp_ctx* ctx, const int* h_pairs, int m, int* h_f, int* 
   PGP_HIP(hipMemcpyAsync(d_pairs, h_pairs, M * 8, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(ppf_features, dim3((m + 255) / 256), dim3(256), 0, st, a, (const int2*)d_pairs, m, d_f, d_row);
   PGP_HIP(hipGetLastError());
-  if (h_f) PGP_HIP(hipMemcpyAsync(h_f, d_f, M * 16, hipMemcpyDeviceToHost, st));   // (null: the caller wants the rows only)
-  if (h_row) PGP_HIP(hipMemcpyAsync(h_row, d_row, M * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  return PGP_OK;
+  HostOut out(ctx, st);
+  if (h_f && (rc = out.to(h_f, d_f, M * 16)) != PGP_OK) return rc;   // (null: the caller wants the rows only)
+  if (h_row && (rc = out.to(h_row, d_row, M * 4)) != PGP_OK) return rc;
+  return out.sync();
 }
 
 int launch_stage_weights(pgp_ctx* ctx, int stage, int b1, int b2, int b3, float* h_cur, float* h_sum, int* h_present,
@@ -838,11 +838,11 @@ int launch_stage_weights(pgp_ctx* ctx, int stage, int b1, int b2, int b3, float*
   PGP_HIP(hipMemcpyAsync(d_cur, h_cur, (size_t)n * 4, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(stage_weights, dim3(1), dim3(256), 0, st, a, stage, b1, b2, b3, d_cur, d_sum, d_present);
   PGP_HIP(hipGetLastError());
-  PGP_HIP(hipMemcpyAsync(h_cur, d_cur, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(h_sum, d_sum, 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(h_present, d_present, 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  return PGP_OK;
+  HostOut out(ctx, st);
+  if ((rc = out.to(h_cur, d_cur, (size_t)n * 4)) != PGP_OK || (rc = out.to(h_sum, d_sum, 4)) != PGP_OK ||
+      (rc = out.to(h_present, d_present, 4)) != PGP_OK)
+    return rc;
+  return out.sync();
 }
 
 int launch_base_invariants(pgp_ctx* ctx, int* h_ids, int m, float* h_inv, int* h_ok, hipStream_t st) {
@@ -860,11 +860,11 @@ int launch_base_invariants(pgp_ctx* ctx, int* h_ids, int m, float* h_inv, int* h
   PGP_HIP(hipMemcpyAsync(d_ids, h_ids, M * 16, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(base_invariants, dim3(m), dim3(64), 0, st, ctx->d_P.as<float4>(), ctx->nP, d_ids, m, d_inv, d_ok);
   PGP_HIP(hipGetLastError());
-  PGP_HIP(hipMemcpyAsync(h_ids, d_ids, M * 16, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(h_inv, d_inv, M * 8, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(h_ok, d_ok, M * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  return PGP_OK;
+  HostOut out(ctx, st);
+  if ((rc = out.to(h_ids, d_ids, M * 16)) != PGP_OK || (rc = out.to(h_inv, d_inv, M * 8)) != PGP_OK ||
+      (rc = out.to(h_ok, d_ok, M * 4)) != PGP_OK)
+    return rc;
+  return out.sync();
 }
 
 }  // namespace pgp

@@ -626,8 +626,10 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
   PGP_HIP(hipMemsetAsync(d_assign, 0xFF, (size_t)n * sizeof(int), st));
   hipLaunchKernelGGL(cluster_keys, dim3((n + 255) / 256), dim3(256), 0, st, d_scores, n, bar, keys_in, d_cnt);
   int m = 0;
-  PGP_HIP(hipMemcpyAsync(&m, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  {
+    HostOut out(ctx, st);   // (a 4-byte copy into pageable memory keeps the host 12 us longer than one into pinned memory)
+    if ((rc = out.to(&m, d_cnt, sizeof(int))) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+  }
   *h_m = m;
   if (m == 0) return PGP_OK;
   // the m survivors only (typically a tenth of the batch: one block sort instead of a dozen merge passes)
@@ -662,8 +664,10 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
                        d_cnt + 1, d_cnt + 2);
     PGP_HIP(hipGetLastError());
     int res[2] = {0, 0};
-    PGP_HIP(hipMemcpyAsync(res, d_cnt + 1, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipStreamSynchronize(st));
+    {
+      HostOut out(ctx, st);
+      if ((rc = out.to(res, d_cnt + 1, 2 * sizeof(int))) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+    }
     if (res[1]) {
       *h_n_rep = res[0];
       return PGP_OK;
@@ -680,9 +684,9 @@ int launch_cluster(pgp_ctx* ctx, const float* d_T, const float* d_scores, int n,
     hipLaunchKernelGGL(cluster_greedy, dim3(1), dim3(kGreedyThreads), (size_t)W * 8, st, bits, m, W, idx_sorted, d_rep,
                        d_assign, d_cnt + 1);
   PGP_HIP(hipGetLastError());
-  PGP_HIP(hipMemcpyAsync(h_n_rep, d_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  return PGP_OK;
+  HostOut out(ctx, st);
+  if ((rc = out.to(h_n_rep, d_cnt + 1, sizeof(int))) != PGP_OK) return rc;
+  return out.sync();
 }
 
 }  // namespace pgp

@@ -964,8 +964,10 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     PGP_HIP(hipMemsetAsync(d_nkeys, 0, ((size_t)nb + 1) * 4, st));
     hipLaunchKernelGGL(bq_match, gq, dim3(256), 0, st, a);
     hipLaunchKernelGGL(batch_base_starts, dim3(1), dim3(256), 0, st, (const uint32_t*)d_base_cnt, nb, d_base_start);
-    PGP_HIP(hipMemcpyAsync(starts.data(), d_base_start, ((size_t)nb + 1) * 4, hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipStreamSynchronize(st));
+    {
+      HostOut out(ctx, st);
+      if ((rc = out.to(starts.data(), d_base_start, ((size_t)nb + 1) * 4)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+    }
     total = starts[nb];
     if ((size_t)total <= cap) {
       ctx->csb_keys_off = (uint32_t)cap;

@@ -153,6 +153,7 @@ struct IcpArgs {
   unsigned* x_ticks;             // [2][n][4] search time of every share, published with it
   unsigned solo_ticks;           // every share searched faster than this: the pose goes on in ONE workgroup
   int slot_budget;               // A/B knob (PGP_ICP_SLOTS): lane slots up to which queries get more lanes; 0 = one pass
+  int rows_mode;                 // A/B knob (PGP_ICP_ROWS): phase B's lanes dealt by rows -- 0: where it pays (default), 1: always, 2: never
   // vicinity graph of the target (nnidx_vic_*): per image position the kVicK nearest other target points and a
   // radius inside which no unlisted point lies -- resolves a query next to a known candidate without a search
   const uint4* nn_vic;           // [n_tgt] or nullptr
@@ -1734,8 +1735,9 @@ __device__ __forceinline__ int nn_cost(const NnBox& b) { return (b.y1 - b.y0 + 1
 // (round 5, tools/icp_lane_balance.py: the dearest lane of a wave-pass carries about twice the mean lane's work; ordering
 // the queries of a class by the next two bits of their cost did not change that -- neighbouring queries' costs differ by
 // their ROW lengths, which the box cost does not see -- and timed equal or slower: profiles/r05_ab/icp_lane_balance.log)
-__device__ __forceinline__ int nn_class(const NnGeom& g, float x, float y, float z, float bound_d2) {
+__device__ __forceinline__ int nn_class(const NnGeom& g, float x, float y, float z, float bound_d2, unsigned* rows = nullptr) {
   const NnBox b = nn_box(g, x, y, z, bound_d2);
+  if (rows) *rows = (unsigned)((b.y1 - b.y0 + 1) * (b.z1 - b.z0 + 1));
   const int cost = nn_cost(b);   // rows x (row overhead + cells)
   const int c = 31 - __clz(cost);   // cost >= 3
   return c < kNnClasses - 2 ? c : kNnClasses - 2;
@@ -1783,13 +1785,16 @@ __device__ __forceinline__ bool nn_vic_check(const NnLds& t, const uint4 rec, fl
 // point); the group's results are merged by the caller.  The row loop is the cost of a far query
 // (~(2U/h + 1)^2 pi/4 rows): everything in it works in CELL UNITS on values prepared once per query.
 // (returns the lane's work in instruction units -- ~45 per row, ~12 per point -- in PGP_ICP_STAMPS builds, 0 otherwise)
+// box_d2 >= 0: the box is cut for THAT squared distance (every lane of a query's group must enumerate the same rows, while
+// `best` may already hold a nearer point another lane found); scan_all: the query has no bound at all.
 __device__ __forceinline__ unsigned nn_search(const NnGeom& g, const NnLds& t, int n_tgt, float x, float y, float z,
-                                              int sub, int L, unsigned long long& best, int& bpos) {
-  if (bpos < 0) {
+                                              int sub, int L, unsigned long long& best, int& bpos, float box_d2 = -1.f,
+                                              bool scan_all = false) {
+  if (box_d2 < 0.f ? bpos < 0 : scan_all) {
     for (int k = sub; k < n_tgt; k += L) nn_consider(x, y, z, t.pts[k], k, best, bpos);
     return 0u;
   }
-  const float bound = __uint_as_float((unsigned)(best >> 32));
+  const float bound = box_d2 < 0.f ? __uint_as_float((unsigned)(best >> 32)) : box_d2;
   const NnBox b = nn_box(g, x, y, z, bound);
   const float mag = fabsf(x) + fabsf(y) + fabsf(z) + fabsf(g.ox) + fabsf(g.oy) + fabsf(g.oz);
   // query in cell units relative to the grid origin; a cell c spans [c, c + 1].  Slack of the row tests:
@@ -1918,6 +1923,9 @@ __device__ __forceinline__ int nn_class_lanes_log2(int c, int base = kNnBaseClas
   return l < 0 ? 0 : (l > 6 ? 6 : l);
 }
 constexpr int kNnFew = 64;        // up to this many unanswered queries skip the sort: 16 lanes each, one pass
+#ifndef PGP_NN_ROWS
+#define PGP_NN_ROWS 0             // phase B's lanes dealt by exact row counts instead of cost classes: 0 nowhere (default), 1 in the kernels with
+#endif                            // several workgroups per pose, 2 everywhere.  Built, same bits, measured: profiles/r05_ab/icp_rows_dealt.log
 struct NnSched {
   unsigned cnt[kNnClasses + 1];    // offset of every class in `order` (dearest class first); [kNnClasses] = n_q
   unsigned slot_end[kNnClasses];   // end of the class's lane slots
@@ -1925,6 +1933,7 @@ struct NnSched {
   unsigned wave_sum[16];
   unsigned search_ticks;           // time of the search loop below as thread 0 saw it (100 MHz ticks)
   unsigned n_unres;                // queries the vicinity graph did not answer: phase B's population
+  unsigned all_rows, max_rows;     // rows of their search boxes, summed / the largest box beyond 2048 rows (PGP_NN_ROWS)
   uint16_t few[kNnFew];            // the first of them, in arrival order: the short path of phase B
   unsigned help_s0[2];             // helping: the pass this workgroup has claimed (ping-pong across turns)
   unsigned help_avail;             // helping: some workgroup of the launch is through with its pose
@@ -2045,7 +2054,7 @@ __host__ __device__ __forceinline__ int nn_share_count(int n, int part, int P) {
 }
 __host__ __device__ __forceinline__ bool nn_share_owns(int q, int part, int P) { return P == 1 || ((q >> 3) % P) == part; }
 
-template <int NT, int R, bool HELP = false>
+template <int NT, int R, bool HELP = false, bool ROWS = false>
 __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t, const float* G, int q_base, int n_q,
                                                NnSched* sch /* LDS */, int tid, int part = 0, int P = 1, int help_pose = 0,
                                                unsigned help_tag = 0, int* lost = nullptr, int first_walk = 0) {
@@ -2055,7 +2064,11 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   {   // zero the sort's counters
     uint4* b4 = reinterpret_cast<uint4*>(t.bins);
     b4[tid] = make_uint4(0u, 0u, 0u, 0u);
-    if (tid == 0) sch->n_unres = 0;
+    if (tid == 0) {
+      sch->n_unres = 0;
+      sch->all_rows = 0;
+      sch->max_rows = 0;
+    }
   }
   __syncthreads();
 #ifdef PGP_ICP_STAMPS
@@ -2144,6 +2157,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
   for (int r = 0; r < R; ++r) {
     tag[r] = kNoTag;
     bool unres = false;
+    unsigned q_rows = 0;
     const int q = nn_share_query(r * NT + tid, part, P);
     if (live[r]) {
       const bool proven = vic && bpos[r] >= 0 && nn_vic_check(t, rec[r], qx[r], qy[r], qz[r], best[r], bpos[r]);
@@ -2152,7 +2166,8 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       if (!proven) {
         unres = true;
         // no candidate at all (a non-finite or astronomically far query): the plain scan, class 15
-        const int c = bpos[r] < 0 ? kNnClasses - 1 : nn_class(a.nn, qx[r], qy[r], qz[r], __uint_as_float((unsigned)(best[r] >> 32)));
+        q_rows = ((unsigned)a.n_tgt + 63u) >> 6;
+        const int c = bpos[r] < 0 ? kNnClasses - 1 : nn_class(a.nn, qx[r], qy[r], qz[r], __uint_as_float((unsigned)(best[r] >> 32)), &q_rows);
         const int cell = nn_cell_of(a.nn, qx[r], qy[r], qz[r]);
         const unsigned key = (unsigned)(kNnClasses - 1 - c) * kNnStrips + (unsigned)min(cell >> strip_shift, kNnStrips - 1);
         const unsigned old = atomicAdd(&t.bins[key >> 1], (key & 1u) ? 0x10000u : 1u);
@@ -2167,6 +2182,10 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
       const unsigned slot = base + (unsigned)__popcll(um & ((1ull << (tid & 63)) - 1ull));
       if (unres && slot < (unsigned)kNnFew) sch->few[slot] = (uint16_t)q;
+      if (ROWS) {   // the rows of the boxes (a lane's share of phase B): one add per wave and sweep
+        const unsigned incl = wave_scan_incl_u32(unres ? q_rows : 0u);
+        if ((tid & 63) == 63) atomicAdd(&sch->all_rows, incl);
+      }
     }
   }
   __syncthreads();
@@ -2371,6 +2390,124 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
     for (unsigned s0 = 0; s0 < n_slots; s0 += NT) help_pass<NT>(a, t, sch, G, nullptr, s0, n_slots, tid, false, false);
     if (tid == 0) sch->search_ticks = 1;
     __syncthreads();
+    return;
+  }
+  if (ROWS && !HELP && a.rows_mode != 2) {
+    // ---- phase B, lanes dealt by ROWS (round 5).  The class scheme above gives a query 2^k lanes from the log2 of its box
+    // cost: per-lane work then spreads over a factor of two inside a class alone, and tools/icp_lane_balance.py measured
+    // the dearest lane of a wave-pass at 1.85 - 2.3 x the mean.  Here the rows of the queries' boxes are counted exactly,
+    // `per` = ceil(all rows / NT) rows is a lane's share, query j gets L_j = ceil(rows_j / per) consecutive lane slots
+    // (any number, in the sort's dearest-first order) and lane `sub` of the group takes its rows sub, sub + L_j, ... --
+    // at most `per` of them.  The lanes of a group need not sit in one wave: their results meet in a 64-bit minimum in
+    // LDS, key = d2 | original index (16 bits: an indexed target has at most 65 535 points) | position, the same order as
+    // nn_consider's.  The sort's bins are free by now: keys (8 B) and slot prefixes (4 B) of up to NT queries per batch.
+    // Exact nearest neighbours either way: same bits as every other schedule.
+    static_assert((size_t)kNnBins * 2 >= (size_t)NT * 12, "keys + slot prefixes of a batch fit the sort's bins");
+    unsigned long long* keys = reinterpret_cast<unsigned long long*>(t.bins);
+    unsigned* slotpre = reinterpret_cast<unsigned*>(t.bins) + 2 * NT;
+    constexpr unsigned long long kNoKey = ((unsigned long long)0x7F7FFFFFu << 32) | 0xFFFFFFFFull;
+    const unsigned long long search_t0 = __builtin_amdgcn_s_memrealtime();
+    const unsigned per = max((sch->all_rows + (unsigned)NT - 1u) / (unsigned)NT, 1u);
+    for (unsigned b0 = 0; b0 < n_unres; b0 += NT) {
+      const unsigned nb = min((unsigned)NT, n_unres - b0);
+      unsigned rows = 0;
+      int q_mine = 0;
+      if ((unsigned)tid < nb) {
+        q_mine = t.order[b0 + tid];
+        const unsigned pp = t.pos[q_mine];
+        if (pp == 0xFFFFu) {   // no candidate at all: the plain scan, dealt in runs of 64 points
+          rows = ((unsigned)a.n_tgt + 63u) >> 6;
+          keys[tid] = kNoKey;
+        } else {
+          const float4 s = nn_src(a, t, q_base, q_mine);
+          const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                      z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+          const float d2 = t.d2[q_mine];
+          const NnBox bx = nn_box(a.nn, x, y, z, d2);
+          rows = (unsigned)((bx.y1 - bx.y0 + 1) * (bx.z1 - bx.z0 + 1));
+          keys[tid] = ((unsigned long long)__float_as_uint(d2) << 32) | ((unsigned long long)((unsigned)__float_as_int(t.pts[pp].w) & 0xFFFFu) << 16) |
+                      (unsigned long long)pp;
+        }
+      }
+      const unsigned lanes = rows ? (rows + per - 1u) / per : 0u;   // (all batches share one `per`: phase A summed every box)
+      {   // exclusive scan of the lane counts in the sort's order
+        const unsigned incl = wave_scan_incl_u32(lanes);
+        if ((tid & 63) == 63) sch->wave_sum[tid >> 6] = incl;
+        __syncthreads();
+        unsigned base = 0;
+        for (int wv = 0; wv < (tid >> 6); ++wv) base += sch->wave_sum[wv];
+        slotpre[tid] = base + incl - lanes;
+      }
+      unsigned n_slots = 0;
+      for (int wv = 0; wv < NT / 64; ++wv) n_slots += sch->wave_sum[wv];
+      __syncthreads();
+      for (unsigned s0 = 0; s0 < n_slots; s0 += NT) {
+        const unsigned sl = s0 + (unsigned)tid;
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 6
+        unsigned lane_cost = 0;
+#endif
+        if (sl < n_slots) {
+          // the query of slot sl: the last j with slotpre[j] <= sl
+          unsigned j = 0;
+#pragma unroll
+          for (unsigned step = (unsigned)NT / 2; step; step >>= 1) {
+            const unsigned cand = j + step;
+            if (cand < nb && slotpre[cand] <= sl) j = cand;
+          }
+          const unsigned first = slotpre[j], L = (j + 1 < nb ? slotpre[j + 1] : n_slots) - first;
+          const int q = t.order[b0 + j];
+          const float4 s = nn_src(a, t, q_base, q);
+          const unsigned long long key = keys[j];
+          const float x = row_xf(g00, g01, g02, g03, s.x, s.y, s.z), y = row_xf(g10, g11, g12, g13, s.x, s.y, s.z),
+                      z = row_xf(g20, g21, g22, g23, s.x, s.y, s.z);
+          const bool scan_all = t.pos[q] == 0xFFFFu;
+          unsigned long long best = kNnNone;
+          int bpos = -1;
+          if ((key & 0xFFFFull) != 0xFFFFull) {
+            best = (key & 0xFFFFFFFF00000000ull) | ((key >> 16) & 0xFFFFull);
+            bpos = (int)(key & 0xFFFFull);
+          }
+          if (scan_all) {   // run `sub + k L` of 64 points
+            for (unsigned run = sl - first; run * 64u < (unsigned)a.n_tgt; run += L) {
+              const int k_end = min((int)(run * 64u) + 64, a.n_tgt);
+              for (int k = (int)(run * 64u); k < k_end; ++k) nn_consider(x, y, z, t.pts[k], k, best, bpos);
+            }
+          } else {
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 6
+            lane_cost =
+#endif
+            nn_search(a.nn, t, a.n_tgt, x, y, z, (int)(sl - first), (int)L, best, bpos, t.d2[q], false);
+          }
+          if (bpos >= 0) {
+            const unsigned long long nk = (best & 0xFFFFFFFF00000000ull) | ((best & 0xFFFFull) << 16) | (unsigned long long)(unsigned)bpos;
+            if (nk < key) atomicMin(&keys[j], nk);
+          }
+        }
+#if defined(PGP_ICP_STAMPS) && PGP_ICP_STAMPS == 6
+        {   // how well a wave's lanes are balanced (tools/icp_lane_balance.py)
+          unsigned mx = lane_cost, sm = lane_cost;
+          for (int off = 32; off >= 1; off >>= 1) {
+            mx = max(mx, (unsigned)__shfl_xor((int)mx, off, 64));
+            sm += (unsigned)__shfl_xor((int)sm, off, 64);
+          }
+          if ((tid & 63) == 0 && t.dbg && sm > 0) {
+            atomicAdd(&t.dbg[0], mx);
+            atomicAdd(&t.dbg[1], sm / 64u);
+            atomicAdd(&t.dbg[2], 1u);
+          }
+        }
+#endif
+      }
+      __syncthreads();
+      if ((unsigned)tid < nb) {
+        const unsigned long long k = keys[tid];
+        const unsigned pp = (unsigned)(k & 0xFFFFull);
+        t.d2[q_mine] = pp == 0xFFFFu ? FLT_MAX : __uint_as_float((unsigned)(k >> 32));
+        t.pos[q_mine] = (uint16_t)pp;
+      }
+      __syncthreads();   // keys and slot prefixes belong to the next batch (and, after the last, to the next sort)
+    }
+    if (tid == 0) sch->search_ticks = max((unsigned)(__builtin_amdgcn_s_memrealtime() - search_t0), 1u);
     return;
   }
   const int lane_base = sch->base;
@@ -2582,7 +2719,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
   for (;;) {
     PGP_STAMP(0);
     // ---- 1. correspondences ---------------------------------------------------------------------
-    nn_all_queries<kIcpThreads, PIR, HELP>(a, t, s_G, 0, n_share, &s_sch, tid, part, P, pose, (unsigned)(it + 1), &s_lost,
+    nn_all_queries<kIcpThreads, PIR, HELP, PGP_NN_ROWS == 2 || (PGP_NN_ROWS == 1 && CLUSTER)>(a, t, s_G, 0, n_share, &s_sch, tid, part, P, pose, (unsigned)(it + 1), &s_lost,
                                             it == 0 ? a.first_walk : 0);
     if (HELP && s_lost) break;
     if (CLUSTER && P > 1) {
@@ -3386,6 +3523,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     a.wgs_per_pose = 1;
     if (const char* v = getenv("PGP_ICP_DBG_POSE")) a.dbg_pose = atoi(v);
     if (const char* v = getenv("PGP_ICP_SLOTS")) a.slot_budget = atoi(v);
+    if (const char* v = getenv("PGP_ICP_ROWS")) a.rows_mode = atoi(v);
     int want_wgs = n * 4 <= ctx->n_cus ? 4 : (n * 2 <= ctx->n_cus ? 2 : 1);
     if (const char* v = getenv("PGP_ICP_WGS")) want_wgs = atoi(v) == 4 ? 4 : (atoi(v) == 2 ? 2 : 1);   // A/B knob
     if (want_wgs > 1 && a.smooth == 0 && n * want_wgs <= ctx->n_cus && n_src >= 64 * want_wgs) {

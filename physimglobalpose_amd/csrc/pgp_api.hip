@@ -213,6 +213,11 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
     ctx->h_pin = nullptr;
   }
+  if (ctx->h_out) {
+    hipError_t e = hipHostFree(ctx->h_out);
+    (void)e;
+    ctx->h_out = nullptr;
+  }
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
     (void)r;
@@ -633,10 +638,10 @@ int pgp_registered(pgp_ctx* ctx, const float* T16, int mode, float gate_deg, int
   PGP_HIP(hipMemcpyAsync(ctx->d_T.p, T16, 16 * sizeof(float), hipMemcpyHostToDevice, st));
   rc = launch_registered(ctx, ctx->d_T.as<float>(), mode, gate_deg, ctx->d_hits.as<int>(), st);
   if (rc != PGP_OK) return rc;
-  std::vector<int> hits((size_t)std::max(ctx->nQ, 1));
-  if (ctx->nQ > 0)
-    PGP_HIP(hipMemcpyAsync(hits.data(), ctx->d_hits.p, (size_t)ctx->nQ * sizeof(int), hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  HostOut out(ctx, st);
+  const unsigned char* got = nullptr;
+  if ((rc = out.fetch(&got, ctx->d_hits.p, (size_t)ctx->nQ * sizeof(int))) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+  const int* hits = reinterpret_cast<const int*>(got);
   if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   int k = 0;
   for (int i = 0; i < ctx->nQ; ++i)
@@ -674,9 +679,10 @@ int pgp_registered_model(pgp_ctx* ctx, const float* T16, const float* q_xyz, con
   PGP_HIP(hipMemcpyAsync(d_T, T16, 64, hipMemcpyHostToDevice, st));
   rc = launch_registered_model(ctx, d_T, d_q, d_n, n, gate_deg, d_hits, st);
   if (rc != PGP_OK) return rc;
-  std::vector<int> hits(N);
-  PGP_HIP(hipMemcpyAsync(hits.data(), d_hits, N * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  HostOut out(ctx, st);
+  const unsigned char* got = nullptr;
+  if ((rc = out.fetch(&got, d_hits, N * 4)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+  const int* hits = reinterpret_cast<const int*>(got);
   if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   int k = 0;
   for (int i = 0; i < n; ++i)
@@ -1813,10 +1819,10 @@ int pgp_cluster_poses(pgp_ctx* ctx, const float* T, const float* scores, int n_h
   if (rc != PGP_OK) return rc;
   *n_rep = nr;
   const int n_copy = nr < cap ? nr : cap;
-  if (n_copy > 0) PGP_HIP(hipMemcpyAsync(rep_index, d_rep, (size_t)n_copy * 4, hipMemcpyDeviceToHost, st));
-  if (assignment) PGP_HIP(hipMemcpyAsync(assignment, d_assign, (size_t)n_h * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
-  return PGP_OK;
+  HostOut out(ctx, st);
+  if (n_copy > 0 && (rc = out.to(rep_index, d_rep, (size_t)n_copy * 4)) != PGP_OK) return rc;
+  if (assignment && (rc = out.to(assignment, d_assign, (size_t)n_h * 4)) != PGP_OK) return rc;
+  return out.sync();
 }
 
 int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, const float sym_deg[3],

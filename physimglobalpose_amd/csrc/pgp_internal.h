@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -192,6 +193,10 @@ struct pgp_ctx {
   // pinned host staging for the host-pointer scoring call (transforms in, scores | counts | best out)
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
+  // pinned landing area of small results on their way to the caller's (pageable) memory: pgp::HostOut
+  void* h_out = nullptr;
+  size_t h_out_cap = 0, h_out_used = 0;
+  bool h_out_failed = false;
   pgp::DevBuf d_out;      // scores | counts | best of one host-pointer call, contiguous: ONE copy back
 
   // tuning knobs (env PGP_UNROLL / PGP_HPB at pgp_create; defaults chosen by measurement)
@@ -218,6 +223,76 @@ struct pgp_ctx {
 };
 
 namespace pgp {
+
+// Small results on their way to the caller's memory.  A device-to-host copy into PAGEABLE memory keeps the host 12 us
+// longer than one into pinned memory, whatever its size (tools/copy_cost.hip on the bench box: 24.4 against 12.2 us for
+// 64 B .. 4 KB, copy + stream synchronisation) -- and a drop-in call makes five of them.  A HostOut lands the copies in a
+// pinned area of the context and hands them on after ONE synchronisation:
+//     HostOut out(ctx, st);  out.to(h_dst, d_src, bytes); ...  rc = out.sync();
+// fetch() instead returns where the bytes will be (valid after sync(), until the HostOut goes out of scope).  Stack
+// discipline (a callee's HostOut sits above its caller's); results beyond the area's room, or all of them when the area
+// cannot be allocated, are copied straight to their destination as before.  Leaving the scope without sync() drops the
+// pending deliveries (the error paths).
+struct HostOut {
+  static constexpr size_t kArea = 1u << 20, kMaxItems = 8;
+  pgp_ctx* ctx;
+  hipStream_t st;
+  size_t mark;
+  struct Item {
+    void* dst;
+    size_t off, n;
+  } items[kMaxItems];
+  int n_items = 0;
+  std::vector<unsigned char> spill;   // fetch() without room in the area
+
+  HostOut(pgp_ctx* c, hipStream_t s) : ctx(c), st(s), mark(c->h_out_used) {}
+  ~HostOut() { ctx->h_out_used = mark; }
+  HostOut(const HostOut&) = delete;
+  HostOut& operator=(const HostOut&) = delete;
+
+  unsigned char* room(size_t bytes) {
+    if (!ctx->h_out && !ctx->h_out_failed) {
+      if (hipHostMalloc(&ctx->h_out, kArea, hipHostMallocDefault) == hipSuccess) ctx->h_out_cap = kArea;
+      else {
+        (void)hipGetLastError();
+        ctx->h_out = nullptr;
+        ctx->h_out_failed = true;
+      }
+    }
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (!ctx->h_out || ctx->h_out_used + need > ctx->h_out_cap) return nullptr;
+    unsigned char* p = static_cast<unsigned char*>(ctx->h_out) + ctx->h_out_used;
+    ctx->h_out_used += need;
+    return p;
+  }
+  int to(void* dst, const void* d_src, size_t bytes) {
+    if (bytes == 0) return PGP_OK;
+    unsigned char* p = n_items < (int)kMaxItems ? room(bytes) : nullptr;
+    if (!p) {
+      PGP_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+      return PGP_OK;
+    }
+    PGP_HIP(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, st));
+    items[n_items++] = Item{dst, (size_t)(p - static_cast<unsigned char*>(ctx->h_out)), bytes};
+    return PGP_OK;
+  }
+  int fetch(const unsigned char** where, const void* d_src, size_t bytes) {
+    unsigned char* p = room(bytes);
+    if (!p) {
+      spill.resize(bytes);   // (one fetch per HostOut may spill: a second resize would move the first)
+      p = spill.data();
+    }
+    *where = p;
+    if (bytes) PGP_HIP(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, st));
+    return PGP_OK;
+  }
+  int sync() {
+    PGP_HIP(hipStreamSynchronize(st));
+    for (int k = 0; k < n_items; ++k) std::memcpy(items[k].dst, static_cast<unsigned char*>(ctx->h_out) + items[k].off, items[k].n);
+    n_items = 0;
+    return PGP_OK;
+  }
+};
 
 // cell (x, y, z) -> position in the blocked numbering (word index * 32 + bit)
 __host__ __device__ inline uint32_t grid_word(const GridDesc& g, int x, int y, int z) {
