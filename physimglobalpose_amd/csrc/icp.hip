@@ -161,6 +161,10 @@ struct IcpArgs {
   // lost meetings (clustered launch): a workgroup whose partners did not arrive sets *x_lost; the follow-up launch
   // (run_if = x_lost, one workgroup per pose, starting again from the transforms saved in T_save) repairs the call
   unsigned* x_lost;              // [1] in the library's own workspace
+  unsigned* x_done;              // [n] workgroups of the pose that have left: the last one zeroes the pose's counters for the next call
+  unsigned* lost_out;            // nullable: the lost flag once more, where the CALLER reads it (a host-pointer call checks it itself
+                                 // after its one synchronisation instead of paying for a repair launch behind every call)
+  int force_lost;                // test knob (PGP_ICP_FORCE_LOST): the first meeting is declared lost
   float* T_save;                 // [n][16]: clustered launch: part 0 stores the pose's initial transform here
   const float* T_in;             // where a pose's initial transform is read (T itself, or T_save in the repair launch)
   const unsigned* run_if;        // non-null: the whole launch returns at once unless *run_if != 0
@@ -2648,6 +2652,19 @@ constexpr int kSelRank = 512;   // keys of the threshold's 12-bit bin that are r
 // of the extra stop rules) -- the hot form; its branches on the other forms' options are gone at compile time.
 // PIR: source points per thread (n_src <= PIR x 1024): every per-thread array of the search's phase A, of the
 // selection and of the sums has PIR entries -- a 1756-point segment takes PIR = 2 and half the registers of PIR = 4.
+// A workgroup of a clustered launch leaves its pose (its share published and the pose handed to workgroup 0; or the pose
+// finished): the LAST of the pose's workgroups to leave puts the pose's arrival counter back to zero -- nobody polls it any
+// more -- so the next clustered launch on this context starts without a memset in front of it (a fill is ~3 us of GPU time
+// and ~9 us of dependency latency on a call that lasts 200).
+__device__ __forceinline__ void cluster_leave(const IcpArgs& a, int pose, int tid) {
+  if (tid != 0) return;
+  const unsigned left = __hip_atomic_fetch_add(&a.x_done[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (left + 1u == (unsigned)a.wgs_per_pose) {
+    __hip_atomic_store(&a.x_ctr[pose], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.x_done[pose], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 template <int METRIC, bool IMG_LDS, bool CLUSTER, bool TRIM_ONLY, int PIR, bool HELP = false>
 __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALUE: a reference to the kernel argument costs 16 -> 83 spilled registers
   extern __shared__ __align__(16) unsigned char smem[];
@@ -2751,6 +2768,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
             break;
           }
         }
+        if (a.force_lost) s_lost = 1;
         unsigned slowest = 0;
         for (int k = 0; k < P; ++k)
           slowest = max(slowest, __hip_atomic_load(&xt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -2758,7 +2776,10 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
       }
       __syncthreads();
       if (s_lost) break;
-      if (s_solo && part != 0) return;   // this share is published; workgroup 0 finishes the pose
+      if (s_solo && part != 0) {         // this share is published; workgroup 0 finishes the pose
+        cluster_leave(a, pose, tid);
+        return;
+      }
       for (int q = tid; q < a.n_src; q += kIcpThreads) {
         if (nn_share_owns(q, part, P)) continue;
         const unsigned long long v = __hip_atomic_load(&xb[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3109,9 +3130,13 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
     // a partner never arrived (another process holding the GPU's CUs): this call's transforms are not to be
     // trusted.  The flag lives in the library's workspace; the repair launch that follows every clustered launch
     // sees it and runs all poses again from their saved initial transforms, one workgroup per pose.
-    if (tid == 0) __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return;
+    if (tid == 0) {
+      __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.lost_out) __hip_atomic_store(a.lost_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;   // (the counters stay as they are: the host zeroes them before the next clustered launch)
   }
+  if (CLUSTER) cluster_leave(a, pose, tid);
   if (CLUSTER && part != 0) return;
   if (tid < 16) Tg[tid] = s_G[tid];
   if (tid == 0) {
@@ -3421,7 +3446,7 @@ static bool icp_trim_only(const IcpArgs& a) {
 
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
-               unsigned long long tgt_token) {
+               unsigned long long tgt_token, unsigned* d_lost_out, bool no_cluster) {
   if (n <= 0) return PGP_OK;
   if (n_src <= 0 || n_tgt <= 0) {
     set_error("icp: empty source or target cloud");
@@ -3441,7 +3466,8 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     for (int off = 0; off < n; off += kMaxPoses) {
       const int m = n - off < kMaxPoses ? n - off : kMaxPoses;
       int rc = launch_icp(ctx, d_src, n_src, d_tgt, d_tgt_n, n_tgt, d_T + 16 * (size_t)off, m, prm,
-                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream, tgt_token);
+                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream, tgt_token, d_lost_out,
+                          no_cluster);
       if (rc != PGP_OK) return rc;
     }
     return PGP_OK;
@@ -3526,6 +3552,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     if (const char* v = getenv("PGP_ICP_ROWS")) a.rows_mode = atoi(v);
     int want_wgs = n * 4 <= ctx->n_cus ? 4 : (n * 2 <= ctx->n_cus ? 2 : 1);
     if (const char* v = getenv("PGP_ICP_WGS")) want_wgs = atoi(v) == 4 ? 4 : (atoi(v) == 2 ? 2 : 1);   // A/B knob
+    if (no_cluster) want_wgs = 1;   // (the caller's second attempt after a lost meeting)
     if (want_wgs > 1 && a.smooth == 0 && n * want_wgs <= ctx->n_cus && n_src >= 64 * want_wgs) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
@@ -3539,21 +3566,42 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       std::lock_guard<std::mutex> chain(g_coop.mu);
       if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
       else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
-      // meeting buffers | arrival counters | lost flag | search ticks | saved transforms
-      const size_t xbytes = 2 * need * 8, ctr_words = (size_t)n + 4;
+      // meeting buffers | arrival counters | lost flag | workgroups that have left | search ticks | saved transforms
+      const size_t xbytes = 2 * need * 8, ctr_words = 2 * (size_t)n + 4;
+      const void* x_before = ctx->d_icp_x.p;
+      const size_t x_cap_before = ctx->d_icp_x.cap;
       if ((rc = ctx->d_icp_x.ensure(xbytes + ctr_words * 4 + (size_t)n * 32 + (size_t)n * 64 + 64)) != PGP_OK) return rc;
       a.x_buf = ctx->d_icp_x.as<unsigned long long>();
       a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
       a.x_lost = a.x_ctr + n;
+      a.x_done = a.x_lost + 4;
+      a.lost_out = d_lost_out;
+      if (getenv("PGP_ICP_FORCE_LOST")) a.force_lost = 1;   // test knob: the first meeting of every pose counts as lost
       a.x_ticks = a.x_ctr + ctr_words;
       a.T_save = reinterpret_cast<float*>(a.x_ticks + (size_t)n * 8);
       a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
       if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
-      PGP_HIP(hipMemsetAsync(a.x_ctr, 0, ctr_words * 4, stream));
+      // The counters are zero when the last clustered launch on this context ran to its end (every pose's last
+      // workgroup puts them back: cluster_leave) AND the same words are theirs again; a caller that checks the lost
+      // flag itself (d_lost_out: the host-pointer call) knows whether it did.  Otherwise: a fill first.
+      const bool same_words = ctx->d_icp_x.p == x_before && ctx->d_icp_x.cap == x_cap_before && ctx->icp_x_n == n &&
+                              ctx->icp_x_need == (size_t)need;
+      if (!(d_lost_out && same_words && ctx->icp_x_clean)) PGP_HIP(hipMemsetAsync(a.x_ctr, 0, ctr_words * 4, stream));
+      ctx->icp_x_clean = false;
+      ctx->icp_x_n = n;
+      ctx->icp_x_need = (size_t)need;
       void* params[] = {&a};
       hipError_t e = hipLaunchCooperativeKernel(fn_cluster, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG"))
         fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
+      if (e == hipSuccess && d_lost_out) {
+        // The caller reads the lost flag with the results it synchronises for anyway and, should it ever be set,
+        // calls again with no_cluster: no repair launch behind the kernel (1.6 us + ~12 us of dependency latency).
+        ctx->icp_x_clean = true;   // (the caller takes this back when it sees the flag)
+        PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
+        PGP_HIP(hipGetLastError());
+        return PGP_OK;
+      }
       if (e == hipSuccess) {
         // The repair launch: one workgroup per pose, an ordinary launch; every workgroup returns at once unless a
         // meeting of the clustered launch was lost (another process spinning on the CUs), in which case all poses
@@ -3599,6 +3647,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       // counters (claim words | slot counts | passes done | finished, lost) | saved transforms | publications
       const size_t N = (size_t)n, hdr = (N * 16 + 8 + 255) & ~(size_t)255, save = (N * 64 + 255) & ~(size_t)255, hb = help_bytes(n_src);
       if ((rc = ctx->d_icp_x.ensure(hdr + save + N * hb + 256)) != PGP_OK) return rc;
+      ctx->icp_x_clean = false;   // (the clustered launch's counters live in the same buffer)
       unsigned char* base = ctx->d_icp_x.as<unsigned char>();
       IcpArgs h = a;
       h.help_ctl = reinterpret_cast<unsigned long long*>(base);
@@ -3820,6 +3869,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
       else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
       if ((rc = ctx->d_icp_x.ensure(w_bytes + uc_bytes + tail + 256)) != PGP_OK) return rc;
+      ctx->icp_x_clean = false;   // (the clustered launch's counters live in the same buffer)
       unsigned char* xb = ctx->d_icp_x.as<unsigned char>();
       z.W = reinterpret_cast<double*>(xb);
       z.unit_ctr = reinterpret_cast<unsigned*>(xb + w_bytes);
