@@ -165,6 +165,8 @@ struct IcpArgs {
   unsigned* lost_out;            // nullable: the lost flag once more, where the CALLER reads it (a host-pointer call checks it itself
                                  // after its one synchronisation instead of paying for a repair launch behind every call)
   int force_lost;                // test knob (PGP_ICP_FORCE_LOST): the first meeting is declared lost
+  unsigned call_seq;             // what a lost meeting writes into *x_lost: this launch's number on its context (never 0), so that a
+  unsigned run_if_value;         // repair launch (run_if, run_if_value) answers to ITS clustered launch only and nobody has to clear the flag
   float* T_save;                 // [n][16]: clustered launch: part 0 stores the pose's initial transform here
   const float* T_in;             // where a pose's initial transform is read (T itself, or T_save in the repair launch)
   const unsigned* run_if;        // non-null: the whole launch returns at once unless *run_if != 0
@@ -2683,7 +2685,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
   __shared__ NnSched s_sch;
 
   // the repair launch of a clustered call (launch_icp): nothing to do unless a meeting was lost
-  if (!CLUSTER && a.run_if && *a.run_if == 0u) return;   // (the repair launch is a one-workgroup-per-pose launch)
+  if (!CLUSTER && a.run_if && *a.run_if != a.run_if_value) return;   // (the repair launch is a one-workgroup-per-pose launch)
 
   // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
   // searches its share of the source points (nn_share_query); the shares meet in HBM (x_buf) once per iteration,
@@ -3057,7 +3059,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         if (a.iters) a.iters[pose] = it;
       }
     } else if (tid == 0) {
-      __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.x_lost, a.call_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- this pose is through: take search passes of the poses that are still running (see HelpPub)
     __shared__ int h_pose;
@@ -3131,10 +3133,13 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
     // trusted.  The flag lives in the library's workspace; the repair launch that follows every clustered launch
     // sees it and runs all poses again from their saved initial transforms, one workgroup per pose.
     if (tid == 0) {
-      __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.x_lost, a.call_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (a.lost_out) __hip_atomic_store(a.lost_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    return;   // (the counters stay as they are: the host zeroes them before the next clustered launch)
+    // every workgroup of the launch runs and leaves sooner or later -- the one that came too late meets nobody and times
+    // out in its turn --, so the counters are back at zero when the launch is over, lost or not
+    cluster_leave(a, pose, tid);
+    return;
   }
   if (CLUSTER) cluster_leave(a, pose, tid);
   if (CLUSTER && part != 0) return;
@@ -3473,6 +3478,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     return PGP_OK;
   }
   IcpArgs a{};
+  a.call_seq = a.run_if_value = 1u;
   a.src = d_src;
   a.tgt = d_tgt;
   a.tgt_n = d_tgt_n;
@@ -3581,15 +3587,17 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       a.T_save = reinterpret_cast<float*>(a.x_ticks + (size_t)n * 8);
       a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
       if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
-      // The counters are zero when the last clustered launch on this context ran to its end (every pose's last
-      // workgroup puts them back: cluster_leave) AND the same words are theirs again; a caller that checks the lost
-      // flag itself (d_lost_out: the host-pointer call) knows whether it did.  Otherwise: a fill first.
-      const bool same_words = ctx->d_icp_x.p == x_before && ctx->d_icp_x.cap == x_cap_before && ctx->icp_x_n == n &&
-                              ctx->icp_x_need == (size_t)need;
-      if (!(d_lost_out && same_words && ctx->icp_x_clean)) PGP_HIP(hipMemsetAsync(a.x_ctr, 0, ctr_words * 4, stream));
-      ctx->icp_x_clean = false;
+      // The counters are zero whenever a clustered launch on this context is over (every pose's last workgroup to leave
+      // puts them back, lost meeting or not: cluster_leave): a fill only when these words were not the counters of the
+      // last such launch (first use, a grown buffer, another pose count, the helping launch's layout in between).
+      const bool same_words = ctx->icp_x_clean && ctx->d_icp_x.p == x_before && ctx->d_icp_x.cap == x_cap_before &&
+                              ctx->icp_x_n == n && ctx->icp_x_need == (size_t)need;
+      if (!same_words) PGP_HIP(hipMemsetAsync(a.x_ctr, 0, ctr_words * 4, stream));
+      ctx->icp_x_clean = true;
       ctx->icp_x_n = n;
       ctx->icp_x_need = (size_t)need;
+      if (++ctx->icp_x_seq == 0u) ++ctx->icp_x_seq;
+      a.call_seq = ctx->icp_x_seq;
       void* params[] = {&a};
       hipError_t e = hipLaunchCooperativeKernel(fn_cluster, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG"))
@@ -3597,7 +3605,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (e == hipSuccess && d_lost_out) {
         // The caller reads the lost flag with the results it synchronises for anyway and, should it ever be set,
         // calls again with no_cluster: no repair launch behind the kernel (1.6 us + ~12 us of dependency latency).
-        ctx->icp_x_clean = true;   // (the caller takes this back when it sees the flag)
         PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
         PGP_HIP(hipGetLastError());
         return PGP_OK;
@@ -3610,6 +3617,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
         IcpArgs fix = a;
         fix.wgs_per_pose = 1;
         fix.run_if = a.x_lost;
+        fix.run_if_value = a.call_seq;
         fix.T_in = a.T_save;
         fix.T_save = nullptr;
         void* fparams[] = {&fix};
@@ -3650,6 +3658,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       ctx->icp_x_clean = false;   // (the clustered launch's counters live in the same buffer)
       unsigned char* base = ctx->d_icp_x.as<unsigned char>();
       IcpArgs h = a;
+      h.call_seq = h.run_if_value = 1u;   // (its lost flag is filled with zero before every launch)
       h.help_ctl = reinterpret_cast<unsigned long long*>(base);
       h.help_nslots = reinterpret_cast<unsigned*>(base + N * 8);
       h.help_done = h.help_nslots + N;
@@ -3667,6 +3676,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
         IcpArgs fix = a;
         fix.wgs_per_pose = 1;
         fix.run_if = h.x_lost;
+        fix.run_if_value = 1u;
         fix.T_in = h.T_save;
         fix.T_save = nullptr;
         void* fparams[] = {&fix};

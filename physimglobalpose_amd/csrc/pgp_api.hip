@@ -1381,7 +1381,6 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   unsigned lost = 0;
   std::memcpy(&lost, static_cast<const unsigned char*>(ctx->h_pin) + g.off_f, 4);
   if (lost) {
-    ctx->icp_x_clean = false;
     if ((rc = icp_host_stage(ctx, src_xyz, n_src, tgt_xyz, n_tgt, T, n, st, &g)) != PGP_OK) return rc;
     rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token, nullptr, true);
     if (rc != PGP_OK) return rc;

@@ -167,11 +167,12 @@ struct pgp_ctx {
   size_t icp_idx_vic_off = 0;   // byte offset of the vicinity graph inside d_icp_grid (0: none)
   alignas(8) unsigned char icp_idx_geom[96] = {0};
   // the uniform grid of the capped scene-sized search (icp.hip use_grid), kept across calls by the same rule
-  // clustered ICP launches: the meeting counters in d_icp_x are known to be zero (the last such launch ran to its end and its
-  // caller saw no lost meeting) for `icp_x_n` poses over `icp_x_need` meeting records
+  // clustered ICP launches: the words of d_icp_x that hold the meeting counters of `icp_x_n` poses over `icp_x_need` meeting
+  // records were the counters of the last such launch (which leaves them at zero); the launches' running number
   bool icp_x_clean = false;
   int icp_x_n = 0;
   size_t icp_x_need = 0;
+  unsigned icp_x_seq = 0;
   bool icp_grid_valid = false;
   unsigned long long icp_grid_token = 0;
   const void* icp_grid_tgt = nullptr;
