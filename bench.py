@@ -734,6 +734,12 @@ def main():
     # chip takes to leave its idle clocks (BENCH_r02: the driver's --steps 20 --warmup 5 run read 0.1176 ms per
     # step where 200 steps read 0.1076).  >= 150 ms of the same steps first, so the timed region measures
     # the steady state a caller scoring batch after batch sees.
+    # the interpreter's cycle collector off while the clock runs (as timeit does): with torch loaded one full pass is
+    # tens of milliseconds, and the timed region of the default run is two (tools/icp_hiccup_probe.py found one such
+    # pass about every fifty calls of a ctypes loop).  Collected HERE, in front of the pre-heat: the chip idles while
+    # the collector runs, and a timed region behind an idle chip reads 10 % low.
+    gc.collect()
+    gc.disable()
     t_heat = time.perf_counter()
     # (not in the gloo smoke mode, whose host-side collectives make every flush a matter of milliseconds)
     while (backend == "nccl" or not multi) and time.perf_counter() - t_heat < 0.15:
@@ -745,11 +751,6 @@ def main():
     # so timing all of them would take 7 % off the throughput being measured
     sc.set_kernel_timing(TIMING_STRIDE)
     sc.kernel_timing(reset=True)
-    # the interpreter's cycle collector off while the clock runs (as timeit does): with torch loaded one full pass is
-    # tens of milliseconds, and the timed region of the default run is two (tools/icp_hiccup_probe.py found one such
-    # pass about every fifty calls of a ctypes loop)
-    gc.collect()
-    gc.disable()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
