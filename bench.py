@@ -742,11 +742,20 @@ def main():
     gc.disable()
     t_heat = time.perf_counter()
     # (not in the gloo smoke mode, whose host-side collectives make every flush a matter of milliseconds)
-    while (backend == "nccl" or not multi) and time.perf_counter() - t_heat < 0.15:
+    # ... and on until two chunks of 64 steps in a row take the same time within 3 % (a box fresh from its idle state, or
+    # one whose first process this is, can take longer than that to settle), a second at most
+    chunk_prev = None
+    while backend == "nccl" or not multi:
+        tc = time.perf_counter()
         for _ in range(64):
             step()
         ex.drain()
         torch.cuda.synchronize()
+        chunk = time.perf_counter() - tc
+        heated = time.perf_counter() - t_heat
+        if heated >= 1.0 or (heated >= 0.15 and chunk_prev is not None and abs(chunk - chunk_prev) <= 0.03 * chunk_prev):
+            break
+        chunk_prev = chunk
     # HIP events on every 8th launch of the timed region: a timed dispatch costs the stream ~8 us,
     # so timing all of them would take 7 % off the throughput being measured
     sc.set_kernel_timing(TIMING_STRIDE)
@@ -860,8 +869,13 @@ def main():
         if os.environ.get("PGP_BENCH_NATIVE_MULTI", "1") != "0" and not (world == 1 and args.no_cpu_baseline):
             # every rank has finished its timed work: the native group (pgp_multi_*: objects, ICP pose shards,
             # congruent sets sharded by base) takes the same `world` devices, in a child process
-            del sc
+            # (this process still holds the device: what it can give back -- contexts with their streams, cached blocks --
+            #  it gives back first; a child beside a parent with dozens of idle queues measured its host-driven calls
+            #  0.1 ms per synchronisation slower: tools/child_probe.py)
+            del sc, ex, d_batches, T_all
+            gc.collect()
             torch.cuda.synchronize()
+            torch.cuda.empty_cache()
             out["native_multi"] = native_multi_row(min(world, torch.cuda.device_count()), args.mode,
                                                    max(20, min(args.steps, 100)))
         os.write(real_stdout, (json.dumps(compact_line(out)) + "\n").encode())

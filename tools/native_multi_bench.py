@@ -190,7 +190,17 @@ def main():
             extra[name] = fn(args, mode)
         except Exception as e:   # a secondary row must not take the others down
             extra[name] = {"error": repr(e)}
-    out = {"devices": n, "mode": args.mode, "hypotheses_per_call": args.hyp * n, "steps": args.steps, **extra,
+    diag = {}
+    try:   # who else is on the CPUs while this runs (bench.py starts it as a child: its own threads should be asleep)
+        ppid = os.getppid()
+        states = {}
+        for t in os.listdir(f"/proc/{ppid}/task"):
+            st = open(f"/proc/{ppid}/task/{t}/stat").read().rsplit(")", 1)[1].split()[0]
+            states[st] = states.get(st, 0) + 1
+        diag = {"cpus": len(os.sched_getaffinity(0)), "loadavg": os.getloadavg()[0], "parent_threads_by_state": states}
+    except OSError:
+        pass
+    out = {"devices": n, "mode": args.mode, "hypotheses_per_call": args.hyp * n, "steps": args.steps, "diag": diag, **extra,
            "resident": {"ms_per_call": dt_res * 1e3, "hypotheses_per_s": args.hyp * n / dt_res},
            "host_pointers": {"ms_per_call": dt_host * 1e3, "hypotheses_per_s": args.hyp * n / dt_host,
                              "last_call_ms": tim},
