@@ -249,7 +249,7 @@ struct HostOut {
     size_t off, n;
   } items[kMaxItems];
   int n_items = 0;
-  std::vector<unsigned char> spill;   // fetch() without room in the area
+  std::vector<std::vector<unsigned char>> spill;   // fetch() without room in the area: pageable landing buffers of its own
 
   HostOut(pgp_ctx* c, hipStream_t s) : ctx(c), st(s), mark(c->h_out_used) {}
   ~HostOut() { ctx->h_out_used = mark; }
@@ -285,8 +285,8 @@ struct HostOut {
   int fetch(const unsigned char** where, const void* d_src, size_t bytes) {
     unsigned char* p = room(bytes);
     if (!p) {
-      spill.resize(bytes);   // (one fetch per HostOut may spill: a second resize would move the first)
-      p = spill.data();
+      spill.emplace_back(bytes ? bytes : 1);
+      p = spill.back().data();
     }
     *where = p;
     if (bytes) PGP_HIP(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, st));
