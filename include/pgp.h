@@ -349,11 +349,11 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * iterations are driven from the host (many workgroups per pose) and the call synchronises the
  * stream every four iterations to test for convergence.  While few poses are in flight (n x 4 or
  * n x 2 <= the device's compute units) that ONE launch is cooperative, with 4 or 2 workgroups per pose
- * sharing the search (not on a stream that is being captured; PGP_ICP_WGS=1 switches it off), followed by a
- * repair launch that does nothing unless the workgroups of a pose failed to meet (another process spinning on
- * the same GPU): it then refines every pose again from its initial transform, one workgroup per pose -- the
- * caller always receives refined transforms, with or without d_iters.  Clustered launches of one process never
- * overlap on a device.  Checker paths, same results:
+ * sharing the search (not on a stream that is being captured; PGP_ICP_WGS=1 switches it off).  Should the
+ * workgroups of a pose ever fail to meet (another process holding the GPU's compute units for seconds), the pose's
+ * first workgroup searches every query again and finishes the pose alone, inside the same launch -- the caller always
+ * receives refined transforms, the same bits.  Clustered launches of one process never overlap on a device.
+ * Checker paths, same results:
  * PGP_ICP_NN=scan (exhaustive search), PGP_ICP_PERSIST=0 (index, host-driven iterations),
  * PGP_ICP_SPLIT=0/1 (the exhaustive persistent / host-driven kernels). */
 int pgp_icp_refine_device(pgp_ctx* ctx, const float* d_src4, int n_src, const float* d_tgt4, int n_tgt,

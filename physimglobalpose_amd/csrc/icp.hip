@@ -158,15 +158,12 @@ struct IcpArgs {
   // radius inside which no unlisted point lies -- resolves a query next to a known candidate without a search
   const uint4* nn_vic;           // [n_tgt] or nullptr
   int first_walk;                // moves downhill on the graph in the FIRST iteration (no previous correspondence yet)
-  // lost meetings (clustered launch): a workgroup whose partners did not arrive sets *x_lost; the follow-up launch
-  // (run_if = x_lost, one workgroup per pose, starting again from the transforms saved in T_save) repairs the call
+  // lost passes (the helping launch, PGP_ICP_HELP): a workgroup sets *x_lost; the follow-up launch (run_if = x_lost, one
+  // workgroup per pose, starting again from the transforms saved in T_save) repairs the call.  (The clustered launch
+  // repairs a lost meeting inside itself: workgroup 0 of the pose goes on alone.)
   unsigned* x_lost;              // [1] in the library's own workspace
   unsigned* x_done;              // [n] workgroups of the pose that have left: the last one zeroes the pose's counters for the next call
-  unsigned* lost_out;            // nullable: the lost flag once more, where the CALLER reads it (a host-pointer call checks it itself
-                                 // after its one synchronisation instead of paying for a repair launch behind every call)
-  int force_lost;                // test knob (PGP_ICP_FORCE_LOST): the first meeting is declared lost
-  unsigned call_seq;             // what a lost meeting writes into *x_lost: this launch's number on its context (never 0), so that a
-  unsigned run_if_value;         // repair launch (run_if, run_if_value) answers to ITS clustered launch only and nobody has to clear the flag
+  int force_lost;                // test knob (PGP_ICP_FORCE_LOST): every pose's first meeting is declared lost
   float* T_save;                 // [n][16]: clustered launch: part 0 stores the pose's initial transform here
   const float* T_in;             // where a pose's initial transform is read (T itself, or T_save in the repair launch)
   const unsigned* run_if;        // non-null: the whole launch returns at once unless *run_if != 0
@@ -2685,7 +2682,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
   __shared__ NnSched s_sch;
 
   // the repair launch of a clustered call (launch_icp): nothing to do unless a meeting was lost
-  if (!CLUSTER && a.run_if && *a.run_if != a.run_if_value) return;   // (the repair launch is a one-workgroup-per-pose launch)
+  if (!CLUSTER && a.run_if && *a.run_if == 0u) return;   // (the helping launch's repair launch: one workgroup per pose)
 
   // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
   // searches its share of the source points (nn_share_query); the shares meet in HBM (x_buf) once per iteration,
@@ -2770,14 +2767,29 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
             break;
           }
         }
-        if (a.force_lost) s_lost = 1;
+        if (a.force_lost && it == 0) s_lost = 1;
         unsigned slowest = 0;
         for (int k = 0; k < P; ++k)
           slowest = max(slowest, __hip_atomic_load(&xt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
         s_solo = slowest < a.solo_ticks ? 1 : 0;   // the same P numbers in every workgroup: the same decision
       }
       __syncthreads();
-      if (s_lost) break;
+      if (s_lost) {
+        // A partner did not arrive in time (another process holding the chip's compute units for seconds): workgroup 0
+        // goes on ALONE from this very iteration -- it holds every query's previous correspondence (each meeting hands
+        // all shares to everybody) and searches all queries again under the same transform --, the others leave.  Exact
+        // nearest neighbours whoever searches: the bits of the undisturbed launch.  (A workgroup that comes late finds
+        // the counter short of its next target, times out in its turn and leaves, or -- workgroup 0 -- goes on alone.)
+        if (part != 0) {
+          cluster_leave(a, pose, tid);
+          return;
+        }
+        __syncthreads();
+        if (tid == 0) s_lost = 0;
+        P = 1;
+        n_share = a.n_src;
+        continue;   // (the loop's head searches again: the iteration count has not moved)
+      }
       if (s_solo && part != 0) {         // this share is published; workgroup 0 finishes the pose
         cluster_leave(a, pose, tid);
         return;
@@ -3059,7 +3071,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         if (a.iters) a.iters[pose] = it;
       }
     } else if (tid == 0) {
-      __hip_atomic_store(a.x_lost, a.call_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.x_lost, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // ---- this pose is through: take search passes of the poses that are still running (see HelpPub)
     __shared__ int h_pose;
@@ -3128,19 +3140,8 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
     }
     return;
   }
-  if (CLUSTER && s_lost) {
-    // a partner never arrived (another process holding the GPU's CUs): this call's transforms are not to be
-    // trusted.  The flag lives in the library's workspace; the repair launch that follows every clustered launch
-    // sees it and runs all poses again from their saved initial transforms, one workgroup per pose.
-    if (tid == 0) {
-      __hip_atomic_store(a.x_lost, a.call_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.lost_out) __hip_atomic_store(a.lost_out, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // every workgroup of the launch runs and leaves sooner or later -- the one that came too late meets nobody and times
-    // out in its turn --, so the counters are back at zero when the launch is over, lost or not
-    cluster_leave(a, pose, tid);
-    return;
-  }
+  // (every workgroup of a clustered launch runs and leaves sooner or later -- also the one that came too late for a meeting --,
+  //  so the counters are back at zero when the launch is over)
   if (CLUSTER) cluster_leave(a, pose, tid);
   if (CLUSTER && part != 0) return;
   if (tid < 16) Tg[tid] = s_G[tid];
@@ -3451,7 +3452,7 @@ static bool icp_trim_only(const IcpArgs& a) {
 
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
-               unsigned long long tgt_token, unsigned* d_lost_out, bool no_cluster) {
+               unsigned long long tgt_token) {
   if (n <= 0) return PGP_OK;
   if (n_src <= 0 || n_tgt <= 0) {
     set_error("icp: empty source or target cloud");
@@ -3471,14 +3472,12 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     for (int off = 0; off < n; off += kMaxPoses) {
       const int m = n - off < kMaxPoses ? n - off : kMaxPoses;
       int rc = launch_icp(ctx, d_src, n_src, d_tgt, d_tgt_n, n_tgt, d_T + 16 * (size_t)off, m, prm,
-                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream, tgt_token, d_lost_out,
-                          no_cluster);
+                          d_energy ? d_energy + off : nullptr, d_iters ? d_iters + off : nullptr, stream, tgt_token);
       if (rc != PGP_OK) return rc;
     }
     return PGP_OK;
   }
   IcpArgs a{};
-  a.call_seq = a.run_if_value = 1u;
   a.src = d_src;
   a.tgt = d_tgt;
   a.tgt_n = d_tgt_n;
@@ -3558,7 +3557,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     if (const char* v = getenv("PGP_ICP_ROWS")) a.rows_mode = atoi(v);
     int want_wgs = n * 4 <= ctx->n_cus ? 4 : (n * 2 <= ctx->n_cus ? 2 : 1);
     if (const char* v = getenv("PGP_ICP_WGS")) want_wgs = atoi(v) == 4 ? 4 : (atoi(v) == 2 ? 2 : 1);   // A/B knob
-    if (no_cluster) want_wgs = 1;   // (the caller's second attempt after a lost meeting)
     if (want_wgs > 1 && a.smooth == 0 && n * want_wgs <= ctx->n_cus && n_src >= 64 * want_wgs) {
       hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
       if (hipStreamIsCapturing(stream, &cap) != hipSuccess) cap = hipStreamCaptureStatusActive;
@@ -3572,19 +3570,16 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       std::lock_guard<std::mutex> chain(g_coop.mu);
       if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
       else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
-      // meeting buffers | arrival counters | lost flag | workgroups that have left | search ticks | saved transforms
+      // meeting buffers | arrival counters | workgroups that have left | search ticks
       const size_t xbytes = 2 * need * 8, ctr_words = 2 * (size_t)n + 4;
       const void* x_before = ctx->d_icp_x.p;
       const size_t x_cap_before = ctx->d_icp_x.cap;
-      if ((rc = ctx->d_icp_x.ensure(xbytes + ctr_words * 4 + (size_t)n * 32 + (size_t)n * 64 + 64)) != PGP_OK) return rc;
+      if ((rc = ctx->d_icp_x.ensure(xbytes + ctr_words * 4 + (size_t)n * 32 + 64)) != PGP_OK) return rc;
       a.x_buf = ctx->d_icp_x.as<unsigned long long>();
       a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
-      a.x_lost = a.x_ctr + n;
-      a.x_done = a.x_lost + 4;
-      a.lost_out = d_lost_out;
+      a.x_done = a.x_ctr + n + 4;
       if (getenv("PGP_ICP_FORCE_LOST")) a.force_lost = 1;   // test knob: the first meeting of every pose counts as lost
       a.x_ticks = a.x_ctr + ctr_words;
-      a.T_save = reinterpret_cast<float*>(a.x_ticks + (size_t)n * 8);
       a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
       if (const char* v = getenv("PGP_ICP_SOLO_TICKS")) a.solo_ticks = (unsigned)atoi(v);
       // The counters are zero whenever a clustered launch on this context is over (every pose's last workgroup to leave
@@ -3596,39 +3591,21 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       ctx->icp_x_clean = true;
       ctx->icp_x_n = n;
       ctx->icp_x_need = (size_t)need;
-      if (++ctx->icp_x_seq == 0u) ++ctx->icp_x_seq;
-      a.call_seq = ctx->icp_x_seq;
       void* params[] = {&a};
       hipError_t e = hipLaunchCooperativeKernel(fn_cluster, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG"))
         fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
-      if (e == hipSuccess && d_lost_out) {
-        // The caller reads the lost flag with the results it synchronises for anyway and, should it ever be set,
-        // calls again with no_cluster: no repair launch behind the kernel (1.6 us + ~12 us of dependency latency).
-        PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
-        PGP_HIP(hipGetLastError());
-        return PGP_OK;
-      }
       if (e == hipSuccess) {
-        // The repair launch: one workgroup per pose, an ordinary launch; every workgroup returns at once unless a
-        // meeting of the clustered launch was lost (another process spinning on the CUs), in which case all poses
-        // run again from their saved initial transforms.  The caller -- host-pointer or device-pointer API, with
-        // or without d_iters -- always gets refined transforms; nothing is reported through iters any more.
-        IcpArgs fix = a;
-        fix.wgs_per_pose = 1;
-        fix.run_if = a.x_lost;
-        fix.run_if_value = a.call_seq;
-        fix.T_in = a.T_save;
-        fix.T_save = nullptr;
-        void* fparams[] = {&fix};
-        PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), fparams, plds, stream));
+        // Nothing behind the kernel: a meeting that is lost (another process holding the chip's compute units for
+        // seconds) makes the pose's workgroup 0 go on alone inside the launch (icp_persist_body), so the caller --
+        // host-pointer or device-pointer API -- always gets refined transforms.  (Rounds 3-4 queued a repair launch
+        // behind every clustered launch for that case: 1.6 us + ~12 us of dependency latency per call.)
         PGP_HIP(hipEventRecord(g_coop.last[dev], stream));
         PGP_HIP(hipGetLastError());
         return PGP_OK;
       }
       (void)hipGetLastError();   // the grid does not fit as a cooperative launch here: one workgroup per pose
       a.wgs_per_pose = 1;
-      a.T_save = nullptr;
     }
     // One workgroup per pose and all of them resident at once (129 .. 256 poses on 256 compute units): a workgroup
     // that is through with its pose takes search passes of the poses still running (HelpPub) -- the launch then
@@ -3658,7 +3635,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       ctx->icp_x_clean = false;   // (the clustered launch's counters live in the same buffer)
       unsigned char* base = ctx->d_icp_x.as<unsigned char>();
       IcpArgs h = a;
-      h.call_seq = h.run_if_value = 1u;   // (its lost flag is filled with zero before every launch)
       h.help_ctl = reinterpret_cast<unsigned long long*>(base);
       h.help_nslots = reinterpret_cast<unsigned*>(base + N * 8);
       h.help_done = h.help_nslots + N;
@@ -3676,7 +3652,6 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
         IcpArgs fix = a;
         fix.wgs_per_pose = 1;
         fix.run_if = h.x_lost;
-        fix.run_if_value = 1u;
         fix.T_in = h.T_save;
         fix.T_save = nullptr;
         void* fparams[] = {&fix};

@@ -1277,8 +1277,7 @@ int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
   int rc;
   IcpHostStage g{};
   g.off_T = (size_t)std::max(n_src, 1) * 16;
-  g.off_f = g.off_T + (size_t)n * 64;
-  g.off_e = g.off_f + 64;
+  g.off_e = g.off_T + (size_t)n * 64;
   g.off_i = g.off_e + (size_t)n * 4;
   g.total = g.off_i + (size_t)n * 4;
   if ((rc = ctx->d_icp_src.ensure(g.total)) != PGP_OK) return rc;
@@ -1300,7 +1299,6 @@ int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
     for (int i = 0; i < n_src; ++i)
       ps[i] = make_float4(src_xyz[3 * (size_t)i], src_xyz[3 * (size_t)i + 1], src_xyz[3 * (size_t)i + 2], 0.f);
     std::memcpy(pin + g.off_T, T, (size_t)n * 64);
-    std::memset(pin + g.off_f, 0, 64);
   }
   const unsigned long long tok = hash_of(tgt_xyz, n_tgt);
   if (!(tok == ctx->icp_host_token && n_tgt == ctx->icp_host_ntgt)) {
@@ -1317,7 +1315,6 @@ int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
   g.d_src = reinterpret_cast<const float4*>(dev);
   g.d_tgt = ctx->d_icp_tgt.as<float4>();
   g.d_T = reinterpret_cast<float*>(dev + g.off_T);
-  g.d_lost = reinterpret_cast<unsigned*>(dev + g.off_f);
   g.d_energy = reinterpret_cast<float*>(dev + g.off_e);
   g.d_iters = reinterpret_cast<int*>(dev + g.off_i);
   g.token = tok;
@@ -1371,22 +1368,10 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
     }
     d_n = ctx->d_icp_tgt_n.as<float4>();
   }
-  // The call synchronises for its results anyway: it reads the clustered launch's lost flag with them (no repair launch
-  // queued behind every call) and, should a meeting ever have been lost -- another process holding the chip's compute
-  // units for seconds --, runs the poses again from the caller's transforms, one workgroup per pose.
-  rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token, g.d_lost, false);
+  rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token);
   if (rc != PGP_OK) return rc;
   if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
   PGP_HIP(hipStreamSynchronize(st));
-  unsigned lost = 0;
-  std::memcpy(&lost, static_cast<const unsigned char*>(ctx->h_pin) + g.off_f, 4);
-  if (lost) {
-    if ((rc = icp_host_stage(ctx, src_xyz, n_src, tgt_xyz, n_tgt, T, n, st, &g)) != PGP_OK) return rc;
-    rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token, nullptr, true);
-    if (rc != PGP_OK) return rc;
-    if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
-    PGP_HIP(hipStreamSynchronize(st));
-  }
   icp_host_collect(ctx, g, n, T, energy, iters);
   return PGP_OK;
 }

@@ -168,11 +168,10 @@ struct pgp_ctx {
   alignas(8) unsigned char icp_idx_geom[96] = {0};
   // the uniform grid of the capped scene-sized search (icp.hip use_grid), kept across calls by the same rule
   // clustered ICP launches: the words of d_icp_x that hold the meeting counters of `icp_x_n` poses over `icp_x_need` meeting
-  // records were the counters of the last such launch (which leaves them at zero); the launches' running number
+  // records were the counters of the last such launch (which leaves them at zero)
   bool icp_x_clean = false;
   int icp_x_n = 0;
   size_t icp_x_need = 0;
-  unsigned icp_x_seq = 0;
   bool icp_grid_valid = false;
   unsigned long long icp_grid_token = 0;
   const void* icp_grid_tgt = nullptr;
@@ -370,7 +369,7 @@ struct IcpJob {
 int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm, hipStream_t stream);
 int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt, const float4* d_tgt_n, int n_tgt,
                float* d_T, int n, const pgp_icp_options* prm, float* d_energy, int* d_iters, hipStream_t stream,
-               unsigned long long tgt_token = 0, unsigned* d_lost_out = nullptr, bool no_cluster = false);
+               unsigned long long tgt_token = 0);
 
 // pgp_api.hip: a host-pointer ICP job staged in a context's buffers (pgp_icp_refine_ex; the device group's pose shards)
 struct IcpHostStage {
@@ -381,8 +380,6 @@ struct IcpHostStage {
   int* d_iters;
   unsigned long long token;          // hash of the target's coordinates: the key of its resident index
   size_t off_T, off_e, off_i, total; // byte offsets inside d_icp_src and its pinned image
-  size_t off_f;                      // 64 bytes of flags between the transforms and the energies (word 0: a meeting was lost)
-  unsigned* d_lost;
 };
 int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, int n_tgt, const float* T, int n,
                    hipStream_t st, IcpHostStage* out);

@@ -1,9 +1,8 @@
 """The clustered ICP launch (several workgroups per pose, up to 128 poses: csrc/icp.hip) around its edges: a LOST meeting --
-forced by PGP_ICP_FORCE_LOST -- must end in the same transforms through both repairs (the host-pointer call reads the flag with
-its results and runs the poses again, one workgroup each; the device-pointer call has a repair launch queued behind the
-kernel); and the meeting counters, which the kernel puts back to zero itself instead of a fill before every call, must hold
-across calls of changing shape on one context.  The reference's consumer: the per-expansion refinement of the search
-(UCTState.cpp:121-204)."""
+forced by PGP_ICP_FORCE_LOST -- must end in the same transforms (the pose's workgroup 0 goes on alone inside the launch, the
+others leave: no repair launch, no flag for the caller), through the host-pointer and the device-pointer call; and the meeting
+counters, which the kernel puts back to zero itself instead of a fill before every call, must hold across calls of changing
+shape on one context.  The reference's consumer: the per-expansion refinement of the search (UCTState.cpp:121-204)."""
 import numpy as np
 import pytest
 import torch
@@ -24,7 +23,7 @@ def _same(a, b):
     return all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
-def test_lost_meeting_is_repaired_by_the_host_call_and_by_the_device_call(monkeypatch):
+def test_lost_meeting_is_repaired_inside_the_launch(monkeypatch):
     S, M, N, G = _problem(81, 5000, 2500, 24, rot_deg=4.0, trans=0.004, outliers=0.03)
     sc = LcpScorer()
     monkeypatch.setenv("PGP_ICP_WGS", "1")
@@ -32,16 +31,16 @@ def test_lost_meeting_is_repaired_by_the_host_call_and_by_the_device_call(monkey
     monkeypatch.delenv("PGP_ICP_WGS")
     assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), ref)          # clustered, nothing lost
     monkeypatch.setenv("PGP_ICP_FORCE_LOST", "1")
-    assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), ref)          # lost: the call runs the poses again
+    assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), ref)          # lost: workgroup 0 of every pose goes on alone
     d_src, d_tgt = _dev4(S), _dev4(M)
     d_T = torch.from_numpy(G.copy()).cuda().reshape(-1, 16)
     d_e = torch.zeros(len(G), device="cuda")
     d_it = torch.zeros(len(G), dtype=torch.int32, device="cuda")
-    sc.icp_refine_device(d_src, d_tgt, d_T, d_e, d_it, trim=0.9, max_iterations=12)   # lost: the repair launch behind it
+    sc.icp_refine_device(d_src, d_tgt, d_T, d_e, d_it, trim=0.9, max_iterations=12)   # the same through the device-pointer call
     torch.cuda.synchronize()
     assert _same((d_T.cpu().numpy().reshape(ref[0].shape), d_e.cpu().numpy(), d_it.cpu().numpy()), ref)
     monkeypatch.delenv("PGP_ICP_FORCE_LOST")
-    # the counters a lost call left behind are zeroed before the next clustered launch
+    # the counters are back at zero after a lost call too
     assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), ref)
     assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), ref)
     sc.close()
@@ -59,7 +58,7 @@ def test_counters_hold_across_calls_of_changing_shape(monkeypatch):
         for (S, M, N, G), ref in zip(probs, refs):
             assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=8), ref)
             assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=8), ref)
-    # a device-pointer call in between (it fills the counters itself and leaves them "unknown")
+    # a device-pointer call in between
     S, M, N, G = probs[0]
     d_T = torch.from_numpy(G.copy()).cuda().reshape(-1, 16)
     sc.icp_refine_device(_dev4(S), _dev4(M), d_T, trim=0.9, max_iterations=8)
