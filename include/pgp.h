@@ -232,6 +232,11 @@ int pgp_set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int*
  * status[n_attempts]: 1 = base found, 0 = the reference would have returned false (no candidate
  * left for the 2nd / 3rd / 4th point).  Host pointers, synchronous. */
 int pgp_select_bases(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, float* invariants, int* status);
+/* The same, and rows[n_attempts][2]: the rows of the pair-feature table under which ExtractCongruentSet finds pairs1 and
+ * pairs6 of the base -- PPFMap->find(computePPF(ids[0], ids[1])) and (ids[2], ids[3]), base.cc:1970-1981; -1: not a key --
+ * computed where the base is selected, for pgp_find_congruent_batch_rows below (one launch and one round trip less per
+ * object than asking for them again). */
+int pgp_select_bases_rows(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, float* invariants, int* status, int* rows);
 
 /* The pieces of the above, for parity tests and for callers that keep their own sampling loop:
  * pgp_ppf_features: computePPF for m (i, j) pairs of scene ids -> features[m][4] (-1: not a key,
@@ -306,6 +311,10 @@ int pgp_find_congruent_4pcs(pgp_ctx* ctx, float invariant1, float invariant2, fl
  *     device: the reference's sampling of <= 100 quads per base (base.cc:1858-1872) decides the picks. */
 int pgp_find_congruent_batch(pgp_ctx* ctx, const int* base_ids, const float* base_xyz, const float* invariants,
                              int n_bases, float threshold, int* n_quads);
+/* pgp_find_congruent_batch for a caller that already holds rows[n_bases][2] (pgp_select_bases_rows, or pgp_ppf_features of
+ * the edges (ids 0-1), (ids 2-3)): same quads, same order.  A row outside [-1, rows of the table) is PGP_EINVAL. */
+int pgp_find_congruent_batch_rows(pgp_ctx* ctx, const int* base_ids, const float* base_xyz, const float* invariants,
+                                  const int* rows, int n_bases, float threshold, int* n_quads);
 int pgp_congruent_batch_quads(pgp_ctx* ctx, const int* picks, int m, int* quads);
 int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
                             const float centroid_Q[3], float* T, double* pose, int* status, float* rms);
@@ -320,6 +329,21 @@ int pgp_congruent_batch_fit_score(pgp_ctx* ctx, const int* picks, const int* bas
                                   const float centroid_Q[3], int mode, float gate_deg, float* scores, int* status,
                                   int* best_index, float* best_score);
 int pgp_congruent_batch_fetch(pgp_ctx* ctx, const int* index, int k, float* T, double* pose);
+/* pgp_congruent_batch_fit_score and everything the caller of Perform_N_steps reads afterwards, in ONE call with ONE copy
+ * back and ONE synchronisation: the running-best walk of the verification loop (base.cc:1891-1908, what pgp_running_best
+ * computes on the host -- run with pgp_set_exact_records for the reference's own decisions) on the device, the poses it
+ * keeps, the best pose (base.cc:1787-1790) and the scene points the best pose registers (pgp_registered).
+ *   n_list: the number of records; list_index / list_score / list_T [.][16] / list_pose [.][16] hold the first
+ *     min(n_list, list_cap) of them in walk order (list_cap <= 4096; n_list > list_cap: call pgp_congruent_batch_fetch
+ *     for the rest -- the scores stay on the device, the fits too);
+ *   n_pushed (nullable): the number of fits the reference pushes (status == 1, base.cc:1467-1485);
+ *   best_index = -1: no hypothesis scored above 0 -- best_T / best_pose / registered are then left alone, n_registered = 0;
+ *   registered: room for every model point (pgp_set_model's n).  Nullable outputs: n_pushed, best_*, registered. */
+int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                                       const float centroid_Q[3], int mode, float gate_deg, int list_cap, int* n_list,
+                                       int* list_index, float* list_score, float* list_T, double* list_pose, int* n_pushed,
+                                       int* best_index, float* best_score, float* best_T, double* best_pose, int* registered,
+                                       int* n_registered);
 
 /* ICP refinement.  Replaces the inner loop behind pcl::recognition::TrimmedICP::align
  * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and

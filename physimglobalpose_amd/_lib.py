@@ -81,6 +81,7 @@ SIGNATURES = {
     "pgp_set_search_model": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_set_ppf_map": (C.c_int, [C.c_void_p, _i, _i, _i, C.c_int]),
     "pgp_select_bases": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, _i, _f, _i]),
+    "pgp_select_bases_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, _i, _f, _i, _i]),
     "pgp_ppf_features": (C.c_int, [C.c_void_p, _i, C.c_int, _i, _i]),
     "pgp_stocs_stage_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _i]),
     "pgp_base_invariants": (C.c_int, [C.c_void_p, _i, C.c_int, _f, _i]),
@@ -93,10 +94,13 @@ SIGNATURES = {
     "pgp_find_congruent": (C.c_int, [C.c_void_p, _f, C.c_float, C.c_float, C.c_float, _i, C.c_int,
                                      _i, C.c_int, _i, C.c_int, _i]),
     "pgp_find_congruent_batch": (C.c_int, [C.c_void_p, _i, _f, _f, C.c_int, C.c_float, _i]),
+    "pgp_find_congruent_batch_rows": (C.c_int, [C.c_void_p, _i, _f, _f, _i, C.c_int, C.c_float, _i]),
     "pgp_congruent_batch_quads": (C.c_int, [C.c_void_p, _i, C.c_int, _i]),
     "pgp_congruent_batch_fit": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, _f, C.POINTER(C.c_double), _i, _f]),
     "pgp_congruent_batch_fit_score": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, C.c_int, C.c_float, _f, _i, _i, _f]),
     "pgp_congruent_batch_fetch": (C.c_int, [C.c_void_p, _i, C.c_int, _f, C.POINTER(C.c_double)]),
+    "pgp_congruent_batch_fit_score_list": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, C.c_int, C.c_float, C.c_int, _i, _i, _f, _f,
+                                                    C.POINTER(C.c_double), _i, _i, _f, _f, C.POINTER(C.c_double), _i, _i]),
     "pgp_icp_refine": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _f, C.c_int,
                                  C.POINTER(IcpParams), _f, _i]),
     "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -132,6 +132,7 @@ struct SelectArgs {
   int4* ids;
   float2* inv;
   int* status;              // 1 ok; 0 no candidate left at stage 2 / 3 / 4 (the reference returns false)
+  int2* rows;               // nullable: the table rows of the base's two edges (ids 0-1, ids 2-3), what ExtractCongruentSet looks up
 };
 
 // ---- the three weighting loops, one point per call (base.cc:625-652, 662-699, 713-769) ----------
@@ -393,6 +394,7 @@ __global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
       a.status[att] = 0;
       a.ids[att] = make_int4(-1, -1, -1, -1);
       a.inv[att] = make_float2(0.f, 0.f);
+      if (a.rows) a.rows[att] = make_int2(-1, -1);
     }
   };
   // ---- point 1: discrete_distribution over orig_probabilities_ (its double prefix sums are shared)
@@ -505,10 +507,20 @@ __global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
     int ids[4] = {b1, b2, b3, b4};
     float i1 = 0.f, i2 = 0.f;
     try_quadrilateral(a.P, ids, &i1, &i2);
+    // the rows of the pair-feature table that hold pairs1 / pairs6 of this base (computePPF of its two edges,
+    // base.cc:1970-1981): they ride home with the base, so that pgp_find_congruent_batch_rows need not ask for them
+    int row = -1;
+    if (a.rows && threadIdx.x < 2) {
+      const int i = threadIdx.x == 0 ? ids[0] : ids[2], j = threadIdx.x == 0 ? ids[1] : ids[3];
+      const float4 n1 = a.Pnw[i], n2 = a.Pnw[j];
+      row = table_find(a.tab, ppf_key(a.tab, ld3(a.P, i), {n1.x, n1.y, n1.z}, ld3(a.P, j), {n2.x, n2.y, n2.z}, nullptr));
+    }
+    const int row6 = __shfl(row, 1, 64);
     if (threadIdx.x == 0) {
       a.ids[att] = make_int4(ids[0], ids[1], ids[2], ids[3]);
       a.inv[att] = make_float2(i1, i2);
       a.status[att] = 1;
+      if (a.rows) a.rows[att] = make_int2(row, row6);
     }
   }
 }
@@ -751,7 +763,7 @@ int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pai
 }
 
 int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_ids, float* h_inv, int* h_status,
-                        hipStream_t st) {
+                        int* h_rows, hipStream_t st) {
   SelectArgs a{};
   int rc = fill_select_args(ctx, &a);
   if (rc != PGP_OK) return rc;
@@ -773,15 +785,16 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
     ctx->prob_cdf_valid = true;
   }
   const size_t A = (size_t)n_attempts;
-  // workspace: u (double) | ids (int4) | inv (float2) | status (int) | cur (float [A][n])
-  const size_t bytes = A * 32 + A * 16 + A * 8 + A * 4 + A * (size_t)n * 4 + 256;
+  // workspace: u (double) | ids (int4) | inv (float2) | status (int) | rows (int2) | cur (float [A][n])
+  const size_t bytes = A * 32 + A * 16 + A * 8 + A * 4 + A * 8 + A * (size_t)n * 4 + 256;
   if ((rc = ctx->d_sel_ws.ensure(bytes)) != PGP_OK) return rc;
   unsigned char* base = ctx->d_sel_ws.as<unsigned char>();
   double* d_u = reinterpret_cast<double*>(base);
   int4* d_ids = reinterpret_cast<int4*>(base + A * 32);
   float2* d_inv = reinterpret_cast<float2*>(base + A * 48);
   int* d_status = reinterpret_cast<int*>(base + A * 56);
-  float* d_cur = reinterpret_cast<float*>(base + ((A * 60 + 255) & ~(size_t)255));
+  int2* d_rows = reinterpret_cast<int2*>(base + A * 60);
+  float* d_cur = reinterpret_cast<float*>(base + ((A * 68 + 255) & ~(size_t)255));
   PGP_HIP(hipMemcpyAsync(d_u, h_u, A * 32, hipMemcpyHostToDevice, st));
   a.prob_cdf = ctx->d_prob_cdf.as<double>();
   a.u = d_u;
@@ -789,15 +802,17 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   a.ids = d_ids;
   a.inv = d_inv;
   a.status = d_status;
+  a.rows = h_rows ? d_rows : nullptr;
   hipLaunchKernelGGL(select_bases, dim3(n_attempts), dim3(kSelThreads), 0, st, a);
   PGP_HIP(hipGetLastError());
-  // ids | inv | status lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
+  // ids | inv | status | rows lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
   HostOut out(ctx, st);
   const unsigned char* got = nullptr;
-  if ((rc = out.fetch(&got, d_ids, A * 28)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+  if ((rc = out.fetch(&got, d_ids, A * (h_rows ? 36 : 28))) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
   std::memcpy(h_ids, got, A * 16);
   std::memcpy(h_inv, got + A * 16, A * 8);
   std::memcpy(h_status, got + A * 24, A * 4);
+  if (h_rows) std::memcpy(h_rows, got + A * 28, A * 8);
   return PGP_OK;
 }
 

@@ -812,7 +812,7 @@ int cone_for_base(const float base[12], float* cone /*[56][3]*/) {
 
 // Phase 1 + 2 for all bases: leaves the sorted match keys and the per-base starts in the context.
 int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
-                                int nb, float threshold, int* h_n_quads, hipStream_t st) {
+                                const int* h_rows, int nb, float threshold, int* h_n_quads, hipStream_t st) {
   ctx->csb_fit_m = 0;
   ctx->csb_nb = 0;
   if (ctx->nQs <= 0 || !ctx->d_Qs.p) {
@@ -847,8 +847,20 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     edge_pairs[4 * b + 2] = h_base_ids[4 * b + 2];   // computePPF(base_id3, base_id4)
     edge_pairs[4 * b + 3] = h_base_ids[4 * b + 3];
   }
-  int rc = launch_ppf_features(ctx, edge_pairs.data(), 2 * nb, nullptr, rows.data(), st);
-  if (rc != PGP_OK) return rc;
+  int rc = PGP_OK;
+  if (h_rows) {   // the caller holds them already (pgp_select_bases_rows): one launch and one round trip less
+    const int n_rows = (int)ctx->ppf_off_host.size() - 1;
+    for (int k = 0; k < 2 * nb; ++k) {
+      if (h_rows[k] < -1 || h_rows[k] >= n_rows) {
+        set_error("pgp_find_congruent_batch_rows: row %d of base %d is not a row of the table (%d rows)", h_rows[k], k / 2, n_rows);
+        return PGP_EINVAL;
+      }
+      rows[(size_t)k] = h_rows[k];
+    }
+  } else {
+    rc = launch_ppf_features(ctx, edge_pairs.data(), 2 * nb, nullptr, rows.data(), st);
+    if (rc != PGP_OK) return rc;
+  }
   stage("pair features of the bases");
   const float eps = threshold / ctx->cs_ratio;          // getNormalizedEpsilon
   const int gridDepth = (int)(-std::log2(eps));          // normalset.h:116

@@ -779,7 +779,17 @@ int pgp_select_bases(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, fl
   }
   if (n_attempts == 0) return PGP_OK;
   CtxGuard guard(ctx);
-  return launch_select_bases(ctx, u, n_attempts, ids, invariants, status, ctx->stream);
+  return launch_select_bases(ctx, u, n_attempts, ids, invariants, status, nullptr, ctx->stream);
+}
+
+int pgp_select_bases_rows(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, float* invariants, int* status, int* rows) {
+  if (!ctx || n_attempts < 0 || (n_attempts > 0 && (!u || !ids || !invariants || !status || !rows))) {
+    set_error("pgp_select_bases_rows: bad argument");
+    return PGP_EINVAL;
+  }
+  if (n_attempts == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  return launch_select_bases(ctx, u, n_attempts, ids, invariants, status, rows, ctx->stream);
 }
 
 int pgp_ppf_features(pgp_ctx* ctx, const int* pairs, int m, int* features, int* rows) {
@@ -918,7 +928,17 @@ int pgp_find_congruent_batch(pgp_ctx* ctx, const int* base_ids, const float* bas
     return PGP_EINVAL;
   }
   CtxGuard guard(ctx);
-  return launch_find_congruent_batch(ctx, base_ids, base_xyz, invariants, n_bases, threshold, n_quads, ctx->stream);
+  return launch_find_congruent_batch(ctx, base_ids, base_xyz, invariants, nullptr, n_bases, threshold, n_quads, ctx->stream);
+}
+
+int pgp_find_congruent_batch_rows(pgp_ctx* ctx, const int* base_ids, const float* base_xyz, const float* invariants,
+                                  const int* rows, int n_bases, float threshold, int* n_quads) {
+  if (!ctx || n_bases < 0 || (n_bases > 0 && (!base_ids || !base_xyz || !invariants || !rows || !n_quads))) {
+    set_error("pgp_find_congruent_batch_rows: bad argument");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx);
+  return launch_find_congruent_batch(ctx, base_ids, base_xyz, invariants, rows, n_bases, threshold, n_quads, ctx->stream);
 }
 
 int pgp_congruent_batch_quads(pgp_ctx* ctx, const int* picks, int m, int* quads) {
@@ -999,6 +1019,104 @@ __global__ __launch_bounds__(64) void gather_fits(const int* __restrict__ index,
   const size_t h = (size_t)index[j];
   T_out[16 * (size_t)j + q] = T[16 * h + q];
   pose_out[16 * (size_t)j + q] = pose[16 * h + q];
+}
+
+// The running-best walk of the verification loop (base.cc:1891-1908: hypothesis i enters when lcp_i > best so far, strict,
+// best_LCP_ = 0 to begin with) over the FINAL scores on the device -- what pgp_running_best does on the host, entry for
+// entry.  One block; 16 consecutive scores per thread, the running maximum in front of a thread's run by a prefix-max over
+// the block.  list[0] = number of records (all of them), list[1] = number of fits that were pushed (status == 1),
+// list[2 .. 2 + cap) = the first cap records' indices, rec_score[cap] their scores.
+__global__ __launch_bounds__(256) void records_walk(int n, const float* __restrict__ scores, const int* __restrict__ status, int cap,
+                                                    int* __restrict__ list, float* __restrict__ rec_score) {
+  constexpr int kPer = 16;
+  __shared__ float s_wmax[4];
+  __shared__ int s_wcnt[4], s_wkept[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float carry = 0.f;
+  int base = 0, kept = 0;
+  for (int s0 = 0; s0 < n; s0 += 256 * kPer) {
+    float v[kPer];
+    const int lo = s0 + tid * kPer;
+    int my_kept = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) {
+      v[k] = lo + k < n ? scores[lo + k] : 0.f;
+      my_kept += (lo + k < n && status[lo + k] == 1) ? 1 : 0;
+    }
+    float m = 0.f;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k) m = fmaxf(m, v[k]);
+    float inc = m;
+    int ik = my_kept;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(inc, off, 64);
+      const int ok = __shfl_up(ik, off, 64);
+      if (lane >= off) {
+        inc = fmaxf(inc, o);
+        ik += ok;
+      }
+    }
+    float excl = __shfl_up(inc, 1, 64);
+    if (lane == 0) excl = 0.f;
+    if (lane == 63) {
+      s_wmax[wave] = inc;
+      s_wkept[wave] = ik;
+    }
+    __syncthreads();
+    float run = fmaxf(carry, excl);
+    for (int w = 0; w < wave; ++w) run = fmaxf(run, s_wmax[w]);
+    unsigned mask = 0u;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (v[k] > run) {
+        run = v[k];
+        mask |= 1u << k;
+        ++c;
+      }
+    int ic = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(ic, off, 64);
+      if (lane >= off) ic += o;
+    }
+    if (lane == 63) s_wcnt[wave] = ic;
+    __syncthreads();
+    int at = base + ic - c;
+    for (int w = 0; w < wave; ++w) at += s_wcnt[w];
+#pragma unroll
+    for (int k = 0; k < kPer; ++k)
+      if (mask & (1u << k)) {
+        if (at < cap) {
+          list[2 + at] = lo + k;
+          rec_score[at] = v[k];
+        }
+        ++at;
+      }
+    base += s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    kept += s_wkept[0] + s_wkept[1] + s_wkept[2] + s_wkept[3];
+    carry = fmaxf(fmaxf(fmaxf(carry, s_wmax[0]), fmaxf(s_wmax[1], s_wmax[2])), s_wmax[3]);
+    __syncthreads();
+  }
+  if (tid == 0) {
+    list[0] = base;
+    list[1] = kept;
+  }
+}
+
+// entries 0 .. min(records, cap) - 1: the records of `list`; entry cap: the best hypothesis (best[0] < 0: zeros)
+__global__ __launch_bounds__(64) void gather_fits_list(const int* __restrict__ list, int cap, const int* __restrict__ best,
+                                                       const float* __restrict__ T, const double* __restrict__ pose,
+                                                       float* __restrict__ T_out, double* __restrict__ pose_out) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 4), q = threadIdx.x & 15;
+  if (j > cap) return;
+  const int n_rec = list[0] < cap ? list[0] : cap;
+  int h = -1;
+  if (j < n_rec) h = list[2 + j];
+  else if (j == cap) h = best[0];
+  T_out[16 * (size_t)j + q] = h >= 0 ? T[16 * (size_t)h + q] : 0.f;
+  pose_out[16 * (size_t)j + q] = h >= 0 ? pose[16 * (size_t)h + q] : 0.0;
 }
 }  // namespace
 
@@ -1120,6 +1238,119 @@ int pgp_congruent_batch_fetch(pgp_ctx* ctx, const int* index, int k, float* T, d
   PGP_HIP(hipStreamSynchronize(ctx->stream));
   if (pose) std::memcpy(pose, pin + off_pose, K * 128);
   if (T) std::memcpy(T, pin + off_T, K * 64);
+  return PGP_OK;
+}
+
+int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                                       const float centroid_Q[3], int mode, float gate_deg, int list_cap, int* n_list,
+                                       int* list_index, float* list_score, float* list_T, double* list_pose, int* n_pushed,
+                                       int* best_index, float* best_score, float* best_T, double* best_pose, int* registered,
+                                       int* n_registered) {
+  if (!ctx || m < 0 || !centroid_P || !centroid_Q || list_cap < 0 || list_cap > 4096 || !n_list || !n_registered ||
+      (m > 0 && (!picks || !base_ids)) || (list_cap > 0 && (!list_index || !list_score || !list_T || !list_pose))) {
+    set_error("pgp_congruent_batch_fit_score_list: bad argument");
+    return PGP_EINVAL;
+  }
+  *n_list = 0;
+  *n_registered = 0;
+  if (n_pushed) *n_pushed = 0;
+  if (best_index) *best_index = -1;
+  if (best_score) *best_score = 0.f;
+  if (m == 0) return PGP_OK;
+  CtxGuard guard(ctx);
+  hipStream_t st = ctx->stream;
+  const size_t N = (size_t)m, C = (size_t)list_cap, nQ = (size_t)std::max(ctx->nQ, 0);
+  int rc;
+  if ((rc = pgp_reserve(ctx, m)) != PGP_OK) return rc;
+  if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  ctx->csb_fit_m = 0;
+  if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
+  // scores | (counts) | best -- then what goes home in ONE copy: best {index, score bits} | list {records, pushed, indices}
+  // | record scores | poses (records, best) | transforms (records, best) | hits of the best pose
+  const size_t off_best = N * 8, off_list = off_best + 16, off_rs = off_list + (C + 2) * 4, off_pose = (off_rs + C * 4 + 127) & ~(size_t)127,
+               off_T = off_pose + (C + 1) * 128, off_hits = off_T + (C + 1) * 64, total = off_hits + nQ * 4 + 64;
+  if ((rc = ctx->d_out.ensure(total)) != PGP_OK) return rc;
+  const size_t in_bytes = N * 16, home = total - off_best, pin_need = in_bytes + home + 256;
+  if (pin_need > ctx->h_pin_cap) {
+    if (ctx->h_pin) {
+      hipError_t e = hipHostFree(ctx->h_pin);
+      (void)e;
+      ctx->h_pin = nullptr;
+      ctx->h_pin_cap = 0;
+    }
+    const size_t want = pin_need + pin_need / 4;
+    PGP_HIP(hipHostMalloc(&ctx->h_pin, want, hipHostMallocDefault));
+    ctx->h_pin_cap = want;
+  }
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
+  int* hb = reinterpret_cast<int*>(pin);
+  for (size_t k = 0; k < N; ++k) {
+    const int b = picks[2 * k];
+    if (b < 0 || b >= ctx->csb_nb) {
+      set_error("pgp_congruent_batch_fit_score_list: pick %zu names base %d of %d", k, b, ctx->csb_nb);
+      return PGP_EINVAL;
+    }
+    for (int j = 0; j < 4; ++j) hb[4 * k + j] = base_ids[4 * (size_t)b + j];
+  }
+  int* d_b = ctx->d_ids.as<int>();
+  int* d_q = d_b + 4 * N;
+  PGP_HIP(hipMemcpyAsync(d_b, hb, in_bytes, hipMemcpyHostToDevice, st));
+  rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st);
+  if (rc != PGP_OK) return rc;
+  double* d_pose = ctx->d_rig.as<double>();
+  float* d_T = reinterpret_cast<float*>(d_pose + 16 * N);
+  float* d_rms = d_T + 16 * N;
+  int* d_status = reinterpret_cast<int*>(d_rms + N);
+  rc = launch_rigid(ctx, d_b, d_q, m, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms, st);
+  if (rc != PGP_OK) return rc;
+  hipLaunchKernelGGL(mask_failed_fits, dim3((m + 255) / 256), dim3(256), 0, st, (const int*)d_status, m, d_T);
+  unsigned char* dev = ctx->d_out.as<unsigned char>();
+  float* d_scores = reinterpret_cast<float*>(dev);
+  int* d_best = reinterpret_cast<int*>(dev + off_best);
+  int* d_list = reinterpret_cast<int*>(dev + off_list);
+  float* d_rs = reinterpret_cast<float*>(dev + off_rs);
+  double* d_pose_out = reinterpret_cast<double*>(dev + off_pose);
+  float* d_T_out = reinterpret_cast<float*>(dev + off_T);
+  int* d_hits = reinterpret_cast<int*>(dev + off_hits);
+  rc = launch_score(ctx, d_T, m, mode, gate_deg, d_scores, nullptr, d_best, st);
+  if (rc != PGP_OK) return rc;
+  // the walk, the poses it keeps, the best pose and the points it registers: all behind the scores on the stream
+  hipLaunchKernelGGL(records_walk, dim3(1), dim3(256), 0, st, m, (const float*)d_scores, (const int*)d_status, list_cap, d_list, d_rs);
+  hipLaunchKernelGGL(gather_fits_list, dim3((list_cap + 1 + 3) / 4), dim3(64), 0, st, (const int*)d_list, list_cap, (const int*)d_best,
+                     (const float*)d_T, (const double*)d_pose, d_T_out, d_pose_out);
+  PGP_HIP(hipGetLastError());
+  if (nQ > 0 && (rc = launch_registered(ctx, d_T_out + 16 * C, mode, gate_deg, d_hits, st)) != PGP_OK) return rc;
+  unsigned char* pin_out = pin + ((in_bytes + 63) & ~(size_t)63);
+  PGP_HIP(hipMemcpyAsync(pin_out, dev + off_best, home, hipMemcpyDeviceToHost, st));
+  PGP_HIP(hipStreamSynchronize(st));
+  if ((rc = index_settled(ctx)) != PGP_OK) return rc;
+  const unsigned char* h = pin_out - off_best;   // (offsets as on the device)
+  int best[2], lst[2];
+  std::memcpy(best, h + off_best, sizeof best);
+  std::memcpy(lst, h + off_list, sizeof lst);
+  *n_list = lst[0];
+  if (n_pushed) *n_pushed = lst[1];
+  if (best_index) *best_index = best[0];
+  if (best_score) std::memcpy(best_score, &best[1], 4);
+  const size_t n_rec = (size_t)std::min(std::max(lst[0], 0), list_cap);
+  if (n_rec) {
+    std::memcpy(list_index, h + off_list + 8, n_rec * 4);
+    std::memcpy(list_score, h + off_rs, n_rec * 4);
+    std::memcpy(list_pose, h + off_pose, n_rec * 128);
+    std::memcpy(list_T, h + off_T, n_rec * 64);
+  }
+  if (best[0] >= 0) {
+    if (best_pose) std::memcpy(best_pose, h + off_pose + C * 128, 128);
+    if (best_T) std::memcpy(best_T, h + off_T + C * 64, 64);
+    if (registered) {
+      const int* hits = reinterpret_cast<const int*>(h + off_hits);
+      int k = 0;
+      for (size_t i = 0; i < nQ; ++i)
+        if (hits[i] >= 0) registered[k++] = hits[i];   // model-point order, as push_back in base.cc:1760
+      *n_registered = k;
+    }
+  }
+  ctx->csb_fit_m = m;
   return PGP_OK;
 }
 

@@ -325,7 +325,7 @@ int launch_find_congruent(pgp_ctx* ctx, const float base[12], float inv1, float 
 int launch_find_congruent_4pcs(pgp_ctx* ctx, float inv1, float inv2, float threshold, const int* d_Pp, int nP,
                                const int* d_Qp, int nQ, int* d_quads, int cap, int* n_quads_host, hipStream_t st);
 int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
-                                int nb, float threshold, int* h_n_quads, hipStream_t st);
+                                const int* h_rows /* nullable */, int nb, float threshold, int* h_n_quads, hipStream_t st);
 int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st);
 
 // lcp_score.hip
@@ -391,7 +391,7 @@ pgp_icp_options icp_options_of(const pgp_icp_params* p);
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);
 int ppf_thresholds(float tpos[9], float tneg[9]);
 int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_ids, float* h_inv, int* h_status,
-                        hipStream_t st);
+                        int* h_rows /* nullable */, hipStream_t st);
 int launch_ppf_features(pgp_ctx* ctx, const int* h_pairs, int m, int* h_f, int* h_row, hipStream_t st);
 int launch_stage_weights(pgp_ctx* ctx, int stage, int b1, int b2, int b3, float* h_cur, float* h_sum, int* h_present,
                          hipStream_t st);

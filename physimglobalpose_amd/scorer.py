@@ -174,13 +174,20 @@ class LcpScorer:
                                              None if c is None else c.ctypes.data_as(_i),
                                              None if p is None else p.ctypes.data_as(_i), len(keys)))
 
-    def select_bases(self, u):
-        """u (n,4) float64 uniforms in [0,1) -> (ids (n,4), invariants (n,2), status (n,))."""
+    def select_bases(self, u, rows=False):
+        """u (n,4) float64 uniforms in [0,1) -> (ids (n,4), invariants (n,2), status (n,)); rows=True: also the pair-feature
+        table rows (n,2) of every base's two edges (pgp_select_bases_rows)."""
         u = np.ascontiguousarray(u, np.float64).reshape(-1, 4)
         n = len(u)
         ids = np.zeros((max(n, 1), 4), np.int32)
         inv = np.zeros((max(n, 1), 2), np.float32)
         st = np.zeros(max(n, 1), np.int32)
+        if rows:
+            rw = np.zeros((max(n, 1), 2), np.int32)
+            _lib.check(self._lib.pgp_select_bases_rows(self._h, u.ctypes.data_as(C.POINTER(C.c_double)), n,
+                                                       ids.ctypes.data_as(_i), _fp(inv), st.ctypes.data_as(_i),
+                                                       rw.ctypes.data_as(_i)))
+            return ids[:n], inv[:n], st[:n], rw[:n]
         _lib.check(self._lib.pgp_select_bases(self._h, u.ctypes.data_as(C.POINTER(C.c_double)), n,
                                               ids.ctypes.data_as(_i), _fp(inv), st.ctypes.data_as(_i)))
         return ids[:n], inv[:n], st[:n]
@@ -212,15 +219,47 @@ class LcpScorer:
         _lib.check(self._lib.pgp_base_invariants(self._h, ids.ctypes.data_as(_i), m, _fp(inv), ok.ctypes.data_as(_i)))
         return ids, inv[:m], ok[:m]
 
-    def find_congruent_batch(self, base_ids, base_xyz, invariants, threshold):
-        """All bases of an object at once (pairs from the device PPF table): returns the quad counts (nb,)."""
+    def find_congruent_batch(self, base_ids, base_xyz, invariants, threshold, rows=None):
+        """All bases of an object at once (pairs from the device PPF table): returns the quad counts (nb,).  rows (nb,2):
+        the table rows of the bases' edges when the caller holds them (select_bases(rows=True)): pgp_find_congruent_batch_rows."""
         b = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
         x = _f32(base_xyz).reshape(-1, 12)
         v = _f32(invariants).reshape(-1, 2)
         n = np.zeros(max(len(b), 1), np.int32)
+        if rows is not None:
+            rw = np.ascontiguousarray(rows, np.int32).reshape(-1, 2)
+            assert len(rw) == len(b)
+            _lib.check(self._lib.pgp_find_congruent_batch_rows(self._h, b.ctypes.data_as(_i), _fp(x), _fp(v), rw.ctypes.data_as(_i),
+                                                           len(b), C.c_float(threshold), n.ctypes.data_as(_i)))
+            return n[: len(b)]
         _lib.check(self._lib.pgp_find_congruent_batch(self._h, b.ctypes.data_as(_i), _fp(x), _fp(v), len(b),
                                                       C.c_float(threshold), n.ctypes.data_as(_i)))
         return n[: len(b)]
+
+    def congruent_batch_fit_score_list(self, picks, base_ids, centroid_P, centroid_Q, mode=PGP_MODE_WEIGHTED, gate_deg=30.0, list_cap=256):
+        """pgp_congruent_batch_fit_score_list: fits + verification + the running-best walk + the kept poses + the best pose and
+        its registered points in one call.  Returns a dict: n_list, index, score, T, pose (the first min(n_list, list_cap)
+        records), n_pushed, best_index, best_score, best_T, best_pose, registered."""
+        pk = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)
+        b = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        cP, cQ = _f32(centroid_P).reshape(3), _f32(centroid_Q).reshape(3)
+        cap = int(list_cap)
+        li = np.zeros(max(cap, 1), np.int32)
+        ls = np.zeros(max(cap, 1), np.float32)
+        lT = np.zeros((max(cap, 1), 16), np.float32)
+        lp = np.zeros((max(cap, 1), 16), np.float64)
+        bT, bp = np.zeros(16, np.float32), np.zeros(16, np.float64)
+        reg = np.zeros(max(self.nQ, 1), np.int32)
+        n_list, n_pushed, best, n_reg = C.c_int(0), C.c_int(0), C.c_int(-1), C.c_int(0)
+        bs = C.c_float(0)
+        _lib.check(self._lib.pgp_congruent_batch_fit_score_list(
+            self._h, pk.ctypes.data_as(_i), b.ctypes.data_as(_i), len(pk), _fp(cP), _fp(cQ), int(mode), C.c_float(gate_deg), cap,
+            C.byref(n_list), li.ctypes.data_as(_i), _fp(ls), _fp(lT), lp.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_pushed),
+            C.byref(best), C.byref(bs), _fp(bT), bp.ctypes.data_as(C.POINTER(C.c_double)), reg.ctypes.data_as(_i), C.byref(n_reg)))
+        k = min(n_list.value, cap)
+        return dict(n_list=n_list.value, index=li[:k].copy(), score=ls[:k].copy(), T=lT[:k].copy(), pose=lp[:k].copy(),
+                    n_pushed=n_pushed.value, best_index=best.value, best_score=float(np.float32(bs.value)), best_T=bT, best_pose=bp,
+                    registered=reg[: n_reg.value].copy())
 
     def congruent_batch_quads(self, picks):
         pk = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)

@@ -564,17 +564,19 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
                                         //  256 workgroups are one wave of the 256 CUs and the reference's 100 bases come out of ONE round: 0.41 -> 0.2 ms)
   std::vector<int> base_ids;       // n_bases x 4 (scene ids, TryQuadrilateral's order)
   std::vector<float> base_inv;     // n_bases x 2
+  std::vector<int> base_rows;      // n_bases x 2: the table rows of pairs1 / pairs6 (they come home with the bases)
   {
     std::vector<double> u(4 * (size_t)attempts_per_round);
-    std::vector<int> ids(4 * (size_t)attempts_per_round), status(attempts_per_round);
+    std::vector<int> ids(4 * (size_t)attempts_per_round), status(attempts_per_round), rows(2 * (size_t)attempts_per_round);
     std::vector<float> inv(2 * (size_t)attempts_per_round);
     for (int round = 0; round < 20 && (int)(base_ids.size() / 4) < max_number_of_bases; ++round) {
       for (double& x : u) x = std::generate_canonical<double, 53>(generator);
-      SHIM_PGP(pgp_select_bases(ctx, u.data(), attempts_per_round, ids.data(), inv.data(), status.data()));
+      SHIM_PGP(pgp_select_bases_rows(ctx, u.data(), attempts_per_round, ids.data(), inv.data(), status.data(), rows.data()));
       for (int k = 0; k < attempts_per_round && (int)(base_ids.size() / 4) < max_number_of_bases; ++k) {
         if (status[k] != 1) continue;
         base_ids.insert(base_ids.end(), ids.begin() + 4 * k, ids.begin() + 4 * k + 4);
         base_inv.insert(base_inv.end(), inv.begin() + 2 * k, inv.begin() + 2 * k + 2);
+        base_rows.insert(base_rows.end(), rows.begin() + 2 * k, rows.begin() + 2 * k + 2);
       }
     }
   }
@@ -591,8 +593,8 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
       for (int d = 0; d < 3; ++d) base_xyz[12 * (size_t)b + 3 * k + d] = seg.xyz[3 * (size_t)base_ids[4 * b + k] + d];
   std::vector<int> n_quads(n_bases > 0 ? n_bases : 1, 0);
   if (n_bases > 0)
-    SHIM_PGP(pgp_find_congruent_batch(ctx, base_ids.data(), base_xyz.data(), base_inv.data(), n_bases, delta,
-                                      n_quads.data()));
+    SHIM_PGP(pgp_find_congruent_batch_rows(ctx, base_ids.data(), base_xyz.data(), base_inv.data(), base_rows.data(), n_bases,
+                                           delta, n_quads.data()));
   mark("congruent_sets");
   std::vector<int> picks;   // (base, j) pairs
   picks.reserve(2 * (size_t)n_bases * max_sampled_csets);
@@ -629,50 +631,61 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   if (!st.group) {
     // ---- single device: the fits never leave HBM -- fitted, verified (Step 3, base.cc:1885-1901, operMode = 1 ->
     // WeightedVerify) and walked there; scores and status come back, then the poses of the few hypotheses that are kept
-    std::vector<float> lcp_all(n_pairs > 0 ? n_pairs : 1);
-    std::vector<int> status(n_pairs > 0 ? n_pairs : 1);
-    int best_pick = -1;
-    float best_lcp = 0.f;
     // hypothesisSet is the running-best list: its entries are decided on exact (reference-order) sums
     SHIM_PGP(pgp_set_exact_records(ctx, 1));
+    // ONE call, ONE copy back: scores, the running-best walk over them, the poses it keeps, the best pose and the points it
+    // registers (pgp_congruent_batch_fit_score_list).  A list beyond kListCap entries (never seen: a walk over n scores
+    // keeps ~ln n of them) takes the calls this one replaces.
+    const int kListCap = 256;
+    std::vector<int> li(kListCap);
+    std::vector<float> ls(kListCap), lT(16 * (size_t)kListCap);
+    std::vector<double> lp(16 * (size_t)kListCap);
+    int n_list = 0, n_pushed = 0, best_pick = -1, n_reg = 0;
+    float best_lcp = 0.f, best_T[16];
+    double best_pose[16];
+    std::vector<int> reg(qval.n > 0 ? qval.n : 1);
     if (n_pairs > 0)
-      SHIM_PGP(pgp_congruent_batch_fit_score(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, PGP_MODE_WEIGHTED, 30.f,
-                                             lcp_all.data(), status.data(), &best_pick, &best_lcp));
-    // allTransforms / allPose hold only the fits that were pushed (base.cc:1467-1485)
-    std::vector<int> kept;
-    std::vector<float> lcp;
-    for (int i = 0; i < n_pairs; ++i)
-      if (status[i] == 1) {
-        kept.push_back(i);
-        lcp.push_back(lcp_all[i]);
-      }
-    const int n_h = (int)kept.size();
+      SHIM_PGP(pgp_congruent_batch_fit_score_list(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, PGP_MODE_WEIGHTED, 30.f, kListCap,
+                                                  &n_list, li.data(), ls.data(), lT.data(), lp.data(), &n_pushed, &best_pick, &best_lcp,
+                                                  best_T, best_pose, reg.data(), &n_reg));
+    const int n_h = n_pushed;
     mark("fit+score+records");
     if (verbose)
       std::cerr << "[libsuper4pcs shim] bases " << n_bases << ", congruent pairs " << n_pairs << ", transforms " << n_h
                 << "; ms: setup " << ms_setup << ", base selection " << ms_bases << ", congruent sets " << ms_cs << std::endl;
-    std::vector<int> selected(n_h > 0 ? n_h : 1);
-    int n_sel = 0;
-    pgp_running_best(lcp.data(), n_h, selected.data(), &n_sel);
-    std::vector<int> want;   // picks whose pose is needed: the running-best list, then the best
-    for (int k = 0; k < n_sel; ++k) want.push_back(kept[selected[k]]);
-    if (best_pick >= 0) want.push_back(best_pick);
-    std::vector<float> Tf(16 * want.size() + 16);
-    std::vector<double> posed(16 * want.size() + 16);
-    if (!want.empty()) SHIM_PGP(pgp_congruent_batch_fetch(ctx, want.data(), (int)want.size(), Tf.data(), posed.data()));
-    auto iso_of = [&posed](size_t k) {
+    auto iso_of = [](const double* m16) {
       Eigen::Isometry3d iso;
-      iso.matrix() = Eigen::Map<const Eigen::Matrix4d>(posed.data() + 16 * k);
+      iso.matrix() = Eigen::Map<const Eigen::Matrix4d>(m16);
       return iso;
     };
     hypothesisSet.clear();   // the reference REPLACES the list by the running-best subsequence (allPose.clear(), base.cc:1903)
-    for (int k = 0; k < n_sel; ++k) hypothesisSet.push_back(std::make_pair(iso_of((size_t)k), lcp[selected[k]]));  // base.cc:1903-1908
+    if (n_list <= kListCap) {
+      for (int k = 0; k < n_list; ++k) hypothesisSet.push_back(std::make_pair(iso_of(lp.data() + 16 * (size_t)k), ls[k]));  // base.cc:1903-1908
+    } else {
+      // the long way round: all scores, the walk on the host, the kept poses fetched
+      std::vector<float> lcp_all(n_pairs);
+      std::vector<int> status(n_pairs);
+      SHIM_PGP(pgp_congruent_batch_fit_score(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, PGP_MODE_WEIGHTED, 30.f,
+                                             lcp_all.data(), status.data(), &best_pick, &best_lcp));
+      std::vector<int> kept, selected(n_pairs);
+      std::vector<float> lcp;
+      for (int i = 0; i < n_pairs; ++i)
+        if (status[i] == 1) {
+          kept.push_back(i);
+          lcp.push_back(lcp_all[i]);
+        }
+      int n_sel = 0;
+      pgp_running_best(lcp.data(), (int)kept.size(), selected.data(), &n_sel);
+      std::vector<int> want;
+      for (int k = 0; k < n_sel; ++k) want.push_back(kept[selected[k]]);
+      std::vector<float> Tf(16 * want.size() + 16);
+      std::vector<double> posed(16 * want.size() + 16);
+      if (!want.empty()) SHIM_PGP(pgp_congruent_batch_fetch(ctx, want.data(), (int)want.size(), Tf.data(), posed.data()));
+      for (int k = 0; k < n_sel; ++k) hypothesisSet.push_back(std::make_pair(iso_of(posed.data() + 16 * (size_t)k), lcp[selected[k]]));
+    }
     if (best_pick >= 0) {
-      bestHypothesis = std::make_pair(iso_of(want.size() - 1), best_lcp);
-      registered_points.resize(qval.n);
-      int n_reg = 0;
-      SHIM_PGP(pgp_registered(ctx, Tf.data() + 16 * (want.size() - 1), PGP_MODE_WEIGHTED, 30.f, registered_points.data(), &n_reg));
-      registered_points.resize(n_reg);
+      bestHypothesis = std::make_pair(iso_of(best_pose), best_lcp);
+      registered_points.assign(reg.begin(), reg.begin() + n_reg);
     } else {
       std::cout << "returning identity" << std::endl;  // base.cc:1791-1794
     }

@@ -156,3 +156,83 @@ print("RESULT " + json.dumps(out[0]))
         res.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT ")][-1][7:]))
     assert res[0] == res[1] and sum(res[0][0]) > 8
 
+
+
+def test_rows_that_ride_home_with_the_bases(case):
+    """pgp_select_bases_rows hands out the table rows of every base's two edges (what ExtractCongruentSet looks up,
+    base.cc:1970-1981) and pgp_find_congruent_batch_rows takes them: same bases, same rows as pgp_ppf_features, same quads
+    in the same order as the call that asks for the rows itself."""
+    w, table, keys, sc, ids0, inv0 = case
+    u = np.random.default_rng(3).random((96, 4))
+    ids_a, inv_a, st_a = sc.select_bases(u)
+    ids, inv, st, rows = sc.select_bases(u, rows=True)
+    assert np.array_equal(ids, ids_a) and np.array_equal(inv, inv_a) and np.array_equal(st, st_a)
+    assert (rows[st != 1] == -1).all()
+    ok = st == 1
+    ids, inv, rows = ids[ok], inv[ok], rows[ok]
+    _, r01 = sc.ppf_features(ids[:, [0, 1]])
+    _, r23 = sc.ppf_features(ids[:, [2, 3]])
+    assert np.array_equal(rows[:, 0], r01) and np.array_equal(rows[:, 1], r23) and (rows >= 0).any()
+    base_xyz = w.P_xyz[ids]
+    n_plain = sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
+    picks = np.array([(b, j) for b in range(len(ids)) for j in range(n_plain[b])], np.int32).reshape(-1, 2)
+    q_plain = sc.congruent_batch_quads(picks)
+    n_rows = sc.find_congruent_batch(ids, base_xyz, inv, w.delta, rows=rows)
+    assert np.array_equal(n_rows, n_plain) and n_plain.sum() > 0
+    assert np.array_equal(sc.congruent_batch_quads(picks), q_plain)
+    bad = rows.copy()
+    bad[0, 0] = len(keys)          # one past the table
+    with pytest.raises(Exception):
+        sc.find_congruent_batch(ids, base_xyz, inv, w.delta, rows=bad)
+
+
+def test_fit_score_list_equals_the_calls_it_replaces(case):
+    """pgp_congruent_batch_fit_score_list (fits, verification, the running-best walk on the device, the kept poses, the best
+    pose and its registered points in one call) against pgp_congruent_batch_fit_score -> pgp_running_best ->
+    pgp_congruent_batch_fetch -> pgp_registered."""
+    import ctypes as C
+    from physimglobalpose_amd import PGP_MODE_WEIGHTED
+    w, table, keys, sc0, ids, inv = case
+    counts = np.array([len(table[tuple(k)]) for k in keys.tolist()], np.int32)
+    pairs = np.concatenate([np.array(table[tuple(k)], np.int32).reshape(-1, 2) for k in keys.tolist()])
+    sc = LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    sc.set_search_model(w.Qs_xyz)
+    sc.set_ppf_map(keys, counts, pairs)
+    sc.set_exact_records(True)
+    base_xyz = w.P_xyz[ids]
+    n_quads = sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
+    rng = np.random.default_rng(11)
+    picks = np.array([(b, j) for b in range(len(ids)) for j in rng.permutation(n_quads[b])[:40]], np.int32).reshape(-1, 2)
+    m = len(picks)
+    assert m > 200
+    L, h = sc._lib, sc._h
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    cP, cQ = np.ascontiguousarray(w.centroid_P, np.float32), np.ascontiguousarray(w.centroid_Q, np.float32)
+    ids_c = np.ascontiguousarray(ids, np.int32)
+    scores, status = np.zeros(m, np.float32), np.zeros(m, np.int32)
+    best, bscore = C.c_int(-1), C.c_float(0)
+    assert L.pgp_congruent_batch_fit_score(h, ip(picks), ip(ids_c), m, fp(cP), fp(cQ), PGP_MODE_WEIGHTED, C.c_float(30.0), fp(scores),
+                                           ip(status), C.byref(best), C.byref(bscore)) == 0
+    sel = LcpScorer.running_best(scores)
+    assert len(sel) >= 1 and best.value >= 0
+    want = np.ascontiguousarray(list(sel) + [best.value], np.int32)
+    T, pose = np.zeros((len(want), 16), np.float32), np.zeros((len(want), 16), np.float64)
+    assert L.pgp_congruent_batch_fetch(h, ip(want), len(want), fp(T), dp(pose)) == 0
+    reg = sc.registered(T[-1], PGP_MODE_WEIGHTED, 30.0)
+    for cap in (256, 1, 0):
+        got = sc.congruent_batch_fit_score_list(picks, ids_c, cP, cQ, PGP_MODE_WEIGHTED, 30.0, list_cap=cap)
+        k = min(len(sel), cap)
+        assert got["n_list"] == len(sel) and got["n_pushed"] == int((status == 1).sum())
+        assert np.array_equal(got["index"], np.asarray(sel[:k], np.int32)) and np.array_equal(got["score"], scores[sel[:k]])
+        assert np.array_equal(got["T"], T[:k]) and np.array_equal(got["pose"], pose[:k])
+        assert got["best_index"] == best.value and got["best_score"] == float(np.float32(bscore.value))
+        assert np.array_equal(got["best_T"], T[-1]) and np.array_equal(got["best_pose"], pose[-1])
+        assert np.array_equal(got["registered"], reg) and len(reg) > 0
+    # the resident fits still answer a fetch
+    T2, pose2 = np.zeros_like(T), np.zeros_like(pose)
+    assert L.pgp_congruent_batch_fetch(h, ip(want), len(want), fp(T2), dp(pose2)) == 0
+    assert np.array_equal(T2, T) and np.array_equal(pose2, pose)
+    sc.close()
