@@ -218,6 +218,16 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
     ctx->h_out = nullptr;
   }
+  if (ctx->h_w_pin) {
+    hipError_t e = hipHostFree(ctx->h_w_pin);
+    (void)e;
+    ctx->h_w_pin = nullptr;
+  }
+  if (ctx->ev_w) {
+    hipError_t e = hipEventDestroy(ctx->ev_w);
+    (void)e;
+    ctx->ev_w = nullptr;
+  }
   for (hipEvent_t e : ctx->ev) {
     hipError_t r = hipEventDestroy(e);
     (void)r;
@@ -367,20 +377,37 @@ int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n) {
   CtxGuard guard(ctx);
   int rc = ctx->d_pre_io.ensure((size_t)n * 4);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, weight, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
-  if ((rc = launch_scene_weights(ctx, ctx->d_pre_io.as<float>(), n, ctx->stream)) != PGP_OK) return rc;
-  // base selection draws its first point from these weights: their double prefix sums (the sequence launch_select_bases
-  // would otherwise read back and add up on its first call) go up with them
-  ctx->prob_cdf_valid = false;
-  std::vector<double> cdf((size_t)n);
+  if ((rc = ctx->d_prob_cdf.ensure((size_t)n * 8)) != PGP_OK) return rc;
+  // The weights and -- base selection draws its first point from them -- their double prefix sums (the sequence
+  // launch_select_bases would otherwise read back and add up on its first call) go up from a pinned staging buffer of
+  // this call's own: nothing of the caller's is read after the return, and nothing waits for the copies here (the
+  // caller's next step, the base selection, queues behind them on the stream).
+  const size_t off_cdf = ((size_t)n * 4 + 63) & ~(size_t)63, need = off_cdf + (size_t)n * 8;
+  if (ctx->ev_w) PGP_HIP(hipEventSynchronize(ctx->ev_w));   // the previous call's copies out of the staging buffer
+  else PGP_HIP(hipEventCreateWithFlags(&ctx->ev_w, hipEventDisableTiming));
+  if (need > ctx->h_w_cap) {
+    if (ctx->h_w_pin) {
+      hipError_t e = hipHostFree(ctx->h_w_pin);
+      (void)e;
+      ctx->h_w_pin = nullptr;
+      ctx->h_w_cap = 0;
+    }
+    PGP_HIP(hipHostMalloc(&ctx->h_w_pin, need + need / 4, hipHostMallocDefault));
+    ctx->h_w_cap = need + need / 4;
+  }
+  unsigned char* pin = static_cast<unsigned char*>(ctx->h_w_pin);
+  std::memcpy(pin, weight, (size_t)n * 4);
+  double* cdf = reinterpret_cast<double*>(pin + off_cdf);
   double run = 0.0;
   for (int i = 0; i < n; ++i) {
     run += (double)weight[i];
     cdf[i] = run;
   }
-  if ((rc = ctx->d_prob_cdf.ensure((size_t)n * 8)) != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(ctx->d_prob_cdf.p, cdf.data(), (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
-  PGP_HIP(hipStreamSynchronize(ctx->stream));   // `weight` is the caller's, `cdf` this call's
+  ctx->prob_cdf_valid = false;
+  PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, pin, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = launch_scene_weights(ctx, ctx->d_pre_io.as<float>(), n, ctx->stream)) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_prob_cdf.p, cdf, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipEventRecord(ctx->ev_w, ctx->stream));
   ctx->prob_cdf_valid = true;
   return PGP_OK;
 }

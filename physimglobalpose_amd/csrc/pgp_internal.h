@@ -198,6 +198,11 @@ struct pgp_ctx {
   // pinned host staging for the host-pointer scoring call (transforms in, scores | counts | best out)
   void* h_pin = nullptr;
   size_t h_pin_cap = 0;
+  // pinned staging of pgp_set_scene_weights alone (weights + their double prefix sums go up without a synchronisation;
+  // ev_w: the copies out of it have finished -- waited for before the next call overwrites it)
+  void* h_w_pin = nullptr;
+  size_t h_w_cap = 0;
+  hipEvent_t ev_w = nullptr;
   // pinned landing area of small results on their way to the caller's (pageable) memory: pgp::HostOut
   void* h_out = nullptr;
   size_t h_out_cap = 0, h_out_used = 0;
