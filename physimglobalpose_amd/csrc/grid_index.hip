@@ -418,8 +418,23 @@ int build_index(pgp_ctx* ctx, const float* h_xyz, float delta) {
   return build_index_bbox(ctx, mn, mx, delta);
 }
 
+// Queues a build that pgp_set_scene prepared and put off (pgp_ctx::deferred_build).
+int flush_deferred_build(pgp_ctx* ctx) {
+  if (!ctx->deferred_build) return PGP_OK;
+  std::function<int()> fn = std::move(ctx->deferred_build);
+  ctx->deferred_build = nullptr;
+  const int rc = fn();
+  if (rc != PGP_OK) {   // a step failed half way: nothing of it may keep running over the index buffers
+    if (ctx->build_stream) (void)hipStreamSynchronize(ctx->build_stream);
+    ctx->index_pending = false;
+    ctx->has_index = false;
+  }
+  return rc;
+}
+
 int finish_index(pgp_ctx* ctx) {
   if (!ctx->index_pending) return PGP_OK;
+  if (int rc = flush_deferred_build(ctx)) return rc;
   PGP_HIP(hipEventSynchronize(ctx->ev_index));
   ctx->index_pending = false;
   ctx->n_cand = (long long)ctx->h_build_counts[0];
@@ -430,6 +445,7 @@ int finish_index(pgp_ctx* ctx) {
 
 int await_index(pgp_ctx* ctx, hipStream_t stream) {
   if (!ctx->index_pending) return PGP_OK;
+  if (int rc = flush_deferred_build(ctx)) return rc;
   {
     // a stream that is being captured into a graph can neither query nor wait for an event recorded outside the capture
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
@@ -446,7 +462,7 @@ int await_index(pgp_ctx* ctx, hipStream_t stream) {
 
 // The dense index of a SMALL scene, queued on ctx->build_stream and left running (see pgp_ctx::build_stream): the
 // candidate array and the occupied-cell table are sized by what nP points can reach at most, so no count has to come
-// back before the next launch.  The points are already resident (pgp_set_scene synchronises its uploads).
+// back before the next launch.  The points are resident, or on their way (the build waits for pgp_set_scene's upload event on its stream).
 static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta) {
   const int nP = ctx->nP;
   int rc;
@@ -474,27 +490,39 @@ static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta
   const int pb = (nP + 255) / 256;
   // everything from here on is queued on the non-blocking build stream over the context's index buffers: a step that
   // fails half way must not leave that work running beside whatever reuses (or reallocates) the buffers next
-  auto enqueue = [&]() -> int {
+  float4* const d_cand = ctx->d_cand.as<float4>();
+  const float4* const d_P = ctx->d_P.as<float4>();
+  uint2* const d_occ = ctx->d_occ_start.as<uint2>();
+  const hipEvent_t ev_up = ctx->scene_upload_pending ? ctx->ev_s : nullptr;   // pgp_set_scene's queued uploads
+  auto enqueue = [=]() -> int {   // (by value: it may run after this function has returned, see below)
+    int rc;
+    if (ev_up) PGP_HIP(hipStreamWaitEvent(st, ev_up, 0));
     PGP_HIP(hipEventRecord(ctx->ev_build0, st));
     PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
-    hipLaunchKernelGGL((scatter_points<false, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
+    hipLaunchKernelGGL((scatter_points<false, false>), dim3(pb), dim3(256), 0, st, g, r, d_P, nP, ctr,
                        (const uint32_t*)nullptr, (float4*)nullptr, (const uint4*)nullptr);
     if ((rc = device_exclusive_scan(ctr, start, n_scan, scan_tmp, st)) != PGP_OK) return rc;
     PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[0], start + n_cells, 4, hipMemcpyDeviceToHost, st));
     PGP_HIP(hipMemsetAsync(ctr, 0, n_scan * 4, st));
-    hipLaunchKernelGGL((scatter_points<true, false>), dim3(pb), dim3(256), 0, st, g, r, ctx->d_P.as<float4>(), nP, ctr,
-                       (const uint32_t*)start, ctx->d_cand.as<float4>(), (const uint4*)nullptr);
+    hipLaunchKernelGGL((scatter_points<true, false>), dim3(pb), dim3(256), 0, st, g, r, d_P, nP, ctr,
+                       (const uint32_t*)start, d_cand, (const uint4*)nullptr);
     hipLaunchKernelGGL(make_words, dim3((unsigned)((n_words + 1 + 255) / 256)), dim3(256), 0, st, g,
                        (const uint32_t*)start, words, ctr, n_words);
     if ((rc = device_exclusive_scan(ctr, ctr, n_words + 1, scan_tmp, st)) != PGP_OK) return rc;
     PGP_HIP(hipMemcpyAsync(&ctx->h_build_counts[1], ctr + n_words, 4, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(fill_occupied, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, st, g,
-                       (const uint32_t*)start, (const uint32_t*)ctr, words, ctx->d_occ_start.as<uint2>(), n_words, n_cells);
+                       (const uint32_t*)start, (const uint32_t*)ctr, words, d_occ, n_words, n_cells);
     PGP_HIP(hipGetLastError());
     PGP_HIP(hipEventRecord(ctx->ev_index, st));
     return PGP_OK;
   };
-  if ((rc = enqueue()) != PGP_OK) {
+  // Queued now, or put off until the caller is about to wait for the device anyway (pgp_ctx::deferred_build): the
+  // drop-in's next steps -- weights, base selection -- then reach the device ~0.1 ms earlier, and the build runs beside
+  // the base selection instead of in front of it.
+  static const bool defer = !(getenv("PGP_DEFER_BUILD") && atoi(getenv("PGP_DEFER_BUILD")) == 0);
+  if (defer) {
+    ctx->deferred_build = enqueue;
+  } else if ((rc = enqueue()) != PGP_OK) {
     (void)hipStreamSynchronize(st);
     return rc;
   }
@@ -514,6 +542,10 @@ int build_index_bbox(pgp_ctx* ctx, const float mn[3], const float mx[3], float d
   const int nP = ctx->nP;
   hipStream_t st = ctx->stream;
   ctx->has_index = false;
+  if (ctx->deferred_build) {   // the previous scene's build was never queued: nobody asked for its index
+    ctx->deferred_build = nullptr;
+    ctx->index_pending = false;
+  }
   int rc = finish_index(ctx);   // a build still running (its consumers are drained by the caller) owns these buffers
   if (rc != PGP_OK) return rc;
   GridDesc g{};

@@ -182,6 +182,7 @@ int pgp_create(pgp_ctx** out, int device_id) {
 int pgp_destroy(pgp_ctx* ctx) {
   if (!ctx) return PGP_OK;
   CtxGuard guard(ctx);
+  ctx->deferred_build = nullptr;   // (a build that was never queued)
   if (ctx->stream) {
     hipError_t e = hipStreamSynchronize(ctx->stream);
     (void)e;
@@ -222,6 +223,16 @@ int pgp_destroy(pgp_ctx* ctx) {
     hipError_t e = hipHostFree(ctx->h_w_pin);
     (void)e;
     ctx->h_w_pin = nullptr;
+  }
+  if (ctx->h_s_pin) {
+    hipError_t e = hipHostFree(ctx->h_s_pin);
+    (void)e;
+    ctx->h_s_pin = nullptr;
+  }
+  if (ctx->ev_s) {
+    hipError_t e = hipEventDestroy(ctx->ev_s);
+    (void)e;
+    ctx->ev_s = nullptr;
   }
   if (ctx->ev_w) {
     hipError_t e = hipEventDestroy(ctx->ev_w);
@@ -335,7 +346,34 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
   ctx->prob_cdf_valid = false;
   ctx->nP = n;
   ctx->has_scene_normals = nrm != nullptr;
-  std::vector<float4> hp((size_t)std::max(n, 1)), hn((size_t)std::max(n, 1));
+  // packed {x, y, z, id} / {nx, ny, nz, w}: through a pinned staging buffer of this call's own for scenes up to 4 MB (the
+  // uploads are then queued and nobody waits for them here: an event tells the side-stream index build when they are
+  // through), through temporaries and a synchronisation beyond
+  const size_t N = (size_t)std::max(n, 1), bytes = N * sizeof(float4);
+  const bool staged = 2 * bytes <= ((size_t)4 << 20);
+  std::vector<float4> tmp;
+  float4 *hp, *hn;
+  int rc;
+  if (staged) {
+    if (ctx->ev_s) PGP_HIP(hipEventSynchronize(ctx->ev_s));   // the previous scene's copies out of the staging buffer
+    else PGP_HIP(hipEventCreateWithFlags(&ctx->ev_s, hipEventDisableTiming));
+    if (2 * bytes > ctx->h_s_cap) {
+      if (ctx->h_s_pin) {
+        hipError_t e = hipHostFree(ctx->h_s_pin);
+        (void)e;
+        ctx->h_s_pin = nullptr;
+        ctx->h_s_cap = 0;
+      }
+      PGP_HIP(hipHostMalloc(&ctx->h_s_pin, 2 * bytes + bytes / 2, hipHostMallocDefault));
+      ctx->h_s_cap = 2 * bytes + bytes / 2;
+    }
+    hp = static_cast<float4*>(ctx->h_s_pin);
+    hn = hp + N;
+  } else {
+    tmp.resize(2 * N);
+    hp = tmp.data();
+    hn = hp + N;
+  }
   for (int i = 0; i < n; ++i) {
     const float* p = xyz + 3 * (size_t)i;
     hp[i] = make_float4(p[0], p[1], p[2], __builtin_bit_cast(float, i));
@@ -345,12 +383,17 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
     else
       hn[i] = make_float4(0.f, 0.f, 0.f, w);
   }
-  int rc;
-  if ((rc = ctx->d_P.ensure(hp.size() * sizeof(float4))) != PGP_OK) return rc;
-  if ((rc = ctx->d_Pnw.ensure(hn.size() * sizeof(float4))) != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(ctx->d_P.p, hp.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  PGP_HIP(hipMemcpyAsync(ctx->d_Pnw.p, hn.data(), (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  PGP_HIP(hipStreamSynchronize(ctx->stream));
+  if ((rc = ctx->d_P.ensure(bytes)) != PGP_OK) return rc;
+  if ((rc = ctx->d_Pnw.ensure(bytes)) != PGP_OK) return rc;
+  PGP_HIP(hipMemcpyAsync(ctx->d_P.p, hp, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  PGP_HIP(hipMemcpyAsync(ctx->d_Pnw.p, hn, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  ctx->scene_upload_pending = false;
+  if (staged) {
+    PGP_HIP(hipEventRecord(ctx->ev_s, ctx->stream));
+    ctx->scene_upload_pending = true;
+  } else {
+    PGP_HIP(hipStreamSynchronize(ctx->stream));
+  }
   ctx->kd_valid = false;
   if (ctx->exact_ties && (rc = build_kd_ties(ctx, xyz, n)) != PGP_OK) return rc;
   return build_index(ctx, xyz, delta);
@@ -484,6 +527,7 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
     return PGP_EINVAL;
   }
   CtxGuard guard(ctx);
+  if (int rc = flush_deferred_build(ctx)) return rc;
   if (ctx->index_pending && hipEventQuery(ctx->ev_index) == hipSuccess) {
     const int rc = finish_index(ctx);   // a finished side-stream build: noticed without waiting
     if (rc != PGP_OK) return rc;

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -100,6 +101,11 @@ struct pgp_ctx {
   hipStream_t build_stream = nullptr;
   hipEvent_t ev_index = nullptr, ev_build0 = nullptr;
   bool index_pending = false;
+  // the side-stream build of the current scene, prepared but not yet QUEUED: its dozen-and-a-half launches cost the host
+  // ~0.1 ms to issue, and pgp_set_scene's caller has better things to put on the device first (the weights, the base
+  // selection).  Whoever is about to wait for the device (pgp::HostOut::sync), or needs the index (await_index /
+  // finish_index), queues it first: pgp::flush_deferred_build.  PGP_DEFER_BUILD=0: queued by pgp_set_scene itself.
+  std::function<int()> deferred_build;
   uint32_t* h_build_counts = nullptr;   // pinned {candidates, occupied cells} of the pending build
   pgp::DevBuf d_build_scan;             // the build's own scan scratch (d_scan_tmp serves the congruent sets meanwhile)
 
@@ -203,6 +209,12 @@ struct pgp_ctx {
   void* h_w_pin = nullptr;
   size_t h_w_cap = 0;
   hipEvent_t ev_w = nullptr;
+  // the same for pgp_set_scene's points and normals (scenes up to 4 MB of them); the side-stream index build waits for
+  // ev_s on its own stream, the host for nothing
+  void* h_s_pin = nullptr;
+  size_t h_s_cap = 0;
+  hipEvent_t ev_s = nullptr;
+  bool scene_upload_pending = false;   // ev_s has been recorded behind this scene's uploads
   // pinned landing area of small results on their way to the caller's (pageable) memory: pgp::HostOut
   void* h_out = nullptr;
   size_t h_out_cap = 0, h_out_used = 0;
@@ -233,6 +245,8 @@ struct pgp_ctx {
 };
 
 namespace pgp {
+
+int flush_deferred_build(pgp_ctx* ctx);   // grid_index.hip
 
 // Small results on their way to the caller's memory.  A device-to-host copy into PAGEABLE memory keeps the host 12 us
 // longer than one into pinned memory, whatever its size (tools/copy_cost.hip on the bench box: 24.4 against 12.2 us for
@@ -297,6 +311,12 @@ struct HostOut {
     return PGP_OK;
   }
   int sync() {
+    // (the host is about to wait: what it has put off issuing -- the scene's index build -- goes to its stream first and
+    //  runs beside whatever this wait is for)
+    if (ctx->deferred_build) {
+      const int rc = flush_deferred_build(ctx);
+      if (rc != PGP_OK) return rc;
+    }
     PGP_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < n_items; ++k) std::memcpy(items[k].dst, static_cast<unsigned char*>(ctx->h_out) + items[k].off, items[k].n);
     n_items = 0;
