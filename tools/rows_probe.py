@@ -1,6 +1,6 @@
 """extract_pairs / find_congruent / rigid fits timed as bench.py's rows do (A/B through PGP_LIB)."""
 import sys, os, time, gc
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.environ.get("PGP_PKG_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import numpy as np
 from physimglobalpose_amd import LcpScorer, synth
 gc.disable()
