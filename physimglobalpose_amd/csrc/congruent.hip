@@ -299,9 +299,13 @@ struct CsBatchArgs {
   float threshold, epsilon, nepsilon;
   int eg;
   unsigned bmask;
-  uint32_t* bucket_cnt;
-  const uint32_t* bucket_start;
-  int4* entries;              // {cell_lo, cell_hi, bin | base << 16, P-pair index}
+  // the P entries of a bucket are a LIST (head[bucket] -> next[entry] -> ... -> -1, entry = flat P index): filled in ONE
+  // pass with an atomic exchange on the head -- a count pass, a scan of the buckets and a fill pass before (seven dependent
+  // small launches and fills, ~45 us of a 0.2 ms phase); the matches are sorted afterwards, so the order in which a walk
+  // meets the entries of a bucket does not matter
+  int* head;                  // [bmask + 1]
+  int* next;                  // [total_p]
+  int4* entries;              // [total_p] {cell_lo, cell_hi, bin | base << 16, P-pair index}
   unsigned long long* keys;   // base << 48 | P-pair << 24 | Q-pair
   uint32_t total_p, total_q;
   uint32_t* n_keys;           // bq_match: matches appended so far (may pass key_cap: the host then grows and repeats)
@@ -326,7 +330,13 @@ __device__ __forceinline__ unsigned bucket_of_b(long long cell, int b, unsigned 
   return (unsigned)(h >> 40) & mask;
 }
 
-template <bool FILL>
+// heads = -1, match counters = 0: one launch instead of two fills split by the runtime into four
+__global__ __launch_bounds__(256) void bp_init(int* __restrict__ head, uint32_t n_head, uint32_t* __restrict__ counters, uint32_t n_counters) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_head) head[t] = -1;
+  if (t < n_counters) counters[t] = 0u;
+}
+
 __global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= a.total_p) return;
@@ -341,9 +351,8 @@ __global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
   int bin = normal_bin(n, a.nepsilon);
   if (c < 0 || bin < 0) return;  // addElement returns false
   unsigned bk = bucket_of_b(c, b, a.bmask);
-  uint32_t slot = atomicAdd(&a.bucket_cnt[bk], 1u);
-  if (FILL)
-    a.entries[a.bucket_start[bk] + slot] = make_int4((int)(c & 0xFFFFFFFFll), (int)(c >> 32), bin | (b << 16), (int)i);
+  a.entries[t] = make_int4((int)(c & 0xFFFFFFFFll), (int)(c >> 32), bin | (b << 16), (int)i);
+  a.next[t] = atomicExch(&a.head[bk], (int)t);   // (the entry is read by the NEXT launch only)
 }
 
 // ONE pass: a thread counts its matches, reserves that many key slots (one atomic per thread that found any, one more on
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(256) void bp_entries(CsBatchArgs a) {
 // thread's keys land does not matter, and the expensive part of a thread (the cone of <= 56 rotated samples) is done once.
 // (Before: a counting launch, a scan over all Q pairs and a second full launch; profiles/r04_dropin_kernels.txt.)
 // does Q pair t fall into a cell that holds a P entry of its base?  (the cheap part of a match: two loads and a bucket walk)
-__device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t t, const int b, uint32_t* first, uint32_t* end) {
+__device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t t, const int b, int* first) {
   const BatchBase B = a.bases[b];
   const int2 qr = a.pairs[B.q_off + (t - B.q_flat)];
   if ((unsigned)qr.x >= (unsigned)a.nQs || (unsigned)qr.y >= (unsigned)a.nQs) return false;
@@ -359,20 +368,18 @@ __device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t
   const long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
   if (c < 0) return false;
   const unsigned bk = bucket_of_b(c, b, a.bmask);
-  const uint32_t s = a.bucket_start[bk], e = a.bucket_start[bk + 1];
   const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
-  for (uint32_t k = s; k < e; ++k) {
+  for (int k = a.head[bk]; k >= 0; k = a.next[k]) {
     const int4 en = a.entries[k];
     if (en.x == clo && en.y == chi && (en.z >> 16) == b) {
       *first = k;   // the walks of the match start at the first entry of the cell
-      *end = e;
       return true;
     }
   }
   return false;
 }
 
-__device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32_t t, const int b, const uint32_t s, const uint32_t e) {
+__device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32_t t, const int b, const int s) {
   const BatchBase B = a.bases[b];
   const uint32_t i = t - B.q_flat;
   const int2 qr = a.pairs[B.q_off + i];
@@ -427,7 +434,7 @@ __device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32
         uint32_t out0 = 0;
         for (int pass = 0; pass < 2; ++pass) {
           uint32_t n = 0;
-          for (uint32_t k = s; k < e; ++k) {
+          for (int k = s; k >= 0; k = a.next[k]) {
             int4 en = a.entries[k];
             if (en.x != clo || en.y != chi || (en.z >> 16) != b) continue;
             const int bin = en.z & 0xFFFF;
@@ -476,7 +483,7 @@ __device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32
 // expensive part) runs on full waves: about one Q pair in four has one, scattered over the waves.
 __global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
   __shared__ uint32_t s_items[256];
-  __shared__ uint2 s_range[256];
+  __shared__ int s_first[256];
   __shared__ unsigned short s_base[256];
   __shared__ uint32_t s_wcnt[4];
   __shared__ int s_b0, s_b1;
@@ -490,8 +497,8 @@ __global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
   int b = s_b0;
   if (t < a.total_q)
     for (const int b1 = s_b1; b < b1 && a.bases[b + 1].q_flat <= t;) ++b;   // last base whose first flat index is <= t
-  uint32_t first = 0, end = 0;
-  const bool any = t < a.total_q && bq_has_cell(a, t, b, &first, &end);
+  int first = -1;
+  const bool any = t < a.total_q && bq_has_cell(a, t, b, &first);
   const unsigned long long m = __ballot(any);
   if (lane == 0) s_wcnt[wave] = (uint32_t)__popcll(m);
   __syncthreads();
@@ -501,14 +508,11 @@ __global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
   if (any) {
     const uint32_t slot = off + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
     s_items[slot] = t;
-    s_range[slot] = make_uint2(first, end);
+    s_first[slot] = first;
     s_base[slot] = (unsigned short)b;   // at most 65535 bases per call
   }
   __syncthreads();
-  if (threadIdx.x < n_any) {
-    const uint2 r = s_range[threadIdx.x];
-    bq_match_item(a, s_items[threadIdx.x], (int)s_base[threadIdx.x], r.x, r.y);
-  }
+  if (threadIdx.x < n_any) bq_match_item(a, s_items[threadIdx.x], (int)s_base[threadIdx.x], s_first[threadIdx.x]);
 }
 
 // starts of the bases in the sorted keys = exclusive prefix sums of their match counts (one workgroup; nb is a few hundred)
@@ -910,11 +914,10 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   unsigned nbk = 1024;
   while (nbk < 2u * (unsigned)tp && nbk < (1u << 26)) nbk <<= 1;
   a.bmask = nbk - 1;
-  // bucket counts | bucket starts | {matches appended, matches per base}
-  const size_t n_cnt = (size_t)nbk + 1 + (size_t)nb + 2;
-  if ((rc = ctx->d_cs_cnt.ensure(n_cnt * 8 + 64)) != PGP_OK) return rc;
+  // bucket heads | entry links | {matches appended, matches per base}
+  const size_t n_cnt = (size_t)nbk + (size_t)tp + (size_t)nb + 4;
+  if ((rc = ctx->d_cs_cnt.ensure(n_cnt * 4 + 64)) != PGP_OK) return rc;
   if ((rc = ctx->d_cs_entries.ensure((size_t)tp * 16 + 16)) != PGP_OK) return rc;
-  if ((rc = ctx->d_scan_tmp.ensure((n_cnt / 2048 + 2) * 4)) != PGP_OK) return rc;
   // bases | cones | base_start, in one staging buffer
   const size_t bb = ((size_t)nb * sizeof(BatchBase) + 255) & ~(size_t)255, cb = ((size_t)nb * 168 * 4 + 255) & ~(size_t)255;
   if ((rc = ctx->d_csb.ensure(bb + cb + ((size_t)nb + 1) * 4 + 64)) != PGP_OK) return rc;
@@ -928,9 +931,9 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   std::memcpy(stage_h.data(), hb.data(), (size_t)nb * sizeof(BatchBase));
   std::memcpy(stage_h.data() + bb, cones.data(), (size_t)nb * 168 * 4);
   PGP_HIP(hipMemcpyAsync(d_bases, stage_h.data(), bb + cb, hipMemcpyHostToDevice, st));
-  uint32_t* bcnt = ctx->d_cs_cnt.as<uint32_t>();
-  uint32_t* bstart = bcnt + (nbk + 1);
-  uint32_t* qcnt = bstart + (nbk + 1);
+  int* head = ctx->d_cs_cnt.as<int>();
+  int* next = head + nbk;
+  uint32_t* qcnt = reinterpret_cast<uint32_t*>(next + tp);
   a.Qw = ctx->d_Qs.as<float4>();
   a.Qu = ctx->d_Qs_unit.as<float4>();
   a.nQs = ctx->nQs;
@@ -939,18 +942,15 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   a.nb = nb;
   a.cones = d_cones;
   a.threshold = threshold;
-  a.bucket_cnt = bcnt;
-  a.bucket_start = bstart;
+  a.head = head;
+  a.next = next;
   a.entries = ctx->d_cs_entries.as<int4>();
   a.total_p = (uint32_t)tp;
   a.total_q = (uint32_t)tq;
-  uint32_t* scan_tmp = ctx->d_scan_tmp.as<uint32_t>();
   const dim3 gp((unsigned)((tp + 255) / 256)), gq((unsigned)((tq + 255) / 256));
-  PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
-  hipLaunchKernelGGL(bp_entries<false>, gp, dim3(256), 0, st, a);
-  if ((rc = device_exclusive_scan(bcnt, bstart, (size_t)nbk + 1, scan_tmp, st)) != PGP_OK) return rc;
-  PGP_HIP(hipMemsetAsync(bcnt, 0, ((size_t)nbk + 1) * 4, st));
-  hipLaunchKernelGGL(bp_entries<true>, gp, dim3(256), 0, st, a);
+  const uint32_t n_init = std::max<uint32_t>(nbk, (uint32_t)nb + 1);
+  hipLaunchKernelGGL(bp_init, dim3((n_init + 255) / 256), dim3(256), 0, st, head, (uint32_t)nbk, qcnt, (uint32_t)nb + 1);
+  hipLaunchKernelGGL(bp_entries, gp, dim3(256), 0, st, a);
   stage("P entries into buckets");
   // the matches: appended to a key array sized by a guess (twice the last batch's total, at least 64 k); a batch that
   // outgrows it is matched again into a larger one
@@ -959,6 +959,7 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   uint32_t* d_nkeys = qcnt;            // [1] appended so far | [nb] per base (the Q counters of the two-pass form)
   uint32_t* d_base_cnt = qcnt + 1;
   size_t sort_bytes = 0;
+  bool repeat = false;
   // (PGP_CS_KEY_CAP=n: the first guess, for the test that makes a batch outgrow it)
   static const size_t cap_env = getenv("PGP_CS_KEY_CAP") ? (size_t)std::max(1, atoi(getenv("PGP_CS_KEY_CAP"))) : 0;
   for (size_t cap = cap_env ? cap_env : std::max<size_t>((size_t)ctx->csb_cap_hint, (size_t)1 << 16);;) {
@@ -973,7 +974,8 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
     a.key_cap = (uint32_t)cap;
     a.n_keys = d_nkeys;
     a.base_cnt = d_base_cnt;
-    PGP_HIP(hipMemsetAsync(d_nkeys, 0, ((size_t)nb + 1) * 4, st));
+    if (repeat) PGP_HIP(hipMemsetAsync(d_nkeys, 0, ((size_t)nb + 1) * 4, st));   // (the first round: bp_init did)
+    repeat = true;
     hipLaunchKernelGGL(bq_match, gq, dim3(256), 0, st, a);
     hipLaunchKernelGGL(batch_base_starts, dim3(1), dim3(256), 0, st, (const uint32_t*)d_base_cnt, nb, d_base_start);
     {
