@@ -1955,7 +1955,7 @@ struct NnSched {
 //   by compare-and-swap on the whole word, so a pass of iteration k + 1 is never taken with the tables of iteration k;
 //   done[p] counts completed passes.  Nobody waits for anybody except the owner for passes that were CLAIMED, and a
 //   claimed pass is always finished: no cycle of waits; every spin is bounded by a clock all the same (a lost pass
-//   sets the lost flag and the repair launch redoes the call, as for the clustered launch).
+//   sets the lost flag and the repair launch behind the helping launch redoes the call).
 struct HelpPub {                     // one per pose, in HBM (write-through stores, agent-scope loads)
   unsigned n_unres, base, pad0, pad1;
   unsigned cnt[kNnClasses + 1];
@@ -2681,7 +2681,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
   __shared__ float s_G_old[16];
   __shared__ NnSched s_sch;
 
-  // the repair launch of a clustered call (launch_icp): nothing to do unless a meeting was lost
+  // the repair launch behind a helping launch (launch_icp, PGP_ICP_HELP): nothing to do unless a pass was lost
   if (!CLUSTER && a.run_if && *a.run_if == 0u) return;   // (the helping launch's repair launch: one workgroup per pose)
 
   // several workgroups per pose (few poses in flight: 64 poses would use 64 of the 256 CUs): workgroup `part`
@@ -2758,7 +2758,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         // polling loop invalidated the XCD's L2 for every workgroup on it: selection + sums 10.7 -> 13.4 us)
         __hip_atomic_fetch_add(&a.x_ctr[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // All workgroups of the launch are resident (cooperative launch, one per CU), so the partners arrive;
-        // the clock bound only turns a broken assumption into a repair launch instead of a hang.
+        // the clock bound only turns a broken assumption into a pose finished by one workgroup instead of a hang.
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&a.x_ctr[pose], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
@@ -3610,7 +3610,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     // One workgroup per pose and all of them resident at once (129 .. 256 poses on 256 compute units): a workgroup
     // that is through with its pose takes search passes of the poses still running (HelpPub) -- the launch then
     // lasts about as long as the MEAN pose, not the slowest.  Cooperative (co-residency checked by the runtime) and
-    // chained like the clustered launches; the same repair launch behind it.
+    // chained like the clustered launches; a repair launch behind it (the clustered launch needs none any more).
     // MEASURED SLOWER and therefore OFF unless PGP_ICP_HELP=1 (profiles/r04_ab/icp_helping.log: 256 poses from far
     // 0.84 -> 1.00 ms, from near 0.25 -> 0.28 ms, same bits): the helped kernel's own passes lose the one-trip-ahead
     // prefetch of the plain slot loop, a published iteration costs ~10 us of write-through traffic and waiting, and
