@@ -379,104 +379,87 @@ __device__ __forceinline__ bool bq_has_cell(const CsBatchArgs& a, const uint32_t
   return false;
 }
 
-__device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32_t t, const int b, const int s) {
+// The cone of a Q pair (<= 56 samples rotated onto its direction, each binned: the expensive part of a match, ~300
+// instructions a sample): lane `part` of G takes the samples part, part + G, ...; the caller ORs the lanes' bit sets.
+__device__ __forceinline__ void bq_cone_mask(const CsBatchArgs& a, const uint32_t t, const int b, const int part, const int G,
+                                             uint32_t colored[11]) {
+  const BatchBase B = a.bases[b];
+  const int2 qr = a.pairs[B.q_off + (t - B.q_flat)];
+  const float* cone = a.cones + (size_t)b * 168;
+  const V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
+  // q.setFromTwoVectors((0,0,1), queryn)   (Eigen Quaternion.h:577-610)
+  V3 queryn = normalized(vsub(p2, p1));
+  V3 v1 = normalized(queryn);
+  float cq = add(mul(v1.x, 0.f), add(mul(v1.y, 0.f), mul(v1.z, 1.f)));
+  V3 qv;
+  float qw;
+  if (cq < add(-1.0f, 1e-5f)) {
+    float cc = cq > -1.0f ? cq : -1.0f;
+    float w2 = mul(add(1.0f, cc), 0.5f);
+    qw = sqrt_rn(w2);
+    qv = {sqrt_rn(sub(1.0f, w2)), 0.f, 0.f};
+  } else {
+    V3 axis = {sub(mul(0.f, v1.z), mul(1.f, v1.y)), sub(mul(1.f, v1.x), mul(0.f, v1.z)),
+               sub(mul(0.f, v1.y), mul(0.f, v1.x))};
+    float sq = sqrt_rn(mul(add(1.0f, cq), 2.0f));
+    float invs = fdiv(1.0f, sq);
+    qv = {mul(axis.x, invs), mul(axis.y, invs), mul(axis.z, invs)};
+    qw = mul(sq, 0.5f);
+  }
+  for (int s2 = part; s2 < B.cone_nb; s2 += G) {
+    V3 v = {cone[3 * s2], cone[3 * s2 + 1], cone[3 * s2 + 2]};
+    V3 uv = cross(qv, v);
+    uv = {add(uv.x, uv.x), add(uv.y, uv.y), add(uv.z, uv.z)};
+    V3 c2 = cross(qv, uv);
+    V3 r = {add(add(v.x, mul(qw, uv.x)), c2.x), add(add(v.y, mul(qw, uv.y)), c2.y),
+            add(add(v.z, mul(qw, uv.z)), c2.z)};
+    int id = normal_bin(normalized(r), a.nepsilon);
+    if (id >= 0) {
+#pragma unroll
+      for (int w = 0; w < 11; ++w)
+        if (w == (id >> 5)) colored[w] |= 1u << (id & 31);
+    }
+  }
+}
+
+// The walk of a Q pair over the P entries of its cell, with the cone's bit set (LDS).  WRITE = false: counts the matches
+// (returned) and keeps the first kBqKeep of them in kept[]; WRITE = true: writes the keys of all matches from keys[out0] on
+// (a thread with more than kBqKeep matches walks a second time).
+constexpr int kBqKeep = 4;
+template <bool WRITE>
+__device__ __forceinline__ uint32_t bq_walk(const CsBatchArgs& a, const uint32_t t, const int b, const int s,
+                                            const uint32_t* __restrict__ colored, uint32_t kept[kBqKeep], uint32_t out0) {
   const BatchBase B = a.bases[b];
   const uint32_t i = t - B.q_flat;
   const int2 qr = a.pairs[B.q_off + i];
-  const float* cone = a.cones + (size_t)b * 168;
-  uint32_t found = 0;
-  {
-    V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
-    long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
-    {
-      const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
-      const bool any = true;   // bq_has_cell said so
-      if (any) {
-        V3 queryn = normalized(vsub(p2, p1));
-        V3 v1 = normalized(queryn);
-        float cq = add(mul(v1.x, 0.f), add(mul(v1.y, 0.f), mul(v1.z, 1.f)));
-        V3 qv;
-        float qw;
-        if (cq < add(-1.0f, 1e-5f)) {
-          float cc = cq > -1.0f ? cq : -1.0f;
-          float w2 = mul(add(1.0f, cc), 0.5f);
-          qw = sqrt_rn(w2);
-          qv = {sqrt_rn(sub(1.0f, w2)), 0.f, 0.f};
-        } else {
-          V3 axis = {sub(mul(0.f, v1.z), mul(1.f, v1.y)), sub(mul(1.f, v1.x), mul(0.f, v1.z)),
-                     sub(mul(0.f, v1.y), mul(0.f, v1.x))};
-          float sq = sqrt_rn(mul(add(1.0f, cq), 2.0f));
-          float invs = fdiv(1.0f, sq);
-          qv = {mul(axis.x, invs), mul(axis.y, invs), mul(axis.z, invs)};
-          qw = mul(sq, 0.5f);
-        }
-        uint32_t colored[11];
+  const V3 p1 = ld3(a.Qu, qr.x), p2 = ld3(a.Qu, qr.y);
+  const long long c = pos_cell(lerp_pt(p1, p2, B.inv2), a.epsilon, a.eg);
+  const int clo = (int)(c & 0xFFFFFFFFll), chi = (int)(c >> 32);
+  const V3 queryQ = lerp_pt(ld3(a.Qw, qr.x), ld3(a.Qw, qr.y), B.inv2);
+  uint32_t n = 0;
+  for (int k = s, nk; k >= 0; k = nk) {
+    nk = a.next[k];
+    const int4 en = a.entries[k];
+    if (en.x != clo || en.y != chi || (en.z >> 16) != b) continue;
+    const int bin = en.z & 0xFFFF;
+    const uint32_t word = colored[bin >> 5];
+    if (!((word >> (bin & 31)) & 1u)) continue;
+    const int2 pp = a.pairs[B.p_off + (uint32_t)en.w];
+    const V3 w1 = ld3(a.Qw, pp.x), w2 = ld3(a.Qw, pp.y);
+    const V3 dd = vsub(w2, w1);
+    const V3 ip = {add(w1.x, mul(dd.x, B.inv1)), add(w1.y, mul(dd.y, B.inv1)), add(w1.z, mul(dd.z, B.inv1))};
+    if (sqnorm(vsub(queryQ, ip)) <= a.threshold) {
+      if (!WRITE) {
 #pragma unroll
-        for (int w = 0; w < 11; ++w) colored[w] = 0u;
-        for (int s2 = 0; s2 < B.cone_nb; ++s2) {
-          V3 v = {cone[3 * s2], cone[3 * s2 + 1], cone[3 * s2 + 2]};
-          V3 uv = cross(qv, v);
-          uv = {add(uv.x, uv.x), add(uv.y, uv.y), add(uv.z, uv.z)};
-          V3 c2 = cross(qv, uv);
-          V3 r = {add(add(v.x, mul(qw, uv.x)), c2.x), add(add(v.y, mul(qw, uv.y)), c2.y),
-                  add(add(v.z, mul(qw, uv.z)), c2.z)};
-          int id = normal_bin(normalized(r), a.nepsilon);
-          if (id >= 0) {
-#pragma unroll
-            for (int w = 0; w < 11; ++w)
-              if (w == (id >> 5)) colored[w] |= 1u << (id & 31);
-          }
-        }
-        V3 queryQ = lerp_pt(ld3(a.Qw, qr.x), ld3(a.Qw, qr.y), B.inv2);
-        // the first matches are kept in registers: a thread with at most kKeep of them (nearly all) walks its bucket once
-        constexpr int kKeep = 4;
-        uint32_t kept[kKeep];
-        uint32_t out0 = 0;
-        for (int pass = 0; pass < 2; ++pass) {
-          uint32_t n = 0;
-          for (int k = s; k >= 0; k = a.next[k]) {
-            int4 en = a.entries[k];
-            if (en.x != clo || en.y != chi || (en.z >> 16) != b) continue;
-            const int bin = en.z & 0xFFFF;
-            uint32_t word = 0;
-#pragma unroll
-            for (int w = 0; w < 11; ++w)
-              if (w == (bin >> 5)) word = colored[w];
-            if (!((word >> (bin & 31)) & 1u)) continue;
-            int2 pp = a.pairs[B.p_off + (uint32_t)en.w];
-            V3 w1 = ld3(a.Qw, pp.x), w2 = ld3(a.Qw, pp.y);
-            V3 dd = vsub(w2, w1);
-            V3 ip = {add(w1.x, mul(dd.x, B.inv1)), add(w1.y, mul(dd.y, B.inv1)), add(w1.z, mul(dd.z, B.inv1))};
-            if (sqnorm(vsub(queryQ, ip)) <= a.threshold) {
-              if (pass == 0) {
-#pragma unroll
-                for (int q = 0; q < kKeep; ++q)
-                  if ((uint32_t)q == n) kept[q] = (uint32_t)en.w;
-              } else if (out0 + n < a.key_cap) {
-                a.keys[out0 + n] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)en.w << 24) |
-                                   (unsigned long long)i;
-              }
-              ++n;
-            }
-          }
-          if (pass == 0) {
-            found = n;
-            if (found == 0) break;
-            out0 = atomicAdd(a.n_keys, found);
-            atomicAdd(&a.base_cnt[b], found);
-            if (found <= (uint32_t)kKeep) {
-#pragma unroll
-              for (int q = 0; q < kKeep; ++q)
-                if ((uint32_t)q < found && out0 + q < a.key_cap)
-                  a.keys[out0 + q] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)kept[q] << 24) |
-                                     (unsigned long long)i;
-              break;
-            }
-          }
-        }
+        for (int q = 0; q < kBqKeep; ++q)
+          if ((uint32_t)q == n) kept[q] = (uint32_t)en.w;
+      } else if (out0 + n < a.key_cap) {
+        a.keys[out0 + n] = ((unsigned long long)(unsigned)b << 48) | ((unsigned long long)(unsigned)en.w << 24) | (unsigned long long)i;
       }
+      ++n;
     }
   }
+  return n;
 }
 
 // The Q pairs of a workgroup that have a cell at all are gathered first, so that the cone (<= 56 rotated samples, the
@@ -484,6 +467,7 @@ __device__ __forceinline__ void bq_match_item(const CsBatchArgs& a, const uint32
 __global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
   __shared__ uint32_t s_items[256];
   __shared__ int s_first[256];
+  __shared__ uint32_t s_col[256][11];   // the cones' bit sets (352 direction bins)
   __shared__ unsigned short s_base[256];
   __shared__ uint32_t s_wcnt[4];
   __shared__ int s_b0, s_b1;
@@ -512,7 +496,64 @@ __global__ __launch_bounds__(256) void bq_match(CsBatchArgs a) {
     s_base[slot] = (unsigned short)b;   // at most 65535 bases per call
   }
   __syncthreads();
-  if (threadIdx.x < n_any) bq_match_item(a, s_items[threadIdx.x], (int)s_base[threadIdx.x], s_first[threadIdx.x]);
+  // the cones: kConeLanes lanes per Q pair (a wave of 64 pairs walked its 56 samples for ~35 us while most of the chip had
+  // nothing to do: the workgroups of this launch are fewer than two per compute unit), their bit sets ORed over the group
+  constexpr int kConeLanes = 4;
+  for (uint32_t it0 = 0; it0 < n_any; it0 += 256 / kConeLanes) {
+    const uint32_t item = it0 + threadIdx.x / kConeLanes;
+    uint32_t colored[11];
+#pragma unroll
+    for (int w = 0; w < 11; ++w) colored[w] = 0u;
+    if (item < n_any) bq_cone_mask(a, s_items[item], (int)s_base[item], (int)(threadIdx.x & (kConeLanes - 1)), kConeLanes, colored);
+#pragma unroll
+    for (int off = 1; off < kConeLanes; off <<= 1)
+#pragma unroll
+      for (int w = 0; w < 11; ++w) colored[w] |= __shfl_xor(colored[w], off, 64);
+    if (item < n_any && (threadIdx.x & (kConeLanes - 1)) == 0)
+#pragma unroll
+      for (int w = 0; w < 11; ++w) s_col[item][w] = colored[w];
+  }
+  __syncthreads();
+  // The walks: count first, then ONE reservation of key slots per workgroup (and one add on the base's counter where the
+  // whole workgroup works on one base: nearly always).  A reservation per thread put ~8000 atomic adds on ONE word: 75 of the
+  // launch's 87 us went into that queue (PGP_BQ_ABLATE builds: look-up 20, cones +9, walks +75 us of the stage).
+  uint32_t kept[kBqKeep];
+  uint32_t found = 0;
+  const bool mine = threadIdx.x < n_any;
+  const uint32_t my_t = mine ? s_items[threadIdx.x] : 0u;
+  const int my_b = mine ? (int)s_base[threadIdx.x] : 0;
+  if (mine) found = bq_walk<false>(a, my_t, my_b, s_first[threadIdx.x], s_col[threadIdx.x], kept, 0u);
+  uint32_t incl = found;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  __syncthreads();   // (s_wcnt is read above by every wave)
+  if (lane == 63) s_wcnt[wave] = incl;
+  __syncthreads();
+  __shared__ uint32_t s_out0;
+  const uint32_t total = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+  if (total == 0u) return;
+  const bool one_base = s_b0 == s_b1;
+  if (threadIdx.x == 0) {
+    s_out0 = atomicAdd(a.n_keys, total);
+    if (one_base) atomicAdd(&a.base_cnt[s_b0], total);
+  }
+  if (!one_base && found) atomicAdd(&a.base_cnt[my_b], found);
+  __syncthreads();
+  uint32_t out0 = s_out0 + incl - found;
+  for (int w = 0; w < wave; ++w) out0 += s_wcnt[w];
+  if (found == 0u) return;
+  if (found <= (uint32_t)kBqKeep) {
+    const uint32_t i = my_t - a.bases[my_b].q_flat;
+#pragma unroll
+    for (int q = 0; q < kBqKeep; ++q)
+      if ((uint32_t)q < found && out0 + q < a.key_cap)
+        a.keys[out0 + q] = ((unsigned long long)(unsigned)my_b << 48) | ((unsigned long long)kept[q] << 24) | (unsigned long long)i;
+  } else {
+    (void)bq_walk<true>(a, my_t, my_b, s_first[threadIdx.x], s_col[threadIdx.x], kept, out0);
+  }
 }
 
 // starts of the bases in the sorted keys = exclusive prefix sums of their match counts (one workgroup; nb is a few hundred)
