@@ -1059,7 +1059,7 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
 }
 
 // picks[m][2] = (base, j) -> d_quads[m] (int4), on the sorted keys left by the call above
-int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st) {
+int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st, const int2* d_picks_there) {
   if (ctx->csb_nb <= 0 || (int)ctx->csb_starts.size() != ctx->csb_nb + 1) {
     set_error("no congruent batch: call pgp_find_congruent_batch first (a later pgp_find_congruent, "
               "pgp_set_ppf_map or pgp_set_search_model discards it)");
@@ -1077,9 +1077,13 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
       return PGP_EINVAL;
     }
   }
-  int rc = ctx->d_csb_picks.ensure((size_t)m * 8 + 16);
-  if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(ctx->d_csb_picks.p, h_picks, (size_t)m * 8, hipMemcpyHostToDevice, st));
+  const int2* d_picks = d_picks_there;   // (the caller has queued their upload already, with other things of its own)
+  if (!d_picks) {
+    int rc = ctx->d_csb_picks.ensure((size_t)m * 8 + 16);
+    if (rc != PGP_OK) return rc;
+    PGP_HIP(hipMemcpyAsync(ctx->d_csb_picks.p, h_picks, (size_t)m * 8, hipMemcpyHostToDevice, st));
+    d_picks = ctx->d_csb_picks.as<int2>();
+  }
   const int nb = ctx->csb_nb;
   const size_t bb = ((size_t)nb * sizeof(BatchBase) + 255) & ~(size_t)255, cb = ((size_t)nb * 168 * 4 + 255) & ~(size_t)255;
   unsigned char* sb = ctx->d_csb.as<unsigned char>();
@@ -1087,7 +1091,7 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
   const uint32_t* d_base_start = reinterpret_cast<const uint32_t*>(sb + bb + cb);
   const unsigned long long* keys_out = ctx->d_cs_keys.as<unsigned long long>() + ctx->csb_keys_off;
   hipLaunchKernelGGL(batch_gather, dim3((m + 255) / 256), dim3(256), 0, st, keys_out, d_base_start, d_bases,
-                     (const int2*)ctx->d_ppf_pairs.as<int2>(), (const int2*)ctx->d_csb_picks.as<int2>(), m, d_quads);
+                     (const int2*)ctx->d_ppf_pairs.as<int2>(), d_picks, m, d_quads);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

@@ -1333,7 +1333,7 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   const size_t N = (size_t)m, C = (size_t)list_cap, nQ = (size_t)std::max(ctx->nQ, 0);
   int rc;
   if ((rc = pgp_reserve(ctx, m)) != PGP_OK) return rc;
-  if ((rc = ctx->d_ids.ensure(N * 32)) != PGP_OK) return rc;
+  if ((rc = ctx->d_ids.ensure(N * 40 + 64)) != PGP_OK) return rc;   // bases of the picks | picks | quads
   ctx->csb_fit_m = 0;
   if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
   // scores | (counts) | best -- then what goes home in ONE copy: best {index, score bits} | list {records, pushed, indices}
@@ -1341,7 +1341,7 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   const size_t off_best = N * 8, off_list = off_best + 16, off_rs = off_list + (C + 2) * 4, off_pose = (off_rs + C * 4 + 127) & ~(size_t)127,
                off_T = off_pose + (C + 1) * 128, off_hits = off_T + (C + 1) * 64, total = off_hits + nQ * 4 + 64;
   if ((rc = ctx->d_out.ensure(total)) != PGP_OK) return rc;
-  const size_t in_bytes = N * 16, home = total - off_best, pin_need = in_bytes + home + 256;
+  const size_t in_bytes = N * 24, home = total - off_best, pin_need = in_bytes + home + 256;   // bases of the picks | picks
   if (pin_need > ctx->h_pin_cap) {
     if (ctx->h_pin) {
       hipError_t e = hipHostFree(ctx->h_pin);
@@ -1363,10 +1363,13 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
     }
     for (int j = 0; j < 4; ++j) hb[4 * k + j] = base_ids[4 * (size_t)b + j];
   }
+  std::memcpy(hb + 4 * N, picks, N * 8);
+  // device: bases of the picks [4 N] | picks [2 N] (ONE copy) | quads [4 N]
   int* d_b = ctx->d_ids.as<int>();
-  int* d_q = d_b + 4 * N;
+  int* d_pk = d_b + 4 * N;
+  int* d_q = d_pk + ((2 * N + 3) & ~(size_t)3);   // (int4 records: 16-byte aligned)
   PGP_HIP(hipMemcpyAsync(d_b, hb, in_bytes, hipMemcpyHostToDevice, st));
-  rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st);
+  rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st, reinterpret_cast<const int2*>(d_pk));
   if (rc != PGP_OK) return rc;
   double* d_pose = ctx->d_rig.as<double>();
   float* d_T = reinterpret_cast<float*>(d_pose + 16 * N);

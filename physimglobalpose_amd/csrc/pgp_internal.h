@@ -351,7 +351,8 @@ int launch_find_congruent_4pcs(pgp_ctx* ctx, float inv1, float inv2, float thres
                                const int* d_Qp, int nQ, int* d_quads, int cap, int* n_quads_host, hipStream_t st);
 int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float* h_base_xyz, const float* h_inv,
                                 const int* h_rows /* nullable */, int nb, float threshold, int* h_n_quads, hipStream_t st);
-int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st);
+int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st,
+                                  const int2* d_picks_there = nullptr);
 
 // lcp_score.hip
 int tiles_for(int nQ);
