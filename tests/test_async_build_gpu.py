@@ -1,6 +1,8 @@
 """The index of a small scene is built on the context's side stream while pgp_set_scene has already returned
 (csrc/grid_index.hip build_index_async): whatever reads it must wait for it by itself, and it must be the same index
-the synchronous build (PGP_ASYNC_BUILD=0, every larger scene) produces."""
+the synchronous build (PGP_ASYNC_BUILD=0, every larger scene) produces.  Round 5: the build is prepared by pgp_set_scene and
+queued when the caller next waits for the device or needs the index (PGP_DEFER_BUILD=0: queued at once) -- same index, and a
+scene replaced before anybody asked for its index never has its build queued."""
 import json
 import os
 import subprocess
@@ -39,6 +41,19 @@ out["plain"] = [np.asarray(s).view(np.uint32).tolist(), np.asarray(c).tolist(), 
 sc.set_scene(w.P_xyz, w.P_nrm, w.P_w, w.delta)
 reg = sc.registered(w.T[int(bi)], PGP_MODE_WEIGHTED, w.gate_deg)     # straight after set_scene
 out["registered"] = np.asarray(reg).tolist()
+# a scene that is replaced before anybody asked for its index (its build is never queued), then the new one scored;
+# and a context that is closed with a build still put off
+w2 = synth.make_workload(1800, 700, 384, config_id=78)
+sc.set_scene(w.P_xyz, w.P_nrm, w.P_w, w.delta)
+sc.set_scene(w2.P_xyz, w2.P_nrm, w2.P_w, w2.delta)
+s, c, bi, bs = sc.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
+out["replaced"] = [np.asarray(s).view(np.uint32).tolist(), np.asarray(c).tolist(), int(bi)]
+fresh = LcpScorer(0)
+fresh.init(w2.P_xyz, w2.P_nrm, w2.P_w, w.Q_xyz, w.Q_nrm, w2.delta)
+s, c, bi, bs = fresh.score(w.T, PGP_MODE_WEIGHTED, w.gate_deg)
+out["replaced_fresh"] = [np.asarray(s).view(np.uint32).tolist(), np.asarray(c).tolist(), int(bi)]
+fresh.set_scene(w.P_xyz, w.P_nrm, w.P_w, w.delta)
+fresh.close()
 print("RESULT " + json.dumps(out))
 """ % ROOT
 
@@ -58,4 +73,9 @@ def test_side_stream_build_equals_the_synchronous_build():
     for k in ("w0", "w1", "w2", "plain", "registered"):
         assert a[k] == b[k], k
     assert a["w0"] == a["w1"] == a["w2"]
+    assert a["replaced"] == a["replaced_fresh"] == b["replaced"]
+    # the build queued by pgp_set_scene itself (PGP_DEFER_BUILD=0) instead of when the caller next waits
+    c = _run({"PGP_DEFER_BUILD": "0"})
+    for k in ("info", "w0", "plain", "registered", "replaced"):
+        assert a[k] == c[k], k
     assert any(x != 0 for x in a["w0"][1])          # the batch registers something: the comparison is not 0 == 0
