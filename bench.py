@@ -618,10 +618,14 @@ def drop_in_row():
     from _dropin import make_dropin_case
     with tempfile.TemporaryDirectory() as d:
         args, case = make_dropin_case(d)
+        # the same case with the probability image dense and in cv::imwrite's encoding (tests/_dropin.py): what the node writes
+        os.makedirs(os.path.join(d, "cv"))
+        args_cv, _ = make_dropin_case(os.path.join(d, "cv"), png="opencv")
         out = {"case": case["info"]}
-        for name, extra, calls in (("file_path", {}, 20), ("in_memory", {"SHIM_TEST_INMEMORY": "1"}, 200)):
+        for name, extra, calls, argv in (("file_path", {}, 20, args), ("file_path_cv_png", {}, 20, args_cv),
+                                         ("in_memory", {"SHIM_TEST_INMEMORY": "1"}, 200, args)):
             env = dict(os.environ, PGP_SHIM_SEED="12345", SHIM_TEST_REPEAT=str(calls), **extra)
-            r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([exe] + argv, env=env, capture_output=True, text=True, timeout=600)
             if r.returncode != 0:
                 out[name] = {"error": r.stderr[-300:]}
                 continue
@@ -630,7 +634,7 @@ def drop_in_row():
             out[name] = {"first_call_ms": ms[0], "drop_in_ms_per_object": float(np.median(rest)), "calls": len(ms),
                          "min_ms": float(rest.min()), "p90_ms": float(np.percentile(rest, 90)),
                          "p99_ms": float(np.percentile(rest, 99)), "max_ms": float(rest.max()),
-                         "phases": "profiles/r04_dropin_phases.txt (tools/dropin_phases.py)"}
+                         "phases": "profiles/r05_dropin_phases.txt (tools/dropin_phases.py)"}
         return out
 
 
@@ -952,7 +956,8 @@ def compact_line(out):
             "cluster_ms": r3(get(o, "cluster", "ms_per_call")),
             "leaf_states_render_and_cost_ms": r3(get(o, "leaf_states_device", "render_and_cost_ms")),
             "drop_in_in_memory_ms_median_p99_first": [r3(get(o, "drop_in", "in_memory", k)) for k in ("drop_in_ms_per_object", "p99_ms", "first_call_ms")],
-            "drop_in_file_path_ms_median_p99": [r3(get(o, "drop_in", "file_path", k)) for k in ("drop_in_ms_per_object", "p99_ms")],
+            "drop_in_file_path_ms_median_p99_cvpng": [r3(get(o, "drop_in", "file_path", k)) for k in ("drop_in_ms_per_object", "p99_ms")]
+                                                     + [r3(get(o, "drop_in", "file_path_cv_png", "drop_in_ms_per_object"))],
         }
     if nm:
         rows["native_multi"] = nm if "error" in nm else {

@@ -197,6 +197,7 @@ class Inflater {
       unsigned char d[30];
       for (int i = 0; i < 30; ++i) d[i] = 5;
       if (!build(l, 288, kLitBits, lit_) || !build(d, 30, kDistBits, dist_)) return false;
+      mark_literals(lit_);
     } else if (btype_ == 2) {
       refill();
       if (bitcnt_ < 14) return false;
@@ -240,6 +241,7 @@ class Inflater {
       }
       if (l[256] == 0) return false;   // no end-of-block code
       if (!build(l, hlit, kLitBits, lit_) || !build(l + hlit, hdist, kDistBits, dist_)) return false;
+      mark_literals(lit_);
     } else {
       return false;
     }
@@ -277,62 +279,110 @@ class Inflater {
     if (last_) done_ = true;
   }
 
+  // entries of the literal / length table whose symbol is a plain literal get bit 9: the hot loop tests one bit
+  static void mark_literals(std::vector<uint32_t>& tab) {
+    for (size_t k = 0; k < tab.size(); ++k) {
+      const uint32_t e = tab[k];
+      if (!(e & 0x100u) && (e & 0xFFu) != 0u && (e >> 16) < 256u) tab[k] = e | 0x200u;
+    }
+  }
+
+  // The decoder's state lives in locals for the length of the call (as members every store to the output -- an unsigned
+  // char -- forces the bit buffer, its count and the input position back to memory and in again: ~8 ns per literal, three
+  // times zlib's rate lost on an image that does not compress), and up to three first-level literals follow one refill.
+  // Input exhaustion (bits taken from the zero padding) is checked where it matters -- at every match, before an end-of-
+  // block is believed, and on the way out -- not per literal: what is decoded from padding stays inside the output
+  // buffer and the call still fails.
   bool huffman(size_t limit, bool to_end) {
     static const unsigned short len_base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const unsigned char len_extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
     static const unsigned short dist_base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
     static const unsigned char dist_extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-    const uint32_t* lit = lit_.data();
-    const uint32_t* dst = dist_.data();
-    unsigned char* out = out_;
-    size_t op = opos_;
-    const size_t n_out = n_out_;
+    const uint32_t* const lit = lit_.data();
+    const uint32_t* const dst = dist_.data();
+    unsigned char* const out = out_;
+    const unsigned char* const src = src_.data();
+    const size_t n_out = n_out_, src_size = src_.size(), n_in = n_in_;
+    const uint64_t lit_mask = (1u << kLitBits) - 1u;
+    size_t op = opos_, ip = ip_;
+    uint64_t bb = bitbuf_;
+    int bc = bitcnt_;
+    bool ok = true, block_done = false;
+    auto input_ok = [&] { return ip <= n_in + 8 && (ip - (size_t)(bc > 0 ? bc / 8 : 0)) <= n_in; };
     while (op < limit || to_end) {
-      refill();   // >= 56 bits: a length code (15) + its extra bits (5) + a distance code (15) + its extra bits (13) = 48
-      if (!input_ok()) return false;
-      uint32_t e = lit[bitbuf_ & ((1u << kLitBits) - 1u)];
+      // >= 56 bits: a length code (15) + its extra bits (5) + a distance code (15) + its extra bits (13) = 48
+      if (bc <= 56 && ip + 8 <= src_size) {
+        uint64_t w;
+        std::memcpy(&w, src + ip, 8);   // little-endian host (x86-64 / the GPU box)
+        bb |= w << bc;
+        const int take = (63 - bc) >> 3;
+        ip += (size_t)take;
+        bc += take * 8;
+      }
+      uint32_t e = lit[bb & lit_mask];
+      if ((e & 0x200u) && op + 3 <= n_out) {   // up to three literals of at most 11 bits each
+        bb >>= (e & 0xFFu);
+        bc -= (int)(e & 0xFFu);
+        out[op++] = (unsigned char)(e >> 16);
+        e = lit[bb & lit_mask];
+        if (e & 0x200u) {
+          bb >>= (e & 0xFFu);
+          bc -= (int)(e & 0xFFu);
+          out[op++] = (unsigned char)(e >> 16);
+          e = lit[bb & lit_mask];
+          if (e & 0x200u) {
+            bb >>= (e & 0xFFu);
+            bc -= (int)(e & 0xFFu);
+            out[op++] = (unsigned char)(e >> 16);
+          }
+        }
+        continue;
+      }
       if (e & 0x100u) {
         const uint32_t sub = e >> 16;
-        bitbuf_ >>= kLitBits;
-        bitcnt_ -= kLitBits;
-        e = lit[(sub >> 4) + (uint32_t)(bitbuf_ & ((1u << (sub & 15u)) - 1u))];
-        if (e & 0x100u) return false;
+        bb >>= kLitBits;
+        bc -= kLitBits;
+        e = lit[(sub >> 4) + (uint32_t)(bb & ((1u << (sub & 15u)) - 1u))];
+        if (e & 0x100u) { ok = false; break; }
       }
       const int el = (int)(e & 0xFFu);
-      if (el == 0) return false;
-      bitbuf_ >>= el;
-      bitcnt_ -= el;
+      if (el == 0) { ok = false; break; }
+      bb >>= el;
+      bc -= el;
       const uint32_t sym = e >> 16;
       if (sym < 256) {
-        if (op >= n_out) return false;
+        if (op >= n_out) { ok = false; break; }
         out[op++] = (unsigned char)sym;
         continue;
       }
       if (sym == 256) {
-        opos_ = op;
-        end_block();
-        return true;
+        block_done = true;
+        break;
       }
-      if (sym > 285) return false;
+      if (sym > 285) { ok = false; break; }
       const uint32_t li = sym - 257;
-      size_t len = len_base[li] + bits(len_extra[li]);
-      uint32_t d = dst[bitbuf_ & ((1u << kDistBits) - 1u)];
+      size_t len = len_base[li] + (size_t)(bb & ((1u << len_extra[li]) - 1u));
+      bb >>= len_extra[li];
+      bc -= len_extra[li];
+      uint32_t d = dst[bb & ((1u << kDistBits) - 1u)];
       if (d & 0x100u) {
         const uint32_t sub = d >> 16;
-        bitbuf_ >>= kDistBits;
-        bitcnt_ -= kDistBits;
-        d = dst[(sub >> 4) + (uint32_t)(bitbuf_ & ((1u << (sub & 15u)) - 1u))];
-        if (d & 0x100u) return false;
+        bb >>= kDistBits;
+        bc -= kDistBits;
+        d = dst[(sub >> 4) + (uint32_t)(bb & ((1u << (sub & 15u)) - 1u))];
+        if (d & 0x100u) { ok = false; break; }
       }
       const int dl = (int)(d & 0xFFu);
-      if (dl == 0) return false;
-      bitbuf_ >>= dl;
-      bitcnt_ -= dl;
+      if (dl == 0) { ok = false; break; }
+      bb >>= dl;
+      bc -= dl;
       const uint32_t ds = d >> 16;
-      if (ds > 29) return false;
-      const size_t dist = dist_base[ds] + bits(dist_extra[ds]);
-      if (bitcnt_ < 0) return false;   // ran past the input
-      if (dist > op || op + len > n_out) return false;
+      if (ds > 29) { ok = false; break; }
+      const size_t dist = dist_base[ds] + (size_t)(bb & ((1u << dist_extra[ds]) - 1u));
+      bb >>= dist_extra[ds];
+      bc -= dist_extra[ds];
+      if (bc < 0 || !input_ok()) { ok = false; break; }   // ran past the input
+      if (dist > op || op + len > n_out) { ok = false; break; }
       unsigned char* to = out + op;
       const unsigned char* from = to - dist;
       op += len;
@@ -343,12 +393,13 @@ class Inflater {
           std::memcpy(&w, from + k, 8);
           std::memcpy(to + k, &w, 8);
         }
-      } else if (dist == 1) {
-        std::memset(to, *from, len);
-      } else if ((dist == 2 || dist == 4) && op + 8 <= n_out) {
-        // a run of one 16-bit (or 32-bit) value -- most of a probability image: the pattern in words (8 % dist == 0)
+      } else if ((dist == 1 || dist == 2 || dist == 4) && op + 8 <= n_out) {
+        // a run of one byte (all a Z_RLE encoder, cv::imwrite's default strategy, ever emits), of one 16-bit or one 32-bit
+        // value -- most of a probability image: the pattern in words (8 % dist == 0)
         uint64_t w;
-        if (dist == 2) {
+        if (dist == 1) {
+          w = (uint64_t)*from * 0x0101010101010101ull;
+        } else if (dist == 2) {
           uint16_t v;
           std::memcpy(&v, from, 2);
           w = (uint64_t)v * 0x0001000100010001ull;
@@ -362,7 +413,12 @@ class Inflater {
         for (size_t k = 0; k < len; ++k) to[k] = from[k];
       }
     }
+    bitbuf_ = bb;
+    bitcnt_ = bc;
+    ip_ = ip;
     opos_ = op;
+    if (!ok || !input_ok()) return false;
+    if (block_done) end_block();
     return true;
   }
 };

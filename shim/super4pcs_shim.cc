@@ -42,6 +42,7 @@
 #include <functional>
 #include <iostream>
 #include <map>
+#include <mutex>
 #include <random>
 #include <set>
 #include <sstream>
@@ -307,18 +308,24 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
   // the four files are parsed on four host threads (three ASCII PLYs + the PNG's inflate): the parse was
   // ~1.7 of the drop-in's 3.6 ms per object on one thread
   Cloud seg, qval, qsearch;
-  std::vector<uint16_t> px;
+  // the decoded probability image: in a buffer the process keeps between calls when no other call holds it (a fresh
+  // 600 KB vector per call is an mmap + 150 page faults + a munmap on the image thread's critical path)
+  static std::mutex px_mu;
+  static std::vector<uint16_t> px_kept;
+  std::unique_lock<std::mutex> px_lock(px_mu, std::try_to_lock);
+  std::vector<uint16_t> px_own;
+  std::vector<uint16_t>& px = px_lock.owns_lock() ? px_kept : px_own;
   int rows = 0, cols = 0;
   bool ok1 = false, ok2 = false, ok3 = false, have = false;
   const auto t_files = std::chrono::steady_clock::now();
-  double ms_part[4] = {0, 0, 0, 0};
+  double ms_part[4] = {0, 0, 0, 0}, ms_spawn = 0;
   auto timed = [&](int k, const std::function<void()>& fn) {
     const auto t0 = std::chrono::steady_clock::now();
     fn();
     ms_part[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   };
   // A worker that throws (bad_alloc on a huge file) must not take the host node down through std::terminate: every
-  // worker body catches and reports failure through its flag, and the guard joins whatever is still joinable when
+  // worker body catches and reports failure through its flag, and the guards join whatever is still joinable when
   // this frame unwinds -- the reference would propagate the exception, and so does this function after the join.
   struct JoinGuard {
     std::thread& t;
@@ -331,22 +338,37 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
       *flag = false;
     }
   };
-  // the PNG (inflate + unfilter: the longest of the four) keeps decoding while the clouds are centred,
-  // uploaded and indexed; the match waits for it only where the weights are first needed
+  // Starting a thread costs this one ~0.016 ms (MI355X host), so it starts ONE -- the validation model's reader, which
+  // first starts the other two -- and is parsing the segment, the longest of the three clouds, 0.03 ms earlier.  (Threads
+  // kept between calls start in 0.006 ms but run slower: woken next to the thread that wakes them, they share its core
+  // -- segment 0.154 -> 0.22 ms, the call 0.90 -> 1.01 ms; measured, not kept.)  A reader that cannot get a thread runs
+  // inline on the one that wanted to start it.
+  // The PNG (inflate + unfilter) keeps decoding while the clouds are centred, uploaded and indexed; the match waits
+  // for it only where the weights are first needed.
   std::atomic<int> last_row(1 << 30);   // until the match knows which rows its points fall on: all of them
-  std::thread t4([&] { timed(3, [&] { guarded(&have, [&] { return read_png_gray(probImagePath, px, rows, cols, &last_row); }); }); });
-  JoinGuard g4{t4};
-  {
-    std::thread t2([&] { timed(1, [&] { guarded(&ok2, [&] { return read_ply(input2, qval); }); }); });
-    JoinGuard g2{t2};
-    std::thread t3([&] { timed(2, [&] { guarded(&ok3, [&] { return read_ply(input3, qsearch); }); }); });
-    JoinGuard g3{t3};
-    timed(0, [&] { ok1 = read_ply(input1, seg); });
-    t2.join();
-    t3.join();
-  }
+  const std::function<void()> read_image = [&] { timed(3, [&] { guarded(&have, [&] { return read_png_gray(probImagePath, px, rows, cols, &last_row); }); }); };
+  const std::function<void()> read_search = [&] { timed(2, [&] { guarded(&ok3, [&] { return read_ply(input3, qsearch); }); }); };
+  const std::function<void()> read_validation = [&] { timed(1, [&] { guarded(&ok2, [&] { return read_ply(input2, qval); }); }); };
+  auto on_a_thread = [](std::thread& t, const std::function<void()>& body) {
+    try {
+      t = std::thread(body);
+    } catch (const std::system_error&) {
+      body();
+    }
+  };
+  std::thread t4, t3, t2;   // t4 and t3 are started by t2's thread: only looked at after t2 is joined
+  JoinGuard g4{t4}, g3{t3}, g2{t2};   // (destroyed in reverse: t2 first)
+  on_a_thread(t2, [&] {
+    on_a_thread(t4, read_image);
+    on_a_thread(t3, read_search);
+    read_validation();
+  });
+  ms_spawn = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_files).count();
+  timed(0, [&] { ok1 = read_ply(input1, seg); });
+  if (t2.joinable()) t2.join();
+  if (t3.joinable()) t3.join();
   if (!ok1 || !ok2 || !ok3) {
-    t4.join();
+    if (t4.joinable()) t4.join();
     std::cerr << "[libsuper4pcs shim] cannot read the input PLY files" << std::endl;
     return;
   }
@@ -357,11 +379,11 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
   auto image = [&](int* r, int* c, int last_needed) -> const unsigned short* {
     if (!joined) {
       last_row.store(last_needed, std::memory_order_release);
-      t4.join();
+      if (t4.joinable()) t4.join();
       joined = true;
       if (getenv("PGP_SHIM_VERBOSE"))
         std::cerr << "[libsuper4pcs shim] file hand-off: image ready " << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_files).count()
-                  << " ms after the call (segment " << ms_part[0] << ", validation model " << ms_part[1] << ", search model " << ms_part[2]
+                  << " ms after the call (reader thread started " << ms_spawn << ", segment " << ms_part[0] << ", validation model " << ms_part[1] << ", search model " << ms_part[2]
                   << ", probability image " << ms_part[3] << " ms, in parallel)" << std::endl;
       if (!have) std::cerr << "[libsuper4pcs shim] no probability image at " << probImagePath << ": weights = 1" << std::endl;
     }
@@ -370,7 +392,7 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
     return have ? px.data() : nullptr;
   };
   match_impl(vs, vq, vqs, image, bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
-  if (!joined && t4.joinable()) t4.join();
+  if (t4.joinable()) t4.join();
 }
 
 void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,

@@ -150,7 +150,33 @@ static int check_zlib(const Bytes& z, size_t cap, std::mt19937& g) {
   return 0;
 }
 
+// adler32_of (the 32-bytes-at-a-time form where the CPU has AVX2) against zlib's own on seeded random buffers: every length
+// 0 .. 300, lengths around the block size of the vector loop and around zlib's NMAX, all-0xFF buffers (the largest sums)
+static int check_adler(unsigned seed) {
+  std::mt19937 g(seed);
+  std::vector<size_t> lens;
+  for (size_t n = 0; n <= 300; ++n) lens.push_back(n);
+  for (size_t c : {(size_t)5520, (size_t)5536, (size_t)5552, (size_t)11072, (size_t)65521, (size_t)614880, (size_t)1 << 20})
+    for (int d = -33; d <= 33; d += 11) lens.push_back(c + d);
+  int bad = 0;
+  for (size_t n : lens) {
+    for (int fill = 0; fill < 2; ++fill) {
+      Bytes b(n + 3);
+      for (auto& x : b) x = fill ? 0xFF : (unsigned char)(g() & 0xFF);
+      const unsigned char* p = b.data() + (n % 3);   // (unaligned starts too)
+      const uint32_t want = (uint32_t)adler32(adler32(0L, Z_NULL, 0), p, (uInt)n);
+      if (shimio::adler32_of(p, n) != want) {
+        std::fprintf(stderr, "adler32_of differs at length %zu (fill %d)\n", n, fill);
+        ++bad;
+      }
+    }
+  }
+  std::printf("adler %zu lengths checked, %d differ\n", lens.size() * 2, bad);
+  return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc == 3 && std::strcmp(argv[1], "adler") == 0) return check_adler((unsigned)std::atoi(argv[2]));
   if (argc == 4 && std::strcmp(argv[1], "file") == 0) {
     const int r = std::strcmp(argv[2], "ply") == 0 ? check_ply(argv[3]) : check_png(argv[3]);
     std::printf("%s %s\n", argv[3], r > 0 ? "READ" : (r == 0 ? "REFUSED" : "BROKEN"));

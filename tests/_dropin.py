@@ -56,8 +56,68 @@ def ppf_map(P, N, trans_disc=5, rot_disc=10):
 
 
 
-def make_dropin_case(tmp, binary=False, n_scene=8000, n_model=1500, n_search=800, config_id=91):
-    """Writes the files under `tmp`; returns (argv for shim/test_shim, info dict with the workload)."""
+def write_png_with_filter(img, ftype, path):
+    """A greyscale PNG of `img` (uint8 / uint16) whose every row carries scanline filter `ftype` (a list gives one per
+    row, cycled) -- cv::imwrite writes Sub on every row, PIL picks per row by heuristic and rarely leaves one alone."""
+    import struct, zlib
+    bpp = img.dtype.itemsize
+    raw = img.astype(">u2" if bpp == 2 else np.uint8).tobytes()
+    stride = img.shape[1] * bpp
+    types = ftype if isinstance(ftype, (list, tuple)) else [ftype]
+    body = bytearray()
+    prev = bytes(stride)
+    for r in range(img.shape[0]):
+        cur = raw[r * stride:(r + 1) * stride]
+        f = types[r % len(types)]
+        line = bytearray(stride)
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = prev[i]
+            c = prev[i - bpp] if i >= bpp else 0
+            if f == 0: pred = 0
+            elif f == 1: pred = a
+            elif f == 2: pred = b
+            elif f == 3: pred = (a + b) >> 1
+            else:
+                q = a + b - c
+                pa, pb, pc = abs(q - a), abs(q - b), abs(q - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            line[i] = (cur[i] - pred) & 0xFF
+        body += bytes([f]) + line
+        prev = cur
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as fh:
+        fh.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", img.shape[1], img.shape[0], 8 * bpp, 0, 0, 0, 0))
+                 + chunk(b"IDAT", zlib.compress(bytes(body), 6)) + chunk(b"IEND", b""))
+
+
+def write_png_like_opencv(path, img):
+    """16-bit greyscale PNG in the form cv::imwrite gives a CV_16UC1 image with its defaults (OpenCV is not in this
+    image; its PNG encoder documents strategy IMWRITE_PNG_STRATEGY_RLE and a low compression level as the defaults
+    and applies filter Sub to every row): what the reference node writes and base.cc:317 reads back."""
+    import struct, zlib
+    be = img.astype(">u2").view(np.uint8).reshape(img.shape[0], -1)
+    sub = be.copy()
+    sub[:, 2:] = be[:, 2:] - be[:, :-2]
+    body = np.concatenate([np.ones((img.shape[0], 1), np.uint8), sub], axis=1).tobytes()
+    z = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_RLE)
+    data = z.compress(body) + z.flush()
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", img.shape[1], img.shape[0], 16, 0, 0, 0, 0)))
+        for k in range(0, len(data), 8192):                      # libpng's default IDAT size
+            f.write(chunk(b"IDAT", data[k:k + 8192]))
+        f.write(chunk(b"IEND", b""))
+
+
+def make_dropin_case(tmp, binary=False, n_scene=8000, n_model=1500, n_search=800, config_id=91, png="pil"):
+    """Writes the files under `tmp`; returns (argv for shim/test_shim, info dict with the workload).
+    png="opencv": the probability image as the node's network writes it -- a dense map (class probability over the whole
+    frame, the same values as the sparse image at every pixel a segment point falls on, so the match is the same) in
+    cv::imwrite's encoding; "opencv_noisy": the same with noise in every pixel (the decoder's worst case); "pil": the
+    points' pixels only, PIL's encoding (the r1-r4 form)."""
     from PIL import Image
     w = synth.make_workload(n_scene, n_model, 4, config_id=config_id, n_search=n_search)
     # a segment as the node produces it: mostly the object, some clutter around it
@@ -82,8 +142,28 @@ def make_dropin_case(tmp, binary=False, n_scene=8000, n_model=1500, n_search=800
     ok = (row >= 0) & (row < 480) & (col >= 0) & (col < 640)
     order = np.argsort(w.P_w[ok])                       # object pixels (w = 1) are written last
     img[row[ok][order], col[ok][order]] = np.round(w.P_w[ok][order] * 10000).astype(np.uint16)
-    png = os.path.join(str(tmp), "prob.png")
-    Image.fromarray(img).save(png)
+    png_path = os.path.join(str(tmp), "prob.png")
+    if png in ("opencv", "opencv_noisy"):
+        yy, xx = np.mgrid[0:480, 0:640]
+        cr, cc = (row[ok].mean(), col[ok].mean()) if ok.any() else (240.0, 320.0)
+        dist = np.sqrt((yy - cr) ** 2 + (xx - cc) ** 2)
+        noise = np.random.default_rng(3).standard_normal(dist.shape)
+        if png == "opencv":
+            # a confident network: 1 inside the object's blob, 0 outside, an uncertain band between them
+            prob = 1.0 / (1.0 + np.exp((dist - 110.0) / 6.0))
+            dense = 10000.0 * prob + 600.0 * prob * (1.0 - prob) * noise
+        else:
+            # no flat region anywhere (the low byte of every pixel is noise): the encoder finds nothing to match and the
+            # decoder's time is all literals -- the slowest image of this size there is
+            dense = 10000.0 * np.exp(-dist ** 2 / (2 * 90.0 ** 2)) + 40.0 * noise
+        dense = np.round(dense).clip(0, 10000).astype(np.uint16)
+        hit = np.zeros(img.shape, bool)
+        hit[row[ok], col[ok]] = True
+        img = np.where(hit, img, dense)
+        write_png_like_opencv(png_path, img)
+    else:
+        Image.fromarray(img).save(png_path)
+    png = png_path
     table = ppf_map(Qs, w.Qs_nrm)
     ppf = os.path.join(str(tmp), "PPFMap.txt")
     with open(ppf, "w") as f:

@@ -13,6 +13,8 @@ import zlib
 import numpy as np
 import pytest
 
+from _dropin import write_png_like_opencv, write_png_with_filter
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "shim")
 EXE = os.path.join(SHIM, "test_parsers_asan")
@@ -69,7 +71,12 @@ def _files(tmp):
     p16, p8 = os.path.join(tmp, "prob16.png"), os.path.join(tmp, "prob8.png")
     _png(p16, img, 16)
     _png(p8, img >> 8, 8)
-    return a, b, p16, p8
+    # cv::imwrite's form (Sub on every row, byte runs only, several IDAT chunks) and every filter above every other: the
+    # 16-bytes-at-a-time unfilter loops and the decoder's run / literal paths under the sanitizers
+    pcv, pmix = os.path.join(tmp, "prob_cv.png"), os.path.join(tmp, "prob_mix.png")
+    write_png_like_opencv(pcv, img)
+    write_png_with_filter(img[:40, :77], [0, 1, 2, 3, 4, 0, 2, 4, 1, 3, 0, 3, 1, 4, 2, 0, 4, 3, 2, 1, 1, 0], pmix)
+    return a, b, p16, p8, pcv, pmix
 
 
 def _run(exe, *args):
@@ -79,16 +86,17 @@ def _run(exe, *args):
 
 
 def test_valid_files_are_read(exe, tmp_path):
-    for f, kind in zip(_files(str(tmp_path)), ("ply", "ply", "png", "png")):
+    for f, kind in zip(_files(str(tmp_path)), ("ply", "ply", "png", "png", "png", "png")):
         assert "READ" in _run(exe, "file", kind, f), f
 
 
 def test_seeded_mutations_of_ply_png_and_zlib_streams(exe, tmp_path):
-    a, b, p16, p8 = _files(str(tmp_path))
+    a, b, p16, p8, pcv, pmix = _files(str(tmp_path))
     scratch = os.path.join(str(tmp_path), "mutated.bin")
     total = 0
     for kind, f, n, seed in (("ply", a, 700, 1), ("ply", b, 700, 2), ("png", p16, 700, 3), ("png", p8, 400, 4),
-                             ("zlib", p16, 500, 5), ("zlib", p8, 300, 6)):
+                             ("png", pcv, 500, 7), ("png", pmix, 400, 8),
+                             ("zlib", p16, 500, 5), ("zlib", p8, 300, 6), ("zlib", pcv, 400, 9)):
         out = _run(exe, kind, f, n, seed, scratch if kind != "zlib" else "-")
         assert out.strip().endswith("OK"), out
         read, refused = (int(out.split(w)[0].split()[-1]) for w in (" read", " refused"))
@@ -96,11 +104,20 @@ def test_seeded_mutations_of_ply_png_and_zlib_streams(exe, tmp_path):
         assert read > 0 or kind != "ply"                    # ... and some survive it and are read consistently (a PNG's
         #                                                     Adler-32 refuses nearly every damaged stream)
         total += n
-    assert total >= 2000
+    assert total >= 3000
+
+
+def test_fast_adler32_equals_zlibs(exe):
+    """shimio::adler32_of -- 32 bytes at a time where the CPU has AVX2, zlib's otherwise -- is what decides whether a
+    decoded probability image is accepted: against zlib's adler32 over ~800 seeded buffers (all short lengths, lengths
+    around the vector loop's block size, all-0xFF contents, unaligned starts), under the sanitizers."""
+    r = subprocess.run([exe, "adler", "7"], capture_output=True, text=True, env=ENV, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 differ" in r.stdout
 
 
 def test_crafted_headers_are_refused_without_the_memory_they_ask_for(exe, tmp_path):
-    a, b, p16, _ = _files(str(tmp_path))
+    a, b, p16 = _files(str(tmp_path))[:3]
     tmp = str(tmp_path)
     cases = []
     for name, src in (("ascii", a), ("binary", b)):

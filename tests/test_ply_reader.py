@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 from _checkers import have_ref, ref_lib
+from _dropin import write_png_with_filter
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "shim", "libsuper4pcs.so")
@@ -112,6 +113,37 @@ def test_shim_png_decoder_matches_pil(tmp_path):
         assert rc == 0 and (rows.value, cols.value) == img.shape
         assert np.array_equal(out.reshape(img.shape), want)
     assert L.super4pcs_shim_read_png(str(tmp_path / "missing.png").encode(), None, 0, C.byref(rows), C.byref(cols)) == -1
+
+
+def test_shim_png_decoder_every_scanline_filter(tmp_path):
+    """Each of the five scanline filters on every row (Sub is what cv::imwrite writes, base.cc:317 reads it back) and a
+    mix that puts every filter above every other: 16- and 8-bit, widths that end inside, on and just past the 16-byte
+    blocks the Sub / Up / byte-swap loops take."""
+    L = C.CDLL(SHIM)
+    L.super4pcs_shim_read_png.argtypes = [C.c_char_p, C.POINTER(C.c_ushort), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    rng = np.random.default_rng(23)
+    mix = [0, 1, 2, 3, 4, 0, 2, 4, 1, 3, 0, 3, 1, 4, 2, 0, 4, 3, 2, 1, 1, 0]
+    k = 0
+    for dtype, hi in ((np.uint16, 65536), (np.uint8, 256)):
+        for w in (1, 2, 7, 8, 9, 15, 16, 17, 23, 33, 64, 131):
+            h = 23
+            img = rng.integers(0, hi, (h, w)).astype(dtype)
+            img[::3] = (np.arange(w) * 301 % hi).astype(dtype)          # rows with structure too
+            for ftype in (0, 1, 2, 3, 4, mix):
+                p = str(tmp_path / f"f_{k}.png")
+                k += 1
+                write_png_with_filter(img, ftype, p)
+                out = np.zeros(img.size, np.uint16)
+                rows, cols = C.c_int(0), C.c_int(0)
+                rc = L.super4pcs_shim_read_png(p.encode(), out.ctypes.data_as(C.POINTER(C.c_ushort)), out.size, C.byref(rows), C.byref(cols))
+                assert rc == 0 and (rows.value, cols.value) == img.shape, (dtype, w, ftype)
+                assert np.array_equal(out.reshape(img.shape), img.astype(np.uint16)), (dtype, w, ftype)
+    # the writer above against an independent decoder, once
+    from PIL import Image
+    img = rng.integers(0, 65536, (9, 21)).astype(np.uint16)
+    p = str(tmp_path / "pil_check.png")
+    write_png_with_filter(img, mix, p)
+    assert np.array_equal(np.array(Image.open(p)).astype(np.uint16), img)
 
 
 def test_shim_png_decoder_stops_after_the_last_row_needed(tmp_path):

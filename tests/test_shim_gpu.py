@@ -65,6 +65,25 @@ def test_drop_in_symbol_recovers_the_pose(tmp_path, binary):
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
+def test_drop_in_reads_the_probability_image_in_the_encoding_of_cv_imwrite(tmp_path):
+    """The probability image as the node writes it (dense, Sub filter on every row, byte runs only, several IDAT chunks;
+    also with noise in every pixel, which leaves the decoder nothing but literals) holds the same values as the sparse
+    PIL-encoded one at every pixel a segment point falls on: the file hand-off returns the same poses and scores."""
+    outs = {}
+    for kind in ("pil", "opencv", "opencv_noisy"):
+        d = tmp_path / kind
+        d.mkdir()
+        argv, _ = make_dropin_case(d, png=kind)
+        env = dict(os.environ, PGP_SHIM_SEED="2024", SHIM_TEST_REPEAT="2")
+        r = subprocess.run([BIN, *argv], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[kind] = [l for l in r.stdout.splitlines() if not l.startswith("ELAPSED_MS")]
+        assert any(l.startswith("BEST_SCORE") and float(l.split()[1]) > 0 for l in outs[kind])
+    assert outs["opencv"] == outs["pil"]
+    assert outs["opencv_noisy"] == outs["pil"]
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
 def test_drop_in_takes_the_reference_tie_rule_for_a_segment_with_duplicated_points(tmp_path):
     """A segment that holds duplicated points makes exact distance ties an every-query event; the drop-in notices
     (a hash of the coordinates) and switches pgp_set_exact_ties on for that object: same output as forcing it, and a

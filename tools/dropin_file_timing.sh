@@ -9,7 +9,7 @@ import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 from _dropin import make_dropin_case
 d = os.path.join(sys.argv[1], "case"); os.makedirs(d, exist_ok=True)
-args, case = make_dropin_case(d)
+args, case = make_dropin_case(d, png=os.environ.get("DROPIN_PNG", "pil"))   # pil | opencv | opencv_noisy (tests/_dropin.py)
 open(os.path.join(sys.argv[1], "args.txt"), "w").write("\n".join(args))
 PY
 mapfile -t ARGS < $OUT/args.txt
