@@ -4,8 +4,9 @@
 // 16-bit PNG; inflating its 614 KB with zlib's inflate() was ~1 ms, the longest single step of a 1.8 ms call.  This
 // decoder has the whole input and the whole output buffer in front of it, so it can refill its bit buffer eight
 // bytes at a time, look a symbol up in one table probe (11 bits for literals / lengths, 8 for distances, second-level
-// tables behind them) and copy matches in words.  It is RESUMABLE at any output position (run(limit) decodes until at
-// least `limit` bytes exist), which is what lets the caller stop after the last image row it needs.
+// tables behind them; two literals from one probe where both codes fit in it) and copy matches in words.  It is
+// RESUMABLE at any output position (run(limit) decodes until at least `limit` bytes exist -- up to five more), which is
+// what lets the caller stop after the last image row it needs.
 //
 // Safety: every table probe and copy is bounded by the buffers given; a malformed stream returns false.  The caller
 // checks the Adler-32 (zlib's adler32()) of a completely decoded stream against trailer() and falls back to zlib's own
@@ -152,9 +153,10 @@ class Inflater {
     for (size_t p = 0; p < sub_bits.size(); ++p) {
       if (!sub_bits[p]) continue;
       sub_off[p] = (uint32_t)tab.size();
-      if (sub_off[p] >= 4096u) return false;   // (does not happen for 15-bit codes behind these roots; the entry has 12 bits for it)
+      const uint32_t rel = sub_off[p] - (1u << root);   // the entry holds the offset behind the first level, in 12 bits
+      if (rel >= 4096u) return false;   // (does not happen for 15-bit codes behind these roots)
       tab.resize(tab.size() + ((size_t)1 << sub_bits[p]), 0u);
-      tab[p] = ((sub_off[p] << 4 | (uint32_t)sub_bits[p]) << 16) | 0x100u | (uint32_t)root;
+      tab[p] = ((rel << 4 | (uint32_t)sub_bits[p]) << 16) | 0x100u | (uint32_t)root;
     }
     for (int i = 0; i < n; ++i) {
       const int l = len[i];
@@ -279,12 +281,31 @@ class Inflater {
     if (last_) done_ = true;
   }
 
-  // entries of the literal / length table whose symbol is a plain literal get bit 9: the hot loop tests one bit
+  // Entries of the literal / length table whose symbol is a plain literal get bit 9: the hot loop tests one bit.  Where the
+  // bits behind such a literal decide a SECOND literal inside the same first-level probe (both codes together at most
+  // kLitBits long: the short codes of the high bytes next to the long ones of the low bytes, in a Sub-filtered 16-bit
+  // image), the entry carries both -- bit 10, the two literals in bits 16..31, the total length in bits 0..7 and the first
+  // literal's own length in bits 11..14 for the places that take one symbol at a time.
   static void mark_literals(std::vector<uint32_t>& tab) {
     for (size_t k = 0; k < tab.size(); ++k) {
       const uint32_t e = tab[k];
       if (!(e & 0x100u) && (e & 0xFFu) != 0u && (e >> 16) < 256u) tab[k] = e | 0x200u;
     }
+    const uint32_t root = 1u << kLitBits;
+    std::vector<uint32_t> two(root, 0u);
+    for (uint32_t k = 0; k < root; ++k) {
+      const uint32_t e1 = tab[k];
+      if (!(e1 & 0x200u)) continue;
+      const uint32_t l1 = e1 & 0xFFu;
+      if (l1 >= (uint32_t)kLitBits) continue;
+      const uint32_t e2 = tab[k >> l1];   // the bits behind the first code, zeros above them
+      if (!(e2 & 0x200u)) continue;
+      const uint32_t l2 = e2 & 0xFFu;
+      if (l1 + l2 > (uint32_t)kLitBits) continue;   // else the second code depends on bits this probe does not hold
+      two[k] = ((e2 >> 16) << 24) | ((e1 >> 16) << 16) | (l1 << 11) | 0x400u | 0x200u | (l1 + l2);
+    }
+    for (uint32_t k = 0; k < root; ++k)
+      if (two[k]) tab[k] = two[k];
   }
 
   // The decoder's state lives in locals for the length of the call (as members every store to the output -- an unsigned
@@ -320,29 +341,36 @@ class Inflater {
         bc += take * 8;
       }
       uint32_t e = lit[bb & lit_mask];
-      if ((e & 0x200u) && op + 3 <= n_out) {   // up to three literals of at most 11 bits each
+      if ((e & 0x200u) && op + 8 <= n_out) {   // up to three probes of at most 11 bits, one or two literals each
         bb >>= (e & 0xFFu);
         bc -= (int)(e & 0xFFu);
-        out[op++] = (unsigned char)(e >> 16);
+        out[op] = (unsigned char)(e >> 16);
+        out[op + 1] = (unsigned char)(e >> 24);   // (written either way: overwritten by what follows when the entry holds one)
+        op += 1 + ((e >> 10) & 1u);
         e = lit[bb & lit_mask];
         if (e & 0x200u) {
           bb >>= (e & 0xFFu);
           bc -= (int)(e & 0xFFu);
-          out[op++] = (unsigned char)(e >> 16);
+          out[op] = (unsigned char)(e >> 16);
+          out[op + 1] = (unsigned char)(e >> 24);
+          op += 1 + ((e >> 10) & 1u);
           e = lit[bb & lit_mask];
           if (e & 0x200u) {
             bb >>= (e & 0xFFu);
             bc -= (int)(e & 0xFFu);
-            out[op++] = (unsigned char)(e >> 16);
+            out[op] = (unsigned char)(e >> 16);
+            out[op + 1] = (unsigned char)(e >> 24);
+            op += 1 + ((e >> 10) & 1u);
           }
         }
         continue;
       }
+      if (e & 0x400u) e = (e & 0x00FF0000u) | 0x200u | ((e >> 11) & 0xFu);   // near the end of the buffer: its first literal alone
       if (e & 0x100u) {
         const uint32_t sub = e >> 16;
         bb >>= kLitBits;
         bc -= kLitBits;
-        e = lit[(sub >> 4) + (uint32_t)(bb & ((1u << (sub & 15u)) - 1u))];
+        e = lit[(1u << kLitBits) + (sub >> 4) + (uint32_t)(bb & ((1u << (sub & 15u)) - 1u))];
         if (e & 0x100u) { ok = false; break; }
       }
       const int el = (int)(e & 0xFFu);
@@ -369,7 +397,7 @@ class Inflater {
         const uint32_t sub = d >> 16;
         bb >>= kDistBits;
         bc -= kDistBits;
-        d = dst[(sub >> 4) + (uint32_t)(bb & ((1u << (sub & 15u)) - 1u))];
+        d = dst[(1u << kDistBits) + (sub >> 4) + (uint32_t)(bb & ((1u << (sub & 15u)) - 1u))];
         if (d & 0x100u) { ok = false; break; }
       }
       const int dl = (int)(d & 0xFFu);
