@@ -372,8 +372,10 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * target's bounding box) and ONE launch runs every iteration of every pose.  Otherwise the
  * iterations are driven from the host (many workgroups per pose) and the call synchronises the
  * stream every four iterations to test for convergence.  While few poses are in flight (n x 4 or
- * n x 2 <= the device's compute units) that ONE launch is cooperative, with 4 or 2 workgroups per pose
- * sharing the search (not on a stream that is being captured; PGP_ICP_WGS=1 switches it off).  Should the
+ * n x 2 <= the device's compute units) that ONE launch has 4 or 2 workgroups per pose sharing the search, one per
+ * compute unit (a plain launch of a grid that fits the device -- PGP_COOPERATIVE_LAUNCH=1: hipLaunchCooperativeKernel,
+ * whose queue makes the hardware scheduler time-slice the GPU between processes; not on a stream that is being
+ * captured; PGP_ICP_WGS=1 switches the sharing off).  Should the
  * workgroups of a pose ever fail to meet (another process holding the GPU's compute units for seconds), the pose's
  * first workgroup searches every query again and finishes the pose alone, inside the same launch -- the caller always
  * receives refined transforms, the same bits.  Clustered launches of one process never overlap on a device.

@@ -1222,7 +1222,7 @@ __global__ __launch_bounds__(256) void icp_nn_grid_open(IcpArgs a, float r2_safe
 // The reference's one LIVE ICP call aligns the whole scene to the table model (SceneCfg.cpp:101,135-141: ~30 000 source
 // points, a 100 000-point target, correspondence cap 1 cm, <= 50 iterations).  Host-driven, an iteration was three launches
 // (icp_nn_grid, icp_sums_partial, icp_refine<true, true>) and every fourth a host synchronisation: 63 us of which 42 in
-// kernels.  Here ONE cooperative launch of resident workgroups runs every iteration, with the arithmetic of those three
+// kernels.  Here ONE launch of resident workgroups (launch_resident) runs every iteration, with the arithmetic of those three
 // kernels operation for operation (same grid search, same 4-points-per-lane accumulation, same wave tree, the same
 // order of the wave and block sums), so transforms, energies and iteration counts are theirs bit for bit:
 //   chunk  = 16 consecutive source points: one round of a 256-thread workgroup, 16 lanes per query (grid_nn27); keys go
@@ -2757,8 +2757,9 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         // agent-scope loads below, so no cache has to be written back or invalidated here (an acquire in the
         // polling loop invalidated the XCD's L2 for every workgroup on it: selection + sums 10.7 -> 13.4 us)
         __hip_atomic_fetch_add(&a.x_ctr[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // All workgroups of the launch are resident (cooperative launch, one per CU), so the partners arrive;
-        // the clock bound only turns a broken assumption into a pose finished by one workgroup instead of a hang.
+        // The grid fits the device (launch_resident: one workgroup per CU), so the partners arrive -- at once on an idle
+        // device, as compute units come free behind somebody else's kernel; the clock bound turns a device that stays
+        // taken for seconds into a pose finished by one workgroup instead of a hang.
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         while (__hip_atomic_load(&a.x_ctr[pose], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
@@ -3181,7 +3182,7 @@ __global__ __launch_bounds__(kIcpThreads) void icp_persist_help(IcpArgs a) {
 
 // SEVERAL (source, target) pairs in ONE launch: the children of an MCTS expansion belong to different objects
 // (UCTSearch.cpp:200-266 -> UCTState.cpp:121-204), and the node's per-object loop (SceneCfg.cpp:379-402) refines
-// the candidates of every object of a frame -- 3 x 64 poses are three cooperative launches one after the other
+// the candidates of every object of a frame -- 3 x 64 poses are three clustered launches one after the other
 // through the single-target entry, or 192 workgroups of one launch here.  Workgroup = one pose; its target (index
 // image, geometry, vicinity graph), its segment and its slice of the transform / energy / iteration arrays come
 // from the descriptor of the pose's job -- a table that travels in the kernel arguments (no upload, no sync).
@@ -3410,9 +3411,9 @@ static int build_nn_index(pgp_ctx* ctx, const float4* d_tgt, int n_tgt, int n_q,
 }
 
 // Clustered launches (several workgroups per pose that meet every iteration) must not interleave with each other on
-// a device: two of them, each half resident, would wait for partners that cannot be scheduled.  The runtime serialises
-// cooperative launches as far as it is documented; this chain makes it certain for every stream of THIS process: each
-// clustered launch waits for the previous one's completion event (no host synchronisation).
+// a device: two of them, each half resident, would wait for partners that cannot be scheduled (until the clock bound of
+// their waits frees them).  This chain rules it out for every stream of THIS process: each launch of resident
+// workgroups waits for the previous one's completion event (no host synchronisation).
 namespace {
 struct CoopChain {
   std::mutex mu;
@@ -3420,6 +3421,42 @@ struct CoopChain {
 };
 CoopChain g_coop;
 }  // namespace
+
+// A launch whose workgroups wait for each other (the clustered, the helping and the scene-sized kernels).  By default a
+// PLAIN launch of a grid that fits on the device at the kernel's occupancy: on an idle or lightly shared device every
+// workgroup is resident at once; behind somebody else's long kernel the late ones arrive when it ends, and every wait in
+// these kernels is bounded by a clock (a lost meeting is finished by the pose's first workgroup, a lost unit by the host-
+// driven iterations).  hipLaunchCooperativeKernel gives the same launch a runtime check and a queue of its own -- and
+// that queue, once it exists, makes the hardware scheduler time-slice the device between processes: every OTHER process
+// on the GPU (the node's segmentation network, say) then meets stalls of ~11 ms although this one is idle (measured:
+// tools/child_under_parent.py, profiles/r05_ab/cooperative_queue_stalls.log).  PGP_COOPERATIVE_LAUNCH=1: the runtime's form.
+static hipError_t launch_resident(pgp_ctx* ctx, const void* fn, unsigned grid, unsigned threads, void** params, unsigned lds,
+                                  hipStream_t stream) {
+  const char* coop = getenv("PGP_COOPERATIVE_LAUNCH");
+  if (coop && atoi(coop) != 0) return hipLaunchCooperativeKernel(fn, dim3(grid), dim3(threads), params, lds, stream);
+  struct Known {
+    const void* fn;
+    unsigned threads, lds;
+    int per_cu;
+  };
+  static std::mutex mu;
+  static std::vector<Known> known;
+  int per_cu = -1;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Known& k : known)
+      if (k.fn == fn && k.threads == threads && k.lds == lds) per_cu = k.per_cu;
+    if (per_cu < 0) {
+      int v = 0;
+      const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, fn, (int)threads, lds);
+      if (e != hipSuccess) return e;
+      per_cu = v;
+      known.push_back(Known{fn, threads, lds, v});
+    }
+  }
+  if ((long long)grid > (long long)per_cu * ctx->n_cus) return hipErrorCooperativeLaunchTooLarge;
+  return hipLaunchKernel(fn, dim3(grid), dim3(threads), params, lds, stream);
+}
 
 // the options of a call (pgp_icp_options) as kernel arguments; k_trim = the trimmed count of a cloud of n_src points
 static int icp_trim_count(const pgp_icp_options* prm, int n_src) {
@@ -3548,9 +3585,9 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     const void* fn = persist_kernel(a.metric, il, false, trim_only, n_src);
     const void* fn_cluster = persist_kernel(a.metric, il, true, trim_only, n_src);
     // Few poses: 2 or 4 workgroups per pose share the search (64 poses alone would use 64 of the 256 CUs).  They
-    // meet once per iteration, so all of them must be resident at once: a COOPERATIVE launch (the runtime checks
-    // that the grid fits and keeps such launches from interleaving), one workgroup per CU.  Not while the stream
-    // is being captured (a graph cannot hold the launch) and not with the pointmatcher history.
+    // meet once per iteration, so all of them should be resident at once: a grid that fits the device, one workgroup
+    // per CU, chained behind the previous such launch (launch_resident, g_coop).  Not while the stream is being
+    // captured (the chain's event wait is not for a graph) and not with the pointmatcher history.
     a.wgs_per_pose = 1;
     if (const char* v = getenv("PGP_ICP_DBG_POSE")) a.dbg_pose = atoi(v);
     if (const char* v = getenv("PGP_ICP_SLOTS")) a.slot_budget = atoi(v);
@@ -3592,9 +3629,9 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       ctx->icp_x_n = n;
       ctx->icp_x_need = (size_t)need;
       void* params[] = {&a};
-      hipError_t e = hipLaunchCooperativeKernel(fn_cluster, dim3(n * a.wgs_per_pose), dim3(kIcpThreads), params, (unsigned)plds, stream);
+      hipError_t e = launch_resident(ctx, fn_cluster, (unsigned)(n * a.wgs_per_pose), kIcpThreads, params, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG"))
-        fprintf(stderr, "icp: %d poses x %d workgroups, cooperative launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
+        fprintf(stderr, "icp: %d poses x %d workgroups, resident launch: %s\n", n, a.wgs_per_pose, hipGetErrorString(e));
       if (e == hipSuccess) {
         // Nothing behind the kernel: a meeting that is lost (another process holding the chip's compute units for
         // seconds) makes the pose's workgroup 0 go on alone inside the launch (icp_persist_body), so the caller --
@@ -3604,13 +3641,13 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
         PGP_HIP(hipGetLastError());
         return PGP_OK;
       }
-      (void)hipGetLastError();   // the grid does not fit as a cooperative launch here: one workgroup per pose
+      (void)hipGetLastError();   // the grid does not fit on this device at the kernel's occupancy: one workgroup per pose
       a.wgs_per_pose = 1;
     }
     // One workgroup per pose and all of them resident at once (129 .. 256 poses on 256 compute units): a workgroup
     // that is through with its pose takes search passes of the poses still running (HelpPub) -- the launch then
-    // lasts about as long as the MEAN pose, not the slowest.  Cooperative (co-residency checked by the runtime) and
-    // chained like the clustered launches; a repair launch behind it (the clustered launch needs none any more).
+    // lasts about as long as the MEAN pose, not the slowest.  Launched and chained like the clustered launches
+    // (launch_resident); a repair launch behind it (the clustered launch needs none any more).
     // MEASURED SLOWER and therefore OFF unless PGP_ICP_HELP=1 (profiles/r04_ab/icp_helping.log: 256 poses from far
     // 0.84 -> 1.00 ms, from near 0.25 -> 0.28 ms, same bits): the helped kernel's own passes lose the one-trip-ahead
     // prefetch of the plain slot loop, a published iteration costs ~10 us of write-through traffic and waiting, and
@@ -3645,8 +3682,8 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       h.help_stride = hb;
       PGP_HIP(hipMemsetAsync(base, 0, hdr, stream));
       void* hparams[] = {&h};
-      hipError_t e = hipLaunchCooperativeKernel(help_kernel(trim_only, n_src <= 2 * kIcpBase ? 2 : (n_src <= 3 * kIcpBase ? 3 : 4)),
-                                                dim3(n), dim3(kIcpThreads), hparams, (unsigned)plds, stream);
+      hipError_t e = launch_resident(ctx, help_kernel(trim_only, n_src <= 2 * kIcpBase ? 2 : (n_src <= 3 * kIcpBase ? 3 : 4)),
+                                     (unsigned)n, kIcpThreads, hparams, (unsigned)plds, stream);
       if (getenv("PGP_ICP_DEBUG")) fprintf(stderr, "icp: %d poses, helping launch: %s\n", n, hipGetErrorString(e));
       if (e == hipSuccess) {
         IcpArgs fix = a;
@@ -3660,7 +3697,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
         PGP_HIP(hipGetLastError());
         return PGP_OK;
       }
-      (void)hipGetLastError();   // not launchable cooperatively here: the plain launch below
+      (void)hipGetLastError();   // the grid does not fit here: the launch without helpers below
     }
     void* params[] = {&a};
     PGP_HIP(hipLaunchKernel(fn, dim3(n), dim3(kIcpThreads), params, plds, stream));
@@ -3835,10 +3872,10 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       ctx->icp_grid_n[2] = a.gnz;
     }
   }
-  // The capped grid search with sums by block -- the shape of the reference's table alignment -- as ONE cooperative launch
-  // (icp_scene_persist): every iteration on the device, no host round trip.  PGP_ICP_SCENE_PERSIST=0: the host-driven
-  // iterations below (the checker of that kernel: same bits); also taken while the stream is being captured, with the
-  // pointmatcher history, and where the device takes no cooperative launch.
+  // The capped grid search with sums by block -- the shape of the reference's table alignment -- as ONE launch of resident
+  // workgroups (icp_scene_persist): every iteration on the device, no host round trip.  PGP_ICP_SCENE_PERSIST=0: the host-
+  // driven iterations below (the checker of that kernel: same bits); also taken while the stream is being captured and with
+  // the pointmatcher history.
   {
     if (scene_persist) {
       SceneArgs z{};
@@ -3850,7 +3887,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       const size_t st_bytes = N * kSceneRep * kSceneRepStride * 4, pc_bytes = (N * 4 + 63) & ~(size_t)63, eo_bytes = (N * 8 + 63) & ~(size_t)63;
       const size_t tail = pc_bytes + st_bytes + eo_bytes + 64;
       const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
-      std::lock_guard<std::mutex> chain(g_coop.mu);   // cooperative launches of one process never overlap on a device
+      std::lock_guard<std::mutex> chain(g_coop.mu);   // launches of resident workgroups of one process never overlap on a device
       if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
       else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
       if ((rc = ctx->d_icp_x.ensure(w_bytes + uc_bytes + tail + 256)) != PGP_OK) return rc;
@@ -3881,9 +3918,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       z.poll_sleep = 1;
       if (const char* v = getenv("PGP_ICP_SCENE_SLEEP")) z.poll_sleep = atoi(v);
       void* params[] = {&a, &z};
-      const hipError_t e = room > z.n_upd ? hipLaunchCooperativeKernel(fn_scene, dim3(grid), dim3(kSceneThreads),
-                                                                   params, 0, stream)
-                                      : hipErrorInvalidValue;
+      const hipError_t e = room > z.n_upd ? launch_resident(ctx, fn_scene, grid, kSceneThreads, params, 0, stream) : hipErrorInvalidValue;
       if (getenv("PGP_ICP_DEBUG"))
         fprintf(stderr, "icp: scene-sized capped ICP in one launch: %d poses x %d chunks on %u workgroups (%d per CU): %s\n", n, z.n_chunks,
                 grid, per_cu, hipGetErrorString(e));
@@ -3926,7 +3961,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
 #endif
         return PGP_OK;
       }
-      (void)hipGetLastError();   // not launchable cooperatively here: the host-driven iterations
+      (void)hipGetLastError();   // the grid does not fit here: the host-driven iterations
       if ((rc = init_split_state()) != PGP_OK) return rc;
     }
   }

@@ -156,7 +156,7 @@ int pgp_create(pgp_ctx** out, int device_id) {
     int cus = 0, coop = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0 &&
         hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device_id) == hipSuccess && coop)
-      ctx->n_cus = cus;   // 0: no cooperative launches on this device (the clustered ICP then stays off)
+      ctx->n_cus = cus;   // 0: the kernels whose workgroups wait for each other stay off (icp.hip launch_resident)
   }
   if (const char* v = getenv("PGP_UNROLL")) ctx->unroll = atoi(v);
   if (const char* v = getenv("PGP_HPB")) ctx->hpb_override = atoi(v);

@@ -67,3 +67,55 @@ def test_counters_hold_across_calls_of_changing_shape(monkeypatch):
     assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=8), refs[0])
     one.close()
     sc.close()
+
+
+def test_plain_and_cooperative_launch_give_the_same_bits(monkeypatch):
+    """The kernels whose workgroups wait for each other go out as plain launches of a grid that fits the device (no
+    cooperative queue: its existence makes the hardware scheduler time-slice the GPU between processes, csrc/icp.hip
+    launch_resident); PGP_COOPERATIVE_LAUNCH=1 is the runtime's checked form.  Same transforms, energies and iteration
+    counts from both: clustered launches of 1 and 24 poses, and the scene-sized capped form in one launch."""
+    S, M, N, G = _problem(83, 5000, 2500, 24, rot_deg=4.0, trans=0.004, outliers=0.03)
+    rng = np.random.default_rng(12)
+    tgt = np.c_[rng.uniform(-0.6, 0.6, 60000), rng.uniform(-0.4, 0.4, 60000), 0.0005 * rng.standard_normal(60000)].astype(np.float32)
+    src = (tgt[rng.choice(len(tgt), 20000, replace=False)] + np.array([0.004, -0.003, 0.002]) + 0.0008 * rng.standard_normal((20000, 3))).astype(np.float32)
+    eye = np.eye(4, dtype=np.float32).T.reshape(1, 16).copy()
+    sc = LcpScorer()
+
+    def run():
+        return (sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), sc.icp_refine(S, M, G[:1], trim=0.9, max_iterations=12),
+                sc.icp_refine_ex(src, tgt, eye, max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9,
+                                 absolute_mse=1e-12))
+    plain = run()
+    monkeypatch.setenv("PGP_COOPERATIVE_LAUNCH", "1")
+    coop = run()
+    monkeypatch.delenv("PGP_COOPERATIVE_LAUNCH")
+    again = run()
+    for a, b, c in zip(plain, coop, again):
+        assert _same(a, b) and _same(a, c)
+    assert plain[2][2][0] > 3          # the scene-sized form really iterated
+    sc.close()
+
+
+def test_clustered_launch_behind_a_kernel_that_holds_the_device():
+    """A plain launch promises no co-residency: with another stream's long kernel on the compute units the workgroups of a
+    clustered launch arrive late, one after the other, and wait for their partners meanwhile.  Same bits as on an idle device."""
+    S, M, N, G = _problem(85, 5000, 2500, 48, rot_deg=4.0, trans=0.004, outliers=0.03)
+    sc = LcpScorer()
+    ref = sc.icp_refine(S, M, G, trim=0.9, max_iterations=12)
+    d_src, d_tgt = _dev4(S), _dev4(M)
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    torch.cuda.synchronize()
+    for rep in range(3):
+        d_T = torch.from_numpy(G.copy()).cuda().reshape(-1, 16)
+        d_e = torch.zeros(len(G), device="cuda")
+        d_it = torch.zeros(len(G), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            b = a
+            for _ in range(6):               # a few milliseconds of full-device work
+                b = torch.sin(b @ a * 1e-3)
+        sc.icp_refine_device(d_src, d_tgt, d_T, d_e, d_it, trim=0.9, max_iterations=12)
+        torch.cuda.synchronize()
+        assert _same((d_T.cpu().numpy().reshape(ref[0].shape), d_e.cpu().numpy(), d_it.cpu().numpy()), ref)
+    sc.close()

@@ -25,16 +25,25 @@ def _group(args, n_objects=1):
     return grp
 
 
-def _time(fn, reps):
+CALLS = {}   # per-call times of every _time() of this run: [min, median, max] ms, printed with the rows
+
+
+def _time(fn, reps, tag=None):
+    """MEDIAN seconds per call over `reps` calls timed one by one (the mean of 5-10 calls moves by a factor of three when
+    one of them meets a 15 ms stall of the host; the spread goes into CALLS)."""
     import gc
     fn()
     gc.disable()   # one full pass of the cycle collector is tens of milliseconds (tools/icp_hiccup_probe.py)
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         r = fn()
-    dt = (time.perf_counter() - t0) / reps
+        ts.append(time.perf_counter() - t0)
     gc.enable()
-    return dt, r
+    ts.sort()
+    if tag:
+        CALLS[tag] = [round(ts[0] * 1e3, 4), round(ts[len(ts) // 2] * 1e3, 4), round(ts[-1] * 1e3, 4)]
+    return ts[len(ts) // 2], r
 
 
 def objects_row(args, mode):
@@ -48,9 +57,9 @@ def objects_row(args, mode):
         grp.init_object(o, w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
     Ts = [w.T for w in objs]
     reps = max(5, min(args.steps, 20))
-    dt_host, got = _time(lambda: grp.score_objects(Ts, mode, 30.0), reps)
+    dt_host, got = _time(lambda: grp.score_objects(Ts, mode, 30.0), reps, "objects_host_pointers")
     grp.upload_objects(Ts)
-    dt_res, got = _time(lambda: grp.score_objects_uploaded(mode, 30.0), reps)
+    dt_res, got = _time(lambda: grp.score_objects_uploaded(mode, 30.0), reps, "objects_resident")
     same = True
     for w, g in zip(objs, got):
         one = LcpScorer(0)
@@ -81,14 +90,14 @@ def icp_row(args, mode):
                       for _ in range(64)])
         jobs.append((S, M, G))
     grp = _group(args)
-    dt, got = _time(lambda: grp.icp_refine(jobs, trim=0.9, max_iterations=10), 5)
+    dt, got = _time(lambda: grp.icp_refine(jobs, trim=0.9, max_iterations=10), 9, "icp_group")
     same, n_it = True, 0
     one = [LcpScorer(0) for _ in jobs]
     for sc, (S, M, G), g in zip(one, jobs, got):
         a = sc.icp_refine(S, M, G, trim=0.9, max_iterations=10)
         same = same and all(bool(np.array_equal(x, y)) for x, y in zip(a, g))
         n_it += int(a[2].sum())
-    dt_one, _ = _time(lambda: [sc.icp_refine(S, M, G, trim=0.9, max_iterations=10) for sc, (S, M, G) in zip(one, jobs)], 5)
+    dt_one, _ = _time(lambda: [sc.icp_refine(S, M, G, trim=0.9, max_iterations=10) for sc, (S, M, G) in zip(one, jobs)], 9, "icp_one_context_per_job")
     grp.close()
     return {"jobs": 6, "poses": 6 * 64, "pose_iterations": n_it, "ms_per_call": round(dt * 1e3, 4),
             "pose_iterations_per_s": round(n_it / dt), "one_context_per_job_ms": round(dt_one * 1e3, 4), "equals_single_context": same}
@@ -131,8 +140,8 @@ def congruent_row(args, mode):
         nq = sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
         return nq, sc.congruent_batch_fit(picks_of(nq), ids, w.centroid_P, w.centroid_Q)
 
-    dt, (nq, fit) = _time(group_call, 10)
-    dt_one, (nq1, fit1) = _time(single_call, 10)
+    dt, (nq, fit) = _time(group_call, 15, "congruent_group")
+    dt_one, (nq1, fit1) = _time(single_call, 15, "congruent_one_context")
     good = fit1[2] == 1
     same = bool(np.array_equal(nq, nq1) and np.array_equal(fit[2], fit1[2]) and np.array_equal(fit[0][good], fit1[0][good])
                 and np.array_equal(fit[1][good], fit1[1][good]))
@@ -200,7 +209,7 @@ def main():
         diag = {"cpus": len(os.sched_getaffinity(0)), "loadavg": os.getloadavg()[0], "parent_threads_by_state": states}
     except OSError:
         pass
-    out = {"devices": n, "mode": args.mode, "hypotheses_per_call": args.hyp * n, "steps": args.steps, "diag": diag, **extra,
+    out = {"devices": n, "mode": args.mode, "hypotheses_per_call": args.hyp * n, "steps": args.steps, "diag": diag, "calls_min_median_max_ms": CALLS, **extra,
            "resident": {"ms_per_call": dt_res * 1e3, "hypotheses_per_s": args.hyp * n / dt_res},
            "host_pointers": {"ms_per_call": dt_host * 1e3, "hypotheses_per_s": args.hyp * n / dt_host,
                              "last_call_ms": tim},
