@@ -379,6 +379,9 @@ int pgp_icp_refine(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
  * workgroups of a pose ever fail to meet (another process holding the GPU's compute units for seconds), the pose's
  * first workgroup searches every query again and finishes the pose alone, inside the same launch -- the caller always
  * receives refined transforms, the same bits.  Clustered launches of one process never overlap on a device.
+ * The scene-sized capped form in one launch (n_src > 4096, a correspondence cap, no trimming, n <= 64) reports a pose
+ * whose work did not arrive within the same clock bound with d_iters = -1 and leaves its transform where it was; the
+ * host-pointer calls then redo the job with the host-driven iterations themselves.
  * Checker paths, same results:
  * PGP_ICP_NN=scan (exhaustive search), PGP_ICP_PERSIST=0 (index, host-driven iterations),
  * PGP_ICP_SPLIT=0/1 (the exhaustive persistent / host-driven kernels). */

@@ -1245,6 +1245,7 @@ struct SceneArgs {
   int n_chunks, n_units, n_units16, n_blk;
   int poll_sleep;             // s_sleep argument between two polls of a pose's state word
   int n_upd;                  // workgroups 0 .. n_upd-1 are updaters (pose p: updater p % n_upd), the rest workers
+  int force_lost;             // test knob (PGP_ICP_FORCE_LOST): every pose's first wait for its units counts as run out
   unsigned long long* dbg;    // PGP_SCENE_STAMPS builds: [64 iterations][16] clock stamps (100 MHz) of updater 0 and of three workers
 };
 #ifdef PGP_SCENE_STAMPS
@@ -1307,6 +1308,7 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
               break;
             }
           }
+          if (z.force_lost && it == 0) lost = 1;
           s_upd[0] = lost;
         }
         __syncthreads();
@@ -3422,11 +3424,16 @@ struct CoopChain {
 CoopChain g_coop;
 }  // namespace
 
+// The host-pointer call redoes a scene-sized job whose one-launch form reported a pose as lost (iteration count -1: its
+// units did not arrive within the clock bound) with the host-driven iterations: this thread's next launch_icp calls.
+static thread_local bool t_scene_form_off = false;
+void icp_scene_form_off(bool off) { t_scene_form_off = off; }
+
 // A launch whose workgroups wait for each other (the clustered, the helping and the scene-sized kernels).  By default a
 // PLAIN launch of a grid that fits on the device at the kernel's occupancy: on an idle or lightly shared device every
 // workgroup is resident at once; behind somebody else's long kernel the late ones arrive when it ends, and every wait in
-// these kernels is bounded by a clock (a lost meeting is finished by the pose's first workgroup, a lost unit by the host-
-// driven iterations).  hipLaunchCooperativeKernel gives the same launch a runtime check and a queue of its own -- and
+// these kernels is bounded by a clock (a lost meeting is finished by the pose's first workgroup; a lost unit of the scene-
+// sized form ends the pose with iteration count -1, and the host-pointer call redoes the job host-driven).  hipLaunchCooperativeKernel gives the same launch a runtime check and a queue of its own -- and
 // that queue, once it exists, makes the hardware scheduler time-slice the device between processes: every OTHER process
 // on the GPU (the node's segmentation network, say) then meets stalls of ~11 ms although this one is idle (measured:
 // tools/child_under_parent.py, profiles/r05_ab/cooperative_queue_stalls.log).  PGP_COOPERATIVE_LAUNCH=1: the runtime's form.
@@ -3747,7 +3754,8 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
     return PGP_OK;
   };
   // (up to 64 poses: the reference's call has one; the unit sums of many poses would be gigabytes)
-  bool scene_persist = use_grid && n_blk > 1 && !(a.max_corr2 < 0.f && a.k_trim < a.n_src) && a.smooth == 0 && ctx->n_cus > 0 && n <= 64;
+  bool scene_persist = use_grid && n_blk > 1 && !(a.max_corr2 < 0.f && a.k_trim < a.n_src) && a.smooth == 0 && ctx->n_cus > 0 && n <= 64 &&
+                       !t_scene_form_off;
   if (const char* v = getenv("PGP_ICP_PART")) scene_persist = scene_persist && atoi(v) != 0;
   if (const char* v = getenv("PGP_ICP_SCENE_PERSIST")) scene_persist = scene_persist && atoi(v) != 0;
   if (scene_persist) {
@@ -3917,6 +3925,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (const char* v = getenv("PGP_ICP_SCENE_WGS")) grid = std::max((unsigned)z.n_upd + 1u, std::min(grid, (unsigned)atoi(v)));   // A/B knob
       z.poll_sleep = 1;
       if (const char* v = getenv("PGP_ICP_SCENE_SLEEP")) z.poll_sleep = atoi(v);
+      if (getenv("PGP_ICP_FORCE_LOST")) z.force_lost = 1;
       void* params[] = {&a, &z};
       const hipError_t e = room > z.n_upd ? launch_resident(ctx, fn_scene, grid, kSceneThreads, params, 0, stream) : hipErrorInvalidValue;
       if (getenv("PGP_ICP_DEBUG"))

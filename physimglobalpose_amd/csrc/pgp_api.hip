@@ -1645,6 +1645,10 @@ void icp_host_collect(pgp_ctx* ctx, const IcpHostStage& g, int n, float* T, floa
 
 }  // namespace pgp
 
+namespace pgp {
+void icp_scene_form_off(bool off);   // icp.hip: this thread's next launch_icp calls take the host-driven scene-sized form
+}
+
 extern "C" {
 
 int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* tgt_xyz, const float* tgt_nrm,
@@ -1677,6 +1681,25 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   if (rc != PGP_OK) return rc;
   if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
   PGP_HIP(hipStreamSynchronize(st));
+  {
+    // A pose the scene-sized one-launch form gave up on (iteration count -1: the device was held by somebody else for
+    // seconds and the pose's units did not arrive, icp.hip icp_scene_persist) -- the caller's transforms are still
+    // untouched: the whole job once more, host-driven.
+    const int* it = reinterpret_cast<const int*>(static_cast<const unsigned char*>(ctx->h_pin) + g.off_i);
+    bool lost = false;
+    for (int i = 0; i < n; ++i) lost = lost || it[i] < 0;
+    if (lost) {
+      struct Off {
+        Off() { pgp::icp_scene_form_off(true); }
+        ~Off() { pgp::icp_scene_form_off(false); }
+      } off;
+      if ((rc = icp_host_stage(ctx, src_xyz, n_src, tgt_xyz, n_tgt, T, n, st, &g)) != PGP_OK) return rc;
+      rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token);
+      if (rc != PGP_OK) return rc;
+      if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
+      PGP_HIP(hipStreamSynchronize(st));
+    }
+  }
   icp_host_collect(ctx, g, n, T, energy, iters);
   return PGP_OK;
 }

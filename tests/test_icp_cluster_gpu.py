@@ -119,3 +119,33 @@ def test_clustered_launch_behind_a_kernel_that_holds_the_device():
         torch.cuda.synchronize()
         assert _same((d_T.cpu().numpy().reshape(ref[0].shape), d_e.cpu().numpy(), d_it.cpu().numpy()), ref)
     sc.close()
+
+
+def test_scene_sized_form_that_loses_a_pose_is_redone_host_driven(monkeypatch):
+    """The scene-sized capped ICP in one launch ends a pose whose units do not arrive within its clock bound with
+    iteration count -1 (a device held by somebody else for seconds; forced here by PGP_ICP_FORCE_LOST).  The host-pointer
+    call then redoes the job with the host-driven iterations -- the checker of that kernel, same bits; the device-pointer
+    call reports the -1."""
+    rng = np.random.default_rng(14)
+    tgt = np.c_[rng.uniform(-0.6, 0.6, 60000), rng.uniform(-0.4, 0.4, 60000), 0.0005 * rng.standard_normal(60000)].astype(np.float32)
+    src = (tgt[rng.choice(len(tgt), 20000, replace=False)] + np.array([0.004, -0.003, 0.002]) + 0.0008 * rng.standard_normal((20000, 3))).astype(np.float32)
+    eye = np.eye(4, dtype=np.float32).T.reshape(1, 16).copy()
+    kw = dict(max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
+    sc = LcpScorer()
+    ref = sc.icp_refine_ex(src, tgt, eye, **kw)
+    assert ref[2][0] > 3
+    monkeypatch.setenv("PGP_ICP_FORCE_LOST", "1")
+    assert _same(sc.icp_refine_ex(src, tgt, eye, **kw), ref)
+    d_T = torch.from_numpy(eye.copy()).cuda()
+    d_e = torch.zeros(1, device="cuda")
+    d_it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    sc.icp_refine_device(_dev4(src), _dev4(tgt), d_T, d_e, d_it, trim=1.0, max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0)
+    torch.cuda.synchronize()
+    assert int(d_it[0]) == -1
+    monkeypatch.delenv("PGP_ICP_FORCE_LOST")
+    d_T.copy_(torch.from_numpy(eye))
+    sc.icp_refine_device(_dev4(src), _dev4(tgt), d_T, d_e, d_it, trim=1.0, max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0)
+    torch.cuda.synchronize()
+    assert int(d_it[0]) > 3
+    assert _same(sc.icp_refine_ex(src, tgt, eye, **kw), ref)
+    sc.close()
