@@ -380,14 +380,19 @@ __device__ void try_quadrilateral(const float4* __restrict__ P, int ids[4], floa
   }
 }
 
+// kSelLdsPoints: an attempt's stage weights live in LDS up to this many points (the sequential sums are one wave's 64-wide
+// trips over them, each waiting for its load: from memory that wait, not the chain of additions, was most of a stage)
+constexpr int kSelLdsPoints = 12288;
+template <bool LDS>
 __global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
+  extern __shared__ float s_cur[];
   __shared__ double s_part[257];
   __shared__ int s_pick;
   __shared__ float s_sum;
   __shared__ int s_present;
   const int att = blockIdx.x;
   const double* u = a.u + 4 * (size_t)att;
-  float* cur = a.cur + (size_t)att * a.n;
+  float* cur = LDS ? s_cur : a.cur + (size_t)att * a.n;
   const int n = a.n;
   auto fail = [&]() {
     if (threadIdx.x == 0) {
@@ -803,7 +808,10 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   a.inv = d_inv;
   a.status = d_status;
   a.rows = h_rows ? d_rows : nullptr;
-  hipLaunchKernelGGL(select_bases, dim3(n_attempts), dim3(kSelThreads), 0, st, a);
+  if (getenv("PGP_SEL_GLOBAL") || a.n > kSelLdsPoints)   // (A/B knob; segments beyond the LDS form)
+    hipLaunchKernelGGL(select_bases<false>, dim3(n_attempts), dim3(kSelThreads), 0, st, a);
+  else
+    hipLaunchKernelGGL(select_bases<true>, dim3(n_attempts), dim3(kSelThreads), (size_t)a.n * 4, st, a);
   PGP_HIP(hipGetLastError());
   // ids | inv | status | rows lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
   HostOut out(ctx, st);
