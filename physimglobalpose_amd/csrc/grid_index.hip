@@ -29,6 +29,8 @@
 // HBM layout: 28 copies of each point on average (h = 0.85 delta, two dilation rings) = 22.6 MB at
 // |P| = 50 k; the index trades capacity (288 GB) for one-run locality.
 
+#include <mutex>
+
 #include "pgp_internal.h"
 
 #include <cfloat>
@@ -467,7 +469,24 @@ static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta
   const int nP = ctx->nP;
   int rc;
   // (each on its own: a failure half way leaves what exists, and the next call goes on from there)
-  if (!ctx->build_stream) PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+  if (!ctx->build_stream) {
+    // ONE side stream per device for the builds of all contexts: the runtime gives a process four hardware queues
+    // (GPU_MAX_HW_QUEUES), and a second context's own side stream came to share a queue with that context's main stream --
+    // its build then ran IN FRONT of the congruent-set search instead of beside it (the drop-in's second object: 0.75 ms
+    // per call instead of 0.55, profiles/r05_ab/hardware_queues.log).  PGP_BUILD_STREAM_PER_CONTEXT=1: a stream per context.
+    if (getenv("PGP_BUILD_STREAM_PER_CONTEXT")) {
+      PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+      ctx->build_stream_own = true;
+    } else {
+      static std::mutex mu;
+      static hipStream_t shared[64] = {};
+      const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
+      std::lock_guard<std::mutex> lk(mu);
+      if (!shared[dev]) PGP_HIP(hipStreamCreateWithFlags(&shared[dev], hipStreamNonBlocking));
+      ctx->build_stream = shared[dev];
+      ctx->build_stream_own = false;
+    }
+  }
   if (!ctx->ev_index) PGP_HIP(hipEventCreate(&ctx->ev_index));
   if (!ctx->ev_build0) PGP_HIP(hipEventCreate(&ctx->ev_build0));
   if (!ctx->h_build_counts) PGP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_build_counts), 64, hipHostMallocDefault));

@@ -191,7 +191,7 @@ int pgp_destroy(pgp_ctx* ctx) {
     hipError_t e = hipSuccess;
     if (ctx->build_stream) {
       e = hipStreamSynchronize(ctx->build_stream);
-      e = hipStreamDestroy(ctx->build_stream);
+      if (ctx->build_stream_own) e = hipStreamDestroy(ctx->build_stream);   // (else the device's shared one: it stays)
     }
     if (ctx->ev_index) e = hipEventDestroy(ctx->ev_index);
     if (ctx->ev_build0) e = hipEventDestroy(ctx->ev_build0);

@@ -99,6 +99,7 @@ struct pgp_ctx {
   // on its own stream first (await_index, grid_index.hip) -- base selection and the congruent sets, which only read
   // the points, run beside the build.
   hipStream_t build_stream = nullptr;
+  bool build_stream_own = false;   // false: the device's shared build stream (grid_index.hip build_index_async)
   hipEvent_t ev_index = nullptr, ev_build0 = nullptr;
   bool index_pending = false;
   // the side-stream build of the current scene, prepared but not yet QUEUED: its dozen-and-a-half launches cost the host

@@ -34,6 +34,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -137,6 +138,9 @@ static unsigned long long cloud_hash(const std::vector<float>& a, const std::vec
   for (size_t i = 0; i < b.size(); ++i) h1 = (h1 ^ w[i]) * 0x100000001B3ull + (h1 >> 31);
   return (h0 ^ (h1 * 0x9E3779B97F4A7C15ull)) | 1ull;
 }
+
+// set on the threads of getProbableTransformsSuper4PCSFrame: the call's quad sampling draws from a generator of its own
+static thread_local bool t_private_rand = false;
 
 ShimState& shim_state() {
   static thread_local ShimState st;
@@ -407,6 +411,113 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
              bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
 }
 
+// ---- the objects of one frame side by side --------------------------------------------------------------------------
+// The node matches the objects of a frame one after the other (SceneCfg.cpp:379-402 -> ObjectPoseCandidateSet.cpp:53-68); a
+// call is a chain of short device steps with the host in between (three round trips), so one object leaves most of the GPU
+// and most of the call's wall-clock unused.  Here every job runs on a thread the process keeps for it -- job k of a frame
+// always on worker k % 8, whose thread-local state holds the object's context, models and pair-feature table from the
+// frame before -- and the jobs' device work overlaps on their contexts' streams.  Same results as the jobs called one by one
+// (with a generator of the call's own for the quad sampling: PGP_SHIM_PRIVATE_RAND above).
+namespace {
+class FramePool {
+ public:
+  static const int kWorkers = 8;
+  std::mutex use_mu;   // one frame at a time
+  static FramePool* get() {
+    static FramePool* pool = make();
+    return pool;
+  }
+  void start(int k, std::function<void()> fn) {
+    Worker& w = workers_[k];
+    {
+      std::lock_guard<std::mutex> lk(w.mu);
+      w.job = std::move(fn);
+      w.has_job = true;
+      w.done = false;
+    }
+    w.cv.notify_all();
+  }
+  void wait(int k) {
+    Worker& w = workers_[k];
+    std::unique_lock<std::mutex> lk(w.mu);
+    w.cv.wait(lk, [&] { return w.done; });
+  }
+
+ private:
+  struct Worker {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool has_job = false, done = true;
+  };
+  Worker workers_[kWorkers];
+  static FramePool* make() {
+    FramePool* p = new FramePool;   // never destroyed: the workers sleep on their condition variables until the process ends
+    try {
+      for (int k = 0; k < kWorkers; ++k) std::thread([p, k] { p->loop(k); }).detach();
+    } catch (...) {
+      return nullptr;   // (workers already started sleep for good; the frame is then matched job by job on the caller's thread)
+    }
+    return p;
+  }
+  void loop(int k) {
+    Worker& w = workers_[k];
+    t_private_rand = true;
+    for (;;) {
+      std::function<void()> fn;
+      {
+        std::unique_lock<std::mutex> lk(w.mu);
+        w.cv.wait(lk, [&] { return w.has_job; });
+        fn.swap(w.job);
+        w.has_job = false;
+      }
+      fn();
+      {
+        std::lock_guard<std::mutex> lk(w.mu);
+        w.done = true;
+      }
+      w.cv.notify_all();
+    }
+  }
+};
+}  // namespace
+
+void getProbableTransformsSuper4PCSFrame(Super4PCSJob* jobs, int n_jobs) {
+  if (!jobs || n_jobs <= 0) return;
+  auto run = [jobs](int j) {
+    Super4PCSJob& q = jobs[j];
+    set_identity(q.bestHypothesis);
+    q.hypothesisSet.clear();
+    q.registered_points.clear();
+    q.failed = false;
+    if (!q.PPFMap) {
+      q.failed = true;
+      return;
+    }
+    try {
+      getProbableTransformsSuper4PCS(q.segment, q.model_validation, q.model_search, q.prob_image, q.rows, q.cols, q.bestHypothesis,
+                                     q.hypothesisSet, *q.PPFMap, q.camIntrinsic, q.registered_points);
+    } catch (...) {
+      q.failed = true;   // (what the single call would have thrown: bad_alloc; the other jobs of the frame are not lost)
+    }
+  };
+  FramePool* pool = n_jobs > 1 && !getenv("PGP_SHIM_FRAME_SERIAL") ? FramePool::get() : nullptr;
+  if (!pool) {
+    const bool before = t_private_rand;
+    t_private_rand = true;
+    for (int j = 0; j < n_jobs; ++j) run(j);
+    t_private_rand = before;
+    return;
+  }
+  std::lock_guard<std::mutex> frame(pool->use_mu);
+  const int used = n_jobs < FramePool::kWorkers ? n_jobs : FramePool::kWorkers;
+  for (int k = 0; k < used; ++k)
+    pool->start(k, [=] {
+      for (int j = k; j < n_jobs; j += FramePool::kWorkers) run(j);
+    });
+  for (int k = 0; k < used; ++k) pool->wait(k);
+}
+
 // `image` hands over the probability image when the weights are needed (the file entry point is still
 // decoding it on another thread while the clouds are uploaded and indexed)
 static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
@@ -581,9 +692,16 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   // the four uniform variates of an attempt's std::discrete_distribution draws come from this engine
   unsigned seed = (unsigned)std::chrono::system_clock::now().time_since_epoch().count();
   if (const char* s = getenv("PGP_SHIM_SEED")) { seed = (unsigned)strtoul(s, nullptr, 10); srand(seed); }
+  // rand() is one stream per PROCESS: calls that run side by side (getProbableTransformsSuper4PCSFrame) would interleave
+  // their draws, so each of them -- and a single call under PGP_SHIM_PRIVATE_RAND=1, their checker -- draws its quad
+  // samples from a generator of its own, seeded like the engine above
+  unsigned private_rand = seed;
+  const bool use_private_rand = t_private_rand || getenv("PGP_SHIM_PRIVATE_RAND") != nullptr;
+  auto next_rand = [&]() -> int { return use_private_rand ? rand_r(&private_rand) : rand(); };
   std::default_random_engine generator(seed);
   const int attempts_per_round = 256;   // (the variates are drawn in attempt order, so the round size does not change which bases are taken;
                                         //  256 workgroups are one wave of the 256 CUs and the reference's 100 bases come out of ONE round: 0.41 -> 0.2 ms)
+  int n_rounds = 0;
   std::vector<int> base_ids;       // n_bases x 4 (scene ids, TryQuadrilateral's order)
   std::vector<float> base_inv;     // n_bases x 2
   std::vector<int> base_rows;      // n_bases x 2: the table rows of pairs1 / pairs6 (they come home with the bases)
@@ -592,6 +710,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     std::vector<int> ids(4 * (size_t)attempts_per_round), status(attempts_per_round), rows(2 * (size_t)attempts_per_round);
     std::vector<float> inv(2 * (size_t)attempts_per_round);
     for (int round = 0; round < 20 && (int)(base_ids.size() / 4) < max_number_of_bases; ++round) {
+      ++n_rounds;
       for (double& x : u) x = std::generate_canonical<double, 53>(generator);
       SHIM_PGP(pgp_select_bases_rows(ctx, u.data(), attempts_per_round, ids.data(), inv.data(), status.data(), rows.data()));
       for (int k = 0; k < attempts_per_round && (int)(base_ids.size() / 4) < max_number_of_bases; ++k) {
@@ -632,7 +751,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
       const size_t nw = ((size_t)nq + 63) / 64;
       seen.assign(nw, 0ull);
       for (int n = 0; n < max_sampled_csets;) {
-        const unsigned v = (unsigned)(rand() % nq);
+        const unsigned v = (unsigned)(next_rand() % nq);
         unsigned long long& w = seen[v >> 6];
         const unsigned long long m = 1ull << (v & 63);
         n += (w & m) ? 0 : 1;
@@ -642,7 +761,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
         for (unsigned long long w = seen[k]; w; w &= w - 1) { picks.push_back(b); picks.push_back((int)(k * 64 + (size_t)__builtin_ctzll(w))); }
     } else {
       std::set<int> chosen;
-      while ((int)chosen.size() < max_sampled_csets) chosen.insert(rand() % nq);
+      while ((int)chosen.size() < max_sampled_csets) chosen.insert(next_rand() % nq);
       for (int j : chosen) { picks.push_back(b); picks.push_back(j); }
     }
   }
@@ -715,7 +834,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     if (verbose) {
       std::cerr << "[libsuper4pcs shim] PHASES";
       for (const auto& ph : phases) std::cerr << " " << ph.first << "=" << ph.second;
-      std::cerr << " n_h=" << n_h << std::endl;
+      std::cerr << " n_h=" << n_h << " rounds=" << n_rounds << " bases=" << n_bases << std::endl;
     }
     return;
   }
@@ -776,6 +895,6 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   if (verbose) {
     std::cerr << "[libsuper4pcs shim] PHASES";
     for (const auto& ph : phases) std::cerr << " " << ph.first << "=" << ph.second;
-    std::cerr << " n_h=" << n_h << std::endl;
+    std::cerr << " n_h=" << n_h << " rounds=" << n_rounds << " bases=" << n_bases << std::endl;
   }
 }

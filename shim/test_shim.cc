@@ -67,6 +67,69 @@ int main(int argc, char** argv) {
   // the list's scores, the registered points -- bit for bit (a soak for races between the calls' asynchronous parts)
   int n_same = std::getenv("SHIM_TEST_CHECK_SAME") ? 0 : -1;
   std::vector<double> first_sig;
+  // SHIM_TEST_FRAME=n: n objects of one frame (the same clouds, each object with a pair-feature table of its own) through
+  // getProbableTransformsSuper4PCSFrame, `repeat` frames; before them every object once through the single call (under
+  // PGP_SHIM_PRIVATE_RAND, set by the test): FRAME_SAME counts the jobs whose outputs equal that call's bit for bit
+  if (const char* fr = std::getenv("SHIM_TEST_FRAME")) {
+    const int n_obj = std::max(1, std::atoi(fr));
+    std::vector<float> sx, sn, vx, vn, qx, qn;
+    std::vector<unsigned short> px;
+    int rows = 0, cols = 0;
+    if (!super4pcs_shim_read_ply(argv[1], sx, sn) || !super4pcs_shim_read_ply(argv[2], vx, vn) || !super4pcs_shim_read_ply(argv[3], qx, qn)) return 3;
+    const bool have = super4pcs_shim_read_png16(argv[4], px, rows, cols);
+    const Super4PCSCloudView sv = {sx.data(), sn.data(), (int)(sx.size() / 3)};
+    const Super4PCSCloudView vv = {vx.data(), vn.data(), (int)(vx.size() / 3)};
+    const Super4PCSCloudView qv = {qx.data(), qn.data(), (int)(qx.size() / 3)};
+    auto signature = [](const std::pair<Eigen::Isometry3d, float>& b, const std::vector<std::pair<Eigen::Isometry3d, float> >& h,
+                        const std::vector<int>& reg) {
+      std::vector<double> sig;
+      sig.push_back(b.second);
+      for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c) sig.push_back(b.first.matrix()(r, c));
+      for (size_t i = 0; i < h.size(); ++i) sig.push_back(h[i].second);
+      sig.push_back((double)reg.size());
+      for (int v : reg) sig.push_back((double)v);
+      return sig;
+    };
+    getProbableTransformsSuper4PCS(sv, vv, qv, have ? px.data() : nullptr, rows, cols, best, hyps, PPFMap, K, registered);
+    const std::vector<double> want = signature(best, hyps, registered);
+    std::vector<std::map<std::vector<int>, std::vector<std::pair<int, int> > > > tables((size_t)n_obj, PPFMap);
+    std::vector<Super4PCSJob> jobs((size_t)n_obj);
+    for (int j = 0; j < n_obj; ++j) {
+      jobs[j].segment = sv;
+      jobs[j].model_validation = vv;
+      jobs[j].model_search = qv;
+      jobs[j].prob_image = have ? px.data() : nullptr;
+      jobs[j].rows = rows;
+      jobs[j].cols = cols;
+      jobs[j].PPFMap = std::getenv("SHIM_TEST_FRAME_SAME_TABLE") && j == 0 ? &PPFMap : &tables[j];   // (probe knob)
+      jobs[j].camIntrinsic = K;
+    }
+    int same = 0, total = 0;
+    const int gap_us = std::getenv("SHIM_TEST_FRAME_GAP_US") ? std::atoi(std::getenv("SHIM_TEST_FRAME_GAP_US")) : 0;
+    for (int rep = 0; rep < repeat; ++rep) {
+      if (gap_us > 0) {   // the node's own work between two frames, as a busy wait
+        const auto g0 = std::chrono::steady_clock::now();
+        while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count() < gap_us) {}
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      if (std::getenv("SHIM_TEST_FRAME_DIRECT"))   // (probe knob: the single call in this loop instead)
+        getProbableTransformsSuper4PCS(sv, vv, qv, jobs[0].prob_image, rows, cols, jobs[0].bestHypothesis, jobs[0].hypothesisSet, *jobs[0].PPFMap, K,
+                                       jobs[0].registered_points);
+      else
+      getProbableTransformsSuper4PCSFrame(jobs.data(), n_obj);
+      elapsed.push_back(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      for (int j = 0; j < n_obj; ++j, ++total) {
+        const std::vector<double> got = signature(jobs[j].bestHypothesis, jobs[j].hypothesisSet, jobs[j].registered_points);
+        if (!jobs[j].failed && got.size() == want.size() && std::memcmp(got.data(), want.data(), got.size() * sizeof(double)) == 0) ++same;
+      }
+    }
+    std::printf("FRAME_SAME %d of %d\n", same, total);
+    std::printf("FRAME_MS");
+    for (double e : elapsed) std::printf(" %.3f", e);
+    std::printf("\nBEST_SCORE %.9g\n", best.second);
+    return 0;
+  }
   for (int rep = 0; rep < repeat; ++rep) {
     std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMapCall = *maps[rep & 1];
     best.first.matrix().setIdentity();

@@ -16,7 +16,8 @@ PY
 mapfile -t ARGS < $OUT/args.txt
 rm -rf $OUT/trace
 cd /tmp && export TMPDIR=/tmp
-PGP_SHIM_SEED=12345 SHIM_TEST_REPEAT=50 SHIM_TEST_INMEMORY=1 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- $REPO/shim/test_shim "${ARGS[@]}" > $OUT/out.txt 2> $OUT/err.txt
+export PGP_SHIM_SEED=12345 SHIM_TEST_REPEAT=50 ${TIMELINE_ENV:-SHIM_TEST_INMEMORY=1}
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d $OUT/trace -- $REPO/shim/test_shim "${ARGS[@]}" > $OUT/out.txt 2> $OUT/err.txt
 python3 - "$OUT" <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
