@@ -635,6 +635,18 @@ def drop_in_row():
                          "min_ms": float(rest.min()), "p90_ms": float(np.percentile(rest, 90)),
                          "p99_ms": float(np.percentile(rest, 99)), "max_ms": float(rest.max()),
                          "phases": "profiles/r05_dropin_phases.txt (tools/dropin_phases.py)"}
+        # the node's object loop as ONE call (getProbableTransformsSuper4PCSFrame): three objects side by side against one by one
+        for name, extra in (("frame_of_3", {}), ("frame_of_3_one_by_one", {"PGP_SHIM_FRAME_SERIAL": "1"})):
+            env = dict(os.environ, PGP_SHIM_SEED="12345", PGP_SHIM_PRIVATE_RAND="1", SHIM_TEST_FRAME="3", SHIM_TEST_REPEAT="40", **extra)
+            r = subprocess.run([exe] + args, env=env, capture_output=True, text=True, timeout=600)
+            ms = [float(x) for l in r.stdout.splitlines() if l.startswith("FRAME_MS") for x in l.split()[1:]]
+            same = [l for l in r.stdout.splitlines() if l.startswith("FRAME_SAME")]
+            if r.returncode != 0 or len(ms) < 4:
+                out[name] = {"error": r.stderr[-300:]}
+                continue
+            rest = np.array(ms[2:])
+            out[name] = {"ms_per_frame": float(np.median(rest)), "p90_ms": float(np.percentile(rest, 90)), "frames": len(ms),
+                         "equal_to_single_calls": same[0] if same else None}
         return out
 
 
@@ -956,6 +968,7 @@ def compact_line(out):
             "cluster_ms": r3(get(o, "cluster", "ms_per_call")),
             "leaf_states_render_and_cost_ms": r3(get(o, "leaf_states_device", "render_and_cost_ms")),
             "drop_in_in_memory_ms_median_p99_first": [r3(get(o, "drop_in", "in_memory", k)) for k in ("drop_in_ms_per_object", "p99_ms", "first_call_ms")],
+            "drop_in_frame_of_3_ms_side_by_side_one_by_one": [r3(get(o, "drop_in", "frame_of_3", "ms_per_frame")), r3(get(o, "drop_in", "frame_of_3_one_by_one", "ms_per_frame"))],
             "drop_in_file_path_ms_median_p99_cvpng": [r3(get(o, "drop_in", "file_path", k)) for k in ("drop_in_ms_per_object", "p99_ms")]
                                                      + [r3(get(o, "drop_in", "file_path_cv_png", "drop_in_ms_per_object"))],
         }

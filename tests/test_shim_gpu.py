@@ -84,6 +84,23 @@ def test_drop_in_reads_the_probability_image_in_the_encoding_of_cv_imwrite(tmp_p
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
+@pytest.mark.parametrize("n_objects", [1, 3, 10])
+def test_objects_of_one_frame_side_by_side_equal_the_single_calls(tmp_path, n_objects):
+    """getProbableTransformsSuper4PCSFrame (the node's object loop, SceneCfg.cpp:379-402, as ONE call: every object on a
+    thread and a context of its own, device work overlapping): every job of every frame returns what the single call
+    returns -- best pose and score, the list's scores, the registered points, bit for bit -- for one object (the caller's
+    thread), three, and ten (more jobs than worker threads); the serial form of the same entry point too."""
+    argv, _ = make_dropin_case(tmp_path)
+    for extra in ({}, {"PGP_SHIM_FRAME_SERIAL": "1"}):
+        env = dict(os.environ, PGP_SHIM_SEED="777", PGP_SHIM_PRIVATE_RAND="1", SHIM_TEST_FRAME=str(n_objects), SHIM_TEST_REPEAT="6", **extra)
+        r = subprocess.run([BIN, *argv], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l and l[0].isupper()}
+        assert lines["FRAME_SAME"] == [str(6 * n_objects), "of", str(6 * n_objects)], r.stdout
+        assert float(lines["BEST_SCORE"][0]) > 0
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
 def test_drop_in_takes_the_reference_tie_rule_for_a_segment_with_duplicated_points(tmp_path):
     """A segment that holds duplicated points makes exact distance ties an every-query event; the drop-in notices
     (a hash of the coordinates) and switches pgp_set_exact_ties on for that object: same output as forcing it, and a
