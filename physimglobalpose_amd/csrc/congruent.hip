@@ -844,10 +844,25 @@ int cone_for_base(const float base[12], float* cone /*[56][3]*/) {
   const unsigned nb = (nbf == nbf && nbf > 0.f && nbf <= 56.f) ? (unsigned)nbf : 0u;
   const float angleStep = (float)((double)2.0f * M_PI / (double)(float)nb);
   const float sinAlpha = std::sin(alpha);
+  // cos / sin of the steps depend on nb alone (an even count up to 56): kept per thread -- a hundred bases were 6000 libm
+  // calls, most of the 27 us this host step took between two device phases of pgp_find_congruent_batch.  Same floats.
+  struct Steps {
+    bool have = false;
+    float c[56], s[56];
+  };
+  static thread_local Steps steps[57];
+  Steps& t = steps[nb];
+  if (!t.have) {
+    for (unsigned s = 0; s < nb; ++s) {
+      const float theta = (float)s * angleStep;
+      t.c[s] = std::cos(theta);
+      t.s[s] = std::sin(theta);
+    }
+    t.have = true;
+  }
   for (unsigned s = 0; s < nb; ++s) {
-    float theta = (float)s * angleStep;
-    cone[3 * s] = sinAlpha * std::cos(theta);
-    cone[3 * s + 1] = sinAlpha * std::sin(theta);
+    cone[3 * s] = sinAlpha * t.c[s];
+    cone[3 * s + 1] = sinAlpha * t.s[s];
     cone[3 * s + 2] = cosAlpha;
   }
   return (int)nb;
