@@ -297,7 +297,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
                        std::pair<Eigen::Isometry3d, float>& bestHypothesis,
                        std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
                        std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
-                       Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points);
+                       Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points, bool want_rows = true);
 
 void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std::string input3,
                                     std::pair<Eigen::Isometry3d, float>& bestHypothesis,
@@ -408,7 +408,7 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
                                     Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points) {
   match_impl(segment, model_validation, model_search,
              [&](int* r, int* c, int) -> const unsigned short* { *r = rows; *c = cols; return prob_image; },
-             bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
+             bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points, false);
 }
 
 // ---- the objects of one frame side by side --------------------------------------------------------------------------
@@ -526,7 +526,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
                        std::pair<Eigen::Isometry3d, float>& bestHypothesis,
                        std::vector<std::pair<Eigen::Isometry3d, float> >& hypothesisSet,
                        std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
-                       Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points) {
+                       Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points, bool want_rows) {
   const float delta = 0.005f;              // super4pcs_test.cc:20
   const int max_number_of_bases = 100;     // base.cc:290
   const int max_sampled_csets = 100;       // base.cc:1858
@@ -676,7 +676,8 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     // the last image row the segment's points fall on (whatever the image's size turns out to be): a decoder that
     // is still running stops there
     int row_lo = -1, row_hi = -1;
-    pgp_image_rows_needed(seg.xyz.data(), seg.n, cP, K, 1 << 24, 1 << 24, &row_lo, &row_hi);
+    if (want_rows)   // (only a decoder that is still running has a use for them: the file entry point)
+      pgp_image_rows_needed(seg.xyz.data(), seg.n, cP, K, 1 << 24, 1 << 24, &row_lo, &row_hi);
     const unsigned short* prob_image = image(&rows, &cols, row_hi);
     if (prob_image && rows > 0 && cols > 0) {
       std::vector<float> prob(seg.n, 1.f);
