@@ -800,7 +800,12 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   int* d_status = reinterpret_cast<int*>(base + A * 56);
   int2* d_rows = reinterpret_cast<int2*>(base + A * 60);
   float* d_cur = reinterpret_cast<float*>(base + ((A * 68 + 255) & ~(size_t)255));
-  PGP_HIP(hipMemcpyAsync(d_u, h_u, A * 32, hipMemcpyHostToDevice, st));
+  // the variates go up from the pinned area the results come home to (the call synchronises before it returns): a
+  // copy out of the caller's pageable array costs the host ~10 us whatever its size
+  HostOut out(ctx, st);
+  unsigned char* up = out.room(A * 32);
+  if (up) std::memcpy(up, h_u, A * 32);
+  PGP_HIP(hipMemcpyAsync(d_u, up ? (const void*)up : (const void*)h_u, A * 32, hipMemcpyHostToDevice, st));
   a.prob_cdf = ctx->d_prob_cdf.as<double>();
   a.u = d_u;
   a.cur = d_cur;
@@ -814,7 +819,6 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
     hipLaunchKernelGGL(select_bases<true>, dim3(n_attempts), dim3(kSelThreads), (size_t)a.n * 4, st, a);
   PGP_HIP(hipGetLastError());
   // ids | inv | status | rows lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
-  HostOut out(ctx, st);
   const unsigned char* got = nullptr;
   if ((rc = out.fetch(&got, d_ids, A * (h_rows ? 36 : 28))) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
   std::memcpy(h_ids, got, A * 16);

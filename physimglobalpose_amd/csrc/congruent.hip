@@ -983,10 +983,17 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   uint32_t* d_base_start = reinterpret_cast<uint32_t*>(sb + bb + cb);
   // bases and cones in ONE copy (a pageable copy costs the call ~10 us whatever its size); the staging vector lives until
   // the stream is synchronised below
-  std::vector<unsigned char> stage_h(bb + cb, 0);
-  std::memcpy(stage_h.data(), hb.data(), (size_t)nb * sizeof(BatchBase));
-  std::memcpy(stage_h.data() + bb, cones.data(), (size_t)nb * 168 * 4);
-  PGP_HIP(hipMemcpyAsync(d_bases, stage_h.data(), bb + cb, hipMemcpyHostToDevice, st));
+  // (in the context's pinned area when there is room: the pageable form costs the host ~10 us)
+  HostOut staging(ctx, st);
+  std::vector<unsigned char> stage_h;
+  unsigned char* stage_p = staging.room(bb + cb);
+  if (!stage_p) {
+    stage_h.assign(bb + cb, 0);
+    stage_p = stage_h.data();
+  }
+  std::memcpy(stage_p, hb.data(), (size_t)nb * sizeof(BatchBase));
+  std::memcpy(stage_p + bb, cones.data(), (size_t)nb * 168 * 4);
+  PGP_HIP(hipMemcpyAsync(d_bases, stage_p, bb + cb, hipMemcpyHostToDevice, st));
   int* head = ctx->d_cs_cnt.as<int>();
   int* next = head + nbk;
   uint32_t* qcnt = reinterpret_cast<uint32_t*>(next + tp);
