@@ -94,40 +94,97 @@ struct ObjectSlot {
   bool map_loaded = false;
   unsigned long long model_hash = 0, search_hash = 0;
   unsigned long long stamp = 0;
+  std::mutex busy;   // held by the call that is matching this object (ShimState::acquire .. SlotLease)
 };
+// The state is the PROCESS's, not a thread's (it was thread-local up to round 5): whichever thread brings an object finds
+// its context -- a ROS callback on another spinner thread, the std::thread per object the reference's authors left
+// commented out around this call (SceneCfg.cpp:377,402-403, ObjectPoseCandidateSet.cpp:64-65), a worker of
+// getProbableTransformsSuper4PCSFrame.  Calls for different objects run side by side; two calls for the SAME object take
+// turns (the second waits for the first's lease).  Never destroyed: the contexts go with the process (no HIP call from
+// an exit handler or a thread-local destructor, which the profiler's tooling does not survive).
 struct ShimState {
-  static constexpr int kSlots = 8;
+  static constexpr int kSlots = 16;
   ObjectSlot slot[kSlots];
+  std::mutex mu;                      // guards the slots' identity fields and the clock
+  std::mutex single_mu;               // held for the length of a call that uses `ctx` / `group` below
   unsigned long long clock = 0;
-  pgp_ctx* ctx = nullptr;             // PGP_SHIM_NO_CACHE / several devices: the single context of older rounds
+  pgp_ctx* ctx = nullptr;             // several devices: the single context of older rounds
   pgp_multi* group = nullptr;
   const void* map_addr = nullptr;
   size_t map_size = 0;
   unsigned long long map_print = 0;   // fingerprint of the map's two end entries
   const void* map_ctx = nullptr;      // the context the table was uploaded to
-  ObjectSlot* find(const void* addr, size_t size, unsigned long long print) {
-    ObjectSlot* lru = &slot[0];
-    for (ObjectSlot& o : slot) {
-      if (o.ctx && o.map_addr == addr && o.map_size == size && o.map_print == print) {
-        o.stamp = ++clock;
-        return &o;
+  // the object's slot, leased to the caller (slot->busy held): its own from an earlier call, or the least recently used
+  // one that nobody is using, re-keyed (its context keeps its allocations)
+  ObjectSlot* acquire(const void* addr, size_t size, unsigned long long print) {
+    for (;;) {
+      ObjectSlot* pick = nullptr;
+      bool mine = false;
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        for (ObjectSlot& o : slot)
+          if (o.map_addr == addr && o.map_size == size && o.map_print == print && (o.ctx || o.stamp)) {
+            pick = &o;
+            mine = true;
+            break;
+          }
+        if (!pick) {
+          ObjectSlot* lru = nullptr;
+          for (ObjectSlot& o : slot) {
+            if (!o.busy.try_lock()) continue;
+            if (!lru || o.stamp < lru->stamp) {
+              if (lru) lru->busy.unlock();
+              lru = &o;
+            } else {
+              o.busy.unlock();
+            }
+          }
+          if (lru) {
+            lru->map_addr = addr;
+            lru->map_size = size;
+            lru->map_print = print;
+            lru->map_loaded = false;
+            lru->model_hash = lru->search_hash = 0;
+            lru->stamp = ++clock;
+            return lru;
+          }
+          pick = &slot[0];   // every slot is in use: wait for the least recently used one
+          for (ObjectSlot& o : slot)
+            if (o.stamp < pick->stamp) pick = &o;
+        }
       }
-      if (o.stamp < lru->stamp) lru = &o;
+      pick->busy.lock();
+      {
+        std::lock_guard<std::mutex> lk(mu);
+        const bool still = pick->map_addr == addr && pick->map_size == size && pick->map_print == print;
+        if (mine && still) {
+          pick->stamp = ++clock;
+          return pick;
+        }
+        if (!mine) {   // waited for a victim: it is free now, take it over
+          pick->map_addr = addr;
+          pick->map_size = size;
+          pick->map_print = print;
+          pick->map_loaded = false;
+          pick->model_hash = pick->search_hash = 0;
+          pick->stamp = ++clock;
+          return pick;
+        }
+      }
+      pick->busy.unlock();   // the object's slot was given away while this call waited for it: look again
     }
-    // the least recently used slot is re-used for the new object (its context keeps its allocations)
-    lru->map_addr = addr;
-    lru->map_size = size;
-    lru->map_print = print;
-    lru->map_loaded = false;
-    lru->model_hash = lru->search_hash = 0;
-    lru->stamp = ++clock;
-    return lru;
   }
-  ~ShimState() {
+  ~ShimState() {   // (only a call's own state under PGP_SHIM_NO_CACHE is ever destroyed)
     if (group) pgp_multi_destroy(group);
     if (ctx) pgp_destroy(ctx);
     for (ObjectSlot& o : slot)
       if (o.ctx) pgp_destroy(o.ctx);
+  }
+};
+struct SlotLease {
+  ObjectSlot* s = nullptr;
+  ~SlotLease() {
+    if (s) s->busy.unlock();
   }
 };
 static unsigned long long cloud_hash(const std::vector<float>& a, const std::vector<float>& b) {
@@ -143,8 +200,8 @@ static unsigned long long cloud_hash(const std::vector<float>& a, const std::vec
 static thread_local bool t_private_rand = false;
 
 ShimState& shim_state() {
-  static thread_local ShimState st;
-  return st;
+  static ShimState* st = new ShimState;   // (never destroyed: see above)
+  return *st;
 }
 
 int shim_device_count() {   // PGP_SHIM_DEVICES: 1 (default), a number, or "all"
@@ -414,9 +471,9 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
 // ---- the objects of one frame side by side --------------------------------------------------------------------------
 // The node matches the objects of a frame one after the other (SceneCfg.cpp:379-402 -> ObjectPoseCandidateSet.cpp:53-68); a
 // call is a chain of short device steps with the host in between (three round trips), so one object leaves most of the GPU
-// and most of the call's wall-clock unused.  Here every job runs on a thread the process keeps for it -- job k of a frame
-// always on worker k % 8, whose thread-local state holds the object's context, models and pair-feature table from the
-// frame before -- and the jobs' device work overlaps on their contexts' streams.  Same results as the jobs called one by one
+// and most of the call's wall-clock unused.  Here every job runs on a thread the process keeps (job k on worker k % 8), finds
+// its object's context, models and pair-feature table from the frame before in the process's state (ShimState: one slot per
+// object), and the jobs' device work overlaps on their contexts' streams.  Same results as the jobs called one by one
 // (with a generator of the call's own for the quad sampling: PGP_SHIM_PRIVATE_RAND above).
 namespace {
 class FramePool {
@@ -569,6 +626,8 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   ShimState local_state;
   ShimState& st = getenv("PGP_SHIM_NO_CACHE") ? local_state : shim_state();
   ObjectSlot* obj = nullptr;
+  SlotLease lease;                                   // the object's slot is this call's until it returns
+  std::unique_lock<std::mutex> single_lock;          // (the device group / single context of the modes that have one)
   // fingerprint of the caller's PPFMap (its two end entries): with its address and size, what an object is known by
   unsigned long long print = 0x9E3779B97F4A7C15ull;
   if (!PPFMap.empty()) {
@@ -595,6 +654,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   if (n_dev != 1) {
     // hypotheses sharded over the devices of the node (pgp_multi_*: RCCL all-reduce of the scores);
     // device 0's context of the group also serves the single-device steps
+    if (&st != &local_state) single_lock = std::unique_lock<std::mutex>(st.single_mu);
     if (!st.group) SHIM_PGP(pgp_multi_create(&st.group, nullptr, n_dev));
     ctx = pgp_multi_context(st.group, 0);
     for (int d = 0; pgp_multi_context(st.group, d); ++d) SHIM_PGP(pgp_set_exact_ties(pgp_multi_context(st.group, d), exact_ties ? 1 : 0));
@@ -611,7 +671,8 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     mark("set_model");
   } else {
     // the object's own context: models and pair-feature table stay resident in it
-    obj = st.find((const void*)&PPFMap, PPFMap.size(), print);
+    obj = st.acquire((const void*)&PPFMap, PPFMap.size(), print);
+    lease.s = obj;
     if (!obj->ctx) SHIM_PGP(pgp_create(&obj->ctx, -1));
     ctx = obj->ctx;
     SHIM_PGP(pgp_set_exact_ties(ctx, exact_ties ? 1 : 0));

@@ -33,9 +33,9 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
                                     std::map<std::vector<int>, std::vector<std::pair<int, int> > >& PPFMap,
                                     Eigen::Matrix3f camIntrinsic, std::vector<int>& registered_points);
 
-// The objects of ONE frame side by side (the node matches them one after the other, SceneCfg.cpp:379-402): job k runs on a
-// thread the library keeps for it, so the object's context, models and pair-feature table stay resident from frame to frame,
-// and the jobs' device work overlaps.  Inputs and outputs of a job are those of the overload above; `failed` is set where the
+// The objects of ONE frame side by side (the node matches them one after the other, SceneCfg.cpp:379-402): the jobs run on
+// threads the library keeps, each object's context, models and pair-feature table stay resident from frame to frame (as they
+// do for the single calls, from whichever thread those come), and the jobs' device work overlaps.  Inputs and outputs of a job are those of the overload above; `failed` is set where the
 // single call would have thrown (the other jobs of the frame still complete).  Results equal the jobs called one by one,
 // except that each call samples its quads from a generator of its own instead of the process-wide rand() (with
 // PGP_SHIM_SEED fixed: the single calls under PGP_SHIM_PRIVATE_RAND=1, bit for bit).  PGP_SHIM_FRAME_SERIAL=1: job by job.

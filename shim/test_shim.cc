@@ -11,6 +11,7 @@
 #include <iostream>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <Eigen/Core>
@@ -101,6 +102,7 @@ int main(int argc, char** argv) {
       jobs[j].rows = rows;
       jobs[j].cols = cols;
       jobs[j].PPFMap = std::getenv("SHIM_TEST_FRAME_SAME_TABLE") && j == 0 ? &PPFMap : &tables[j];   // (probe knob)
+      if (std::getenv("SHIM_TEST_FRAME_ONE_OBJECT")) jobs[j].PPFMap = &tables[0];   // every job the SAME object: the calls take turns
       jobs[j].camIntrinsic = K;
     }
     // (the single call they are compared with runs AFTER the frames: its context and streams would otherwise sit beside the
@@ -114,7 +116,17 @@ int main(int argc, char** argv) {
         while (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g0).count() < gap_us) {}
       }
       const auto t0 = std::chrono::steady_clock::now();
-      if (std::getenv("SHIM_TEST_FRAME_DIRECT"))   // (probe knob: the single call in this loop instead)
+      if (std::getenv("SHIM_TEST_FRAME_THREADS")) {
+        // the reference's own commented-out form (SceneCfg.cpp:377,402-403): a fresh std::thread per object around the single
+        // call, joined at the end of the loop -- the objects' contexts are the process's, so the new threads find them
+        std::vector<std::thread> th;
+        for (int j = 0; j < n_obj; ++j)
+          th.emplace_back([&, j] {
+            getProbableTransformsSuper4PCS(sv, vv, qv, jobs[j].prob_image, rows, cols, jobs[j].bestHypothesis, jobs[j].hypothesisSet, *jobs[j].PPFMap, K,
+                                           jobs[j].registered_points);
+          });
+        for (std::thread& t : th) t.join();
+      } else if (std::getenv("SHIM_TEST_FRAME_DIRECT"))   // (probe knob: the single call in this loop instead)
         getProbableTransformsSuper4PCS(sv, vv, qv, jobs[0].prob_image, rows, cols, jobs[0].bestHypothesis, jobs[0].hypothesisSet, *jobs[0].PPFMap, K,
                                        jobs[0].registered_points);
       else

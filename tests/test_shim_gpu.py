@@ -101,6 +101,24 @@ def test_objects_of_one_frame_side_by_side_equal_the_single_calls(tmp_path, n_ob
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
+@pytest.mark.parametrize("extra", [{"SHIM_TEST_FRAME_THREADS": "1"}, {"SHIM_TEST_FRAME_THREADS": "1", "SHIM_TEST_FRAME_ONE_OBJECT": "1"},
+                                   {"SHIM_TEST_FRAME_ONE_OBJECT": "1"}])
+def test_single_calls_from_fresh_threads_find_their_objects(tmp_path, extra):
+    """The drop-in's state belongs to the process: a fresh std::thread per object around the single call -- the form the
+    reference's authors left commented out at SceneCfg.cpp:377,402-403 -- finds each object's context and table from the
+    frame before (no 13 ms re-upload per call) and returns the single call's result; calls for ONE object from several
+    threads (or several jobs of one frame) take turns on its context, same result."""
+    argv, _ = make_dropin_case(tmp_path)
+    env = dict(os.environ, PGP_SHIM_SEED="4321", PGP_SHIM_PRIVATE_RAND="1", SHIM_TEST_FRAME="4", SHIM_TEST_REPEAT="8", **extra)
+    r = subprocess.run([BIN, *argv], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = {l.split()[0]: l.split()[1:] for l in r.stdout.splitlines() if l and l[0].isupper()}
+    assert lines["FRAME_SAME"] == ["32", "of", "32"], r.stdout
+    ms = [float(x) for x in lines["FRAME_MS"]]
+    assert np.median(ms[2:]) < 8.0, ms          # four objects per frame: nowhere near a table upload (13 ms) per call
+
+
+@pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
 def test_drop_in_takes_the_reference_tie_rule_for_a_segment_with_duplicated_points(tmp_path):
     """A segment that holds duplicated points makes exact distance ties an every-query event; the drop-in notices
     (a hash of the coordinates) and switches pgp_set_exact_ties on for that object: same output as forcing it, and a
