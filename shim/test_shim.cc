@@ -122,8 +122,12 @@ int main(int argc, char** argv) {
         std::vector<std::thread> th;
         for (int j = 0; j < n_obj; ++j)
           th.emplace_back([&, j] {
-            getProbableTransformsSuper4PCS(sv, vv, qv, jobs[j].prob_image, rows, cols, jobs[j].bestHypothesis, jobs[j].hypothesisSet, *jobs[j].PPFMap, K,
-                                           jobs[j].registered_points);
+            if (!std::strcmp(std::getenv("SHIM_TEST_FRAME_THREADS"), "files"))   // through the files, exactly the reference's signature
+              getProbableTransformsSuper4PCS(argv[1], argv[2], argv[3], jobs[j].bestHypothesis, jobs[j].hypothesisSet, argv[4], *jobs[j].PPFMap, 0, K,
+                                             "synthetic_object", "./", jobs[j].registered_points);
+            else
+              getProbableTransformsSuper4PCS(sv, vv, qv, jobs[j].prob_image, rows, cols, jobs[j].bestHypothesis, jobs[j].hypothesisSet, *jobs[j].PPFMap, K,
+                                             jobs[j].registered_points);
           });
         for (std::thread& t : th) t.join();
       } else if (std::getenv("SHIM_TEST_FRAME_DIRECT"))   // (probe knob: the single call in this loop instead)

@@ -101,7 +101,8 @@ def test_objects_of_one_frame_side_by_side_equal_the_single_calls(tmp_path, n_ob
 
 
 @pytest.mark.skipif(not os.path.exists(BIN), reason="shim/test_shim not built (needs Eigen: make -C shim)")
-@pytest.mark.parametrize("extra", [{"SHIM_TEST_FRAME_THREADS": "1"}, {"SHIM_TEST_FRAME_THREADS": "1", "SHIM_TEST_FRAME_ONE_OBJECT": "1"},
+@pytest.mark.parametrize("extra", [{"SHIM_TEST_FRAME_THREADS": "1"}, {"SHIM_TEST_FRAME_THREADS": "files"},
+                                   {"SHIM_TEST_FRAME_THREADS": "1", "SHIM_TEST_FRAME_ONE_OBJECT": "1"},
                                    {"SHIM_TEST_FRAME_ONE_OBJECT": "1"}])
 def test_single_calls_from_fresh_threads_find_their_objects(tmp_path, extra):
     """The drop-in's state belongs to the process: a fresh std::thread per object around the single call -- the form the
