@@ -20,3 +20,10 @@ for MODE in "SHIM_TEST_INMEMORY=1" "SHIM_TEST_INMEMORY=1 SHIM_TEST_TWO_OBJECTS=1
   echo "== $MODE, $N calls"
   env $MODE SHIM_TEST_CHECK_SAME=1 PGP_SHIM_SEED=12345 SHIM_TEST_REPEAT=$N $REPO/shim/test_shim "${ARGS[@]}" 2>/dev/null | grep "SAME_AS_FIRST\|BEST_SCORE"
 done
+# frames of three objects, side by side: through the frame entry point, through a fresh thread per object around the single call
+# (in memory and through the files), and every job of a frame the SAME object (the calls take turns on its context)
+for MODE in "SHIM_TEST_FRAME=3" "SHIM_TEST_FRAME=3 SHIM_TEST_FRAME_THREADS=1" "SHIM_TEST_FRAME=3 SHIM_TEST_FRAME_THREADS=files" "SHIM_TEST_FRAME=4 SHIM_TEST_FRAME_ONE_OBJECT=1"; do
+  M=$((N / 4))
+  echo "== $MODE, $M frames"
+  env $MODE PGP_SHIM_PRIVATE_RAND=1 PGP_SHIM_SEED=12345 SHIM_TEST_REPEAT=$M $REPO/shim/test_shim "${ARGS[@]}" 2>/dev/null | grep "FRAME_SAME\|BEST_SCORE"
+done
