@@ -383,8 +383,10 @@ __device__ void try_quadrilateral(const float4* __restrict__ P, int ids[4], floa
 // kSelLdsPoints: an attempt's stage weights live in LDS up to this many points (the sequential sums are one wave's 64-wide
 // trips over them, each waiting for its load: from memory that wait, not the chain of additions, was most of a stage)
 constexpr int kSelLdsPoints = 12288;
+// (8 waves per SIMD asked for: 106 scalar registers had capped the kernel at 7, one workgroup of 1024 threads per CU; with
+//  78 two fit, so the base selections of two objects of a frame can share the compute units -- neutral for a single call)
 template <bool LDS>
-__global__ __launch_bounds__(kSelThreads) void select_bases(SelectArgs a) {
+__global__ __launch_bounds__(kSelThreads, 8) void select_bases(SelectArgs a) {
   extern __shared__ float s_cur[];
   __shared__ double s_part[257];
   __shared__ int s_pick;
