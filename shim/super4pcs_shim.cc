@@ -452,8 +452,12 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
     *c = cols;
     return have ? px.data() : nullptr;
   };
+  const double ms_parsed = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_files).count();
   match_impl(vs, vq, vqs, image, bestHypothesis, hypothesisSet, PPFMap, camIntrinsic, registered_points);
   if (t4.joinable()) t4.join();
+  if (getenv("PGP_SHIM_VERBOSE"))
+    std::cerr << "[libsuper4pcs shim] file hand-off: clouds parsed " << ms_parsed << " ms after the call, matched "
+              << std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_files).count() << std::endl;
 }
 
 void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Super4PCSCloudView& model_validation,
