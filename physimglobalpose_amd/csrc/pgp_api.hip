@@ -1841,8 +1841,8 @@ int pgp_backproject_depth(pgp_ctx* ctx, const void* image, int raw16, const unsi
   *n_out = total;
   const int n_copy = total < cap ? total : cap;
   if (n_copy > 0) {
-    PGP_HIP(hipMemcpyAsync(xyz_out, d_xyz, (size_t)n_copy * 12, hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipStreamSynchronize(st));
+    HostOut out(ctx, st);
+    if ((rc = out.to(xyz_out, d_xyz, (size_t)n_copy * 12)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
   }
   return PGP_OK;
 }
@@ -1891,8 +1891,8 @@ int pgp_voxel_grid(pgp_ctx* ctx, const float* xyz, int n, float leaf, float* out
   if (rc != PGP_OK) return rc;
   const int n_copy = *n_out < cap ? *n_out : cap;
   if (n_copy > 0) {
-    PGP_HIP(hipMemcpyAsync(out_xyz, d_out, (size_t)n_copy * 12, hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipStreamSynchronize(st));
+    HostOut out(ctx, st);
+    if ((rc = out.to(out_xyz, d_out, (size_t)n_copy * 12)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
   }
   return PGP_OK;
 }
@@ -1938,11 +1938,14 @@ int pgp_mls_normals(pgp_ctx* ctx, const float* xyz, int n, float radius, float* 
   if (rc != PGP_OK) return rc;
   const size_t m = (size_t)(*n_out < cap ? *n_out : cap);
   if (m > 0) {
-    PGP_HIP(hipMemcpyAsync(out_xyz, d_x, m * 12, hipMemcpyDeviceToHost, st));
-    if (out_nrm) PGP_HIP(hipMemcpyAsync(out_nrm, d_n, m * 12, hipMemcpyDeviceToHost, st));
-    if (out_curvature) PGP_HIP(hipMemcpyAsync(out_curvature, d_c, m * 4, hipMemcpyDeviceToHost, st));
-    if (out_index) PGP_HIP(hipMemcpyAsync(out_index, d_i, m * 4, hipMemcpyDeviceToHost, st));
-    PGP_HIP(hipStreamSynchronize(st));
+    // through the context's pinned landing area, one wait for all four (a copy into the caller's pageable array is a
+    // synchronisation of its own: four of them were 160 us of a 0.52 ms call, tools/call_timeline.sh mls)
+    HostOut out(ctx, st);
+    if ((rc = out.to(out_xyz, d_x, m * 12)) != PGP_OK) return rc;
+    if (out_nrm && (rc = out.to(out_nrm, d_n, m * 12)) != PGP_OK) return rc;
+    if (out_curvature && (rc = out.to(out_curvature, d_c, m * 4)) != PGP_OK) return rc;
+    if (out_index && (rc = out.to(out_index, d_i, m * 4)) != PGP_OK) return rc;
+    if ((rc = out.sync()) != PGP_OK) return rc;
   }
   return PGP_OK;
 }
