@@ -933,11 +933,15 @@ int pgp_rigid_from_congruent(pgp_ctx* ctx, const int* base_ids, const int* quad_
   PGP_HIP(hipMemcpyAsync(d_q, quad_ids, N * 16, hipMemcpyHostToDevice, st));
   rc = launch_rigid(ctx, d_b, d_q, n, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms, st);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(T, d_T, N * 64, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(status, d_status, N * 4, hipMemcpyDeviceToHost, st));
-  if (pose) PGP_HIP(hipMemcpyAsync(pose, d_pose, N * 128, hipMemcpyDeviceToHost, st));
-  if (rms) PGP_HIP(hipMemcpyAsync(rms, d_rms, N * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  {
+    // (through the pinned landing area where there is room, one wait for all: pgp::HostOut)
+    HostOut out(ctx, st);
+    int rc_out;
+    if ((rc_out = out.to(status, d_status, N * 4)) != PGP_OK || (rms && (rc_out = out.to(rms, d_rms, N * 4)) != PGP_OK) ||
+        (rc_out = out.to(T, d_T, N * 64)) != PGP_OK || (pose && (rc_out = out.to(pose, d_pose, N * 128)) != PGP_OK) ||
+        (rc_out = out.sync()) != PGP_OK)
+      return rc_out;
+  }
   return PGP_OK;
 }
 
@@ -1063,11 +1067,15 @@ int pgp_congruent_batch_fit(pgp_ctx* ctx, const int* picks, const int* base_ids,
   int* d_status = reinterpret_cast<int*>(d_rms + N);
   rc = launch_rigid(ctx, d_b, d_q, m, centroid_P, centroid_Q, d_T, d_pose, d_status, d_rms, st);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(T, d_T, N * 64, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(status, d_status, N * 4, hipMemcpyDeviceToHost, st));
-  if (pose) PGP_HIP(hipMemcpyAsync(pose, d_pose, N * 128, hipMemcpyDeviceToHost, st));
-  if (rms) PGP_HIP(hipMemcpyAsync(rms, d_rms, N * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));   // also: hb is a stack-owned staging vector
+  {
+    // (through the pinned landing area where there is room, one wait for all: pgp::HostOut)
+    HostOut out(ctx, st);
+    int rc_out;
+    if ((rc_out = out.to(status, d_status, N * 4)) != PGP_OK || (rms && (rc_out = out.to(rms, d_rms, N * 4)) != PGP_OK) ||
+        (rc_out = out.to(T, d_T, N * 64)) != PGP_OK || (pose && (rc_out = out.to(pose, d_pose, N * 128)) != PGP_OK) ||
+        (rc_out = out.sync()) != PGP_OK)
+      return rc_out;
+  }   // also: hb is a stack-owned staging vector
   return PGP_OK;
 }
 
@@ -1977,9 +1985,13 @@ int pgp_pose_hausdorff(pgp_ctx* ctx, const float* hull_xyz, int n_hull, const fl
   PGP_HIP(hipMemcpyAsync(d_p, pairs, (size_t)m * 8, hipMemcpyHostToDevice, st));
   rc = launch_pose_hausdorff(ctx, d_h, n_hull, d_T, n_poses, d_p, m, d_mx, d_sm, st);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(dist_max, d_mx, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-  if (dist_sum) PGP_HIP(hipMemcpyAsync(dist_sum, d_sm, (size_t)m * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));   // also: hh is a stack-owned staging vector
+  {
+    HostOut out(ctx, st);
+    int rc_out;
+    if ((rc_out = out.to(dist_max, d_mx, (size_t)m * 4)) != PGP_OK || (dist_sum && (rc_out = out.to(dist_sum, d_sm, (size_t)m * 4)) != PGP_OK) ||
+        (rc_out = out.sync()) != PGP_OK)   // (the wait also covers hh, a stack-owned staging vector)
+      return rc_out;
+  }
   return PGP_OK;
 }
 
@@ -2177,9 +2189,13 @@ int pgp_pose_error(pgp_ctx* ctx, const float* test, const float* gt, int n, cons
   PGP_HIP(hipMemcpyAsync(d_g, gt, nT, hipMemcpyHostToDevice, st));
   rc = launch_pose_error(ctx, d_a, d_g, n, sym_deg, d_r, d_t, st);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(rot_err_deg, d_r, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipMemcpyAsync(trans_err, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  {
+    HostOut out(ctx, st);
+    int rc_out;
+    if ((rc_out = out.to(rot_err_deg, d_r, (size_t)n * 4)) != PGP_OK || (rc_out = out.to(trans_err, d_t, (size_t)n * 4)) != PGP_OK ||
+        (rc_out = out.sync()) != PGP_OK)
+      return rc_out;
+  }
   return PGP_OK;
 }
 
