@@ -5,16 +5,27 @@ A "step" = one pass of the hot path over one batch: every rank LCP-scores its sh
 (C2: 4096 per GPU, 5 000-pt model vs 50 000-pt scene) with the clouds, the index and the transforms
 already resident in HBM; the timed loop rotates through 8 DISTINCT hypothesis batches.  Default mode
 is WEIGHTED LCP = the reference's live verifier (operMode 1 -> WeightedVerify, base.cc:300,1733-1766);
-`--mode plain` (Verify without early-out) is reported under other_rows.  With N > 1 ranks the
-per-hypothesis scores are combined with RCCL all-reduces (physimglobalpose_amd.sharding.
-BucketedExchange: the class a streaming caller uses) and arg-maxed; `per_call` then reports the
-UNBUCKETED form next to it -- one all-reduce + arg-max + host sync per batch, the latency a caller
-that needs each batch's scores before it proceeds (HypothesisSelection.cpp:248-257) would see.
-value = hypotheses all ranks scored / max-over-ranks wall time.
+`--mode plain` (Verify without early-out) is reported under other_rows.
+
+N > 1 is measured through the PRODUCT's device group behind the C ABI (pgp_multi_*, csrc/multi_gpu.hip: the slices, ONE
+ncclAllReduce per step issued from C++ on a second stream under the next step's scoring, member 0's arg-max with the near-tie
+settlement), whichever way the run is launched:
+  * `python bench.py --gpus N` (no launcher): this process touches no GPU; a CHILD process runs one single-process group
+    over N devices (ncclCommInitAll: the form a C++ node links, SceneCfg.cpp:376-406) and a second child runs the
+    torch.distributed form below as `rows.torch_twin`;
+  * `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (the driver's form): every rank holds one
+    member of a group that spans the processes (pgp_multi_create_ranked: ncclCommInitRank with an id passed through the
+    launcher's store); torch.distributed only carries the id, the barriers and the max over ranks.
+`per_call` reports the SYNCHRONOUS form next to it -- one call, host pointers in, scores out, the latency a caller that needs
+each batch's scores before it proceeds (HypothesisSelection.cpp:248-257) sees.  `rccl_ranks` is ncclCommCount of the
+communicator the exchange ran on.  The Python twin of the exchange (physimglobalpose_amd.sharding.BucketedExchange over
+torch.distributed) stays as the secondary row `rows.torch_twin`.  value = hypotheses all ranks scored / max-over-ranks wall time.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--mode weighted|plain]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    PGP_MULTI_EMULATE=2 python bench.py --gpus 2 --steps 6     # N logical members on ONE device: a smoke run of the
+                                                               # N > 1 code, `emulated: true`, never a performance figure
 
 Prints ONE JSON line on rank 0: metric/value/unit/... plus "roofline" (dominant kernel: its live
 HIP-event duration against the units that can bind it -- vector L1, VALU issue, HBM -- with the
@@ -666,6 +677,298 @@ def native_multi_row(n_dev, mode_name, steps):
         return {"error": repr(e)}
 
 
+def _quantiles_ms(ts):
+    a = np.sort(np.asarray(ts)) * 1e3
+    return {"median_ms": float(a[len(a) // 2]), "p99_ms": float(a[min(len(a) - 1, int(np.ceil(0.99 * len(a))) - 1)]),
+            "min_ms": float(a[0]), "calls": int(len(a))}
+
+
+def per_call_one_device(sc, w, torch, mode, d_batches, calls=200):
+    """SURVEY 8(d)'s metric as a caller meets it: the wall time of ONE synchronous call, clouds resident.  `host_pointers` =
+    pgp_score_lcp (transforms in the caller's memory, scores / counts / best back in it: what base.cc:1885-1901's consumer
+    gets); `device_pointers` = pgp_score_lcp_device + a stream synchronisation (transforms and results stay in HBM).  Median
+    and p99 of `calls` calls timed one by one, 8 distinct batches in rotation, at the bench's 4096 hypotheses and at 3000 (the
+    size of a list the reference's own generator produces, base.cc:290,1858)."""
+    out = {}
+    ds = torch.zeros(N_HYP, device="cuda")
+    dc = torch.zeros(N_HYP, dtype=torch.int32, device="cuda")
+    db = torch.zeros(2, dtype=torch.int32, device="cuda")
+    T_host = w.T.reshape(-1, N_HYP, 16)
+    gc.collect()
+    gc.disable()
+    try:
+        for n in (N_HYP, 3000):
+            hs, dv = [], []
+            for k in range(calls + 20):
+                T = T_host[k % len(T_host)][:n]
+                t0 = time.perf_counter()
+                sc.score(T, mode, w.gate_deg)
+                if k >= 20:
+                    hs.append(time.perf_counter() - t0)
+            for k in range(calls + 20):
+                dT = d_batches[k % len(d_batches)][:n]
+                t0 = time.perf_counter()
+                sc.score_device(dT, ds[:n], dc[:n], db, mode=mode, gate_deg=w.gate_deg)
+                torch.cuda.synchronize()
+                if k >= 20:
+                    dv.append(time.perf_counter() - t0)
+            h, d = _quantiles_ms(hs), _quantiles_ms(dv)
+            out[str(n)] = {"host_pointers": dict(h, hypotheses_per_s=n / (h["median_ms"] * 1e-3)),
+                           "device_pointers": dict(d, hypotheses_per_s=n / (d["median_ms"] * 1e-3))}
+    finally:
+        gc.enable()
+    out["form"] = ("one synchronous call, timed one by one: host_pointers = pgp_score_lcp; device_pointers = "
+                   "pgp_score_lcp_device + stream synchronisation")
+    return out
+
+
+def group_headline(grp, args, w, mode, mode_name, n_h, world, barrier, max_over_ranks, check_device, torch=None):
+    """The headline through the product's own device group (pgp_multi_*): N_BATCH resident batches of world * n_h
+    hypotheses, K steps queued back to back (pgp_multi_enqueue_slot: no host wait per step), ONE pgp_multi_collect at the end;
+    then the synchronous per-call forms.  The same function serves the single-process group (barrier = no-op) and the ranked
+    group under a launcher (barrier / max over ranks through torch.distributed)."""
+    from physimglobalpose_amd import LcpScorer
+    batches = w.T.reshape(N_BATCH, world * n_h, 16)
+    t0 = time.perf_counter()
+    grp.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    cold_ms = (time.perf_counter() - t0) * 1e3
+    for b in range(N_BATCH):
+        grp.upload_slot(b, batches[b])
+    info = grp.info()
+    emulated = bool(info["emulated"])
+    m0 = grp.member(0)
+    state = {"k": 0}
+
+    def step():
+        grp.enqueue_slot(state["k"] % N_BATCH, mode, w.gate_deg)
+        state["k"] += 1
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    grp.collect()
+    gc.collect()
+    gc.disable()
+    # pre-heat as the one-device headline does: chunks of 64 steps until two in a row agree within 3 %, a second at most
+    t_heat, chunk_prev = time.perf_counter(), None
+    while not emulated:
+        tc = time.perf_counter()
+        for _ in range(64):
+            step()
+        grp.collect()
+        chunk, heated = time.perf_counter() - tc, time.perf_counter() - t_heat
+        if heated >= 1.0 or (heated >= 0.15 and chunk_prev is not None and abs(chunk - chunk_prev) <= 0.03 * chunk_prev):
+            break
+        chunk_prev = chunk
+    m0.set_kernel_timing(TIMING_STRIDE)
+    m0.kernel_timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    t_issue = time.perf_counter() - t0
+    last = grp.collect()            # every step's exchange and arg-max complete inside the timed region
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
+    launches, kern_ms = m0.kernel_timing(reset=True)
+    m0.set_kernel_timing(False)
+    lb = (state["k"] - 1) % N_BATCH
+    # ---- the synchronous forms, call by call (every rank makes the same calls: the collective needs them all)
+    k_pc = max(40, min(args.steps, 200)) if not emulated else 6
+    hs, rs = [], []
+    gc.disable()
+    for k in range(k_pc + 4):
+        barrier()
+        t1 = time.perf_counter()
+        got = grp.score(batches[k % N_BATCH], mode, w.gate_deg)
+        if k >= 4:
+            hs.append(max_over_ranks(time.perf_counter() - t1) if world > info["n_local"] else time.perf_counter() - t1)
+    grp.upload(batches[0])
+    for k in range(k_pc + 4):
+        barrier()
+        t1 = time.perf_counter()
+        got0 = grp.score_uploaded(mode, w.gate_deg)
+        if k >= 4:
+            rs.append(max_over_ranks(time.perf_counter() - t1) if world > info["n_local"] else time.perf_counter() - t1)
+    gc.enable()
+    h, r = _quantiles_ms(hs), _quantiles_ms(rs)
+    N = world * n_h
+    per_call = {"host_pointers": dict(h, hypotheses_per_s=N / (h["median_ms"] * 1e-3)),
+                "resident": dict(r, hypotheses_per_s=N / (r["median_ms"] * 1e-3)),
+                "form": "pgp_multi_score_lcp (transforms from the caller's memory) / pgp_multi_score_uploaded (resident): slices -> "
+                        "ONE ncclAllReduce -> member 0's arg-max with near-tie settlement -> ONE copy back -> host wait, per call"}
+    # ---- sanity inside the bench: the group's answer = one device's answer for the complete batch
+    same = None
+    if check_device is not None:
+        one = LcpScorer(check_device)
+        one.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+        a = one.score(batches[lb], mode, w.gate_deg)
+        a0 = one.score(batches[0], mode, w.gate_deg)
+        same = bool(np.array_equal(a[0], last[0]) and np.array_equal(a[1], last[1]) and a[2:] == last[2:]
+                    and np.array_equal(a0[0], got0[0]) and a0[2:] == got0[2:])
+        assert same, "the device group's scores differ from one device's"
+        one.close()
+    info = grp.info()
+    kern_avg_ms = kern_ms / max(launches, 1)
+    out = {
+        "metric": "pose hypotheses/sec LCP-scored (50k-pt scene x 5k-pt model)",
+        "value": N * args.steps / dt, "unit": "hypotheses/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "host_issue_ms_per_step": t_issue / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "rccl_ranks": info["rccl_ranks"], "devices": info["devices"], "exchanges_issued": info["exchanges"],
+        "config": {"workload": "C2 (BASELINE.json configs[1]): 1 object, 5000-pt model vs 50000-pt synthetic scene, "
+                               f"4096 hypotheses per GPU per step ({N_BATCH} distinct batches in rotation), {mode_name} LCP"
+                               + (" = the reference's live WeightedVerify" if mode_name == "weighted" else "") + ", delta 5 mm",
+                   "n_scene": N_SCENE, "n_model": N_MODEL, "hypotheses_per_gpu": n_h, "distinct_batches": N_BATCH,
+                   "mode": mode_name, "sharding": f"hypotheses x{world}, clouds replicated",
+                   "exchange": "libpgp's device group (pgp_multi_enqueue_slot): ONE ncclAllReduce(int32 sum over {scores | counts}) "
+                               "per step, issued from C++ on each member's second stream under the next step's scoring; member 0's "
+                               "arg-max with near-tie settlement behind it; per_call = the synchronous form",
+                   "group": (f"{info['n_local']} member(s) in this process" + (f", ranks {info['rank0']}.. of {info['world']} processes' members"
+                             if info["world"] > info["n_local"] else " (single process, ncclCommInitAll)"))},
+        "roofline": roofline_block(mode_name, n_h, kern_avg_ms, launches),
+        "index": m0.index_info(), "cold_setup_ms": cold_ms, "best_index": int(last[2]),
+        "equals_single_device": same, "per_call": per_call,
+    }
+    if emulated:
+        out["emulated"] = True
+        out["note"] = ("PGP_MULTI_EMULATE: the members share ONE device and the exchange is a sum kernel -- a smoke run of the N > 1 "
+                       "code path, NOT a performance figure")
+    return out
+
+
+def group_process(args, real_stdout):
+    """`--form group`: ONE process, one device group over args.gpus devices (the child the launcher-less run starts)."""
+    from physimglobalpose_amd import MultiGpuScorer, PGP_MODE_PLAIN, PGP_MODE_WEIGHTED, synth
+    mode = PGP_MODE_PLAIN if args.mode == "plain" else PGP_MODE_WEIGHTED
+    emulate = int(os.environ.get("PGP_MULTI_EMULATE", "0") or 0)
+    if emulate >= 2 and emulate != args.gpus:
+        os.environ["PGP_MULTI_EMULATE"] = str(args.gpus)     # the emulated group has as many members as --gpus asks for
+    grp = MultiGpuScorer([0] if emulate >= 2 else list(range(args.gpus)))
+    world = grp.n_devices
+    w = synth.make_workload(N_SCENE, N_MODEL, args.hyp * world * N_BATCH, config_id=2)
+    out = group_headline(grp, args, w, mode, args.mode, args.hyp, world, lambda: None, lambda x: x, 0)
+    grp.close()
+    os.write(real_stdout, (json.dumps(compact_line(out)) + "\n").encode())
+    os.close(real_stdout)
+
+
+def orchestrate(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset, N > 1).  This process never touches a GPU (no torch,
+    no HIP): the measurements run in fresh CHILD processes -- (1) ONE process driving the product's device group over the N
+    devices, whose line is the headline; (2) the torch.distributed form (one rank per GPU) as rows.torch_twin.  Either may
+    fail without taking the other down; the ONE JSON line is printed whatever happened, and the exit code is 0 when a
+    headline exists."""
+    import socket
+    import subprocess
+    here = os.path.abspath(__file__)
+    common = ["--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup), "--mode", args.mode,
+              "--hyp", str(args.hyp)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    emulate = int(os.environ.get("PGP_MULTI_EMULATE", "0") or 0) >= 2
+    limit = float(os.environ.get("PGP_BENCH_CHILD_TIMEOUT", "900"))
+
+    def run(cmd, env):
+        try:
+            r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=limit)
+        except subprocess.TimeoutExpired:
+            return None, f"timed out after {limit:.0f} s"
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not lines:
+            return None, f"rc {r.returncode}: {r.stderr.strip()[-600:]}"
+        try:
+            return json.loads(lines[-1]), None
+        except ValueError as e:
+            return None, f"unparsable line: {e!r}"
+
+    group, err_g = run([sys.executable, here] + common + ["--form", "group"], env)
+    twin, err_t = None, "skipped"
+    if os.environ.get("PGP_BENCH_TWIN", "1") != "0" and not (emulate and args.gpus > 4):   # (a 1-GPU box takes few processes)
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        tenv = dict(env, PGP_BENCH_FORM="twin", PGP_BENCH_NATIVE_MULTI="0")
+        tenv.pop("PGP_MULTI_EMULATE", None)
+        if emulate:
+            tenv["PGP_DIST_BACKEND"] = "gloo"     # ranks share the one device, the collective goes through the host: a smoke mode
+        twin, err_t = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), here] + common + ["--no-cpu-baseline"], tenv)
+
+    def twin_row():
+        if twin is None:
+            return {"error": err_t}
+        return {"value": twin.get("value"), "ms_per_step": twin.get("ms_per_step"), "n_gpus": twin.get("n_gpus"),
+                "per_call_ms": (twin.get("per_call") or {}).get("ms_per_step"),
+                "form": "torch.distributed ranks, sharding.BucketedExchange (the Python twin of the exchange)"
+                        + (", gloo on one device (smoke)" if emulate else "")}
+
+    if group is not None:
+        line = group
+        line.setdefault("rows", {})["torch_twin"] = twin_row()
+        line["launch"] = "python bench.py --gpus N: one process, libpgp's device group (child process)"
+        rc = 0
+    elif twin is not None:
+        line = twin
+        line["native_group_error"] = err_g
+        line["launch"] = "python bench.py --gpus N: the device group's child failed, headline = torch.distributed ranks (child)"
+        rc = 0
+    else:
+        line = {"metric": "pose hypotheses/sec LCP-scored (50k-pt scene x 5k-pt model)", "value": None, "unit": "hypotheses/s",
+                "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True,
+                "error": {"device_group": err_g, "torch_ranks": err_t}}
+        rc = 1
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+    return rc
+
+
+def ranked_group_headline(args, torch, dist, rank, world, dev_index, w, mode):
+    """Under a launcher (one process per GPU): this rank's member of the product's group (pgp_multi_create_ranked), the id
+    through the launcher's store.  Returns (line or None, error or None); every rank takes the same branch."""
+    from physimglobalpose_amd import MultiGpuScorer
+    dev = torch.device("cuda", dev_index)
+    grp, err = None, None
+    try:
+        store = dist.distributed_c10d._get_default_store()
+        if rank == 0:
+            try:
+                store.set("pgp_multi_uid", MultiGpuScorer.unique_id())
+            except Exception as e:
+                store.set("pgp_multi_uid", b"ERR " + repr(e).encode()[:200])
+                raise
+        uid = bytes(store.get("pgp_multi_uid"))
+        if uid.startswith(b"ERR "):
+            raise RuntimeError("rank 0 could not draw the id: " + uid[4:].decode(errors="replace"))
+        grp = MultiGpuScorer.ranked([dev_index], rank, world, uid)
+    except Exception as e:
+        err = repr(e)
+    ok = torch.tensor([0 if grp is None else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        if grp is not None:
+            grp.close()
+        return None, err or "another rank could not join the group"
+
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def barrier():
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    try:
+        out = group_headline(grp, args, w, mode, args.mode, args.hyp, world, barrier, max_over_ranks,
+                             dev_index if rank == 0 else None, torch)
+        out["launch"] = "torch.distributed.run: one process per GPU, each holding one member of libpgp's group (ncclCommInitRank)"
+        return out, None
+    finally:
+        grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -674,7 +977,13 @@ def main():
     ap.add_argument("--mode", choices=["plain", "weighted"], default="weighted")
     ap.add_argument("--hyp", type=int, default=N_HYP, help="hypotheses per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--form", choices=["group"], default=None,
+                    help="group: ONE process drives libpgp's device group over --gpus devices (what the launcher-less "
+                         "`python bench.py --gpus N` starts as its child)")
     args = ap.parse_args()
+    if args.form is None and args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("PGP_BENCH_FORCE_DIST") != "1":
+        # no launcher: this process stays off the GPU (nothing below has been imported yet) and starts the children
+        raise SystemExit(orchestrate(args))
 
     # The contract is ONE JSON line on stdout.  Libraries below us write there too (RCCL prints a
     # version banner through C stdio, flushed at exit, i.e. AFTER anything Python printed): keep the
@@ -684,15 +993,16 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if args.form == "group":
+        return group_process(args, real_stdout)
+
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # (--gpus is what the launcher was asked for; the ranks that exist are the launcher's: world decides)
     # one rank per GPU; PGP_DIST_BACKEND=gloo + fewer GPUs than ranks is a functional smoke mode
     # (ranks share a device, the collective goes through the host) used to exercise the N > 1
     # code path on a 1-GPU box -- never a performance configuration
@@ -722,6 +1032,11 @@ def main():
     # N_BATCH distinct batches of world*n_h hypotheses, rank r takes slice r of each (weak scaling:
     # per-GPU work fixed)
     w = synth.make_workload(N_SCENE, N_MODEL, n_h * world * N_BATCH, config_id=2)
+    # N > 1 ranks on their own devices: the headline goes through the PRODUCT's group, one member per rank (the torch twin
+    # below stays as rows.torch_twin -- and takes the headline over, saying so, should the group fail to form)
+    native, native_err = None, None
+    if world > 1 and backend == "nccl" and os.environ.get("PGP_BENCH_FORM") != "twin":
+        native, native_err = ranked_group_headline(args, torch, dist, rank, world, dev_index, w, mode)
     sc = LcpScorer(dev_index)
     t0 = time.perf_counter()
     sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
@@ -868,6 +1183,17 @@ def main():
         }
         if per_call is not None:
             out["per_call"] = per_call
+        if native is not None:
+            # the product's group is the headline; what this function measured above becomes the secondary row
+            twin = {"value": out["value"], "ms_per_step": out["ms_per_step"], "per_call_ms": (per_call or {}).get("ms_per_step"),
+                    "form": "torch.distributed ranks, sharding.BucketedExchange (the Python twin of the exchange)"}
+            out = native
+            out["other_rows"] = {"torch_twin": twin}
+        elif world > 1:
+            out["native_group_error"] = native_err or ("skipped: " + ("PGP_BENCH_FORM=twin" if backend == "nccl" else
+                                                                      "ranks share one device (gloo smoke mode)"))
+        if world == 1 and not multi:
+            out["per_call"] = per_call_one_device(sc, w, torch, mode, d_batches)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.mode)
             try:
@@ -951,7 +1277,9 @@ def compact_line(out):
             r[n_p] = [r3(v.get("pose_iterations_per_s")), r3(v.get("pose_iterations_per_s_min")), r3(v.get("pose_iterations_per_s_max"))]
         return r
 
-    if o and "error" not in o:
+    if o and "error" not in o and "torch_twin" in o:
+        rows = {"torch_twin": {k: (r3(v) if isinstance(v, float) else v) for k, v in o["torch_twin"].items()}}
+    elif o and "error" not in o:
         rows = {
             "plain_lcp_hyp_per_s": r3(get(o, "plain_lcp", "hypotheses_per_s") or get(o, "weighted_lcp", "hypotheses_per_s")),
             "exact_ties_hyp_per_s": r3(get(o, "weighted_lcp_exact_ties", "hypotheses_per_s")),
@@ -978,6 +1306,8 @@ def compact_line(out):
             "lcp_resident_ms": r3(get(nm, "resident", "ms_per_call")), "lcp_resident_hyp_per_s": r3(get(nm, "resident", "hypotheses_per_s")),
             "lcp_host_pointers_ms": r3(get(nm, "host_pointers", "ms_per_call")),
             "objects": nm.get("objects"), "icp_shards": nm.get("icp_shards"), "congruent_shards": nm.get("congruent_shards")}
+    if isinstance(line.get("per_call"), dict):   # (the quantiles to four digits: the line's kept tail is what the driver records)
+        line["per_call"] = json.loads(json.dumps(line["per_call"]), parse_float=lambda x: round(float(x), 4) if abs(float(x)) < 1000 else round(float(x)))
     line["detail"] = detail
     line["rows"] = rows
     return line

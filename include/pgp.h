@@ -720,6 +720,46 @@ int pgp_multi_congruent_batch_fit(pgp_multi* m, int obj, const int* picks, const
                                   const float centroid_P[3], const float centroid_Q[3], float* T, double* pose,
                                   int* status, float* rms);
 
+/* ---- a group that spans several PROCESSES (one process per GPU under a launcher: python -m torch.distributed.run, mpirun) ----
+ * The same group, its members spread over processes: this process holds n_local members (devices device_ids[0 ..
+ * n_local-1]) which are ranks rank0 .. rank0 + n_local - 1 of `world`.  One process calls pgp_multi_unique_id
+ * (ncclGetUniqueId; 128 bytes) and hands the id to the others by whatever channel the launcher offers (a torch.distributed
+ * store, MPI_Bcast, a file); every process then calls pgp_multi_create_ranked with it (ncclCommInitRank: the calls meet).
+ * Every process uploads the SAME clouds and the SAME complete hypothesis list; rank r scores the slice
+ * pgp_multi_slice(n_h, r, world), the all-reduce leaves every process with all scores, and member 0 of EVERY process takes
+ * the arg-max -- each process returns what pgp_score_lcp returns on one device.  The scoring entry points
+ * (pgp_multi_score_lcp, _upload, _score_uploaded, _score_objects*, the streaming form below) work on such a group; the
+ * calls that gather into the caller's arrays without a collective (pgp_multi_icp_refine, pgp_multi_find_congruent_batch,
+ * ...) need a single-process group and return PGP_ESTATE otherwise.  The consumer is the same per-object loop
+ * (SceneCfg.cpp:376-406) in a node that was started once per GPU. */
+int pgp_multi_unique_id(void* id128);
+int pgp_multi_create_ranked(pgp_multi** out, const int* device_ids, int n_local, int rank0, int world, const void* id128);
+
+/* What the group is made of.  rccl_ranks = ncclCommCount of the communicator the exchange runs on (0: the group has no
+ * communicator -- one member without PGP_MULTI_FORCE_COLLECTIVE, or an emulated group); exchanges = all-reduces (or, in
+ * an emulated group, sum kernels) issued so far. */
+typedef struct {
+  int n_local, world, rank0;
+  int rccl_ranks;
+  int emulated;
+  int devices[16];        /* the first 16 local members' devices */
+  long long exchanges;
+} pgp_multi_info;
+int pgp_multi_get_info(pgp_multi* m, pgp_multi_info* info);
+
+/* ---- streaming form: the verification loop batch after batch without a host wait per batch (base.cc:1885-1901 run over
+ * the lists of successive objects / expansions; bench.py's N > 1 headline) --------------------------------------------
+ * pgp_multi_upload_slot leaves a hypothesis list resident in one of 16 slots (object 0's clouds; synchronous).
+ * pgp_multi_enqueue_slot queues one scoring step over a slot and returns: every member scores its slice into one of two
+ * {scores | counts} vectors on its stream, the all-reduce runs on a SECOND stream of the member -- under the scoring of
+ * the next step --, and member 0's arg-max (near-tie settlement, exact records, Verify's early termination as set on
+ * member 0's context) is queued behind that next step's scoring.  pgp_multi_collect completes everything queued and
+ * returns the LAST step's arrays, bit for bit those of pgp_multi_score_lcp on the same list.  pgp_multi_upload_slot
+ * between an enqueue and its collect returns PGP_ESTATE. */
+int pgp_multi_upload_slot(pgp_multi* m, int slot, const float* T, int n_h);
+int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg);
+int pgp_multi_collect(pgp_multi* m, float* scores, int* counts, int* best_index, float* best_score);
+
 /* Host wall clock of the last scoring call in ms: upload (pinned copy + H2D enqueue), enqueue
  * (kernels + collective issued on every device), total (until the results are back). */
 int pgp_multi_last_timing(pgp_multi* m, float* upload_ms, float* enqueue_ms, float* total_ms);

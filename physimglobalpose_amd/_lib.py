@@ -47,6 +47,11 @@ class MultiIcpJob(C.Structure):
                 ("T", C.POINTER(C.c_float)), ("n", C.c_int), ("energy", C.POINTER(C.c_float)), ("iters", C.POINTER(C.c_int))]
 
 
+class MultiInfo(C.Structure):
+    _fields_ = [("n_local", C.c_int), ("world", C.c_int), ("rank0", C.c_int), ("rccl_ranks", C.c_int), ("emulated", C.c_int),
+                ("devices", C.c_int * 16), ("exchanges", C.c_longlong)]
+
+
 class Camera(C.Structure):
     _fields_ = [("rows", C.c_int), ("cols", C.c_int), ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float),
                 ("cy", C.c_float), ("z_near", C.c_float), ("z_max", C.c_float)]
@@ -158,6 +163,12 @@ SIGNATURES = {
     "pgp_multi_upload": (C.c_int, [C.c_void_p, _f, C.c_int]),
     "pgp_multi_score_uploaded": (C.c_int, [C.c_void_p, C.c_int, C.c_float, _f, _i, _i, _f]),
     "pgp_multi_last_timing": (C.c_int, [C.c_void_p, _f, _f, _f]),
+    "pgp_multi_unique_id": (C.c_int, [C.c_void_p]),
+    "pgp_multi_create_ranked": (C.c_int, [C.POINTER(C.c_void_p), _i, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "pgp_multi_get_info": (C.c_int, [C.c_void_p, C.POINTER(MultiInfo)]),
+    "pgp_multi_upload_slot": (C.c_int, [C.c_void_p, C.c_int, _f, C.c_int]),
+    "pgp_multi_enqueue_slot": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float]),
+    "pgp_multi_collect": (C.c_int, [C.c_void_p, _f, _i, _i, _f]),
     "pgp_multi_add_object": (C.c_int, [C.c_void_p]),
     "pgp_multi_objects": (C.c_int, [C.c_void_p]),
     "pgp_multi_object_context": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),

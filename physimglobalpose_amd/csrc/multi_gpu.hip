@@ -45,6 +45,9 @@ namespace {
 struct Rccl {
   void* handle = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
@@ -53,6 +56,7 @@ struct Rccl {
 };
 
 bool load_rccl(Rccl* r) {
+  if (r->handle) return true;
   static const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   for (const char* n : names) {
     r->handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
@@ -69,6 +73,9 @@ bool load_rccl(Rccl* r) {
     return false;                                                        \
   }
   PGP_SYM(CommInitAll, "ncclCommInitAll")
+  PGP_SYM(CommInitRank, "ncclCommInitRank")
+  PGP_SYM(GetUniqueId, "ncclGetUniqueId")
+  PGP_SYM(CommCount, "ncclCommCount")
   PGP_SYM(CommDestroy, "ncclCommDestroy")
   PGP_SYM(AllReduce, "ncclAllReduce")
   PGP_SYM(GroupStart, "ncclGroupStart")
@@ -156,8 +163,20 @@ double now_ms() {
 
 using namespace pgp;
 
+// The streaming form's per-member state (pgp_multi_enqueue_slot): a second stream for the exchange and two {scores | counts}
+// vectors, so that the all-reduce of step i runs under the scoring of step i + 1.
+struct Streaming {
+  hipStream_t x = nullptr;
+  DevBuf ring[2];
+  hipEvent_t scored[2] = {nullptr, nullptr}, reduced[2] = {nullptr, nullptr};
+};
+constexpr int kSlots = 16;        // resident hypothesis batches of the streaming form
+constexpr int kEmulateMax = 16;   // members of an emulated group the streaming form's sum kernel takes
+
 struct pgp_multi {
-  int n = 0;
+  int n = 0;                      // members in THIS process
+  int world = 0, rank0 = 0;       // member k is rank rank0 + k of `world` (single-process group: world = n, rank0 = 0)
+  long long n_exchanges = 0;      // exchanges (all-reduces) issued per member since the group was created
   std::vector<int> dev;
   // [object][member]: an object = one (scene, model) pair -- a segment of the frame and the object model it is
   // matched against (SceneCfg.cpp:376-406 loops over them) -- replicated on every member.  Object 0 exists from
@@ -187,6 +206,17 @@ struct pgp_multi {
   std::mutex bar_mu;
   std::condition_variable bar_cv;
   int bar_count = 0, bar_gen = 0;
+
+  // streaming form
+  std::vector<Streaming> s2;                 // [member]
+  std::vector<std::vector<DevBuf>> slot_T;   // [slot][member]: the transforms of a resident batch (member 0: all of it)
+  std::vector<int> slot_n;                   // [slot] hypotheses, -1 = empty
+  DevBuf d_best2;                            // member 0: {index, score bits} of ring[0] and ring[1]
+  hipEvent_t ev_sum[2] = {nullptr, nullptr}; // emulate: the summed vector of ring[b] has been handed to every member
+  long long step = 0;                        // steps enqueued since the last collect
+  int pend_slot[2] = {0, 0}, pend_mode[2] = {0, 0}, pend_n[2] = {0, 0};
+  float pend_gate[2] = {0.f, 0.f};
+  bool exchange() const { return world > 1 || use_coll; }
 
   int total() const { return off.back(); }
   int objects() const { return (int)octx.size(); }
@@ -276,10 +306,10 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
   // every member: its pieces of the flat space into a zeroed full-length vector (the sum over members is the gather)
   auto score_slice = [&](int k) -> int {
     int lo, hi;
-    slice_of(N, k, m->n, &lo, &hi);
+    slice_of(N, m->rank0 + k, m->world, &lo, &hi);
     float* d_s = m->d_all[k].as<float>();
     int* d_c = reinterpret_cast<int*>(d_s + N);
-    if (N > 0 && m->n > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)N * 8, m->stream[k]));
+    if (N > 0 && m->world > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)N * 8, m->stream[k]));
     for (int o = 0; o < n_obj; ++o) {
       const int a = std::max(lo, m->off[o]), b = std::min(hi, m->off[o + 1]);
       if (b <= a) continue;
@@ -376,7 +406,8 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
     return PGP_OK;
   };
 
-  const bool exchange = m->n > 1 || m->use_coll;
+  const bool exchange = m->exchange();
+  if (exchange && N > 0) ++m->n_exchanges;
   if (m->emulate && m->n > 1 && N > 0) {
     rc = run_all(m, [&](int k) -> int {
       int r = emulate_exchange(k, score_slice(k));
@@ -456,7 +487,7 @@ int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) 
   m->off = off;
   rc = run_all(m, [m, nT, N, n_obj](int k) -> int {
     int lo, hi, r;
-    slice_of(N, k, m->n, &lo, &hi);
+    slice_of(N, m->rank0 + k, m->world, &lo, &hi);
     if ((r = m->d_T[k].ensure(nT)) != PGP_OK) return r;
     if ((r = m->d_all[k].ensure((size_t)N * 8)) != PGP_OK) return r;
     if ((r = m->d_best[k].ensure((size_t)n_obj * 8 + 16)) != PGP_OK) return r;
@@ -524,7 +555,10 @@ int pgp_multi_flat_slices(const int* n_h, int n_obj, int k, int n_dev, int* obj,
   return PGP_OK;
 }
 
-int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
+namespace {
+// rank0 < 0: a single-process group (world = its members); else the members are ranks rank0 .. rank0 + n_dev - 1 of `world`
+// and `id` is the 128-byte ncclUniqueId every process of the group was given
+int create_group(pgp_multi** out, const int* device_ids, int n_dev, int rank0, int world, const void* id) {
   if (!out) {
     set_error("pgp_multi_create: out is NULL");
     return PGP_EINVAL;
@@ -537,12 +571,23 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
               e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     return PGP_ENODEV;
   }
+  const bool ranked = rank0 >= 0;
   int emulate = 0;
   if (const char* v = getenv("PGP_MULTI_EMULATE")) emulate = atoi(v);
+  if (ranked && emulate >= 2) {
+    set_error("pgp_multi_create_ranked: PGP_MULTI_EMULATE applies to single-process groups");
+    return PGP_EINVAL;
+  }
   if (emulate >= 2) n_dev = emulate;   // n logical members on the first listed device
   if (n_dev <= 0) n_dev = visible;  // every visible device
+  if (ranked && (world < n_dev || rank0 + n_dev > world || !id)) {
+    set_error("pgp_multi_create_ranked: ranks %d .. %d of %d", rank0, rank0 + n_dev - 1, world);
+    return PGP_EINVAL;
+  }
   pgp_multi* m = new pgp_multi();
   m->n = n_dev;
+  m->world = ranked ? world : n_dev;
+  m->rank0 = ranked ? rank0 : 0;
   m->emulate = emulate >= 2;
   for (int k = 0; k < n_dev; ++k) {
     const int d = m->emulate ? (device_ids ? device_ids[0] : 0) : (device_ids ? device_ids[k] : k);
@@ -566,6 +611,9 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
   m->d_T.resize(n_dev);
   m->d_all.resize(n_dev);
   m->d_best.resize(n_dev);
+  m->s2.resize((size_t)n_dev);
+  m->slot_T.assign(kSlots, std::vector<DevBuf>((size_t)n_dev));
+  m->slot_n.assign(kSlots, -1);
   int rc = PGP_OK;
   for (int k = 0; k < n_dev && rc == PGP_OK; ++k) {
     Worker* w = new Worker();
@@ -580,7 +628,7 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
     return m->d_best[k].ensure(16);
   });
   const char* force = getenv("PGP_MULTI_FORCE_COLLECTIVE");
-  m->use_coll = n_dev > 1 || (force && atoi(force) != 0);
+  m->use_coll = m->world > 1 || (force && atoi(force) != 0);
   if (const char* v = getenv("PGP_MULTI_COLL")) m->grouped = std::strcmp(v, "grouped") == 0;
   if (rc == PGP_OK && m->emulate) {
     m->ev.assign(n_dev, nullptr);
@@ -593,9 +641,32 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
     if (!load_rccl(&m->rccl)) rc = PGP_ENODEV;
     if (rc == PGP_OK) {
       m->comm.assign(n_dev, nullptr);
-      ncclResult_t nr = m->rccl.CommInitAll(m->comm.data(), n_dev, m->dev.data());
+      ncclResult_t nr = ncclSuccess;
+      if (!ranked) {
+        nr = m->rccl.CommInitAll(m->comm.data(), n_dev, m->dev.data());
+      } else {
+        // one communicator per local member, joined to the ranks of the other processes through the shared id; several
+        // members of one process are initialised inside ONE group (the form RCCL documents for one thread, many devices)
+        ncclUniqueId uid;
+        std::memcpy(&uid, id, sizeof uid);
+        int keep = 0;
+        (void)hipGetDevice(&keep);
+        if (n_dev > 1) nr = m->rccl.GroupStart();
+        for (int k = 0; k < n_dev && nr == ncclSuccess; ++k) {
+          if (hipSetDevice(m->dev[k]) != hipSuccess) {
+            nr = ncclUnhandledCudaError;
+            break;
+          }
+          nr = m->rccl.CommInitRank(&m->comm[(size_t)k], m->world, uid, m->rank0 + k);
+        }
+        if (n_dev > 1) {
+          const ncclResult_t ge = m->rccl.GroupEnd();
+          if (nr == ncclSuccess) nr = ge;
+        }
+        (void)hipSetDevice(keep);
+      }
       if (nr != ncclSuccess) {
-        set_error("ncclCommInitAll failed: %s", m->rccl.GetErrorString(nr));
+        set_error("%s failed: %s", ranked ? "ncclCommInitRank" : "ncclCommInitAll", m->rccl.GetErrorString(nr));
         m->comm.clear();
         rc = PGP_EHIP;
       }
@@ -613,12 +684,75 @@ int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
   return PGP_OK;
 }
 
+bool single_process(const pgp_multi* m, const char* who) {
+  if (m->world == m->n) return true;
+  set_error("%s: the group spans several processes (ranks %d .. %d of %d); this entry point gathers into the caller's "
+            "arrays and needs a single-process group", who, m->rank0, m->rank0 + m->n - 1, m->world);
+  return false;
+}
+}  // namespace
+
+int pgp_multi_create(pgp_multi** out, const int* device_ids, int n_dev) {
+  return create_group(out, device_ids, n_dev, -1, 0, nullptr);
+}
+
+int pgp_multi_unique_id(void* id128) {
+  if (!id128) {
+    set_error("pgp_multi_unique_id: id128 is NULL");
+    return PGP_EINVAL;
+  }
+  static Rccl r;   // (the handle stays loaded for the life of the process, as a group's does)
+  if (!load_rccl(&r)) return PGP_ENODEV;
+  ncclUniqueId uid;
+  const ncclResult_t nr = r.GetUniqueId(&uid);
+  if (nr != ncclSuccess) {
+    set_error("ncclGetUniqueId failed: %s", r.GetErrorString(nr));
+    return PGP_EHIP;
+  }
+  static_assert(sizeof uid == 128, "pgp.h promises 128 bytes");
+  std::memcpy(id128, &uid, sizeof uid);
+  return PGP_OK;
+}
+
+int pgp_multi_create_ranked(pgp_multi** out, const int* device_ids, int n_local, int rank0, int world, const void* id128) {
+  if (n_local <= 0 || rank0 < 0) {
+    set_error("pgp_multi_create_ranked: %d local members from rank %d", n_local, rank0);
+    return PGP_EINVAL;
+  }
+  return create_group(out, device_ids, n_local, rank0, world, id128);
+}
+
+int pgp_multi_get_info(pgp_multi* m, pgp_multi_info* info) {
+  if (!m || !info) {
+    set_error("pgp_multi_get_info: bad argument");
+    return PGP_EINVAL;
+  }
+  std::memset(info, 0, sizeof *info);
+  info->n_local = m->n;
+  info->world = m->world;
+  info->rank0 = m->rank0;
+  info->emulated = m->emulate ? 1 : 0;
+  info->exchanges = m->n_exchanges;
+  for (int k = 0; k < m->n && k < 16; ++k) info->devices[k] = m->dev[(size_t)k];
+  if (!m->comm.empty() && m->comm[0]) {
+    int cnt = 0;
+    const ncclResult_t nr = m->rccl.CommCount(m->comm[0], &cnt);
+    if (nr != ncclSuccess) {
+      set_error("ncclCommCount failed: %s", m->rccl.GetErrorString(nr));
+      return PGP_EHIP;
+    }
+    info->rccl_ranks = cnt;
+  }
+  return PGP_OK;
+}
+
 int pgp_multi_destroy(pgp_multi* m) {
   if (!m) return PGP_OK;
   const bool workers = !m->worker.empty() && (int)m->worker.size() == m->n;
   if (workers) {
     run_all(m, [m](int k) -> int {
       if (m->stream[k]) (void)hipStreamSynchronize(m->stream[k]);
+      if (k < (int)m->s2.size() && m->s2[(size_t)k].x) (void)hipStreamSynchronize(m->s2[(size_t)k].x);
       return PGP_OK;
     });
   }
@@ -630,7 +764,24 @@ int pgp_multi_destroy(pgp_multi* m) {
       m->d_all[k].release();
       m->d_best[k].release();
       if (k < (int)m->ev.size() && m->ev[k]) (void)hipEventDestroy(m->ev[k]);
-      if (k == 0) m->d_sum.release();
+      if (k == 0) {
+        m->d_sum.release();
+        m->d_best2.release();
+        for (hipEvent_t ev : m->ev_sum)
+          if (ev) (void)hipEventDestroy(ev);
+      }
+      if (k < (int)m->s2.size()) {
+        Streaming& z = m->s2[(size_t)k];
+        if (z.x) (void)hipStreamSynchronize(z.x);
+        for (int b = 0; b < 2; ++b) {
+          z.ring[b].release();
+          if (z.scored[b]) (void)hipEventDestroy(z.scored[b]);
+          if (z.reduced[b]) (void)hipEventDestroy(z.reduced[b]);
+        }
+        if (z.x) (void)hipStreamDestroy(z.x);
+      }
+      for (auto& per_slot : m->slot_T)
+        if (k < (int)per_slot.size()) per_slot[(size_t)k].release();
       if (m->stream[k]) (void)hipStreamDestroy(m->stream[k]);
       for (auto& per_obj : m->octx)
         if (per_obj[(size_t)k]) pgp_destroy(per_obj[(size_t)k]);
@@ -798,6 +949,238 @@ int pgp_multi_score_objects(pgp_multi* m, const float* const* T, const int* n_h,
   return rc;
 }
 
+// ---- streaming form: resident batches, steps queued without a host wait, the exchange under the next step's scoring ----
+namespace {
+struct SumPtrs {
+  const float* p[kEmulateMax];
+};
+// emulate_sum with the members' vectors passed by value (nothing to upload, nothing to wait for on the host)
+__global__ __launch_bounds__(256) void emulate_sum_args(SumPtrs in, int n_members, int n_h, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n_h) return;
+  int s = 0;
+  for (int k = 0; k < n_members; ++k) s += reinterpret_cast<const int*>(in.p[k])[i];
+  reinterpret_cast<int*>(out)[i] = s;
+}
+
+int streaming_ready(pgp_multi* m, int k) {
+  Streaming& z = m->s2[(size_t)k];
+  if (z.x) return PGP_OK;
+  PGP_HIP(hipStreamCreateWithFlags(&z.x, hipStreamNonBlocking));
+  for (int b = 0; b < 2; ++b) {
+    PGP_HIP(hipEventCreateWithFlags(&z.scored[b], hipEventDisableTiming));
+    PGP_HIP(hipEventCreateWithFlags(&z.reduced[b], hipEventDisableTiming));
+    if (k == 0 && m->emulate) PGP_HIP(hipEventCreateWithFlags(&m->ev_sum[b], hipEventDisableTiming));
+  }
+  if (k == 0) {
+    const int r = m->d_best2.ensure(64);
+    if (r != PGP_OK) return r;
+  }
+  return PGP_OK;
+}
+
+// member 0, on its scoring stream: the complete vector of ring[b] is there once the exchange has finished -> arg-max with
+// the near-tie settlement (and the opt-in passes over the complete vector), exactly score_flat's tail
+int queue_tail(pgp_multi* m, int b) {
+  Streaming& z = m->s2[0];
+  hipStream_t st = m->stream[0];
+  const int N = m->pend_n[b], mode = m->pend_mode[b];
+  const float gate = m->pend_gate[b];
+  if (N <= 0) return PGP_OK;   // (the empty batch: its {-1, 0} was published by the scoring call)
+  PGP_HIP(hipStreamWaitEvent(st, z.reduced[b], 0));
+  pgp_ctx* c = m->octx[0][0];
+  float* d_s = z.ring[b].as<float>();
+  const float* d_T = m->slot_T[(size_t)m->pend_slot[b]][0].as<float>();
+  int r = pgp_settle_best_device(c, d_T, N, mode, gate, d_s, m->d_best2.as<int>() + 2 * b, st);
+  if (r != PGP_OK) return r;
+  if (c->exact_records && (r = pgp_settle_records_device(c, d_T, N, mode, gate, d_s, st)) != PGP_OK) return r;
+  if (c->verify_early_out && mode == PGP_MODE_PLAIN &&
+      (r = pgp_verify_early_out_device(c, d_T, N, d_s, reinterpret_cast<int*>(d_s + N), st)) != PGP_OK)
+    return r;
+  return PGP_OK;
+}
+}  // namespace
+
+int pgp_multi_upload_slot(pgp_multi* m, int slot, const float* T, int n_h) {
+  if (!m || slot < 0 || slot >= kSlots || n_h < 0 || (n_h > 0 && !T) || n_h > 0x3FFFFFFF) {
+    set_error("pgp_multi_upload_slot: bad argument (slot %d of %d, %d hypotheses)", slot, kSlots, n_h);
+    return PGP_EINVAL;
+  }
+  if (m->step != 0) {
+    set_error("pgp_multi_upload_slot: %lld steps are in flight (pgp_multi_collect first)", m->step);
+    return PGP_ESTATE;
+  }
+  if (m->emulate && m->n > kEmulateMax) {
+    set_error("pgp_multi_upload_slot: the streaming form emulates at most %d members", kEmulateMax);
+    return PGP_EINVAL;
+  }
+  const int N = n_h;
+  const size_t nT = (size_t)N * 64;
+  int rc = ensure_pin(m, nT + (size_t)N * 8 + 256);
+  if (rc != PGP_OK) return rc;
+  if (nT) std::memcpy(m->h_pin, T, nT);
+  rc = run_all(m, [m, slot, N, nT](int k) -> int {
+    int lo, hi, r;
+    slice_of(N, m->rank0 + k, m->world, &lo, &hi);
+    if ((r = streaming_ready(m, k)) != PGP_OK) return r;
+    Streaming& z = m->s2[(size_t)k];
+    DevBuf& dT = m->slot_T[(size_t)slot][(size_t)k];
+    if ((r = dT.ensure(nT + 64)) != PGP_OK) return r;
+    for (int b = 0; b < 2; ++b)
+      if ((r = z.ring[b].ensure((size_t)N * 8 + 64)) != PGP_OK) return r;
+    if (k == 0 && m->emulate && (r = m->d_sum.ensure((size_t)N * 8 + 64)) != PGP_OK) return r;
+    // member 0 settles over the complete vector: its context takes all N, the others their slice
+    if ((r = pgp_reserve(m->octx[0][(size_t)k], k == 0 ? N : hi - lo)) != PGP_OK) return r;
+    const size_t a = k == 0 ? 0 : (size_t)lo * 64, b = k == 0 ? nT : (size_t)hi * 64;
+    if (b > a)
+      PGP_HIP(hipMemcpyAsync(dT.as<unsigned char>() + a, static_cast<unsigned char*>(m->h_pin) + a, b - a,
+                             hipMemcpyHostToDevice, m->stream[k]));
+    PGP_HIP(hipStreamSynchronize(m->stream[k]));   // the pinned image is free again when this call returns
+    return PGP_OK;
+  });
+  m->slot_n[(size_t)slot] = rc == PGP_OK ? N : -1;
+  return rc;
+}
+
+int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg) {
+  if (!m || slot < 0 || slot >= kSlots || m->slot_n[(size_t)slot] < 0) {
+    set_error("pgp_multi_enqueue_slot: slot %d holds no batch (pgp_multi_upload_slot)", slot);
+    return PGP_EINVAL;
+  }
+  const int N = m->slot_n[(size_t)slot];
+  const int b = (int)(m->step & 1);
+  const bool exchange = m->exchange() && N > 0;
+  const bool tail_before = m->step > 0 && m->exchange();   // the previous step's tail: queued BEHIND this step's scoring
+  std::vector<int> fail((size_t)m->n, 0);
+  m->pend_slot[b] = slot;
+  m->pend_mode[b] = mode;
+  m->pend_gate[b] = gate_deg;
+  m->pend_n[b] = N;
+  if (exchange) ++m->n_exchanges;
+  const long long step = m->step;
+  const int rc = run_all(m, [&, m](int k) -> int {
+    Streaming& z = m->s2[(size_t)k];
+    hipStream_t S = m->stream[k], X = z.x;
+    int lo, hi;
+    slice_of(N, m->rank0 + k, m->world, &lo, &hi);
+    float* d_s = z.ring[b].as<float>();
+    int* d_c = reinterpret_cast<int*>(d_s + N);
+    pgp_ctx* c = m->octx[0][(size_t)k];
+    // ---- this member's slice into ring[b] (zeroed first: the sum over the members is the gather) ----
+    int r1 = [&]() -> int {
+      if (!m->exchange())   // one member, no collective: the scoring call publishes the best itself (and runs the opt-in passes)
+        return pgp_score_lcp_device(c, m->slot_T[(size_t)slot][(size_t)k].as<float>(), N, mode, gate_deg, d_s, d_c,
+                                    m->d_best2.as<int>() + 2 * b, S);
+      // ring[b] was last used two steps ago: its exchange (and, on member 0, its tail -- on S already) must be through
+      if (step >= 2) PGP_HIP(hipStreamWaitEvent(S, z.reduced[b], 0));
+      if (N > 0 && m->world > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)N * 8, S));
+      const bool records = c->exact_records, early = c->verify_early_out;
+      c->exact_records = false;   // they belong to the complete vector (queue_tail)
+      c->verify_early_out = false;
+      const int r = hi > lo || N == 0
+                        ? pgp_score_lcp_device(c, m->slot_T[(size_t)slot][(size_t)k].as<float>() + 16 * (size_t)lo, hi - lo, mode,
+                                               gate_deg, d_s + lo, d_c + lo, N == 0 && k == 0 ? m->d_best2.as<int>() + 2 * b : nullptr, S)
+                        : PGP_OK;
+      c->exact_records = records;
+      c->verify_early_out = early;
+      return r;
+    }();
+    if (!exchange) {
+      if (r1 == PGP_OK && k == 0 && tail_before) r1 = queue_tail(m, b ^ 1);
+      return r1;
+    }
+    // ---- the exchange of ring[b] on the second stream ----
+    if (r1 == PGP_OK && hipEventRecord(z.scored[b], S) != hipSuccess) r1 = PGP_EHIP;
+    if (r1 == PGP_OK && hipStreamWaitEvent(X, z.scored[b], 0) != hipSuccess) r1 = PGP_EHIP;
+    int r2 = PGP_OK;
+    if (m->emulate) {
+      fail[(size_t)k] = r1 != PGP_OK;
+      m->barrier();   // every member's slice is queued (or has failed)
+      bool any = false;
+      for (int f : fail) any = any || f;
+      if (k == 0 && !any) {
+        r2 = [&]() -> int {
+          SumPtrs ptrs{};
+          for (int j = 0; j < m->n; ++j) {
+            ptrs.p[j] = m->s2[(size_t)j].ring[b].as<float>();
+            if (j > 0) PGP_HIP(hipStreamWaitEvent(X, m->s2[(size_t)j].scored[b], 0));
+          }
+          float* d_out = m->d_sum.as<float>();
+          hipLaunchKernelGGL(emulate_sum_args, dim3((2 * N + 255) / 256), dim3(256), 0, X, ptrs, m->n, N, d_out);
+          PGP_HIP(hipGetLastError());
+          for (int j = 0; j < m->n; ++j)
+            PGP_HIP(hipMemcpyAsync(m->s2[(size_t)j].ring[b].p, d_out, (size_t)N * 8, hipMemcpyDeviceToDevice, X));
+          PGP_HIP(hipEventRecord(m->ev_sum[b], X));
+          return PGP_OK;
+        }();
+        fail[0] = r2 != PGP_OK;
+      }
+      m->barrier();   // the sum is queued
+      if (r1 == PGP_OK && r2 == PGP_OK && (any || fail[0])) {
+        set_error("another member of the group failed");
+        r2 = PGP_EHIP;
+      }
+      if (r1 == PGP_OK && r2 == PGP_OK && k > 0) PGP_HIP(hipStreamWaitEvent(X, m->ev_sum[b], 0));
+    } else {
+      // (a member whose slice failed to queue still joins the collective: the others' streams would wait for it forever)
+      const ncclResult_t nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)N, ncclInt32, ncclSum, m->comm[(size_t)k], X);
+      if (nr != ncclSuccess) {
+        set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
+        r2 = PGP_EHIP;
+      }
+    }
+    if (r1 != PGP_OK) return r1;
+    if (r2 != PGP_OK) return r2;
+    PGP_HIP(hipEventRecord(z.reduced[b], X));
+    // member 0: the previous step's tail, behind this step's scoring -- its exchange ran under that scoring
+    if (k == 0 && tail_before) return queue_tail(m, b ^ 1);
+    return PGP_OK;
+  });
+  if (rc != PGP_OK) return rc;
+  ++m->step;
+  return PGP_OK;
+}
+
+int pgp_multi_collect(pgp_multi* m, float* scores, int* counts, int* best_index, float* best_score) {
+  if (!m) {
+    set_error("pgp_multi_collect: handle is NULL");
+    return PGP_EINVAL;
+  }
+  if (m->step == 0) {
+    set_error("pgp_multi_collect: no step has been enqueued (pgp_multi_enqueue_slot)");
+    return PGP_ESTATE;
+  }
+  const int b = (int)((m->step - 1) & 1);
+  const int N = m->pend_n[b];
+  unsigned char* pin_out = static_cast<unsigned char*>(m->h_pin);   // (sized by pgp_multi_upload_slot; no upload is in flight)
+  const int rc = run_all(m, [&, m](int k) -> int {
+    Streaming& z = m->s2[(size_t)k];
+    hipStream_t S = m->stream[k];
+    if (k == 0) {
+      if (m->exchange()) {
+        const int r = queue_tail(m, b);
+        if (r != PGP_OK) return r;
+      }
+      if (N > 0) PGP_HIP(hipMemcpyAsync(pin_out, z.ring[b].p, (size_t)N * 8, hipMemcpyDeviceToHost, S));
+      PGP_HIP(hipMemcpyAsync(pin_out + (size_t)N * 8, m->d_best2.as<int>() + 2 * b, 8, hipMemcpyDeviceToHost, S));
+    }
+    PGP_HIP(hipStreamSynchronize(S));
+    if (z.x) PGP_HIP(hipStreamSynchronize(z.x));
+    return PGP_OK;
+  });
+  m->step = 0;
+  if (rc != PGP_OK) return rc;
+  if (N > 0) {
+    if (scores) std::memcpy(scores, pin_out, (size_t)N * 4);
+    if (counts) std::memcpy(counts, pin_out + (size_t)N * 4, (size_t)N * 4);
+  }
+  int best[2];
+  std::memcpy(best, pin_out + (size_t)N * 8, sizeof best);
+  if (best_index) *best_index = best[0];
+  if (best_score) std::memcpy(best_score, &best[1], 4);
+  return PGP_OK;
+}
+
 int pgp_multi_last_timing(pgp_multi* m, float* upload_ms, float* enqueue_ms, float* total_ms) {
   if (!m) {
     set_error("pgp_multi_last_timing: handle is NULL");
@@ -824,6 +1207,7 @@ int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs
     }
     cnt[(size_t)j] = q.n;
   }
+  if (!single_process(m, "pgp_multi_icp_refine")) return PGP_ESTATE;
   if (n_jobs == 0) return PGP_OK;
   const pgp_icp_options opt = icp_options_of(params);
   return run_all(m, [&, m](int k) -> int {
@@ -866,6 +1250,31 @@ int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs
     for (int p = 0; p < np; ++p)
       if ((r = icp_host_collect_enqueue(dj[(size_t)p].ctx, stage[(size_t)p], st)) != PGP_OK) return r;
     PGP_HIP(hipStreamSynchronize(st));
+    // A piece whose pose the one-launch scene-sized form gave up on (iteration count -1, transform left where it was:
+    // icp.hip icp_scene_persist; pgp.h promises host-pointer entries redo such a job) -- that piece once more through
+    // the host-driven form, exactly as pgp_icp_refine_ex does, so that the caller sees one pgp_icp_refine per job.
+    for (int p = 0; p < np; ++p) {
+      const IcpHostStage& g = stage[(size_t)p];
+      pgp_ctx* c = dj[(size_t)p].ctx;
+      const int* it = reinterpret_cast<const int*>(static_cast<const unsigned char*>(c->h_pin) + g.off_i);
+      bool lost = false;
+      for (int i = 0; i < dj[(size_t)p].n; ++i) lost = lost || it[i] < 0;
+      if (!lost) continue;
+      struct Off {
+        Off() { pgp::icp_scene_form_off(true); }
+        ~Off() { pgp::icp_scene_form_off(false); }
+      } off;
+      const pgp_multi_icp_job& q = jobs[pj[(size_t)p]];
+      const int n = dj[(size_t)p].n;
+      if ((r = icp_host_stage(c, q.src_xyz, q.n_src, q.tgt_xyz, q.n_tgt, q.T + 16 * (size_t)plo[(size_t)p], n, st, &stage[(size_t)p])) != PGP_OK)
+        return r;
+      const IcpHostStage& g2 = stage[(size_t)p];
+      dj[(size_t)p] = IcpJob{c, g2.d_src, q.n_src, g2.d_tgt, q.n_tgt, g2.d_T, n, g2.d_energy, g2.d_iters, g2.token};
+      if ((r = launch_icp(c, g2.d_src, q.n_src, g2.d_tgt, nullptr, q.n_tgt, g2.d_T, n, &opt, g2.d_energy, g2.d_iters, st, g2.token)) != PGP_OK)
+        return r;
+      if ((r = icp_host_collect_enqueue(c, g2, st)) != PGP_OK) return r;
+      PGP_HIP(hipStreamSynchronize(st));
+    }
     // the gather: every member writes its poses' results into the caller's arrays (disjoint ranges, no collective)
     for (int p = 0; p < np; ++p) {
       const pgp_multi_icp_job& q = jobs[pj[(size_t)p]];
@@ -881,6 +1290,7 @@ int pgp_multi_icp_refine(pgp_multi* m, const pgp_multi_icp_job* jobs, int n_jobs
 int pgp_multi_find_congruent_batch(pgp_multi* m, int obj, const int* base_ids, const float* base_xyz, const float* invariants,
                                    int n_bases, float threshold, int* n_quads) {
   if (bad_object(m, obj, "pgp_multi_find_congruent_batch")) return PGP_EINVAL;
+  if (!single_process(m, "pgp_multi_find_congruent_batch")) return PGP_ESTATE;
   if (n_bases < 0 || (n_bases > 0 && (!base_ids || !base_xyz || !invariants || !n_quads))) {
     set_error("pgp_multi_find_congruent_batch: bad argument");
     return PGP_EINVAL;

@@ -413,6 +413,7 @@ int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
 int icp_host_collect_enqueue(pgp_ctx* ctx, const IcpHostStage& g, hipStream_t st);
 void icp_host_collect(pgp_ctx* ctx, const IcpHostStage& g, int n, float* T, float* energy, int* iters);
 pgp_icp_options icp_options_of(const pgp_icp_params* p);
+void icp_scene_form_off(bool off);   // icp.hip: this THREAD's next launch_icp calls take the host-driven scene-sized form
 
 // base_select.hip
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);

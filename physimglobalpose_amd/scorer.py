@@ -47,9 +47,22 @@ class LcpScorer:
         self.nP = 0
         self.delta = None
 
+    @classmethod
+    def borrowed(cls, handle):
+        """A view of a context somebody else owns (a member of a device group: MultiGpuScorer.member): never destroyed here."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        self._h = C.c_void_p(handle)
+        self._borrowed = True
+        self.nQ = 0
+        self.nP = 0
+        self.delta = None
+        return self
+
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.pgp_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.pgp_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -771,6 +784,59 @@ class MultiGpuScorer:
         self.nQ = 0
         self._n_up = 0
         self._n_up_obj = np.zeros(1, np.int32)
+
+    @staticmethod
+    def unique_id():
+        """128 bytes from ncclGetUniqueId: one process of a ranked group draws it, all of them pass it to ranked()."""
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().pgp_multi_unique_id(buf))
+        return buf.raw
+
+    @classmethod
+    def ranked(cls, device_ids, rank0, world, unique_id):
+        """This process's members of a group that spans several processes (pgp_multi_create_ranked): the devices
+        `device_ids` are ranks rank0 .. rank0 + len - 1 of `world`.  Blocks until every process has called it."""
+        self = cls.__new__(cls)
+        self._lib = _lib.load()
+        arr = np.ascontiguousarray(device_ids, np.int32)
+        h = C.c_void_p()
+        _lib.check(self._lib.pgp_multi_create_ranked(C.byref(h), arr.ctypes.data_as(_i), len(arr), int(rank0), int(world),
+                                                     C.c_char_p(bytes(unique_id))))
+        self._h = h
+        self.n_devices = int(self._lib.pgp_multi_size(h))
+        self.nQ = 0
+        self._n_up = 0
+        self._n_up_obj = np.zeros(1, np.int32)
+        self._slot_n = {}
+        return self
+
+    def member(self, k=0):
+        """Member k's context of object 0 as a (borrowed) LcpScorer: kernel timing, index info."""
+        return LcpScorer.borrowed(self._lib.pgp_multi_context(self._h, int(k)))
+
+    def info(self):
+        inf = _lib.MultiInfo()
+        _lib.check(self._lib.pgp_multi_get_info(self._h, C.byref(inf)))
+        return {"n_local": inf.n_local, "world": inf.world, "rank0": inf.rank0, "rccl_ranks": inf.rccl_ranks,
+                "emulated": bool(inf.emulated), "devices": list(inf.devices[:min(inf.n_local, 16)]), "exchanges": int(inf.exchanges)}
+
+    # ---- streaming form: resident batches, steps queued without a host wait (pgp_multi_enqueue_slot) ----
+    def upload_slot(self, slot, T):
+        T = _f32(T, 16)
+        _lib.check(self._lib.pgp_multi_upload_slot(self._h, int(slot), _fp(T), len(T)))
+        if not hasattr(self, "_slot_n"):
+            self._slot_n = {}
+        self._slot_n[int(slot)] = len(T)
+
+    def enqueue_slot(self, slot, mode=PGP_MODE_PLAIN, gate_deg=30.0):
+        _lib.check(self._lib.pgp_multi_enqueue_slot(self._h, int(slot), int(mode), C.c_float(gate_deg)))
+        self._last_slot = int(slot)
+
+    def collect(self):
+        """Completes every queued step; (scores, counts, best_index, best_score) of the LAST one."""
+        s, c, bi, bs = self._out(self._slot_n[self._last_slot])
+        _lib.check(self._lib.pgp_multi_collect(self._h, _fp(s), c.ctypes.data_as(_i), C.byref(bi), C.byref(bs)))
+        return s, c, bi.value, float(np.float32(bs.value))
 
     def close(self):
         if getattr(self, "_h", None):

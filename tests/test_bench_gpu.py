@@ -71,6 +71,12 @@ def test_single_gpu_line():
     if "in_memory" in o["drop_in"] and "error" not in o["drop_in"]["in_memory"]:
         im = o["drop_in"]["in_memory"]
         assert im["calls"] == 200 and im["drop_in_ms_per_object"] <= im["p99_ms"] <= im["max_ms"]
+    pc = d["per_call"]                                   # SURVEY 8(d)'s metric: ONE synchronous call, median / p99 of 200
+    for n in ("4096", "3000"):
+        for form in ("host_pointers", "device_pointers"):
+            q = pc[n][form]
+            assert 0 < q["min_ms"] <= q["median_ms"] <= q["p99_ms"] and q["calls"] == 200 and q["hypotheses_per_s"] > 1e6
+        assert pc[n]["device_pointers"]["median_ms"] <= pc[n]["host_pointers"]["median_ms"] * 1.2
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     if cb["kind"] == "reference":               # the prebuilt oracle/_ref travelled along
@@ -105,3 +111,25 @@ def test_one_rank_through_rccl():
     assert len(lines) == 1
     d = _check(lines[0], 1)
     assert d["per_call"]["ms_per_step"] > 0
+
+
+def test_launcherless_multi_gpu_run_emulated():
+    """`python bench.py --gpus 2` WITHOUT a launcher must run by itself: the parent stays off the GPU, one
+    child drives libpgp's device group (two emulated members on this box's one device: PGP_MULTI_EMULATE), a second child the
+    torch.distributed twin; ONE JSON line, exit code 0, `emulated: true` -- a smoke run, never a performance figure."""
+    env = {k: v for k, v in os.environ.items() if k not in ("PGP_DIST_BACKEND", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["PGP_MULTI_EMULATE"] = "2"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
+    d = _check(lines[0], 2)
+    assert d["emulated"] is True and "NOT a performance figure" in d["note"]
+    assert d["devices"] == [0, 0] and d["rccl_ranks"] == 0 and d["exchanges_issued"] > 6
+    assert d["equals_single_device"] is True and "device group" in d["launch"]
+    pc = d["per_call"]
+    assert pc["host_pointers"]["median_ms"] > 0 and pc["resident"]["median_ms"] > 0
+    assert "cpu_baseline" not in d
+    tw = d["rows"]["torch_twin"]
+    assert "error" not in tw and tw["value"] > 0 and tw["n_gpus"] == 2, tw

@@ -149,3 +149,40 @@ def test_scene_sized_form_that_loses_a_pose_is_redone_host_driven(monkeypatch):
     assert int(d_it[0]) > 3
     assert _same(sc.icp_refine_ex(src, tgt, eye, **kw), ref)
     sc.close()
+
+
+@pytest.mark.parametrize("n_jobs", [1, 2])
+def test_group_icp_redoes_a_lost_scene_sized_piece(n_jobs, monkeypatch):
+    """pgp_multi_icp_refine is a host-pointer entry too: a piece whose pose the one-launch scene-sized form gave up
+    on (iters -1, transform untouched) is redone host-driven, so the caller gets one pgp_icp_refine per job -- for a member
+    with a single piece (plain launch_icp) and with several (launch_icp_multi's job-by-job fall-back for big segments)."""
+    from physimglobalpose_amd import MultiGpuScorer
+    rng = np.random.default_rng(14)
+    tgt = np.c_[rng.uniform(-0.6, 0.6, 60000), rng.uniform(-0.4, 0.4, 60000), 0.0005 * rng.standard_normal(60000)].astype(np.float32)
+    src = (tgt[rng.choice(len(tgt), 20000, replace=False)] + np.array([0.004, -0.003, 0.002]) + 0.0008 * rng.standard_normal((20000, 3))).astype(np.float32)
+    eye = np.eye(4, dtype=np.float32).T.reshape(1, 16).copy()
+    jobs = [(src, tgt, eye)]
+    if n_jobs == 2:
+        S, M, N, G = _problem(85, 5000, 2500, 6, rot_deg=2.0, trans=0.002, outliers=0.0)
+        jobs.append((S, M, G))
+    kw = dict(trim=1.0, max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0)
+    sc = LcpScorer()
+    ref = [sc.icp_refine(s, t, g, **kw) for s, t, g in jobs]
+    assert ref[0][2][0] > 3
+    monkeypatch.delenv("PGP_MULTI_EMULATE", raising=False)
+    grp = MultiGpuScorer([0])
+    monkeypatch.setenv("PGP_ICP_FORCE_LOST", "1")
+    # (the knob reaches the form: the device-pointer call reports the lost pose)
+    d_T, d_it = torch.from_numpy(eye.copy()).cuda(), torch.zeros(1, dtype=torch.int32, device="cuda")
+    sc.icp_refine_device(_dev4(src), _dev4(tgt), d_T, None, d_it, **kw)
+    torch.cuda.synchronize()
+    assert int(d_it[0]) == -1
+    got = grp.icp_refine(jobs, **kw)
+    for a, b in zip(got, ref):
+        assert _same(a, b)
+    monkeypatch.delenv("PGP_ICP_FORCE_LOST")
+    got = grp.icp_refine(jobs, **kw)
+    for a, b in zip(got, ref):
+        assert _same(a, b)
+    grp.close()
+    sc.close()

@@ -140,10 +140,46 @@ def test_bench_under_real_rccl(n):
     assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
     d = json.loads(lines[0])
     assert d["n_gpus"] == n and d["scaling"] == "weak" and d["value"] > 1e6
+    # the headline went through the PRODUCT's group: one member per rank, ncclCommInitRank, n ranks in the communicator
+    assert "native_group_error" not in d, d.get("native_group_error")
+    assert d["rccl_ranks"] == n and d["devices"] == [0] and d["equals_single_device"] is True and d["exchanges_issued"] > 6
     pc = d["per_call"]
-    assert pc["ms_per_step"] > 0 and pc["value"] > 0 and "error" not in pc
+    assert pc["host_pointers"]["median_ms"] > 0 and pc["resident"]["median_ms"] > 0
+    tw = d["rows"]["torch_twin"]                                   # the Python twin, secondary
+    assert tw["value"] > 1e6 and tw["ms_per_step"] > 0
     nm = d["rows"].get("native_multi")
     assert nm is not None and "error" not in nm, nm
     assert nm["devices"] == n and nm["equals_single_device"] is True
     for k in ("objects", "icp_shards", "congruent_shards"):      # row e-2 over the physical devices
         assert nm[k]["equals_single_context"] is True and nm[k]["ms_per_call"] > 0, k
+
+
+@pytest.mark.parametrize("n", GROUPS[:2])
+def test_bench_plain_python_launch(n):
+    """`python bench.py --gpus n` with NO launcher: one child process drives libpgp's single-process group over n physical
+    devices (ncclCommInitAll), a second child the torch twin; rc 0, ONE line, rccl_ranks = n."""
+    env = {k: v for k, v in os.environ.items() if k not in ("PGP_DIST_BACKEND", "PGP_MULTI_EMULATE", "WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, "bench.py", "--gpus", str(n), "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["scaling"] == "weak" and d["value"] > 1e6 and "emulated" not in d
+    assert d["rccl_ranks"] == n and d["devices"] == list(range(n)) and d["equals_single_device"] is True
+    assert d["per_call"]["host_pointers"]["median_ms"] > 0
+    assert "error" not in d["rows"]["torch_twin"], d["rows"]["torch_twin"]
+
+
+@pytest.mark.parametrize("n", GROUPS)
+def test_streaming_form_over_physical_devices(n):
+    """pgp_multi_enqueue_slot / _collect with the real all-reduce on the members' second streams"""
+    from test_multi_streaming_gpu import _check_streaming, _workload
+    w, lists = _workload()
+    one = LcpScorer(0)
+    one.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    grp = MultiGpuScorer(list(range(n)))
+    assert grp.info()["rccl_ranks"] == n
+    _check_streaming(grp, one, w, lists)
+    grp.close()
