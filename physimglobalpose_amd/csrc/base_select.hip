@@ -807,7 +807,11 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   HostOut out(ctx, st);
   unsigned char* up = out.room(A * 32);
   if (up) std::memcpy(up, h_u, A * 32);
-  PGP_HIP(hipMemcpyAsync(d_u, up ? (const void*)up : (const void*)h_u, A * 32, hipMemcpyHostToDevice, st));
+  if (up) {
+    if ((rc = stage_to_device(st, d_u, up, A * 32)) != PGP_OK) return rc;
+  } else {
+    PGP_HIP(hipMemcpyAsync(d_u, h_u, A * 32, hipMemcpyHostToDevice, st));
+  }
   a.prob_cdf = ctx->d_prob_cdf.as<double>();
   a.u = d_u;
   a.cur = d_cur;

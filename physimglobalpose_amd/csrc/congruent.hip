@@ -993,7 +993,11 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   }
   std::memcpy(stage_p, hb.data(), (size_t)nb * sizeof(BatchBase));
   std::memcpy(stage_p + bb, cones.data(), (size_t)nb * 168 * 4);
-  PGP_HIP(hipMemcpyAsync(d_bases, stage_p, bb + cb, hipMemcpyHostToDevice, st));
+  if (stage_h.empty()) {   // (the pinned area: by a kernel on the stream)
+    if ((rc = stage_to_device(st, d_bases, stage_p, bb + cb)) != PGP_OK) return rc;
+  } else {
+    PGP_HIP(hipMemcpyAsync(d_bases, stage_p, bb + cb, hipMemcpyHostToDevice, st));
+  }
   int* head = ctx->d_cs_cnt.as<int>();
   int* next = head + nbk;
   uint32_t* qcnt = reinterpret_cast<uint32_t*>(next + tp);

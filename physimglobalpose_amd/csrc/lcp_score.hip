@@ -1433,12 +1433,40 @@ __device__ __forceinline__ void settle_and_publish(const ScoreArgs& a, int n_h, 
   }
 }
 
-__global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2* __restrict__ partial,
+// The host-pointer call's results on their way home WITHOUT a copy engine and without the end-of-kernel signal: every block
+// also stores its scores and counts straight into the call's pinned landing area (system-scope stores, complete before the
+// block's ticket), and the launch's last block writes the best and then a completion word the host polls (pgp_api.hip
+// pgp_score_lcp).  A device-to-host DMA behind the kernel costs ~10 us whatever its size and the stream's completion signal a
+// few more: 13 us of a 144 us call (profiles/r06_ab/fused_exact_tile_order.log).  best[2] = 1: a weighted near-tie was settled
+// on the device (scores rewritten there): the host fetches the arrays the old way for that call.
+struct HostPub {
+  float* scores;   // NULL: nothing is published
+  int* counts;
+  int* best;       // {index, score bits, settled-on-device, spare}
+  unsigned int* flag;
+  unsigned int flag_value;
+};
+
+// The kernels' FIRST parameter, read back through the kernel-argument pointer where the rare settlement path needs it: taken
+// from the by-value parameter, its 50 words were fetched at the top of the kernel and held in scalar registers through the
+// common path (42-51 scalar spills in finalize_scores / settle_best_kernel).
+__device__ __forceinline__ const ScoreArgs& score_args_in_kernarg() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  const ScoreArgs* ap = (const ScoreArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ap));   // the loads stay where they are used
+  return *ap;
+#else
+  static const ScoreArgs none{};
+  return none;
+#endif
+}
+
+__global__ __launch_bounds__(256) void finalize_scores(ScoreArgs /* read through score_args_in_kernarg() */, const uint2* __restrict__ partial,
                                                        int n_tiles, int n_h, int nQ, int mode, int refine,
                                                        float* scores, int* __restrict__ counts,
                                                        unsigned long long* best_key, unsigned long long* runner_key,
                                                        unsigned int* ticket, int* __restrict__ best,
-                                                       float* __restrict__ seq) {
+                                                       float* __restrict__ seq, HostPub hp) {
   int h = blockIdx.x * blockDim.x + threadIdx.x;
   unsigned long long key = 0;
   if (h < n_h) {
@@ -1451,12 +1479,29 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
       uint2 pp[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) pp[j] = partial[(size_t)min(t0 + j, n_tiles - 1) * n_h + h];
+      // (the C2 model has 20 tiles: the second batch's four loads go out before the first batch is consumed)
+      uint2 pq[4];
+      const bool tail4 = n_tiles - (t0 + 16) > 0 && n_tiles - (t0 + 16) <= 4;
+      if (tail4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pq[j] = partial[(size_t)min(t0 + 16 + j, n_tiles - 1) * n_h + h];
+      }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (t0 + j < n_tiles) {
           c += (int)pp[j].x;
           f += __uint_as_float(pp[j].y);
         }
+      }
+      if (tail4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (t0 + 16 + j < n_tiles) {
+            c += (int)pq[j].x;
+            f += __uint_as_float(pq[j].y);
+          }
+        }
+        break;
       }
     }
     float score = (mode == PGP_MODE_PLAIN) ? __fdiv_rn((float)c, (float)nQ) : __fdiv_rn(f, (float)nQ);
@@ -1466,6 +1511,10 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
     // two ~3.5 us fences on its critical chain, every call: MI355X_MICROARCH.md, __threadfence row.)
     __hip_atomic_store(&scores[h], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (counts) counts[h] = c;
+    if (hp.scores) {
+      __hip_atomic_store(&hp.scores[h], score, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&hp.counts[h], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     if (score > 0.f)  // NaN and <= 0 never become best (best_LCP_ starts at 0, strict >)
       key = ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)h);
   }
@@ -1536,15 +1585,30 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
     }
     __syncthreads();
 #if !(defined(PGP_ABLATE) && PGP_ABLATE == 11)   // 11: what the common launch would cost without the settlement in its code object
-    settle_and_publish(a, n_h, mode, refine, scores, kk, best, seq, s_key);
+    settle_and_publish(score_args_in_kernarg(), n_h, mode, refine, scores, kk, best, seq, s_key);
 #endif
+    if (hp.scores) {   // (settled values and the best live in device memory: the host copies them back for this call)
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&hp.best[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(hp.flag, hp.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
   } else if (threadIdx.x == 0) {
-    if (kk == 0) {
-      best[0] = -1;
-      best[1] = 0;  // best_LCP_ = 0.0f
-    } else {
-      best[0] = (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
-      best[1] = (int)(unsigned)(kk >> 32);
+    const int bi = kk == 0 ? -1 : (int)(0xFFFFFFFFu - (unsigned)(kk & 0xFFFFFFFFull));
+    const int bs = kk == 0 ? 0 : (int)(unsigned)(kk >> 32);   // (none: best_LCP_ = 0.0f)
+    best[0] = bi;
+    best[1] = bs;
+    if (hp.scores) {
+      __hip_atomic_store(&hp.best[0], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&hp.best[1], bs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(&hp.best[2], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // Every block's host stores were complete (acknowledged: system-scope stores are written through) before its ticket;
+      // these three before the word the host polls.  No release FENCE: at system scope that is a write-back of everything
+      // dirty in this die's L2 -- the launch's 0.6 MB of partials among it -- for the sake of stores that never were in it.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __hip_atomic_store(hp.flag, hp.flag_value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -1552,9 +1616,9 @@ __global__ __launch_bounds__(256) void finalize_scores(ScoreArgs a, const uint2*
 // The same publication over a COMPLETE score vector that was assembled elsewhere (the slices of
 // several devices after the all-reduce, pgp_settle_best_device): one block finds the arg-max key
 // and settles near-ties with this device's copy of the clouds and the full transform list.
-__global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs a, int n_h, int mode, int refine,
+__global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs /* read through score_args_in_kernarg() */, int n_h, int mode, int refine,
                                                           float* scores, int* __restrict__ best,
-                                                          float* __restrict__ seq) {
+                                                          float* __restrict__ seq, int nQ) {
   __shared__ unsigned long long s_key[4], s_key2[4];
   unsigned long long key = 0, key2 = 0;   // this thread's best and second-best keys (keys > 0 are unique: they carry h)
   // sixteen scores per thread in flight: ONE block walks the complete vector of a device group (65 536 scores at configs[3]),
@@ -1610,9 +1674,9 @@ __global__ __launch_bounds__(256) void settle_best_kernel(ScoreArgs a, int n_h, 
   // runner-up is within it -- the same decision finalize_scores takes from its two keys
   const bool near_tie = mode == PGP_MODE_WEIGHTED && refine && key != 0ull && key2 != 0ull &&
                         __uint_as_float((unsigned)(key2 >> 32)) >=
-                            __uint_as_float((unsigned)(key >> 32)) - refine_tol(__uint_as_float((unsigned)(key >> 32)), a.nQ);
+                            __uint_as_float((unsigned)(key >> 32)) - refine_tol(__uint_as_float((unsigned)(key >> 32)), nQ);
   if (near_tie) {
-    settle_and_publish(a, n_h, mode, refine, scores, key, best, seq, s_key);
+    settle_and_publish(score_args_in_kernarg(), n_h, mode, refine, scores, key, best, seq, s_key);
   } else if (threadIdx.x == 0) {
     if (key == 0) {
       best[0] = -1;
@@ -1978,8 +2042,9 @@ void gate_thresholds(float gate_deg, float* c_aligned_min, float* c_anti_max) {
 }
 
 int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
-                 float* d_scores, int* d_counts, int* d_best, hipStream_t stream) {
+                 float* d_scores, int* d_counts, int* d_best, hipStream_t stream, ScoreHostOut* host) {
   ScoreArgs a{};
+  if (host) host->published = false;
   int rc = await_index(ctx, stream);
   if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
@@ -2085,7 +2150,9 @@ int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_d
                        mode, ctx->refine_best ? 1 : 0, d_scores,
                        d_counts ? d_counts : (ctx->verify_early_out && mode == PGP_MODE_PLAIN ? ctx->d_counts.as<int>() : nullptr),
                        key, key + 3, ticket,
-                       d_best ? d_best : best_local, ctx->d_seq.as<float>());
+                       d_best ? d_best : best_local, ctx->d_seq.as<float>(),
+                       host ? HostPub{host->scores, host->counts, host->best, host->flag, host->flag_value} : HostPub{});
+    if (host) host->published = true;
   } else {
     hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best ? d_best : best_local);
   }
@@ -2128,7 +2195,7 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
   if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
   hipLaunchKernelGGL(settle_best_kernel, dim3(1), dim3(256), 0, stream, a, n_h, mode, ctx->refine_best ? 1 : 0,
-                     d_scores, d_best, ctx->d_seq.as<float>());
+                     d_scores, d_best, ctx->d_seq.as<float>(), a.nQ);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

@@ -345,6 +345,11 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
         return r;
     }
     t_enq = now_ms();
+    // home: by ONE kernel and a completion word while the arrays are small (pgp::publish_and_wait), else two copies and the stream
+    const PubItem items[2] = {{d_s, pin_out, (size_t)N * 8}, {d_b, pin_out + (size_t)N * 8, (size_t)n_obj * 8}};
+    const PubItem* first = N > 0 ? items : items + 1;
+    const int n_items = N > 0 ? 2 : 1;
+    if (publish_usable(first, n_items)) return publish_and_wait(m->octx[0][0], st, first, n_items);
     if (N > 0) PGP_HIP(hipMemcpyAsync(pin_out, d_s, (size_t)N * 8, hipMemcpyDeviceToHost, st));
     PGP_HIP(hipMemcpyAsync(pin_out + (size_t)N * 8, d_b, (size_t)n_obj * 8, hipMemcpyDeviceToHost, st));
     PGP_HIP(hipStreamSynchronize(st));
@@ -500,9 +505,9 @@ int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) 
     // member 0 holds ALL transforms (it settles near-ties across slices); the others copy their slice only, to the
     // place it has in the flat list (64 B per hypothesis: 4 MB at 65 536 -- every device over its own PCIe link)
     const size_t a = k == 0 ? 0 : (size_t)lo * 64, b = k == 0 ? nT : (size_t)hi * 64;
-    if (b > a)
-      PGP_HIP(hipMemcpyAsync(m->d_T[k].as<unsigned char>() + a, static_cast<unsigned char*>(m->h_pin) + a, b - a,
-                             hipMemcpyHostToDevice, m->stream[k]));
+    // (out of the portable pinned image by a kernel on the member's stream: no copy-engine hand-over in front of the scoring)
+    if (b > a && (r = stage_to_device(m->stream[k], m->d_T[k].as<unsigned char>() + a, static_cast<unsigned char*>(m->h_pin) + a, b - a)) != PGP_OK)
+      return r;
     return PGP_OK;
   });
   if (rc != PGP_OK) m->off.assign(2, 0);   // nothing usable is resident: a later *_uploaded call scores the empty batch

@@ -3,6 +3,8 @@
 
 #include "pgp_internal.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -82,6 +84,8 @@ struct DeviceGuard {
 struct CtxGuard : DeviceGuard {
   // join = false for the *_device entry points themselves: they queue on the caller's stream, behind whatever
   // the caller queued there before, and must not synchronise anything while the caller may be capturing a graph
+  // (A call that returned on a completion WORD in host memory -- pgp_score_lcp, pgp::publish_and_wait -- leaves a kernel that
+  //  has made its last memory access and is merely retiring: nothing to order against.)
   explicit CtxGuard(pgp_ctx* ctx, bool join = true) : DeviceGuard(ctx->device) {
     if (join && ok && ctx->device_work_pending) {
       (void)hipDeviceSynchronize();
@@ -213,6 +217,11 @@ int pgp_destroy(pgp_ctx* ctx) {
     hipError_t e = hipHostFree(ctx->h_pin);
     (void)e;
     ctx->h_pin = nullptr;
+  }
+  if (ctx->h_flag) {
+    hipError_t e = hipHostFree(ctx->h_flag);
+    (void)e;
+    ctx->h_flag = nullptr;
   }
   if (ctx->h_out) {
     hipError_t e = hipHostFree(ctx->h_out);
@@ -385,8 +394,13 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
   }
   if ((rc = ctx->d_P.ensure(bytes)) != PGP_OK) return rc;
   if ((rc = ctx->d_Pnw.ensure(bytes)) != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(ctx->d_P.p, hp, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
-  PGP_HIP(hipMemcpyAsync(ctx->d_Pnw.p, hn, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  if (staged) {   // (out of the pinned image: by a kernel on the stream, no copy-engine hand-over in front of the next launch)
+    if ((rc = stage_to_device(ctx->stream, ctx->d_P.p, hp, (size_t)n * sizeof(float4))) != PGP_OK) return rc;
+    if ((rc = stage_to_device(ctx->stream, ctx->d_Pnw.p, hn, (size_t)n * sizeof(float4))) != PGP_OK) return rc;
+  } else {
+    PGP_HIP(hipMemcpyAsync(ctx->d_P.p, hp, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    PGP_HIP(hipMemcpyAsync(ctx->d_Pnw.p, hn, (size_t)n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+  }
   ctx->scene_upload_pending = false;
   if (staged) {
     PGP_HIP(hipEventRecord(ctx->ev_s, ctx->stream));
@@ -447,9 +461,9 @@ int pgp_set_scene_weights(pgp_ctx* ctx, const float* weight, int n) {
     cdf[i] = run;
   }
   ctx->prob_cdf_valid = false;
-  PGP_HIP(hipMemcpyAsync(ctx->d_pre_io.p, pin, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = stage_to_device(ctx->stream, ctx->d_pre_io.p, pin, (size_t)n * 4)) != PGP_OK) return rc;
   if ((rc = launch_scene_weights(ctx, ctx->d_pre_io.as<float>(), n, ctx->stream)) != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(ctx->d_prob_cdf.p, cdf, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream));
+  if ((rc = stage_to_device(ctx->stream, ctx->d_prob_cdf.p, cdf, (size_t)n * 8)) != PGP_OK) return rc;
   PGP_HIP(hipEventRecord(ctx->ev_w, ctx->stream));
   ctx->prob_cdf_valid = true;
   return PGP_OK;
@@ -521,11 +535,129 @@ int pgp_set_model(pgp_ctx* ctx, const float* xyz, const float* nrm, int n) {
   return PGP_OK;
 }
 
+static int reserve_impl(pgp_ctx* ctx, int max_hypotheses);
+
+}  // extern "C"
+
+namespace pgp {
+namespace {
+// n16 16-byte vectors, then n_tail (< 4) words
+__global__ __launch_bounds__(256) void stage_from_host(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16, int n_tail) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) dst[i] = src[i];
+  else if (i < n16 + (size_t)n_tail)
+    reinterpret_cast<uint32_t*>(dst + n16)[i - n16] = reinterpret_cast<const uint32_t*>(src + n16)[i - n16];
+}
+
+struct PubArgs {
+  const uint32_t* src[kPubMaxItems];
+  uint32_t* dst[kPubMaxItems];
+  uint32_t words[kPubMaxItems];
+  int n;
+  unsigned int* flag;
+  unsigned int value;
+};
+// one workgroup: the items word by word into host memory (system-scope stores: written through, acknowledged), then the word
+// the host polls
+__global__ __launch_bounds__(1024) void publish_items(PubArgs p) {
+  for (int k = 0; k < p.n; ++k) {
+    const uint32_t* __restrict__ s = p.src[k];
+    uint32_t* d = p.dst[k];
+    const uint32_t nw = p.words[k];
+    if ((((uintptr_t)s | (uintptr_t)d) & 7u) == 0) {   // two words per store
+      const unsigned long long* __restrict__ s2 = reinterpret_cast<const unsigned long long*>(s);
+      unsigned long long* d2 = reinterpret_cast<unsigned long long*>(d);
+      for (uint32_t i = threadIdx.x; i < nw / 2; i += 1024u) __hip_atomic_store(&d2[i], s2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((nw & 1u) && threadIdx.x == 0) __hip_atomic_store(&d[nw - 1], s[nw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      for (uint32_t i = threadIdx.x; i < nw; i += 1024u) __hip_atomic_store(&d[i], s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(p.flag, p.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+bool publish_usable(const PubItem* items, int n) {
+  static const bool off = getenv("PGP_HOSTOUT_KERNEL") && atoi(getenv("PGP_HOSTOUT_KERNEL")) == 0;
+  if (off || n <= 0 || n > kPubMaxItems) return false;
+  size_t total = 0;
+  for (int k = 0; k < n; ++k) {
+    if (((reinterpret_cast<uintptr_t>(items[k].d_src) | reinterpret_cast<uintptr_t>(items[k].h_dst) | items[k].bytes) & 3u) != 0) return false;
+    total += items[k].bytes;
+  }
+  return total <= kPubMaxBytes;
+}
+
+// Queues the publishing kernel behind whatever `st` holds and waits for its completion word.  The word is the context's
+// (one wait at a time per context); a wait that runs past a generous bound falls back to the stream itself.
+int publish_and_wait(pgp_ctx* ctx, hipStream_t st, const PubItem* items, int n) {
+  if (!ctx->h_flag) {
+    PGP_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_flag), 64, hipHostMallocDefault));
+    *ctx->h_flag = 0u;
+  }
+  PubArgs a{};
+  a.n = n;
+  for (int k = 0; k < n; ++k) {
+    a.src[k] = static_cast<const uint32_t*>(items[k].d_src);
+    a.dst[k] = static_cast<uint32_t*>(items[k].h_dst);
+    a.words[k] = (uint32_t)(items[k].bytes / 4);
+  }
+  a.flag = ctx->h_flag;
+  a.value = ++ctx->flag_seq ? ctx->flag_seq : ++ctx->flag_seq;
+  hipLaunchKernelGGL(publish_items, dim3(1), dim3(1024), 0, st, a);
+  PGP_HIP(hipGetLastError());
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(250);
+  for (unsigned spins = 0;; ++spins) {
+    if (__atomic_load_n(ctx->h_flag, __ATOMIC_ACQUIRE) == a.value) {
+      return PGP_OK;
+    }
+    __builtin_ia32_pause();
+    if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() >= t_end) break;
+  }
+  PGP_HIP(hipStreamSynchronize(st));
+  if (__atomic_load_n(ctx->h_flag, __ATOMIC_ACQUIRE) != a.value) {
+    set_error("publish_and_wait: the stream finished without the completion word");
+    return PGP_EHIP;
+  }
+  return PGP_OK;
+}
+
+// Small inputs on their way from a PINNED host image to the device, fetched by a KERNEL on the stream that is about to use
+// them instead of a copy-engine transfer in front of that stream's kernels: the hand-over from the copy engine to the compute
+// queue costs ~15 us whatever the size (tools/per_call_probe.py: the 4096-hypothesis host-pointer call 140 -> 126 us, the
+// 1024-hypothesis one 70 -> 55 us; profiles/r06_ab/stage_kernel.log), a kernel behind a kernel ~2.5 us.  Up to 2 MB (a
+// kernel reads host memory at PCIe speed like the engine does, but occupies compute units while it waits); beyond that,
+// unaligned, or with PGP_STAGE_KERNEL=0: hipMemcpyAsync as before.
+int stage_to_device(hipStream_t st, void* d_dst, const void* h_pinned, size_t bytes) {
+  if (bytes == 0) return PGP_OK;
+  static const bool off = getenv("PGP_STAGE_KERNEL") && atoi(getenv("PGP_STAGE_KERNEL")) == 0;
+  const bool aligned = ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(h_pinned)) & 15u) == 0 && (bytes & 3u) == 0;
+  if (off || !aligned || bytes > (2u << 20)) {
+    PGP_HIP(hipMemcpyAsync(d_dst, h_pinned, bytes, hipMemcpyHostToDevice, st));
+    return PGP_OK;
+  }
+  const size_t n16 = bytes / 16;
+  const int n_tail = (int)((bytes & 15u) / 4);
+  hipLaunchKernelGGL(stage_from_host, dim3((unsigned)((n16 + (size_t)n_tail + 255) / 256)), dim3(256), 0, st,
+                     static_cast<const uint4*>(h_pinned), static_cast<uint4*>(d_dst), n16, n_tail);
+  PGP_HIP(hipGetLastError());
+  return PGP_OK;
+}
+}  // namespace pgp
+
+extern "C" {
+
 int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
   if (!ctx || max_hypotheses < 0) {
     set_error("pgp_reserve: bad argument");
     return PGP_EINVAL;
   }
+  return reserve_impl(ctx, max_hypotheses);
+}
+
+static int reserve_impl(pgp_ctx* ctx, int max_hypotheses) {
   CtxGuard guard(ctx);
   if (int rc = flush_deferred_build(ctx)) return rc;
   if (ctx->index_pending && hipEventQuery(ctx->ev_index) == hipSuccess) {
@@ -545,8 +677,8 @@ int pgp_reserve(pgp_ctx* ctx, int max_hypotheses) {
   if ((rc = ctx->d_scores.ensure(cap * sizeof(float))) != PGP_OK) return rc;
   if ((rc = ctx->d_counts.ensure(cap * sizeof(int))) != PGP_OK) return rc;
   if ((rc = ctx->d_eo_ws.ensure(cap * sizeof(int) + 64)) != PGP_OK) return rc;
-  if ((rc = ctx->d_acc.ensure(cap * 16)) != PGP_OK) return rc;
-  PGP_HIP(hipMemset(ctx->d_acc.p, 0, cap * 16));
+  if ((rc = ctx->d_acc.ensure(cap * 16 + 256)) != PGP_OK) return rc;   // the near word + one ticket per chunk (<= cap / 2 + 2)
+  PGP_HIP(hipMemset(ctx->d_acc.p, 0, cap * 16 + 256));
   ctx->cap_h = max_hypotheses;
   return PGP_OK;
 }
@@ -649,17 +781,33 @@ int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_de
     set_error("pgp_score_lcp: bad argument");
     return PGP_EINVAL;
   }
+  // PGP_CALL_PHASES=1: where a call's wall time goes, printed to stderr every 100 calls (diagnostic)
+  static const bool phases = getenv("PGP_CALL_PHASES") != nullptr;
+  static thread_local double ph_acc[8] = {0};
+  static thread_local int ph_n = 0;
+  double ph_t = 0.0;
+  int ph_k = 0;
+  auto ph_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  auto ph_mark = [&] {
+    if (!phases) return;
+    const double t = ph_now();
+    if (ph_k > 0) ph_acc[ph_k - 1] += t - ph_t;
+    ph_t = t;
+    ++ph_k;
+  };
+  ph_mark();
   CtxGuard guard(ctx);
-  int rc = pgp_reserve(ctx, n_h);
+  int rc = reserve_impl(ctx, n_h);
   if (rc != PGP_OK) return rc;
   hipStream_t st = ctx->stream;
+  ph_mark();   // [0] guard + reserve
   // The caller's arrays are pageable (std::vector storage in the node): copying them through a
   // pinned staging buffer of our own makes the two transfers plain DMA (one H2D, ONE D2H of
   // scores | counts | best) instead of the runtime's chunked pageable path -- 199 -> ~150 us per
   // 4096-hypothesis call.
   const size_t nT = (size_t)n_h * 16 * sizeof(float);
   const size_t out_bytes = (size_t)n_h * 8 + 8;
-  const size_t pin_need = nT + out_bytes + 64;
+  const size_t pin_need = nT + out_bytes + 64 + 256;   // + {index, score bits, near, spare} and the completion word
   if (pin_need > ctx->h_pin_cap) {
     if (ctx->h_pin) {
       hipError_t e = hipHostFree(ctx->h_pin);
@@ -679,21 +827,78 @@ int pgp_score_lcp(pgp_ctx* ctx, const float* T, int n_h, int mode, float gate_de
   int* d_best = d_counts + n_h;
   if (n_h > 0) {
     std::memcpy(pin, T, nT);
-    PGP_HIP(hipMemcpyAsync(ctx->d_T.p, pin, nT, hipMemcpyHostToDevice, st));
+    ph_mark();   // [1] transforms into the pinned image
+    if ((rc = stage_to_device(st, ctx->d_T.p, pin, nT)) != PGP_OK) return rc;
+    ph_mark();   // [2] H2D queued
   }
-  rc = launch_score(ctx, ctx->d_T.as<float>(), n_h, mode, gate_deg, d_scores, d_counts, d_best, st);
+  // The results' way back.  finalize_scores writes scores, counts and the best straight into the pinned landing area, and a
+  // completion word behind them (lcp_score.hip HostPub): no device-to-host copy (a DMA of its own behind the kernel: ~10 us
+  // whatever its size) and no wait for the end-of-kernel signal -- the host polls the word.  The opt-in passes over the score
+  // vector (exact records, Verify's early termination), a weighted near-tie settled on the device and PGP_HOST_RESULTS=0
+  // copy back as before.
+  static const bool host_results = !(getenv("PGP_HOST_RESULTS") && atoi(getenv("PGP_HOST_RESULTS")) == 0);
+  unsigned char* pin_tail = pin_out + ((out_bytes + 63) & ~(size_t)63);
+  ScoreHostOut ho{};
+  ho.scores = reinterpret_cast<float*>(pin_out);
+  ho.counts = reinterpret_cast<int*>(pin_out + (size_t)n_h * 4);
+  ho.best = reinterpret_cast<int*>(pin_tail);
+  ho.flag = reinterpret_cast<unsigned int*>(pin_tail + 64);
+  ho.flag_value = ++ctx->flag_seq ? ctx->flag_seq : ++ctx->flag_seq;   // never 0
+  const bool want_host = host_results && n_h > 0 && !ctx->exact_records && !(ctx->verify_early_out && mode == PGP_MODE_PLAIN);
+  if (want_host) {
+    // (the word must not hold this call's value from the area's earlier life: the area is re-allocated when it grows)
+    __atomic_store_n(ho.flag, 0u, __ATOMIC_RELAXED);
+  }
+  rc = launch_score(ctx, ctx->d_T.as<float>(), n_h, mode, gate_deg, d_scores, d_counts, d_best, st, want_host ? &ho : nullptr);
   if (rc != PGP_OK) return rc;
-  PGP_HIP(hipMemcpyAsync(pin_out, d_scores, out_bytes, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  ph_mark();     // [3] kernels queued
+  bool via_host = want_host && ho.published;
+  if (via_host) {
+    ph_mark();   // [4] (no copy to queue)
+    // the kernel's own launch is ~0.1 ms per 4096 hypotheses; past a generous bound the stream is asked instead
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(20 + n_h / 64);
+    bool seen = false;
+    for (unsigned spins = 0;; ++spins) {
+      if (__atomic_load_n(ho.flag, __ATOMIC_ACQUIRE) == ho.flag_value) {
+        seen = true;
+        break;
+      }
+      __builtin_ia32_pause();
+      if ((spins & 1023u) == 1023u && std::chrono::steady_clock::now() >= t_end) break;
+    }
+    if (!seen) {
+      PGP_HIP(hipStreamSynchronize(st));
+      if (__atomic_load_n(ho.flag, __ATOMIC_ACQUIRE) != ho.flag_value) {
+        set_error("pgp_score_lcp: the scoring launch finished without publishing its results");
+        return PGP_EHIP;
+      }
+    }
+    ph_mark();   // [5] the wait
+    if (ho.best[2] != 0) via_host = false;   // weighted near-tie (rare): settled on the device, its arrays come the old way
+  }
+  if (!via_host) {
+    PGP_HIP(hipMemcpyAsync(pin_out, d_scores, out_bytes, hipMemcpyDeviceToHost, st));
+    ph_mark();     // [4] D2H queued
+    PGP_HIP(hipStreamSynchronize(st));
+      ph_mark();     // [5] the wait
+  }
   if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   if (n_h > 0) {
     std::memcpy(scores, pin_out, (size_t)n_h * sizeof(float));
     if (counts) std::memcpy(counts, pin_out + (size_t)n_h * 4, (size_t)n_h * sizeof(int));
   }
   int best[2];
-  std::memcpy(best, pin_out + (size_t)n_h * 8, sizeof best);
+  std::memcpy(best, via_host ? pin_tail : pin_out + (size_t)n_h * 8, sizeof best);
   if (best_index) *best_index = best[0];
   if (best_score) std::memcpy(best_score, &best[1], 4);
+  ph_mark();     // [6] results out of the pinned image
+  if (phases && ++ph_n == 100) {
+    fprintf(stderr, "pgp_score_lcp phases (us, mean of 100 calls, n_h %d): reserve %.1f | stage T %.1f | queue H2D %.1f | queue kernels %.1f | "
+                    "queue D2H %.1f | wait %.1f | copy out %.1f\n", n_h, ph_acc[0] / 100, ph_acc[1] / 100, ph_acc[2] / 100, ph_acc[3] / 100,
+            ph_acc[4] / 100, ph_acc[5] / 100, ph_acc[6] / 100);
+    for (double& a : ph_acc) a = 0;
+    ph_n = 0;
+  }
   return PGP_OK;
 }
 
@@ -1376,7 +1581,7 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   int* d_b = ctx->d_ids.as<int>();
   int* d_pk = d_b + 4 * N;
   int* d_q = d_pk + ((2 * N + 3) & ~(size_t)3);   // (int4 records: 16-byte aligned)
-  PGP_HIP(hipMemcpyAsync(d_b, hb, in_bytes, hipMemcpyHostToDevice, st));
+  if ((rc = stage_to_device(st, d_b, hb, in_bytes)) != PGP_OK) return rc;
   rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st, reinterpret_cast<const int2*>(d_pk));
   if (rc != PGP_OK) return rc;
   double* d_pose = ctx->d_rig.as<double>();
@@ -1403,8 +1608,18 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   PGP_HIP(hipGetLastError());
   if (nQ > 0 && (rc = launch_registered(ctx, d_T_out + 16 * C, mode, gate_deg, d_hits, st)) != PGP_OK) return rc;
   unsigned char* pin_out = pin + ((in_bytes + 63) & ~(size_t)63);
-  PGP_HIP(hipMemcpyAsync(pin_out, dev + off_best, home, hipMemcpyDeviceToHost, st));
-  PGP_HIP(hipStreamSynchronize(st));
+  {
+    // one kernel brings everything home and writes the word the host polls (pgp::publish_and_wait); the build that was put
+    // off goes to its stream first, as before any wait of the host
+    if (ctx->deferred_build && (rc = flush_deferred_build(ctx)) != PGP_OK) return rc;
+    const PubItem item{dev + off_best, pin_out, home};
+    if (publish_usable(&item, 1)) {
+      if ((rc = publish_and_wait(ctx, st, &item, 1)) != PGP_OK) return rc;
+    } else {
+      PGP_HIP(hipMemcpyAsync(pin_out, dev + off_best, home, hipMemcpyDeviceToHost, st));
+      PGP_HIP(hipStreamSynchronize(st));
+    }
+  }
   if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   const unsigned char* h = pin_out - off_best;   // (offsets as on the device)
   int best[2], lst[2];
@@ -1631,7 +1846,7 @@ int icp_host_stage(pgp_ctx* ctx, const float* src_xyz, int n_src, const float* t
   g.d_energy = reinterpret_cast<float*>(dev + g.off_e);
   g.d_iters = reinterpret_cast<int*>(dev + g.off_i);
   g.token = tok;
-  PGP_HIP(hipMemcpyAsync(dev, pin, g.off_e, hipMemcpyHostToDevice, st));
+  if ((rc = stage_to_device(st, dev, pin, g.off_e)) != PGP_OK) return rc;
   *out = g;
   return PGP_OK;
 }

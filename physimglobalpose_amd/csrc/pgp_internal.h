@@ -73,6 +73,9 @@ struct pgp_ctx {
   // a *_device call returns with its kernels still queued on the caller's stream; the next host-pointer
   // entry point drains the device before it touches the context's arrays (pgp_api.hip CtxGuard)
   bool device_work_pending = false;
+  // completion words in host memory (lcp_score.hip HostPub, pgp_api.hip publish_and_wait): the value the next wait looks for
+  unsigned int flag_seq = 0;
+  unsigned int* h_flag = nullptr;   // pinned completion word of pgp::publish_and_wait
 
   // scene
   int nP = 0;
@@ -194,7 +197,7 @@ struct pgp_ctx {
   int cap_h = 0;
   pgp::DevBuf d_T;        // staged transforms (host API)            [cap_h*16] float
   pgp::DevBuf d_partial;  // per (tile, hypothesis) partials          [n_tiles*cap_h] int2/float
-  pgp::DevBuf d_acc;      // fused finalisation (lcp_score.hip PGP_FUSED): 2 x cap_h accumulator words, zero between launches
+  pgp::DevBuf d_acc;      // fused finalisation (lcp_score.hip FuseArgs): the near word, then one ticket per chunk, zero between launches
   pgp::DevBuf d_scores;   // [cap_h] float
   pgp::DevBuf d_counts;   // [cap_h] int
   pgp::DevBuf d_best;     // 2 x uint64 packed argmax + {index, score bits}
@@ -248,6 +251,8 @@ struct pgp_ctx {
 namespace pgp {
 
 int flush_deferred_build(pgp_ctx* ctx);   // grid_index.hip
+// pgp_api.hip: a small input from a PINNED host image to the device by a kernel on `st` (no copy-engine hand-over)
+int stage_to_device(hipStream_t st, void* d_dst, const void* h_pinned, size_t bytes);
 
 // Small results on their way to the caller's memory.  A device-to-host copy into PAGEABLE memory keeps the host 12 us
 // longer than one into pinned memory, whatever its size (tools/copy_cost.hip on the bench box: 24.4 against 12.2 us for
@@ -258,16 +263,31 @@ int flush_deferred_build(pgp_ctx* ctx);   // grid_index.hip
 // discipline (a callee's HostOut sits above its caller's); results beyond the area's room, or all of them when the area
 // cannot be allocated, are copied straight to their destination as before.  Leaving the scope without sync() drops the
 // pending deliveries (the error paths).
+// (pgp_api.hip) One kernel that copies up to 8 small device arrays into PINNED host memory and writes a completion word
+// behind them, and the host's wait for that word: see HostOut::sync.
+struct PubItem {
+  const void* d_src;
+  void* h_dst;      // pinned
+  size_t bytes;     // a multiple of 4, both ends 4-byte aligned
+};
+constexpr int kPubMaxItems = 8;
+constexpr size_t kPubMaxBytes = 96u << 10;
+bool publish_usable(const PubItem* items, int n);
+int publish_and_wait(pgp_ctx* ctx, hipStream_t st, const PubItem* items, int n);
+
 struct HostOut {
   static constexpr size_t kArea = 1u << 20, kMaxItems = 8;
   pgp_ctx* ctx;
   hipStream_t st;
   size_t mark;
   struct Item {
-    void* dst;
+    void* dst;          // NULL: fetch() -- the caller reads the landing area itself
     size_t off, n;
-  } items[kMaxItems];
+    const void* d_src;
+    unsigned char* spill;   // fetch() without room in the area: a pageable landing buffer
+  } items[kMaxItems + 4];
   int n_items = 0;
+  bool direct = false;      // a copy straight into the caller's memory has been queued: the stream itself must be waited for
   std::vector<std::vector<unsigned char>> spill;   // fetch() without room in the area: pageable landing buffers of its own
 
   HostOut(pgp_ctx* c, hipStream_t s) : ctx(c), st(s), mark(c->h_out_used) {}
@@ -290,27 +310,39 @@ struct HostOut {
     ctx->h_out_used += need;
     return p;
   }
+  // The copies are QUEUED BY sync(), not here: every caller's pattern is kernels -> to() ... -> sync() with nothing
+  // launched in between, and sync() can then bring all of them home with ONE kernel (below).
   int to(void* dst, const void* d_src, size_t bytes) {
     if (bytes == 0) return PGP_OK;
     unsigned char* p = n_items < (int)kMaxItems ? room(bytes) : nullptr;
     if (!p) {
       PGP_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st));
+      direct = true;
       return PGP_OK;
     }
-    PGP_HIP(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, st));
-    items[n_items++] = Item{dst, (size_t)(p - static_cast<unsigned char*>(ctx->h_out)), bytes};
+    items[n_items++] = Item{dst, (size_t)(p - static_cast<unsigned char*>(ctx->h_out)), bytes, d_src, nullptr};
     return PGP_OK;
   }
   int fetch(const unsigned char** where, const void* d_src, size_t bytes) {
-    unsigned char* p = room(bytes);
+    unsigned char* p = n_items < (int)kMaxItems ? room(bytes) : nullptr;
     if (!p) {
       spill.emplace_back(bytes ? bytes : 1);
       p = spill.back().data();
+      *where = p;
+      if (bytes) {
+        PGP_HIP(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, st));
+        direct = true;
+      }
+      return PGP_OK;
     }
     *where = p;
-    if (bytes) PGP_HIP(hipMemcpyAsync(p, d_src, bytes, hipMemcpyDeviceToHost, st));
+    if (bytes) items[n_items++] = Item{nullptr, (size_t)(p - static_cast<unsigned char*>(ctx->h_out)), bytes, d_src, nullptr};
     return PGP_OK;
   }
+  // Results home after ONE wait.  Small results (<= 96 KB in all, word-aligned) are copied into the pinned area by ONE kernel
+  // on the stream, which writes a completion word behind them that the host polls (publish_and_wait): a copy-engine transfer
+  // behind a kernel and the stream's completion signal cost 10-15 us per wait, a kernel behind a kernel ~2.5 us
+  // (profiles/r06_ab/stage_kernel.log).  Anything else: one device-to-host copy per item and a stream synchronisation.
   int sync() {
     // (the host is about to wait: what it has put off issuing -- the scene's index build -- goes to its stream first and
     //  runs beside whatever this wait is for)
@@ -318,9 +350,21 @@ struct HostOut {
       const int rc = flush_deferred_build(ctx);
       if (rc != PGP_OK) return rc;
     }
-    PGP_HIP(hipStreamSynchronize(st));
-    for (int k = 0; k < n_items; ++k) std::memcpy(items[k].dst, static_cast<unsigned char*>(ctx->h_out) + items[k].off, items[k].n);
+    unsigned char* area = static_cast<unsigned char*>(ctx->h_out);
+    PubItem pub[kMaxItems + 4];
+    for (int k = 0; k < n_items; ++k) pub[k] = PubItem{items[k].d_src, area + items[k].off, items[k].n};
+    if (!direct && n_items > 0 && publish_usable(pub, n_items)) {
+      const int rc = publish_and_wait(ctx, st, pub, n_items);
+      if (rc != PGP_OK) return rc;
+    } else {
+      for (int k = 0; k < n_items; ++k)
+        PGP_HIP(hipMemcpyAsync(area + items[k].off, items[k].d_src, items[k].n, hipMemcpyDeviceToHost, st));
+      PGP_HIP(hipStreamSynchronize(st));
+    }
+    for (int k = 0; k < n_items; ++k)
+      if (items[k].dst) std::memcpy(items[k].dst, area + items[k].off, items[k].n);
     n_items = 0;
+    direct = false;
     return PGP_OK;
   }
 };
@@ -357,8 +401,19 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
 
 // lcp_score.hip
 int tiles_for(int nQ);
+// host (nullable): the caller wants the results in HOST memory as well, written by finalize_scores itself, with a completion
+// word behind them (lcp_score.hip HostPub).  `published` says on return whether the launch will do so (an empty batch does
+// not).  best[2] = 1: a weighted near-tie was settled on the device -- copy d_scores / d_counts / d_best back for that call.
+struct ScoreHostOut {
+  float* scores;
+  int* counts;
+  int* best;            // {index, score bits, settled-on-device, spare}
+  unsigned int* flag;
+  unsigned int flag_value;
+  bool published;
+};
 int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
-                 float* d_scores, int* d_counts, int* d_best, hipStream_t stream);
+                 float* d_scores, int* d_counts, int* d_best, hipStream_t stream, ScoreHostOut* host = nullptr);
 int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
                        int* d_best, hipStream_t stream);
 // the launches that follow on `stream` read the scene's index: orders them behind a build still running on
