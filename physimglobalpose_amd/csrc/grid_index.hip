@@ -32,6 +32,7 @@
 #include <mutex>
 
 #include "pgp_internal.h"
+#include "host_worker.h"
 
 #include <cfloat>
 #include <cmath>
@@ -552,13 +553,18 @@ static int build_index_async(pgp_ctx* ctx, const GridDesc& g, int r, float delta
       PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
       ctx->build_stream_own = true;
     } else {
-      static std::mutex mu;
-      static hipStream_t shared[64] = {};
-      const int dev = ctx->device >= 0 && ctx->device < 64 ? ctx->device : 0;
-      std::lock_guard<std::mutex> lk(mu);
-      if (!shared[dev]) PGP_HIP(hipStreamCreateWithFlags(&shared[dev], hipStreamNonBlocking));
-      ctx->build_stream = shared[dev];
-      ctx->build_stream_own = false;
+      static PerDeviceTable<hipStream_t> shared;   // (host_worker.h; never destroyed)
+      hipStream_t got = nullptr;
+      if (shared.get(ctx->device, [](hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking) == hipSuccess; }, &got)) {
+        ctx->build_stream = got;
+        ctx->build_stream_own = false;
+      } else {
+        // a device id beyond the table (or a stream that could not be created there): a stream of the context's own, never
+        // another device's
+        (void)hipGetLastError();
+        PGP_HIP(hipStreamCreateWithFlags(&ctx->build_stream, hipStreamNonBlocking));
+        ctx->build_stream_own = true;
+      }
     }
   }
   if (!ctx->ev_index) PGP_HIP(hipEventCreate(&ctx->ev_index));

@@ -24,6 +24,7 @@
 // production code path.  A test vehicle, never a performance configuration.
 
 #include "pgp_internal.h"
+#include "host_worker.h"
 
 #include <rccl/rccl.h>
 
@@ -85,74 +86,7 @@ bool load_rccl(Rccl* r) {
   return true;
 }
 
-// One host thread per device: runs the jobs posted to it with its device current.
-// Both hand-offs (caller -> worker, worker -> caller) first SPIN on an atomic flag for a short while and only then sleep
-// on the condition variable: a scoring call is ~0.1 ms of GPU work, and a futex wake-up costs 20-40 us each way -- calls
-// that come back to back (the node's per-object loop, the search's expansions) never sleep, an idle group costs no CPU.
-struct Worker {
-  int device = 0;
-  std::thread th;
-  std::mutex mu;
-  std::condition_variable cv;
-  std::function<int()> job;
-  std::atomic<bool> has_job{false}, done{true};
-  bool stop = false;
-  int rc = PGP_OK;
-  char err[512] = "";
-  static constexpr double kSpinWorkerMs = 0.2, kSpinCallerMs = 2.0;
-
-  template <class Pred>
-  static bool spin(double ms, Pred p) {
-    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration<double, std::milli>(ms);
-    for (;;) {
-      for (int i = 0; i < 64; ++i) {
-        if (p()) return true;
-        __builtin_ia32_pause();
-      }
-      if (std::chrono::steady_clock::now() >= t_end) return p();
-    }
-  }
-  void loop() {
-    (void)hipSetDevice(device);
-    for (;;) {
-      std::function<int()> j;
-      spin(kSpinWorkerMs, [&] { return has_job.load(std::memory_order_acquire); });
-      {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return has_job.load(std::memory_order_acquire) || stop; });
-        if (stop) return;
-        j = std::move(job);
-        has_job.store(false, std::memory_order_relaxed);
-      }
-      int r = j();
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        rc = r;
-        if (r != PGP_OK) {
-          std::strncpy(err, pgp_last_error(), sizeof err - 1);
-          err[sizeof err - 1] = 0;
-        }
-        done.store(true, std::memory_order_release);
-      }
-      cv.notify_all();
-    }
-  }
-  void post(std::function<int()> j) {
-    {
-      std::lock_guard<std::mutex> lk(mu);
-      job = std::move(j);
-      done.store(false, std::memory_order_relaxed);
-      has_job.store(true, std::memory_order_release);
-    }
-    cv.notify_all();
-  }
-  int wait() {
-    spin(kSpinCallerMs, [&] { return done.load(std::memory_order_acquire); });
-    std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return done.load(std::memory_order_acquire); });
-    return rc;
-  }
-};
+// (Worker: one host thread per device, csrc/host_worker.h -- HIP-free so that it also builds under ThreadSanitizer)
 
 double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -623,6 +557,8 @@ int create_group(pgp_multi** out, const int* device_ids, int n_dev, int rank0, i
   for (int k = 0; k < n_dev && rc == PGP_OK; ++k) {
     Worker* w = new Worker();
     w->device = m->dev[k];
+    w->on_start = [w] { (void)hipSetDevice(w->device); };
+    w->last_error = [] { return pgp_last_error(); };
     w->th = std::thread([w] { w->loop(); });
     m->worker.push_back(w);
   }
@@ -796,12 +732,7 @@ int pgp_multi_destroy(pgp_multi* m) {
     });
   }
   for (Worker* w : m->worker) {
-    {
-      std::lock_guard<std::mutex> lk(w->mu);
-      w->stop = true;
-    }
-    w->cv.notify_all();
-    if (w->th.joinable()) w->th.join();
+    w->shut_down();
     delete w;
   }
   if (m->h_pin) (void)hipHostFree(m->h_pin);

@@ -348,9 +348,14 @@ int pgp_set_scene(pgp_ctx* ctx, const float* xyz, const float* nrm, const float*
     set_error("pgp_set_scene: bad argument (n=%d, delta=%g)", n, (double)delta);
     return PGP_EINVAL;
   }
-  CtxGuard guard(ctx);
-  // *_device calls may still be queued on the caller's stream and read the arrays replaced below
-  PGP_HIP(hipDeviceSynchronize());
+  CtxGuard guard(ctx);   // (*_device calls still queued on a caller's stream read the arrays replaced below: the guard drains them)
+  // What else can still touch those arrays: the PREVIOUS scene's index build on the side stream (it reads the points) -- the
+  // uploads below are ordered behind it on the context's stream, where everything else that rewrites the scene is queued
+  // anyway.  (Up to round 5 an unconditional hipDeviceSynchronize stood here; behind a call that returned on its completion
+  // word -- the drop-in's last step -- it waited ~30 us for a kernel that had long made its last access to retire.)
+  static const bool sync_always = getenv("PGP_SET_SCENE_SYNC") && atoi(getenv("PGP_SET_SCENE_SYNC")) != 0;
+  if (sync_always) PGP_HIP(hipDeviceSynchronize());
+  else if (ctx->index_pending && ctx->ev_index && !ctx->deferred_build) PGP_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_index, 0));
   ctx->has_index = false;
   ctx->prob_cdf_valid = false;
   ctx->nP = n;

@@ -60,6 +60,8 @@
 #include "fast_inflate.h"
 #include "file_readers.h"
 #include "super4pcs_shim.h"
+#include "object_slots.h"
+#include "frame_pool.h"
 
 namespace {
 
@@ -71,122 +73,16 @@ using shimio::read_ply;
 using shimio::read_png_gray;
 using shimio::ascii_number;
 
-// ---------------------------------------------------------------------------------------------
-// Per-thread device state kept across calls: the context (and, with PGP_SHIM_DEVICES > 1, the
-// device group) and the flattened pair-feature table of the object that was matched last -- the
-// node hands the SAME std::map of an object to every request (PPE/data_layer/Objects.cpp:31-49 fills
-// it once), so its 10^4-10^5 keys are flattened and uploaded again only when a different map arrives:
-// different address, size, first / last entry (keys, pair counts, first pairs) or target context.  A caller
-// that rebuilds a map IN PLACE with the same size and the same two end entries would still be taken for the
-// old one: such callers set PGP_SHIM_NO_CACHE=1 (every call gets a fresh context and uploads its map).
-// ---------------------------------------------------------------------------------------------
-// One context PER OBJECT (the node loops over the objects of a frame, ObjectPoseCandidateSet.cpp:53-68 per object,
-// SceneCfg.cpp:379-402): an object's pair-feature table (5 MB at 18 682 keys: milliseconds to flatten, upload and
-// hash), its validation model (Morton sort + upload) and its search model stay resident in ITS context from frame
-// to frame, so that alternating objects do not evict each other; what a call uploads is the segment.  An object is
-// recognised by its PPFMap (address, size, fingerprint of its end entries); the models are compared by a hash of
-// their (centred) coordinates and re-sent only when they changed.  At most kSlots objects, least recently used out.
-struct ObjectSlot {
-  pgp_ctx* ctx = nullptr;
-  const void* map_addr = nullptr;
-  size_t map_size = 0;
-  unsigned long long map_print = 0;
-  bool map_loaded = false;
-  unsigned long long model_hash = 0, search_hash = 0;
-  unsigned long long stamp = 0;
-  std::mutex busy;   // held by the call that is matching this object (ShimState::acquire .. SlotLease)
-};
-// The state is the PROCESS's, not a thread's (it was thread-local up to round 5): whichever thread brings an object finds
-// its context -- a ROS callback on another spinner thread, the std::thread per object the reference's authors left
-// commented out around this call (SceneCfg.cpp:377,402-403, ObjectPoseCandidateSet.cpp:64-65), a worker of
-// getProbableTransformsSuper4PCSFrame.  Calls for different objects run side by side; two calls for the SAME object take
-// turns (the second waits for the first's lease).  Never destroyed: the contexts go with the process (no HIP call from
-// an exit handler or a thread-local destructor, which the profiler's tooling does not survive).
-struct ShimState {
-  static constexpr int kSlots = 16;
-  ObjectSlot slot[kSlots];
-  std::mutex mu;                      // guards the slots' identity fields and the clock
-  std::mutex single_mu;               // held for the length of a call that uses `ctx` / `group` below
-  unsigned long long clock = 0;
-  pgp_ctx* ctx = nullptr;             // several devices: the single context of older rounds
-  pgp_multi* group = nullptr;
-  const void* map_addr = nullptr;
-  size_t map_size = 0;
-  unsigned long long map_print = 0;   // fingerprint of the map's two end entries
-  const void* map_ctx = nullptr;      // the context the table was uploaded to
-  // the object's slot, leased to the caller (slot->busy held): its own from an earlier call, or the least recently used
-  // one that nobody is using, re-keyed (its context keeps its allocations)
-  ObjectSlot* acquire(const void* addr, size_t size, unsigned long long print) {
-    for (;;) {
-      ObjectSlot* pick = nullptr;
-      bool mine = false;
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        for (ObjectSlot& o : slot)
-          if (o.map_addr == addr && o.map_size == size && o.map_print == print && (o.ctx || o.stamp)) {
-            pick = &o;
-            mine = true;
-            break;
-          }
-        if (!pick) {
-          ObjectSlot* lru = nullptr;
-          for (ObjectSlot& o : slot) {
-            if (!o.busy.try_lock()) continue;
-            if (!lru || o.stamp < lru->stamp) {
-              if (lru) lru->busy.unlock();
-              lru = &o;
-            } else {
-              o.busy.unlock();
-            }
-          }
-          if (lru) {
-            lru->map_addr = addr;
-            lru->map_size = size;
-            lru->map_print = print;
-            lru->map_loaded = false;
-            lru->model_hash = lru->search_hash = 0;
-            lru->stamp = ++clock;
-            return lru;
-          }
-          pick = &slot[0];   // every slot is in use: wait for the least recently used one
-          for (ObjectSlot& o : slot)
-            if (o.stamp < pick->stamp) pick = &o;
-        }
-      }
-      pick->busy.lock();
-      {
-        std::lock_guard<std::mutex> lk(mu);
-        const bool still = pick->map_addr == addr && pick->map_size == size && pick->map_print == print;
-        if (mine && still) {
-          pick->stamp = ++clock;
-          return pick;
-        }
-        if (!mine) {   // waited for a victim: it is free now, take it over
-          pick->map_addr = addr;
-          pick->map_size = size;
-          pick->map_print = print;
-          pick->map_loaded = false;
-          pick->model_hash = pick->search_hash = 0;
-          pick->stamp = ++clock;
-          return pick;
-        }
-      }
-      pick->busy.unlock();   // the object's slot was given away while this call waited for it: look again
-    }
-  }
-  ~ShimState() {   // (only a call's own state under PGP_SHIM_NO_CACHE is ever destroyed)
-    if (group) pgp_multi_destroy(group);
-    if (ctx) pgp_destroy(ctx);
-    for (ObjectSlot& o : slot)
-      if (o.ctx) pgp_destroy(o.ctx);
-  }
-};
-struct SlotLease {
-  ObjectSlot* s = nullptr;
-  ~SlotLease() {
-    if (s) s->busy.unlock();
-  }
-};
+// The per-object device state and its leases: shim/object_slots.h (ObjectSlot, ShimState::acquire, SlotLease) -- a header
+// without Eigen or HIP, so that `make -C shim tsan` runs the same code under ThreadSanitizer on a machine without a GPU.
+// The node hands the SAME std::map of an object to every request (PPE/data_layer/Objects.cpp:31-49 fills it once), so its
+// 10^4-10^5 keys are flattened and uploaded again only when a different map arrives: different address, size, first / last
+// entry (keys, pair counts, first pairs) or target context.  A caller that rebuilds a map IN PLACE with the same size and the
+// same two end entries would still be taken for the old one: such callers set PGP_SHIM_NO_CACHE=1 (every call gets a fresh
+// context and uploads its map).
+using shimstate::ObjectSlot;
+using shimstate::ShimState;
+using shimstate::SlotLease;
 static unsigned long long cloud_hash(const std::vector<float>& a, const std::vector<float>& b) {
   unsigned long long h0 = 0x9E3779B97F4A7C15ull ^ (unsigned long long)a.size(), h1 = 0xC2B2AE3D27D4EB4Full ^ (unsigned long long)b.size();
   const uint32_t* w = reinterpret_cast<const uint32_t*>(a.data());
@@ -480,67 +376,12 @@ void getProbableTransformsSuper4PCS(const Super4PCSCloudView& segment, const Sup
 // object), and the jobs' device work overlaps on their contexts' streams.  Same results as the jobs called one by one
 // (with a generator of the call's own for the quad sampling: PGP_SHIM_PRIVATE_RAND above).
 namespace {
-class FramePool {
- public:
-  static const int kWorkers = 8;
-  std::mutex use_mu;   // one frame at a time
-  static FramePool* get() {
-    static FramePool* pool = make();
-    return pool;
-  }
-  void start(int k, std::function<void()> fn) {
-    Worker& w = workers_[k];
-    {
-      std::lock_guard<std::mutex> lk(w.mu);
-      w.job = std::move(fn);
-      w.has_job = true;
-      w.done = false;
-    }
-    w.cv.notify_all();
-  }
-  void wait(int k) {
-    Worker& w = workers_[k];
-    std::unique_lock<std::mutex> lk(w.mu);
-    w.cv.wait(lk, [&] { return w.done; });
-  }
-
- private:
-  struct Worker {
-    std::mutex mu;
-    std::condition_variable cv;
-    std::function<void()> job;
-    bool has_job = false, done = true;
-  };
-  Worker workers_[kWorkers];
-  static FramePool* make() {
-    FramePool* p = new FramePool;   // never destroyed: the workers sleep on their condition variables until the process ends
-    try {
-      for (int k = 0; k < kWorkers; ++k) std::thread([p, k] { p->loop(k); }).detach();
-    } catch (...) {
-      return nullptr;   // (workers already started sleep for good; the frame is then matched job by job on the caller's thread)
-    }
-    return p;
-  }
-  void loop(int k) {
-    Worker& w = workers_[k];
-    t_private_rand = true;
-    for (;;) {
-      std::function<void()> fn;
-      {
-        std::unique_lock<std::mutex> lk(w.mu);
-        w.cv.wait(lk, [&] { return w.has_job; });
-        fn.swap(w.job);
-        w.has_job = false;
-      }
-      fn();
-      {
-        std::lock_guard<std::mutex> lk(w.mu);
-        w.done = true;
-      }
-      w.cv.notify_all();
-    }
-  }
-};
+// (the kept worker threads: shim/frame_pool.h, HIP- and Eigen-free for the ThreadSanitizer build)
+using shimstate::FramePool;
+FramePool* frame_pool() {
+  static FramePool* pool = FramePool::make([] { t_private_rand = true; });
+  return pool;
+}
 }  // namespace
 
 void getProbableTransformsSuper4PCSFrame(Super4PCSJob* jobs, int n_jobs) {
@@ -562,7 +403,7 @@ void getProbableTransformsSuper4PCSFrame(Super4PCSJob* jobs, int n_jobs) {
       q.failed = true;   // (what the single call would have thrown: bad_alloc; the other jobs of the frame are not lost)
     }
   };
-  FramePool* pool = n_jobs > 1 && !getenv("PGP_SHIM_FRAME_SERIAL") ? FramePool::get() : nullptr;
+  FramePool* pool = n_jobs > 1 && !getenv("PGP_SHIM_FRAME_SERIAL") ? frame_pool() : nullptr;
   if (!pool) {
     const bool before = t_private_rand;
     t_private_rand = true;
