@@ -163,6 +163,8 @@ struct IcpArgs {
   // repairs a lost meeting inside itself: workgroup 0 of the pose goes on alone.)
   unsigned* x_lost;              // [1] in the library's own workspace
   unsigned* x_done;              // [n] workgroups of the pose that have left: the last one zeroes the pose's counters for the next call
+  unsigned* x_abandon;           // [n] set by the first workgroup whose wait for a meeting ran out: the partners leave at once
+  unsigned wait_ticks;           // floor of every wait's clock bound (100 MHz ticks; launch_icp: 3 ms, PGP_ICP_WAIT_MS)
   int force_lost;                // test knob (PGP_ICP_FORCE_LOST): every pose's first meeting is declared lost
   float* T_save;                 // [n][16]: clustered launch: part 0 stores the pose's initial transform here
   const float* T_in;             // where a pose's initial transform is read (T itself, or T_save in the repair launch)
@@ -1246,6 +1248,7 @@ struct SceneArgs {
   int poll_sleep;             // s_sleep argument between two polls of a pose's state word
   int n_upd;                  // workgroups 0 .. n_upd-1 are updaters (pose p: updater p % n_upd), the rest workers
   int force_lost;             // test knob (PGP_ICP_FORCE_LOST): every pose's first wait for its units counts as run out
+  unsigned wait_ticks;        // floor of every wait's clock bound (100 MHz ticks; 3 ms, PGP_ICP_WAIT_MS)
   unsigned long long* dbg;    // PGP_SCENE_STAMPS builds: [64 iterations][16] clock stamps (100 MHz) of updater 0 and of three workers
 };
 #ifdef PGP_SCENE_STAMPS
@@ -1289,6 +1292,7 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
     // ================= updater =================
     __shared__ double s_blk[8][kRedPlane + 1];   // the block sums of one pass (eight blocks), formed by four waves
     __shared__ int s_upd[2];
+    unsigned long long upd_longest = 0;   // (thread 0) the longest wait for a pose's units that ended well, in ticks
     for (int it = 0;; ++it) {
       bool any = false;
       for (int pose = blockIdx.x; pose < a.n; pose += z.n_upd) {
@@ -1299,15 +1303,20 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
         // ---- every unit of the pose has arrived (their sums are in memory: written through before the arrival)
         const unsigned target = (unsigned)z.n_units * (unsigned)(it + 1);
         if (tid == 0) {
+          // The bound follows the WORK: 64 x the longest wait this updater has seen so far, a few milliseconds at least
+          // (z.wait_ticks).  An iteration is ~25 us; up to round 5 a fixed 2 s stood here -- with the workgroups of two
+          // processes each holding a part of the device, every lost wait cost the caller those 2 s.
           const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          const unsigned long long bound = max((unsigned long long)z.wait_ticks, 64ull * upd_longest);
           int lost = 0;
           while (agent_load(&z.pose_ctr[pose]) < target) {
             __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz: cannot happen with every workgroup resident
+            if (__builtin_amdgcn_s_memrealtime() - t0 > bound) {
               lost = 1;
               break;
             }
           }
+          if (!lost) upd_longest = max(upd_longest, __builtin_amdgcn_s_memrealtime() - t0);
           if (z.force_lost && it == 0) lost = 1;
           s_upd[0] = lost;
         }
@@ -1386,6 +1395,7 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
   // ================= worker =================
   const int items = a.n * z.n_chunks, n_work = (int)gridDim.x - z.n_upd, me = (int)blockIdx.x - z.n_upd;
   const unsigned* my_state = z.state + (size_t)(me % kSceneRep) * kSceneRepStride;
+  unsigned long long wrk_longest = 0;   // (thread 0) the longest wait for a state word that ended well, in ticks
   for (int it = 0;; ++it) {
     bool any = false;
     for (int item = me; item < items; item += n_work) {
@@ -1397,15 +1407,25 @@ __global__ __launch_bounds__(kSceneThreads) PGP_SCENE_ATTR void icp_scene_persis
       if (tid == 0) {
         unsigned st = 0;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        // (twice the updaters' floor: an updater that is there gives up -- and says so in the state word -- before its workers do)
+        const unsigned long long bound = max(2ull * (unsigned long long)z.wait_ticks, 64ull * wrk_longest);
         for (;;) {
           st = agent_load(&my_state[(size_t)pose * kSceneRep * kSceneRepStride]);
           if ((st >> 31) != 0u || (st & 0x7FFFFFFFu) >= (unsigned)it) break;
           for (int q = 0; q < z.poll_sleep; ++q) __builtin_amdgcn_s_sleep(8);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s: the updater reports it (it has lost the units, too)
+          if (__builtin_amdgcn_s_memrealtime() - t0 > bound) {
+            // The pose's updater is not there (its workgroup never became resident: another process holds the compute
+            // units): the pose is ABANDONED for everybody -- the state word says done in all its copies, so that no other
+            // worker (and no later item of this one) waits for it again, and the iteration count says lost (the host-pointer
+            // calls redo the job host-driven; an updater that turns up late finds the pose closed).
+            agent_store(z.lost, 1u);
+            if (a.iters) a.iters[pose] = -1;
+            for (int r = 0; r < kSceneRep; ++r) agent_store(&z.state[((size_t)pose * kSceneRep + r) * kSceneRepStride], 0x80000000u);
             st = 0x80000000u;
             break;
           }
         }
+        if ((st >> 31) == 0u) wrk_longest = max(wrk_longest, __builtin_amdgcn_s_memrealtime() - t0);
         s_flag[0] = (int)(st >> 31);
       }
       __syncthreads();
@@ -2373,7 +2393,7 @@ __device__ __forceinline__ void nn_all_queries(const IcpArgs& a, const NnLds& t,
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
       while (ld_agent(&a.help_done[help_pose]) < n_passes) {
         __builtin_amdgcn_s_sleep(1);
-        if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz
+        if (__builtin_amdgcn_s_memrealtime() - t0 > max(200000ull, 4ull * (unsigned long long)a.wait_ticks)) {   // (claimed passes are being worked on by RUNNING workgroups)
           if (lost) *lost = 1;
           break;
         }
@@ -2662,6 +2682,7 @@ __device__ __forceinline__ void cluster_leave(const IcpArgs& a, int pose, int ti
   const unsigned left = __hip_atomic_fetch_add(&a.x_done[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (left + 1u == (unsigned)a.wgs_per_pose) {
     __hip_atomic_store(&a.x_ctr[pose], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&a.x_abandon[pose], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(&a.x_done[pose], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -2699,9 +2720,13 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
   const int part = CLUSTER ? (int)blockIdx.x / a.n : 0, pose = (int)blockIdx.x - part * a.n;
   int n_share = nn_share_count(a.n_src, part, P);
   __shared__ int s_lost, s_solo;
+  __shared__ unsigned s_slowest;   // (thread 0) the slowest share / longest wait of the pose's meetings so far, in ticks
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float* Tg = a.T + 16 * (size_t)pose;
-  if (tid == 0) s_lost = s_solo = 0;
+  if (tid == 0) {
+    s_lost = s_solo = 0;
+    s_slowest = 0u;
+  }
 #if defined(PGP_ICP_STAMPS)
   const unsigned long long k_start = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -2762,10 +2787,20 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         // The grid fits the device (launch_resident: one workgroup per CU), so the partners arrive -- at once on an idle
         // device, as compute units come free behind somebody else's kernel; the clock bound turns a device that stays
         // taken for seconds into a pose finished by one workgroup instead of a hang.
+        // The bound follows the WORK: 64 x the slowest share of the previous meeting, a few
+        // milliseconds at least (a.wait_ticks) -- not the 2 s of round 5, which two processes holding half the device each
+        // could run into meeting after meeting.  And whoever runs out of it says so in the pose's ABANDON word, which every
+        // waiting partner polls: the late ones leave at once instead of spinning out a bound of their own.
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long bound = max((unsigned long long)a.wait_ticks, 64ull * (unsigned long long)s_slowest);
         while (__hip_atomic_load(&a.x_ctr[pose], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
           __builtin_amdgcn_s_sleep(1);
-          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {   // 2 s at 100 MHz
+          if (__hip_atomic_load(&a.x_abandon[pose], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            s_lost = 1;
+            break;
+          }
+          if (__builtin_amdgcn_s_memrealtime() - t0 > bound) {
+            __hip_atomic_store(&a.x_abandon[pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_lost = 1;
             break;
           }
@@ -2774,6 +2809,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
         unsigned slowest = 0;
         for (int k = 0; k < P; ++k)
           slowest = max(slowest, __hip_atomic_load(&xt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (!s_lost) s_slowest = max(slowest, (unsigned)(__builtin_amdgcn_s_memrealtime() - t0));
         s_solo = slowest < a.solo_ticks ? 1 : 0;   // the same P numbers in every workgroup: the same decision
       }
       __syncthreads();
@@ -3084,7 +3120,7 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
       __builtin_amdgcn_s_waitcnt(0);
       __hip_atomic_fetch_add(a.help_finished, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    const unsigned long long h_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long h_t0 = __builtin_amdgcn_s_memrealtime();   // (thread 0 reads it) the last time this helper had something to do
     for (;;) {
       // every thread looks at one pose's counter; the lowest open one is tried
       unsigned long long c = 0;
@@ -3131,12 +3167,15 @@ __device__ __forceinline__ void icp_persist_body(const IcpArgs a) {   // BY VALU
           __builtin_amdgcn_s_waitcnt(0);
           __syncthreads();
           if (tid == 0) __hip_atomic_fetch_add(&a.help_done[hp_pose], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          h_t0 = __builtin_amdgcn_s_memrealtime();
         }
         continue;   // (a lost race for the pass: look again at once)
       }
-      // nothing open: done when every pose is through; never spin for ever
+      // nothing open: done when every pose is through -- or when nobody has asked for help for a few milliseconds: an idle
+      // helper holds a compute unit that a workgroup of this launch which is not resident yet (or another process) waits for
       if (tid == 0)
-        h_pose = (ld_agent(a.help_finished) >= (unsigned)a.n || __builtin_amdgcn_s_memrealtime() - h_t0 > 200000000ull) ? -2 : -1;
+        h_pose = (ld_agent(a.help_finished) >= (unsigned)a.n ||
+                  __builtin_amdgcn_s_memrealtime() - h_t0 > (unsigned long long)a.wait_ticks) ? -2 : -1;
       __syncthreads();
       if (h_pose == -2) break;
       __builtin_amdgcn_s_sleep(127);   // ~3 us between looks: 255 idle workgroups must not crowd the counters
@@ -3426,6 +3465,15 @@ CoopChain g_coop;
 
 // The host-pointer call redoes a scene-sized job whose one-launch form reported a pose as lost (iteration count -1: its
 // units did not arrive within the clock bound) with the host-driven iterations: this thread's next launch_icp calls.
+// The floor of the clock bounds of the kernels whose workgroups wait for each other, in ticks of the 100 MHz counter: 3 ms --
+// two orders above an iteration (~25 us), three below the 2 s of round 5.  PGP_ICP_WAIT_MS overrides it (tests).
+static unsigned icp_wait_ticks() {   // (read at every launch: a test changes it between calls)
+  double ms = 3.0;
+  if (const char* v = getenv("PGP_ICP_WAIT_MS")) ms = atof(v) > 0.0 ? atof(v) : ms;
+  const double t = ms * 1e5;
+  return (unsigned)(t < 100.0 ? 100.0 : (t > 4.0e9 ? 4.0e9 : t));
+}
+
 static thread_local bool t_scene_form_off = false;
 void icp_scene_form_off(bool off) { t_scene_form_off = off; }
 
@@ -3532,6 +3580,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
   icp_option_args(prm, n_src, &a);
   a.first_walk = 1;
   if (const char* v = getenv("PGP_ICP_FIRST_WALK")) a.first_walk = atoi(v) < 0 ? 0 : atoi(v);   // A/B knob
+  a.wait_ticks = icp_wait_ticks();
   int rc;
   size_t need = (size_t)n * n_src;
   // measured (tools/icp_time.py, 2500 x 5000, 10 iterations): the split path wins at every batch
@@ -3615,13 +3664,14 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       if (g_coop.last[dev]) PGP_HIP(hipStreamWaitEvent(stream, g_coop.last[dev], 0));
       else PGP_HIP(hipEventCreateWithFlags(&g_coop.last[dev], hipEventDisableTiming));
       // meeting buffers | arrival counters | workgroups that have left | search ticks
-      const size_t xbytes = 2 * need * 8, ctr_words = 2 * (size_t)n + 4;
+      const size_t xbytes = 2 * need * 8, ctr_words = 3 * (size_t)n + 4;
       const void* x_before = ctx->d_icp_x.p;
       const size_t x_cap_before = ctx->d_icp_x.cap;
       if ((rc = ctx->d_icp_x.ensure(xbytes + ctr_words * 4 + (size_t)n * 32 + 64)) != PGP_OK) return rc;
       a.x_buf = ctx->d_icp_x.as<unsigned long long>();
       a.x_ctr = reinterpret_cast<unsigned*>(a.x_buf + 2 * need);
       a.x_done = a.x_ctr + n + 4;
+      a.x_abandon = a.x_done + n;
       if (getenv("PGP_ICP_FORCE_LOST")) a.force_lost = 1;   // test knob: the first meeting of every pose counts as lost
       a.x_ticks = a.x_ctr + ctr_words;
       a.solo_ticks = 1100;   // 11 us (tools/icp_time.py, PGP_ICP_SOLO_TICKS sweep)
@@ -3924,6 +3974,7 @@ int launch_icp(pgp_ctx* ctx, const float4* d_src, int n_src, const float4* d_tgt
       unsigned grid = (unsigned)std::max<long long>(z.n_upd + 1, std::min(items + z.n_upd, room));
       if (const char* v = getenv("PGP_ICP_SCENE_WGS")) grid = std::max((unsigned)z.n_upd + 1u, std::min(grid, (unsigned)atoi(v)));   // A/B knob
       z.poll_sleep = 1;
+      z.wait_ticks = icp_wait_ticks();
       if (const char* v = getenv("PGP_ICP_SCENE_SLEEP")) z.poll_sleep = atoi(v);
       if (getenv("PGP_ICP_FORCE_LOST")) z.force_lost = 1;
       void* params[] = {&a, &z};
@@ -4027,6 +4078,7 @@ int launch_icp_multi(const IcpJob* jobs, int n_jobs, const pgp_icp_options* prm,
   icp_option_args(prm, 1, &a);
   a.first_walk = 1;
   if (const char* v = getenv("PGP_ICP_FIRST_WALK")) a.first_walk = atoi(v) < 0 ? 0 : atoi(v);
+  a.wait_ticks = icp_wait_ticks();
   bool one_launch = n_jobs >= 2 && n_jobs <= kIcpMultiMax && a.metric == 0 && a.smooth == 0 && prm->nn_search != 1 &&
                     prm->nn_search != 2 && !getenv("PGP_ICP_NN") && !getenv("PGP_ICP_PERSIST") && !getenv("PGP_ICP_SPLIT");
   if (const char* v = getenv("PGP_ICP_MULTI")) one_launch = one_launch && atoi(v) != 0;   // A/B knob: 0 = job by job

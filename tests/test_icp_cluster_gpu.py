@@ -186,3 +186,29 @@ def test_group_icp_redoes_a_lost_scene_sized_piece(n_jobs, monkeypatch):
         assert _same(a, b)
     grp.close()
     sc.close()
+
+
+@pytest.mark.parametrize("wait_ms", ["0.002", "0.02", "0.2"])
+def test_meetings_that_run_out_at_random_keep_the_bits(wait_ms, monkeypatch):
+    """The waits' clock bounds follow the work now (3 ms floor; 2 s up to round 5).  With the floor pulled down to 0.2 .. 20 us
+    (PGP_ICP_WAIT_MS) meetings run out for real, at random points of random poses: the first workgroup to notice marks the
+    pose abandoned, its partners leave at once, workgroup 0 goes on alone -- and the scene-sized form reports the pose lost and
+    the host-pointer call redoes it.  Whatever happens when: the undisturbed launch's bits."""
+    S, M, N, G = _problem(86, 5000, 2500, 64, rot_deg=4.0, trans=0.004, outliers=0.03)
+    rng = np.random.default_rng(15)
+    tgt = np.c_[rng.uniform(-0.6, 0.6, 60000), rng.uniform(-0.4, 0.4, 60000), 0.0005 * rng.standard_normal(60000)].astype(np.float32)
+    src = (tgt[rng.choice(len(tgt), 20000, replace=False)] + np.array([0.004, -0.003, 0.002]) + 0.0008 * rng.standard_normal((20000, 3))).astype(np.float32)
+    eye = np.eye(4, dtype=np.float32).T.reshape(1, 16).copy()
+    kw = dict(max_iterations=30, max_corr_dist=0.01, energy_ratio=0.0, transformation_epsilon=1e-9, absolute_mse=1e-12)
+    sc = LcpScorer()
+    monkeypatch.delenv("PGP_ICP_WAIT_MS", raising=False)
+    ref_c = [sc.icp_refine(S, M, G[:n], trim=0.9, max_iterations=12) for n in (64, 24, 7)]
+    ref_s = sc.icp_refine_ex(src, tgt, eye, **kw)
+    monkeypatch.setenv("PGP_ICP_WAIT_MS", wait_ms)
+    for rep in range(4):
+        for n, ref in zip((64, 24, 7), ref_c):
+            assert _same(sc.icp_refine(S, M, G[:n], trim=0.9, max_iterations=12), ref), (wait_ms, rep, n)
+        assert _same(sc.icp_refine_ex(src, tgt, eye, **kw), ref_s), (wait_ms, rep)
+    monkeypatch.delenv("PGP_ICP_WAIT_MS")
+    assert _same(sc.icp_refine(S, M, G, trim=0.9, max_iterations=12), ref_c[0])      # the counters were left clean
+    sc.close()
