@@ -793,15 +793,17 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   }
   const size_t A = (size_t)n_attempts;
   // workspace: u (double) | ids (int4) | inv (float2) | status (int) | rows (int2) | cur (float [A][n])
-  const size_t bytes = A * 32 + A * 16 + A * 8 + A * 4 + A * 8 + A * (size_t)n * 4 + 256;
+  const size_t bytes = A * 32 + A * 16 + A * 8 + A * 4 + 8 + A * 8 + A * (size_t)n * 4 + 512;
   if ((rc = ctx->d_sel_ws.ensure(bytes)) != PGP_OK) return rc;
   unsigned char* base = ctx->d_sel_ws.as<unsigned char>();
   double* d_u = reinterpret_cast<double*>(base);
   int4* d_ids = reinterpret_cast<int4*>(base + A * 32);
   float2* d_inv = reinterpret_cast<float2*>(base + A * 48);
   int* d_status = reinterpret_cast<int*>(base + A * 56);
-  int2* d_rows = reinterpret_cast<int2*>(base + A * 60);
-  float* d_cur = reinterpret_cast<float*>(base + ((A * 68 + 255) & ~(size_t)255));
+  // (8-byte records: behind ids | inv | status = 28 B per attempt, which ends on an odd word when the attempts are odd in number)
+  const size_t rows_off = (A * 28 + 7) & ~(size_t)7;
+  int2* d_rows = reinterpret_cast<int2*>(base + A * 32 + rows_off);
+  float* d_cur = reinterpret_cast<float*>(base + ((A * 32 + rows_off + A * 8 + 255) & ~(size_t)255));
   // the variates go up from the pinned area the results come home to (the call synchronises before it returns): a
   // copy out of the caller's pageable array costs the host ~10 us whatever its size
   HostOut out(ctx, st);
@@ -826,11 +828,11 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   PGP_HIP(hipGetLastError());
   // ids | inv | status | rows lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
   const unsigned char* got = nullptr;
-  if ((rc = out.fetch(&got, d_ids, A * (h_rows ? 36 : 28))) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
+  if ((rc = out.fetch(&got, d_ids, h_rows ? rows_off + A * 8 : A * 28)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;
   std::memcpy(h_ids, got, A * 16);
   std::memcpy(h_inv, got + A * 16, A * 8);
   std::memcpy(h_status, got + A * 24, A * 4);
-  if (h_rows) std::memcpy(h_rows, got + A * 28, A * 8);
+  if (h_rows) std::memcpy(h_rows, got + rows_off, A * 8);
   return PGP_OK;
 }
 

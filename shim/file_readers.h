@@ -542,6 +542,14 @@ inline bool read_png_gray(const std::string& path, std::vector<uint16_t>& px, in
   std::unique_lock<std::mutex> scratch_lock(scratch.mu, std::try_to_lock);
   std::vector<unsigned char> raw_own;
   std::vector<unsigned char>& raw = scratch_lock.owns_lock() ? scratch.raw : raw_own;
+  // (the process keeps the scratch between calls only at the size of camera frames: one 16384 x 16384 image would
+  //  otherwise leave half a gigabyte resident in the node for good -- ADVICE r5; released before the lock is)
+  struct TrimScratch {
+    std::vector<unsigned char>* v;
+    ~TrimScratch() {
+      if (v && v->capacity() > ((size_t)16 << 20)) std::vector<unsigned char>().swap(*v);
+    }
+  } trim_scratch{scratch_lock.owns_lock() ? &scratch.raw : nullptr};
   raw.resize((stride + 1) * (size_t)rows);   // (every byte that is read below has been written by the inflate before)
   px.resize((size_t)rows * cols);            // (the rows that stay undecoded are zeroed at the end)
   int rows_done = 0;

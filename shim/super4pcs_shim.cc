@@ -272,6 +272,12 @@ void getProbableTransformsSuper4PCS(std::string input1, std::string input2, std:
   std::unique_lock<std::mutex> px_lock(px_mu, std::try_to_lock);
   std::vector<uint16_t> px_own;
   std::vector<uint16_t>& px = px_lock.owns_lock() ? px_kept : px_own;
+  struct TrimKept {   // (kept between calls at the size of camera frames only: ADVICE r5; runs before the lock is released)
+    std::vector<uint16_t>* v;
+    ~TrimKept() {
+      if (v && v->capacity() * sizeof(uint16_t) > ((size_t)16 << 20)) std::vector<uint16_t>().swap(*v);
+    }
+  } trim_kept{px_lock.owns_lock() ? &px_kept : nullptr};
   int rows = 0, cols = 0;
   bool ok1 = false, ok2 = false, ok3 = false, have = false;
   const auto t_files = std::chrono::steady_clock::now();

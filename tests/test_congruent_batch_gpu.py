@@ -177,6 +177,11 @@ def test_rows_that_ride_home_with_the_bases(case):
     n_plain = sc.find_congruent_batch(ids, base_xyz, inv, w.delta)
     picks = np.array([(b, j) for b in range(len(ids)) for j in range(n_plain[b])], np.int32).reshape(-1, 2)
     q_plain = sc.congruent_batch_quads(picks)
+    # an ODD number of attempts: the 8-byte row records must not land on an odd word behind the 28-byte records
+    for n_att in (95, 1, 33):
+        i2, v2, s2, r2 = sc.select_bases(u[:n_att], rows=True)
+        assert np.array_equal(i2, ids_a[:n_att]) and np.array_equal(v2, inv_a[:n_att]) and np.array_equal(s2, st_a[:n_att])
+        assert np.array_equal(r2[s2 == 1], rows[:int((st_a[:n_att] == 1).sum())])
     n_rows = sc.find_congruent_batch(ids, base_xyz, inv, w.delta, rows=rows)
     assert np.array_equal(n_rows, n_plain) and n_plain.sum() > 0
     assert np.array_equal(sc.congruent_batch_quads(picks), q_plain)
