@@ -153,9 +153,9 @@ def main():
     best = max(max(v["upper_bound_on_valu_saved"] for v in out[k].values() if isinstance(v, dict) and "upper_bound_on_valu_saved" in v)
                for k in ("c2_bench_batch", "drop_in_list"))
     out["verdict"] = (f"largest upper bound on the vector instructions a shared look-up could save: {best * 100:.2f} % "
-                      "(adoption bar: 8 % of the step time on the drop-in list) -- a wave's 64 model points span centimetres, the "
-                      "index's cells are 4 mm, and two fits of one base differ by millimetres: some lane always changes its cell.  "
-                      "Not built; closed.")
+                      "(adoption bar: 8 % of the step time on the drop-in list) -- a wave's 64 model points span centimetres and "
+                      "the index's cells are 4 mm: some lane always changes its cell; the wave-trips that do keep every cell on "
+                      "the drop-in list are repeated fits.  Not built; closed.")
     path = os.path.join(ROOT, "profiles", "r06_ab", "shared_lookup.json")
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
