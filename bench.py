@@ -645,7 +645,7 @@ def drop_in_row():
             out[name] = {"first_call_ms": ms[0], "drop_in_ms_per_object": float(np.median(rest)), "calls": len(ms),
                          "min_ms": float(rest.min()), "p90_ms": float(np.percentile(rest, 90)),
                          "p99_ms": float(np.percentile(rest, 99)), "max_ms": float(rest.max()),
-                         "phases": "profiles/r05_dropin_phases.txt (tools/dropin_phases.py)"}
+                         "phases": "profiles/r06_dropin_phases.txt (tools/dropin_phases.py)"}
         # the node's object loop as ONE call (getProbableTransformsSuper4PCSFrame): three objects side by side against one by one
         for name, extra in (("frame_of_3", {}), ("frame_of_3_one_by_one", {"PGP_SHIM_FRAME_SERIAL": "1"})):
             env = dict(os.environ, PGP_SHIM_SEED="12345", PGP_SHIM_PRIVATE_RAND="1", SHIM_TEST_FRAME="3", SHIM_TEST_REPEAT="40", **extra)

@@ -345,6 +345,23 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
                                        int* best_index, float* best_score, float* best_T, double* best_pose, int* registered,
                                        int* n_registered);
 
+/* The same call with the sampling of the quads (base.cc:1858-1866: at most 100 random quads per base) done ON THE DEVICE, where
+ * the quad counts are: no picks to draw on the host between the congruent sets and the fits, none to upload.  The draw is a
+ * function of (seed, base, the base's quad count) alone -- a splitmix64 stream per base, (z >> 33) % n until max_per_base
+ * DIFFERENT values have come, handed out in ascending order; a base with fewer quads hands out all of them --, so the bases are
+ * drawn side by side, and pgp_sample_quads is the same function on the host (the reference draws from rand() seeded from
+ * the clock: any max_per_base distinct uniform draws are its behaviour).  Works on the batch pgp_find_congruent_batch[_rows]
+ * left resident; base_ids[n_bases][4] as there.  picks_out (nullable, room for n_bases x max_per_base x 2) / n_picks
+ * (nullable) return what was drawn: the picks a pgp_congruent_batch_fit_score_list call would need for the same result.
+ * 1 <= max_per_base <= 128. */
+int pgp_congruent_batch_sample_fit_score_list(pgp_ctx* ctx, unsigned long long seed, int max_per_base, const int* base_ids,
+                                              const float centroid_P[3], const float centroid_Q[3], int mode, float gate_deg,
+                                              int list_cap, int* n_list, int* list_index, float* list_score, float* list_T,
+                                              double* list_pose, int* n_pushed, int* best_index, float* best_score, float* best_T,
+                                              double* best_pose, int* registered, int* n_registered, int* picks_out, int* n_picks);
+/* Host helper: the picks that call draws, from the quad counts alone.  picks (nullable: count only) [sum][2] = (base, quad). */
+int pgp_sample_quads(unsigned long long seed, const int* n_quads, int n_bases, int max_per_base, int* picks, int* n_picks);
+
 /* ICP refinement.  Replaces the inner loop behind pcl::recognition::TrimmedICP::align
  * (PPE/hypothesis_verification/mcts/UCTState.cpp:137-139,194; PPE/misc/utilities.cpp:666-676) and
  * pcl::IterativeClosestPoint::align (utilities.cpp:697-703; PPE/data_layer/SceneCfg.cpp:101,135-141)

@@ -106,6 +106,10 @@ SIGNATURES = {
     "pgp_congruent_batch_fetch": (C.c_int, [C.c_void_p, _i, C.c_int, _f, C.POINTER(C.c_double)]),
     "pgp_congruent_batch_fit_score_list": (C.c_int, [C.c_void_p, _i, _i, C.c_int, _f, _f, C.c_int, C.c_float, C.c_int, _i, _i, _f, _f,
                                                     C.POINTER(C.c_double), _i, _i, _f, _f, C.POINTER(C.c_double), _i, _i]),
+    "pgp_congruent_batch_sample_fit_score_list": (C.c_int, [C.c_void_p, C.c_ulonglong, C.c_int, _i, _f, _f, C.c_int, C.c_float, C.c_int,
+                                                           _i, _i, _f, _f, C.POINTER(C.c_double), _i, _i, _f, _f,
+                                                           C.POINTER(C.c_double), _i, _i, _i, _i]),
+    "pgp_sample_quads": (C.c_int, [C.c_ulonglong, _i, C.c_int, C.c_int, _i, _i]),
     "pgp_icp_refine": (C.c_int, [C.c_void_p, _f, C.c_int, _f, C.c_int, _f, C.c_int,
                                  C.POINTER(IcpParams), _f, _i]),
     "pgp_icp_refine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,

@@ -1091,7 +1091,13 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
               "pgp_set_ppf_map or pgp_set_search_model discards it)");
     return PGP_ESTATE;
   }
-  for (int k = 0; k < m; ++k) {   // a bad pick would read past the sorted keys on the device
+  if (!h_picks && !d_picks_there) {
+    set_error("congruent batch: no picks");
+    return PGP_EINVAL;
+  }
+  // (picks that were DRAWN on the device from the batch's own quad counts -- pgp_api.hip sample_quads_kernel -- name quads
+  //  that exist by construction: no host copy to check)
+  for (int k = 0; h_picks && k < m; ++k) {   // a bad pick would read past the sorted keys on the device
     const int b = h_picks[2 * (size_t)k], j = h_picks[2 * (size_t)k + 1];
     if (b < 0 || b >= ctx->csb_nb) {
       set_error("congruent batch: pick %d names base %d of %d", k, b, ctx->csb_nb);
@@ -1122,6 +1128,13 @@ int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4*
   return PGP_OK;
 }
 
+
+// where the resident batch's per-base starts (nb + 1 words) live on the device
+const uint32_t* congruent_batch_starts_device(pgp_ctx* ctx) {
+  const int nb = ctx->csb_nb;
+  const size_t bb = ((size_t)nb * sizeof(BatchBase) + 255) & ~(size_t)255, cb = ((size_t)nb * 168 * 4 + 255) & ~(size_t)255;
+  return reinterpret_cast<const uint32_t*>(ctx->d_csb.as<unsigned char>() + bb + cb);
+}
 
 int launch_find_congruent_4pcs(pgp_ctx* ctx, float inv1, float inv2, float threshold, const int* d_Pp, int nP,
                                const int* d_Qp, int nQ, int* d_quads, int cap, int* n_quads_host, hipStream_t st) {

@@ -1530,15 +1530,185 @@ int pgp_congruent_batch_fetch(pgp_ctx* ctx, const int* index, int k, float* T, d
   return PGP_OK;
 }
 
+}  // extern "C"
+
+namespace pgp {
+namespace {
+// The drop-in's draw of at most `cap` quads per base (base.cc:1858-1866) as a function of (seed, base, quads of the base)
+// alone: every base has a generator of its own -- splitmix64 from a state mixed out of the seed and the base's number --,
+// draws (z >> 33) % nq (31-bit values, as rand() gives) until `cap` DIFFERENT ones have come, and hands them out in ascending
+// order; a base with fewer than `cap` quads hands out all of them.  The reference draws from the process's rand(), seeded from
+// the clock: any set of `cap` distinct uniform draws is the reference's behaviour.  Per-base streams make the draw parallel
+// over the bases -- on the device (sample_quads_kernel) and on the host (pgp_sample_quads), bit for bit the same picks.
+__host__ __device__ inline unsigned long long sample_state(unsigned long long seed, int base) {
+  return (seed ^ 0xD1B54A32D192ED03ull) + (unsigned long long)(base + 1) * 0xBF58476D1CE4E5B9ull;
+}
+__host__ __device__ inline unsigned int sample_draw(unsigned long long* x, unsigned int nq) {
+  *x += 0x9E3779B97F4A7C15ull;
+  unsigned long long z = *x;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (unsigned int)(z >> 33) % nq;
+}
+constexpr int kSampleMax = 128;   // two slots per lane of the base's wave
+
+// one wave per base: where the base's picks start (the sum of the earlier bases' counts), then its draw
+__global__ __launch_bounds__(64) void sample_quads_kernel(const uint32_t* __restrict__ base_start, int nb, int cap, unsigned long long seed,
+                                                          const int4* __restrict__ base_ids, int2* __restrict__ picks,
+                                                          int4* __restrict__ pick_bases) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  uint32_t off = 0;
+  for (int i = lane; i < b; i += 64) off += min(base_start[i + 1] - base_start[i], (uint32_t)cap);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) off += __shfl_xor(off, o, 64);
+  const uint32_t nq = base_start[b + 1] - base_start[b];
+  const int4 ids = base_ids[b];
+  if (nq < (uint32_t)cap) {
+    for (uint32_t j = lane; j < nq; j += 64) {
+      picks[off + j] = make_int2(b, (int)j);
+      pick_bases[off + j] = ids;
+    }
+    return;
+  }
+  uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;   // slot `lane` and slot `lane + 64` (no draw is 2^32 - 1)
+  unsigned long long x = sample_state(seed, b);
+  for (int n = 0; n < cap;) {
+    const uint32_t v = sample_draw(&x, nq);       // (the same value in every lane)
+    if (__ballot(s0 == v || s1 == v) != 0ull) continue;
+    if (lane == (n & 63)) {
+      if (n < 64) s0 = v;
+      else s1 = v;
+    }
+    ++n;
+  }
+  // ascending: a value's place is the number of smaller ones
+  uint32_t r0 = 0, r1 = 0;
+  for (int i = 0; i < cap; ++i) {
+    const uint32_t u = i < 64 ? __shfl(s0, i, 64) : __shfl(s1, i - 64, 64);
+    r0 += u < s0 ? 1u : 0u;
+    r1 += u < s1 ? 1u : 0u;
+  }
+  if (lane < cap) {
+    picks[off + r0] = make_int2(b, (int)s0);
+    pick_bases[off + r0] = ids;
+  }
+  if (lane + 64 < cap) {
+    picks[off + r1] = make_int2(b, (int)s1);
+    pick_bases[off + r1] = ids;
+  }
+}
+
+struct SampleSpec {
+  bool on;
+  unsigned long long seed;
+  int cap;
+  int* picks_out;   // nullable: the picks the device drew, [m][2]
+  int* m_out;       // nullable
+};
+
+int fit_score_list_impl(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                        const float centroid_Q[3], int mode, float gate_deg, int list_cap, int* n_list,
+                        int* list_index, float* list_score, float* list_T, double* list_pose, int* n_pushed,
+                        int* best_index, float* best_score, float* best_T, double* best_pose, int* registered,
+                        int* n_registered, const SampleSpec& smp);
+}  // namespace
+}  // namespace pgp
+
+extern "C" {
+
+int pgp_sample_quads(unsigned long long seed, const int* n_quads, int n_bases, int max_per_base, int* picks, int* n_picks) {
+  if (n_bases < 0 || (n_bases > 0 && !n_quads) || max_per_base < 1 || max_per_base > kSampleMax || !n_picks) {
+    set_error("pgp_sample_quads: bad argument (1 <= max_per_base <= %d)", kSampleMax);
+    return PGP_EINVAL;
+  }
+  int k = 0;
+  std::vector<unsigned int> got;
+  for (int b = 0; b < n_bases; ++b) {
+    const int nq = n_quads[b];
+    if (nq < 0) {
+      set_error("pgp_sample_quads: base %d has %d quads", b, nq);
+      return PGP_EINVAL;
+    }
+    if (nq < max_per_base) {
+      for (int j = 0; j < nq; ++j, ++k)
+        if (picks) { picks[2 * (size_t)k] = b; picks[2 * (size_t)k + 1] = j; }
+      continue;
+    }
+    got.clear();
+    unsigned long long x = sample_state(seed, b);
+    while ((int)got.size() < max_per_base) {
+      const unsigned int v = sample_draw(&x, (unsigned int)nq);
+      if (std::find(got.begin(), got.end(), v) == got.end()) got.push_back(v);
+    }
+    std::sort(got.begin(), got.end());
+    for (unsigned int v : got) {
+      if (picks) { picks[2 * (size_t)k] = b; picks[2 * (size_t)k + 1] = (int)v; }
+      ++k;
+    }
+  }
+  *n_picks = k;
+  return PGP_OK;
+}
+
 int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
                                        const float centroid_Q[3], int mode, float gate_deg, int list_cap, int* n_list,
                                        int* list_index, float* list_score, float* list_T, double* list_pose, int* n_pushed,
                                        int* best_index, float* best_score, float* best_T, double* best_pose, int* registered,
                                        int* n_registered) {
-  if (!ctx || m < 0 || !centroid_P || !centroid_Q || list_cap < 0 || list_cap > 4096 || !n_list || !n_registered ||
-      (m > 0 && (!picks || !base_ids)) || (list_cap > 0 && (!list_index || !list_score || !list_T || !list_pose))) {
+  if (m > 0 && !picks) {
     set_error("pgp_congruent_batch_fit_score_list: bad argument");
     return PGP_EINVAL;
+  }
+  return fit_score_list_impl(ctx, picks, base_ids, m, centroid_P, centroid_Q, mode, gate_deg, list_cap, n_list, list_index, list_score,
+                             list_T, list_pose, n_pushed, best_index, best_score, best_T, best_pose, registered, n_registered,
+                             SampleSpec{false, 0ull, 0, nullptr, nullptr});
+}
+
+int pgp_congruent_batch_sample_fit_score_list(pgp_ctx* ctx, unsigned long long seed, int max_per_base, const int* base_ids,
+                                              const float centroid_P[3], const float centroid_Q[3], int mode, float gate_deg,
+                                              int list_cap, int* n_list, int* list_index, float* list_score, float* list_T,
+                                              double* list_pose, int* n_pushed, int* best_index, float* best_score, float* best_T,
+                                              double* best_pose, int* registered, int* n_registered, int* picks_out, int* n_picks) {
+  if (max_per_base < 1 || max_per_base > kSampleMax) {
+    set_error("pgp_congruent_batch_sample_fit_score_list: 1 <= max_per_base <= %d", kSampleMax);
+    return PGP_EINVAL;
+  }
+  if (n_picks) *n_picks = 0;
+  return fit_score_list_impl(ctx, nullptr, base_ids, 0, centroid_P, centroid_Q, mode, gate_deg, list_cap, n_list, list_index,
+                             list_score, list_T, list_pose, n_pushed, best_index, best_score, best_T, best_pose, registered,
+                             n_registered, SampleSpec{true, seed, max_per_base, picks_out, n_picks});
+}
+
+}  // extern "C"
+
+namespace pgp {
+namespace {
+int fit_score_list_impl(pgp_ctx* ctx, const int* picks, const int* base_ids, int m, const float centroid_P[3],
+                        const float centroid_Q[3], int mode, float gate_deg, int list_cap, int* n_list,
+                        int* list_index, float* list_score, float* list_T, double* list_pose, int* n_pushed,
+                        int* best_index, float* best_score, float* best_T, double* best_pose, int* registered,
+                        int* n_registered, const SampleSpec& smp) {
+  if (!ctx || m < 0 || !centroid_P || !centroid_Q || list_cap < 0 || list_cap > 4096 || !n_list || !n_registered ||
+      ((m > 0 || smp.on) && !base_ids) || (list_cap > 0 && (!list_index || !list_score || !list_T || !list_pose))) {
+    set_error("pgp_congruent_batch_fit_score_list: bad argument");
+    return PGP_EINVAL;
+  }
+  if (smp.on) {
+    // the picks are drawn on the device; how many there will be follows from the resident batch's quad counts
+    if (ctx->csb_nb <= 0 || (int)ctx->csb_starts.size() != ctx->csb_nb + 1) {
+      set_error("pgp_congruent_batch_sample_fit_score_list: no congruent batch resident (pgp_find_congruent_batch first)");
+      return PGP_ESTATE;
+    }
+    long long total = 0;
+    for (int b = 0; b < ctx->csb_nb; ++b)
+      total += std::min<long long>((long long)(ctx->csb_starts[b + 1] - ctx->csb_starts[b]), smp.cap);
+    if (total > 0x3FFFFFFF) {
+      set_error("pgp_congruent_batch_sample_fit_score_list: more than 2^30 picks");
+      return PGP_EINVAL;
+    }
+    m = (int)total;
+    if (smp.m_out) *smp.m_out = m;
   }
   *n_list = 0;
   *n_registered = 0;
@@ -1551,7 +1721,7 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   const size_t N = (size_t)m, C = (size_t)list_cap, nQ = (size_t)std::max(ctx->nQ, 0);
   int rc;
   if ((rc = pgp_reserve(ctx, m)) != PGP_OK) return rc;
-  if ((rc = ctx->d_ids.ensure(N * 40 + 64)) != PGP_OK) return rc;   // bases of the picks | picks | quads
+  if ((rc = ctx->d_ids.ensure(N * 40 + 64 + (size_t)std::max(ctx->csb_nb, 0) * 16 + 64)) != PGP_OK) return rc;   // bases of the picks | picks | quads | ids of the bases
   ctx->csb_fit_m = 0;
   if ((rc = ctx->d_rig.ensure(N * (128 + 64 + 4 + 4))) != PGP_OK) return rc;
   // scores | (counts) | best -- then what goes home in ONE copy: best {index, score bits} | list {records, pushed, indices}
@@ -1559,7 +1729,8 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   const size_t off_best = N * 8, off_list = off_best + 16, off_rs = off_list + (C + 2) * 4, off_pose = (off_rs + C * 4 + 127) & ~(size_t)127,
                off_T = off_pose + (C + 1) * 128, off_hits = off_T + (C + 1) * 64, total = off_hits + nQ * 4 + 64;
   if ((rc = ctx->d_out.ensure(total)) != PGP_OK) return rc;
-  const size_t in_bytes = N * 24, home = total - off_best, pin_need = in_bytes + home + 256;   // bases of the picks | picks
+  const size_t in_bytes = smp.on ? (((size_t)std::max(ctx->csb_nb, 0) * 16 + 63) & ~(size_t)63) : N * 24;   // bases of the picks | picks
+  const size_t home = total - off_best, pin_need = in_bytes + home + (smp.on && smp.picks_out ? N * 8 + 64 : 0) + 256;
   if (pin_need > ctx->h_pin_cap) {
     if (ctx->h_pin) {
       hipError_t e = hipHostFree(ctx->h_pin);
@@ -1573,22 +1744,36 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   }
   unsigned char* pin = static_cast<unsigned char*>(ctx->h_pin);
   int* hb = reinterpret_cast<int*>(pin);
-  for (size_t k = 0; k < N; ++k) {
-    const int b = picks[2 * k];
-    if (b < 0 || b >= ctx->csb_nb) {
-      set_error("pgp_congruent_batch_fit_score_list: pick %zu names base %d of %d", k, b, ctx->csb_nb);
-      return PGP_EINVAL;
-    }
-    for (int j = 0; j < 4; ++j) hb[4 * k + j] = base_ids[4 * (size_t)b + j];
-  }
-  std::memcpy(hb + 4 * N, picks, N * 8);
-  // device: bases of the picks [4 N] | picks [2 N] (ONE copy) | quads [4 N]
+  // device: bases of the picks [4 N] | picks [2 N] (ONE copy) | quads [4 N] | (sampled form) the bases' ids [4 nb]
   int* d_b = ctx->d_ids.as<int>();
   int* d_pk = d_b + 4 * N;
   int* d_q = d_pk + ((2 * N + 3) & ~(size_t)3);   // (int4 records: 16-byte aligned)
-  if ((rc = stage_to_device(st, d_b, hb, in_bytes)) != PGP_OK) return rc;
-  rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st, reinterpret_cast<const int2*>(d_pk));
-  if (rc != PGP_OK) return rc;
+  if (!smp.on) {
+    for (size_t k = 0; k < N; ++k) {
+      const int b = picks[2 * k];
+      if (b < 0 || b >= ctx->csb_nb) {
+        set_error("pgp_congruent_batch_fit_score_list: pick %zu names base %d of %d", k, b, ctx->csb_nb);
+        return PGP_EINVAL;
+      }
+      for (int j = 0; j < 4; ++j) hb[4 * k + j] = base_ids[4 * (size_t)b + j];
+    }
+    std::memcpy(hb + 4 * N, picks, N * 8);
+    if ((rc = stage_to_device(st, d_b, hb, in_bytes)) != PGP_OK) return rc;
+    rc = launch_congruent_batch_gather(ctx, picks, m, reinterpret_cast<int4*>(d_q), st, reinterpret_cast<const int2*>(d_pk));
+    if (rc != PGP_OK) return rc;
+  } else {
+    // the bases' ids go up (16 B each), the picks are drawn where the quads are: one wave per base
+    const int nb = ctx->csb_nb;
+    int* d_base_ids = d_q + 4 * N;
+    std::memcpy(hb, base_ids, (size_t)nb * 16);
+    if ((rc = stage_to_device(st, d_base_ids, hb, (size_t)nb * 16)) != PGP_OK) return rc;
+    const uint32_t* d_base_start = congruent_batch_starts_device(ctx);
+    hipLaunchKernelGGL(sample_quads_kernel, dim3((unsigned)nb), dim3(64), 0, st, d_base_start, nb, smp.cap, smp.seed,
+                       reinterpret_cast<const int4*>(d_base_ids), reinterpret_cast<int2*>(d_pk), reinterpret_cast<int4*>(d_b));
+    PGP_HIP(hipGetLastError());
+    rc = launch_congruent_batch_gather(ctx, nullptr, m, reinterpret_cast<int4*>(d_q), st, reinterpret_cast<const int2*>(d_pk));
+    if (rc != PGP_OK) return rc;
+  }
   double* d_pose = ctx->d_rig.as<double>();
   float* d_T = reinterpret_cast<float*>(d_pose + 16 * N);
   float* d_rms = d_T + 16 * N;
@@ -1617,13 +1802,18 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
     // one kernel brings everything home and writes the word the host polls (pgp::publish_and_wait); the build that was put
     // off goes to its stream first, as before any wait of the host
     if (ctx->deferred_build && (rc = flush_deferred_build(ctx)) != PGP_OK) return rc;
-    const PubItem item{dev + off_best, pin_out, home};
-    if (publish_usable(&item, 1)) {
-      if ((rc = publish_and_wait(ctx, st, &item, 1)) != PGP_OK) return rc;
+    unsigned char* pin_picks = pin_out + ((home + 63) & ~(size_t)63);
+    const bool want_picks = smp.on && smp.picks_out;
+    const PubItem items[2] = {{dev + off_best, pin_out, home}, {d_pk, pin_picks, N * 8}};
+    const int n_items = want_picks ? 2 : 1;
+    if (publish_usable(items, n_items)) {
+      if ((rc = publish_and_wait(ctx, st, items, n_items)) != PGP_OK) return rc;
     } else {
       PGP_HIP(hipMemcpyAsync(pin_out, dev + off_best, home, hipMemcpyDeviceToHost, st));
+      if (want_picks) PGP_HIP(hipMemcpyAsync(pin_picks, d_pk, N * 8, hipMemcpyDeviceToHost, st));
       PGP_HIP(hipStreamSynchronize(st));
     }
+    if (want_picks) std::memcpy(smp.picks_out, pin_picks, N * 8);
   }
   if ((rc = index_settled(ctx)) != PGP_OK) return rc;
   const unsigned char* h = pin_out - off_best;   // (offsets as on the device)
@@ -1655,6 +1845,10 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
   ctx->csb_fit_m = m;
   return PGP_OK;
 }
+}  // namespace
+}  // namespace pgp
+
+extern "C" {
 
 static pgp_icp_options options_of(const pgp_icp_params* p) {
   pgp_icp_options o;

@@ -398,6 +398,7 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
                                 const int* h_rows /* nullable */, int nb, float threshold, int* h_n_quads, hipStream_t st);
 int launch_congruent_batch_gather(pgp_ctx* ctx, const int* h_picks, int m, int4* d_quads, hipStream_t st,
                                   const int2* d_picks_there = nullptr);
+const uint32_t* congruent_batch_starts_device(pgp_ctx* ctx);
 
 // lcp_score.hip
 int tiles_for(int nQ);

@@ -274,6 +274,42 @@ class LcpScorer:
                     n_pushed=n_pushed.value, best_index=best.value, best_score=float(np.float32(bs.value)), best_T=bT, best_pose=bp,
                     registered=reg[: n_reg.value].copy())
 
+    @staticmethod
+    def sample_quads(seed, n_quads, max_per_base=100):
+        """pgp_sample_quads: the picks (base, quad) the device draws for these quad counts (host statement of the same draw)."""
+        nq = np.ascontiguousarray(n_quads, np.int32)
+        out = np.zeros((max(len(nq) * int(max_per_base), 1), 2), np.int32)
+        n = C.c_int(0)
+        _lib.check(_lib.load().pgp_sample_quads(C.c_ulonglong(int(seed)), nq.ctypes.data_as(_i), len(nq), int(max_per_base),
+                                                out.ctypes.data_as(_i), C.byref(n)))
+        return out[: n.value].copy()
+
+    def congruent_batch_sample_fit_score_list(self, seed, base_ids, centroid_P, centroid_Q, max_per_base=100, mode=PGP_MODE_WEIGHTED,
+                                              gate_deg=30.0, list_cap=256):
+        """pgp_congruent_batch_sample_fit_score_list: congruent_batch_fit_score_list with the quads drawn on the device.
+        The dict of that call + `picks` (what was drawn)."""
+        b = np.ascontiguousarray(base_ids, np.int32).reshape(-1, 4)
+        cP, cQ = _f32(centroid_P).reshape(3), _f32(centroid_Q).reshape(3)
+        cap = int(list_cap)
+        li = np.zeros(max(cap, 1), np.int32)
+        ls = np.zeros(max(cap, 1), np.float32)
+        lT = np.zeros((max(cap, 1), 16), np.float32)
+        lp = np.zeros((max(cap, 1), 16), np.float64)
+        bT, bp = np.zeros(16, np.float32), np.zeros(16, np.float64)
+        reg = np.zeros(max(self.nQ, 1), np.int32)
+        pk = np.zeros((max(len(b) * int(max_per_base), 1), 2), np.int32)
+        n_list, n_pushed, best, n_reg, n_pk = C.c_int(0), C.c_int(0), C.c_int(-1), C.c_int(0), C.c_int(0)
+        bs = C.c_float(0)
+        _lib.check(self._lib.pgp_congruent_batch_sample_fit_score_list(
+            self._h, C.c_ulonglong(int(seed)), int(max_per_base), b.ctypes.data_as(_i), _fp(cP), _fp(cQ), int(mode), C.c_float(gate_deg), cap,
+            C.byref(n_list), li.ctypes.data_as(_i), _fp(ls), _fp(lT), lp.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n_pushed),
+            C.byref(best), C.byref(bs), _fp(bT), bp.ctypes.data_as(C.POINTER(C.c_double)), reg.ctypes.data_as(_i), C.byref(n_reg),
+            pk.ctypes.data_as(_i), C.byref(n_pk)))
+        k = min(n_list.value, cap)
+        return dict(n_list=n_list.value, index=li[:k].copy(), score=ls[:k].copy(), T=lT[:k].copy(), pose=lp[:k].copy(),
+                    n_pushed=n_pushed.value, best_index=best.value, best_score=float(np.float32(bs.value)), best_T=bT, best_pose=bp,
+                    registered=reg[: n_reg.value].copy(), picks=pk[: n_pk.value].copy())
+
     def congruent_batch_quads(self, picks):
         pk = np.ascontiguousarray(picks, np.int32).reshape(-1, 2)
         out = np.zeros((max(len(pk), 1), 4), np.int32)

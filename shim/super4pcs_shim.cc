@@ -650,10 +650,21 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     SHIM_PGP(pgp_find_congruent_batch_rows(ctx, base_ids.data(), base_xyz.data(), base_inv.data(), base_rows.data(), n_bases,
                                            delta, n_quads.data()));
   mark("congruent_sets");
+  // The draw of at most 100 quads per base (base.cc:1858-1866): on the host, below, from the process's rand() (or, side by
+  // side with other calls, a generator of the call's own) -- while the device sorts the batch's keys, which takes about as
+  // long.  PGP_SHIM_RAND=device: the draw happens ON THE DEVICE instead, inside the call that fits and verifies
+  // (pgp_congruent_batch_sample_fit_score_list: a generator per base, the bases drawn side by side where their quad counts are;
+  // the host draws nothing and uploads no picks).  Measured (profiles/r06_ab/device_draw.log): the host's 36 us were hidden
+  // behind the sort, the device's draw waits for it -- 0.472 against 0.451 ms per call; kept as an option, not the default.
+  const char* rand_mode = getenv("PGP_SHIM_RAND");
+  const bool device_draw = !st.group && rand_mode && std::strcmp(rand_mode, "device") == 0;
+  // (64 bits of the call's seed: the clock's count, or PGP_SHIM_SEED -- the same picks call after call under a fixed seed)
+  const unsigned long long draw_seed = getenv("PGP_SHIM_SEED") ? (unsigned long long)seed
+                                                               : (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
   std::vector<int> picks;   // (base, j) pairs
-  picks.reserve(2 * (size_t)n_bases * max_sampled_csets);
+  picks.reserve(device_draw ? 0 : 2 * (size_t)n_bases * max_sampled_csets);
   std::vector<unsigned long long> seen;
-  for (int b = 0; b < n_bases; ++b) {
+  for (int b = 0; b < n_bases && !device_draw; ++b) {
     const int nq = n_quads[b];
     if (nq < max_sampled_csets) {
       for (int j = 0; j < nq; ++j) { picks.push_back(b); picks.push_back(j); }
@@ -681,7 +692,11 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   mark("sample_quads");
   const double ms_cs = ms_since(t_cs);
   const auto t_fit = std::chrono::steady_clock::now();
-  const int n_pairs = (int)(picks.size() / 2);
+  int n_pairs = (int)(picks.size() / 2);
+  if (device_draw) {   // (known from the quad counts alone)
+    n_pairs = 0;
+    for (int b = 0; b < n_bases; ++b) n_pairs += n_quads[b] < max_sampled_csets ? n_quads[b] : max_sampled_csets;
+  }
   if (!st.group) {
     // ---- single device: the fits never leave HBM -- fitted, verified (Step 3, base.cc:1885-1901, operMode = 1 ->
     // WeightedVerify) and walked there; scores and status come back, then the poses of the few hypotheses that are kept
@@ -698,10 +713,15 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     float best_lcp = 0.f, best_T[16];
     double best_pose[16];
     std::vector<int> reg(qval.n > 0 ? qval.n : 1);
-    if (n_pairs > 0)
+    if (n_pairs > 0 && device_draw) {
+      SHIM_PGP(pgp_congruent_batch_sample_fit_score_list(ctx, draw_seed, max_sampled_csets, base_ids.data(), cP, cQ, PGP_MODE_WEIGHTED, 30.f,
+                                                         kListCap, &n_list, li.data(), ls.data(), lT.data(), lp.data(), &n_pushed,
+                                                         &best_pick, &best_lcp, best_T, best_pose, reg.data(), &n_reg, nullptr, nullptr));
+    } else if (n_pairs > 0) {
       SHIM_PGP(pgp_congruent_batch_fit_score_list(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, PGP_MODE_WEIGHTED, 30.f, kListCap,
                                                   &n_list, li.data(), ls.data(), lT.data(), lp.data(), &n_pushed, &best_pick, &best_lcp,
                                                   best_T, best_pose, reg.data(), &n_reg));
+    }
     const int n_h = n_pushed;
     mark("fit+score+records");
     if (verbose)
@@ -717,6 +737,13 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
       for (int k = 0; k < n_list; ++k) hypothesisSet.push_back(std::make_pair(iso_of(lp.data() + 16 * (size_t)k), ls[k]));  // base.cc:1903-1908
     } else {
       // the long way round: all scores, the walk on the host, the kept poses fetched
+      if (device_draw && picks.size() != 2 * (size_t)n_pairs) {
+        // (a list beyond kListCap records has never been seen; should it happen, the draw is repeated on the host -- the same
+        //  picks: pgp_sample_quads is the device's draw)
+        picks.resize(2 * (size_t)n_pairs);
+        int got = 0;
+        SHIM_PGP(pgp_sample_quads(draw_seed, n_quads.data(), n_bases, max_sampled_csets, picks.data(), &got));
+      }
       std::vector<float> lcp_all(n_pairs);
       std::vector<int> status(n_pairs);
       SHIM_PGP(pgp_congruent_batch_fit_score(ctx, picks.data(), base_ids.data(), n_pairs, cP, cQ, PGP_MODE_WEIGHTED, 30.f,

@@ -241,3 +241,45 @@ def test_fit_score_list_equals_the_calls_it_replaces(case):
     assert L.pgp_congruent_batch_fetch(h, ip(want), len(want), fp(T2), dp(pose2)) == 0
     assert np.array_equal(T2, T) and np.array_equal(pose2, pose)
     sc.close()
+
+
+def test_quads_drawn_on_the_device_equal_the_host_statement_and_the_picked_call(case):
+    """pgp_congruent_batch_sample_fit_score_list draws the reference's sample of at most 100 quads per base (base.cc:1858-1866) ON
+    THE DEVICE, one wave per base from a generator of the base's own: the picks it reports are pgp_sample_quads' (the same draw
+    stated on the host), and everything it returns is what pgp_congruent_batch_fit_score_list returns for those picks."""
+    from physimglobalpose_amd import PGP_MODE_WEIGHTED
+    w, table, keys, sc0, ids, inv = case
+    counts = np.array([len(table[tuple(k)]) for k in keys.tolist()], np.int32)
+    pairs = np.concatenate([np.array(table[tuple(k)], np.int32).reshape(-1, 2) for k in keys.tolist()])
+    sc = LcpScorer()
+    sc.init(w.P_xyz, w.P_nrm, w.P_w, w.Q_xyz, w.Q_nrm, w.delta)
+    sc.set_search_model(w.Qs_xyz)
+    sc.set_ppf_map(keys, counts, pairs)
+    sc.set_exact_records(True)
+    n_quads = sc.find_congruent_batch(ids, w.P_xyz[ids], inv, w.delta)
+    assert (n_quads >= 100).any() and (n_quads < 100).any()          # both branches of the draw
+    cP, cQ = np.ascontiguousarray(w.centroid_P, np.float32), np.ascontiguousarray(w.centroid_Q, np.float32)
+    for seed, cap_q in ((12345, 100), (2 ** 63 + 7, 100), (99, 7), (5, 128), (6, 1)):
+        picks = LcpScorer.sample_quads(seed, n_quads, cap_q)
+        assert len(picks) == int(np.minimum(n_quads, cap_q).sum())
+        for b in range(len(n_quads)):                                  # distinct, ascending, in range, all of a small base
+            j = picks[picks[:, 0] == b, 1]
+            assert len(j) == min(int(n_quads[b]), cap_q) and (np.diff(j) > 0).all() and (len(j) == 0 or (0 <= j[0] and j[-1] < n_quads[b]))
+        got = sc.congruent_batch_sample_fit_score_list(seed, ids, cP, cQ, max_per_base=cap_q, list_cap=256)
+        assert np.array_equal(got["picks"], picks), (seed, cap_q)
+        n_quads2 = sc.find_congruent_batch(ids, w.P_xyz[ids], inv, w.delta)     # (the picked call on a batch of its own)
+        assert np.array_equal(n_quads2, n_quads)
+        ref = sc.congruent_batch_fit_score_list(picks, ids, cP, cQ, PGP_MODE_WEIGHTED, 30.0, list_cap=256)
+        for k in ("n_list", "n_pushed", "best_index", "best_score"):
+            assert got[k] == ref[k], (k, seed, cap_q)
+        for k in ("index", "score", "T", "pose", "best_T", "best_pose", "registered"):
+            assert np.array_equal(got[k], ref[k]), (k, seed, cap_q)
+        sc.find_congruent_batch(ids, w.P_xyz[ids], inv, w.delta)
+    # the draw of one base does not depend on the others (its generator is its own)
+    a = LcpScorer.sample_quads(777, n_quads, 100)
+    b = LcpScorer.sample_quads(777, n_quads[3:], 100)
+    assert np.array_equal(a[a[:, 0] == 0, 1], LcpScorer.sample_quads(777, n_quads[:1], 100)[:, 1])
+    assert not np.array_equal(a[a[:, 0] == 3, 1], b[b[:, 0] == 0, 1]) or n_quads[3] < 100      # base 3 as base 0 of another batch: another stream
+    with pytest.raises(Exception, match="max_per_base"):
+        sc.congruent_batch_sample_fit_score_list(1, ids, cP, cQ, max_per_base=129)
+    sc.close()
