@@ -237,6 +237,12 @@ int pgp_select_bases(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, fl
  * computed where the base is selected, for pgp_find_congruent_batch_rows below (one launch and one round trip less per
  * object than asking for them again). */
 int pgp_select_bases_rows(pgp_ctx* ctx, const double* u, int n_attempts, int* ids, float* invariants, int* status, int* rows);
+/* pgp_select_bases_rows in two halves, for a caller with host work of its own to do meanwhile (the drop-in hashes the
+ * validation model while the selection's ~0.1 ms kernel runs): _begin copies the variates, queues the launch and returns;
+ * _end waits and returns what pgp_select_bases_rows returns (rows nullable).  Between the two, only calls that leave the
+ * scene, its weights and the pair-feature table alone (pgp_set_model); any other selection call drops the begun one. */
+int pgp_select_bases_rows_begin(pgp_ctx* ctx, const double* u, int n_attempts);
+int pgp_select_bases_rows_end(pgp_ctx* ctx, int* ids, float* invariants, int* status, int* rows);
 
 /* The pieces of the above, for parity tests and for callers that keep their own sampling loop:
  * pgp_ppf_features: computePPF for m (i, j) pairs of scene ids -> features[m][4] (-1: not a key,

@@ -87,6 +87,8 @@ SIGNATURES = {
     "pgp_set_ppf_map": (C.c_int, [C.c_void_p, _i, _i, _i, C.c_int]),
     "pgp_select_bases": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, _i, _f, _i]),
     "pgp_select_bases_rows": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, _i, _f, _i, _i]),
+    "pgp_select_bases_rows_begin": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int]),
+    "pgp_select_bases_rows_end": (C.c_int, [C.c_void_p, _i, _f, _i, _i]),
     "pgp_ppf_features": (C.c_int, [C.c_void_p, _i, C.c_int, _i, _i]),
     "pgp_stocs_stage_weights": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _f, _f, _i]),
     "pgp_base_invariants": (C.c_int, [C.c_void_p, _i, C.c_int, _f, _i]),

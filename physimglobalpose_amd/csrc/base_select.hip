@@ -769,8 +769,20 @@ int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pai
   return PGP_OK;
 }
 
+// phase 0: the whole call; 1: queue only (the variates go up from a pinned image of the selection's own, the kernel is
+// launched, nothing is waited for: pgp_select_bases_rows_begin); 2: bring the results of a phase-1 call home (.._end)
 int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_ids, float* h_inv, int* h_status,
-                        int* h_rows, hipStream_t st) {
+                        int* h_rows, hipStream_t st, int phase) {
+  if (phase == 2) {
+    if (ctx->sel_begun_A <= 0) {
+      set_error("pgp_select_bases_rows_end: no selection has been begun");
+      return PGP_ESTATE;
+    }
+    n_attempts = ctx->sel_begun_A;
+    ctx->sel_begun_A = 0;
+  } else {
+    ctx->sel_begun_A = 0;   // (a begun selection that nobody collected is dropped)
+  }
   SelectArgs a{};
   int rc = fill_select_args(ctx, &a);
   if (rc != PGP_OK) return rc;
@@ -807,12 +819,28 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   // the variates go up from the pinned area the results come home to (the call synchronises before it returns): a
   // copy out of the caller's pageable array costs the host ~10 us whatever its size
   HostOut out(ctx, st);
-  unsigned char* up = out.room(A * 32);
-  if (up) std::memcpy(up, h_u, A * 32);
-  if (up) {
-    if ((rc = stage_to_device(st, d_u, up, A * 32)) != PGP_OK) return rc;
-  } else {
-    PGP_HIP(hipMemcpyAsync(d_u, h_u, A * 32, hipMemcpyHostToDevice, st));
+  if (phase == 2) goto collect;
+  {
+    unsigned char* up = nullptr;
+    if (phase == 1) {
+      // (an image that outlives this call: the stage kernel may run after it has returned)
+      if (ctx->h_sel_cap < A * 32) {
+        if (ctx->h_sel_pin) (void)hipHostFree(ctx->h_sel_pin);
+        ctx->h_sel_pin = nullptr;
+        ctx->h_sel_cap = 0;
+        PGP_HIP(hipHostMalloc(&ctx->h_sel_pin, A * 32 + 4096, hipHostMallocDefault));
+        ctx->h_sel_cap = A * 32 + 4096;
+      }
+      up = static_cast<unsigned char*>(ctx->h_sel_pin);
+    } else {
+      up = out.room(A * 32);
+    }
+    if (up) std::memcpy(up, h_u, A * 32);
+    if (up) {
+      if ((rc = stage_to_device(st, d_u, up, A * 32)) != PGP_OK) return rc;
+    } else {
+      PGP_HIP(hipMemcpyAsync(d_u, h_u, A * 32, hipMemcpyHostToDevice, st));
+    }
   }
   a.prob_cdf = ctx->d_prob_cdf.as<double>();
   a.u = d_u;
@@ -820,12 +848,17 @@ int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_
   a.ids = d_ids;
   a.inv = d_inv;
   a.status = d_status;
-  a.rows = h_rows ? d_rows : nullptr;
+  a.rows = (h_rows || phase == 1) ? d_rows : nullptr;   // (a begun selection always writes them: its collector may ask)
   if (getenv("PGP_SEL_GLOBAL") || a.n > kSelLdsPoints)   // (A/B knob; segments beyond the LDS form)
     hipLaunchKernelGGL(select_bases<false>, dim3(n_attempts), dim3(kSelThreads), 0, st, a);
   else
     hipLaunchKernelGGL(select_bases<true>, dim3(n_attempts), dim3(kSelThreads), (size_t)a.n * 4, st, a);
   PGP_HIP(hipGetLastError());
+  if (phase == 1) {
+    ctx->sel_begun_A = n_attempts;
+    return PGP_OK;
+  }
+collect:
   // ids | inv | status | rows lie back to back in the workspace: ONE copy back, into pinned memory (pgp::HostOut)
   const unsigned char* got = nullptr;
   if ((rc = out.fetch(&got, d_ids, h_rows ? rows_off + A * 8 : A * 28)) != PGP_OK || (rc = out.sync()) != PGP_OK) return rc;

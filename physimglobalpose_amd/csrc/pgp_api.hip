@@ -218,6 +218,11 @@ int pgp_destroy(pgp_ctx* ctx) {
     (void)e;
     ctx->h_pin = nullptr;
   }
+  if (ctx->h_sel_pin) {
+    hipError_t e = hipHostFree(ctx->h_sel_pin);
+    (void)e;
+    ctx->h_sel_pin = nullptr;
+  }
   if (ctx->h_flag) {
     hipError_t e = hipHostFree(ctx->h_flag);
     (void)e;
@@ -1071,6 +1076,24 @@ int pgp_select_bases_rows(pgp_ctx* ctx, const double* u, int n_attempts, int* id
   if (n_attempts == 0) return PGP_OK;
   CtxGuard guard(ctx);
   return launch_select_bases(ctx, u, n_attempts, ids, invariants, status, rows, ctx->stream);
+}
+
+int pgp_select_bases_rows_begin(pgp_ctx* ctx, const double* u, int n_attempts) {
+  if (!ctx || n_attempts <= 0 || !u) {
+    set_error("pgp_select_bases_rows_begin: bad argument");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx);
+  return launch_select_bases(ctx, u, n_attempts, nullptr, nullptr, nullptr, nullptr, ctx->stream, 1);
+}
+
+int pgp_select_bases_rows_end(pgp_ctx* ctx, int* ids, float* invariants, int* status, int* rows) {
+  if (!ctx || !ids || !invariants || !status) {
+    set_error("pgp_select_bases_rows_end: bad argument");
+    return PGP_EINVAL;
+  }
+  CtxGuard guard(ctx);
+  return launch_select_bases(ctx, nullptr, 0, ids, invariants, status, rows, ctx->stream, 2);
 }
 
 int pgp_ppf_features(pgp_ctx* ctx, const int* pairs, int m, int* features, int* rows) {

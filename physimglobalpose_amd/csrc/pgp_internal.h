@@ -152,6 +152,9 @@ struct pgp_ctx {
   pgp::DevBuf d_prob_cdf;               // double prefix sums of the scene weights (first draw)
   bool prob_cdf_valid = false;
   pgp::DevBuf d_sel_ws;                 // base-selection workspace / staging
+  int sel_begun_A = 0;                  // attempts of a selection that was queued and not collected yet (pgp_select_bases_rows_begin)
+  void* h_sel_pin = nullptr;            // its variates' pinned image
+  size_t h_sel_cap = 0;
 
   pgp::DevBuf d_pre_ws, d_vg_ws, d_pre_io;   // preprocess.hip: bbox partials, voxel-grid workspace, host-API staging
   pgp::DevBuf d_mls_ws;                      // mls.hip: sort keys, sorted cloud, per-point results
@@ -475,7 +478,7 @@ void icp_scene_form_off(bool off);   // icp.hip: this THREAD's next launch_icp c
 int set_ppf_map(pgp_ctx* ctx, const int* keys, const int* counts, const int* pairs, int n_keys);
 int ppf_thresholds(float tpos[9], float tneg[9]);
 int launch_select_bases(pgp_ctx* ctx, const double* h_u, int n_attempts, int* h_ids, float* h_inv, int* h_status,
-                        int* h_rows /* nullable */, hipStream_t st);
+                        int* h_rows /* nullable */, hipStream_t st, int phase = 0);
 int launch_ppf_features(pgp_ctx* ctx, const int* h_pairs, int m, int* h_f, int* h_row, hipStream_t st);
 int launch_stage_weights(pgp_ctx* ctx, int stage, int b1, int b2, int b3, float* h_cur, float* h_sum, int* h_present,
                          hipStream_t st);

@@ -205,6 +205,19 @@ class LcpScorer:
                                               ids.ctypes.data_as(_i), _fp(inv), st.ctypes.data_as(_i)))
         return ids[:n], inv[:n], st[:n]
 
+    def select_bases_begin(self, u):
+        """pgp_select_bases_rows_begin: queue the selection and return; select_bases_end() collects (ids, inv, status, rows)."""
+        u = np.ascontiguousarray(u, np.float64).reshape(-1, 4)
+        self._sel_n = len(u)
+        _lib.check(self._lib.pgp_select_bases_rows_begin(self._h, u.ctypes.data_as(C.POINTER(C.c_double)), len(u)))
+
+    def select_bases_end(self):
+        n = self._sel_n
+        ids, inv = np.zeros((n, 4), np.int32), np.zeros((n, 2), np.float32)
+        status, rows = np.zeros(n, np.int32), np.zeros((n, 2), np.int32)
+        _lib.check(self._lib.pgp_select_bases_rows_end(self._h, ids.ctypes.data_as(_i), _fp(inv), status.ctypes.data_as(_i), rows.ctypes.data_as(_i)))
+        return ids, inv, status, rows
+
     def ppf_features(self, pairs):
         """pairs (m,2) scene ids -> (features (m,4), table row (m,) or -1)."""
         pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)

@@ -477,6 +477,7 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   ShimState local_state;
   ShimState& st = getenv("PGP_SHIM_NO_CACHE") ? local_state : shim_state();
   ObjectSlot* obj = nullptr;
+  bool model_deferred = false;
   SlotLease lease;                                   // the object's slot is this call's until it returns
   std::unique_lock<std::mutex> single_lock;          // (the device group / single context of the modes that have one)
   // fingerprint of the caller's PPFMap (its two end entries): with its address and size, what an object is known by
@@ -530,12 +531,9 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     mark("ties+context");
     SHIM_PGP(pgp_set_scene(ctx, seg.xyz.data(), seg.nrm.data(), nullptr, seg.n, delta));
     mark("set_scene");
-    const unsigned long long mh = cloud_hash(qval.xyz, qval.nrm);
-    if (mh != obj->model_hash) {
-      obj->model_hash = 0;
-      SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
-      obj->model_hash = mh;
-    }
+    // (the validation model -- hashed, and sent again only when it changed -- is looked at while the base selection's
+    //  kernel runs: ensure_model below; nothing before the verification reads it)
+    model_deferred = true;
     mark("set_model");
   }
   if (obj) {
@@ -625,7 +623,23 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     for (int round = 0; round < 20 && (int)(base_ids.size() / 4) < max_number_of_bases; ++round) {
       ++n_rounds;
       for (double& x : u) x = std::generate_canonical<double, 53>(generator);
-      SHIM_PGP(pgp_select_bases_rows(ctx, u.data(), attempts_per_round, ids.data(), inv.data(), status.data(), rows.data()));
+      if (model_deferred) {
+        // the first round in two halves: the ~0.1 ms kernel is queued, the host hashes the validation model meanwhile
+        // (and sends it only if it changed: an upload would wait for the kernel), then collects the bases
+        SHIM_PGP(pgp_select_bases_rows_begin(ctx, u.data(), attempts_per_round));
+        model_deferred = false;
+        const unsigned long long mh = cloud_hash(qval.xyz, qval.nrm);
+        if (mh != obj->model_hash) {
+          obj->model_hash = 0;
+          SHIM_PGP(pgp_select_bases_rows_end(ctx, ids.data(), inv.data(), status.data(), rows.data()));
+          SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
+          obj->model_hash = mh;
+        } else {
+          SHIM_PGP(pgp_select_bases_rows_end(ctx, ids.data(), inv.data(), status.data(), rows.data()));
+        }
+      } else {
+        SHIM_PGP(pgp_select_bases_rows(ctx, u.data(), attempts_per_round, ids.data(), inv.data(), status.data(), rows.data()));
+      }
       for (int k = 0; k < attempts_per_round && (int)(base_ids.size() / 4) < max_number_of_bases; ++k) {
         if (status[k] != 1) continue;
         base_ids.insert(base_ids.end(), ids.begin() + 4 * k, ids.begin() + 4 * k + 4);
@@ -635,6 +649,14 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     }
   }
   const int n_bases = (int)(base_ids.size() / 4);
+  if (model_deferred) {   // (no round ran)
+    const unsigned long long mh = cloud_hash(qval.xyz, qval.nrm);
+    if (mh != obj->model_hash) {
+      obj->model_hash = 0;
+      SHIM_PGP(pgp_set_model(ctx, qval.xyz.data(), qval.nrm.data(), qval.n));
+      obj->model_hash = mh;
+    }
+  }
 
   mark("base_selection");
   const double ms_bases = ms_since(t_bases);

@@ -182,6 +182,15 @@ def test_rows_that_ride_home_with_the_bases(case):
         i2, v2, s2, r2 = sc.select_bases(u[:n_att], rows=True)
         assert np.array_equal(i2, ids_a[:n_att]) and np.array_equal(v2, inv_a[:n_att]) and np.array_equal(s2, st_a[:n_att])
         assert np.array_equal(r2[s2 == 1], rows[:int((st_a[:n_att] == 1).sum())])
+    # the selection in two halves (pgp_select_bases_rows_begin / _end) with a pgp_set_model in between: the same bases
+    for n_att in (96, 33):
+        sc.select_bases_begin(u[:n_att])
+        sc.set_model(w.Q_xyz, w.Q_nrm)
+        i3, v3, s3, r3 = sc.select_bases_end()
+        assert np.array_equal(i3, ids_a[:n_att]) and np.array_equal(v3, inv_a[:n_att]) and np.array_equal(s3, st_a[:n_att])
+        assert np.array_equal(r3[s3 == 1], rows[:int((st_a[:n_att] == 1).sum())])
+    with pytest.raises(Exception, match="no selection"):
+        sc.select_bases_end()
     n_rows = sc.find_congruent_batch(ids, base_xyz, inv, w.delta, rows=rows)
     assert np.array_equal(n_rows, n_plain) and n_plain.sum() > 0
     assert np.array_equal(sc.congruent_batch_quads(picks), q_plain)
