@@ -1192,8 +1192,8 @@ def main():
         elif world > 1:
             out["native_group_error"] = native_err or ("skipped: " + ("PGP_BENCH_FORM=twin" if backend == "nccl" else
                                                                       "ranks share one device (gloo smoke mode)"))
-        if world == 1 and not multi:
-            out["per_call"] = per_call_one_device(sc, w, torch, mode, d_batches)
+        if world == 1 and not multi and not args.no_cpu_baseline:   # (--no-cpu-baseline = the headline alone: the counter passes of
+            out["per_call"] = per_call_one_device(sc, w, torch, mode, d_batches)   #  tools/collect_pmc.sh average over 4096-hypothesis launches only)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.mode)
             try:

@@ -71,3 +71,5 @@ doc = {"source_id": h.hexdigest()[:16], "collected": datetime.date.today().isofo
 json.dump(doc, open(out + "/pmc_current.json", "w"), indent=1)
 print(json.dumps({k: {c: v.get(c) for c in ("SQ_INSTS_VALU", "TCP_TOTAL_CACHE_ACCESSES_sum", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "n")} for k, v in res.items()}, indent=1))
 PY
+# the raw per-pass outputs are tens of MB (gpurun brings back at most 64 MiB of gpurun_out/): the summaries stay
+rm -rf $OUT/pmc_plain_[0-9] $OUT/pmc_weighted_[0-9] $OUT/trace_plain $OUT/trace_weighted $OUT/pmc_peaks $OUT/lcp_score.s
