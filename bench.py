@@ -1035,7 +1035,10 @@ def main():
     # N > 1 ranks on their own devices: the headline goes through the PRODUCT's group, one member per rank (the torch twin
     # below stays as rows.torch_twin -- and takes the headline over, saying so, should the group fail to form)
     native, native_err = None, None
-    if world > 1 and backend == "nccl" and os.environ.get("PGP_BENCH_FORM") != "twin":
+    # (PGP_BENCH_FORCE_RANKED=1 with PGP_BENCH_FORCE_DIST=1: the same path with ONE rank -- the launcher form's own code on a
+    #  1-GPU box: id through the store, ncclCommInitRank, barriers and max over ranks through torch.distributed)
+    force_ranked = multi and os.environ.get("PGP_BENCH_FORCE_RANKED") == "1"
+    if (world > 1 or force_ranked) and backend == "nccl" and os.environ.get("PGP_BENCH_FORM") != "twin":
         native, native_err = ranked_group_headline(args, torch, dist, rank, world, dev_index, w, mode)
     sc = LcpScorer(dev_index)
     t0 = time.perf_counter()
@@ -1189,7 +1192,7 @@ def main():
                     "form": "torch.distributed ranks, sharding.BucketedExchange (the Python twin of the exchange)"}
             out = native
             out["other_rows"] = {"torch_twin": twin}
-        elif world > 1:
+        elif world > 1 or force_ranked:
             out["native_group_error"] = native_err or ("skipped: " + ("PGP_BENCH_FORM=twin" if backend == "nccl" else
                                                                       "ranks share one device (gloo smoke mode)"))
         if world == 1 and not multi and not args.no_cpu_baseline:   # (--no-cpu-baseline = the headline alone: the counter passes of

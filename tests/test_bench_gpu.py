@@ -133,3 +133,23 @@ def test_launcherless_multi_gpu_run_emulated():
     assert "cpu_baseline" not in d
     tw = d["rows"]["torch_twin"]
     assert "error" not in tw and tw["value"] > 0 and tw["n_gpus"] == 2, tw
+
+
+def test_launcher_form_with_one_rank_goes_through_the_products_group():
+    """The driver's launch form (`torch.distributed.run ... bench.py --gpus N`) takes its headline from libpgp's RANKED group: one
+    member per rank, the communicator's id through the launcher's store, ncclCommInitRank, barriers / max over ranks through
+    torch.distributed.  With one rank on this box's one device (PGP_BENCH_FORCE_DIST + PGP_BENCH_FORCE_RANKED, a real one-rank
+    communicator: PGP_MULTI_FORCE_COLLECTIVE) every line of that path runs; the torch twin becomes rows.torch_twin."""
+    env = dict(os.environ, PGP_BENCH_FORCE_DIST="1", PGP_BENCH_FORCE_RANKED="1", PGP_MULTI_FORCE_COLLECTIVE="1", MASTER_PORT="29549")
+    out = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                         cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
+    d = _check(lines[0], 1)
+    assert "native_group_error" not in d, d.get("native_group_error")
+    assert d["rccl_ranks"] == 1 and d["devices"] == [0] and d["equals_single_device"] is True and d["exchanges_issued"] > 6
+    assert "ncclCommInitRank" in d["launch"] and "ranks 0.." in d["config"]["group"] or "single process" in d["config"]["group"]
+    assert d["per_call"]["host_pointers"]["median_ms"] > 0 and d["per_call"]["resident"]["median_ms"] > 0
+    tw = d["rows"]["torch_twin"]
+    assert tw["value"] > 1e6 and tw["ms_per_step"] > 0
