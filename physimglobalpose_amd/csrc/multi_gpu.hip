@@ -181,9 +181,45 @@ __global__ __launch_bounds__(256) void emulate_sum(const float* const* __restric
   reinterpret_cast<int*>(out)[i] = s;
 }
 
+// member 0's job with its device current on the CALLING thread (restored afterwards)
+int on_caller(pgp_multi* m, const std::function<int()>& job) {
+  int prev = -1;
+  if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  if (prev != m->dev[0] && hipSetDevice(m->dev[0]) != hipSuccess) {
+    set_error("hipSetDevice(%d) failed", m->dev[0]);
+    return PGP_EHIP;
+  }
+  const int r = job();
+  if (prev >= 0 && prev != m->dev[0]) (void)hipSetDevice(prev);
+  return r;
+}
+
+// fn(k) for every member: members 1 .. n-1 on their worker threads, member 0 -- the one whose work ends the call: the arg-max
+// and the way home -- on the calling thread itself: a hand-off to a worker and back costs the call ~20 us (0.146 against
+// 0.127 ms for a one-member group's host-pointer call), and a group of one then hands nothing off at all.
+// PGP_MULTI_CALLER_RUNS=0: every member on its worker (the form up to round 5).
 int run_all(pgp_multi* m, const std::function<int(int)>& fn) {
-  for (int k = 0; k < m->n; ++k) m->worker[k]->post([&fn, k] { return fn(k); });
+  static const bool caller_runs = !(getenv("PGP_MULTI_CALLER_RUNS") && atoi(getenv("PGP_MULTI_CALLER_RUNS")) == 0);
+  const int first = caller_runs ? 1 : 0;
+  for (int k = first; k < m->n; ++k) m->worker[k]->post([&fn, k] { return fn(k); });
   int rc = PGP_OK;
+  if (caller_runs) {
+    char keep[512] = "";
+    rc = on_caller(m, [&fn] { return fn(0); });
+    if (rc != PGP_OK) {   // (the text is this thread's own already: keep it across the waits below)
+      std::strncpy(keep, pgp_last_error(), sizeof keep - 1);
+      keep[sizeof keep - 1] = 0;
+    }
+    for (int k = 1; k < m->n; ++k) {
+      const int r = m->worker[k]->wait();
+      if (r != PGP_OK && rc == PGP_OK) {
+        rc = r;
+        set_error("device %d: %s", m->dev[k], m->worker[k]->err);
+      }
+    }
+    if (keep[0]) set_error("device %d: %s", m->dev[0], keep);
+    return rc;
+  }
   for (int k = 0; k < m->n; ++k) {
     int r = m->worker[k]->wait();
     if (r != PGP_OK && rc == PGP_OK) {
@@ -382,10 +418,7 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
         return PGP_EHIP;
       }
     }
-    Worker* w0 = m->worker[0];
-    w0->post(tail);
-    rc = w0->wait();
-    if (rc != PGP_OK) set_error("device %d: %s", m->dev[0], w0->err);
+    rc = on_caller(m, tail);
   }
   if (rc != PGP_OK) return rc;
   if (N > 0) {
