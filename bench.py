@@ -1038,7 +1038,10 @@ def main():
     # (PGP_BENCH_FORCE_RANKED=1 with PGP_BENCH_FORCE_DIST=1: the same path with ONE rank -- the launcher form's own code on a
     #  1-GPU box: id through the store, ncclCommInitRank, barriers and max over ranks through torch.distributed)
     force_ranked = multi and os.environ.get("PGP_BENCH_FORCE_RANKED") == "1"
-    if (world > 1 or force_ranked) and backend == "nccl" and os.environ.get("PGP_BENCH_FORM") != "twin":
+    # (PGP_MULTI_EMULATE_RANKED=1 with the gloo smoke mode: the ranks share ONE device and libpgp exchanges through shared
+    #  memory -- the launcher form with several ranks on a 1-GPU box, `emulated: true`, never a performance figure)
+    emulate_ranked = os.environ.get("PGP_MULTI_EMULATE_RANKED", "0") not in ("", "0")
+    if (world > 1 or force_ranked) and (backend == "nccl" or emulate_ranked) and os.environ.get("PGP_BENCH_FORM") != "twin":
         native, native_err = ranked_group_headline(args, torch, dist, rank, world, dev_index, w, mode)
     sc = LcpScorer(dev_index)
     t0 = time.perf_counter()

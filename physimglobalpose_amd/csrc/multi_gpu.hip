@@ -29,14 +29,20 @@
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <random>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -104,6 +110,23 @@ struct Streaming {
   DevBuf ring[2];
   hipEvent_t scored[2] = {nullptr, nullptr}, reduced[2] = {nullptr, nullptr};
 };
+// PGP_MULTI_EMULATE_RANKED=1: the exchange of a group that spans PROCESSES without RCCL (which refuses one device twice):
+// every rank's slice goes through a POSIX shared-memory segment named after the group's id -- so that the launcher form (one
+// process per rank, slices by global rank, every process holding all transforms and taking the arg-max itself) runs with
+// several ranks on ONE device.  Host-synchronous, a test vehicle like PGP_MULTI_EMULATE, never a performance configuration.
+struct ShmExchange {
+  struct Header {
+    std::atomic<unsigned> arrived;
+    unsigned pad[15];
+  };
+  Header* h = nullptr;
+  unsigned char* data = nullptr;   // two buffers of `cap` bytes
+  size_t cap = 0, total = 0;
+  std::string name;
+  unsigned seq = 0;
+};
+constexpr size_t kShmCap = (size_t)16 << 20;   // per buffer: 2 M hypotheses
+
 constexpr int kSlots = 16;        // resident hypothesis batches of the streaming form
 constexpr int kEmulateMax = 16;   // members of an emulated group the streaming form's sum kernel takes
 
@@ -121,6 +144,8 @@ struct pgp_multi {
   bool use_coll = false;
   bool grouped = false;   // PGP_MULTI_COLL=grouped: the collective is issued for all members by the calling thread
   bool emulate = false;   // PGP_MULTI_EMULATE: members share one device, exchange = emulate_sum
+  bool emulate_ranked = false;   // PGP_MULTI_EMULATE_RANKED: a ranked group's exchange through shared memory (ShmExchange)
+  ShmExchange shm;
   std::vector<hipEvent_t> ev;   // emulate: one event per member
   DevBuf d_sum;                 // emulate: the summed vector before it is handed to every member
   Rccl rccl;
@@ -262,6 +287,40 @@ void slice_of(int n_total, int k, int n_dev, int* lo, int* hi) {
   *hi = *lo + base + (k < rem ? 1 : 0);
 }
 
+// The all-reduce of a ranked group under PGP_MULTI_EMULATE_RANKED: this rank's slice of {scores | counts} into the shared
+// segment, a barrier over the ranks, the complete vector back (= the sum: every element is non-zero on its owner only).
+int shm_exchange(pgp_multi* m, float* d_s, int N, hipStream_t st) {
+  ShmExchange& x = m->shm;
+  const size_t bytes = (size_t)N * 8;
+  if (bytes > x.cap) {
+    set_error("PGP_MULTI_EMULATE_RANKED: %d hypotheses exceed the shared segment", N);
+    return PGP_EINVAL;
+  }
+  int lo, hi;
+  slice_of(N, m->rank0, m->world, &lo, &hi);
+  unsigned char* buf = x.data + (size_t)(x.seq & 1u) * x.cap;
+  if (hi > lo) {
+    PGP_HIP(hipMemcpyAsync(buf + (size_t)lo * 4, d_s + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, st));
+    PGP_HIP(hipMemcpyAsync(buf + (size_t)N * 4 + (size_t)lo * 4, reinterpret_cast<int*>(d_s + N) + lo, (size_t)(hi - lo) * 4,
+                           hipMemcpyDeviceToHost, st));
+  }
+  PGP_HIP(hipStreamSynchronize(st));
+  x.h->arrived.fetch_add(1u, std::memory_order_acq_rel);
+  const unsigned want = (unsigned)m->world * (x.seq + 1u);
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(120);
+  while (x.h->arrived.load(std::memory_order_acquire) < want) {
+    if (std::chrono::steady_clock::now() >= t_end) {
+      set_error("PGP_MULTI_EMULATE_RANKED: a rank did not arrive at exchange %u", x.seq);
+      return PGP_EHIP;
+    }
+    std::this_thread::yield();
+  }
+  PGP_HIP(hipMemcpyAsync(d_s, buf, bytes, hipMemcpyHostToDevice, st));
+  PGP_HIP(hipStreamSynchronize(st));   // (the buffer is written again two exchanges on, behind the next one's barrier)
+  ++x.seq;
+  return PGP_OK;
+}
+
 // The scoring call over whatever pgp_multi_upload[_objects] left on the devices.  scores / counts: flat, object after
 // object; best_index / best_score: one entry per object.
 int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* counts, int* best_index, float* best_score) {
@@ -373,6 +432,7 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
   // latency-bound (32 KB per member), so two collectives cost twice what one does.
   auto own_allreduce = [&](int k) -> int {
     float* d_s = m->d_all[k].as<float>();
+    if (m->emulate_ranked) return shm_exchange(m, d_s, N, m->stream[k]);
     const ncclResult_t nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)N, ncclInt32, ncclSum, m->comm[k], m->stream[k]);
     if (nr != ncclSuccess) {
       set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
@@ -389,7 +449,7 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
       if (r == PGP_OK && k == 0) r = tail();
       return r;
     });
-  } else if (exchange && m->use_coll && !m->emulate && N > 0 && !m->grouped) {
+  } else if (exchange && m->use_coll && !m->emulate && N > 0 && (!m->grouped || m->emulate_ranked)) {
     // default: every member's worker thread queues its slice, its own all-reduce call (one communicator per device, the
     // multi-thread form RCCL documents) and, on member 0, the tail -- ONE rendezvous of the calling thread per call.
     // A member whose slice failed to queue still joins the collective: the others' streams would wait for it forever.
@@ -611,7 +671,34 @@ int create_group(pgp_multi** out, const int* device_ids, int n_dev, int rank0, i
       return PGP_OK;
     });
   }
-  if (rc == PGP_OK && m->use_coll && !m->emulate) {
+  if (rc == PGP_OK && ranked && getenv("PGP_MULTI_EMULATE_RANKED") && atoi(getenv("PGP_MULTI_EMULATE_RANKED")) != 0) {
+    if (n_dev != 1) {
+      set_error("PGP_MULTI_EMULATE_RANKED: one member per process");
+      rc = PGP_EINVAL;
+    } else {
+      unsigned long long hsh = 0xCBF29CE484222325ull;
+      for (int i = 0; i < 128; ++i) hsh = (hsh ^ static_cast<const unsigned char*>(id)[i]) * 0x100000001B3ull;
+      char name[64];
+      std::snprintf(name, sizeof name, "/pgp_emu_%016llx", hsh);
+      ShmExchange& x = m->shm;
+      x.name = name;
+      x.cap = kShmCap;
+      x.total = 4096 + 2 * x.cap;
+      const int fd = shm_open(name, O_CREAT | O_RDWR, 0600);
+      void* p = MAP_FAILED;
+      if (fd >= 0 && ftruncate(fd, (off_t)x.total) == 0) p = mmap(nullptr, x.total, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+      if (fd >= 0) close(fd);
+      if (p == MAP_FAILED) {
+        set_error("PGP_MULTI_EMULATE_RANKED: shared segment %s: %s", name, std::strerror(errno));
+        rc = PGP_EHIP;
+      } else {
+        x.h = static_cast<ShmExchange::Header*>(p);   // (a fresh segment is zero-filled: arrived = 0)
+        x.data = static_cast<unsigned char*>(p) + 4096;
+        m->emulate_ranked = true;
+      }
+    }
+  }
+  if (rc == PGP_OK && m->use_coll && !m->emulate && !m->emulate_ranked) {
     if (!load_rccl(&m->rccl)) rc = PGP_ENODEV;
     if (rc == PGP_OK) {
       m->comm.assign(n_dev, nullptr);
@@ -675,6 +762,16 @@ int pgp_multi_unique_id(void* id128) {
     set_error("pgp_multi_unique_id: id128 is NULL");
     return PGP_EINVAL;
   }
+  if (getenv("PGP_MULTI_EMULATE_RANKED") && atoi(getenv("PGP_MULTI_EMULATE_RANKED")) != 0) {
+    // (no communicator will be made of it: 128 random bytes name the ranks' shared segment)
+    std::random_device rd;
+    unsigned char* out = static_cast<unsigned char*>(id128);
+    for (int i = 0; i < 128; i += 4) {
+      const unsigned v = rd();
+      std::memcpy(out + i, &v, 4);
+    }
+    return PGP_OK;
+  }
   static Rccl r;   // (the handle stays loaded for the life of the process, as a group's does)
   if (!load_rccl(&r)) return PGP_ENODEV;
   ncclUniqueId uid;
@@ -705,7 +802,7 @@ int pgp_multi_get_info(pgp_multi* m, pgp_multi_info* info) {
   info->n_local = m->n;
   info->world = m->world;
   info->rank0 = m->rank0;
-  info->emulated = m->emulate ? 1 : 0;
+  info->emulated = (m->emulate || m->emulate_ranked) ? 1 : 0;
   info->exchanges = m->n_exchanges;
   for (int k = 0; k < m->n && k < 16; ++k) info->devices[k] = m->dev[(size_t)k];
   if (!m->comm.empty() && m->comm[0]) {
@@ -767,6 +864,10 @@ int pgp_multi_destroy(pgp_multi* m) {
   for (Worker* w : m->worker) {
     w->shut_down();
     delete w;
+  }
+  if (m->shm.h) {
+    (void)munmap(m->shm.h, m->shm.total);
+    if (m->rank0 == 0) (void)shm_unlink(m->shm.name.c_str());
   }
   if (m->h_pin) (void)hipHostFree(m->h_pin);
   // the RCCL handle stays loaded for the life of the process (its own teardown runs at exit)
@@ -1092,10 +1193,14 @@ int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg) {
       if (r1 == PGP_OK && r2 == PGP_OK && k > 0) PGP_HIP(hipStreamWaitEvent(X, m->ev_sum[b], 0));
     } else {
       // (a member whose slice failed to queue still joins the collective: the others' streams would wait for it forever)
-      const ncclResult_t nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)N, ncclInt32, ncclSum, m->comm[(size_t)k], X);
-      if (nr != ncclSuccess) {
-        set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
-        r2 = PGP_EHIP;
+      if (m->emulate_ranked) {
+        r2 = shm_exchange(m, d_s, N, X);   // (host-synchronous: X has waited for the slice)
+      } else {
+        const ncclResult_t nr = m->rccl.AllReduce(d_s, d_s, 2 * (size_t)N, ncclInt32, ncclSum, m->comm[(size_t)k], X);
+        if (nr != ncclSuccess) {
+          set_error("ncclAllReduce failed: %s", m->rccl.GetErrorString(nr));
+          r2 = PGP_EHIP;
+        }
       }
     }
     if (r1 != PGP_OK) return r1;

@@ -153,3 +153,22 @@ def test_launcher_form_with_one_rank_goes_through_the_products_group():
     assert d["per_call"]["host_pointers"]["median_ms"] > 0 and d["per_call"]["resident"]["median_ms"] > 0
     tw = d["rows"]["torch_twin"]
     assert tw["value"] > 1e6 and tw["ms_per_step"] > 0
+
+
+def test_launcher_form_with_two_ranks_on_one_device_through_the_products_group():
+    """The driver's launch line with TWO ranks on this box's one device: torch.distributed over gloo carries the id, the barriers and
+    the max over ranks; libpgp's ranked group exchanges through shared memory (PGP_MULTI_EMULATE_RANKED: RCCL refuses one device
+    twice).  The headline comes from the product's group (`emulated: true`), the twin is the secondary row."""
+    env = dict(os.environ, PGP_DIST_BACKEND="gloo", PGP_MULTI_EMULATE_RANKED="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", "bench.py", "--gpus", "2",
+                          "--steps", "6", "--warmup", "2"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), out.stdout[-500:]
+    d = _check(lines[0], 2)
+    assert "native_group_error" not in d, d.get("native_group_error")
+    assert d["emulated"] is True and d["rccl_ranks"] == 0 and d["devices"] == [0] and d["equals_single_device"] is True
+    assert "ncclCommInitRank" in d["launch"] and "of 2 processes" in d["config"]["group"]
+    assert d["per_call"]["host_pointers"]["median_ms"] > 0
+    assert d["rows"]["torch_twin"]["value"] > 0
