@@ -353,10 +353,11 @@ int pgp_congruent_batch_fit_score_list(pgp_ctx* ctx, const int* picks, const int
 
 /* The same call with the sampling of the quads (base.cc:1858-1866: at most 100 random quads per base) done ON THE DEVICE, where
  * the quad counts are: no picks to draw on the host between the congruent sets and the fits, none to upload.  The draw is a
- * function of (seed, base, the base's quad count) alone -- a splitmix64 stream per base, (z >> 33) % n until max_per_base
- * DIFFERENT values have come, handed out in ascending order; a base with fewer quads hands out all of them --, so the bases are
- * drawn side by side, and pgp_sample_quads is the same function on the host (the reference draws from rand() seeded from
- * the clock: any max_per_base distinct uniform draws are its behaviour).  Works on the batch pgp_find_congruent_batch[_rows]
+ * function of (seed, base, the base's quad count) alone -- a counter-based splitmix64 generator per base feeding Floyd's subset
+ * algorithm (max_per_base steps whatever the count, every subset equally likely), handed out in ascending order; a base with
+ * fewer quads hands out all of them --, so the bases are drawn side by side, and pgp_sample_quads is the same function on the
+ * host (the reference draws from rand() seeded from the clock: any uniform sample of max_per_base distinct quads is its
+ * behaviour).  Works on the batch pgp_find_congruent_batch[_rows]
  * left resident; base_ids[n_bases][4] as there.  picks_out (nullable, room for n_bases x max_per_base x 2) / n_picks
  * (nullable) return what was drawn: the picks a pgp_congruent_batch_fit_score_list call would need for the same result.
  * 1 <= max_per_base <= 128. */

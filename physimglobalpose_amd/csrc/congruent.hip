@@ -1070,6 +1070,9 @@ int launch_find_congruent_batch(pgp_ctx* ctx, const int* h_base_ids, const float
   unsigned long long* keys_in = ctx->d_cs_keys.as<unsigned long long>();
   unsigned long long* keys_out = keys_in + ctx->csb_keys_off;
   void* sort_tmp = keys_out + ctx->csb_keys_off;
+  // (Round 6 tried the keys in order WITHOUT the device-wide radix sort -- scattered to their base's segment, every segment sorted
+  //  by one workgroup in LDS (bitonic): ~190 us against rocPRIM's ~35, because ONE base of the drop-in's case holds 4389 of the
+  //  13 928 keys and a bitonic sort of 8192 64-bit keys by 256 threads is 91 passes over LDS; profiles/r06_ab/device_draw.log.)
   hipError_t he = rocprim::radix_sort_keys(sort_tmp, sort_bytes, keys_in, keys_out, (size_t)total, 0, 64, st);
   if (he != hipSuccess) {
     set_error("rocprim::radix_sort_keys failed: %s", hipGetErrorString(he));

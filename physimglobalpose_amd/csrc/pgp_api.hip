@@ -1558,21 +1558,22 @@ int pgp_congruent_batch_fetch(pgp_ctx* ctx, const int* index, int k, float* T, d
 namespace pgp {
 namespace {
 // The drop-in's draw of at most `cap` quads per base (base.cc:1858-1866) as a function of (seed, base, quads of the base)
-// alone: every base has a generator of its own -- splitmix64 from a state mixed out of the seed and the base's number --,
-// draws (z >> 33) % nq (31-bit values, as rand() gives) until `cap` DIFFERENT ones have come, and hands them out in ascending
-// order; a base with fewer than `cap` quads hands out all of them.  The reference draws from the process's rand(), seeded from
-// the clock: any set of `cap` distinct uniform draws is the reference's behaviour.  Per-base streams make the draw parallel
-// over the bases -- on the device (sample_quads_kernel) and on the host (pgp_sample_quads), bit for bit the same picks.
+// alone.  Every base has a COUNTER-BASED generator of its own: variate i is splitmix64's finaliser of state + (i + 1) * gamma, the
+// state mixed out of the seed and the base's number -- so a wave computes all `cap` variates at once.  The subset is Floyd's: for
+// i = 0 .. cap-1, with j = n - cap + i: t = (variate i >> 33) % (j + 1) (31-bit values, as rand() gives); t joins the sample
+// unless it is in it already, in which case j does.  Exactly `cap` steps whatever n (drawing until `cap` different values have
+// come takes ~5 n draws when n is barely above cap), every subset equally likely; handed out in ascending order; a base with
+// fewer than `cap` quads hands out all of them.  The reference draws from the process's rand(), seeded from the clock: any
+// uniform sample of `cap` distinct quads is its behaviour.  sample_quads_kernel and pgp_sample_quads: bit for bit the same picks.
 __host__ __device__ inline unsigned long long sample_state(unsigned long long seed, int base) {
   return (seed ^ 0xD1B54A32D192ED03ull) + (unsigned long long)(base + 1) * 0xBF58476D1CE4E5B9ull;
 }
-__host__ __device__ inline unsigned int sample_draw(unsigned long long* x, unsigned int nq) {
-  *x += 0x9E3779B97F4A7C15ull;
-  unsigned long long z = *x;
+__host__ __device__ inline unsigned int sample_variate(unsigned long long state, int i) {
+  unsigned long long z = state + (unsigned long long)(i + 1) * 0x9E3779B97F4A7C15ull;
   z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
   z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
   z ^= z >> 31;
-  return (unsigned int)(z >> 33) % nq;
+  return (unsigned int)(z >> 33);
 }
 constexpr int kSampleMax = 128;   // two slots per lane of the base's wave
 
@@ -1594,21 +1595,25 @@ __global__ __launch_bounds__(64) void sample_quads_kernel(const uint32_t* __rest
     }
     return;
   }
-  uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;   // slot `lane` and slot `lane + 64` (no draw is 2^32 - 1)
-  unsigned long long x = sample_state(seed, b);
-  for (int n = 0; n < cap;) {
-    const uint32_t v = sample_draw(&x, nq);       // (the same value in every lane)
-    if (__ballot(s0 == v || s1 == v) != 0ull) continue;
-    if (lane == (n & 63)) {
-      if (n < 64) s0 = v;
+  // this lane's two candidates of Floyd's steps i = lane and i = lane + 64, all lanes at once
+  const unsigned long long x = sample_state(seed, b);
+  const uint32_t j0 = nq - (uint32_t)cap + (uint32_t)lane, j1 = j0 + 64u;
+  const uint32_t t0 = lane < cap ? sample_variate(x, lane) % (j0 + 1u) : 0u;
+  const uint32_t t1 = lane + 64 < cap ? sample_variate(x, lane + 64) % (j1 + 1u) : 0u;
+  uint32_t s0 = 0xFFFFFFFFu, s1 = 0xFFFFFFFFu;   // slot `lane` and slot `lane + 64` (no quad is number 2^32 - 1)
+  for (int i = 0; i < cap; ++i) {
+    // (i is the same in every lane: v_readlane, not a cross-lane permute in the middle of the chain)
+    const uint32_t t = (uint32_t)(i < 64 ? __builtin_amdgcn_readlane((int)t0, i) : __builtin_amdgcn_readlane((int)t1, i - 64));
+    const uint32_t v = __ballot(s0 == t || s1 == t) != 0ull ? nq - (uint32_t)cap + (uint32_t)i : t;
+    if (lane == (i & 63)) {
+      if (i < 64) s0 = v;
       else s1 = v;
     }
-    ++n;
   }
   // ascending: a value's place is the number of smaller ones
   uint32_t r0 = 0, r1 = 0;
   for (int i = 0; i < cap; ++i) {
-    const uint32_t u = i < 64 ? __shfl(s0, i, 64) : __shfl(s1, i - 64, 64);
+    const uint32_t u = (uint32_t)(i < 64 ? __builtin_amdgcn_readlane((int)s0, i) : __builtin_amdgcn_readlane((int)s1, i - 64));
     r0 += u < s0 ? 1u : 0u;
     r1 += u < s1 ? 1u : 0u;
   }
@@ -1659,10 +1664,11 @@ int pgp_sample_quads(unsigned long long seed, const int* n_quads, int n_bases, i
       continue;
     }
     got.clear();
-    unsigned long long x = sample_state(seed, b);
-    while ((int)got.size() < max_per_base) {
-      const unsigned int v = sample_draw(&x, (unsigned int)nq);
-      if (std::find(got.begin(), got.end(), v) == got.end()) got.push_back(v);
+    const unsigned long long x = sample_state(seed, b);
+    for (int i = 0; i < max_per_base; ++i) {   // Floyd's steps (see sample_quads_kernel)
+      const unsigned int j = (unsigned int)(nq - max_per_base + i);
+      const unsigned int t = sample_variate(x, i) % (j + 1u);
+      got.push_back(std::find(got.begin(), got.end(), t) == got.end() ? t : j);
     }
     std::sort(got.begin(), got.end());
     for (unsigned int v : got) {

@@ -676,8 +676,8 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
   // side with other calls, a generator of the call's own) -- while the device sorts the batch's keys, which takes about as
   // long.  PGP_SHIM_RAND=device: the draw happens ON THE DEVICE instead, inside the call that fits and verifies
   // (pgp_congruent_batch_sample_fit_score_list: a generator per base, the bases drawn side by side where their quad counts are;
-  // the host draws nothing and uploads no picks).  Measured (profiles/r06_ab/device_draw.log): the host's 36 us were hidden
-  // behind the sort, the device's draw waits for it -- 0.472 against 0.451 ms per call; kept as an option, not the default.
+  // the host draws nothing and uploads no picks).  Measured (profiles/r06_ab/device_draw.log): the host's 36 us are hidden
+  // behind the device's key sort, the device's draw waits for it -- equal within 2 % per call; an option, not the default.
   const char* rand_mode = getenv("PGP_SHIM_RAND");
   const bool device_draw = !st.group && rand_mode && std::strcmp(rand_mode, "device") == 0;
   // (64 bits of the call's seed: the clock's count, or PGP_SHIM_SEED -- the same picks call after call under a fixed seed)
