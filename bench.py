@@ -1333,6 +1333,39 @@ def compact_line(out):
         line["per_call"] = json.loads(json.dumps(line["per_call"]), parse_float=lambda x: round(float(x), 4) if abs(float(x)) < 1000 else round(float(x)))
     line["detail"] = detail
     line["rows"] = rows
+    # LAST: what a reader of the record's kept tail (the driver keeps the line's last 2000 characters) must not miss, in
+    # ~1500 characters -- the honesty lines next to the headline and the rows this round moved
+    pc = out.get("per_call") or {}
+
+    def q(n, form):
+        v = get(pc, n, form) or {}
+        return [r3(v.get("median_ms")), r3(v.get("p99_ms"))]
+
+    summary = {"headline_stream_form_hyp_per_s": r3(out.get("value")), "ms_per_step": r3(out.get("ms_per_step"))}
+    if get(out, "parity_clean_value", "hypotheses_per_s") is not None:
+        summary["exact_ties_hyp_per_s_every_score_within_1e-4"] = r3(get(out, "parity_clean_value", "hypotheses_per_s"))
+    if "4096" in pc:
+        summary["one_synchronous_call_ms_median_p99"] = {"pgp_score_lcp_4096": q("4096", "host_pointers"), "pgp_score_lcp_3000": q("3000", "host_pointers"),
+                                                         "device_pointers_plus_sync_4096": q("4096", "device_pointers")}
+    elif "host_pointers" in pc:   # the device group's forms (N > 1)
+        summary["one_synchronous_call_ms_median_p99"] = {"pgp_multi_score_lcp": [r3(get(pc, "host_pointers", "median_ms")), r3(get(pc, "host_pointers", "p99_ms"))],
+                                                         "pgp_multi_score_uploaded": [r3(get(pc, "resident", "median_ms")), r3(get(pc, "resident", "p99_ms"))]}
+    hbm, valu = get(out, "roofline", "units", "hbm", "frac"), get(out, "roofline", "units", "valu_issue", "frac")
+    summary["roofline"] = (f"binding unit VALU issue {valu if valu is None else round(valu, 2)}; HBM fraction {hbm if hbm is None else round(hbm, 2)} "
+                           "(north_star's 40 % HBM target does not apply to an indexed kernel)")
+    for k in ("rccl_ranks", "devices", "emulated", "equals_single_device", "native_group_error"):
+        if k in out:
+            summary[k] = out[k]
+    if rows and "error" not in rows:
+        for k in ("drop_in_in_memory_ms_median_p99_first", "drop_in_frame_of_3_ms_side_by_side_one_by_one", "drop_in_file_path_ms_median_p99_cvpng"):
+            if k in rows:
+                summary[k] = rows[k]
+        nmr = rows.get("native_multi")
+        if isinstance(nmr, dict) and "error" not in nmr:
+            summary["one_member_group_ms_resident_host_pointers"] = [nmr.get("lcp_resident_ms"), nmr.get("lcp_host_pointers_ms")]
+        if "torch_twin" in rows:
+            summary["torch_twin_hyp_per_s"] = get(rows, "torch_twin", "value")
+    line["summary"] = summary
     return line
 
 

@@ -49,7 +49,11 @@ def test_single_gpu_line():
     assert len(lines) == 1
     d = _check(lines[0], 1)
     # the driver keeps a TAIL of this line: it must be short, and the round's secondary rows come LAST in it
-    assert len(lines[0]) < 7000 and list(d)[-1] == "rows" and len(json.dumps(d["rows"])) < 3000
+    assert len(lines[0]) < 8000 and list(d)[-2:] == ["rows", "summary"] and len(json.dumps(d["rows"])) < 3000
+    sm = d["summary"]                                    # the record keeps the line's last 2000 characters: the honesty lines are there
+    assert len(json.dumps(sm)) < 1800 and lines[0].endswith(json.dumps(sm) + "}")
+    assert sm["exact_ties_hyp_per_s_every_score_within_1e-4"] > 1e6 and sm["headline_stream_form_hyp_per_s"] == pytest.approx(d["value"], rel=1e-3)
+    assert sm["one_synchronous_call_ms_median_p99"]["pgp_score_lcp_4096"][0] > 0 and "VALU issue" in sm["roofline"]
     rows = d["rows"]
     med, lo, hi = rows["icp_pose_iter_per_s_median_min_max"]["64"]
     assert lo <= med <= hi and rows["icp_table_alignment_ms"] > 0 and rows["exact_ties_hyp_per_s"] > 1e6
