@@ -672,21 +672,29 @@ static void match_impl(const Super4PCSCloudView& segment, const Super4PCSCloudVi
     SHIM_PGP(pgp_find_congruent_batch_rows(ctx, base_ids.data(), base_xyz.data(), base_inv.data(), base_rows.data(), n_bases,
                                            delta, n_quads.data()));
   mark("congruent_sets");
-  // The draw of at most 100 quads per base (base.cc:1858-1866): on the host, below, from the process's rand() (or, side by
-  // side with other calls, a generator of the call's own) -- while the device sorts the batch's keys, which takes about as
-  // long.  PGP_SHIM_RAND=device: the draw happens ON THE DEVICE instead, inside the call that fits and verifies
-  // (pgp_congruent_batch_sample_fit_score_list: a generator per base, the bases drawn side by side where their quad counts are;
-  // the host draws nothing and uploads no picks).  Measured (profiles/r06_ab/device_draw.log): the host's 36 us are hidden
-  // behind the device's key sort, the device's draw waits for it -- equal within 2 % per call; an option, not the default.
+  // The draw of at most 100 quads per base (base.cc:1858-1866).  By default it happens ON THE DEVICE, inside the call that fits
+  // and verifies (pgp_congruent_batch_sample_fit_score_list: counter-based variates and Floyd's subset algorithm, one wave per
+  // base, seeded from this call's seed -- the host draws nothing and uploads no picks; the device group's path draws the SAME
+  // picks on the host, pgp_sample_quads).  PGP_SHIM_RAND=host: the host loop below, from the process's rand() (or, side by side
+  // with other calls, a generator of the call's own) -- the streams of rounds 2-5, kept for their fixed-seed soaks.  The two
+  // come out within 2 % of each other (the host's draw hides behind the device's key sort, the device's waits for it but
+  // saves the picks' way up): profiles/r06_ab/device_draw.log.
   const char* rand_mode = getenv("PGP_SHIM_RAND");
-  const bool device_draw = !st.group && rand_mode && std::strcmp(rand_mode, "device") == 0;
+  const bool host_draw = rand_mode && std::strcmp(rand_mode, "host") == 0;
+  const bool device_draw = !st.group && !host_draw;
   // (64 bits of the call's seed: the clock's count, or PGP_SHIM_SEED -- the same picks call after call under a fixed seed)
   const unsigned long long draw_seed = getenv("PGP_SHIM_SEED") ? (unsigned long long)seed
                                                                : (unsigned long long)std::chrono::system_clock::now().time_since_epoch().count();
   std::vector<int> picks;   // (base, j) pairs
   picks.reserve(device_draw ? 0 : 2 * (size_t)n_bases * max_sampled_csets);
   std::vector<unsigned long long> seen;
-  for (int b = 0; b < n_bases && !device_draw; ++b) {
+  if (st.group && !host_draw && n_bases > 0) {   // (the device's draw, stated on the host: the group's fits take picks)
+    picks.resize(2 * (size_t)n_bases * max_sampled_csets);
+    int got = 0;
+    SHIM_PGP(pgp_sample_quads(draw_seed, n_quads.data(), n_bases, max_sampled_csets, picks.data(), &got));
+    picks.resize(2 * (size_t)got);
+  }
+  for (int b = 0; b < n_bases && host_draw; ++b) {
     const int nq = n_quads[b];
     if (nq < max_sampled_csets) {
       for (int j = 0; j < nq; ++j) { picks.push_back(b); picks.push_back(j); }
