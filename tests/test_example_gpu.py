@@ -58,3 +58,20 @@ def test_cpp_host_six_objects_over_the_device_group(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("OK")
     print(out.stdout)
+
+
+@pytest.mark.skipif(not shutil.which("g++"), reason="no g++")
+def test_cpp_host_streams_lists_through_the_device_group(tmp_path):
+    """examples/stream_batches.cc: the streaming form of the device group (pgp_multi_upload_slot / _enqueue_slot / _collect) from a
+    C++ host -- four logical members on this one GPU, then one member: streamed == synchronous == one context (the program checks)."""
+    exe = str(tmp_path / "stream_batches")
+    lib = os.path.join(ROOT, "physimglobalpose_amd")
+    r = subprocess.run(["g++", "-O2", "-std=c++11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "stream_batches.cc"), "-L", lib, "-lpgp", f"-Wl,-rpath,{lib}",
+                        "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for env in (dict(os.environ, PGP_MULTI_EMULATE="4"), {k: v for k, v in os.environ.items() if k != "PGP_MULTI_EMULATE"}):
+        out = subprocess.run([exe, "1500", "5"], capture_output=True, text=True, timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        assert out.stdout.strip().endswith("OK") and "streamed == synchronous == one context: yes" in out.stdout
+        print(out.stdout)
