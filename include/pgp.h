@@ -777,7 +777,7 @@ int pgp_multi_get_info(pgp_multi* m, pgp_multi_info* info);
  * pgp_multi_enqueue_slot queues one scoring step over a slot and returns: every member scores its slice into one of two
  * {scores | counts} vectors on its stream, the all-reduce runs on a SECOND stream of the member -- under the scoring of
  * the next step --, and member 0's arg-max (near-tie settlement, exact records, Verify's early termination as set on
- * member 0's context) is queued behind that next step's scoring.  pgp_multi_collect completes everything queued and
+ * member 0's context) follows it on that second stream, with a settlement workspace of its own.  pgp_multi_collect completes everything queued and
  * returns the LAST step's arrays, bit for bit those of pgp_multi_score_lcp on the same list.  pgp_multi_upload_slot
  * between an enqueue and its collect returns PGP_ESTATE. */
 int pgp_multi_upload_slot(pgp_multi* m, int slot, const float* T, int n_h);

@@ -2184,7 +2184,7 @@ int launch_verify_early_out(pgp_ctx* ctx, const float* d_T, int n_h, float* d_sc
 }
 
 int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
-                       int* d_best, hipStream_t stream) {
+                       int* d_best, hipStream_t stream, float* seq_ws) {
   if (n_h <= 0) {
     hipLaunchKernelGGL(publish_none, dim3(1), dim3(1), 0, stream, d_best);
     PGP_HIP(hipGetLastError());
@@ -2195,7 +2195,7 @@ int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float 
   if (rc == PGP_OK) rc = fill_args(ctx, d_T, n_h, mode, gate_deg, &a);
   if (rc != PGP_OK) return rc;
   hipLaunchKernelGGL(settle_best_kernel, dim3(1), dim3(256), 0, stream, a, n_h, mode, ctx->refine_best ? 1 : 0,
-                     d_scores, d_best, ctx->d_seq.as<float>(), a.nQ);
+                     d_scores, d_best, seq_ws ? seq_ws : ctx->d_seq.as<float>(), a.nQ);
   PGP_HIP(hipGetLastError());
   return PGP_OK;
 }

@@ -171,6 +171,7 @@ struct pgp_multi {
   std::vector<std::vector<DevBuf>> slot_T;   // [slot][member]: the transforms of a resident batch (member 0: all of it)
   std::vector<int> slot_n;                   // [slot] hypotheses, -1 = empty
   DevBuf d_best2;                            // member 0: {index, score bits} of ring[0] and ring[1]
+  DevBuf d_tail_seq;                         // member 0: the settlement's workspace of the tails (they run on the exchange stream)
   hipEvent_t ev_sum[2] = {nullptr, nullptr}; // emulate: the summed vector of ring[b] has been handed to every member
   long long step = 0;                        // steps enqueued since the last collect
   int pend_slot[2] = {0, 0}, pend_mode[2] = {0, 0}, pend_n[2] = {0, 0};
@@ -838,6 +839,7 @@ int pgp_multi_destroy(pgp_multi* m) {
       if (k == 0) {
         m->d_sum.release();
         m->d_best2.release();
+        m->d_tail_seq.release();
         for (hipEvent_t ev : m->ev_sum)
           if (ev) (void)hipEventDestroy(ev);
       }
@@ -1049,19 +1051,22 @@ int streaming_ready(pgp_multi* m, int k) {
   return PGP_OK;
 }
 
-// member 0, on its scoring stream: the complete vector of ring[b] is there once the exchange has finished -> arg-max with
-// the near-tie settlement (and the opt-in passes over the complete vector), exactly score_flat's tail
+// member 0, on its EXCHANGE stream behind the all-reduce of ring[b]: the arg-max over the complete vector with the near-tie
+// settlement (and the opt-in passes over the complete vector), exactly score_flat's tail -- beside the next step's scoring on the
+// member's other stream (a settle over 32 768 scores is ~15 us: an eighth of a step that the scoring stream does not wait for).
+// The settlement's re-score workspace is the tail's own (finalize_scores on the scoring stream uses the context's); the opt-in
+// passes' workspaces are not touched by the slices' scoring (score_slice switches those passes off).
 int queue_tail(pgp_multi* m, int b) {
   Streaming& z = m->s2[0];
-  hipStream_t st = m->stream[0];
+  hipStream_t st = z.x;
   const int N = m->pend_n[b], mode = m->pend_mode[b];
   const float gate = m->pend_gate[b];
   if (N <= 0) return PGP_OK;   // (the empty batch: its {-1, 0} was published by the scoring call)
-  PGP_HIP(hipStreamWaitEvent(st, z.reduced[b], 0));
   pgp_ctx* c = m->octx[0][0];
   float* d_s = z.ring[b].as<float>();
   const float* d_T = m->slot_T[(size_t)m->pend_slot[b]][0].as<float>();
-  int r = pgp_settle_best_device(c, d_T, N, mode, gate, d_s, m->d_best2.as<int>() + 2 * b, st);
+  int r = launch_settle_best(c, d_T, N, mode, gate, d_s, m->d_best2.as<int>() + 2 * b, st, m->d_tail_seq.as<float>());
+  c->device_work_pending = true;   // (what pgp_settle_best_device's guard notes: work queued outside the context's stream)
   if (r != PGP_OK) return r;
   if (c->exact_records && (r = pgp_settle_records_device(c, d_T, N, mode, gate, d_s, st)) != PGP_OK) return r;
   if (c->verify_early_out && mode == PGP_MODE_PLAIN &&
@@ -1099,6 +1104,7 @@ int pgp_multi_upload_slot(pgp_multi* m, int slot, const float* T, int n_h) {
     for (int b = 0; b < 2; ++b)
       if ((r = z.ring[b].ensure((size_t)N * 8 + 64)) != PGP_OK) return r;
     if (k == 0 && m->emulate && (r = m->d_sum.ensure((size_t)N * 8 + 64)) != PGP_OK) return r;
+    if (k == 0 && (r = m->d_tail_seq.ensure(std::max<size_t>(m->octx[0][0]->d_seq.cap, 64))) != PGP_OK) return r;
     // member 0 settles over the complete vector: its context takes all N, the others their slice
     if ((r = pgp_reserve(m->octx[0][(size_t)k], k == 0 ? N : hi - lo)) != PGP_OK) return r;
     const size_t a = k == 0 ? 0 : (size_t)lo * 64, b = k == 0 ? nT : (size_t)hi * 64;
@@ -1120,7 +1126,6 @@ int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg) {
   const int N = m->slot_n[(size_t)slot];
   const int b = (int)(m->step & 1);
   const bool exchange = m->exchange() && N > 0;
-  const bool tail_before = m->step > 0 && m->exchange();   // the previous step's tail: queued BEHIND this step's scoring
   std::vector<int> fail((size_t)m->n, 0);
   m->pend_slot[b] = slot;
   m->pend_mode[b] = mode;
@@ -1141,7 +1146,7 @@ int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg) {
       if (!m->exchange())   // one member, no collective: the scoring call publishes the best itself (and runs the opt-in passes)
         return pgp_score_lcp_device(c, m->slot_T[(size_t)slot][(size_t)k].as<float>(), N, mode, gate_deg, d_s, d_c,
                                     m->d_best2.as<int>() + 2 * b, S);
-      // ring[b] was last used two steps ago: its exchange (and, on member 0, its tail -- on S already) must be through
+      // ring[b] was last used two steps ago: its exchange (and, on member 0, its tail behind it) must be through
       if (step >= 2) PGP_HIP(hipStreamWaitEvent(S, z.reduced[b], 0));
       if (N > 0 && m->world > 1) PGP_HIP(hipMemsetAsync(d_s, 0, (size_t)N * 8, S));
       const bool records = c->exact_records, early = c->verify_early_out;
@@ -1155,10 +1160,7 @@ int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg) {
       c->verify_early_out = early;
       return r;
     }();
-    if (!exchange) {
-      if (r1 == PGP_OK && k == 0 && tail_before) r1 = queue_tail(m, b ^ 1);
-      return r1;
-    }
+    if (!exchange) return r1;   // (one member without a collective, or the empty batch: nothing to exchange, nothing to settle)
     // ---- the exchange of ring[b] on the second stream ----
     if (r1 == PGP_OK && hipEventRecord(z.scored[b], S) != hipSuccess) r1 = PGP_EHIP;
     if (r1 == PGP_OK && hipStreamWaitEvent(X, z.scored[b], 0) != hipSuccess) r1 = PGP_EHIP;
@@ -1205,9 +1207,16 @@ int pgp_multi_enqueue_slot(pgp_multi* m, int slot, int mode, float gate_deg) {
     }
     if (r1 != PGP_OK) return r1;
     if (r2 != PGP_OK) return r2;
-    PGP_HIP(hipEventRecord(z.reduced[b], X));
-    // member 0: the previous step's tail, behind this step's scoring -- its exchange ran under that scoring
-    if (k == 0 && tail_before) return queue_tail(m, b ^ 1);
+    // member 0: the step's tail behind its exchange, on the exchange stream -- beside the next step's scoring
+    if (k == 0) {
+      if (m->d_tail_seq.cap < c->d_seq.cap) {   // (the model changed since the batches went up)
+        const int r = m->d_tail_seq.ensure(c->d_seq.cap);
+        if (r != PGP_OK) return r;
+      }
+      const int r = queue_tail(m, b);
+      if (r != PGP_OK) return r;
+    }
+    PGP_HIP(hipEventRecord(z.reduced[b], X));   // ring[b] is free again (two steps on) once this has passed
     return PGP_OK;
   });
   if (rc != PGP_OK) return rc;
@@ -1230,15 +1239,14 @@ int pgp_multi_collect(pgp_multi* m, float* scores, int* counts, int* best_index,
   const int rc = run_all(m, [&, m](int k) -> int {
     Streaming& z = m->s2[(size_t)k];
     hipStream_t S = m->stream[k];
-    if (k == 0) {
-      if (m->exchange()) {
-        const int r = queue_tail(m, b);
-        if (r != PGP_OK) return r;
-      }
-      if (N > 0) PGP_HIP(hipMemcpyAsync(pin_out, z.ring[b].p, (size_t)N * 8, hipMemcpyDeviceToHost, S));
-      PGP_HIP(hipMemcpyAsync(pin_out + (size_t)N * 8, m->d_best2.as<int>() + 2 * b, 8, hipMemcpyDeviceToHost, S));
-    }
     PGP_HIP(hipStreamSynchronize(S));
+    if (k == 0) {
+      // the last step's arrays: behind its tail on the exchange stream (no exchange: behind the scoring call, just waited for)
+      hipStream_t cs = m->exchange() && z.x ? z.x : S;
+      if (N > 0) PGP_HIP(hipMemcpyAsync(pin_out, z.ring[b].p, (size_t)N * 8, hipMemcpyDeviceToHost, cs));
+      PGP_HIP(hipMemcpyAsync(pin_out + (size_t)N * 8, m->d_best2.as<int>() + 2 * b, 8, hipMemcpyDeviceToHost, cs));
+      if (cs == S) PGP_HIP(hipStreamSynchronize(S));
+    }
     if (z.x) PGP_HIP(hipStreamSynchronize(z.x));
     return PGP_OK;
   });

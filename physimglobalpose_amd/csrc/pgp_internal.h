@@ -418,8 +418,10 @@ struct ScoreHostOut {
 };
 int launch_score(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg,
                  float* d_scores, int* d_counts, int* d_best, hipStream_t stream, ScoreHostOut* host = nullptr);
+// seq_ws (nullable): the exact re-score's workspace, the size of ctx->d_seq -- a caller that settles on ANOTHER stream than the
+// one the context's scoring launches run on (the device group's streaming form) brings its own: finalize_scores uses ctx->d_seq
 int launch_settle_best(pgp_ctx* ctx, const float* d_T, int n_h, int mode, float gate_deg, float* d_scores,
-                       int* d_best, hipStream_t stream);
+                       int* d_best, hipStream_t stream, float* seq_ws = nullptr);
 // the launches that follow on `stream` read the scene's index: orders them behind a build still running on
 // ctx->build_stream (a no-op otherwise); finish_index() waits for it on the host and takes over its counts
 int await_index(pgp_ctx* ctx, hipStream_t stream);
