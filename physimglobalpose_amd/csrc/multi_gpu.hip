@@ -172,6 +172,11 @@ struct pgp_multi {
   std::vector<int> slot_n;                   // [slot] hypotheses, -1 = empty
   DevBuf d_best2;                            // member 0: {index, score bits} of ring[0] and ring[1]
   DevBuf d_tail_seq;                         // member 0: the settlement's workspace of the tails (they run on the exchange stream)
+  // member 0 scores its slice like everybody else but needs ALL transforms for the arg-max's near-tie settlement: the ones
+  // outside its slice go up on a side stream, beside its scoring; the tail waits for ev_rest
+  hipStream_t up_stream = nullptr;
+  hipEvent_t ev_rest = nullptr;
+  bool rest_pending = false;
   hipEvent_t ev_sum[2] = {nullptr, nullptr}; // emulate: the summed vector of ring[b] has been handed to every member
   long long step = 0;                        // steps enqueued since the last collect
   int pend_slot[2] = {0, 0}, pend_mode[2] = {0, 0}, pend_n[2] = {0, 0};
@@ -362,6 +367,7 @@ int score_flat(pgp_multi* m, int mode, float gate_deg, float* scores, int* count
     float* d_s = m->d_all[0].as<float>();
     int* d_b = m->d_best[0].as<int>();
     hipStream_t st = m->stream[0];
+    if (m->rest_pending) PGP_HIP(hipStreamWaitEvent(st, m->ev_rest, 0));   // the transforms outside member 0's slice (upload_flat)
     for (int o = 0; o < n_obj; ++o) {
       pgp_ctx* c = m->octx[o][0];
       const int a = m->off[o], cnt = m->off[o + 1] - a;
@@ -513,6 +519,10 @@ int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) 
   }
   const int N = off[n_obj];
   const size_t nT = (size_t)N * 64;
+  if (m->rest_pending) {   // (the previous list's side-stream copies read the pinned image that is rewritten below)
+    PGP_HIP(hipEventSynchronize(m->ev_rest));
+    m->rest_pending = false;
+  }
   int rc = ensure_pin(m, nT + (size_t)N * 8 + (size_t)n_obj * 8 + 256);
   if (rc != PGP_OK) return rc;
   for (int o = 0; o < n_obj; ++o)
@@ -532,10 +542,23 @@ int upload_flat(pgp_multi* m, const float* const* T, const int* n_h, int n_obj) 
     }
     // member 0 holds ALL transforms (it settles near-ties across slices); the others copy their slice only, to the
     // place it has in the flat list (64 B per hypothesis: 4 MB at 65 536 -- every device over its own PCIe link)
-    const size_t a = k == 0 ? 0 : (size_t)lo * 64, b = k == 0 ? nT : (size_t)hi * 64;
+    const size_t a = (size_t)lo * 64, b = (size_t)hi * 64;
+    unsigned char* dst = m->d_T[k].as<unsigned char>();
+    unsigned char* src = static_cast<unsigned char*>(m->h_pin);
     // (out of the portable pinned image by a kernel on the member's stream: no copy-engine hand-over in front of the scoring)
-    if (b > a && (r = stage_to_device(m->stream[k], m->d_T[k].as<unsigned char>() + a, static_cast<unsigned char*>(m->h_pin) + a, b - a)) != PGP_OK)
-      return r;
+    if (b > a && (r = stage_to_device(m->stream[k], dst + a, src + a, b - a)) != PGP_OK) return r;
+    if (k == 0 && (a > 0 || b < nT)) {
+      // the rest of the list, for the settlement only: on the side stream, under this member's scoring (at eight members
+      // 7/8 of 2 MB: ~35 us that were in front of the scoring launch)
+      if (!m->up_stream) {
+        PGP_HIP(hipStreamCreateWithFlags(&m->up_stream, hipStreamNonBlocking));
+        PGP_HIP(hipEventCreateWithFlags(&m->ev_rest, hipEventDisableTiming));
+      }
+      if (a > 0 && (r = stage_to_device(m->up_stream, dst, src, a)) != PGP_OK) return r;
+      if (b < nT && (r = stage_to_device(m->up_stream, dst + b, src + b, nT - b)) != PGP_OK) return r;
+      PGP_HIP(hipEventRecord(m->ev_rest, m->up_stream));
+      m->rest_pending = true;
+    }
     return PGP_OK;
   });
   if (rc != PGP_OK) m->off.assign(2, 0);   // nothing usable is resident: a later *_uploaded call scores the empty batch
@@ -840,6 +863,11 @@ int pgp_multi_destroy(pgp_multi* m) {
         m->d_sum.release();
         m->d_best2.release();
         m->d_tail_seq.release();
+        if (m->up_stream) {
+          (void)hipStreamSynchronize(m->up_stream);
+          (void)hipStreamDestroy(m->up_stream);
+        }
+        if (m->ev_rest) (void)hipEventDestroy(m->ev_rest);
         for (hipEvent_t ev : m->ev_sum)
           if (ev) (void)hipEventDestroy(ev);
       }
