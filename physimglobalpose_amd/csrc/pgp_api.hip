@@ -210,7 +210,7 @@ int pgp_destroy(pgp_ctx* ctx) {
                     &ctx->d_bitmap, &ctx->d_blocktab, &ctx->d_kd_nodes, &ctx->d_kd_pts, &ctx->d_occ_start, &ctx->d_cand, &ctx->d_Q, &ctx->d_Qn, &ctx->d_Qpos, &ctx->d_eo_ws, &ctx->d_T, &ctx->d_partial,
                     &ctx->d_scores, &ctx->d_counts, &ctx->d_best, &ctx->d_rec_ws, &ctx->d_hits, &ctx->d_seq, &ctx->d_Qs, &ctx->d_ids,
                     &ctx->d_rig, &ctx->d_icp_src, &ctx->d_icp_tgt, &ctx->d_icp_tgt_n, &ctx->d_icp_grid, &ctx->d_icp_T, &ctx->d_icp_out, &ctx->d_icp_ws, &ctx->d_icp_x, &ctx->d_Qs_unit, &ctx->d_cs_cnt, &ctx->d_cs_entries, &ctx->d_cs_keys,
-                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp, &ctx->d_top_ws, &ctx->d_acc};
+                    &ctx->d_cs_pairs, &ctx->d_cs_out, &ctx->d_ppf_keys, &ctx->d_ppf_val, &ctx->d_ppf_off, &ctx->d_ppf_pairs, &ctx->d_prob_cdf, &ctx->d_sel_ws, &ctx->d_csb, &ctx->d_csb_picks, &ctx->d_pre_ws, &ctx->d_vg_ws, &ctx->d_mls_ws, &ctx->d_pre_io, &ctx->d_depth, &ctx->d_render_ws, &ctx->d_render_io, &ctx->d_cl_keys, &ctx->d_cl_ws, &ctx->d_cl_io, &ctx->d_bp, &ctx->d_top_ws, &ctx->d_acc, &ctx->d_pub_ticket};
   for (DevBuf* b : bufs) b->release();
   ctx->d_out.release();
   if (ctx->h_pin) {
@@ -566,10 +566,13 @@ struct PubArgs {
   int n;
   unsigned int* flag;
   unsigned int value;
+  unsigned int* ticket;   // device word, zero between launches: the workgroup that draws the last number writes the flag
 };
-// one workgroup: the items word by word into host memory (system-scope stores: written through, acknowledged), then the word
-// the host polls
+// The items word by word into host memory (system-scope stores: written through, acknowledged), then the word the host polls.
+// One workgroup per ~32 KB (up to 32): every workgroup's stores are complete before it draws its ticket, the last one writes
+// the word and puts the ticket back.
 __global__ __launch_bounds__(1024) void publish_items(PubArgs p) {
+  const uint32_t t0 = blockIdx.x * 1024u + threadIdx.x, step = gridDim.x * 1024u;
   for (int k = 0; k < p.n; ++k) {
     const uint32_t* __restrict__ s = p.src[k];
     uint32_t* d = p.dst[k];
@@ -577,15 +580,22 @@ __global__ __launch_bounds__(1024) void publish_items(PubArgs p) {
     if ((((uintptr_t)s | (uintptr_t)d) & 7u) == 0) {   // two words per store
       const unsigned long long* __restrict__ s2 = reinterpret_cast<const unsigned long long*>(s);
       unsigned long long* d2 = reinterpret_cast<unsigned long long*>(d);
-      for (uint32_t i = threadIdx.x; i < nw / 2; i += 1024u) __hip_atomic_store(&d2[i], s2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-      if ((nw & 1u) && threadIdx.x == 0) __hip_atomic_store(&d[nw - 1], s[nw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (uint32_t i = t0; i < nw / 2; i += step) __hip_atomic_store(&d2[i], s2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((nw & 1u) && t0 == 0) __hip_atomic_store(&d[nw - 1], s[nw - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     } else {
-      for (uint32_t i = threadIdx.x; i < nw; i += 1024u) __hip_atomic_store(&d[i], s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      for (uint32_t i = t0; i < nw; i += step) __hip_atomic_store(&d[i], s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_store(p.flag, p.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (threadIdx.x == 0) {
+    bool last = gridDim.x == 1;
+    if (!last) {
+      last = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
+      if (last) __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (last) __hip_atomic_store(p.flag, p.value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 }  // namespace
 
@@ -616,7 +626,18 @@ int publish_and_wait(pgp_ctx* ctx, hipStream_t st, const PubItem* items, int n) 
   }
   a.flag = ctx->h_flag;
   a.value = ++ctx->flag_seq ? ctx->flag_seq : ++ctx->flag_seq;
-  hipLaunchKernelGGL(publish_items, dim3(1), dim3(1024), 0, st, a);
+  size_t total = 0;
+  for (int k = 0; k < n; ++k) total += items[k].bytes;
+  const unsigned groups = (unsigned)std::min<size_t>(32, std::max<size_t>(1, (total + (32u << 10) - 1) / (32u << 10)));
+  if (groups > 1) {
+    if (!ctx->d_pub_ticket.p) {
+      int rc = ctx->d_pub_ticket.ensure(64);
+      if (rc != PGP_OK) return rc;
+      PGP_HIP(hipMemsetAsync(ctx->d_pub_ticket.p, 0, 64, st));
+    }
+    a.ticket = ctx->d_pub_ticket.as<unsigned int>();
+  }
+  hipLaunchKernelGGL(publish_items, dim3(groups), dim3(1024), 0, st, a);
   PGP_HIP(hipGetLastError());
   const auto t_end = std::chrono::steady_clock::now() + std::chrono::milliseconds(250);
   for (unsigned spins = 0;; ++spins) {

@@ -76,6 +76,7 @@ struct pgp_ctx {
   // completion words in host memory (lcp_score.hip HostPub, pgp_api.hip publish_and_wait): the value the next wait looks for
   unsigned int flag_seq = 0;
   unsigned int* h_flag = nullptr;   // pinned completion word of pgp::publish_and_wait
+  pgp::DevBuf d_pub_ticket;         // its arrival counter when several workgroups publish (zero between launches)
 
   // scene
   int nP = 0;
@@ -274,7 +275,7 @@ struct PubItem {
   size_t bytes;     // a multiple of 4, both ends 4-byte aligned
 };
 constexpr int kPubMaxItems = 8;
-constexpr size_t kPubMaxBytes = 96u << 10;
+constexpr size_t kPubMaxBytes = 1u << 20;   // (one workgroup per 32 KB, up to 32: a megabyte leaves at PCIe speed)
 bool publish_usable(const PubItem* items, int n);
 int publish_and_wait(pgp_ctx* ctx, hipStream_t st, const PubItem* items, int n);
 
