@@ -2151,8 +2151,17 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
   }
   rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token);
   if (rc != PGP_OK) return rc;
-  if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
-  PGP_HIP(hipStreamSynchronize(st));
+  // the results' way home: one publishing kernel + the completion word (pgp::publish_and_wait) where they are small and aligned,
+  // else a copy and the stream
+  auto home = [&]() -> int {
+    const PubItem item{ctx->d_icp_src.as<unsigned char>() + g.off_T, static_cast<unsigned char*>(ctx->h_pin) + g.off_T, g.total - g.off_T};
+    if (publish_usable(&item, 1)) return publish_and_wait(ctx, st, &item, 1);
+    const int r = icp_host_collect_enqueue(ctx, g, st);
+    if (r != PGP_OK) return r;
+    PGP_HIP(hipStreamSynchronize(st));
+    return PGP_OK;
+  };
+  if ((rc = home()) != PGP_OK) return rc;
   {
     // A pose the scene-sized one-launch form gave up on (iteration count -1: the device was held by somebody else for
     // seconds and the pose's units did not arrive, icp.hip icp_scene_persist) -- the caller's transforms are still
@@ -2168,8 +2177,7 @@ int pgp_icp_refine_ex(pgp_ctx* ctx, const float* src_xyz, int n_src, const float
       if ((rc = icp_host_stage(ctx, src_xyz, n_src, tgt_xyz, n_tgt, T, n, st, &g)) != PGP_OK) return rc;
       rc = launch_icp(ctx, g.d_src, n_src, g.d_tgt, d_n, n_tgt, g.d_T, n, opt, g.d_energy, g.d_iters, st, g.token);
       if (rc != PGP_OK) return rc;
-      if ((rc = icp_host_collect_enqueue(ctx, g, st)) != PGP_OK) return rc;
-      PGP_HIP(hipStreamSynchronize(st));
+      if ((rc = home()) != PGP_OK) return rc;
     }
   }
   icp_host_collect(ctx, g, n, T, energy, iters);
