@@ -34,3 +34,4 @@ for k, d in agg.items():
 json.dump({"how": "tools/collect_rows_pmc.sh: rocprofv3 --pmc <group> --kernel-trace over tools/profile_rows.py, per-launch averages; FETCH_SIZE / WRITE_SIZE in KB", "kernels": res}, open(out + "/pmc_rows.json", "w"), indent=1)
 print(sorted(res))
 PY
+rm -rf $OUT/pmc_[0-9] $OUT/trace
